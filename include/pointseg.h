@@ -1,0 +1,178 @@
+/* include/pointseg.h -- C ABI of libpointseg_hip.so: the MI355X-native replacement for the native ops and
+ * the forward graph on Point-Unet's PointSegment hot path.  Plain pointers and sizes only; no torch / numpy /
+ * C++ types cross this boundary.  All citations are relative to the reference repository root.
+ *
+ * What each entry point replaces
+ * ------------------------------
+ *   ps_knn_batch / ps_knn_batch_i64    cpp_knn_batch_omp / cpp_knn_batch / cpp_knn / cpp_knn_omp
+ *                                      PointSegment/utils/nearest_neighbors/knn_.h:2-17, knn_.cxx:22-135,
+ *                                      as bound by knn.pyx:33-109 and DataProcessing.knn_search
+ *                                      (PointSegment/helper_tool.py:84-94)
+ *   ps_pyramid_build                   tf_map's per-layer loop, PointSegment/runBraTS.py:147-156
+ *                                      (== runPancreas.py:131-140)
+ *   ps_grid_subsample                  grid_subsampling(), .../cpp_subsampling/grid_subsampling/
+ *                                      grid_subsampling.h:84-91, as bound by wrapper.cpp:58-286 and
+ *                                      DataProcessing.grid_sub_sampling (helper_tool.py:123-143)
+ *   ps_randla_*                        Network.inference, PointSegment/RandLANet.py:110-152, and the blocks it
+ *                                      calls (:314-401) with helper_tf_util.conv2d / conv2d_transpose
+ *                                      (PointSegment/helper_tf_util.py:115-250) in inference mode
+ *   ps_op_*                            the individual Network.* static methods (RandLANet.py:337-401) for
+ *                                      callers that keep the reference's op-by-op graph
+ *
+ * Conventions
+ * -----------
+ *   - every function returns 0 on success, a PS_E* code otherwise; ps_last_error() returns a thread-local
+ *     message (the reference's KNN entry points are `void` and abort on error, knn_.h:2-27; the grid op raises
+ *     RuntimeError with a text, wrapper.cpp:76-229 -- the Python facade re-creates those).
+ *   - all buffers are caller-owned.  `device_ptrs != 0`: pointers are device memory valid on the context's
+ *     device and the call is asynchronous on the context's stream.  `device_ptrs == 0`: pointers are host
+ *     memory; the call copies in/out and returns when the result is in the host buffer (NumPy drop-in mode).
+ *   - the context owns a workspace that grows to the high-water mark and is then reused (no hipMalloc on the
+ *     hot path after warm-up), one HIP stream (its own or one adopted with ps_set_stream), no global state.
+ *   - arrays are dense row-major; indices are int32 on the wire (the reference casts its int64 to int32 at
+ *     helper_tool.py:94).  Clouds of a batch are independent; point i of cloud b is row b*N + i.
+ */
+#ifndef POINTSEG_H
+#define POINTSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PS_OK 0
+#define PS_EINVAL 1  /* bad argument (shape, dtype flag, null pointer)            */
+#define PS_EHIP 2    /* a HIP runtime call failed                                 */
+#define PS_ENOMEM 3  /* workspace allocation failed                               */
+#define PS_ESTATE 4  /* call made in the wrong state (e.g. forward before weights) */
+
+#define PS_MAX_LAYERS 8
+
+typedef struct ps_context ps_context;
+typedef struct ps_randla ps_randla;
+
+/* ---- context ------------------------------------------------------------------------------------------ */
+int ps_create(int device, ps_context** out);
+int ps_destroy(ps_context* ctx);
+/* Adopt the caller's hipStream_t (e.g. torch's current stream); NULL restores the context's own stream. */
+int ps_set_stream(ps_context* ctx, void* hip_stream);
+int ps_synchronize(ps_context* ctx);
+const char* ps_last_error(void);
+/* "pointseg-hip <version> gfx950" */
+const char* ps_version(void);
+
+/* Per-call kernel timing on the context's stream, measured with hipEvents recorded on THAT stream.
+ * ps_timing_begin arms it; every subsequent API call accumulates per-stage device time; ps_timing_end
+ * synchronises and writes up to `cap` (name, ms, launches) rows.  Used by bench.py for the roofline line. */
+typedef struct {
+    char name[48];
+    double ms;
+    int64_t launches;
+} ps_timing_row;
+int ps_timing_begin(ps_context* ctx);
+int ps_timing_end(ps_context* ctx, ps_timing_row* rows, int cap, int* n_rows);
+
+/* ---- KNN ---------------------------------------------------------------------------------------------- */
+/* Exact K nearest neighbours, squared L2 in fp32, ascending, equal-distance ties broken exactly as the
+ * reference's nanoflann 1.2.3 kd-tree (leaf 10) visits them.  support f32[B,n_support,3],
+ * queries f32[B,n_queries,3], out int32[B,n_queries,K].  dim must be 3.  If n_support < K the trailing
+ * K-n_support slots of every row are written as 0 (the reference returns np.zeros there, knn.pyx:93). */
+int ps_knn_batch(ps_context* ctx, const float* support, const float* queries, int64_t B, int64_t n_support,
+                 int64_t n_queries, int64_t dim, int64_t K, int32_t* out_idx, int device_ptrs);
+/* Same with the reference's wire type (`long* batch_indices`, knn_.h:15-17). */
+int ps_knn_batch_i64(ps_context* ctx, const float* support, const float* queries, int64_t B,
+                     int64_t n_support, int64_t n_queries, int64_t dim, int64_t K, int64_t* out_idx,
+                     int device_ptrs);
+
+/* ---- index pyramid ------------------------------------------------------------------------------------ */
+/* For layer i (N_0 = n0, N_{i+1} = N_i / ratio[i]):
+ *   xyz[i]        f32[B,N_i,3]    the first N_i points of every cloud ("random sampling" of a pre-shuffled
+ *                                 cloud is a prefix slice, runBraTS.py:149)
+ *   neigh_idx[i]  i32[B,N_i,K]    knn(xyz[i], xyz[i], K)
+ *   sub_idx[i]    i32[B,N_{i+1},K] = neigh_idx[i][:, :N_{i+1}, :]
+ *   interp_idx[i] i32[B,N_i,1]    knn(xyz[i+1], xyz[i], 1)
+ * All buffers device memory, caller-allocated with exactly these shapes. */
+typedef struct {
+    int32_t num_layers;
+    int32_t K;
+    int64_t B;
+    int64_t n[PS_MAX_LAYERS + 1];
+    float* xyz[PS_MAX_LAYERS];
+    int32_t* neigh_idx[PS_MAX_LAYERS];
+    int32_t* sub_idx[PS_MAX_LAYERS];
+    int32_t* interp_idx[PS_MAX_LAYERS];
+} ps_pyramid;
+int ps_pyramid_build(ps_context* ctx, const float* xyz0, int64_t B, int64_t n0, int32_t num_layers,
+                     const int32_t* ratios, int32_t K, ps_pyramid* pyr);
+
+/* ---- grid subsampling --------------------------------------------------------------------------------- */
+/* Voxel-grid barycentre subsampling (points f32[n,3]; optional features f32[n,fdim]; optional classes
+ * i32[n,ldim]).  Two-call protocol because M is data dependent: call with out_points == NULL to get *M, then
+ * with buffers of M rows.  Rows are emitted in ascending cell-key order (the reference emits unordered_map
+ * iteration order, grid_subsampling.cpp:85).  Majority-label ties resolve to the smallest label (the
+ * reference's tie order is implementation defined, grid_subsampling.cpp:100-101). Host pointers only. */
+int ps_grid_subsample(ps_context* ctx, const float* points, int64_t n, const float* features, int64_t fdim,
+                      const int32_t* classes, int64_t ldim, float sampleDl, int64_t* M, float* out_points,
+                      float* out_features, int32_t* out_classes);
+
+/* ---- RandLA-Net forward ------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t num_layers;            /* ConfigBraTS.num_layers (helper_tool.py:23)           */
+    int32_t k_n;                   /* ConfigBraTS.k_n (helper_tool.py:22); 16 or 32        */
+    int32_t num_classes;           /* helper_tool.py:26                                    */
+    int32_t in_channels;           /* xyz + modalities: 7 BraTS (runBraTS.py:142), 4 Pancreas */
+    int32_t d_out[PS_MAX_LAYERS];  /* helper_tool.py:36                                    */
+} ps_randla_config;
+
+int ps_randla_create(ps_context* ctx, const ps_randla_config* cfg, ps_randla** out);
+int ps_randla_destroy(ps_randla* net);
+/* Number of floats ps_randla_set_weights expects, and the layout (see DESIGN.md "weight blob"):
+ * inference-mode BatchNorm folded into each conv's W and b on the host (point-unet_amd/weights.py). */
+int64_t ps_randla_weight_count(const ps_randla* net);
+int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t count); /* host pointer */
+/* features f32[B,N0,in_channels] -> logits f32[B,N0,num_classes]; device pointers. */
+int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const float* features, float* logits);
+/* Debug/parity taps: copies an internal activation to a host buffer after the last forward.
+ * which: 0 fc0 [N0,8]; 10+i enc_i [N_i,2d_i]; 20+i pool_i [N_{i+1},2d_i]; 30 decoder_0; 40+j dec_j.
+ * Returns PS_EINVAL if count does not match the tensor's size. */
+int ps_randla_tap(ps_randla* net, int which, float* host_out, int64_t count);
+
+/* ---- op-by-op surface (Network.* static methods, RandLANet.py:337-401); device pointers --------------- */
+/* gather_neighbour: pc f32[B,N,d], idx i32[B,M,K] -> out f32[B,M,K,d] */
+int ps_op_gather_neighbour(ps_context* ctx, const float* pc, const int32_t* idx, int64_t B, int64_t N,
+                           int64_t M, int64_t K, int64_t d, float* out);
+/* relative_pos_encoding: xyz f32[B,N,3], idx i32[B,N,K] -> out f32[B,N,K,10] = [dis, rel, centre, nbr] */
+int ps_op_relative_pos_encoding(ps_context* ctx, const float* xyz, const int32_t* idx, int64_t B, int64_t N,
+                                int64_t K, float* out);
+/* random_sample: feature f32[B,N,d], pool_idx i32[B,M,K] -> out f32[B,M,d] = max over K */
+int ps_op_random_sample(ps_context* ctx, const float* feature, const int32_t* pool_idx, int64_t B, int64_t N,
+                        int64_t M, int64_t K, int64_t d, float* out);
+/* nearest_interpolation: feature f32[B,N,d], interp_idx i32[B,M,1] -> out f32[B,M,d] */
+int ps_op_nearest_interpolation(ps_context* ctx, const float* feature, const int32_t* interp_idx, int64_t B,
+                                int64_t N, int64_t M, int64_t d, float* out);
+/* conv2d 1x1 (helper_tf_util.conv2d with BN folded): x f32[R,cin], w f32[cin,cout], b f32[cout] (may be
+ * NULL) -> y f32[R,cout]; leaky != 0 applies LeakyReLU(0.2). */
+int ps_op_conv1x1(ps_context* ctx, const float* x, const float* w, const float* b, int64_t R, int64_t cin,
+                  int64_t cout, int leaky, float* y);
+/* att_pooling up to (not including) its trailing conv2d: fset f32[R,K,d], wfc f32[d,d] ->
+ * agg f32[R,d] = sum_K fset * softmax_K(fset . wfc) */
+int ps_op_att_pool(ps_context* ctx, const float* fset, const float* wfc, int64_t R, int64_t K, int64_t d,
+                   float* agg);
+
+/* ---- host-only debug doors (CPU test-suite; never bound by the Python facade, never on the product path) ---- */
+/* The product's own kd-tree construction + the per-query search routine the HIP kernel instantiates, run on the
+ * host.  K in {1,5,7,16,32}. */
+int ps_debug_knn_host(const float* support, const float* queries, int64_t B, int64_t n_support,
+                      int64_t n_queries, int64_t K, int32_t* out_idx);
+/* vind i32[n], nodes i32[2n,4], pts f32[n,4], root_depth i32[2], bbox f32[6] (layout: csrc/kdtree.h). */
+int ps_debug_kdtree_host(const float* support, int64_t n, int32_t* vind, int32_t* nodes, float* pts,
+                         int32_t* root_depth, float* bbox);
+/* MFMA B-fragment packing of a row-major W[cin,cout] (csrc/rowgemm.h). */
+int ps_debug_pack_weights(const float* W, int cin, int cout, int ntb, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POINTSEG_H */

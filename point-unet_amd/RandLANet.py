@@ -1,0 +1,133 @@
+"""Host-side mirror of PointSegment/RandLANet.py's Network for the forward path, executing on MI355X through
+libpointseg_hip.so.
+
+`Network.inference` is the fused production path (one C-ABI call, csrc/randla.hip).  The individual block
+methods keep the reference's names, argument meaning and tensor shapes (with the dummy axis of the reference's
+[B,N,1,C] layout preserved) so that call sites written against RandLANet.py:314-401 keep working; they run the
+op-by-op kernels of csrc/ops.hip.  All tensors are float32 / int32 CUDA torch tensors.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, runtime, weights
+from .pyramid import Pyramid
+
+
+def _ctx(t):
+    c = runtime.default_context(t.device.index)
+    return c
+
+
+class Network:
+    def __init__(self, config, params=None, device=0, seed=0, ctx=None):
+        """config: ConfigBraTS-like (k_n, num_layers, d_out, num_classes, in_channels).
+        params: dict of TF-named arrays (weights.init_params / a converted checkpoint); random init if None."""
+        self.config = config
+        self.device = torch.device("cuda", device)
+        self.ctx = ctx or runtime.default_context(device)
+        self.params = params if params is not None else weights.init_params(config, seed=seed)
+        cfg = _lib.PsRandlaConfig()
+        cfg.num_layers = config.num_layers
+        cfg.k_n = config.k_n
+        cfg.num_classes = config.num_classes
+        cfg.in_channels = config.in_channels
+        for i in range(config.num_layers):
+            cfg.d_out[i] = config.d_out[i]
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.lib().ps_randla_create(self.ctx.handle, ctypes.byref(cfg), ctypes.byref(self._h)))
+        self.set_params(self.params)
+
+    def set_params(self, params):
+        self.params = params
+        blob = weights.fold_to_blob(self.config, params)
+        want = _lib.lib().ps_randla_weight_count(self._h)
+        assert blob.size == want, (blob.size, want)
+        _lib.check(_lib.lib().ps_randla_set_weights(self._h, runtime.ptr(blob), blob.size))
+
+    # ------------------------------------------------------------------------------------------------
+    def inference(self, inputs, is_training=False):
+        """inputs: dict with 'features' [B,N0,Cin] and either 'pyramid' (a pyramid.Pyramid) or the reference's
+        'xyz','neigh_idx','sub_idx','interp_idx' lists (RandLANet.py:33-36).  Returns logits [B,N0,num_classes]."""
+        if is_training:
+            raise NotImplementedError("training-mode forward (batch-stat BN, dropout) is not built yet")
+        pyr = inputs.get("pyramid")
+        if pyr is None:
+            pyr = Pyramid([t.contiguous() for t in inputs["xyz"]], [t.contiguous() for t in inputs["neigh_idx"]],
+                          [t.contiguous() for t in inputs["sub_idx"]], [t.contiguous() for t in inputs["interp_idx"]],
+                          self.config.k_n)
+        feats = inputs["features"].contiguous()
+        B, n0 = feats.shape[0], feats.shape[1]
+        logits = torch.empty((B, n0, self.config.num_classes), dtype=torch.float32, device=feats.device)
+        _lib.check(_lib.lib().ps_randla_forward(self._h, ctypes.byref(pyr.struct), runtime.ptr(feats), runtime.ptr(logits)))
+        return logits
+
+    def tap(self, which, shape):
+        """Copy an internal activation of the last forward to the host (parity tests)."""
+        out = np.empty(shape, np.float32)
+        _lib.check(_lib.lib().ps_randla_tap(self._h, int(which), runtime.ptr(out), out.size))
+        return out
+
+    # ---- op-by-op surface (RandLANet.py:337-401) ---------------------------------------------------------
+    @staticmethod
+    def gather_neighbour(pc, neighbor_idx):
+        """pc [B,N,d], neighbor_idx [B,N',K] -> [B,N',K,d]   (RandLANet.py:377-386)"""
+        pc, idx = pc.contiguous(), neighbor_idx.contiguous()
+        B, N, d = pc.shape
+        M, K = idx.shape[1], idx.shape[2]
+        out = torch.empty((B, M, K, d), dtype=torch.float32, device=pc.device)
+        _lib.check(_lib.lib().ps_op_gather_neighbour(_ctx(pc).handle, runtime.ptr(pc), runtime.ptr(idx), B, N, M, K, d, runtime.ptr(out)))
+        return out
+
+    @staticmethod
+    def relative_pos_encoding(xyz, neigh_idx):
+        """xyz [B,N,3], neigh_idx [B,N,K] -> [B,N,K,10]   (RandLANet.py:337-343)"""
+        xyz, idx = xyz.contiguous(), neigh_idx.contiguous()
+        B, N, K = idx.shape
+        out = torch.empty((B, N, K, 10), dtype=torch.float32, device=xyz.device)
+        _lib.check(_lib.lib().ps_op_relative_pos_encoding(_ctx(xyz).handle, runtime.ptr(xyz), runtime.ptr(idx), B, N, K, runtime.ptr(out)))
+        return out
+
+    @staticmethod
+    def random_sample(feature, pool_idx):
+        """feature [B,N,1,d], pool_idx [B,N',K] -> [B,N',1,d]   (RandLANet.py:345-360)"""
+        f = feature.squeeze(2).contiguous()
+        idx = pool_idx.contiguous()
+        B, N, d = f.shape
+        M, K = idx.shape[1], idx.shape[2]
+        out = torch.empty((B, M, d), dtype=torch.float32, device=f.device)
+        _lib.check(_lib.lib().ps_op_random_sample(_ctx(f).handle, runtime.ptr(f), runtime.ptr(idx), B, N, M, K, d, runtime.ptr(out)))
+        return out.unsqueeze(2)
+
+    @staticmethod
+    def nearest_interpolation(feature, interp_idx):
+        """feature [B,N,1,d], interp_idx [B,up,1] -> [B,up,1,d]   (RandLANet.py:362-375)"""
+        f = feature.squeeze(2).contiguous()
+        idx = interp_idx.contiguous()
+        B, N, d = f.shape
+        M = idx.shape[1]
+        out = torch.empty((B, M, d), dtype=torch.float32, device=f.device)
+        _lib.check(_lib.lib().ps_op_nearest_interpolation(_ctx(f).handle, runtime.ptr(f), runtime.ptr(idx), B, N, M, d, runtime.ptr(out)))
+        return out.unsqueeze(2)
+
+    @staticmethod
+    def conv2d(inputs, w, b, leaky=True):
+        """helper_tf_util.conv2d with a 1x1 kernel and BN already folded into (w [Cin,Cout], b [Cout])."""
+        x = inputs.contiguous()
+        cin, cout = w.shape
+        R = x.numel() // cin
+        out = torch.empty(tuple(x.shape[:-1]) + (cout,), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().ps_op_conv1x1(_ctx(x).handle, runtime.ptr(x), runtime.ptr(w.contiguous()), runtime.ptr(b.contiguous()),
+                                            R, cin, cout, 1 if leaky else 0, runtime.ptr(out)))
+        return out
+
+    @staticmethod
+    def att_pooling(feature_set, wfc, w_mlp, b_mlp):
+        """feature_set [B,N,K,d]; wfc [d,d]; trailing conv2d (w_mlp [d,d_out], b_mlp) -> [B,N,1,d_out]
+        (RandLANet.py:388-401)."""
+        f = feature_set.contiguous()
+        B, N, K, d = f.shape
+        agg = torch.empty((B, N, d), dtype=torch.float32, device=f.device)
+        _lib.check(_lib.lib().ps_op_att_pool(_ctx(f).handle, runtime.ptr(f), runtime.ptr(wfc.contiguous()), B * N, K, d, runtime.ptr(agg)))
+        return Network.conv2d(agg.unsqueeze(2), w_mlp, b_mlp, leaky=True)

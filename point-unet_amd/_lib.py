@@ -1,0 +1,109 @@
+"""ctypes binding of libpointseg_hip.so -- the only door between the Python host code and the HIP kernels.
+
+The signatures below are include/pointseg.h verbatim.  The library is built in-tree by compile_op.sh
+(csrc/Makefile); a missing library is a hard error: there is no CPU fallback anywhere in this package.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpointseg_hip.so")
+
+PS_MAX_LAYERS = 8
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_vp = ctypes.c_void_p
+
+
+class PsPyramid(ctypes.Structure):
+    _fields_ = [
+        ("num_layers", ctypes.c_int32),
+        ("K", ctypes.c_int32),
+        ("B", ctypes.c_int64),
+        ("n", ctypes.c_int64 * (PS_MAX_LAYERS + 1)),
+        ("xyz", c_vp * PS_MAX_LAYERS),
+        ("neigh_idx", c_vp * PS_MAX_LAYERS),
+        ("sub_idx", c_vp * PS_MAX_LAYERS),
+        ("interp_idx", c_vp * PS_MAX_LAYERS),
+    ]
+
+
+class PsRandlaConfig(ctypes.Structure):
+    _fields_ = [
+        ("num_layers", ctypes.c_int32),
+        ("k_n", ctypes.c_int32),
+        ("num_classes", ctypes.c_int32),
+        ("in_channels", ctypes.c_int32),
+        ("d_out", ctypes.c_int32 * PS_MAX_LAYERS),
+    ]
+
+
+class PsTimingRow(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("ms", ctypes.c_double), ("launches", ctypes.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol include/pointseg.h declares
+PROTOTYPES = {
+    "ps_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "ps_destroy": (ctypes.c_int, [c_vp]),
+    "ps_set_stream": (ctypes.c_int, [c_vp, c_vp]),
+    "ps_synchronize": (ctypes.c_int, [c_vp]),
+    "ps_last_error": (ctypes.c_char_p, []),
+    "ps_version": (ctypes.c_char_p, []),
+    "ps_timing_begin": (ctypes.c_int, [c_vp]),
+    "ps_timing_end": (ctypes.c_int, [c_vp, ctypes.POINTER(PsTimingRow), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "ps_knn_batch": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 5 + [c_vp, ctypes.c_int]),
+    "ps_knn_batch_i64": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 5 + [c_vp, ctypes.c_int]),
+    "ps_pyramid_build": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, c_i32p, ctypes.c_int32,
+                                        ctypes.POINTER(PsPyramid)]),
+    "ps_grid_subsample": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, ctypes.c_int64, c_vp, ctypes.c_int64, ctypes.c_float,
+                                         c_i64p, c_vp, c_vp, c_vp]),
+    "ps_randla_create": (ctypes.c_int, [c_vp, ctypes.POINTER(PsRandlaConfig), ctypes.POINTER(c_vp)]),
+    "ps_randla_destroy": (ctypes.c_int, [c_vp]),
+    "ps_randla_weight_count": (ctypes.c_int64, [c_vp]),
+    "ps_randla_set_weights": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64]),
+    "ps_randla_forward": (ctypes.c_int, [c_vp, ctypes.POINTER(PsPyramid), c_vp, c_vp]),
+    "ps_randla_tap": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, ctypes.c_int64]),
+    "ps_op_gather_neighbour": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 5 + [c_vp]),
+    "ps_op_relative_pos_encoding": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp]),
+    "ps_op_random_sample": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 5 + [c_vp]),
+    "ps_op_nearest_interpolation": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 4 + [c_vp]),
+    "ps_op_conv1x1": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [ctypes.c_int, c_vp]),
+    "ps_op_att_pool": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp]),
+    # host-only debug doors (bound for the CPU test-suite only; the facade never calls them)
+    "ps_debug_knn_host": (ctypes.c_int, [c_vp, c_vp] + [ctypes.c_int64] * 4 + [c_vp]),
+    "ps_debug_kdtree_host": (ctypes.c_int, [c_vp, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ps_debug_pack_weights": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp]),
+}
+
+_lib = None
+
+
+class PointSegError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built -- never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PointSegError("libpointseg_hip.so is missing: build it with `sh point-unet_amd/compile_op.sh` "
+                                "(or __graft_entry__.build()); there is no CPU fallback")
+        try:  # share torch's HIP runtime (same SONAME libamdhip64.so.7) when torch is in the process
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover
+            pass
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise PointSegError("libpointseg_hip: %s (code %d)" % (lib().ps_last_error().decode(), rc))

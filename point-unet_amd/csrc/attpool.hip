@@ -1,0 +1,214 @@
+// attpool.hip -- fused local spatial encoding + neighbour gather + attentive pooling, one wave per point.
+//
+// Device form of building_block / relative_pos_encoding / gather_neighbour / att_pooling
+// (PointSegment/RandLANet.py:323-343, 377-401) up to (not including) att_pooling's trailing conv2d.
+// No [N,K,C] tensor ever reaches HBM: per point the wave
+//   1. gathers the K neighbour coordinates and forms the 10-vector [dis, rel, centre, nbr]      (:337-343)
+//   2. runs LFA mlp1 (10 -> d/2, BN folded, LeakyReLU) on fp32 MFMA straight from registers      (:326)
+//      (stage 2 additionally LFA mlp2 d/2 -> d/2 from the LDS tile)                              (:331)
+//   3. computes the attention scores  [f_nb | f_xyz] . Wfc  as  G[idx] + f_xyz . Wfc[d/2:, :]    (:395)
+//      where G = f . Wfc[:d/2, :] was produced once per point by the preceding dense layer: gathering commutes
+//      with a per-row linear map, which halves the score FLOPs of the reference formulation
+//   4. softmax over the K rows of each column with wave shuffles, weighted sum of [f_nb | f_xyz] (:396-398)
+// A 16x16 MFMA output tile is exactly (16 neighbours) x (16 channels) of one point.
+//
+// Bound: fp32 MFMA for d >= 64; latency/L2 for d = 16 (level 0).
+#include "attpool.h"
+#include "mfma_tile.h"
+
+namespace ps {
+
+struct AttArgs {
+    const float* xyz;
+    const int32_t* idx;
+    const float* fg;
+    const float* w1p; const float* b1;
+    const float* w2p; const float* b2;
+    const float* wbp;
+    float* agg;
+    int n_total, n_cloud;
+};
+
+template <int D, int STAGE, int KN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
+{
+    constexpr int H = D / 2, RT = KN / 16, PITCH = H + 2, LDF = H + D;
+    constexpr int NTB_H = ntb_for(H), NTB_D = ntb_for(D);
+    constexpr int NT_H = (H + 15) / 16, NT_D = D / 16;
+    constexpr int CB_H = (NT_H + NTB_H - 1) / NTB_H, CB_D = (NT_D + NTB_D - 1) / NTB_D;
+    constexpr int KS_H = (H + 3) / 4;
+    using bfH = typename BFrag<NTB_H>::type;
+    using bfD = typename BFrag<NTB_D>::type;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, c16 = lane & 15;
+    float* T1 = smem + wave * (KN * PITCH * (STAGE == 2 ? 2 : 1));
+    float* T2 = T1 + KN * PITCH;
+
+    for (int p = blockIdx.x * WAVES + wave; p < a.n_total; p += gridDim.x * WAVES) {
+        const int base = (p / a.n_cloud) * a.n_cloud;
+        const float cx = a.xyz[3 * (size_t)p], cy = a.xyz[3 * (size_t)p + 1], cz = a.xyz[3 * (size_t)p + 2];
+        int nb[RT];
+        float a0[RT], a1[RT], a2[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            nb[rt] = base + a.idx[(size_t)p * KN + rt * 16 + c16];
+            const float nx = a.xyz[3 * (size_t)nb[rt]], ny = a.xyz[3 * (size_t)nb[rt] + 1], nz = a.xyz[3 * (size_t)nb[rt] + 2];
+            const float rx = cx - nx, ry = cy - ny, rz = cz - nz;
+            const float dis = __fsqrt_rn(rx * rx + ry * ry + rz * rz);
+            a0[rt] = g == 0 ? dis : (g == 1 ? rx : (g == 2 ? ry : rz));
+            a1[rt] = g == 0 ? cx : (g == 1 ? cy : (g == 2 ? cz : nx));
+            a2[rt] = g == 0 ? ny : (g == 1 ? nz : 0.f);
+        }
+        // ---- LFA mlp1: f_xyz1 = lrelu(enc10 . W1 + b1) -> T1 ----
+#pragma unroll
+        for (int cb = 0; cb < CB_H; ++cb) {
+            f32x4 acc[RT][NTB_H];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int j = 0; j < NTB_H; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bfH* w = reinterpret_cast<const bfH*>(a.w1p) + (size_t)cb * 3 * 64 + lane;
+            const bfH b0 = w[0], b1v = w[64], b2v = w[128];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int j = 0; j < NTB_H; ++j) {
+                    acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[rt], bfrag_get<NTB_H>(b0, j), acc[rt][j], 0, 0, 0);
+                    acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rt], bfrag_get<NTB_H>(b1v, j), acc[rt][j], 0, 0, 0);
+                    acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[rt], bfrag_get<NTB_H>(b2v, j), acc[rt][j], 0, 0, 0);
+                }
+#pragma unroll
+            for (int j = 0; j < NTB_H; ++j) {
+                const int col = (cb * NTB_H + j) * 16 + c16;
+                if (col < H) {
+                    const float bb = a.b1[col];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) T1[(rt * 16 + g * 4 + r) * PITCH + col] = leaky02(acc[rt][j][r] + bb);
+                }
+            }
+        }
+        wave_lds_sync();
+        const float* TX = T1;
+        if constexpr (STAGE == 2) {
+            // ---- LFA mlp2: f_xyz2 = lrelu(f_xyz1 . W2 + b2) -> T2 ----
+            for (int cb = 0; cb < CB_H; ++cb) {
+                f32x4 acc[RT][NTB_H];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int j = 0; j < NTB_H; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                tile_mma<NTB_H, RT>(T1, PITCH, KS_H, reinterpret_cast<const bfH*>(a.w2p) + (size_t)cb * KS_H * 64 + lane, acc, lane);
+#pragma unroll
+                for (int j = 0; j < NTB_H; ++j) {
+                    const int col = (cb * NTB_H + j) * 16 + c16;
+                    if (col < H) {
+                        const float bb = a.b2[col];
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) T2[(rt * 16 + g * 4 + r) * PITCH + col] = leaky02(acc[rt][j][r] + bb);
+                    }
+                }
+            }
+            wave_lds_sync();
+            TX = T2;
+        }
+        // neighbour row of C-layout row (g*4 + r): held by lane (g*4 + r) of group 0
+        size_t jr[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) jr[rt][r] = (size_t)__shfl(nb[rt], g * 4 + r) * LDF;
+
+        // ---- scores, softmax over the K rows, weighted sum ----
+        for (int cb = 0; cb < CB_D; ++cb) {
+            f32x4 acc[RT][NTB_D];
+#pragma unroll
+            for (int j = 0; j < NTB_D; ++j) {
+                const int col = (cb * NTB_D + j) * 16 + c16;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[rt][j][r] = a.fg[jr[rt][r] + H + col];
+            }
+            tile_mma<NTB_D, RT>(TX, PITCH, KS_H, reinterpret_cast<const bfD*>(a.wbp) + (size_t)cb * KS_H * 64 + lane, acc, lane);
+#pragma unroll
+            for (int j = 0; j < NTB_D; ++j) {
+                const int col = (cb * NTB_D + j) * 16 + c16;
+                float m = acc[0][j][0];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[rt][j][r]);
+                m = xor_max(m);
+                float ssum = 0.f, num = 0.f;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __expf(acc[rt][j][r] - m);
+                        const float v = col < H ? a.fg[jr[rt][r] + col] : TX[(rt * 16 + g * 4 + r) * PITCH + (col - H)];
+                        ssum += e;
+                        num += e * v;
+                    }
+                ssum = xor_sum(ssum);
+                num = xor_sum(num);
+                if (g == 0) a.agg[(size_t)p * D + col] = num / ssum;
+            }
+        }
+        wave_lds_sync();  // T1/T2 are overwritten by the next point
+    }
+}
+
+template <int D, int STAGE, int KN>
+static int launch_att(ps_context* c, const AttArgs& a)
+{
+    constexpr int H = D / 2, PITCH = H + 2;
+    constexpr size_t per_wave = (size_t)KN * PITCH * (STAGE == 2 ? 2 : 1) * sizeof(float);
+    constexpr int WAVES = per_wave * 4 <= 160 * 1024 ? 4 : (per_wave * 2 <= 160 * 1024 ? 2 : 1);
+    static_assert(per_wave * WAVES <= 160 * 1024, "attention tile does not fit the LDS");
+    const size_t smem = per_wave * WAVES;
+    auto kern = att_kernel<D, STAGE, KN, WAVES>;
+    if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const int blocks = std::min(ceil_div(a.n_total, WAVES), 256 * 8);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+template <int STAGE, int KN>
+static int dispatch_d(ps_context* c, int d, const AttArgs& a)
+{
+    switch (d) {
+        case 16: return launch_att<16, STAGE, KN>(c, a);
+        case 32: return launch_att<32, STAGE, KN>(c, a);
+        case 64: return launch_att<64, STAGE, KN>(c, a);
+        case 128: return launch_att<128, STAGE, KN>(c, a);
+        case 256: return launch_att<256, STAGE, KN>(c, a);
+        case 512: return launch_att<512, STAGE, KN>(c, a);
+        default: set_error("att_pool: d_out %d is not a compiled size (16,32,64,128,256,512)", d); return PS_EINVAL;
+    }
+}
+
+int att_pool_stage(ps_context* c, const AttStage& s)
+{
+    AttArgs a;
+    a.xyz = s.xyz; a.idx = s.idx; a.fg = s.fg;
+    a.w1p = s.lfa1->wp; a.b1 = s.lfa1->bias;
+    a.w2p = s.lfa2 ? s.lfa2->wp : nullptr; a.b2 = s.lfa2 ? s.lfa2->bias : nullptr;
+    a.wbp = s.wbot->wp;
+    a.agg = s.agg;
+    a.n_total = (int)s.n_total; a.n_cloud = (int)s.n_cloud;
+    if (s.n_total <= 0) return PS_OK;
+    const int stage = s.lfa2 ? 2 : 1;
+    if (s.k == 16) return stage == 1 ? dispatch_d<1, 16>(c, s.d, a) : dispatch_d<2, 16>(c, s.d, a);
+    if (s.k == 32) return stage == 1 ? dispatch_d<1, 32>(c, s.d, a) : dispatch_d<2, 32>(c, s.d, a);
+    set_error("att_pool: k_n %d is not a compiled size (16, 32)", s.k);
+    return PS_EINVAL;
+}
+
+}  // namespace ps

@@ -1,0 +1,173 @@
+// kdtree.h -- device layout of the kd-tree and the per-query search, shared by the tree builders and the
+// search kernels.  The search routine is __host__ __device__ so the exact same code is exercised by the CPU
+// unit tests (tests/test_host_logic.py via ps_debug_*) and by the HIP kernel.
+//
+// Behaviour being reproduced (so that equal-distance ties resolve to the same index as the reference):
+//   nanoflann 1.2.3 as used by PointSegment/utils/nearest_neighbors/knn_.cxx:104-135
+//     tree shape / vind permutation   nanoflann.hpp:916-1043
+//     query descent, pruning          nanoflann.hpp:1244-1258, 1045-1061, 1351-1408
+//     stable result insertion         nanoflann.hpp:115-139
+//     metric (dim 3 tail loop)        nanoflann.hpp:343-346
+//
+// Layout (one tree = one cloud at one pyramid level, n points):
+//   pts[n]    float4  points in `vind` order: (x, y, z, bit-cast original index)  -> a leaf is a contiguous,
+//                     coalescable run and needs no second indirection
+//   nodes[2n] int4    indexed by a deterministic node id:
+//                       leaf  over vind range [l, r)            id = 2*l      (even)  {l, r, 0, 0}
+//                       inner whose children meet at position m id = 2*m - 1  (odd)   {child1 | axis<<30,
+//                                                                                      child2, divlow, divhigh}
+//                     every split position belongs to exactly one inner node and every range start to exactly
+//                     one leaf, so ids never collide and do not depend on scheduling order.
+#pragma once
+
+#include <cfloat>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PS_HD __host__ __device__ __forceinline__
+#else
+#define PS_HD inline
+struct int4 { int x, y, z, w; };
+struct float4 { float x, y, z, w; };
+#endif
+
+namespace ps {
+
+constexpr int kLeafMax = 10;   // KDTreeTableAdaptor(npts, dim, points, 10)  knn_.cxx:116
+constexpr int kStackMax = 64;  // deferred far-children per query; builders report the tree depth
+
+// Produced by the builder (on the device in production): root id, depth, root bounding box.
+struct TreeMeta {
+    int32_t root;
+    int32_t depth;
+    float lo[3], hi[3];
+};
+
+struct TreeView {
+    const int4* nodes;
+    const float4* pts;
+    const TreeMeta* meta;
+    int32_t n;
+};
+
+// fp32 arithmetic with one rounding per operation, never contracted into FMA (the reference is built without
+// -march / -ffast-math: plain SSE2 mulss/addss).
+#if defined(__HIP_DEVICE_COMPILE__)
+PS_HD float f_mul(float a, float b) { return __fmul_rn(a, b); }
+PS_HD float f_add(float a, float b) { return __fadd_rn(a, b); }
+PS_HD float f_sub(float a, float b) { return __fsub_rn(a, b); }
+PS_HD float as_f(int v) { return __int_as_float(v); }
+PS_HD int as_i(float v) { return __float_as_int(v); }
+#else
+PS_HD float f_mul(float a, float b) { volatile float r = a * b; return r; }
+PS_HD float f_add(float a, float b) { volatile float r = a + b; return r; }
+PS_HD float f_sub(float a, float b) { volatile float r = a - b; return r; }
+PS_HD float as_f(int v) { float f; __builtin_memcpy(&f, &v, 4); return f; }
+PS_HD int as_i(float v) { int i; __builtin_memcpy(&i, &v, 4); return i; }
+#endif
+
+PS_HD float sq_dist(float qx, float qy, float qz, float px, float py, float pz)
+{
+    // ((dx*dx) + dy*dy) + dz*dz with diff = query - point   (nanoflann.hpp:343-346)
+    float dx = f_sub(qx, px), dy = f_sub(qy, py), dz = f_sub(qz, pz);
+    return f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz));
+}
+
+// Ascending list of the K best (distance, index); first-visited wins among equals (shift while stored > d).
+// Written with compile-time indices only so that dist/idx stay in registers on the device.
+template <int K>
+PS_HD void topk_insert(float (&dist)[K], int (&idx)[K], float d, int p)
+{
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) {
+        const bool mine = dist[j] > d;                             // slot j moves or takes the newcomer
+        const bool prev = (j > 0) ? (dist[j > 0 ? j - 1 : 0] > d) : false;  // the element below also moves up
+        const float nd = prev ? dist[j > 0 ? j - 1 : 0] : d;
+        const int ni = prev ? idx[j > 0 ? j - 1 : 0] : p;
+        dist[j] = mine ? nd : dist[j];
+        idx[j] = mine ? ni : idx[j];
+    }
+}
+
+// One query against one tree.  dist/idx must be initialised by the caller (FLT_MAX / 0).
+// Returns false if the deferred-node stack overflowed (tree deeper than kStackMax).
+template <int K>
+PS_HD bool knn_search_one(const TreeView& t, float qx, float qy, float qz, float (&dist)[K], int (&idx)[K])
+{
+    if (t.n <= 0) return true;
+    const TreeMeta mt = *t.meta;
+    // computeInitialDistances, nanoflann.hpp:1045-1061
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, m = 0.f;
+    if (qx < mt.lo[0]) { d0 = f_mul(f_sub(qx, mt.lo[0]), f_sub(qx, mt.lo[0])); m = f_add(m, d0); }
+    if (qx > mt.hi[0]) { d0 = f_mul(f_sub(qx, mt.hi[0]), f_sub(qx, mt.hi[0])); m = f_add(m, d0); }
+    if (qy < mt.lo[1]) { d1 = f_mul(f_sub(qy, mt.lo[1]), f_sub(qy, mt.lo[1])); m = f_add(m, d1); }
+    if (qy > mt.hi[1]) { d1 = f_mul(f_sub(qy, mt.hi[1]), f_sub(qy, mt.hi[1])); m = f_add(m, d1); }
+    if (qz < mt.lo[2]) { d2 = f_mul(f_sub(qz, mt.lo[2]), f_sub(qz, mt.lo[2])); m = f_add(m, d2); }
+    if (qz > mt.hi[2]) { d2 = f_mul(f_sub(qz, mt.hi[2]), f_sub(qz, mt.hi[2])); m = f_add(m, d2); }
+
+    int st_id[kStackMax];
+    float st_m[kStackMax], st_d0[kStackMax], st_d1[kStackMax], st_d2[kStackMax];
+    int sp = 0;
+    bool ok = true;
+    int cur = mt.root;
+    for (;;) {
+        // ---- descend to a leaf, deferring the far children (searchLevel, nanoflann.hpp:1372-1406) ----
+        while (cur & 1) {
+            const int4 nd = t.nodes[cur];
+            const int ax = (int)((unsigned)nd.x >> 30);
+            const int c1 = nd.x & 0x3fffffff, c2 = nd.y;
+            const float divlow = as_f(nd.z), divhigh = as_f(nd.w);
+            const float val = ax == 0 ? qx : (ax == 1 ? qy : qz);
+            const float diff1 = f_sub(val, divlow), diff2 = f_sub(val, divhigh);
+            const bool left_first = f_add(diff1, diff2) < 0.f;
+            const float e = left_first ? diff2 : diff1;  // accum_dist(val, divhigh) or (val, divlow)
+            const float cut = f_mul(e, e);
+            const float dax = ax == 0 ? d0 : (ax == 1 ? d1 : d2);
+            const float m2 = f_sub(f_add(m, cut), dax);
+            // The reference tests `m2 <= worstDist()` AFTER the near subtree returns; worstDist() only ever
+            // decreases, so a far child that already fails now can never pass later: do not defer it.
+            if (m2 <= dist[K - 1]) {
+                if (sp < kStackMax) {
+                    st_id[sp] = left_first ? c2 : c1;
+                    st_m[sp] = m2;
+                    st_d0[sp] = ax == 0 ? cut : d0;
+                    st_d1[sp] = ax == 1 ? cut : d1;
+                    st_d2[sp] = ax == 2 ? cut : d2;
+                    ++sp;
+                } else
+                    ok = false;
+            }
+            cur = left_first ? c1 : c2;
+        }
+        // ---- leaf: scan its points in vind order (nanoflann.hpp:1355-1369) ----
+        {
+            const int4 lf = t.nodes[cur];
+            for (int i = lf.x; i < lf.y; ++i) {
+                const float4 p = t.pts[i];
+                const float d = sq_dist(qx, qy, qz, p.x, p.y, p.z);
+                // the reference filters on a worst distance sampled once per leaf and lets addPoint drop the
+                // late-comers; both together accept exactly the points with d < current worst.
+                if (d < dist[K - 1]) topk_insert<K>(dist, idx, d, as_i(p.w));
+            }
+        }
+        // ---- resume at the most recent deferred child that still passes the prune test ----
+        bool found = false;
+        while (sp > 0) {
+            --sp;
+            if (st_m[sp] <= dist[K - 1]) {
+                cur = st_id[sp];
+                m = st_m[sp];
+                d0 = st_d0[sp];
+                d1 = st_d1[sp];
+                d2 = st_d2[sp];
+                found = true;
+                break;
+            }
+        }
+        if (!found) break;
+    }
+    return ok;
+}
+
+}  // namespace ps

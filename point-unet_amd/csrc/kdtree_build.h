@@ -1,0 +1,53 @@
+// kdtree_build.h -- a set of kd-trees carved from the context's workspace and built in one go.
+#pragma once
+
+#include <vector>
+
+#include "common.h"
+#include "kdtree.h"
+
+namespace ps {
+
+struct TreeSetPlan {
+    // inputs
+    std::vector<int32_t> n;          // points per tree
+    std::vector<const float*> src;   // device pointer to that tree's [n,3] fp32 rows
+    int extra_jobs = 0;              // additional KnnJob slots wanted in d_jobs (beyond one per tree)
+    // carved device storage
+    std::vector<int4*> d_nodes;      // [2n] per tree
+    std::vector<float4*> d_pts;      // [n]  per tree (vind order, w = original index)
+    TreeMeta* d_meta = nullptr;      // [trees]
+    void* d_jobs = nullptr;          // KnnJob table (trees + extra_jobs entries of 64 B)
+    int32_t* d_flags = nullptr;      // [16] error flags, zeroed by build_trees
+    void* d_scratch = nullptr;       // builder scratch
+    size_t scratch_bytes = 0;
+
+    void add(int32_t count)
+    {
+        n.push_back(count);
+        src.push_back(nullptr);
+        d_nodes.push_back(nullptr);
+        d_pts.push_back(nullptr);
+    }
+    size_t total_points() const
+    {
+        size_t t = 0;
+        for (int32_t v : n) t += (size_t)v;
+        return t;
+    }
+    void carve(Arena& a);
+    TreeView view(int i) const
+    {
+        TreeView v;
+        v.nodes = d_nodes[i];
+        v.pts = d_pts[i];
+        v.meta = d_meta + i;
+        v.n = n[i];
+        return v;
+    }
+};
+
+// Builds every tree of the plan on the context's stream.
+int build_trees(ps_context* c, TreeSetPlan& plan);
+
+}  // namespace ps

@@ -1,0 +1,326 @@
+// knn.hip -- exact KNN search kernel + the C-ABI entry points built on it (ps_knn_batch, ps_pyramid_build).
+//
+// Replaces cpp_knn_batch_omp (PointSegment/utils/nearest_neighbors/knn_.cxx:104-135) and the per-layer loop
+// of tf_map (PointSegment/runBraTS.py:147-156).
+//
+// Kernel shape: one lane per query, the per-query routine of kdtree.h (iterative descent with an explicit
+// deferred-node stack, top-K list in registers).  Lanes of a wave are given queries in the *support tree's
+// leaf order* whenever the caller can provide it (self-queries and the pyramid's up-sampling queries), so a
+// wave walks almost the same root-to-leaf path and its node/leaf loads hit the same cache lines.
+// Roofline: neither HBM nor MFMA -- a divergent, latency-bound tree walk; reported in queries/s with the
+// algorithmic bytes of SURVEY 8(d) next to it.
+#include "common.h"
+#include "kdtree.h"
+#include "kdtree_build.h"
+
+#include <cfloat>
+
+namespace ps {
+
+struct KnnJob {
+    TreeView tree;
+    const float4* q4;   // queries as (x,y,z,bitcast row) -- e.g. another tree's `pts` -- or NULL
+    const float* q3;    // raw [nq,3] queries (row = query position) when q4 == NULL
+    int32_t nq;
+    int32_t* out;       // [nq, K]
+    int32_t* overflow;  // set to 1 if any query overflowed the deferred-node stack
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void knn_kernel(const KnnJob* __restrict__ jobs)
+{
+    const KnnJob& job = jobs[blockIdx.y];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= job.nq) return;
+    float qx, qy, qz;
+    int row;
+    if (job.q4) {
+        const float4 q = job.q4[t];
+        qx = q.x; qy = q.y; qz = q.z;
+        row = as_i(q.w);
+    } else {
+        qx = job.q3[3 * (size_t)t];
+        qy = job.q3[3 * (size_t)t + 1];
+        qz = job.q3[3 * (size_t)t + 2];
+        row = t;
+    }
+    float dist[K];
+    int idx[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        dist[j] = FLT_MAX;
+        idx[j] = 0;
+    }
+    const bool ok = knn_search_one<K>(job.tree, qx, qy, qz, dist, idx);
+    if (!ok) *job.overflow = 1;
+    int32_t* o = job.out + (size_t)row * K;
+    if constexpr (K % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < K; j += 4) *reinterpret_cast<int4*>(o + j) = make_int4(idx[j], idx[j + 1], idx[j + 2], idx[j + 3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) o[j] = idx[j];
+    }
+}
+
+__global__ void widen_kernel(const int32_t* __restrict__ in, int64_t* __restrict__ out, size_t count)
+{
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < count) out[i] = in[i];
+}
+
+static int launch_knn(ps_context* c, const KnnJob* d_jobs, int n_jobs, int max_nq, int K)
+{
+    dim3 grid(ceil_div(max_nq, 256), n_jobs);
+    if (grid.x == 0 || n_jobs == 0) return PS_OK;
+    switch (K) {
+#define PS_KCASE(k)                                                             \
+    case k:                                                                     \
+        hipLaunchKernelGGL(knn_kernel<k>, grid, dim3(256), 0, c->stream, d_jobs); \
+        break;
+        PS_KCASE(1) PS_KCASE(2) PS_KCASE(3) PS_KCASE(4) PS_KCASE(5) PS_KCASE(6) PS_KCASE(7) PS_KCASE(8)
+        PS_KCASE(9) PS_KCASE(10) PS_KCASE(11) PS_KCASE(12) PS_KCASE(13) PS_KCASE(14) PS_KCASE(15) PS_KCASE(16)
+        PS_KCASE(20) PS_KCASE(24) PS_KCASE(32) PS_KCASE(48) PS_KCASE(64)
+#undef PS_KCASE
+        default:
+            set_error("ps_knn: K=%d is not a compiled size (1..16, 20, 24, 32, 48, 64)", K);
+            return PS_EINVAL;
+    }
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+}  // namespace ps
+
+using namespace ps;
+
+// --------------------------------------------------------------------------------------------------------
+// ps_knn_batch
+// --------------------------------------------------------------------------------------------------------
+static int knn_batch_impl(ps_context* c, const float* support, const float* queries, int64_t B, int64_t n1, int64_t n2,
+                          int64_t dim, int64_t K, int32_t* out32, int64_t* out64, int device_ptrs)
+{
+    PS_CHECK(c != nullptr, "ps_knn_batch: ctx is NULL");
+    PS_CHECK(dim == 3, "ps_knn_batch: dim must be 3 (got %lld)", (long long)dim);
+    PS_CHECK(B >= 0 && n1 >= 0 && n2 >= 0 && K >= 1, "ps_knn_batch: negative size or K < 1");
+    PS_CHECK(n1 < (1 << 29), "ps_knn_batch: n_support too large");
+    PS_CHECK(out32 != nullptr || out64 != nullptr, "ps_knn_batch: out_idx is NULL");
+    if (B == 0 || n2 == 0) return PS_OK;
+    PS_CHECK(support != nullptr || n1 == 0, "ps_knn_batch: support is NULL");
+    PS_CHECK(queries != nullptr, "ps_knn_batch: queries is NULL");
+    PS_HIP(hipSetDevice(c->device));
+
+    const size_t out_count = (size_t)B * n2 * K;
+    const float* d_support = support;
+    const float* d_queries = queries;
+    int32_t* d_out32 = out32;
+    int64_t* d_out64 = out64;
+    if (!device_ptrs) {
+        const size_t sb = (size_t)B * n1 * 3 * sizeof(float), qb = (size_t)B * n2 * 3 * sizeof(float);
+        PS_TRY(c->stage_in.reserve(sb + qb + 512));
+        PS_TRY(c->stage_out.reserve(out_count * (out64 ? 12 : 4) + 512));
+        float* ds = c->stage_in.as<float>();
+        float* dq = reinterpret_cast<float*>(c->stage_in.as<char>() + ((sb + 255) & ~size_t(255)));
+        if (sb) PS_HIP(hipMemcpyAsync(ds, support, sb, hipMemcpyHostToDevice, c->stream));
+        PS_HIP(hipMemcpyAsync(dq, queries, qb, hipMemcpyHostToDevice, c->stream));
+        d_support = ds;
+        d_queries = dq;
+        d_out32 = c->stage_out.as<int32_t>();
+        d_out64 = out64 ? reinterpret_cast<int64_t*>(c->stage_out.as<char>() + ((out_count * 4 + 255) & ~size_t(255))) : nullptr;
+    } else if (out64) {
+        // device int64 output: search into a scratch int32 image first
+        PS_TRY(c->stage_out.reserve(out_count * 4 + 256));
+        d_out32 = c->stage_out.as<int32_t>();
+    }
+
+    // plan + carve the workspace: B trees and the job table
+    TreeSetPlan plan;
+    for (int64_t b = 0; b < B; ++b) plan.add((int32_t)n1);
+    for (int pass = 0; pass < 2; ++pass) {
+        c->knn_arena.begin(pass == 0);
+        plan.carve(c->knn_arena);
+        if (pass == 0) PS_TRY(c->knn_arena.buf.reserve(c->knn_arena.off));
+    }
+    {
+        Stage st(c, "kdtree_build", 1);
+        for (int64_t b = 0; b < B; ++b) plan.src[b] = d_support + (size_t)b * n1 * 3;
+        PS_TRY(build_trees(c, plan));
+    }
+    std::vector<KnnJob> jobs(B);
+    for (int64_t b = 0; b < B; ++b) {
+        jobs[b].tree = plan.view((int)b);
+        jobs[b].q4 = nullptr;
+        jobs[b].q3 = d_queries + (size_t)b * n2 * 3;
+        jobs[b].nq = (int32_t)n2;
+        jobs[b].out = d_out32 + (size_t)b * n2 * K;
+        jobs[b].overflow = plan.d_flags;
+    }
+    PS_HIP(hipMemcpyAsync(plan.d_jobs, jobs.data(), sizeof(KnnJob) * B, hipMemcpyHostToDevice, c->stream));
+    {
+        Stage st(c, "knn_search", 1);
+        PS_TRY(launch_knn(c, reinterpret_cast<const KnnJob*>(plan.d_jobs), (int)B, (int)n2, (int)K));
+    }
+    if (out64) {
+        hipLaunchKernelGGL(widen_kernel, dim3(ceil_div(out_count, 256)), dim3(256), 0, c->stream, d_out32, d_out64 ? d_out64 : out64,
+                           out_count);
+        PS_HIP(hipGetLastError());
+    }
+    int32_t flag = 0;
+    if (!device_ptrs) {
+        if (out64)
+            PS_HIP(hipMemcpyAsync(out64, d_out64, out_count * 8, hipMemcpyDeviceToHost, c->stream));
+        else
+            PS_HIP(hipMemcpyAsync(out32, d_out32, out_count * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    PS_HIP(hipMemcpyAsync(&flag, plan.d_flags, 4, hipMemcpyDeviceToHost, c->stream));
+    // the job table lives in pageable host memory of this frame: wait before returning
+    PS_HIP(hipStreamSynchronize(c->stream));
+    PS_CHECK(flag == 0, "ps_knn_batch: kd-tree deeper than the %d-entry traversal stack", kStackMax);
+    return PS_OK;
+}
+
+extern "C" int ps_knn_batch(ps_context* c, const float* support, const float* queries, int64_t B, int64_t n1, int64_t n2,
+                            int64_t dim, int64_t K, int32_t* out_idx, int device_ptrs)
+{
+    return knn_batch_impl(c, support, queries, B, n1, n2, dim, K, out_idx, nullptr, device_ptrs);
+}
+
+extern "C" int ps_knn_batch_i64(ps_context* c, const float* support, const float* queries, int64_t B, int64_t n1, int64_t n2,
+                                int64_t dim, int64_t K, int64_t* out_idx, int device_ptrs)
+{
+    return knn_batch_impl(c, support, queries, B, n1, n2, dim, K, nullptr, out_idx, device_ptrs);
+}
+
+// --------------------------------------------------------------------------------------------------------
+// ps_pyramid_build
+// --------------------------------------------------------------------------------------------------------
+namespace ps {
+
+__global__ void slice_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t B, int64_t n_src, int64_t n_dst,
+                                  int width)
+{
+    // dst[b, i, :] = src[b, i, :] for i < n_dst  (prefix slice of every cloud)
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t per = (size_t)n_dst * width;
+    if (i >= (size_t)B * per) return;
+    size_t b = i / per, r = i % per;
+    dst[i] = src[b * (size_t)n_src * width + r];
+}
+
+__global__ void slice_rows_i32_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int64_t B, int64_t n_src,
+                                      int64_t n_dst, int width)
+{
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t per = (size_t)n_dst * width;
+    if (i >= (size_t)B * per) return;
+    size_t b = i / per, r = i % per;
+    dst[i] = src[b * (size_t)n_src * width + r];
+}
+
+}  // namespace ps
+
+extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int64_t n0, int32_t L, const int32_t* ratios, int32_t K,
+                                ps_pyramid* pyr)
+{
+    PS_CHECK(c && xyz0 && ratios && pyr, "ps_pyramid_build: NULL argument");
+    PS_CHECK(L >= 1 && L <= PS_MAX_LAYERS, "ps_pyramid_build: num_layers %d out of range", L);
+    PS_CHECK(B >= 1 && n0 >= 1 && n0 < (1 << 29), "ps_pyramid_build: bad B / n0");
+    PS_HIP(hipSetDevice(c->device));
+    int64_t n[PS_MAX_LAYERS + 1];
+    n[0] = n0;
+    for (int i = 0; i < L; ++i) {
+        PS_CHECK(ratios[i] >= 1, "ps_pyramid_build: ratio[%d] < 1", i);
+        n[i + 1] = n[i] / ratios[i];
+        PS_CHECK(n[i + 1] >= 1, "ps_pyramid_build: level %d would be empty", i + 1);
+    }
+    pyr->num_layers = L;
+    pyr->K = K;
+    pyr->B = B;
+    for (int i = 0; i <= L; ++i) pyr->n[i] = n[i];
+    for (int i = 0; i < L; ++i)
+        PS_CHECK(pyr->xyz[i] && pyr->neigh_idx[i] && pyr->sub_idx[i] && pyr->interp_idx[i], "ps_pyramid_build: NULL buffer at layer %d", i);
+
+    // xyz[i] = prefix slices (xyz[0] is a plain copy unless the caller aliased it)
+    {
+        Stage st(c, "pyramid_slices", L);
+        for (int i = 0; i < L; ++i) {
+            if (i == 0 && pyr->xyz[0] == xyz0) continue;
+            size_t tot = (size_t)B * n[i] * 3;
+            hipLaunchKernelGGL(slice_rows_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, c->stream, xyz0, pyr->xyz[i], B, n0, n[i], 3);
+        }
+        PS_HIP(hipGetLastError());
+    }
+
+    // trees: (level l in 0..L) x (cloud b).  Level l's point set is the first n[l] points of every cloud.
+    TreeSetPlan plan;
+    for (int l = 0; l <= L; ++l)
+        for (int64_t b = 0; b < B; ++b) plan.add((int32_t)n[l]);
+    plan.extra_jobs = (int)(2 * L * B);
+    for (int pass = 0; pass < 2; ++pass) {
+        c->knn_arena.begin(pass == 0);
+        plan.carve(c->knn_arena);
+        if (pass == 0) PS_TRY(c->knn_arena.buf.reserve(c->knn_arena.off));
+    }
+    for (int l = 0; l <= L; ++l)
+        for (int64_t b = 0; b < B; ++b) plan.src[l * B + b] = xyz0 + (size_t)b * n0 * 3;
+    {
+        Stage st(c, "kdtree_build", 1);
+        PS_TRY(build_trees(c, plan));
+    }
+
+    // jobs: K-NN self queries per level, then 1-NN up-sampling queries per level, both in the query set's own
+    // tree (leaf) order so neighbouring lanes walk neighbouring paths.
+    std::vector<KnnJob> jobs;
+    jobs.reserve(2 * L * B);
+    int max_nq = 0;
+    for (int l = 0; l < L; ++l)
+        for (int64_t b = 0; b < B; ++b) {
+            KnnJob j;
+            j.tree = plan.view((int)(l * B + b));
+            j.q4 = j.tree.pts;
+            j.q3 = nullptr;
+            j.nq = (int32_t)n[l];
+            j.out = pyr->neigh_idx[l] + (size_t)b * n[l] * K;
+            j.overflow = plan.d_flags;
+            jobs.push_back(j);
+            max_nq = std::max(max_nq, j.nq);
+        }
+    const size_t n_self = jobs.size();
+    for (int l = 0; l < L; ++l)
+        for (int64_t b = 0; b < B; ++b) {
+            KnnJob j;
+            j.tree = plan.view((int)((l + 1) * B + b));
+            j.q4 = plan.view((int)(l * B + b)).pts;
+            j.q3 = nullptr;
+            j.nq = (int32_t)n[l];
+            j.out = pyr->interp_idx[l] + (size_t)b * n[l];
+            j.overflow = plan.d_flags;
+            jobs.push_back(j);
+        }
+    // NOTE: jobs is pageable host memory: the copy below is synchronous w.r.t. the host buffer by the time
+    // hipMemcpyAsync returns for pageable sources, but we do not rely on it -- see the stream sync at the end.
+    PS_HIP(hipMemcpyAsync(plan.d_jobs, jobs.data(), sizeof(KnnJob) * jobs.size(), hipMemcpyHostToDevice, c->stream));
+    const KnnJob* dj = reinterpret_cast<const KnnJob*>(plan.d_jobs);
+    {
+        Stage st(c, "knn_search_k", 1);
+        PS_TRY(launch_knn(c, dj, (int)n_self, max_nq, K));
+    }
+    {
+        Stage st(c, "knn_search_1nn", 1);
+        PS_TRY(launch_knn(c, dj + n_self, (int)(jobs.size() - n_self), max_nq, 1));
+    }
+    {
+        Stage st(c, "pyramid_slices", L);
+        for (int l = 0; l < L; ++l) {
+            size_t tot = (size_t)B * n[l + 1] * K;
+            hipLaunchKernelGGL(slice_rows_i32_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, c->stream, pyr->neigh_idx[l], pyr->sub_idx[l],
+                               B, n[l], n[l + 1], K);
+        }
+        PS_HIP(hipGetLastError());
+    }
+    int32_t flag = 0;
+    PS_HIP(hipMemcpyAsync(&flag, plan.d_flags, 4, hipMemcpyDeviceToHost, c->stream));
+    PS_HIP(hipStreamSynchronize(c->stream));
+    PS_CHECK(flag == 0, "ps_pyramid_build: kd-tree deeper than the %d-entry traversal stack", kStackMax);
+    return PS_OK;
+}

@@ -1,0 +1,208 @@
+// ops.hip -- the op-by-op surface: one entry per Network.* static method of the reference graph
+// (PointSegment/RandLANet.py:337-401), for callers that keep the reference's unfused call sites.  These
+// materialise the [B,N,K,C] tensors exactly like the reference does; the fused production path is randla.hip.
+// All of them are gather / elementwise kernels: HBM-bound, coalesced along the channel axis.
+#include "common.h"
+#include "rowgemm.h"
+
+namespace ps {
+
+// out[row, :] = pc[batch(row)*N + idx[row], :]   rows = B*M*K
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ pc, const int32_t* __restrict__ idx, float* __restrict__ out,
+                                                          size_t rows, int rows_per_cloud, int n_cloud, int d)
+{
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= rows * d) return;
+    const size_t row = t / d;
+    const int ch = (int)(t - row * d);
+    const size_t b = row / rows_per_cloud;
+    out[t] = pc[(b * n_cloud + idx[row]) * d + ch];
+}
+
+// out[b,n,k,0:10] = [dis, rel(3), centre(3), nbr(3)]   (RandLANet.py:337-343)
+__global__ __launch_bounds__(256) void relpos_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ idx, float* __restrict__ out,
+                                                     size_t total /* B*N*K */, int n_cloud, int K)
+{
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const size_t p = t / K;  // global point row
+    const size_t b = p / n_cloud;
+    const size_t q = b * n_cloud + idx[t];
+    const float cx = xyz[3 * p], cy = xyz[3 * p + 1], cz = xyz[3 * p + 2];
+    const float nx = xyz[3 * q], ny = xyz[3 * q + 1], nz = xyz[3 * q + 2];
+    const float rx = cx - nx, ry = cy - ny, rz = cz - nz;
+    float* o = out + t * 10;
+    o[0] = __fsqrt_rn(rx * rx + ry * ry + rz * rz);
+    o[1] = rx; o[2] = ry; o[3] = rz;
+    o[4] = cx; o[5] = cy; o[6] = cz;
+    o[7] = nx; o[8] = ny; o[9] = nz;
+}
+
+// out[row, ch] = max_k feature[batch*N + pool_idx[row,k], ch]   (RandLANet.py:345-360)
+__global__ __launch_bounds__(256) void pool_max_scalar_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx, float* __restrict__ out,
+                                                              size_t rows, int m_cloud, int n_cloud, int K, int d)
+{
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= rows * d) return;
+    const size_t row = t / d;
+    const int ch = (int)(t - row * d);
+    const size_t base = (row / m_cloud) * n_cloud;
+    const int32_t* ix = idx + row * K;
+    float m = feat[(base + ix[0]) * d + ch];
+    for (int k = 1; k < K; ++k) m = fmaxf(m, feat[(base + ix[k]) * d + ch]);
+    out[t] = m;
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ W, int cin, int cout, int ntb, int ks, int cblocks, float* __restrict__ out)
+{
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t total = (size_t)cblocks * ks * 64 * ntb;
+    if (t >= total) return;
+    const int j = (int)(t % ntb);
+    const int l = (int)((t / ntb) % 64);
+    const int s = (int)((t / ntb / 64) % ks);
+    const int cb = (int)(t / ntb / 64 / ks);
+    const int k = s * 4 + (l >> 4), col = (cb * ntb + j) * 16 + (l & 15);
+    out[t] = (k < cin && col < cout) ? W[(size_t)k * cout + col] : 0.f;
+}
+
+// agg[r, col] = sum_k fset[r,k,col] * softmax_k( (fset[r] . wfc)[k, col] )    (RandLANet.py:394-398)
+template <int KMAX>
+__global__ __launch_bounds__(256) void att_pool_op_kernel(const float* __restrict__ fset, const float* __restrict__ wfc, float* __restrict__ agg,
+                                                          int R, int K, int d)
+{
+    extern __shared__ float tile[];  // [K][d]
+    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < K * d; e += blockDim.x) tile[e] = fset[(size_t)r * K * d + e];
+        __syncthreads();
+        for (int col = threadIdx.x; col < d; col += blockDim.x) {
+            float s[KMAX];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) s[k] = 0.f;
+            for (int j = 0; j < d; ++j) {
+                const float w = wfc[(size_t)j * d + col];
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < K) s[k] = fmaf(tile[k * d + j], w, s[k]);
+            }
+            float m = s[0];
+#pragma unroll
+            for (int k = 1; k < KMAX; ++k)
+                if (k < K) m = fmaxf(m, s[k]);
+            float den = 0.f, num = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) {
+                    const float e = expf(s[k] - m);
+                    den += e;
+                    num += e * tile[k * d + col];
+                }
+            agg[(size_t)r * d + col] = num / den;
+        }
+    }
+}
+
+}  // namespace ps
+
+using namespace ps;
+
+extern "C" int ps_op_gather_neighbour(ps_context* c, const float* pc, const int32_t* idx, int64_t B, int64_t N, int64_t M, int64_t K, int64_t d,
+                                      float* out)
+{
+    PS_CHECK(c && pc && idx && out, "ps_op_gather_neighbour: NULL argument");
+    PS_CHECK(B >= 0 && N >= 1 && M >= 0 && K >= 1 && d >= 1, "ps_op_gather_neighbour: bad shape");
+    const size_t rows = (size_t)B * M * K;
+    if (!rows) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "op_gather_neighbour", 1);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div(rows * d, 256)), dim3(256), 0, c->stream, pc, idx, out, rows, (int)(M * K), (int)N, (int)d);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+extern "C" int ps_op_relative_pos_encoding(ps_context* c, const float* xyz, const int32_t* idx, int64_t B, int64_t N, int64_t K, float* out)
+{
+    PS_CHECK(c && xyz && idx && out, "ps_op_relative_pos_encoding: NULL argument");
+    const size_t total = (size_t)B * N * K;
+    if (!total) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "op_relative_pos_encoding", 1);
+    hipLaunchKernelGGL(relpos_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, c->stream, xyz, idx, out, total, (int)N, (int)K);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+extern "C" int ps_op_random_sample(ps_context* c, const float* feature, const int32_t* pool_idx, int64_t B, int64_t N, int64_t M, int64_t K,
+                                   int64_t d, float* out)
+{
+    PS_CHECK(c && feature && pool_idx && out, "ps_op_random_sample: NULL argument");
+    const size_t rows = (size_t)B * M;
+    if (!rows) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "op_random_sample", 1);
+    hipLaunchKernelGGL(pool_max_scalar_kernel, dim3(ceil_div(rows * d, 256)), dim3(256), 0, c->stream, feature, pool_idx, out, rows, (int)M, (int)N,
+                       (int)K, (int)d);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+extern "C" int ps_op_nearest_interpolation(ps_context* c, const float* feature, const int32_t* interp_idx, int64_t B, int64_t N, int64_t M, int64_t d,
+                                           float* out)
+{
+    PS_CHECK(c && feature && interp_idx && out, "ps_op_nearest_interpolation: NULL argument");
+    const size_t rows = (size_t)B * M;
+    if (!rows) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "op_nearest_interpolation", 1);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div(rows * d, 256)), dim3(256), 0, c->stream, feature, interp_idx, out, rows, (int)M, (int)N,
+                       (int)d);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+extern "C" int ps_op_conv1x1(ps_context* c, const float* x, const float* w, const float* b, int64_t R, int64_t cin, int64_t cout, int leaky, float* y)
+{
+    PS_CHECK(c && x && w && y, "ps_op_conv1x1: NULL argument");
+    PS_CHECK(R >= 0 && cin >= 1 && cout >= 1, "ps_op_conv1x1: bad shape");
+    if (!R) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    PackedLinear L;
+    L.cin = (int)cin; L.cout = (int)cout; L.leaky = leaky;
+    L.ks = (L.cin + 3) / 4;
+    L.ntb = choose_ntb(L.cout);
+    L.cblocks = (L.cout + 16 * L.ntb - 1) / (16 * L.ntb);
+    PS_TRY(c->ops_ws.reserve(L.packed_floats() * sizeof(float)));
+    Stage st(c, "op_conv1x1", 2);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(ceil_div(L.packed_floats(), 256)), dim3(256), 0, c->stream, w, L.cin, L.cout, L.ntb, L.ks, L.cblocks,
+                       c->ops_ws.as<float>());
+    PS_HIP(hipGetLastError());
+    L.wp = c->ops_ws.as<float>();
+    L.bias = b;
+    RowSrc s1, none;
+    s1.x = x; s1.ld = L.cin; s1.c = L.cin;
+    return rowgemm(c, L, s1, none, R, y, L.cout);
+}
+
+extern "C" int ps_op_att_pool(ps_context* c, const float* fset, const float* wfc, int64_t R, int64_t K, int64_t d, float* agg)
+{
+    PS_CHECK(c && fset && wfc && agg, "ps_op_att_pool: NULL argument");
+    PS_CHECK(K >= 1 && K <= 32 && d >= 1, "ps_op_att_pool: K must be in 1..32");
+    if (!R) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    const size_t smem = (size_t)K * d * sizeof(float);
+    PS_CHECK(smem <= 160 * 1024, "ps_op_att_pool: K*d too large for the LDS");
+    Stage st(c, "op_att_pool", 1);
+    const int blocks = (int)std::min<int64_t>(R, 256 * 8);
+    if (K <= 16) {
+        auto kern = att_pool_op_kernel<16>;
+        if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, c->stream, fset, wfc, agg, (int)R, (int)K, (int)d);
+    } else {
+        auto kern = att_pool_op_kernel<32>;
+        if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, c->stream, fset, wfc, agg, (int)R, (int)K, (int)d);
+    }
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}

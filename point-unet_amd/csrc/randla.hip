@@ -1,0 +1,394 @@
+// randla.hip -- RandLA-Net inference forward (ps_randla_*): the device form of Network.inference
+// (PointSegment/RandLANet.py:110-152) and the blocks it calls (:314-401), inference-mode BatchNorm folded.
+//
+// Launch plan per encoder level (rows R = B*N_i, h = d/2):
+//   rowgemm  mlp1            X[R,d_in]            -> FG1[:, 0:h]          (RandLANet.py:315)
+//   rowgemm  Wfc1[:h,:]      FG1[:, 0:h]          -> FG1[:, h:h+d]        (score pre-product, see attpool.hip)
+//   att<1>   LocSE+gather+att-pool 1              -> AGG[R,d]             (:325-329, :337-343, :394-398)
+//   rowgemm  att_pooling_1 mlp  AGG               -> FG2[:, 0:h]          (:400)
+//   rowgemm  Wfc2[:h,:]      FG2[:, 0:h]          -> FG2[:, h:h+d]
+//   att<2>   LocSE+mlp2+gather+att-pool 2         -> AGG[R,d]             (:331-334)
+//   rowgemm  att_pooling_2 mlp  AGG               -> TMP[R,d]             (:400)
+//   rowgemm  [mlp2 ; shortcut] [TMP | X]          -> ENC_i[R,2d]  (+LeakyReLU)   (:317-321)
+//   pool_max random_sample                        -> POOL_i[B*N_{i+1},2d] (:345-360)
+// decoder: rowgemm decoder_0 (:130-132); per level rowgemm over [skip | up[interp_idx]] (:137-141);
+// head: rowgemm fc1, fc2, fc (:146-151; dropout is the identity in inference).
+#include "attpool.h"
+#include "common.h"
+#include "rowgemm.h"
+
+#include <memory>
+
+namespace ps {
+
+// ---- random_sample: out[b,m,:] = max_k feature[b, pool_idx[b,m,k], :]  (RandLANet.py:345-360) ----------------
+__global__ __launch_bounds__(256) void pool_max_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx, float* __restrict__ out,
+                                                       int rows_out, int m_cloud, int n_cloud, int K, int c4 /* channels / 4 */)
+{
+    // one thread per (output row, float4 of channels)
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= (size_t)rows_out * c4) return;
+    const int row = (int)(t / c4), q = (int)(t - (size_t)row * c4);
+    const int base = (row / m_cloud) * n_cloud;
+    const int32_t* ix = idx + (size_t)row * K;
+    const float4* f4 = reinterpret_cast<const float4*>(feat);
+    float4 m = f4[(size_t)(base + ix[0]) * c4 + q];
+    for (int k = 1; k < K; ++k) {
+        const float4 v = f4[(size_t)(base + ix[k]) * c4 + q];
+        m.x = fmaxf(m.x, v.x);
+        m.y = fmaxf(m.y, v.y);
+        m.z = fmaxf(m.z, v.z);
+        m.w = fmaxf(m.w, v.w);
+    }
+    reinterpret_cast<float4*>(out)[t] = m;
+}
+
+int pool_max(ps_context* c, const float* feat, const int32_t* idx, float* out, int64_t B, int64_t n, int64_t m, int K, int ch)
+{
+    PS_CHECK(ch % 4 == 0, "pool_max: channel count %d is not a multiple of 4", ch);
+    const size_t tot = (size_t)B * m * (ch / 4);
+    if (!tot) return PS_OK;
+    hipLaunchKernelGGL(pool_max_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, c->stream, feat, idx, out, (int)(B * m), (int)m, (int)n, K, ch / 4);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+struct LayerSpec {
+    int cin, cout, leaky;
+    size_t w_off, b_off;  // offsets into the host blob (floats)
+};
+
+struct EncLevel {
+    PackedLinear mlp1, top1, lfa1, bot1, att1mlp, lfa2, top2, bot2, att2mlp, mlp2sc;
+    int d_in, d;
+};
+
+}  // namespace ps
+
+using namespace ps;
+
+struct ps_randla {
+    ps_context* ctx = nullptr;
+    ps_randla_config cfg;
+    std::vector<LayerSpec> specs;  // blob order
+    int64_t blob_floats = 0;
+    bool have_weights = false;
+    DevBuf wbuf;
+    PackedLinear fc0, decoder0, fc1, fc2, fc;
+    std::vector<EncLevel> enc;
+    std::vector<PackedLinear> dec;
+    // taps of the last forward (device pointers into ctx->net_arena) and their sizes
+    struct Tap { int which; const float* p; int64_t count; };
+    std::vector<Tap> taps;
+};
+
+namespace {
+
+// blob order: fc0; per level {mlp1, lfa1, att1_fc, att1_mlp, lfa2, att2_fc, att2_mlp, mlp2, shortcut};
+// decoder_0; Decoder_layer_j (rows = [skip | interp] input channels); fc1; fc2; fc.  Each entry: W[cin,cout] then b[cout].
+void plan_specs(ps_randla* net)
+{
+    const ps_randla_config& c = net->cfg;
+    auto add = [&](int cin, int cout, int leaky) {
+        LayerSpec s{cin, cout, leaky, (size_t)net->blob_floats, 0};
+        net->blob_floats += (int64_t)cin * cout;
+        s.b_off = (size_t)net->blob_floats;
+        net->blob_floats += cout;
+        net->specs.push_back(s);
+    };
+    net->specs.clear();
+    net->blob_floats = 0;
+    add(c.in_channels, 8, 1);
+    int d_in = 8;
+    for (int i = 0; i < c.num_layers; ++i) {
+        const int d = c.d_out[i], h = d / 2;
+        add(d_in, h, 1);   // mlp1
+        add(10, h, 1);     // LFA mlp1
+        add(d, d, 0);      // att_pooling_1 fc (bias slot = zeros)
+        add(d, h, 1);      // att_pooling_1 mlp
+        add(h, h, 1);      // LFA mlp2
+        add(d, d, 0);      // att_pooling_2 fc
+        add(d, d, 1);      // att_pooling_2 mlp
+        add(d, 2 * d, 0);  // mlp2 (no activation)
+        add(d_in, 2 * d, 0);  // shortcut (no activation)
+        d_in = 2 * d;
+    }
+    add(d_in, d_in, 1);  // decoder_0
+    // skip channels per decoder step j: f_encoder_list[-j-2]
+    std::vector<int> chans;  // [enc0, pool0, ..., pool_{L-1}]
+    chans.push_back(2 * c.d_out[0]);
+    for (int i = 0; i < c.num_layers; ++i) chans.push_back(2 * c.d_out[i]);
+    int up = d_in;
+    for (int j = 0; j < c.num_layers; ++j) {
+        const int skip = chans[chans.size() - 2 - j];
+        add(skip + up, skip, 1);
+        up = skip;
+    }
+    add(up, 64, 1);
+    add(64, 32, 1);
+    add(32, c.num_classes, 0);
+}
+
+}  // namespace
+
+extern "C" int ps_randla_create(ps_context* ctx, const ps_randla_config* cfg, ps_randla** out)
+{
+    PS_CHECK(ctx && cfg && out, "ps_randla_create: NULL argument");
+    PS_CHECK(cfg->num_layers >= 1 && cfg->num_layers <= PS_MAX_LAYERS, "ps_randla_create: num_layers %d out of range", cfg->num_layers);
+    PS_CHECK(cfg->k_n == 16 || cfg->k_n == 32, "ps_randla_create: k_n must be 16 or 32 (got %d)", cfg->k_n);
+    PS_CHECK(cfg->num_classes >= 1 && cfg->in_channels >= 1, "ps_randla_create: bad channel counts");
+    for (int i = 0; i < cfg->num_layers; ++i) {
+        const int d = cfg->d_out[i];
+        PS_CHECK(d == 16 || d == 32 || d == 64 || d == 128 || d == 256 || d == 512, "ps_randla_create: d_out[%d]=%d unsupported", i, d);
+    }
+    ps_randla* net = new ps_randla();
+    net->ctx = ctx;
+    net->cfg = *cfg;
+    plan_specs(net);
+    *out = net;
+    return PS_OK;
+}
+
+extern "C" int ps_randla_destroy(ps_randla* net)
+{
+    if (!net) return PS_OK;
+    (void)hipSetDevice(net->ctx->device);
+    (void)hipStreamSynchronize(net->ctx->stream);
+    net->wbuf.release();
+    delete net;
+    return PS_OK;
+}
+
+extern "C" int64_t ps_randla_weight_count(const ps_randla* net) { return net ? net->blob_floats : -1; }
+
+extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t count)
+{
+    PS_CHECK(net && blob, "ps_randla_set_weights: NULL argument");
+    PS_CHECK(count == net->blob_floats, "ps_randla_set_weights: blob has %lld floats, expected %lld", (long long)count, (long long)net->blob_floats);
+    ps_context* c = net->ctx;
+    PS_HIP(hipSetDevice(c->device));
+    std::vector<float> host;  // packed image of everything, then one upload
+    struct Pending { PackedLinear* L; size_t wp_off, b_off; };
+    std::vector<Pending> pend;
+    auto emit = [&](PackedLinear& L, const float* W, const float* b, int cin, int cout, int leaky) {
+        L = PackedLinear();
+        L.cin = cin; L.cout = cout; L.leaky = leaky;
+        L.ks = (cin + 3) / 4;
+        L.ntb = choose_ntb(cout);
+        L.cblocks = (cout + 16 * L.ntb - 1) / (16 * L.ntb);
+        size_t off = (host.size() + 63) & ~size_t(63);
+        host.resize(off + L.packed_floats());
+        pack_weights(W, cin, cout, L.ntb, host.data() + off);
+        size_t boff = (host.size() + 63) & ~size_t(63);
+        host.resize(boff + (size_t)L.cout_pad());
+        for (int i = 0; i < L.cout_pad(); ++i) host[boff + i] = (b && i < cout) ? b[i] : 0.f;
+        pend.push_back({&L, off, boff});
+    };
+    size_t si = 0;
+    auto W = [&](size_t i) { return blob + net->specs[i].w_off; };
+    auto Bv = [&](size_t i) { return blob + net->specs[i].b_off; };
+    const ps_randla_config& cfg = net->cfg;
+    emit(net->fc0, W(si), Bv(si), cfg.in_channels, 8, 1);
+    ++si;
+    net->enc.assign(cfg.num_layers, EncLevel());
+    int d_in = 8;
+    std::vector<float> tmp;
+    for (int i = 0; i < cfg.num_layers; ++i) {
+        EncLevel& e = net->enc[i];
+        const int d = cfg.d_out[i], h = d / 2;
+        e.d = d; e.d_in = d_in;
+        emit(e.mlp1, W(si), Bv(si), d_in, h, 1); ++si;
+        emit(e.lfa1, W(si), Bv(si), 10, h, 1); ++si;
+        emit(e.top1, W(si), nullptr, h, d, 0);                      // Wfc1[:h, :]
+        emit(e.bot1, W(si) + (size_t)h * d, nullptr, h, d, 0);      // Wfc1[h:, :]
+        ++si;
+        emit(e.att1mlp, W(si), Bv(si), d, h, 1); ++si;
+        emit(e.lfa2, W(si), Bv(si), h, h, 1); ++si;
+        emit(e.top2, W(si), nullptr, h, d, 0);
+        emit(e.bot2, W(si) + (size_t)h * d, nullptr, h, d, 0);
+        ++si;
+        emit(e.att2mlp, W(si), Bv(si), d, d, 1); ++si;
+        // [mlp2 ; shortcut] over the concatenated K axis, biases summed, LeakyReLU on the sum (RandLANet.py:317-321)
+        tmp.assign((size_t)(d + d_in) * 2 * d + 2 * d, 0.f);
+        std::memcpy(tmp.data(), W(si), sizeof(float) * (size_t)d * 2 * d);
+        std::memcpy(tmp.data() + (size_t)d * 2 * d, W(si + 1), sizeof(float) * (size_t)d_in * 2 * d);
+        float* bsum = tmp.data() + (size_t)(d + d_in) * 2 * d;
+        for (int k = 0; k < 2 * d; ++k) bsum[k] = Bv(si)[k] + Bv(si + 1)[k];
+        emit(e.mlp2sc, tmp.data(), bsum, d + d_in, 2 * d, 1);
+        si += 2;
+        d_in = 2 * d;
+    }
+    emit(net->decoder0, W(si), Bv(si), d_in, d_in, 1); ++si;
+    net->dec.assign(cfg.num_layers, PackedLinear());
+    for (int j = 0; j < cfg.num_layers; ++j) {
+        emit(net->dec[j], W(si), Bv(si), net->specs[si].cin, net->specs[si].cout, 1);
+        ++si;
+    }
+    emit(net->fc1, W(si), Bv(si), net->specs[si].cin, 64, 1); ++si;
+    emit(net->fc2, W(si), Bv(si), 64, 32, 1); ++si;
+    emit(net->fc, W(si), Bv(si), 32, cfg.num_classes, 0); ++si;
+
+    PS_TRY(net->wbuf.reserve(host.size() * sizeof(float)));
+    PS_HIP(hipMemcpyAsync(net->wbuf.p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    PS_HIP(hipStreamSynchronize(c->stream));
+    for (auto& p : pend) {
+        p.L->wp = net->wbuf.as<float>() + p.wp_off;
+        p.L->bias = net->wbuf.as<float>() + p.b_off;
+    }
+    net->have_weights = true;
+    return PS_OK;
+}
+
+extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const float* features, float* logits)
+{
+    PS_CHECK(net && pyr && features && logits, "ps_randla_forward: NULL argument");
+    if (!net->have_weights) {
+        set_error("ps_randla_forward: weights not set");
+        return PS_ESTATE;
+    }
+    ps_context* c = net->ctx;
+    const ps_randla_config& cfg = net->cfg;
+    const int L = cfg.num_layers;
+    PS_CHECK(pyr->num_layers == L && pyr->K == cfg.k_n, "ps_randla_forward: pyramid (layers %d, K %d) does not match the network (%d, %d)",
+             pyr->num_layers, pyr->K, L, cfg.k_n);
+    PS_HIP(hipSetDevice(c->device));
+    const int64_t B = pyr->B;
+    const int64_t* n = pyr->n;
+
+    // ---- carve activations ----
+    Arena& A = c->net_arena;
+    float *fc0 = nullptr, *fg = nullptr, *agg = nullptr, *tmp = nullptr, *dec0 = nullptr, *h1 = nullptr, *h2 = nullptr;
+    std::vector<float*> encb(L), poolb(L), decb(L);
+    for (int pass = 0; pass < 2; ++pass) {
+        A.begin(pass == 0);
+        fc0 = A.take<float>((size_t)B * n[0] * 8);
+        size_t fg_max = 0, agg_max = 0;
+        for (int i = 0; i < L; ++i) {
+            const int d = cfg.d_out[i];
+            fg_max = std::max(fg_max, (size_t)B * n[i] * (d / 2 + d));
+            agg_max = std::max(agg_max, (size_t)B * n[i] * d);
+            encb[i] = A.take<float>((size_t)B * n[i] * 2 * d);
+            poolb[i] = A.take<float>((size_t)B * n[i + 1] * 2 * d);
+        }
+        fg = A.take<float>(fg_max);
+        agg = A.take<float>(agg_max);
+        tmp = A.take<float>(agg_max);
+        dec0 = A.take<float>((size_t)B * n[L] * 2 * cfg.d_out[L - 1]);
+        for (int j = 0; j < L; ++j) decb[j] = A.take<float>((size_t)B * n[L - 1 - j] * net->dec[j].cout);
+        h1 = A.take<float>((size_t)B * n[0] * 64);
+        h2 = A.take<float>((size_t)B * n[0] * 32);
+        if (pass == 0) PS_TRY(A.buf.reserve(A.off));
+    }
+    net->taps.clear();
+    auto tap = [&](int which, const float* p, int64_t count) { net->taps.push_back({which, p, count}); };
+
+    const RowSrc none;
+    auto src = [](const float* x, int ld, int ch) {
+        RowSrc s;
+        s.x = x; s.ld = ld; s.c = ch;
+        return s;
+    };
+
+    {
+        Stage st(c, "fc0", 1);
+        PS_TRY(rowgemm(c, net->fc0, src(features, cfg.in_channels, cfg.in_channels), none, B * n[0], fc0, 8));
+    }
+    tap(0, fc0, B * n[0] * 8);
+
+    const float* X = fc0;
+    int d_in = 8;
+    for (int i = 0; i < L; ++i) {
+        const EncLevel& e = net->enc[i];
+        const int d = e.d, h = d / 2, ldf = h + d;
+        const int64_t R = B * n[i];
+        char nm[48];
+        AttStage s;
+        s.xyz = pyr->xyz[i]; s.idx = pyr->neigh_idx[i]; s.fg = fg; s.lfa1 = &e.lfa1; s.agg = agg;
+        s.n_total = R; s.n_cloud = n[i]; s.d = d; s.k = cfg.k_n;
+        {
+            std::snprintf(nm, sizeof nm, "enc%d_dense", i);
+            Stage st(c, nm, 2);
+            PS_TRY(rowgemm(c, e.mlp1, src(X, d_in, d_in), none, R, fg, ldf));
+            PS_TRY(rowgemm(c, e.top1, src(fg, ldf, h), none, R, fg + h, ldf));
+        }
+        {
+            std::snprintf(nm, sizeof nm, "enc%d_att1", i);
+            Stage st(c, nm, 1);
+            s.lfa2 = nullptr; s.wbot = &e.bot1;
+            PS_TRY(att_pool_stage(c, s));
+        }
+        {
+            std::snprintf(nm, sizeof nm, "enc%d_dense", i);
+            Stage st(c, nm, 2);
+            PS_TRY(rowgemm(c, e.att1mlp, src(agg, d, d), none, R, fg, ldf));
+            PS_TRY(rowgemm(c, e.top2, src(fg, ldf, h), none, R, fg + h, ldf));
+        }
+        {
+            std::snprintf(nm, sizeof nm, "enc%d_att2", i);
+            Stage st(c, nm, 1);
+            s.lfa2 = &e.lfa2; s.wbot = &e.bot2;
+            PS_TRY(att_pool_stage(c, s));
+        }
+        {
+            std::snprintf(nm, sizeof nm, "enc%d_dense", i);
+            Stage st(c, nm, 2);
+            PS_TRY(rowgemm(c, e.att2mlp, src(agg, d, d), none, R, tmp, d));
+            PS_TRY(rowgemm(c, e.mlp2sc, src(tmp, d, d), src(X, d_in, d_in), R, encb[i], 2 * d));
+        }
+        {
+            std::snprintf(nm, sizeof nm, "enc%d_pool", i);
+            Stage st(c, nm, 1);
+            PS_TRY(pool_max(c, encb[i], pyr->sub_idx[i], poolb[i], B, n[i], n[i + 1], cfg.k_n, 2 * d));
+        }
+        tap(10 + i, encb[i], R * 2 * d);
+        tap(20 + i, poolb[i], B * n[i + 1] * 2 * d);
+        X = poolb[i];
+        d_in = 2 * d;
+    }
+
+    {
+        Stage st(c, "decoder_0", 1);
+        PS_TRY(rowgemm(c, net->decoder0, src(X, d_in, d_in), none, B * n[L], dec0, d_in));
+    }
+    tap(30, dec0, B * n[L] * d_in);
+
+    const float* up = dec0;
+    int up_c = d_in;
+    for (int j = 0; j < L; ++j) {
+        const int lvl = L - 1 - j;  // output lives on level `lvl` points
+        const float* skip = lvl == 0 ? encb[0] : poolb[lvl - 1];
+        const int skip_c = net->dec[j].cout;
+        RowSrc s2 = src(up, up_c, up_c);
+        s2.gather = pyr->interp_idx[lvl];
+        s2.gm = (int)n[lvl];
+        s2.gn = (int)n[lvl + 1];
+        char nm[48];
+        std::snprintf(nm, sizeof nm, "dec%d", j);
+        Stage st(c, nm, 1);
+        PS_TRY(rowgemm(c, net->dec[j], src(skip, skip_c, skip_c), s2, B * n[lvl], decb[j], skip_c));
+        tap(40 + j, decb[j], B * n[lvl] * skip_c);
+        up = decb[j];
+        up_c = skip_c;
+    }
+    {
+        Stage st(c, "head", 3);
+        PS_TRY(rowgemm(c, net->fc1, src(up, up_c, up_c), none, B * n[0], h1, 64));
+        PS_TRY(rowgemm(c, net->fc2, src(h1, 64, 64), none, B * n[0], h2, 32));
+        PS_TRY(rowgemm(c, net->fc, src(h2, 32, 32), none, B * n[0], logits, cfg.num_classes));
+    }
+    return PS_OK;
+}
+
+extern "C" int ps_randla_tap(ps_randla* net, int which, float* host_out, int64_t count)
+{
+    PS_CHECK(net && host_out, "ps_randla_tap: NULL argument");
+    for (auto& t : net->taps)
+        if (t.which == which) {
+            PS_CHECK(t.count == count, "ps_randla_tap: tensor %d has %lld floats, caller expects %lld", which, (long long)t.count, (long long)count);
+            PS_HIP(hipMemcpyAsync(host_out, t.p, sizeof(float) * (size_t)count, hipMemcpyDeviceToHost, net->ctx->stream));
+            PS_HIP(hipStreamSynchronize(net->ctx->stream));
+            return PS_OK;
+        }
+    set_error("ps_randla_tap: no tensor %d (run a forward first)", which);
+    return PS_EINVAL;
+}

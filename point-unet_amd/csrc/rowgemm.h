@@ -1,0 +1,47 @@
+// rowgemm.h -- per-point dense layer  Y = act([X1[g1] | X2[g2]] . W + b)  on fp32 MFMA (v_mfma_f32_16x16x4_f32).
+//
+// This is the device form of every 1x1 conv / dense layer of the reference graph applied to [B,N,1,C] tensors:
+// helper_tf_util.conv2d (PointSegment/helper_tf_util.py:115-170), conv2d_transpose (:173-250) and
+// tf.layers.dense (PointSegment/RandLANet.py:114), with inference-mode BatchNorm folded into W and b on the
+// host.  Two row sources with optional gather indices cover
+//   * tf.concat([skip, nearest_interpolation(feature, interp_idx)]) -> conv2d_transpose (RandLANet.py:137-141)
+//   * mlp2(f_pc) + shortcut(feature) as one GEMM over the concatenated K axis       (RandLANet.py:317-321)
+// without materialising the concatenation.
+#pragma once
+
+#include "common.h"
+
+namespace ps {
+
+// Weights packed on the host into MFMA B-fragment order (see pack_weights() in rowgemm.hip):
+//   for column block cb (NTB*16 output channels), k-step s (4 input channels), lane l, tile j:
+//     wp[((cb*KS + s)*64 + l)*NTB + j] = W[s*4 + (l>>4)][(cb*NTB + j)*16 + (l&15)]      (0 outside W)
+struct PackedLinear {
+    const float* wp = nullptr;  // device
+    const float* bias = nullptr;  // device [cout_pad] (zeros when the layer has no bias)
+    int cin = 0, cout = 0;
+    int ks = 0;       // k-steps = ceil(cin/4)
+    int ntb = 0;      // 1, 2 or 4
+    int cblocks = 0;  // ceil(cout / (16*ntb))
+    int leaky = 0;
+    size_t packed_floats() const { return (size_t)cblocks * ks * 64 * ntb; }
+    int cout_pad() const { return cblocks * ntb * 16; }
+};
+
+inline int choose_ntb(int cout) { return cout >= 64 ? 4 : (cout >= 32 ? 2 : 1); }
+
+// Host-side packing: W is row-major [cin, cout]; out must hold packed_floats() floats.
+void pack_weights(const float* W, int cin, int cout, int ntb, float* out);
+
+struct RowSrc {
+    const float* x = nullptr;
+    const int32_t* gather = nullptr;  // row r reads x[gather[r]] when non-null
+    int ld = 0;                       // row stride in floats
+    int c = 0;                        // channels taken from this source
+    int gm = 0, gn = 0;               // batched gather: row r reads x[(r / gm) * gn + gather[r]] when gm != 0
+};
+
+// y[r, 0:cout] (row stride ldy) for r in [0, R)
+int rowgemm(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc& s2, int64_t R, float* y, int ldy);
+
+}  // namespace ps

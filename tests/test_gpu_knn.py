@@ -1,0 +1,113 @@
+"""GPU parity of the KNN op and the index pyramid: HIP kernels (through the C ABI) vs the CPU oracle.
+Bar: bit-exact indices, including the order among equal distances."""
+import numpy as np
+import pytest
+
+from conftest import brats_cloud, uniform_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def _knn_gpu(s, q, K):
+    from point_unet_amd.utils.nearest_neighbors.lib.python import nearest_neighbors as nn
+    return nn.knn_batch(s, q, K, omp=True)
+
+
+@pytest.mark.parametrize("K", [1, 16, 32])
+@pytest.mark.parametrize("kind", ["uniform", "lattice"])
+def test_self_knn_bit_exact(oracle, kind, K):
+    p = uniform_cloud(18000, 3) if kind == "uniform" else brats_cloud(18000, 3, grid=(60, 60, 40))
+    got = _knn_gpu(p[None], p[None], K)
+    want = oracle.knn_batch(p[None], p[None], K)
+    assert got.dtype == np.int64 and got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_upsampling_queries_outside_support_bbox(oracle):
+    p = brats_cloud(20000, 5, grid=(64, 64, 48))
+    sub = p[:5000]
+    assert np.array_equal(_knn_gpu(sub[None], p[None], 1), oracle.knn_batch(sub[None], p[None], 1))
+
+
+def test_fewer_points_than_k_and_tiny_clouds(oracle):
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 7, 10, 11, 12, 33):
+        p = rng.random((n, 3), dtype=np.float32)
+        for K in (1, 5, 16):
+            got = _knn_gpu(p[None], p[None], K)
+            assert np.array_equal(got, oracle.knn_batch(p[None], p[None], K)), (n, K)
+
+
+def test_duplicate_points(oracle):
+    rng = np.random.default_rng(1)
+    d = np.repeat(rng.random((60, 3), dtype=np.float32), 50, axis=0)
+    rng.shuffle(d)
+    assert np.array_equal(_knn_gpu(d[None], d[None], 16), oracle.knn_batch(d[None], d[None], 16))
+
+
+def test_batched_clouds(oracle):
+    rng = np.random.default_rng(2)
+    s = rng.random((3, 4000, 3), dtype=np.float32)
+    q = rng.random((3, 1500, 3), dtype=np.float32) * 1.4 - 0.2
+    assert np.array_equal(_knn_gpu(s, q, 16), oracle.knn_batch(s, q, 16))
+
+
+def test_knn_search_facade_dtype(oracle):
+    from point_unet_amd.helper_tool import DataProcessing as DP
+    p = uniform_cloud(3000, 9)
+    idx = DP.knn_search(p[None], p[None], 16)
+    assert idx.dtype == np.int32 and idx.shape == (1, 3000, 16)
+    assert np.array_equal(idx, oracle.knn_batch(p[None], p[None], 16).astype(np.int32))
+
+
+def test_golden_fixtures(oracle):
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "knn_*.npz")))
+    assert files, "golden KNN fixtures are missing"
+    for f in files:
+        g = np.load(f)
+        got = _knn_gpu(g["support"], g["queries"], int(g["K"]))
+        assert np.array_equal(got, g["idx"]), f
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_pyramid_matches_reference_loop(oracle, B):
+    import torch
+    from oracle import randla_oracle as ro
+    from point_unet_amd.helper_tool import ConfigBraTS
+    from point_unet_amd.pyramid import build_pyramid
+
+    class Cfg(ConfigBraTS):
+        num_layers = 3
+        sub_sampling_ratio = [4, 4, 2]
+
+    xyz = np.stack([brats_cloud(12000, 10 + b, grid=(50, 50, 40)) for b in range(B)])
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), Cfg)
+    torch.cuda.synchronize()
+    pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: oracle.knn_batch(s, q, k), xyz, Cfg.k_n, Cfg.sub_sampling_ratio)
+    for i in range(3):
+        assert np.array_equal(pyr.xyz[i].cpu().numpy(), pts[i])
+        assert np.array_equal(pyr.neigh_idx[i].cpu().numpy(), nbr[i]), i
+        assert np.array_equal(pyr.sub_idx[i].cpu().numpy(), pool[i]), i
+        assert np.array_equal(pyr.interp_idx[i].cpu().numpy(), up[i]), i
+
+
+def test_full_size_properties():
+    """180 000-point BraTS-shaped cloud, K=16 (BASELINE config 2): size-independent properties --
+    self is its own nearest neighbour at distance 0, rows sorted by distance, indices in range, and the
+    distance multiset equals a brute-force check on sampled rows."""
+    p = brats_cloud(180000, 0)
+    idx = _knn_gpu(p[None], p[None], 16)[0]
+    assert idx.min() >= 0 and idx.max() < len(p)
+    d = ((p[:, None, :] - p[idx]) ** 2).sum(-1)
+    assert np.all(d[:, 0] == 0)
+    assert np.all(np.diff(d, axis=1) >= 0)
+    rows = np.random.default_rng(0).choice(len(p), 200, replace=False)
+    for r in rows:
+        # same fp32 expression as the metric: ((dx*dx)+dy*dy)+dz*dz
+        diff = p[r] - p
+        bf = np.sort((diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2])[:16]
+        dr = p[r] - p[idx[r]]
+        mine = (dr[:, 0] * dr[:, 0] + dr[:, 1] * dr[:, 1]) + dr[:, 2] * dr[:, 2]
+        assert np.array_equal(bf, mine), r

@@ -1,0 +1,116 @@
+"""GPU parity of the RandLA-Net forward: fused HIP path (through the C ABI) vs the float64 NumPy restatement
+of the reference graph (oracle/randla_oracle.py).  Tolerance: |logit diff| <= 1e-4 (BASELINE.json north_star:
+"segmentation logits within 1e-4 fp32")."""
+import numpy as np
+import pytest
+
+import netcase
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _run_case(oracle, cfg, xyz, feats, seed=2, taps=True):
+    import torch
+    from oracle import randla_oracle as ro
+    from point_unet_amd import weights
+    from point_unet_amd.RandLANet import Network
+    from point_unet_amd.pyramid import build_pyramid
+
+    params = weights.init_params(cfg, seed=seed, randomize_bn=True)
+    net = Network(cfg, params=params)
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    logits = net.inference({"pyramid": pyr, "features": torch.from_numpy(feats).cuda()}).cpu().numpy()
+    # oracle on the oracle's own pyramid (bit-exact equality of the two pyramids is test_gpu_knn's job)
+    pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: oracle.knn_batch(s, q, k), xyz, cfg.k_n, cfg.sub_sampling_ratio)
+    for i in range(cfg.num_layers):
+        assert np.array_equal(pyr.neigh_idx[i].cpu().numpy(), nbr[i])
+        assert np.array_equal(pyr.interp_idx[i].cpu().numpy(), up[i])
+    tap = {}
+    want = ro.inference(params, cfg.num_layers, pts, nbr, pool, up, feats, np.float64, tap=tap)
+    report = []
+    if taps:
+        B = xyz.shape[0]
+        names = [(0, "fc0")] + [(10 + i, "enc%d" % i) for i in range(cfg.num_layers)] + [(20 + i, "pool%d" % i) for i in range(cfg.num_layers)]
+        names += [(30, "decoder_0")] + [(40 + j, "dec%d" % j) for j in range(cfg.num_layers)]
+        for which, nm in names:
+            ref = tap[nm]
+            got = net.tap(which, ref.shape)
+            report.append((nm, float(np.abs(got - ref).max()), float(np.abs(ref).max())))
+    err = float(np.abs(logits - want).max())
+    return err, float(np.abs(want).max()), report
+
+
+def test_config1_18k_two_layers(oracle):
+    cfg, xyz, feats = netcase.config1()
+    err, mag, report = _run_case(oracle, cfg, xyz, feats)
+    print("max|logit| %.3f  max err %.3e" % (mag, err), report)
+    assert err <= TOL, (err, report)
+
+
+def test_all_five_widths_small_cloud(oracle):
+    cfg, xyz, feats = netcase.small_deep(6000)
+    err, mag, report = _run_case(oracle, cfg, xyz, feats)
+    print("max|logit| %.3f  max err %.3e" % (mag, err), report)
+    assert err <= TOL, (err, report)
+
+
+def test_batch_of_two_clouds(oracle):
+    cfg, xyz, feats = netcase.small_deep(4000, seed=7, B=2)
+    err, mag, report = _run_case(oracle, cfg, xyz, feats, taps=False)
+    assert err <= TOL, err
+
+
+def test_k32_pancreas_shape(oracle):
+    """BASELINE config 5 shape family: K=32, 4 input channels, 2 classes (small cloud)."""
+    cfg, xyz, feats = netcase.small_deep(4096, seed=3, k_n=32, classes=2, mods=1)
+    err, mag, report = _run_case(oracle, cfg, xyz, feats)
+    assert err <= TOL, (err, report)
+
+
+def test_forward_is_deterministic(oracle):
+    import torch
+    from point_unet_amd import weights
+    from point_unet_amd.RandLANet import Network
+    from point_unet_amd.pyramid import build_pyramid
+    cfg, xyz, feats = netcase.small_deep(5000, seed=11)
+    net = Network(cfg, params=weights.init_params(cfg, seed=5, randomize_bn=True))
+    x, f = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda()
+    a = net.inference({"pyramid": build_pyramid(x, cfg), "features": f}).cpu().numpy()
+    b = net.inference({"pyramid": build_pyramid(x, cfg), "features": f}).cpu().numpy()
+    assert np.array_equal(a, b)
+
+
+def test_full_size_config2_properties(oracle):
+    """180 000-point BraTS-shaped cloud, full 5-level network (BASELINE config 2).  The float64 oracle is too slow
+    for the whole cloud, so: (1) logits finite; (2) permutation equivariance is NOT a property of this net (prefix
+    subsampling), instead check the first 2 000 points' logits against the oracle evaluated on the sub-problem is
+    not possible either (global receptive field) -- so check (3) linear-head consistency: recompute the last three
+    dense layers on the host from the tapped dec4 activation and compare."""
+    import torch
+    from conftest import brats_cloud
+    from oracle import randla_oracle as ro
+    from point_unet_amd import weights
+    from point_unet_amd.helper_tool import ConfigBraTS
+    from point_unet_amd.RandLANet import Network
+    from point_unet_amd.pyramid import build_pyramid
+    cfg = ConfigBraTS
+    xyz = brats_cloud(180000, 0)[None]
+    feats = np.concatenate([xyz, np.random.default_rng(1).standard_normal((1, 180000, 4)).astype(np.float32)], -1)
+    params = weights.init_params(cfg, seed=2, randomize_bn=True)
+    net = Network(cfg, params=params)
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    logits = net.inference({"pyramid": pyr, "features": torch.from_numpy(feats).cuda()}).cpu().numpy()
+    assert np.isfinite(logits).all()
+    dec4 = net.tap(44, (1, 180000, 32)).astype(np.float64)
+    f = ro.conv2d(dec4, params, "fc1", np.float64)
+    f = ro.conv2d(f, params, "fc2", np.float64)
+    want = ro.conv2d(f, params, "fc", np.float64, bn=False, act=False)
+    assert np.abs(logits - want).max() <= TOL
+    # encoder level 0 against the oracle on the true pyramid (level 0 only needs neigh_idx[0])
+    nbr0 = pyr.neigh_idx[0].cpu().numpy()
+    fc0 = net.tap(0, (1, 180000, 8)).astype(np.float64)
+    sl = slice(0, 180000)
+    enc0 = ro.dilated_res_block(fc0, xyz.astype(np.float64), nbr0, params, "Encoder_layer_0", np.float64)
+    got = net.tap(10, (1, 180000, 32))
+    assert np.abs(got - enc0).max() <= TOL

@@ -1,0 +1,178 @@
+"""CPU tests of the product's host-side logic (no GPU): the kd-tree construction rules and the per-query search
+routine that the HIP kernel instantiates (run on the host through the ps_debug_* doors), the MFMA weight packing,
+and the BatchNorm folding / blob layout (checked by replaying the device's launch plan in NumPy)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import netcase
+from conftest import brats_cloud, uniform_cloud
+
+
+def _host_knn(lib, s, q, K):
+    s = np.ascontiguousarray(s, np.float32)
+    q = np.ascontiguousarray(q, np.float32)
+    out = np.zeros((s.shape[0], q.shape[1], K), np.int32)
+    rc = lib.ps_debug_knn_host(s.ctypes.data, q.ctypes.data, s.shape[0], s.shape[1], q.shape[1], K, out.ctypes.data)
+    assert rc == 0, lib.ps_last_error()
+    return out
+
+
+@pytest.mark.parametrize("K", [1, 16, 32])
+@pytest.mark.parametrize("kind", ["uniform", "lattice"])
+def test_search_routine_matches_oracle(lib, oracle, kind, K):
+    p = uniform_cloud(6000, 1) if kind == "uniform" else brats_cloud(6000, 1, grid=(40, 40, 30))
+    assert np.array_equal(_host_knn(lib, p[None], p[None], K), oracle.knn_batch(p[None], p[None], K))
+
+
+def test_search_routine_upsampling_and_small(lib, oracle):
+    p = brats_cloud(8000, 2, grid=(40, 40, 30))
+    sub = p[:2000]
+    assert np.array_equal(_host_knn(lib, sub[None], p[None], 1), oracle.knn_batch(sub[None], p[None], 1))
+    rng = np.random.default_rng(0)
+    for n in (1, 3, 10, 11, 25):
+        q = rng.random((n, 3), dtype=np.float32)
+        for K in (1, 5, 16):
+            assert np.array_equal(_host_knn(lib, q[None], q[None], K), oracle.knn_batch(q[None], q[None], K)), (n, K)
+
+
+def test_tree_layout_against_oracle_tree(lib, oracle):
+    """Same permutation, same splits, same child order as the oracle's tree, in the product's id scheme."""
+    p = brats_cloud(5000, 4, grid=(32, 32, 24))
+    n = len(p)
+    vind = np.zeros(n, np.int32)
+    nodes = np.zeros((2 * n, 4), np.int32)
+    pts = np.zeros((n, 4), np.float32)
+    rd = np.zeros(2, np.int32)
+    bbox = np.zeros(6, np.float32)
+    assert lib.ps_debug_kdtree_host(p.ctypes.data, n, vind.ctypes.data, nodes.ctypes.data, pts.ctypes.data, rd.ctypes.data,
+                                    bbox.ctypes.data) == 0
+    t = oracle.kdtree_export(p)
+    assert np.array_equal(vind, t["vind"])
+    assert np.array_equal(bbox, t["bbox"])
+    assert np.array_equal(pts[:, :3], p[vind]) and np.array_equal(pts[:, 3].view(np.int32), vind)
+
+    def walk(oid, pid, lo, hi):
+        if t["axis"][oid] < 0:
+            assert pid % 2 == 0 and pid // 2 == t["a"][oid] == lo and nodes[pid, 0] == lo and nodes[pid, 1] == t["b"][oid] == hi
+            return 1
+        assert pid % 2 == 1
+        m = (pid + 1) // 2
+        ax = (int(nodes[pid, 0]) & 0xffffffff) >> 30
+        assert ax == t["axis"][oid]
+        assert nodes[pid, 2:].view(np.float32)[0] == t["lo"][oid] and nodes[pid, 2:].view(np.float32)[1] == t["hi"][oid]
+        c1, c2 = int(nodes[pid, 0]) & 0x3fffffff, int(nodes[pid, 1])
+        return 1 + max(walk(t["a"][oid], c1, lo, m), walk(t["b"][oid], c2, m, hi))
+
+    depth = walk(0, int(rd[0]), 0, n)
+    assert depth - 1 == rd[1]
+
+
+def test_weight_packing_is_the_mfma_b_fragment_order(lib):
+    rng = np.random.default_rng(0)
+    for cin, cout, ntb in [(7, 8, 1), (10, 32, 2), (96, 128, 4), (24, 32, 2)]:
+        W = rng.standard_normal((cin, cout)).astype(np.float32)
+        ks, cb = (cin + 3) // 4, (cout + 16 * ntb - 1) // (16 * ntb)
+        out = np.zeros(cb * ks * 64 * ntb, np.float32)
+        assert lib.ps_debug_pack_weights(W.ctypes.data, cin, cout, ntb, out.ctypes.data) == 0
+        out = out.reshape(cb, ks, 64, ntb)
+        Wp = np.zeros((ks * 4, cb * ntb * 16), np.float32)
+        Wp[:cin, :cout] = W
+        for l in (0, 5, 17, 33, 63):
+            for s in range(ks):
+                for c in range(cb):
+                    for j in range(ntb):
+                        assert out[c, s, l, j] == Wp[s * 4 + (l >> 4), (c * ntb + j) * 16 + (l & 15)]
+
+
+def _replay_device_plan(cfg, blob, xyz, nbr, pool, up, feats):
+    """NumPy float64 replay of csrc/randla.hip's launch plan from the folded blob: same layer order, the
+    G = f.Wfc[:h] pre-product, [mlp2;shortcut] as one GEMM over the concatenated K axis."""
+    from oracle import randla_oracle as ro
+    from point_unet_amd import weights
+    pos = 0
+    layers = []
+    for scope, kind, cin, cout in weights.layer_dims(cfg):
+        W = blob[pos:pos + cin * cout].reshape(cin, cout).astype(np.float64)
+        pos += cin * cout
+        b = blob[pos:pos + cout].astype(np.float64)
+        pos += cout
+        layers.append((W, b))
+    assert pos == blob.size
+    it = iter(layers)
+    lrelu = ro.leaky_relu
+
+    def dense(x, Wb, act):
+        y = x @ Wb[0] + Wb[1]
+        return lrelu(y) if act else y
+
+    def att(f, G, f_xyz, Wbot):
+        scores = ro.gather_neighbour(G, idx) + f_xyz @ Wbot
+        scores = scores - scores.max(2, keepdims=True)
+        e = np.exp(scores)
+        fset = np.concatenate([ro.gather_neighbour(f, idx), f_xyz], -1)
+        return (e * fset).sum(2) / e.sum(2)
+
+    X = dense(feats.astype(np.float64), next(it), True)
+    enc = []
+    for i in range(cfg.num_layers):
+        d = cfg.d_out[i]
+        h = d // 2
+        idx = nbr[i]
+        mlp1, lfa1, fc1, a1mlp, lfa2, fc2, a2mlp, mlp2, sc = [next(it) for _ in range(9)]
+        enc10 = ro.relative_pos_encoding(xyz[i].astype(np.float64), idx)
+        f_pc = dense(X, mlp1, True)
+        f_xyz1 = dense(enc10, lfa1, True)
+        agg1 = att(f_pc, f_pc @ fc1[0][:h], f_xyz1, fc1[0][h:])
+        f_agg1 = dense(agg1, a1mlp, True)
+        f_xyz2 = dense(f_xyz1, lfa2, True)
+        agg2 = att(f_agg1, f_agg1 @ fc2[0][:h], f_xyz2, fc2[0][h:])
+        tmp = dense(agg2, a2mlp, True)
+        f_enc = lrelu(np.concatenate([tmp, X], -1) @ np.concatenate([mlp2[0], sc[0]], 0) + (mlp2[1] + sc[1]))
+        X = ro.random_sample(f_enc, pool[i])
+        if i == 0:
+            enc.append(f_enc)
+        enc.append(X)
+    f = dense(X, next(it), True)
+    for j in range(cfg.num_layers):
+        f = dense(np.concatenate([enc[-j - 2], ro.nearest_interpolation(f, up[-j - 1])], -1), next(it), True)
+    f = dense(f, next(it), True)
+    f = dense(f, next(it), True)
+    return dense(f, next(it), False)
+
+
+def test_folded_blob_and_launch_plan_reproduce_the_reference_graph(oracle):
+    from oracle import randla_oracle as ro
+    from point_unet_amd import weights
+    cfg, xyz, feats = netcase.small_deep(1500, seed=1)
+    cfg.d_out = [16, 32, 64, 32, 16]  # keep the float64 replay fast; the layout logic is width independent
+    params = weights.init_params(cfg, seed=3, randomize_bn=True)
+    blob = weights.fold_to_blob(cfg, params)
+    pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: oracle.knn_batch(s, q, k), xyz, cfg.k_n, cfg.sub_sampling_ratio)
+    want = ro.inference(params, cfg.num_layers, pts, nbr, pool, up, feats, np.float64)
+    got = _replay_device_plan(cfg, blob, pts, nbr, pool, up, feats)
+    # the blob is fp32 (folded in float64, rounded once): agreement to fp32 rounding of the weights
+    assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+
+
+def test_param_count_matches_the_reference_model():
+    from point_unet_amd import weights
+    from point_unet_amd.helper_tool import ConfigBraTS, ConfigPancreas
+    assert weights.num_params(ConfigBraTS) == 4992852
+    assert weights.num_params(ConfigPancreas) == 4992762
+
+
+def test_facade_validates_arguments():
+    from point_unet_amd.utils.cpp_wrappers.cpp_subsampling import grid_subsampling
+    from point_unet_amd.utils.nearest_neighbors.lib.python import nearest_neighbors as nn
+    with pytest.raises(ValueError):
+        nn.knn_batch(np.zeros((1, 5, 2), np.float32), np.zeros((1, 5, 2), np.float32), 3)
+    with pytest.raises(ValueError):
+        nn.knn_batch(np.zeros((2, 5, 3), np.float32), np.zeros((1, 5, 3), np.float32), 3)
+    with pytest.raises(RuntimeError, match="points.shape is not"):
+        grid_subsampling.compute(np.zeros((5, 2), np.float32))
+    with pytest.raises(RuntimeError, match="features.shape is not"):
+        grid_subsampling.compute(np.zeros((5, 3), np.float32), features=np.zeros((4, 2), np.float32))
+    with pytest.raises(RuntimeError, match="classes.shape is not"):
+        grid_subsampling.compute(np.zeros((5, 3), np.float32), classes=np.zeros((4,), np.int32))
