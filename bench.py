@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- points/sec of the PointSegment hot path (index pyramid + RandLA-Net forward) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one cloud per GPU: ps_pyramid_build (kd-tree build, K-NN and 1-NN
+search for all 5 levels) followed by ps_randla_forward, with the cloud already resident in HBM.  Workload =
+BASELINE.json configs[1]: a 180 000-point BraTS-shaped cloud (voxel-lattice coordinates inside an ellipsoid of a
+240x240x155 grid, shuffled; 4 z-scored modalities), K=16, 5 levels (ratios 4,4,4,4,2; d_out 16..512), fp32,
+random-init weights of the reference architecture (synthetic data: no datasets/checkpoints are reachable).
+
+Multi-GPU: the path shards by cloud (one volume per GPU); the forward has no exchange step, so there
+is no data-path collective -- ranks only meet at the barriers around the timed region ("scaling": "weak").
+
+One JSON line on rank 0; besides the contract's keys it carries
+  "roofline"      for the dominant stage: algorithmic bytes or FLOPs per launch (SURVEY 8d formulas, reference
+                  formulation) / its average duration measured with hipEvents on the launch stream
+  "stages"        the same for every stage (name, ms per step, bound, achieved, frac)
+  "cpu_baseline"  the oracle (a port of the reference CPU path) timed on this host on one cloud
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* = fp32 vector peak
+
+
+def brats_cloud(n, seed, grid=(240, 240, 155)):
+    rng = np.random.default_rng(seed)
+    g = np.asarray(grid)
+    out = np.empty((0, 3), np.int64)
+    while len(out) < n:
+        c = rng.integers(0, g, size=(2 * n, 3))
+        u = (c - g / 2.0) / (0.45 * g)
+        c = c[(u * u).sum(1) < 1.0]
+        out = np.unique(np.concatenate([out, c]), axis=0)
+    out = out[rng.permutation(len(out))[:n]]
+    return (out / g).astype(np.float32)
+
+
+def level_sizes(n0, ratios):
+    n = [n0]
+    for r in ratios:
+        n.append(n[-1] // r)
+    return n
+
+
+def algorithmic_costs(cfg, n0, B):
+    """Per-stage algorithmic FLOPs and bytes per step (FLOP = 2*MAC; gather-counted bytes; [N,K,.]
+    intermediates count zero).  Reference formulation: the score GEMM is counted at its full 2*N*K*d^2."""
+    L, K = cfg.num_layers, cfg.k_n
+    n = level_sizes(n0, cfg.sub_sampling_ratio[:L])
+    c = {}
+    nq = sum(n[:L])
+    c["knn_search_k"] = dict(flops=0, bytes=B * (nq * 12 + nq * K * 4))
+    c["knn_search_1nn"] = dict(flops=0, bytes=B * (nq * 12 + nq * 4))
+    c["kdtree_build"] = dict(flops=0, bytes=B * (sum(n) * 12 + sum(n) * 16 + 2 * sum(n) * 16))
+    c["pyramid_slices"] = dict(flops=0, bytes=B * 2 * (sum(n[:L]) * 12 + sum(n[1:]) * K * 4))
+    c["fc0"] = dict(flops=2 * B * n0 * cfg.in_channels * 8, bytes=B * n0 * (cfg.in_channels + 8) * 4)
+    d_in = 8
+    for i in range(L):
+        d = cfg.d_out[i]
+        h = d // 2
+        N, N1 = B * n[i], B * n[i + 1]
+        locse = K * 10 * h
+        c["enc%d_att1" % i] = dict(flops=2 * N * (locse + K * d * d),
+                                   bytes=N * (12 + K * 4 + K * 12 + K * h * 4 + d * 4))
+        c["enc%d_att2" % i] = dict(flops=2 * N * (locse + K * h * h + K * d * d),
+                                   bytes=N * (12 + K * 4 + K * 12 + K * h * 4 + d * 4))
+        c["enc%d_dense" % i] = dict(flops=2 * N * (d_in * h + d * h + d * d + 2 * d * d + 2 * d_in * d),
+                                    bytes=N * 4 * (2 * d_in + h + d + h + d + d + 2 * d))
+        c["enc%d_pool" % i] = dict(flops=0, bytes=N1 * (K * 4 + K * 2 * d * 4 + 2 * d * 4))
+        d_in = 2 * d
+    c["decoder_0"] = dict(flops=2 * B * n[L] * d_in * d_in, bytes=B * n[L] * 2 * d_in * 4 + d_in * d_in * 4)
+    chans = [2 * cfg.d_out[0]] + [2 * d for d in cfg.d_out[:L]]
+    up = d_in
+    for j in range(L):
+        skip = chans[-j - 2]
+        N = B * n[L - 1 - j]
+        c["dec%d" % j] = dict(flops=2 * N * (skip + up) * skip, bytes=N * 4 * (skip + up + skip + 1) + (skip + up) * skip * 4)
+        up = skip
+    c["head"] = dict(flops=2 * B * n0 * (up * 64 + 64 * 32 + 32 * cfg.num_classes),
+                     bytes=B * n0 * 4 * (up + cfg.num_classes))
+    return c
+
+
+def cpu_baseline(cfg, xyz, feats, params):
+    """The oracle (port of the reference CPU path) on this host: KNN pyramid single-threaded exactly as the reference
+    runs it at batch 1 (knn_.cxx:108 parallelises over the batch only), then the NumPy fp32 forward."""
+    from oracle import bindings as ob
+    from oracle import randla_oracle as ro
+    t0 = time.perf_counter()
+    pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: ob.knn_batch(s, q, k, threads=1), xyz, cfg.k_n,
+                                          cfg.sub_sampling_ratio[:cfg.num_layers])
+    t1 = time.perf_counter()
+    ro.inference(params, cfg.num_layers, pts, nbr, pool, up, feats, np.float32)
+    t2 = time.perf_counter()
+    n = xyz.shape[0] * xyz.shape[1]
+    return dict(value=n / (t2 - t0), unit="points/s", cores=os.cpu_count(), kind="port",
+                sample="1 cloud of %d points, full pyramid + forward: KNN pyramid %.2f s on 1 thread (reference threading at "
+                       "batch 1), NumPy fp32 forward %.2f s on up to %d BLAS threads" % (xyz.shape[1], t1 - t0, t2 - t1, os.cpu_count()),
+                knn_seconds=t1 - t0, net_seconds=t2 - t1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=180000)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from point_unet_amd import runtime, weights
+    from point_unet_amd.helper_tool import ConfigBraTS
+    from point_unet_amd.RandLANet import Network
+    from point_unet_amd.pyramid import alloc_pyramid, build_pyramid
+
+    cfg = ConfigBraTS
+    B, n0 = args.batch, args.points
+    # one volume per GPU: rank r gets cloud(s) seeded by r
+    xyz = np.stack([brats_cloud(n0, 1000 * rank + b) for b in range(B)])
+    mods = np.random.default_rng(7 + rank).standard_normal((B, n0, cfg.in_channels - 3)).astype(np.float32)
+    feats = np.concatenate([xyz, mods], -1)
+    params = weights.init_params(cfg, seed=2, randomize_bn=True)
+
+    ctx = runtime.default_context(local_rank)
+    net = Network(cfg, params=params, device=local_rank, ctx=ctx)
+    d_xyz = torch.from_numpy(xyz).cuda()
+    d_feats = torch.from_numpy(feats).cuda()
+    pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
+
+    def step():
+        build_pyramid(d_xyz, cfg, ctx=ctx, out=pyr)
+        return net.inference({"pyramid": pyr, "features": d_feats})
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    ctx.timing_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits = step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    stage_rows = ctx.timing_end()
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(logits).all())
+
+    if rank == 0:
+        costs = algorithmic_costs(cfg, n0, B)
+        stages = []
+        for name, ms, launches in stage_rows:
+            per_step = ms / args.steps
+            cst = costs.get(name, dict(flops=0, bytes=0))
+            gbs = cst["bytes"] / (per_step * 1e-3) / 1e9 if per_step > 0 else 0.0
+            tfs = cst["flops"] / (per_step * 1e-3) / 1e12 if per_step > 0 else 0.0
+            f_h, f_m = gbs / HBM_PEAK_GBS, tfs / F32_MFMA_PEAK_TF
+            bound = "mfma" if f_m > f_h else "hbm"
+            stages.append(dict(name=name, ms_per_step=round(per_step, 4), launches_per_step=launches / args.steps, bound=bound,
+                               achieved=round(tfs if bound == "mfma" else gbs, 3), unit="TFLOP/s" if bound == "mfma" else "GB/s",
+                               frac=round(max(f_h, f_m), 5)))
+        stages.sort(key=lambda s: -s["ms_per_step"])
+        dom = stages[0] if stages else None
+        roofline = None
+        if dom:
+            roofline = dict(kernel=dom["name"], bound=dom["bound"], achieved=dom["achieved"],
+                            peak=F32_MFMA_PEAK_TF if dom["bound"] == "mfma" else HBM_PEAK_GBS, unit=dom["unit"], frac=dom["frac"],
+                            traffic=None, avg_launch_ms=dom["ms_per_step"] / max(dom["launches_per_step"], 1))
+        total_cost = {k: sum(v[k] for v in costs.values()) for k in ("flops", "bytes")}
+        dev_ms = sum(s["ms_per_step"] for s in stages)
+        out = {
+            "metric": "points_per_sec_forward",
+            "value": world * B * n0 * args.steps / elapsed,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d-point BraTS-shaped cloud (4 modalities), K=16, 5-level RandLA-Net forward "
+                                   "incl. index pyramid, fp32, batch %d per GPU" % (n0, B),
+                       "points": n0, "k_n": cfg.k_n, "num_layers": cfg.num_layers, "batch_per_gpu": B, "sharding": "one cloud per GPU, no collective"},
+            "roofline": roofline,
+            "device_ms_per_step": round(dev_ms, 4),
+            "algorithmic": {"gflop_per_step": total_cost["flops"] / 1e9, "gbyte_per_step": total_cost["bytes"] / 1e9},
+            "stages": stages,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, xyz[:1], feats[:1], params)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

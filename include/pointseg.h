@@ -56,7 +56,9 @@ typedef struct ps_randla ps_randla;
 /* ---- context ------------------------------------------------------------------------------------------ */
 int ps_create(int device, ps_context** out);
 int ps_destroy(ps_context* ctx);
-/* Adopt the caller's hipStream_t (e.g. torch's current stream); NULL restores the context's own stream. */
+/* A new context launches on a private non-blocking stream.  ps_set_stream adopts the caller's hipStream_t instead
+ * (e.g. torch's current stream, so that the caller's allocator and copies are ordered with the kernels);
+ * hip_stream == NULL selects the device's default (null) stream. */
 int ps_set_stream(ps_context* ctx, void* hip_stream);
 int ps_synchronize(ps_context* ctx);
 const char* ps_last_error(void);

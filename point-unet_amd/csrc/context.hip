@@ -127,7 +127,7 @@ int ps_destroy(ps_context* c)
 int ps_set_stream(ps_context* c, void* hip_stream)
 {
     PS_CHECK(c != nullptr, "ps_set_stream: ctx is NULL");
-    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->stream = static_cast<hipStream_t>(hip_stream);  // NULL = the default (null) stream
     return PS_OK;
 }
 

@@ -60,6 +60,8 @@ def default_context(device=None):
     with _ctx_lock:
         if device not in _contexts:
             _contexts[device] = Context(device)
+            # torch tensors are allocated, filled and read on torch's current stream: launch there too
+            _contexts[device].use_torch_stream()
         return _contexts[device]
 
 

@@ -1,0 +1,92 @@
+"""GPU parity of grid subsampling (bit-exact after the canonical row sort) and of the op-by-op surface
+(Network.* static methods) against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _canon(oracle, res, have_f, have_l):
+    if not isinstance(res, tuple):
+        res = (res,)
+    p = res[0]
+    f = res[1] if have_f else None
+    l = res[-1] if have_l else None
+    return oracle.canonical_rows(p, f, l)
+
+
+def test_grid_golden_vectors(oracle):
+    from point_unet_amd.helper_tool import DataProcessing as DP
+    g = np.load(os.path.join(GOLD, "grid_all.npz"))
+    p, f, l = _canon(oracle, DP.grid_sub_sampling(g["points"], g["features"], g["classes"], float(g["sampleDl"])), True, True)
+    assert np.array_equal(p, g["out_points"]) and np.array_equal(f, g["out_features"]) and np.array_equal(l, g["out_classes"])
+    g = np.load(os.path.join(GOLD, "grid_points_only.npz"))
+    res = DP.grid_sub_sampling(g["points"], grid_size=float(g["sampleDl"]))
+    assert isinstance(res, np.ndarray)
+    assert np.array_equal(_canon(oracle, res, False, False)[0], g["out_points"])
+    g = np.load(os.path.join(GOLD, "grid_negative_coords.npz"))
+    p, f, _ = _canon(oracle, DP.grid_sub_sampling(g["points"], g["features"], None, float(g["sampleDl"])), True, False)
+    assert np.array_equal(p, g["out_points"]) and np.array_equal(f, g["out_features"])
+
+
+def test_grid_large_cloud_vs_oracle(oracle):
+    """~1e6 points at the reference's BraTS grid size 0.01 (helper_tool.py:27)."""
+    from point_unet_amd.helper_tool import DataProcessing as DP
+    rng = np.random.default_rng(0)
+    p = rng.random((1000000, 3), dtype=np.float32)
+    f = rng.standard_normal((1000000, 4)).astype(np.float32)
+    got = _canon(oracle, DP.grid_sub_sampling(p, f, None, 0.01), True, False)
+    want = oracle.canonical_rows(*oracle.grid_subsample(p, f, None, 0.01))
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # idempotence-style property: every output point lies in the voxel of its inputs, counts add up
+    assert len(got[0]) == len(want[0])
+
+
+def test_grid_single_point_and_single_voxel(oracle):
+    from point_unet_amd.helper_tool import DataProcessing as DP
+    one = np.array([[0.3, -0.2, 0.9]], np.float32)
+    assert np.array_equal(DP.grid_sub_sampling(one, grid_size=0.1), one)
+    blob = np.random.default_rng(1).random((500, 3), dtype=np.float32) * 0.01 + 0.5
+    got = DP.grid_sub_sampling(blob, grid_size=10.0)
+    want = oracle.grid_subsample(blob, None, None, 10.0)[0]
+    assert got.shape == (1, 3) and np.array_equal(got, want)
+
+
+def test_op_by_op_surface_vs_oracle(oracle):
+    import torch
+    from oracle import randla_oracle as ro
+    from point_unet_amd.RandLANet import Network
+    rng = np.random.default_rng(0)
+    B, N, M, K, d = 2, 900, 300, 16, 24
+    pc = rng.standard_normal((B, N, d)).astype(np.float32)
+    xyz = rng.random((B, N, 3), dtype=np.float32)
+    idx = rng.integers(0, N, (B, N, K)).astype(np.int32)
+    pidx = rng.integers(0, N, (B, M, K)).astype(np.int32)
+    iidx = rng.integers(0, M, (B, N, 1)).astype(np.int32)
+    c = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    assert np.array_equal(Network.gather_neighbour(c(pc), c(idx)).cpu().numpy(), ro.gather_neighbour(pc, idx))
+    rp = Network.relative_pos_encoding(c(xyz), c(idx)).cpu().numpy()
+    want = ro.relative_pos_encoding(xyz, idx)
+    assert np.array_equal(rp[..., 1:], want[..., 1:]) and np.abs(rp[..., 0] - want[..., 0]).max() < 1e-6
+    assert np.array_equal(Network.random_sample(c(pc[:, :, None]), c(pidx)).cpu().numpy()[:, :, 0], ro.random_sample(pc, pidx))
+    sub = pc[:, :M]
+    assert np.array_equal(Network.nearest_interpolation(c(sub[:, :, None]), c(iidx)).cpu().numpy()[:, :, 0],
+                          ro.nearest_interpolation(sub, iidx))
+    # conv2d (BN folded) and att_pooling
+    W = rng.standard_normal((d, 40)).astype(np.float32) * 0.2
+    b = rng.standard_normal(40).astype(np.float32)
+    got = Network.conv2d(c(pc), c(W), c(b), leaky=True).cpu().numpy()
+    assert np.abs(got - ro.leaky_relu(pc.astype(np.float64) @ W + b)).max() < 1e-5
+    fset = rng.standard_normal((B, 200, K, 32)).astype(np.float32)
+    wfc = (rng.standard_normal((32, 32)) * 0.3).astype(np.float32)
+    wm = (rng.standard_normal((32, 16)) * 0.3).astype(np.float32)
+    bm = rng.standard_normal(16).astype(np.float32)
+    got = Network.att_pooling(c(fset), c(wfc), c(wm), c(bm)).cpu().numpy()[:, :, 0]
+    f64 = fset.astype(np.float64)
+    a = f64 @ wfc
+    a = np.exp(a - a.max(2, keepdims=True))
+    want = ro.leaky_relu((f64 * a / a.sum(2, keepdims=True)).sum(2) @ wm + bm)
+    assert np.abs(got - want).max() < 1e-5
