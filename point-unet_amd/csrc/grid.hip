@@ -213,10 +213,13 @@ extern "C" int ps_grid_subsample(ps_context* c, const float* points, int64_t n, 
     hipLaunchKernelGGL(head_flag_kernel, grid, blk, 0, st, k1, (size_t)n, flag);
     PS_HIP(rocprim::exclusive_scan(tmp2, scan_tmp, flag, cell, 0u, (size_t)n, rocprim::plus<unsigned>(), st));
     hipLaunchKernelGGL(seg_start_kernel, grid, blk, 0, st, flag, cell, (size_t)n, start);
-    unsigned last_cell = 0;
+    unsigned last_cell = 0, last_flag = 0;
     PS_HIP(hipMemcpyAsync(&last_cell, cell + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    PS_HIP(hipMemcpyAsync(&last_flag, flag + (n - 1), 4, hipMemcpyDeviceToHost, st));
     PS_HIP(hipStreamSynchronize(st));
-    const unsigned M = last_cell + 1;  // flag[n-1] contributes to a later prefix only; cell[n-1] is its own cell number
+    // cell[] is the EXCLUSIVE scan of the head flags: the exact cell number at head positions (the only place it
+    // is read); the number of cells is the inclusive total
+    const unsigned M = last_cell + last_flag;
     *M_out = M;
     if (!out_points) return PS_OK;
     hipLaunchKernelGGL(cell_reduce_kernel, dim3(ceil_div(M, 128)), dim3(128), 0, st, d_pts, d_feat, d_cls, v1, start, M, (size_t)n, (int)fdim,
