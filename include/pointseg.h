@@ -171,6 +171,10 @@ int ps_debug_knn_host(const float* support, const float* queries, int64_t B, int
 /* vind i32[n], nodes i32[2n,4], pts f32[n,4], root_depth i32[2], bbox f32[6] (layout: csrc/kdtree.h). */
 int ps_debug_kdtree_host(const float* support, int64_t n, int32_t* vind, int32_t* nodes, float* pts,
                          int32_t* root_depth, float* bbox);
+/* The same arrays from the DEVICE builder (csrc/kdtree_build.hip); needs a GPU.  Unreached node slots are
+ * unspecified: compare by walking from the root. */
+int ps_debug_kdtree_device(ps_context* ctx, const float* support, int64_t n, int32_t* vind, int32_t* nodes,
+                           float* pts, int32_t* root_depth, float* bbox);
 /* MFMA B-fragment packing of a row-major W[cin,cout] (csrc/rowgemm.h). */
 int ps_debug_pack_weights(const float* W, int cin, int cout, int ntb, float* out);
 

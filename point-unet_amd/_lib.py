@@ -74,6 +74,7 @@ PROTOTYPES = {
     # host-only debug doors (bound for the CPU test-suite only; the facade never calls them)
     "ps_debug_knn_host": (ctypes.c_int, [c_vp, c_vp] + [ctypes.c_int64] * 4 + [c_vp]),
     "ps_debug_kdtree_host": (ctypes.c_int, [c_vp, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ps_debug_kdtree_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ps_debug_pack_weights": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp]),
 }
 

@@ -1,16 +1,500 @@
-// kdtree_build.hip -- builds the kd-trees of a TreeSetPlan.
+// kdtree_build.hip -- builds every kd-tree of a TreeSetPlan ON THE DEVICE, bit-identical (same `vind` permutation,
+// same splits, same child order) to nanoflann 1.2.3's recursive builder as used by the reference
+// (PointSegment/utils/nearest_neighbors/nanoflann.hpp:916-1043 divideTree / middleSplit_ / planeSplit, :1321-1343
+// computeBoundingBox; leaf_max_size 10, knn_.cxx:116).
 //
-// Bring-up version: the points are copied to the host, the tree is built there by kdtree_host.hip and the
-// arrays are uploaded.  (The device builder replaces this function; the layout and the contract are the same.)
+// The recursion is replaced by a level-synchronous task queue (kernel boundaries are the only global sync):
+//   init kernels     points -> (x,y,z,index) records; root bounding boxes by block reduction + ordered-uint atomics
+//   level kernel     one 1024-thread workgroup per node with more than kSmall points: min/max of the three axes,
+//                    split choice, counts, then nanoflann's two Hoare sweeps reproduced in CLOSED FORM -- the i-th
+//                    misplaced element from the left swaps with the i-th misplaced element from the right, so ranks
+//                    from a block scan of two flag vectors give every swap pair; children go to the next level's
+//                    queue (or to the small queue)
+//   subtree kernel   one wave per node with <= kSmall points: the node's points live in LDS and the wave builds the
+//                    whole subtree with ballot-based ranks
+// Node ids are position-derived (kdtree.h), so the result does not depend on scheduling.  divlow / divhigh are the
+// children's tight extents on the split axis, which the parent can compute at split time as max{v < cut-side} /
+// min{v > cut-side} (the children's bounding boxes are never needed otherwise).
+//
+// Bound: latency / L2 bandwidth of one CU for the top few levels (one workgroup per node), otherwise launch-bound;
+// HBM traffic is a few passes over 16 B per point per level.
 #include "kdtree_build.h"
 
-#include "kdtree_host.h"
+#include <algorithm>
 
 namespace ps {
 
+constexpr int kSmall = 256;     // nodes up to this many points are finished by one wave in LDS
+constexpr int kBigThreads = 1024;
+constexpr int kMaxLevels = 96;  // per-level task counters
+
+struct BuildTask {
+    int32_t tree, l, r, parent, side, level;
+    float lo[3], hi[3];  // incoming bounding box (nanoflann passes the parent's box cut at the plane)
+};
+
+struct BuildTree {
+    const float* src;
+    float4* pts;
+    int4* nodes;
+    TreeMeta* meta;
+    int32_t* posL;  // scratch [n]
+    int32_t* posR;  // scratch [n]
+    unsigned* bbox_ord;  // [6] ordered-uint min[3], max[3]
+    int32_t n;
+};
+
+struct BuildQueues {
+    BuildTask* q[2];
+    BuildTask* small_q;
+    int32_t* level_cnt;  // [kMaxLevels]
+    int32_t* small_cnt;
+    int32_t* flags;      // flags[1] = queue overflow
+    int32_t q_cap, small_cap;
+};
+
+__device__ __forceinline__ unsigned f2ord(float f)
+{
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u)
+{
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ float comp(const float4& p, int ax) { return ax == 0 ? p.x : (ax == 1 ? p.y : p.z); }
+
+// ---- init -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void init_points_kernel(const BuildTree* __restrict__ trees, int chunks_x)
+{
+    const BuildTree t = trees[blockIdx.y];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < t.n; i += chunks_x * 256) {
+        const float x = t.src[3 * (size_t)i], y = t.src[3 * (size_t)i + 1], z = t.src[3 * (size_t)i + 2];
+        t.pts[i] = make_float4(x, y, z, __int_as_float(i));
+        mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+        mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+        mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+        }
+        if ((threadIdx.x & 63) == 0 && mn[a] <= mx[a]) {
+            atomicMin(&t.bbox_ord[a], f2ord(mn[a]));
+            atomicMax(&t.bbox_ord[3 + a], f2ord(mx[a]));
+        }
+    }
+}
+
+__device__ __forceinline__ void push_task(const BuildQueues& Q, const BuildTask& t, int next_level)
+{
+    if (t.r - t.l > kSmall) {
+        const int slot = atomicAdd(&Q.level_cnt[next_level], 1);
+        if (slot < Q.q_cap && next_level < kMaxLevels - 1)
+            Q.q[next_level & 1][slot] = t;
+        else
+            Q.flags[1] = 1;
+    } else {
+        const int slot = atomicAdd(Q.small_cnt, 1);
+        if (slot < Q.small_cap)
+            Q.small_q[slot] = t;
+        else
+            Q.flags[1] = 1;
+    }
+}
+
+__global__ void root_tasks_kernel(const BuildTree* __restrict__ trees, int n_trees, BuildQueues Q)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_trees) return;
+    const BuildTree t = trees[i];
+    TreeMeta m;
+    m.root = 0;
+    m.depth = 0;
+    for (int a = 0; a < 3; ++a) {
+        m.lo[a] = t.n > 0 ? ord2f(t.bbox_ord[a]) : 0.f;
+        m.hi[a] = t.n > 0 ? ord2f(t.bbox_ord[3 + a]) : 0.f;
+    }
+    *t.meta = m;
+    if (t.n <= 0) return;
+    BuildTask k;
+    k.tree = i; k.l = 0; k.r = t.n; k.parent = -1; k.side = 0; k.level = 0;
+    for (int a = 0; a < 3; ++a) { k.lo[a] = m.lo[a]; k.hi[a] = m.hi[a]; }
+    push_task(Q, k, 0);
+}
+
+// ---- the split decision shared by both kernels (middleSplit_, nanoflann.hpp:966-1005) -------------------------
+struct SplitChoice {
+    int ax;
+    float cut;
+};
+__device__ __forceinline__ SplitChoice choose_split(const float* lo, const float* hi, const float* mn, const float* mx)
+{
+    float max_span = __fsub_rn(hi[0], lo[0]);
+    for (int a = 1; a < 3; ++a) {
+        const float s = __fsub_rn(hi[a], lo[a]);
+        if (s > max_span) max_span = s;
+    }
+    const float thresh = __fmul_rn(__fsub_rn(1.0f, 0.00001f), max_span);
+    int cutfeat = 0;
+    float max_spread = -1.f;
+    for (int a = 0; a < 3; ++a) {
+        if (__fsub_rn(hi[a], lo[a]) > thresh) {
+            const float spread = __fsub_rn(mx[a], mn[a]);
+            if (spread > max_spread) {
+                cutfeat = a;
+                max_spread = spread;
+            }
+        }
+    }
+    const float split = __fmul_rn(__fadd_rn(lo[cutfeat], hi[cutfeat]), 0.5f);
+    SplitChoice c;
+    c.ax = cutfeat;
+    c.cut = split < mn[cutfeat] ? mn[cutfeat] : (split > mx[cutfeat] ? mx[cutfeat] : split);
+    return c;
+}
+
+// Everything the parent must record once the partition is known.
+__device__ __forceinline__ void emit_inner(const BuildQueues& Q, const BuildTree& t, const BuildTask& k, int ax, float cut, int lim1, int lim2,
+                                           float maxlt, float mingt, BuildTask* kids /* [2] out */, int* node_id)
+{
+    const int count = k.r - k.l, half = count / 2;
+    const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
+    const int m = k.l + idx;
+    const int id = 2 * m - 1;
+    // left = first idx records of [ <cut | ==cut | >cut ]
+    const float divlow = idx > lim1 ? cut : maxlt;
+    const float divhigh = idx < lim2 ? cut : mingt;
+    t.nodes[id] = make_int4((int)((unsigned)ax << 30), 0, __float_as_int(divlow), __float_as_int(divhigh));
+    for (int s = 0; s < 2; ++s) {
+        BuildTask c = k;
+        c.parent = id;
+        c.side = s;
+        c.level = k.level + 1;
+        if (s == 0) {
+            c.r = m;
+            c.hi[ax] = cut;
+        } else {
+            c.l = m;
+            c.lo[ax] = cut;
+        }
+        kids[s] = c;
+    }
+    *node_id = id;
+}
+
+__device__ __forceinline__ void link_to_parent(const BuildTree& t, const BuildTask& k, int id)
+{
+    if (k.parent < 0)
+        t.meta->root = id;
+    else if (k.side == 0)
+        atomicOr(&t.nodes[k.parent].x, id);  // low 30 bits were written as 0 by the parent, in an earlier kernel / earlier by this wave
+    else
+        t.nodes[k.parent].y = id;
+}
+
+// ---- level kernel: one workgroup per big node ------------------------------------------------------------------
+template <int T>
+struct BlockRed {
+    float mn[T / 64][3], mx[T / 64][3];
+    int ia[T / 64], ib[T / 64];
+    float fa[T / 64], fb[T / 64];
+    int wave_tot[T / 64];
+    int bcast[8];
+    float fbcast[8];
+};
+
+__global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTree* __restrict__ trees, BuildQueues Q, int level)
+{
+    constexpr int T = kBigThreads, W = T / 64;
+    __shared__ BlockRed<T> S;
+    const int n_tasks = min(Q.level_cnt[level], Q.q_cap);
+    if ((int)blockIdx.x >= n_tasks) return;
+    const BuildTask k = Q.q[level & 1][blockIdx.x];
+    const BuildTree t = trees[k.tree];
+    float4* a = t.pts + k.l;
+    const int count = k.r - k.l;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    // ---- pass 1: min / max of the three axes ----
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < count; i += T) {
+        const float4 p = a[i];
+        mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+        mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+        mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        }
+        if (lane == 0) { S.mn[wave][c] = mn[c]; S.mx[wave][c] = mx[c]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float lo = S.mn[0][c], hi = S.mx[0][c];
+        for (int w = 1; w < W; ++w) { lo = fminf(lo, S.mn[w][c]); hi = fmaxf(hi, S.mx[w][c]); }
+        mn[c] = lo; mx[c] = hi;
+    }
+    const SplitChoice sc = choose_split(k.lo, k.hi, mn, mx);
+    const int ax = sc.ax;
+    const float cut = sc.cut;
+
+    // ---- pass 2: lim1 = #(< cut), lim2 = #(<= cut), max{v < cut}, min{v > cut} ----
+    int lt = 0, le = 0;
+    float maxlt = -INFINITY, mingt = INFINITY;
+    for (int i = tid; i < count; i += T) {
+        const float v = comp(a[i], ax);
+        lt += v < cut;
+        le += v <= cut;
+        if (v < cut) maxlt = fmaxf(maxlt, v);
+        if (v > cut) mingt = fminf(mingt, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lt += __shfl_xor(lt, o);
+        le += __shfl_xor(le, o);
+        maxlt = fmaxf(maxlt, __shfl_xor(maxlt, o));
+        mingt = fminf(mingt, __shfl_xor(mingt, o));
+    }
+    __syncthreads();  // S.mn/S.mx reads above are done
+    if (lane == 0) { S.ia[wave] = lt; S.ib[wave] = le; S.fa[wave] = maxlt; S.fb[wave] = mingt; }
+    __syncthreads();
+    lt = 0; le = 0; maxlt = -INFINITY; mingt = INFINITY;
+    for (int w = 0; w < W; ++w) {
+        lt += S.ia[w]; le += S.ib[w];
+        maxlt = fmaxf(maxlt, S.fa[w]); mingt = fminf(mingt, S.fb[w]);
+    }
+    const int lim1 = lt, lim2 = le;
+
+    // ---- the two Hoare sweeps (planeSplit, nanoflann.hpp:1016-1043) in closed form ----
+    // sweep 0: [0,count) by (v < cut); sweep 1: [lim1,count) by (v <= cut).  In sweep s the elements left of the
+    // boundary that fail the predicate ("misplaced left", ascending) pair with the elements right of it that satisfy
+    // it ("misplaced right", descending): i-th with i-th.
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        const int from = sweep == 0 ? 0 : lim1, bound = sweep == 0 ? lim1 : lim2;
+        int offL = 0, offR = 0;
+        for (int s0 = from; s0 < count; s0 += T) {
+            const int p = s0 + tid;
+            bool isL = false, isR = false;
+            if (p < count) {
+                const float v = comp(a[p], ax);
+                const bool keep_left = sweep == 0 ? (v < cut) : (v <= cut);
+                isL = p < bound && !keep_left;
+                isR = p >= bound && keep_left;
+            }
+            const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
+            const unsigned long long lt_mask = (1ull << lane) - 1ull;
+            const int rL = __popcll(bL & lt_mask), rR = __popcll(bR & lt_mask);
+            __syncthreads();  // previous iteration's reads of S.wave_tot / S.ia are done
+            if (lane == 0) { S.wave_tot[wave] = __popcll(bL); S.ia[wave] = __popcll(bR); }
+            __syncthreads();
+            int preL = 0, preR = 0, totL = 0, totR = 0;
+            for (int w = 0; w < W; ++w) {
+                const int cl = S.wave_tot[w], cr = S.ia[w];
+                if (w < wave) { preL += cl; preR += cr; }
+                totL += cl; totR += cr;
+            }
+            if (isL) t.posL[k.l + offL + preL + rL] = p;
+            if (isR) t.posR[k.l + offR + preR + rR] = p;
+            offL += totL;
+            offR += totR;
+        }
+        __syncthreads();  // (global posL/posR written by this workgroup are read below by other waves of it)
+        const int m = offL;  // == offR
+        for (int i = tid; i < m; i += T) {
+            const int pl = t.posL[k.l + i], pr = t.posR[k.l + m - 1 - i];
+            const float4 x = a[pl], y = a[pr];
+            a[pl] = y;
+            a[pr] = x;
+        }
+        __syncthreads();
+    }
+
+    if (tid == 0) {
+        BuildTask kids[2];
+        int id;
+        emit_inner(Q, t, k, ax, cut, lim1, lim2, maxlt, mingt, kids, &id);
+        link_to_parent(t, k, id);
+        push_task(Q, kids[0], level + 1);
+        push_task(Q, kids[1], level + 1);
+    }
+}
+
+// ---- subtree kernel: one wave finishes a node of <= kSmall points -----------------------------------------------
+constexpr int kSubStack = kSmall;  // worst case: every split peels one point
+
+struct SubTask {
+    short l, r;       // range relative to the node's first record
+    int parent;       // node id or -1
+    short side, level;
+    float lo[3], hi[3];
+};
+
+__global__ __launch_bounds__(256) void build_subtree_kernel(const BuildTree* __restrict__ trees, BuildQueues Q)
+{
+    constexpr int WPB = 4, E = kSmall / 64;
+    __shared__ float4 s_pts[WPB][kSmall];
+    __shared__ short s_posL[WPB][kSmall], s_posR[WPB][kSmall];
+    __shared__ SubTask s_stack[WPB][kSubStack];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n_tasks = min(*Q.small_cnt, Q.small_cap);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    float4* P = s_pts[wave];
+    short* posL = s_posL[wave];
+    short* posR = s_posR[wave];
+    SubTask* stack = s_stack[wave];
+
+    for (int ti = blockIdx.x * WPB + wave; ti < n_tasks; ti += gridDim.x * WPB) {
+        const BuildTask k = Q.small_q[ti];
+        const BuildTree t = trees[k.tree];
+        const int total = k.r - k.l;
+        for (int i = lane; i < total; i += 64) P[i] = t.pts[k.l + i];
+        int sp = 0;
+        if (lane == 0) {
+            SubTask r;
+            r.l = 0; r.r = (short)total; r.parent = k.parent; r.side = (short)k.side; r.level = (short)k.level;
+            for (int c = 0; c < 3; ++c) { r.lo[c] = k.lo[c]; r.hi[c] = k.hi[c]; }
+            stack[0] = r;
+        }
+        sp = 1;
+        int max_level = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        while (sp > 0) {
+            --sp;
+            const SubTask u = stack[sp];
+            const int l = u.l, count = u.r - u.l;
+            if (count <= kLeafMax) {
+                const int id = 2 * (k.l + l);
+                if (lane == 0) {
+                    t.nodes[id] = make_int4(k.l + l, k.l + u.r, 0, 0);
+                    if (u.parent < 0) t.meta->root = id;
+                    else if (u.side == 0) atomicOr(&t.nodes[u.parent].x, id);
+                    else t.nodes[u.parent].y = id;
+                }
+                max_level = max(max_level, (int)u.level);
+                continue;
+            }
+            // min / max
+            float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = e * 64 + lane;
+                if (i < count) {
+                    const float4 p = P[l + i];
+                    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+                    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+                    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                for (int o = 32; o > 0; o >>= 1) {
+                    mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+                    mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+                }
+            const SplitChoice sc = choose_split(u.lo, u.hi, mn, mx);
+            const int ax = sc.ax;
+            const float cut = sc.cut;
+            float v[E];
+            int lim1 = 0, lim2 = 0;
+            float maxlt = -INFINITY, mingt = INFINITY;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = e * 64 + lane;
+                const bool in = i < count;
+                v[e] = in ? comp(P[l + i], ax) : 0.f;
+                lim1 += __popcll(__ballot(in && v[e] < cut));
+                lim2 += __popcll(__ballot(in && v[e] <= cut));
+                if (in && v[e] < cut) maxlt = fmaxf(maxlt, v[e]);
+                if (in && v[e] > cut) mingt = fminf(mingt, v[e]);
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                maxlt = fmaxf(maxlt, __shfl_xor(maxlt, o));
+                mingt = fminf(mingt, __shfl_xor(mingt, o));
+            }
+            for (int sweep = 0; sweep < 2; ++sweep) {
+                const int from = sweep == 0 ? 0 : lim1, bound = sweep == 0 ? lim1 : lim2;
+                int offL = 0, offR = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = e * 64 + lane;
+                    bool isL = false, isR = false;
+                    if (i < count && i >= from) {
+                        const bool keep_left = sweep == 0 ? (v[e] < cut) : (v[e] <= cut);
+                        isL = i < bound && !keep_left;
+                        isR = i >= bound && keep_left;
+                    }
+                    const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
+                    if (isL) posL[offL + __popcll(bL & lt_mask)] = (short)i;
+                    if (isR) posR[offR + __popcll(bR & lt_mask)] = (short)i;
+                    offL += __popcll(bL);
+                    offR += __popcll(bR);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int m = offL;
+                for (int i = lane; i < m; i += 64) {
+                    const int pl = posL[i], pr = posR[m - 1 - i];
+                    const float4 x = P[l + pl], y = P[l + pr];
+                    P[l + pl] = y;
+                    P[l + pr] = x;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (sweep == 0) {
+                    // the records moved: refresh the cached split-axis values for the second sweep
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int i = e * 64 + lane;
+                        v[e] = i < count ? comp(P[l + i], ax) : 0.f;
+                    }
+                }
+            }
+            const int half = count / 2;
+            const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
+            const int m = k.l + l + idx;
+            const int id = 2 * m - 1;
+            if (lane == 0) {
+                const float divlow = idx > lim1 ? cut : maxlt;
+                const float divhigh = idx < lim2 ? cut : mingt;
+                t.nodes[id] = make_int4((int)((unsigned)ax << 30), 0, __float_as_int(divlow), __float_as_int(divhigh));
+                if (u.parent < 0) t.meta->root = id;
+                else if (u.side == 0) atomicOr(&t.nodes[u.parent].x, id);
+                else t.nodes[u.parent].y = id;
+                SubTask c0 = u, c1 = u;
+                c0.r = (short)(l + idx); c0.hi[ax] = cut; c0.parent = id; c0.side = 0; c0.level = (short)(u.level + 1);
+                c1.l = (short)(l + idx); c1.lo[ax] = cut; c1.parent = id; c1.side = 1; c1.level = (short)(u.level + 1);
+                stack[sp] = c1;
+                stack[sp + 1] = c0;
+            }
+            sp += 2;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        for (int i = lane; i < total; i += 64) t.pts[k.l + i] = P[i];
+        if (lane == 0) atomicMax(&t.meta->depth, max_level);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------
 void TreeSetPlan::carve(Arena& a)
 {
     const size_t T = n.size();
+    const size_t tot = total_points();
     for (size_t i = 0; i < T; ++i) {
         d_nodes[i] = a.take<int4>(2 * (size_t)(n[i] > 0 ? n[i] : 1));
         d_pts[i] = a.take<float4>((size_t)(n[i] > 0 ? n[i] : 1));
@@ -18,34 +502,94 @@ void TreeSetPlan::carve(Arena& a)
     d_meta = a.take<TreeMeta>(T);
     d_jobs = a.take<char>(128 * (T + (size_t)extra_jobs));
     d_flags = a.take<int32_t>(16);
-    scratch_bytes = 0;
-    d_scratch = nullptr;
+    // builder scratch: tree table, bbox accumulators, posL/posR, queues, counters
+    const size_t q_cap = tot / kSmall + 2 * T + 64, small_cap = tot / 4 + 2 * T + 1024;
+    size_t bytes = 0;
+    auto add = [&](size_t b) { size_t o = bytes; bytes += (b + 255) & ~size_t(255); return o; };
+    add(sizeof(BuildTree) * T);
+    add(sizeof(unsigned) * 8 * T);
+    add(sizeof(int32_t) * 2 * (tot + T));
+    add(sizeof(BuildTask) * q_cap * 2);
+    add(sizeof(BuildTask) * small_cap);
+    add(sizeof(int32_t) * (kMaxLevels + 8));
+    scratch_bytes = bytes;
+    d_scratch = a.take<char>(bytes);
 }
 
 int build_trees(ps_context* c, TreeSetPlan& plan)
 {
     const size_t T = plan.n.size();
-    PS_HIP(hipMemsetAsync(plan.d_flags, 0, 16 * sizeof(int32_t), c->stream));
-    std::vector<TreeMeta> metas(T);
-    std::vector<float> host_pts;
-    HostTree ht;
+    if (T == 0) return PS_OK;
+    const size_t tot = plan.total_points();
+    const size_t q_cap = tot / kSmall + 2 * T + 64, small_cap = tot / 4 + 2 * T + 1024;
+    char* base = static_cast<char*>(plan.d_scratch);
+    size_t off = 0;
+    auto take = [&](size_t b) { char* p = base + off; off += (b + 255) & ~size_t(255); return p; };
+    BuildTree* d_trees = reinterpret_cast<BuildTree*>(take(sizeof(BuildTree) * T));
+    unsigned* d_bbox = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * 8 * T));
+    int32_t* d_pos = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 2 * (tot + T)));
+    BuildTask* d_q = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * q_cap * 2));
+    BuildTask* d_small = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * small_cap));
+    int32_t* d_cnt = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (kMaxLevels + 8)));
+
+    std::vector<BuildTree> h_trees(T);
+    std::vector<unsigned> h_bbox(8 * T);
+    size_t pos_off = 0;
+    int32_t max_n = 0;
     for (size_t i = 0; i < T; ++i) {
-        const int32_t n = plan.n[i];
-        host_pts.resize(3 * (size_t)(n > 0 ? n : 1));
-        if (n > 0) {
-            PS_HIP(hipMemcpyAsync(host_pts.data(), plan.src[i], sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-            PS_HIP(hipStreamSynchronize(c->stream));
-        }
-        build_tree_host(host_pts.data(), n, ht);
-        metas[i] = ht.meta;
-        if (n > 0) {
-            PS_HIP(hipMemcpyAsync(plan.d_nodes[i], ht.nodes.data(), sizeof(int4) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-            PS_HIP(hipMemcpyAsync(plan.d_pts[i], ht.pts.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-            PS_HIP(hipStreamSynchronize(c->stream));  // ht is reused by the next tree
+        BuildTree& t = h_trees[i];
+        t.src = plan.src[i];
+        t.pts = plan.d_pts[i];
+        t.nodes = plan.d_nodes[i];
+        t.meta = plan.d_meta + i;
+        t.posL = d_pos + pos_off;
+        t.posR = d_pos + pos_off + (size_t)plan.n[i] + 1;
+        pos_off += 2 * ((size_t)plan.n[i] + 1);
+        t.bbox_ord = d_bbox + 8 * i;
+        t.n = plan.n[i];
+        max_n = std::max(max_n, t.n);
+        for (int a = 0; a < 3; ++a) {
+            h_bbox[8 * i + a] = 0xffffffffu;
+            h_bbox[8 * i + 3 + a] = 0u;
         }
     }
-    PS_HIP(hipMemcpyAsync(plan.d_meta, metas.data(), sizeof(TreeMeta) * T, hipMemcpyHostToDevice, c->stream));
-    PS_HIP(hipStreamSynchronize(c->stream));
+    hipStream_t st = c->stream;
+    PS_HIP(hipMemcpyAsync(d_trees, h_trees.data(), sizeof(BuildTree) * T, hipMemcpyHostToDevice, st));
+    PS_HIP(hipMemcpyAsync(d_bbox, h_bbox.data(), sizeof(unsigned) * 8 * T, hipMemcpyHostToDevice, st));
+    PS_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (kMaxLevels + 8), st));
+    PS_HIP(hipMemsetAsync(plan.d_flags, 0, 16 * sizeof(int32_t), st));
+    // h_trees / h_bbox are pageable and die with this frame: make sure the copies have consumed them
+    PS_HIP(hipStreamSynchronize(st));
+
+    BuildQueues Q;
+    Q.q[0] = d_q;
+    Q.q[1] = d_q + q_cap;
+    Q.small_q = d_small;
+    Q.level_cnt = d_cnt;
+    Q.small_cnt = d_cnt + kMaxLevels;
+    Q.flags = plan.d_flags;
+    Q.q_cap = (int32_t)q_cap;
+    Q.small_cap = (int32_t)small_cap;
+
+    const int chunks_x = std::max(1, std::min(ceil_div(max_n, 256 * 8), 256));
+    hipLaunchKernelGGL(init_points_kernel, dim3(chunks_x, (unsigned)T), dim3(256), 0, st, d_trees, chunks_x);
+    hipLaunchKernelGGL(root_tasks_kernel, dim3(ceil_div(T, 64)), dim3(64), 0, st, d_trees, (int)T, Q);
+    // big levels: the number of tasks per level is device-side data; a level holds at most tot/kSmall disjoint big nodes.
+    const int grid_big = (int)std::min<size_t>(q_cap, tot / kSmall + T + 1);
+    int level = 0;
+    int batch = 14;
+    for (;;) {
+        for (int i = 0; i < batch && level < kMaxLevels - 1; ++i, ++level)
+            hipLaunchKernelGGL(build_level_kernel, dim3(grid_big), dim3(kBigThreads), 0, st, d_trees, Q, level);
+        int32_t pending = 0;
+        PS_HIP(hipMemcpyAsync(&pending, d_cnt + level, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        PS_HIP(hipStreamSynchronize(st));
+        if (pending == 0) break;
+        PS_CHECK(level < kMaxLevels - 1, "kd-tree build: more than %d levels of nodes above %d points (degenerate cloud)", kMaxLevels, kSmall);
+        batch = 4;
+    }
+    hipLaunchKernelGGL(build_subtree_kernel, dim3(std::min<size_t>(ceil_div(small_cap, 4), 2048)), dim3(256), 0, st, d_trees, Q);
+    PS_HIP(hipGetLastError());
     return PS_OK;
 }
 

@@ -111,3 +111,41 @@ def test_full_size_properties():
         dr = p[r] - p[idx[r]]
         mine = (dr[:, 0] * dr[:, 0] + dr[:, 1] * dr[:, 1]) + dr[:, 2] * dr[:, 2]
         assert np.array_equal(bf, mine), r
+
+
+@pytest.mark.parametrize("case", ["lattice", "uniform", "duplicates", "tiny"])
+def test_device_tree_equals_host_tree(lib, case):
+    """White box: the device builder (level-synchronous, closed-form Hoare sweeps) produces the same permutation,
+    splits, child order, root box and depth as the host restatement of nanoflann's recursive builder."""
+    import ctypes
+    from point_unet_amd import runtime
+    rng = np.random.default_rng(3)
+    if case == "lattice":
+        p = brats_cloud(60000, 8, grid=(96, 96, 64))
+    elif case == "uniform":
+        p = uniform_cloud(50000, 8)
+    elif case == "duplicates":
+        p = np.repeat(rng.random((300, 3), dtype=np.float32), 40, axis=0)
+        rng.shuffle(p)
+    else:
+        p = rng.random((9, 3), dtype=np.float32)
+    n = len(p)
+
+    def arrays():
+        return (np.zeros(n, np.int32), np.zeros((2 * n, 4), np.int32), np.zeros((n, 4), np.float32), np.zeros(2, np.int32), np.zeros(6, np.float32))
+
+    h = arrays()
+    assert lib.ps_debug_kdtree_host(p.ctypes.data, n, *[a.ctypes.data for a in h]) == 0
+    d = arrays()
+    ctx = runtime.default_context(0)
+    rc = lib.ps_debug_kdtree_device(ctx.handle, p.ctypes.data, n, *[a.ctypes.data for a in d])
+    assert rc == 0, lib.ps_last_error()
+    assert np.array_equal(h[0], d[0]), "vind permutation differs"
+    assert np.array_equal(h[2], d[2]) and np.array_equal(h[3], d[3]) and np.array_equal(h[4], d[4])
+    # walk both node tables from the root
+    stack = [int(h[3][0])]
+    while stack:
+        i = stack.pop()
+        assert np.array_equal(h[1][i], d[1][i]), i
+        if i & 1:
+            stack += [int(h[1][i, 0]) & 0x3fffffff, int(h[1][i, 1])]
