@@ -168,7 +168,7 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
     ps_context* c = net->ctx;
     PS_HIP(hipSetDevice(c->device));
     std::vector<float> host;  // packed image of everything, then one upload
-    struct Pending { PackedLinear* L; size_t wp_off, b_off; };
+    struct Pending { PackedLinear* L; size_t wp_off, b_off, wq_off; };
     std::vector<Pending> pend;
     auto emit = [&](PackedLinear& L, const float* W, const float* b, int cin, int cout, int leaky) {
         L = PackedLinear();
@@ -182,7 +182,13 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
         size_t boff = (host.size() + 63) & ~size_t(63);
         host.resize(boff + (size_t)L.cout_pad());
         for (int i = 0; i < L.cout_pad(); ++i) host[boff + i] = (b && i < cout) ? b[i] : 0.f;
-        pend.push_back({&L, off, boff});
+        size_t qoff = 0;
+        if (cin % 16 == 0) {  // k-permuted image for the direct-load kernel
+            qoff = (host.size() + 63) & ~size_t(63);
+            host.resize(qoff + L.kperm_floats());
+            pack_weights_kperm(W, cin, cout, L.ntb, host.data() + qoff);
+        }
+        pend.push_back({&L, off, boff, qoff});
     };
     size_t si = 0;
     auto W = [&](size_t i) { return blob + net->specs[i].w_off; };
@@ -234,6 +240,7 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
     for (auto& p : pend) {
         p.L->wp = net->wbuf.as<float>() + p.wp_off;
         p.L->bias = net->wbuf.as<float>() + p.b_off;
+        p.L->wq = p.wq_off ? net->wbuf.as<float>() + p.wq_off : nullptr;
     }
     net->have_weights = true;
     return PS_OK;

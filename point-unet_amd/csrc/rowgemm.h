@@ -16,8 +16,14 @@ namespace ps {
 // Weights packed on the host into MFMA B-fragment order (see pack_weights() in rowgemm.hip):
 //   for column block cb (NTB*16 output channels), k-step s (4 input channels), lane l, tile j:
 //     wp[((cb*KS + s)*64 + l)*NTB + j] = W[s*4 + (l>>4)][(cb*NTB + j)*16 + (l&15)]      (0 outside W)
+// A second packing ("k-permuted", pack_weights_kperm) serves the direct-load kernel, whose lanes read 16 CONTIGUOUS
+// input channels of their row straight from global memory: within a 64-channel chunk c, lane group g = lane>>4 owns
+// channels [c*64 + 16g, c*64 + 16g + 16) and k-step s multiplies channel c*64 + 16g + s:
+//     wq[((((cb*NC + c)*16 + s)*64 + l)*NTB) + j] = W[c*64 + 16*(l>>4) + s][(cb*NTB + j)*16 + (l&15)]
+// (the sum over k is the same set of products in a different order).
 struct PackedLinear {
     const float* wp = nullptr;  // device
+    const float* wq = nullptr;  // device, k-permuted image (nullptr when cin % 16 != 0)
     const float* bias = nullptr;  // device [cout_pad] (zeros when the layer has no bias)
     int cin = 0, cout = 0;
     int ks = 0;       // k-steps = ceil(cin/4)
@@ -25,6 +31,8 @@ struct PackedLinear {
     int cblocks = 0;  // ceil(cout / (16*ntb))
     int leaky = 0;
     size_t packed_floats() const { return (size_t)cblocks * ks * 64 * ntb; }
+    int nchunks() const { return (cin + 63) / 64; }
+    size_t kperm_floats() const { return (size_t)cblocks * nchunks() * 16 * 64 * ntb; }
     int cout_pad() const { return cblocks * ntb * 16; }
 };
 
@@ -32,6 +40,7 @@ inline int choose_ntb(int cout) { return cout >= 64 ? 4 : (cout >= 32 ? 2 : 1); 
 
 // Host-side packing: W is row-major [cin, cout]; out must hold packed_floats() floats.
 void pack_weights(const float* W, int cin, int cout, int ntb, float* out);
+void pack_weights_kperm(const float* W, int cin, int cout, int ntb, float* out);
 
 struct RowSrc {
     const float* x = nullptr;

@@ -1,36 +1,24 @@
-// rowgemm.hip -- see rowgemm.h.  One wave owns a 16-row x (NTB*16)-column output tile:
-//   A (16 rows x 64-channel chunk) is staged row-major into a per-wave LDS tile with a 66-float row pitch, so the
-//     MFMA A-fragment read  A[lane&15][4s + (lane>>4)]  hits 32 distinct banks (pitch = 2 mod 32);
-//   B comes straight from the host-packed fragment-order weights: one coalesced 4*NTB-byte load per lane per
-//     k-step feeds NTB MFMAs (weights are tiny and stay L1/L2 resident);
-//   the epilogue adds the bias, applies LeakyReLU(0.2) and stores 64-byte row segments.
+// rowgemm.hip -- see rowgemm.h.  Two kernels, both on v_mfma_f32_16x16x4_f32 with a 16-row x (NTB*16)-column
+// output tile per wave:
+//
+//  rowgemm_direct_kernel (every layer whose channel counts are multiples of 16)
+//     no LDS: each lane reads 16 contiguous input channels of its row with four 16-byte loads per 64-channel
+//     chunk (next chunk prefetched into registers while the current one feeds 64 MFMAs); the B fragments come from
+//     the k-permuted packed weights, one coalesced 4*NTB-byte load per lane per k-step, reused by RT row tiles.
+//     SPLITK: for the deep levels (a few hundred rows, 256..1536 input channels) the four waves of a workgroup
+//     take interleaved chunks of the SAME tile and reduce through LDS, which quadruples the waves in flight.
+//  rowgemm_kernel (generic: level 0 / fc0 shapes such as 7->8, 10->8, 24->32)
+//     A staged through a per-wave LDS tile (pitch 66 floats: conflict-free A-fragment reads).
+//
 // Bound: HBM for the wide-N / narrow-C layers (level 0, decoder tail, head), fp32 MFMA for the deep layers.
 #include "rowgemm.h"
 
+#include "mfma_tile.h"
+
 namespace ps {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-constexpr int kKC = 64;      // channels staged per chunk
-constexpr int kPitch = 66;   // LDS row pitch in floats
-
-// LDS hand-off between the lanes of ONE wave: DS operations of a wave execute in order, so only the compiler
-// has to be kept from moving LDS accesses across this point.
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int NTB>
-struct BFrag;
-template <>
-struct BFrag<1> { using type = float; };
-template <>
-struct BFrag<2> { using type = float2; };
-template <>
-struct BFrag<4> { using type = float4; };
+constexpr int kKC = 64;      // channels per chunk
+constexpr int kPitch = 66;   // LDS row pitch in floats (generic kernel)
 
 struct RowGemmArgs {
     const float* x1; const int32_t* g1; int ld1, c1; int g1m, g1n;
@@ -40,6 +28,131 @@ struct RowGemmArgs {
     int cin, cout, ks, R, leaky;
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+template <int NTB, int RT, bool SPLITK>
+__global__ __launch_bounds__(256) void rowgemm_direct_kernel(RowGemmArgs a)
+{
+    using bfrag = typename BFrag<NTB>::type;
+    __shared__ float red[SPLITK ? 4 * NTB * 4 * 64 : 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int arow = lane & 15, g = lane >> 4;
+    const int tile = SPLITK ? blockIdx.x : blockIdx.x * 4 + wave;
+    const int row0 = tile * (16 * RT);
+    if (!SPLITK && row0 >= a.R) return;
+    const int cb = blockIdx.y;
+    const int nchunks = (a.cin + 63) >> 6;
+
+    // per-lane row base pointers (both sources), clamped rows for the tail
+    const float* p1[RT];
+    const float* p2[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int r = min(row0 + rt * 16 + arow, a.R - 1);
+        const int s1 = a.g1 ? (a.g1m ? (r / a.g1m) * a.g1n : 0) + a.g1[r] : r;
+        p1[rt] = a.x1 + (size_t)s1 * a.ld1;
+        if (a.c2) {
+            const int s2 = a.g2 ? (a.g2m ? (r / a.g2m) * a.g2n : 0) + a.g2[r] : r;
+            p2[rt] = a.x2 + (size_t)s2 * a.ld2 - a.c1;  // indexed by the concatenated channel number
+        } else
+            p2[rt] = p1[rt];
+    }
+    auto load_chunk = [&](int c, float4 (&v)[RT][4]) {
+        const int k = c * 64 + g * 16;  // this lane's 16 channels (one source: c1 % 16 == 0)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            if (k < a.cin) {
+                const float4* src = reinterpret_cast<const float4*>((k < a.c1 ? p1[rt] : p2[rt]) + k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[rt][i] = src[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[rt][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+
+    f32x4 acc[RT][NTB];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bfrag* wq = reinterpret_cast<const bfrag*>(a.wp) + (size_t)cb * nchunks * 16 * 64 + lane;
+    const int c_begin = SPLITK ? wave : 0, c_step = SPLITK ? 4 : 1;
+    float4 cur[RT][4], nxt[RT][4];
+    if (c_begin < nchunks) load_chunk(c_begin, cur);
+    for (int c = c_begin; c < nchunks; c += c_step) {
+        if (c + c_step < nchunks) load_chunk(c + c_step, nxt);
+        const bfrag* w = wq + (size_t)c * 16 * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bfrag b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[q] = w[(size_t)(i * 4 + q) * 64];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const float av = q == 0 ? cur[rt][i].x : (q == 1 ? cur[rt][i].y : (q == 2 ? cur[rt][i].z : cur[rt][i].w));
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j)
+                        acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bfrag_get<NTB>(b[q], j), acc[rt][j], 0, 0, 0);
+                }
+        }
+        if (c + c_step < nchunks) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur[rt][i] = nxt[rt][i];
+        }
+    }
+
+    if constexpr (SPLITK) {
+        // (RT == 1) reduce the four partial tiles through LDS; wave w finishes n-tiles w, w+4, ...
+        static_assert(!SPLITK || RT == 1, "split-K uses one row tile");
+#pragma unroll
+        for (int j = 0; j < NTB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((wave * NTB + j) * 4 + r) * 64 + lane] = acc[0][j][r];
+        __syncthreads();
+        for (int j = wave; j < NTB; j += 4) {
+            const int col = (cb * NTB + j) * 16 + (lane & 15);
+            if (col >= a.cout) continue;
+            const float bb = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + g * 4 + r;
+                if (row < a.R) {
+                    float v = bb;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v += red[((w * NTB + j) * 4 + r) * 64 + lane];
+                    if (a.leaky) v = leaky02(v);
+                    a.y[(size_t)row * a.ldy + col] = v;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) {
+            const int col = (cb * NTB + j) * 16 + (lane & 15);
+            if (col >= a.cout) continue;
+            const float bb = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + rt * 16 + g * 4 + r;
+                    if (row < a.R) {
+                        float v = acc[rt][j][r] + bb;
+                        if (a.leaky) v = leaky02(v);
+                        a.y[(size_t)row * a.ldy + col] = v;
+                    }
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 template <int NTB>
 __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a)
 {
@@ -90,17 +203,8 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a)
         for (int s = 0; s < steps; ++s) {
             const float av = tile[arow * kPitch + s * 4 + ag];
             const bfrag bv = wps[(size_t)s * 64];
-            if constexpr (NTB == 1) {
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[0], 0, 0, 0);
-            } else if constexpr (NTB == 2) {
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.y, acc[1], 0, 0, 0);
-            } else {
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.y, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.z, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.w, acc[3], 0, 0, 0);
-            }
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bfrag_get<NTB>(bv, j), acc[j], 0, 0, 0);
         }
         wave_lds_sync();
     }
@@ -116,7 +220,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a)
             const int row = row0 + (lane >> 4) * 4 + r;
             if (row < a.R) {
                 float v = acc[j][r] + b;
-                if (a.leaky) v = v >= 0.f ? v : 0.2f * v;
+                if (a.leaky) v = leaky02(v);
                 a.y[(size_t)row * a.ldy + col] = v;
             }
         }
@@ -138,6 +242,24 @@ void pack_weights(const float* W, int cin, int cout, int ntb, float* out)
                 }
 }
 
+void pack_weights_kperm(const float* W, int cin, int cout, int ntb, float* out)
+{
+    const int nc = (cin + 63) / 64;
+    const int cblocks = (cout + 16 * ntb - 1) / (16 * ntb);
+    for (int cb = 0; cb < cblocks; ++cb)
+        for (int c = 0; c < nc; ++c)
+            for (int s = 0; s < 16; ++s)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < ntb; ++j) {
+                        const int k = c * 64 + 16 * (l >> 4) + s;
+                        const int col = (cb * ntb + j) * 16 + (l & 15);
+                        const float v = (k < cin && col < cout) ? W[(size_t)k * cout + col] : 0.f;
+                        out[((((size_t)cb * nc + c) * 16 + s) * 64 + l) * ntb + j] = v;
+                    }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 int rowgemm(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc& s2, int64_t R, float* y, int ldy)
 {
     if (R <= 0) return PS_OK;
@@ -149,12 +271,40 @@ int rowgemm(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc
     a.wp = L.wp; a.bias = L.bias;
     a.y = y; a.ldy = ldy;
     a.cin = L.cin; a.cout = L.cout; a.ks = L.ks; a.R = (int)R; a.leaky = L.leaky;
-    dim3 grid(ceil_div(R, 64), L.cblocks);
-    switch (L.ntb) {
-        case 1: hipLaunchKernelGGL(rowgemm_kernel<1>, grid, dim3(256), 0, c->stream, a); break;
-        case 2: hipLaunchKernelGGL(rowgemm_kernel<2>, grid, dim3(256), 0, c->stream, a); break;
-        case 4: hipLaunchKernelGGL(rowgemm_kernel<4>, grid, dim3(256), 0, c->stream, a); break;
-        default: set_error("rowgemm: bad ntb %d", L.ntb); return PS_EINVAL;
+
+    const bool direct = L.wq && L.cin % 16 == 0 && s1.c % 16 == 0 && s1.ld % 4 == 0 && aligned16(s1.x) &&
+                        (s2.c == 0 || (s2.ld % 4 == 0 && aligned16(s2.x)));
+    if (direct) {
+        a.wp = L.wq;
+        const int64_t tiles16 = (R + 15) / 16;
+        const bool splitk = L.cin >= 256 && tiles16 * L.cblocks < 2048;
+        const bool rt2 = !splitk && tiles16 * L.cblocks >= 8192;
+#define PS_LAUNCH(NTB, RT, SK, GX)                                                                                             \
+    hipLaunchKernelGGL((rowgemm_direct_kernel<NTB, RT, SK>), dim3((unsigned)(GX), L.cblocks), dim3(256), 0, c->stream, a)
+#define PS_BY_NTB(RT, SK, GX)                                    \
+    switch (L.ntb) {                                             \
+        case 1: PS_LAUNCH(1, RT, SK, GX); break;                 \
+        case 2: PS_LAUNCH(2, RT, SK, GX); break;                 \
+        case 4: PS_LAUNCH(4, RT, SK, GX); break;                 \
+        default: set_error("rowgemm: bad ntb %d", L.ntb); return PS_EINVAL; \
+    }
+        if (splitk) {
+            PS_BY_NTB(1, true, tiles16)
+        } else if (rt2) {
+            PS_BY_NTB(2, false, (tiles16 + 7) / 8)
+        } else {
+            PS_BY_NTB(1, false, (tiles16 + 3) / 4)
+        }
+#undef PS_BY_NTB
+#undef PS_LAUNCH
+    } else {
+        dim3 grid(ceil_div(R, 64), L.cblocks);
+        switch (L.ntb) {
+            case 1: hipLaunchKernelGGL(rowgemm_kernel<1>, grid, dim3(256), 0, c->stream, a); break;
+            case 2: hipLaunchKernelGGL(rowgemm_kernel<2>, grid, dim3(256), 0, c->stream, a); break;
+            case 4: hipLaunchKernelGGL(rowgemm_kernel<4>, grid, dim3(256), 0, c->stream, a); break;
+            default: set_error("rowgemm: bad ntb %d", L.ntb); return PS_EINVAL;
+        }
     }
     PS_HIP(hipGetLastError());
     return PS_OK;
