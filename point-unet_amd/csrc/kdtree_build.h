@@ -21,6 +21,7 @@ struct TreeSetPlan {
     int32_t* d_flags = nullptr;      // [16] error flags, zeroed by build_trees
     void* d_scratch = nullptr;       // builder scratch
     size_t scratch_bytes = 0;
+    std::vector<char> host_blob;     // host staging of the builder's tables (must outlive the async copies)
 
     void add(int32_t count)
     {
@@ -47,7 +48,10 @@ struct TreeSetPlan {
     }
 };
 
-// Builds every tree of the plan on the context's stream.
+// Builds every tree of the plan on the context's stream WITHOUT synchronising.  d_flags[2] receives the number of
+// nodes still waiting after the blind level launches; if the caller finds it non-zero after its own synchronisation it
+// must call build_trees_continue() and redo whatever it ran on the unfinished trees.
 int build_trees(ps_context* c, TreeSetPlan& plan);
+int build_trees_continue(ps_context* c, TreeSetPlan& plan);
 
 }  // namespace ps

@@ -67,6 +67,7 @@ __device__ __forceinline__ float comp(const float4& p, int ax) { return ax == 0 
 // ---- init -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void init_points_kernel(const BuildTree* __restrict__ trees, int chunks_x)
 {
+    __shared__ float s_mn[4][3], s_mx[4][3];
     const BuildTree t = trees[blockIdx.y];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < t.n; i += chunks_x * 256) {
@@ -82,9 +83,16 @@ __global__ __launch_bounds__(256) void init_points_kernel(const BuildTree* __res
             mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
             mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
         }
-        if ((threadIdx.x & 63) == 0 && mn[a] <= mx[a]) {
-            atomicMin(&t.bbox_ord[a], f2ord(mn[a]));
-            atomicMax(&t.bbox_ord[3 + a], f2ord(mx[a]));
+        if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6][a] = mn[a]; s_mx[threadIdx.x >> 6][a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {  // one pair of atomics per axis per workgroup
+        const int a = threadIdx.x;
+        const float lo = fminf(fminf(s_mn[0][a], s_mn[1][a]), fminf(s_mn[2][a], s_mn[3][a]));
+        const float hi = fmaxf(fmaxf(s_mx[0][a], s_mx[1][a]), fmaxf(s_mx[2][a], s_mx[3][a]));
+        if (lo <= hi) {
+            atomicMin(&t.bbox_ord[a], f2ord(lo));
+            atomicMax(&t.bbox_ord[3 + a], f2ord(hi));
         }
     }
 }
@@ -197,19 +205,22 @@ __device__ __forceinline__ void link_to_parent(const BuildTree& t, const BuildTa
 }
 
 // ---- level kernel: one workgroup per big node ------------------------------------------------------------------
+// Every pass walks the node in slabs of T*E records; thread t owns E CONSECUTIVE records of a slab (a wave covers
+// 8 KiB of contiguous memory, all eight 16-byte loads of a lane are independent and in flight together), so the
+// order-preserving ranks of the Hoare sweeps need one block scan per slab.
+constexpr int kE = 8;
+
 template <int T>
 struct BlockRed {
     float mn[T / 64][3], mx[T / 64][3];
     int ia[T / 64], ib[T / 64];
     float fa[T / 64], fb[T / 64];
-    int wave_tot[T / 64];
-    int bcast[8];
-    float fbcast[8];
+    int scan[2][T / 64];
 };
 
 __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTree* __restrict__ trees, BuildQueues Q, int level)
 {
-    constexpr int T = kBigThreads, W = T / 64;
+    constexpr int T = kBigThreads, W = T / 64, E = kE;
     __shared__ BlockRed<T> S;
     const int n_tasks = min(Q.level_cnt[level], Q.q_cap);
     if ((int)blockIdx.x >= n_tasks) return;
@@ -221,11 +232,16 @@ __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTre
 
     // ---- pass 1: min / max of the three axes ----
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = tid; i < count; i += T) {
-        const float4 p = a[i];
-        mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
-        mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
-        mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+    for (int base = tid; base < count; base += T * E) {  // coalesced: record base + e*T
+        float4 p[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) p[e] = a[min(base + e * T, count - 1)];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            mn[0] = fminf(mn[0], p[e].x); mx[0] = fmaxf(mx[0], p[e].x);
+            mn[1] = fminf(mn[1], p[e].y); mx[1] = fmaxf(mx[1], p[e].y);
+            mn[2] = fminf(mn[2], p[e].z); mx[2] = fmaxf(mx[2], p[e].z);
+        }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -249,12 +265,18 @@ __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTre
     // ---- pass 2: lim1 = #(< cut), lim2 = #(<= cut), max{v < cut}, min{v > cut} ----
     int lt = 0, le = 0;
     float maxlt = -INFINITY, mingt = INFINITY;
-    for (int i = tid; i < count; i += T) {
-        const float v = comp(a[i], ax);
-        lt += v < cut;
-        le += v <= cut;
-        if (v < cut) maxlt = fmaxf(maxlt, v);
-        if (v > cut) mingt = fminf(mingt, v);
+    for (int base = tid; base < count; base += T * E) {
+        float v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = comp(a[min(base + e * T, count - 1)], ax);
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (base + e * T < count) {
+                lt += v[e] < cut;
+                le += v[e] <= cut;
+                if (v[e] < cut) maxlt = fmaxf(maxlt, v[e]);
+                if (v[e] > cut) mingt = fminf(mingt, v[e]);
+            }
     }
     for (int o = 32; o > 0; o >>= 1) {
         lt += __shfl_xor(lt, o);
@@ -262,7 +284,6 @@ __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTre
         maxlt = fmaxf(maxlt, __shfl_xor(maxlt, o));
         mingt = fminf(mingt, __shfl_xor(mingt, o));
     }
-    __syncthreads();  // S.mn/S.mx reads above are done
     if (lane == 0) { S.ia[wave] = lt; S.ib[wave] = le; S.fa[wave] = maxlt; S.fb[wave] = mingt; }
     __syncthreads();
     lt = 0; le = 0; maxlt = -INFINITY; mingt = INFINITY;
@@ -279,33 +300,54 @@ __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTre
     for (int sweep = 0; sweep < 2; ++sweep) {
         const int from = sweep == 0 ? 0 : lim1, bound = sweep == 0 ? lim1 : lim2;
         int offL = 0, offR = 0;
-        for (int s0 = from; s0 < count; s0 += T) {
-            const int p = s0 + tid;
-            bool isL = false, isR = false;
-            if (p < count) {
-                const float v = comp(a[p], ax);
-                const bool keep_left = sweep == 0 ? (v < cut) : (v <= cut);
-                isL = p < bound && !keep_left;
-                isR = p >= bound && keep_left;
+        int slab = 0;
+        for (int s0 = from; s0 < count; s0 += T * E, ++slab) {
+            // wave w owns records [s0 + w*64*E, +64*E); lane reads record  wbase + e*64 + lane  (coalesced), so the
+            // position order inside the wave is e-major and ranks come from E ballots
+            const int wbase = s0 + wave * (64 * E);
+            unsigned long long bL[E], bR[E];
+            {
+                float v[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = comp(a[min(wbase + e * 64 + lane, count - 1)], ax);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int p = wbase + e * 64 + lane;
+                    bool isL = false, isR = false;
+                    if (p < count) {
+                        const bool keep_left = sweep == 0 ? (v[e] < cut) : (v[e] <= cut);
+                        isL = p < bound && !keep_left;
+                        isR = p >= bound && keep_left;
+                    }
+                    bL[e] = __ballot(isL);
+                    bR[e] = __ballot(isR);
+                }
             }
-            const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
-            const unsigned long long lt_mask = (1ull << lane) - 1ull;
-            const int rL = __popcll(bL & lt_mask), rR = __popcll(bR & lt_mask);
-            __syncthreads();  // previous iteration's reads of S.wave_tot / S.ia are done
-            if (lane == 0) { S.wave_tot[wave] = __popcll(bL); S.ia[wave] = __popcll(bR); }
+            int wL = 0, wR = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) { wL += __popcll(bL[e]); wR += __popcll(bR[e]); }
+            if (lane == 0) S.scan[slab & 1][wave] = wL | (wR << 16);
             __syncthreads();
-            int preL = 0, preR = 0, totL = 0, totR = 0;
+            int pre = 0, tot = 0;
             for (int w = 0; w < W; ++w) {
-                const int cl = S.wave_tot[w], cr = S.ia[w];
-                if (w < wave) { preL += cl; preR += cr; }
-                totL += cl; totR += cr;
+                const int cw = S.scan[slab & 1][w];
+                if (w < wave) pre += cw;
+                tot += cw;
             }
-            if (isL) t.posL[k.l + offL + preL + rL] = p;
-            if (isR) t.posR[k.l + offR + preR + rR] = p;
-            offL += totL;
-            offR += totR;
+            int rL = offL + (pre & 0xffff), rR = offR + (pre >> 16);
+            const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int p = wbase + e * 64 + lane;
+                if ((bL[e] >> lane) & 1ull) t.posL[k.l + rL + __popcll(bL[e] & lt_mask)] = p;
+                if ((bR[e] >> lane) & 1ull) t.posR[k.l + rR + __popcll(bR[e] & lt_mask)] = p;
+                rL += __popcll(bL[e]);
+                rR += __popcll(bR[e]);
+            }
+            offL += tot & 0xffff;
+            offR += tot >> 16;
         }
-        __syncthreads();  // (global posL/posR written by this workgroup are read below by other waves of it)
+        __syncthreads();  // posL / posR written by this workgroup are read below by other waves of it
         const int m = offL;  // == offR
         for (int i = tid; i < m; i += T) {
             const int pl = t.posL[k.l + i], pr = t.posR[k.l + m - 1 - i];
@@ -336,15 +378,112 @@ struct SubTask {
     float lo[3], hi[3];
 };
 
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct SubSplit {
+    int ax, lim1, lim2;
+    float cut, maxlt, mingt;
+};
+
+// Partitions P[0, count) (count <= 64*E) in place exactly like planeSplit and returns the split facts.
+template <int E>
+__device__ __forceinline__ SubSplit split_in_lds(float4* P, int count, const float* lo, const float* hi, short* posL, short* posR, int lane)
+{
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float4 rec[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * 64 + lane;
+        if (i < count) {
+            rec[e] = P[i];
+            mn[0] = fminf(mn[0], rec[e].x); mx[0] = fmaxf(mx[0], rec[e].x);
+            mn[1] = fminf(mn[1], rec[e].y); mx[1] = fmaxf(mx[1], rec[e].y);
+            mn[2] = fminf(mn[2], rec[e].z); mx[2] = fmaxf(mx[2], rec[e].z);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        }
+    const SplitChoice sc = choose_split(lo, hi, mn, mx);
+    SubSplit r;
+    r.ax = sc.ax;
+    r.cut = sc.cut;
+    const float cut = sc.cut;
+    float v[E];
+    r.lim1 = 0;
+    r.lim2 = 0;
+    r.maxlt = -INFINITY;
+    r.mingt = INFINITY;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool in = e * 64 + lane < count;
+        v[e] = in ? comp(rec[e], sc.ax) : 0.f;
+        r.lim1 += __popcll(__ballot(in && v[e] < cut));
+        r.lim2 += __popcll(__ballot(in && v[e] <= cut));
+        if (in && v[e] < cut) r.maxlt = fmaxf(r.maxlt, v[e]);
+        if (in && v[e] > cut) r.mingt = fminf(r.mingt, v[e]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        r.maxlt = fmaxf(r.maxlt, __shfl_xor(r.maxlt, o));
+        r.mingt = fminf(r.mingt, __shfl_xor(r.mingt, o));
+    }
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        const int from = sweep == 0 ? 0 : r.lim1, bound = sweep == 0 ? r.lim1 : r.lim2;
+        int offL = 0, offR = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = e * 64 + lane;
+            bool isL = false, isR = false;
+            if (i < count && i >= from) {
+                const bool keep_left = sweep == 0 ? (v[e] < cut) : (v[e] <= cut);
+                isL = i < bound && !keep_left;
+                isR = i >= bound && keep_left;
+            }
+            const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
+            if (isL) posL[offL + __popcll(bL & lt_mask)] = (short)i;
+            if (isR) posR[offR + __popcll(bR & lt_mask)] = (short)i;
+            offL += __popcll(bL);
+            offR += __popcll(bR);
+        }
+        if (offL == 0) continue;  // wave-uniform: nothing misplaced in this sweep
+        wave_sync_lds();
+        const int m = offL;
+        for (int i = lane; i < m; i += 64) {
+            const int pl = posL[i], pr = posR[m - 1 - i];
+            const float4 x = P[pl], y = P[pr];
+            P[pl] = y;
+            P[pr] = x;
+        }
+        wave_sync_lds();
+        if (sweep == 0) {
+            // the records moved: refresh the cached split-axis values for the second sweep
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = e * 64 + lane;
+                v[e] = i < count ? comp(P[i], sc.ax) : 0.f;
+            }
+        }
+    }
+    return r;
+}
+
 __global__ __launch_bounds__(256) void build_subtree_kernel(const BuildTree* __restrict__ trees, BuildQueues Q)
 {
-    constexpr int WPB = 4, E = kSmall / 64;
+    constexpr int WPB = 4;
     __shared__ float4 s_pts[WPB][kSmall];
     __shared__ short s_posL[WPB][kSmall], s_posR[WPB][kSmall];
     __shared__ SubTask s_stack[WPB][kSubStack];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_tasks = min(*Q.small_cnt, Q.small_cap);
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     float4* P = s_pts[wave];
     short* posL = s_posL[wave];
     short* posR = s_posR[wave];
@@ -355,18 +494,15 @@ __global__ __launch_bounds__(256) void build_subtree_kernel(const BuildTree* __r
         const BuildTree t = trees[k.tree];
         const int total = k.r - k.l;
         for (int i = lane; i < total; i += 64) P[i] = t.pts[k.l + i];
-        int sp = 0;
         if (lane == 0) {
             SubTask r;
             r.l = 0; r.r = (short)total; r.parent = k.parent; r.side = (short)k.side; r.level = (short)k.level;
             for (int c = 0; c < 3; ++c) { r.lo[c] = k.lo[c]; r.hi[c] = k.hi[c]; }
             stack[0] = r;
         }
-        sp = 1;
+        int sp = 1;
         int max_level = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_sync_lds();
         while (sp > 0) {
             --sp;
             const SubTask u = stack[sp];
@@ -382,113 +518,43 @@ __global__ __launch_bounds__(256) void build_subtree_kernel(const BuildTree* __r
                 max_level = max(max_level, (int)u.level);
                 continue;
             }
-            // min / max
-            float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int i = e * 64 + lane;
-                if (i < count) {
-                    const float4 p = P[l + i];
-                    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
-                    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
-                    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                for (int o = 32; o > 0; o >>= 1) {
-                    mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
-                    mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
-                }
-            const SplitChoice sc = choose_split(u.lo, u.hi, mn, mx);
-            const int ax = sc.ax;
-            const float cut = sc.cut;
-            float v[E];
-            int lim1 = 0, lim2 = 0;
-            float maxlt = -INFINITY, mingt = INFINITY;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int i = e * 64 + lane;
-                const bool in = i < count;
-                v[e] = in ? comp(P[l + i], ax) : 0.f;
-                lim1 += __popcll(__ballot(in && v[e] < cut));
-                lim2 += __popcll(__ballot(in && v[e] <= cut));
-                if (in && v[e] < cut) maxlt = fmaxf(maxlt, v[e]);
-                if (in && v[e] > cut) mingt = fminf(mingt, v[e]);
-            }
-            for (int o = 32; o > 0; o >>= 1) {
-                maxlt = fmaxf(maxlt, __shfl_xor(maxlt, o));
-                mingt = fminf(mingt, __shfl_xor(mingt, o));
-            }
-            for (int sweep = 0; sweep < 2; ++sweep) {
-                const int from = sweep == 0 ? 0 : lim1, bound = sweep == 0 ? lim1 : lim2;
-                int offL = 0, offR = 0;
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int i = e * 64 + lane;
-                    bool isL = false, isR = false;
-                    if (i < count && i >= from) {
-                        const bool keep_left = sweep == 0 ? (v[e] < cut) : (v[e] <= cut);
-                        isL = i < bound && !keep_left;
-                        isR = i >= bound && keep_left;
-                    }
-                    const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
-                    if (isL) posL[offL + __popcll(bL & lt_mask)] = (short)i;
-                    if (isR) posR[offR + __popcll(bR & lt_mask)] = (short)i;
-                    offL += __popcll(bL);
-                    offR += __popcll(bR);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int m = offL;
-                for (int i = lane; i < m; i += 64) {
-                    const int pl = posL[i], pr = posR[m - 1 - i];
-                    const float4 x = P[l + pl], y = P[l + pr];
-                    P[l + pl] = y;
-                    P[l + pr] = x;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (sweep == 0) {
-                    // the records moved: refresh the cached split-axis values for the second sweep
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const int i = e * 64 + lane;
-                        v[e] = i < count ? comp(P[l + i], ax) : 0.f;
-                    }
-                }
-            }
+            SubSplit sr;
+            if (count <= 64) sr = split_in_lds<1>(P + l, count, u.lo, u.hi, posL, posR, lane);
+            else if (count <= 128) sr = split_in_lds<2>(P + l, count, u.lo, u.hi, posL, posR, lane);
+            else sr = split_in_lds<4>(P + l, count, u.lo, u.hi, posL, posR, lane);
             const int half = count / 2;
-            const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
+            const int idx = sr.lim1 > half ? sr.lim1 : (sr.lim2 < half ? sr.lim2 : half);
             const int m = k.l + l + idx;
             const int id = 2 * m - 1;
             if (lane == 0) {
-                const float divlow = idx > lim1 ? cut : maxlt;
-                const float divhigh = idx < lim2 ? cut : mingt;
-                t.nodes[id] = make_int4((int)((unsigned)ax << 30), 0, __float_as_int(divlow), __float_as_int(divhigh));
+                const float divlow = idx > sr.lim1 ? sr.cut : sr.maxlt;
+                const float divhigh = idx < sr.lim2 ? sr.cut : sr.mingt;
+                t.nodes[id] = make_int4((int)((unsigned)sr.ax << 30), 0, __float_as_int(divlow), __float_as_int(divhigh));
                 if (u.parent < 0) t.meta->root = id;
                 else if (u.side == 0) atomicOr(&t.nodes[u.parent].x, id);
                 else t.nodes[u.parent].y = id;
                 SubTask c0 = u, c1 = u;
-                c0.r = (short)(l + idx); c0.hi[ax] = cut; c0.parent = id; c0.side = 0; c0.level = (short)(u.level + 1);
-                c1.l = (short)(l + idx); c1.lo[ax] = cut; c1.parent = id; c1.side = 1; c1.level = (short)(u.level + 1);
+                c0.r = (short)(l + idx); c0.hi[sr.ax] = sr.cut; c0.parent = id; c0.side = 0; c0.level = (short)(u.level + 1);
+                c1.l = (short)(l + idx); c1.lo[sr.ax] = sr.cut; c1.parent = id; c1.side = 1; c1.level = (short)(u.level + 1);
                 stack[sp] = c1;
                 stack[sp + 1] = c0;
             }
             sp += 2;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            wave_sync_lds();
         }
         for (int i = lane; i < total; i += 64) t.pts[k.l + i] = P[i];
         if (lane == 0) atomicMax(&t.meta->depth, max_level);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_sync_lds();
     }
 }
+
+__global__ void pending_flag_kernel(const int32_t* __restrict__ level_cnt, int level, int32_t* __restrict__ flags)
+{
+    flags[2] = level >= 0 ? level_cnt[level] : 0;
+    if (level < 0) flags[0] = 0;  // stack-overflow marks left by searches over the unfinished trees
+}
+
+constexpr int kFastLevels = 16;
 
 // ---- host side -----------------------------------------------------------------------------------------------
 void TreeSetPlan::carve(Arena& a)
@@ -532,8 +598,10 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     BuildTask* d_small = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * small_cap));
     int32_t* d_cnt = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (kMaxLevels + 8)));
 
-    std::vector<BuildTree> h_trees(T);
-    std::vector<unsigned> h_bbox(8 * T);
+    // host staging lives in the plan (the caller keeps the plan alive until its final stream synchronisation)
+    plan.host_blob.resize(sizeof(BuildTree) * T + sizeof(unsigned) * 8 * T);
+    BuildTree* h_trees = reinterpret_cast<BuildTree*>(plan.host_blob.data());
+    unsigned* h_bbox = reinterpret_cast<unsigned*>(plan.host_blob.data() + sizeof(BuildTree) * T);
     size_t pos_off = 0;
     int32_t max_n = 0;
     for (size_t i = 0; i < T; ++i) {
@@ -554,12 +622,10 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
         }
     }
     hipStream_t st = c->stream;
-    PS_HIP(hipMemcpyAsync(d_trees, h_trees.data(), sizeof(BuildTree) * T, hipMemcpyHostToDevice, st));
-    PS_HIP(hipMemcpyAsync(d_bbox, h_bbox.data(), sizeof(unsigned) * 8 * T, hipMemcpyHostToDevice, st));
+    PS_HIP(hipMemcpyAsync(d_trees, h_trees, sizeof(BuildTree) * T, hipMemcpyHostToDevice, st));
+    PS_HIP(hipMemcpyAsync(d_bbox, h_bbox, sizeof(unsigned) * 8 * T, hipMemcpyHostToDevice, st));
     PS_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (kMaxLevels + 8), st));
     PS_HIP(hipMemsetAsync(plan.d_flags, 0, 16 * sizeof(int32_t), st));
-    // h_trees / h_bbox are pageable and die with this frame: make sure the copies have consumed them
-    PS_HIP(hipStreamSynchronize(st));
 
     BuildQueues Q;
     Q.q[0] = d_q;
@@ -571,23 +637,60 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     Q.q_cap = (int32_t)q_cap;
     Q.small_cap = (int32_t)small_cap;
 
-    const int chunks_x = std::max(1, std::min(ceil_div(max_n, 256 * 8), 256));
+    const int chunks_x = std::max(1, std::min(ceil_div(max_n, 256 * 4), 256));
     hipLaunchKernelGGL(init_points_kernel, dim3(chunks_x, (unsigned)T), dim3(256), 0, st, d_trees, chunks_x);
     hipLaunchKernelGGL(root_tasks_kernel, dim3(ceil_div(T, 64)), dim3(64), 0, st, d_trees, (int)T, Q);
-    // big levels: the number of tasks per level is device-side data; a level holds at most tot/kSmall disjoint big nodes.
+    // big levels: the number of tasks per level is device-side data; a level holds at most tot/kSmall disjoint big
+    // nodes.  kFastLevels level kernels are launched blind (surplus ones find an empty queue and exit); the count of
+    // still-pending big nodes goes to flags[2], which the caller reads at its own final synchronisation and, if it is
+    // not zero (a very unbalanced cloud), answers with build_trees_continue().
     const int grid_big = (int)std::min<size_t>(q_cap, tot / kSmall + T + 1);
-    int level = 0;
-    int batch = 14;
+    for (int level = 0; level < kFastLevels; ++level)
+        hipLaunchKernelGGL(build_level_kernel, dim3(grid_big), dim3(kBigThreads), 0, st, d_trees, Q, level);
+    hipLaunchKernelGGL(pending_flag_kernel, dim3(1), dim3(1), 0, st, d_cnt, kFastLevels, plan.d_flags);
+    hipLaunchKernelGGL(build_subtree_kernel, dim3(std::min<size_t>(ceil_div(small_cap, 4), 2048)), dim3(256), 0, st, d_trees, Q);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+int build_trees_continue(ps_context* c, TreeSetPlan& plan)
+{
+    const size_t T = plan.n.size();
+    const size_t tot = plan.total_points();
+    const size_t q_cap = tot / kSmall + 2 * T + 64, small_cap = tot / 4 + 2 * T + 1024;
+    char* base = static_cast<char*>(plan.d_scratch);
+    size_t off = 0;
+    auto take = [&](size_t b) { char* p = base + off; off += (b + 255) & ~size_t(255); return p; };
+    BuildTree* d_trees = reinterpret_cast<BuildTree*>(take(sizeof(BuildTree) * T));
+    take(sizeof(unsigned) * 8 * T);
+    take(sizeof(int32_t) * 2 * (tot + T));
+    BuildTask* d_q = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * q_cap * 2));
+    BuildTask* d_small = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * small_cap));
+    int32_t* d_cnt = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (kMaxLevels + 8)));
+    BuildQueues Q;
+    Q.q[0] = d_q;
+    Q.q[1] = d_q + q_cap;
+    Q.small_q = d_small;
+    Q.level_cnt = d_cnt;
+    Q.small_cnt = d_cnt + kMaxLevels;
+    Q.flags = plan.d_flags;
+    Q.q_cap = (int32_t)q_cap;
+    Q.small_cap = (int32_t)small_cap;
+    hipStream_t st = c->stream;
+    const int grid_big = (int)std::min<size_t>(q_cap, tot / kSmall + T + 1);
+    int level = kFastLevels;
     for (;;) {
-        for (int i = 0; i < batch && level < kMaxLevels - 1; ++i, ++level)
+        for (int i = 0; i < 8 && level < kMaxLevels - 1; ++i, ++level)
             hipLaunchKernelGGL(build_level_kernel, dim3(grid_big), dim3(kBigThreads), 0, st, d_trees, Q, level);
         int32_t pending = 0;
         PS_HIP(hipMemcpyAsync(&pending, d_cnt + level, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         PS_HIP(hipStreamSynchronize(st));
         if (pending == 0) break;
         PS_CHECK(level < kMaxLevels - 1, "kd-tree build: more than %d levels of nodes above %d points (degenerate cloud)", kMaxLevels, kSmall);
-        batch = 4;
     }
+    // The subtree kernel walks the WHOLE small queue again: re-splitting an already partitioned range moves nothing
+    // (no misplaced records), so the subtrees finished by the first run come out identical.
+    hipLaunchKernelGGL(pending_flag_kernel, dim3(1), dim3(1), 0, st, d_cnt, -1, plan.d_flags);
     hipLaunchKernelGGL(build_subtree_kernel, dim3(std::min<size_t>(ceil_div(small_cap, 4), 2048)), dim3(256), 0, st, d_trees, Q);
     PS_HIP(hipGetLastError());
     return PS_OK;

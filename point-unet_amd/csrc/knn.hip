@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const KnnJob* __restrict__ job
     const KnnJob& job = jobs[blockIdx.y];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= job.nq) return;
+    if (job.overflow[2] != 0) return;  // the tree builder has not finished (unbalanced cloud): the host re-runs us
     float qx, qy, qz;
     int row;
     if (job.q4) {
@@ -156,25 +157,30 @@ static int knn_batch_impl(ps_context* c, const float* support, const float* quer
         jobs[b].overflow = plan.d_flags;
     }
     PS_HIP(hipMemcpyAsync(plan.d_jobs, jobs.data(), sizeof(KnnJob) * B, hipMemcpyHostToDevice, c->stream));
-    {
-        Stage st(c, "knn_search", 1);
-        PS_TRY(launch_knn(c, reinterpret_cast<const KnnJob*>(plan.d_jobs), (int)B, (int)n2, (int)K));
+    int32_t flag[3] = {0, 0, 0};
+    for (int attempt = 0;; ++attempt) {
+        {
+            Stage st(c, "knn_search", 1);
+            PS_TRY(launch_knn(c, reinterpret_cast<const KnnJob*>(plan.d_jobs), (int)B, (int)n2, (int)K));
+        }
+        if (out64) {
+            hipLaunchKernelGGL(widen_kernel, dim3(ceil_div(out_count, 256)), dim3(256), 0, c->stream, d_out32, d_out64 ? d_out64 : out64,
+                               out_count);
+            PS_HIP(hipGetLastError());
+        }
+        if (!device_ptrs) {
+            if (out64)
+                PS_HIP(hipMemcpyAsync(out64, d_out64, out_count * 8, hipMemcpyDeviceToHost, c->stream));
+            else
+                PS_HIP(hipMemcpyAsync(out32, d_out32, out_count * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        PS_HIP(hipMemcpyAsync(flag, plan.d_flags, 12, hipMemcpyDeviceToHost, c->stream));
+        // (the job table and the plan's staging live in host memory of this frame: wait before returning)
+        PS_HIP(hipStreamSynchronize(c->stream));
+        if (flag[2] == 0 || attempt > 0) break;
+        PS_TRY(build_trees_continue(c, plan));  // very unbalanced cloud: finish the remaining levels, search again
     }
-    if (out64) {
-        hipLaunchKernelGGL(widen_kernel, dim3(ceil_div(out_count, 256)), dim3(256), 0, c->stream, d_out32, d_out64 ? d_out64 : out64,
-                           out_count);
-        PS_HIP(hipGetLastError());
-    }
-    int32_t flag[2] = {0, 0};
-    if (!device_ptrs) {
-        if (out64)
-            PS_HIP(hipMemcpyAsync(out64, d_out64, out_count * 8, hipMemcpyDeviceToHost, c->stream));
-        else
-            PS_HIP(hipMemcpyAsync(out32, d_out32, out_count * 4, hipMemcpyDeviceToHost, c->stream));
-    }
-    PS_HIP(hipMemcpyAsync(flag, plan.d_flags, 8, hipMemcpyDeviceToHost, c->stream));
-    // the job table lives in pageable host memory of this frame: wait before returning
-    PS_HIP(hipStreamSynchronize(c->stream));
+    PS_CHECK(flag[2] == 0, "ps_knn_batch: kd-tree build did not finish");
     PS_CHECK(flag[1] == 0, "ps_knn_batch: kd-tree builder queue overflow (degenerate cloud)");
     PS_CHECK(flag[0] == 0, "ps_knn_batch: kd-tree deeper than the %d-entry traversal stack", kStackMax);
     return PS_OK;
@@ -302,26 +308,31 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
     // hipMemcpyAsync returns for pageable sources, but we do not rely on it -- see the stream sync at the end.
     PS_HIP(hipMemcpyAsync(plan.d_jobs, jobs.data(), sizeof(KnnJob) * jobs.size(), hipMemcpyHostToDevice, c->stream));
     const KnnJob* dj = reinterpret_cast<const KnnJob*>(plan.d_jobs);
-    {
-        Stage st(c, "knn_search_k", 1);
-        PS_TRY(launch_knn(c, dj, (int)n_self, max_nq, K));
-    }
-    {
-        Stage st(c, "knn_search_1nn", 1);
-        PS_TRY(launch_knn(c, dj + n_self, (int)(jobs.size() - n_self), max_nq, 1));
-    }
-    {
-        Stage st(c, "pyramid_slices", L);
-        for (int l = 0; l < L; ++l) {
-            size_t tot = (size_t)B * n[l + 1] * K;
-            hipLaunchKernelGGL(slice_rows_i32_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, c->stream, pyr->neigh_idx[l], pyr->sub_idx[l],
-                               B, n[l], n[l + 1], K);
+    int32_t flag[3] = {0, 0, 0};
+    for (int attempt = 0;; ++attempt) {
+        {
+            Stage st(c, "knn_search_k", 1);
+            PS_TRY(launch_knn(c, dj, (int)n_self, max_nq, K));
         }
-        PS_HIP(hipGetLastError());
+        {
+            Stage st(c, "knn_search_1nn", 1);
+            PS_TRY(launch_knn(c, dj + n_self, (int)(jobs.size() - n_self), max_nq, 1));
+        }
+        {
+            Stage st(c, "pyramid_slices", L);
+            for (int l = 0; l < L; ++l) {
+                size_t tot = (size_t)B * n[l + 1] * K;
+                hipLaunchKernelGGL(slice_rows_i32_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, c->stream, pyr->neigh_idx[l], pyr->sub_idx[l],
+                                   B, n[l], n[l + 1], K);
+            }
+            PS_HIP(hipGetLastError());
+        }
+        PS_HIP(hipMemcpyAsync(flag, plan.d_flags, 12, hipMemcpyDeviceToHost, c->stream));
+        PS_HIP(hipStreamSynchronize(c->stream));
+        if (flag[2] == 0 || attempt > 0) break;
+        PS_TRY(build_trees_continue(c, plan));  // very unbalanced cloud: finish the remaining levels, search again
     }
-    int32_t flag[2] = {0, 0};
-    PS_HIP(hipMemcpyAsync(flag, plan.d_flags, 8, hipMemcpyDeviceToHost, c->stream));
-    PS_HIP(hipStreamSynchronize(c->stream));
+    PS_CHECK(flag[2] == 0, "ps_pyramid_build: kd-tree build did not finish");
     PS_CHECK(flag[1] == 0, "ps_pyramid_build: kd-tree builder queue overflow (degenerate cloud)");
     PS_CHECK(flag[0] == 0, "ps_pyramid_build: kd-tree deeper than the %d-entry traversal stack", kStackMax);
     return PS_OK;
@@ -347,6 +358,11 @@ extern "C" int ps_debug_kdtree_device(ps_context* c, const float* support, int64
     }
     plan.src[0] = c->stage_in.as<float>();
     PS_TRY(build_trees(c, plan));
+    int32_t flag[3] = {0, 0, 0};
+    PS_HIP(hipMemcpyAsync(flag, plan.d_flags, 12, hipMemcpyDeviceToHost, c->stream));
+    PS_HIP(hipStreamSynchronize(c->stream));
+    if (flag[2] != 0) PS_TRY(build_trees_continue(c, plan));
+    PS_CHECK(flag[1] == 0, "ps_debug_kdtree_device: builder queue overflow");
     TreeMeta m;
     PS_HIP(hipMemcpyAsync(nodes, plan.d_nodes[0], sizeof(int4) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     PS_HIP(hipMemcpyAsync(pts, plan.d_pts[0], sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, c->stream));

@@ -149,3 +149,14 @@ def test_device_tree_equals_host_tree(lib, case):
         assert np.array_equal(h[1][i], d[1][i]), i
         if i & 1:
             stack += [int(h[1][i, 0]) & 0x3fffffff, int(h[1][i, 1])]
+
+
+def test_unbalanced_cloud_takes_the_slow_build_path(oracle):
+    """A geometric progression along x makes every bounding-box-midpoint split peel ~2 % of the node: far more
+    levels of big nodes than the builder launches blind, so the continue path runs.  Results stay bit-exact."""
+    rng = np.random.default_rng(5)
+    n = 1100
+    p = np.stack([0.97 ** np.arange(n), 1e-3 * rng.random(n), 1e-3 * rng.random(n)], 1).astype(np.float32)
+    p = p[rng.permutation(n)]
+    for K in (1, 16):
+        assert np.array_equal(_knn_gpu(p[None], p[None], K), oracle.knn_batch(p[None], p[None], K))
