@@ -29,7 +29,11 @@ struct AttArgs {
     int n_total, n_cloud;
 };
 
-template <int D, int STAGE, int KN, int WAVES>
+// SPLITN = false: every wave owns a point (its own LDS tiles).  SPLITN = true (deep levels: few points, wide d):
+// the WAVES waves of a workgroup share ONE point and one pair of LDS tiles and split the output-column blocks of every
+// phase between them -- the per-point dependent MFMA chain gets WAVES times shorter and WAVES times more waves are in
+// flight (level 4 has 703 points for 1024 SIMDs).
+template <int D, int STAGE, int KN, int WAVES, bool SPLITN>
 __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
 {
     constexpr int H = D / 2, RT = KN / 16, PITCH = H + 2, LDF = H + D;
@@ -43,10 +47,16 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, c16 = lane & 15;
-    float* T1 = smem + wave * (KN * PITCH * (STAGE == 2 ? 2 : 1));
+    float* T1 = smem + (SPLITN ? 0 : wave) * (KN * PITCH * (STAGE == 2 ? 2 : 1));
     float* T2 = T1 + KN * PITCH;
+    constexpr int CB0_STEP = SPLITN ? WAVES : 1;
+    const int cb0 = SPLITN ? wave : 0;
+    auto phase_sync = [&]() {
+        if constexpr (SPLITN) __syncthreads();
+        else wave_lds_sync();
+    };
 
-    for (int p = blockIdx.x * WAVES + wave; p < a.n_total; p += gridDim.x * WAVES) {
+    for (int p = SPLITN ? blockIdx.x : blockIdx.x * WAVES + wave; p < a.n_total; p += SPLITN ? gridDim.x : gridDim.x * WAVES) {
         const int base = (p / a.n_cloud) * a.n_cloud;
         const float cx = a.xyz[3 * (size_t)p], cy = a.xyz[3 * (size_t)p + 1], cz = a.xyz[3 * (size_t)p + 2];
         int nb[RT];
@@ -63,7 +73,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
         }
         // ---- LFA mlp1: f_xyz1 = lrelu(enc10 . W1 + b1) -> T1 ----
 #pragma unroll
-        for (int cb = 0; cb < CB_H; ++cb) {
+        for (int cb = cb0; cb < CB_H; cb += CB0_STEP) {
             f32x4 acc[RT][NTB_H];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
@@ -91,11 +101,11 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
                 }
             }
         }
-        wave_lds_sync();
+        phase_sync();
         const float* TX = T1;
         if constexpr (STAGE == 2) {
             // ---- LFA mlp2: f_xyz2 = lrelu(f_xyz1 . W2 + b2) -> T2 ----
-            for (int cb = 0; cb < CB_H; ++cb) {
+            for (int cb = cb0; cb < CB_H; cb += CB0_STEP) {
                 f32x4 acc[RT][NTB_H];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
                     }
                 }
             }
-            wave_lds_sync();
+            phase_sync();
             TX = T2;
         }
         // neighbour row of C-layout row (g*4 + r): held by lane (g*4 + r) of group 0
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
             for (int r = 0; r < 4; ++r) jr[rt][r] = (size_t)__shfl(nb[rt], g * 4 + r) * LDF;
 
         // ---- scores, softmax over the K rows, weighted sum ----
-        for (int cb = 0; cb < CB_D; ++cb) {
+        for (int cb = cb0; cb < CB_D; cb += CB0_STEP) {
             f32x4 acc[RT][NTB_D];
 #pragma unroll
             for (int j = 0; j < NTB_D; ++j) {
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
                 if (g == 0) a.agg[(size_t)p * D + col] = num / ssum;
             }
         }
-        wave_lds_sync();  // T1/T2 are overwritten by the next point
+        phase_sync();  // T1/T2 are overwritten by the next point
     }
 }
 
@@ -169,10 +179,21 @@ static int launch_att(ps_context* c, const AttArgs& a)
 {
     constexpr int H = D / 2, PITCH = H + 2;
     constexpr size_t per_wave = (size_t)KN * PITCH * (STAGE == 2 ? 2 : 1) * sizeof(float);
+    if (D >= 256 && a.n_total < 16384) {
+        // one point per workgroup, the four waves split the column blocks
+        constexpr int WAVES = 4;
+        const size_t smem = per_wave;
+        auto kern = att_kernel<D, STAGE, KN, WAVES, true>;
+        if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const int blocks = std::min(a.n_total, 256 * 16);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
+        PS_HIP(hipGetLastError());
+        return PS_OK;
+    }
     constexpr int WAVES = per_wave * 4 <= 160 * 1024 ? 4 : (per_wave * 2 <= 160 * 1024 ? 2 : 1);
     static_assert(per_wave * WAVES <= 160 * 1024, "attention tile does not fit the LDS");
     const size_t smem = per_wave * WAVES;
-    auto kern = att_kernel<D, STAGE, KN, WAVES>;
+    auto kern = att_kernel<D, STAGE, KN, WAVES, false>;
     if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int blocks = std::min(ceil_div(a.n_total, WAVES), 256 * 8);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
