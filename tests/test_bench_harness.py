@@ -1,0 +1,61 @@
+"""The N>1 path of bench.py on CPU: two processes on the gloo backend run the timed-region helper with a stand-in
+step of rank-dependent duration; both must agree on the MAX-over-ranks time and rank 0's whole-job value must count
+both ranks' clouds (weak scaling, no data-path collective)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    def step():
+        time.sleep(0.02 * (rank + 1))       # rank 1 is the slow one
+        return rank
+    elapsed, last = bench.timed_region(step, 5, lambda: None, dist)
+    value = bench.whole_job_value(world, 1, 1000, 5, elapsed)
+    print(json.dumps({"rank": rank, "world": world, "elapsed": elapsed, "value": value, "last": last}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+""") % ROOT
+
+
+def test_two_rank_timed_region_takes_the_max_over_ranks(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [json.loads(p.communicate(timeout=120)[0].strip().splitlines()[-1]) for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    outs.sort(key=lambda o: o["rank"])
+    assert outs[0]["world"] == 2
+    assert abs(outs[0]["elapsed"] - outs[1]["elapsed"]) < 1e-9          # both hold the MAX
+    assert outs[0]["elapsed"] >= 5 * 0.04 * 0.95                          # the slow rank's time
+    assert abs(outs[0]["value"] - 2 * 1000 * 5 / outs[0]["elapsed"]) < 1e-6
+
+
+def test_single_process_region_without_dist():
+    sys.path.insert(0, ROOT)
+    import bench
+    n = []
+    elapsed, last = bench.timed_region(lambda: n.append(1) or len(n), 7, lambda: None, None)
+    assert len(n) == 7 and last == 7 and elapsed > 0
+    assert bench.whole_job_value(1, 2, 10, 7, 2.0) == 70.0
+
+
+def test_algorithmic_costs_match_the_survey_totals():
+    """73.3 GFLOP per 180 000-point cloud for the network (reference formulation)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from point_unet_amd.helper_tool import ConfigBraTS
+    c = bench.algorithmic_costs(ConfigBraTS, 180000, 1)
+    net = sum(v["flops"] for k, v in c.items() if not k.startswith(("knn", "kdtree", "pyramid")))
+    assert abs(net / 1e9 - 73.3) < 0.8
