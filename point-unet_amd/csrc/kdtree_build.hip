@@ -25,7 +25,7 @@
 namespace ps {
 
 constexpr int kSmall = 256;     // nodes up to this many points are finished by one wave in LDS
-constexpr int kBigThreads = 1024;
+constexpr int kBigThreads = 512;
 constexpr int kMaxLevels = 96;  // per-level task counters
 
 struct BuildTask {
@@ -548,6 +548,322 @@ __global__ __launch_bounds__(256) void build_subtree_kernel(const BuildTree* __r
     }
 }
 
+// ---- chunked levels: the first kHugeLevels levels of nodes above kHuge points ------------------------------------
+// One workgroup per node cannot pull more than one CU's bandwidth, which made the top three levels of a 180 000-point
+// tree cost ~0.5 ms.  Here every pass of such a node is spread over the chip in 2 048-record chunks, one small
+// kernel per pass (kernel boundaries are the global sync): min/max -> counts -> {flag counts -> ranks -> swaps} x 2
+// -> emit.  Exactly the same arithmetic and the same closed-form Hoare sweeps as build_level_kernel.
+constexpr int kHuge = 16384;
+constexpr int kHugeLevels = 4;
+constexpr int kChunk = 2048;
+
+struct HugeTask {
+    BuildTask k;
+    int chunk0, nchunks;
+    unsigned mn[3], mx[3];  // ordered-uint accumulators
+    int lt, le;
+    unsigned maxlt, mingt;  // ordered-uint
+};
+
+struct HugeState {
+    HugeTask* tasks[2];
+    int32_t* ntasks;       // [kHugeLevels + 1]
+    int32_t* nchunks;      // [kHugeLevels + 1] total chunks of the level
+    int32_t* c_mL;         // [max_chunks] misplaced-left count of a chunk (current sweep)
+    int32_t* c_mR;
+    int32_t cap_tasks, cap_chunks;
+};
+
+__device__ __forceinline__ void route_task(const BuildQueues& Q, const HugeState& H, const BuildTask& t, int next_level)
+{
+    if (t.r - t.l > kHuge && next_level < kHugeLevels) {
+        const int slot = atomicAdd(&H.ntasks[next_level], 1);
+        if (slot < H.cap_tasks)
+            H.tasks[next_level & 1][slot].k = t;
+        else
+            Q.flags[1] = 1;
+    } else
+        push_task(Q, t, next_level);
+}
+
+// Serial plan of a level's chunk ranges + accumulator reset (a handful of tasks): run by one thread.
+__device__ void huge_plan(const HugeState& H, int level)
+{
+    const int n = min(H.ntasks[level], H.cap_tasks);
+    int c = 0;
+    for (int i = 0; i < n; ++i) {
+        HugeTask& t = H.tasks[level & 1][i];
+        t.chunk0 = c;
+        t.nchunks = (t.k.r - t.k.l + kChunk - 1) / kChunk;
+        c += t.nchunks;
+        for (int a = 0; a < 3; ++a) { t.mn[a] = 0xffffffffu; t.mx[a] = 0u; }
+        t.lt = 0; t.le = 0; t.maxlt = 0u; t.mingt = 0xffffffffu;
+    }
+    H.nchunks[level] = min(c, H.cap_chunks);
+}
+
+__global__ void huge_root_kernel(const BuildTree* __restrict__ trees, int n_trees, BuildQueues Q, HugeState H)
+{
+    // (single thread: a few trees) root metadata + routing of every root + the plan of level 0
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (int i = 0; i < n_trees; ++i) {
+        const BuildTree t = trees[i];
+        TreeMeta m;
+        m.root = 0;
+        m.depth = 0;
+        for (int a = 0; a < 3; ++a) {
+            m.lo[a] = t.n > 0 ? ord2f(t.bbox_ord[a]) : 0.f;
+            m.hi[a] = t.n > 0 ? ord2f(t.bbox_ord[3 + a]) : 0.f;
+        }
+        *t.meta = m;
+        if (t.n <= 0) continue;
+        BuildTask k;
+        k.tree = i; k.l = 0; k.r = t.n; k.parent = -1; k.side = 0; k.level = 0;
+        for (int a = 0; a < 3; ++a) { k.lo[a] = m.lo[a]; k.hi[a] = m.hi[a]; }
+        route_task(Q, H, k, 0);
+    }
+    huge_plan(H, 0);
+}
+
+struct ChunkRef {
+    int task, first, count;  // records [first, first+count) relative to the node's first record
+};
+__device__ __forceinline__ ChunkRef find_chunk(const HugeState& H, int level, int c)
+{
+    ChunkRef r;
+    r.task = -1;
+    r.first = 0;
+    r.count = 0;
+    if (c >= H.nchunks[level]) return r;
+    const int n = min(H.ntasks[level], H.cap_tasks);
+    const HugeTask* T = H.tasks[level & 1];
+    for (int i = 0; i < n; ++i)
+        if (c >= T[i].chunk0 && c < T[i].chunk0 + T[i].nchunks) {
+            r.task = i;
+            r.first = (c - T[i].chunk0) * kChunk;
+            r.count = min(kChunk, T[i].k.r - T[i].k.l - r.first);
+            return r;
+        }
+    return r;
+}
+
+__device__ __forceinline__ SplitChoice huge_split(const HugeTask& t)
+{
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) { mn[a] = ord2f(t.mn[a]); mx[a] = ord2f(t.mx[a]); }
+    return choose_split(t.k.lo, t.k.hi, mn, mx);
+}
+
+__global__ __launch_bounds__(256) void huge_minmax_kernel(const BuildTree* __restrict__ trees, HugeState H, int level)
+{
+    __shared__ float s_mn[4][3], s_mx[4][3];
+    const ChunkRef cr = find_chunk(H, level, blockIdx.x);
+    if (cr.task < 0) return;
+    HugeTask& t = H.tasks[level & 1][cr.task];
+    const float4* a = trees[t.k.tree].pts + t.k.l + cr.first;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int e = 0; e < kChunk / 256; ++e) {
+        const int i = e * 256 + threadIdx.x;
+        if (i < cr.count) {
+            const float4 p = a[i];
+            mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+            mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+            mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        }
+        if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6][c] = mn[c]; s_mx[threadIdx.x >> 6][c] = mx[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        atomicMin(&t.mn[c], f2ord(fminf(fminf(s_mn[0][c], s_mn[1][c]), fminf(s_mn[2][c], s_mn[3][c]))));
+        atomicMax(&t.mx[c], f2ord(fmaxf(fmaxf(s_mx[0][c], s_mx[1][c]), fmaxf(s_mx[2][c], s_mx[3][c]))));
+    }
+}
+
+__global__ __launch_bounds__(256) void huge_count_kernel(const BuildTree* __restrict__ trees, HugeState H, int level)
+{
+    __shared__ int s_i[4][2];
+    __shared__ float s_f[4][2];
+    const ChunkRef cr = find_chunk(H, level, blockIdx.x);
+    if (cr.task < 0) return;
+    HugeTask& t = H.tasks[level & 1][cr.task];
+    const SplitChoice sc = huge_split(t);
+    const float4* a = trees[t.k.tree].pts + t.k.l + cr.first;
+    int lt = 0, le = 0;
+    float maxlt = -INFINITY, mingt = INFINITY;
+#pragma unroll
+    for (int e = 0; e < kChunk / 256; ++e) {
+        const int i = e * 256 + threadIdx.x;
+        if (i < cr.count) {
+            const float v = comp(a[i], sc.ax);
+            lt += v < sc.cut;
+            le += v <= sc.cut;
+            if (v < sc.cut) maxlt = fmaxf(maxlt, v);
+            if (v > sc.cut) mingt = fminf(mingt, v);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lt += __shfl_xor(lt, o);
+        le += __shfl_xor(le, o);
+        maxlt = fmaxf(maxlt, __shfl_xor(maxlt, o));
+        mingt = fminf(mingt, __shfl_xor(mingt, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_i[threadIdx.x >> 6][0] = lt; s_i[threadIdx.x >> 6][1] = le;
+        s_f[threadIdx.x >> 6][0] = maxlt; s_f[threadIdx.x >> 6][1] = mingt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&t.lt, s_i[0][0] + s_i[1][0] + s_i[2][0] + s_i[3][0]);
+        atomicAdd(&t.le, s_i[0][1] + s_i[1][1] + s_i[2][1] + s_i[3][1]);
+        const float ml = fmaxf(fmaxf(s_f[0][0], s_f[1][0]), fmaxf(s_f[2][0], s_f[3][0]));
+        const float mg = fminf(fminf(s_f[0][1], s_f[1][1]), fminf(s_f[2][1], s_f[3][1]));
+        if (ml > -INFINITY) atomicMax(&t.maxlt, f2ord(ml));
+        if (mg < INFINITY) atomicMin(&t.mingt, f2ord(mg));
+    }
+}
+
+// flags of one chunk for sweep S as E ballots per wave (wave w owns records [w*512, w*512+512) of the chunk, striped)
+template <int S>
+__device__ __forceinline__ void chunk_flags(const float4* a, const ChunkRef& cr, const SplitChoice& sc, int lim1, int lim2, int wave, int lane,
+                                            unsigned long long (&bL)[8], unsigned long long (&bR)[8])
+{
+    const int from = S == 0 ? 0 : lim1, bound = S == 0 ? lim1 : lim2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int i = wave * 512 + e * 64 + lane;  // within the chunk
+        const int p = cr.first + i;                // within the node
+        bool isL = false, isR = false;
+        if (i < cr.count && p >= from) {
+            const float v = comp(a[i], sc.ax);
+            const bool keep_left = S == 0 ? (v < sc.cut) : (v <= sc.cut);
+            isL = p < bound && !keep_left;
+            isR = p >= bound && keep_left;
+        }
+        bL[e] = __ballot(isL);
+        bR[e] = __ballot(isR);
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void huge_sweepcount_kernel(const BuildTree* __restrict__ trees, HugeState H, int level)
+{
+    __shared__ int s_c[4][2];
+    const ChunkRef cr = find_chunk(H, level, blockIdx.x);
+    if (cr.task < 0) return;
+    const HugeTask& t = H.tasks[level & 1][cr.task];
+    const SplitChoice sc = huge_split(t);
+    const float4* a = trees[t.k.tree].pts + t.k.l + cr.first;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long bL[8], bR[8];
+    chunk_flags<S>(a, cr, sc, t.lt, t.le, wave, lane, bL, bR);
+    int wL = 0, wR = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { wL += __popcll(bL[e]); wR += __popcll(bR[e]); }
+    if (lane == 0) { s_c[wave][0] = wL; s_c[wave][1] = wR; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        H.c_mL[blockIdx.x] = s_c[0][0] + s_c[1][0] + s_c[2][0] + s_c[3][0];
+        H.c_mR[blockIdx.x] = s_c[0][1] + s_c[1][1] + s_c[2][1] + s_c[3][1];
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void huge_scatter_kernel(const BuildTree* __restrict__ trees, HugeState H, int level)
+{
+    __shared__ int s_c[4][2];
+    __shared__ int s_off[2];
+    const ChunkRef cr = find_chunk(H, level, blockIdx.x);
+    if (cr.task < 0) return;
+    const HugeTask& t = H.tasks[level & 1][cr.task];
+    const BuildTree tr = trees[t.k.tree];
+    const SplitChoice sc = huge_split(t);
+    const float4* a = tr.pts + t.k.l + cr.first;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // ranks before this chunk = misplaced counts of the node's earlier chunks
+    int pl = 0, pr = 0;
+    for (int c = t.chunk0 + threadIdx.x; c < (int)blockIdx.x; c += 256) { pl += H.c_mL[c]; pr += H.c_mR[c]; }
+    for (int o = 32; o > 0; o >>= 1) { pl += __shfl_xor(pl, o); pr += __shfl_xor(pr, o); }
+    if (lane == 0) { s_c[wave][0] = pl; s_c[wave][1] = pr; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_off[0] = s_c[0][0] + s_c[1][0] + s_c[2][0] + s_c[3][0];
+        s_off[1] = s_c[0][1] + s_c[1][1] + s_c[2][1] + s_c[3][1];
+    }
+    unsigned long long bL[8], bR[8];
+    chunk_flags<S>(a, cr, sc, t.lt, t.le, wave, lane, bL, bR);
+    int wL = 0, wR = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { wL += __popcll(bL[e]); wR += __popcll(bR[e]); }
+    __syncthreads();  // s_off written, s_c free again
+    if (lane == 0) { s_c[wave][0] = wL; s_c[wave][1] = wR; }
+    __syncthreads();
+    int rL = s_off[0], rR = s_off[1];
+    for (int w = 0; w < wave; ++w) { rL += s_c[w][0]; rR += s_c[w][1]; }
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int p = cr.first + wave * 512 + e * 64 + lane;
+        if ((bL[e] >> lane) & 1ull) tr.posL[t.k.l + rL + __popcll(bL[e] & lt_mask)] = p;
+        if ((bR[e] >> lane) & 1ull) tr.posR[t.k.l + rR + __popcll(bR[e] & lt_mask)] = p;
+        rL += __popcll(bL[e]);
+        rR += __popcll(bR[e]);
+    }
+}
+
+__global__ __launch_bounds__(256) void huge_swap_kernel(const BuildTree* __restrict__ trees, HugeState H, int level)
+{
+    __shared__ int s_c[4];
+    __shared__ int s_m;
+    const ChunkRef cr = find_chunk(H, level, blockIdx.x);
+    if (cr.task < 0) return;
+    const HugeTask& t = H.tasks[level & 1][cr.task];
+    const BuildTree tr = trees[t.k.tree];
+    float4* a = tr.pts + t.k.l;
+    int m = 0;
+    for (int c = t.chunk0 + threadIdx.x; c < t.chunk0 + t.nchunks; c += 256) m += H.c_mL[c];
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) s_m = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+    __syncthreads();
+    m = s_m;
+    // this chunk's share of the m swap pairs
+    for (int i = cr.first + threadIdx.x; i < min(m, cr.first + kChunk); i += 256) {
+        const int pl = tr.posL[t.k.l + i], pr = tr.posR[t.k.l + m - 1 - i];
+        const float4 x = a[pl], y = a[pr];
+        a[pl] = y;
+        a[pr] = x;
+    }
+}
+
+__global__ void huge_emit_kernel(const BuildTree* __restrict__ trees, BuildQueues Q, HugeState H, int level)
+{
+    // (single thread: a handful of nodes) record the nodes, route the children, plan the next level
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const int n = min(H.ntasks[level], H.cap_tasks);
+    for (int i = 0; i < n; ++i) {
+        const HugeTask& t = H.tasks[level & 1][i];
+        const BuildTree tr = trees[t.k.tree];
+        const SplitChoice sc = huge_split(t);
+        BuildTask kids[2];
+        int id;
+        emit_inner(Q, tr, t.k, sc.ax, sc.cut, t.lt, t.le, ord2f(t.maxlt), ord2f(t.mingt), kids, &id);
+        link_to_parent(tr, t.k, id);
+        route_task(Q, H, kids[0], level + 1);
+        route_task(Q, H, kids[1], level + 1);
+    }
+    if (level + 1 < kHugeLevels) huge_plan(H, level + 1);
+}
+
 __global__ void pending_flag_kernel(const int32_t* __restrict__ level_cnt, int level, int32_t* __restrict__ flags)
 {
     flags[2] = level >= 0 ? level_cnt[level] : 0;
@@ -578,6 +894,12 @@ void TreeSetPlan::carve(Arena& a)
     add(sizeof(BuildTask) * q_cap * 2);
     add(sizeof(BuildTask) * small_cap);
     add(sizeof(int32_t) * (kMaxLevels + 8));
+    {   // chunked-level state (must stay AFTER everything build_trees_continue() re-derives)
+        const size_t cap_tasks = tot / kHuge + T + 8, cap_chunks = tot / kChunk + cap_tasks + 8;
+        add(sizeof(HugeTask) * cap_tasks * 2);
+        add(sizeof(int32_t) * 2 * (kHugeLevels + 2));
+        add(sizeof(int32_t) * 2 * cap_chunks);
+    }
     scratch_bytes = bytes;
     d_scratch = a.take<char>(bytes);
 }
@@ -597,6 +919,10 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     BuildTask* d_q = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * q_cap * 2));
     BuildTask* d_small = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * small_cap));
     int32_t* d_cnt = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (kMaxLevels + 8)));
+    const size_t cap_tasks = tot / kHuge + T + 8, cap_chunks = tot / kChunk + cap_tasks + 8;
+    HugeTask* d_huge = reinterpret_cast<HugeTask*>(take(sizeof(HugeTask) * cap_tasks * 2));
+    int32_t* d_hcnt = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 2 * (kHugeLevels + 2)));
+    int32_t* d_cm = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 2 * cap_chunks));
 
     // host staging lives in the plan (the caller keeps the plan alive until its final stream synchronisation)
     plan.host_blob.resize(sizeof(BuildTree) * T + sizeof(unsigned) * 8 * T);
@@ -625,7 +951,18 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     PS_HIP(hipMemcpyAsync(d_trees, h_trees, sizeof(BuildTree) * T, hipMemcpyHostToDevice, st));
     PS_HIP(hipMemcpyAsync(d_bbox, h_bbox, sizeof(unsigned) * 8 * T, hipMemcpyHostToDevice, st));
     PS_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (kMaxLevels + 8), st));
+    PS_HIP(hipMemsetAsync(d_hcnt, 0, sizeof(int32_t) * 2 * (kHugeLevels + 2), st));
     PS_HIP(hipMemsetAsync(plan.d_flags, 0, 16 * sizeof(int32_t), st));
+
+    HugeState H;
+    H.tasks[0] = d_huge;
+    H.tasks[1] = d_huge + cap_tasks;
+    H.ntasks = d_hcnt;
+    H.nchunks = d_hcnt + (kHugeLevels + 2);
+    H.c_mL = d_cm;
+    H.c_mR = d_cm + cap_chunks;
+    H.cap_tasks = (int32_t)cap_tasks;
+    H.cap_chunks = (int32_t)cap_chunks;
 
     BuildQueues Q;
     Q.q[0] = d_q;
@@ -639,14 +976,28 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
 
     const int chunks_x = std::max(1, std::min(ceil_div(max_n, 256 * 4), 256));
     hipLaunchKernelGGL(init_points_kernel, dim3(chunks_x, (unsigned)T), dim3(256), 0, st, d_trees, chunks_x);
-    hipLaunchKernelGGL(root_tasks_kernel, dim3(ceil_div(T, 64)), dim3(64), 0, st, d_trees, (int)T, Q);
+    hipLaunchKernelGGL(huge_root_kernel, dim3(1), dim3(64), 0, st, d_trees, (int)T, Q, H);
     // big levels: the number of tasks per level is device-side data; a level holds at most tot/kSmall disjoint big
     // nodes.  kFastLevels level kernels are launched blind (surplus ones find an empty queue and exit); the count of
     // still-pending big nodes goes to flags[2], which the caller reads at its own final synchronisation and, if it is
     // not zero (a very unbalanced cloud), answers with build_trees_continue().
     const int grid_big = (int)std::min<size_t>(q_cap, tot / kSmall + T + 1);
-    for (int level = 0; level < kFastLevels; ++level)
+    const dim3 gc((unsigned)std::min<size_t>(cap_chunks, tot / kChunk + cap_tasks)), bc(256);
+    for (int level = 0; level < kFastLevels; ++level) {
+        if (level < kHugeLevels && tot > (size_t)kHuge) {
+            // nodes above kHuge points: every pass spread over the chip (see "chunked levels" above)
+            hipLaunchKernelGGL(huge_minmax_kernel, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_count_kernel, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_sweepcount_kernel<0>, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_scatter_kernel<0>, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_swap_kernel, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_sweepcount_kernel<1>, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_scatter_kernel<1>, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_swap_kernel, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_emit_kernel, dim3(1), dim3(64), 0, st, d_trees, Q, H, level);
+        }
         hipLaunchKernelGGL(build_level_kernel, dim3(grid_big), dim3(kBigThreads), 0, st, d_trees, Q, level);
+    }
     hipLaunchKernelGGL(pending_flag_kernel, dim3(1), dim3(1), 0, st, d_cnt, kFastLevels, plan.d_flags);
     hipLaunchKernelGGL(build_subtree_kernel, dim3(std::min<size_t>(ceil_div(small_cap, 4), 2048)), dim3(256), 0, st, d_trees, Q);
     PS_HIP(hipGetLastError());
