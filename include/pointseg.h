@@ -61,6 +61,11 @@ int ps_destroy(ps_context* ctx);
  * hip_stream == NULL selects the device's default (null) stream. */
 int ps_set_stream(ps_context* ctx, void* hip_stream);
 int ps_synchronize(ps_context* ctx);
+/* on != 0: ps_pyramid_build stops synchronising with the host; its device-side status words (tree deeper than the
+ * traversal stack, builder queue overflow, unbalanced cloud needing the slow build path) are copied to pinned memory
+ * and validated by the next ps_synchronize(), which then returns PS_ESTATE.  Lets the host enqueue the forward while
+ * the pyramid is still being built.  Default off (every call validates before returning). */
+int ps_set_deferred_checks(ps_context* ctx, int on);
 const char* ps_last_error(void);
 /* "pointseg-hip <version> gfx950" */
 const char* ps_version(void);
@@ -74,6 +79,9 @@ typedef struct {
     int64_t launches;
 } ps_timing_row;
 int ps_timing_begin(ps_context* ctx);
+/* Restrict event recording to ONE stage (NULL or "" = all stages).  Each recorded event costs ~3 us of stream time, so
+ * bench.py profiles every stage in a separate pass and keeps only the dominant stage's events in its timed region. */
+int ps_timing_select(ps_context* ctx, const char* stage_name);
 int ps_timing_end(ps_context* ctx, ps_timing_row* rows, int cap, int* n_rows);
 
 /* ---- KNN ---------------------------------------------------------------------------------------------- */

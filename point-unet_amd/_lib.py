@@ -49,9 +49,11 @@ PROTOTYPES = {
     "ps_destroy": (ctypes.c_int, [c_vp]),
     "ps_set_stream": (ctypes.c_int, [c_vp, c_vp]),
     "ps_synchronize": (ctypes.c_int, [c_vp]),
+    "ps_set_deferred_checks": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "ps_last_error": (ctypes.c_char_p, []),
     "ps_version": (ctypes.c_char_p, []),
     "ps_timing_begin": (ctypes.c_int, [c_vp]),
+    "ps_timing_select": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
     "ps_timing_end": (ctypes.c_int, [c_vp, ctypes.POINTER(PsTimingRow), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "ps_knn_batch": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 5 + [c_vp, ctypes.c_int]),
     "ps_knn_batch_i64": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 5 + [c_vp, ctypes.c_int]),

@@ -83,8 +83,23 @@ struct ps_context {
     ps::DevBuf stage_in;     // host<->device staging for device_ptrs == 0 calls
     ps::DevBuf stage_out;
     ps::DevBuf ops_ws;       // packed weights of ps_op_conv1x1
+    // deferred status checks (ps_set_deferred_checks): device flags land in pinned slots, validated at ps_synchronize
+    bool deferred = false;
+    int32_t* h_flags = nullptr;   // pinned [8][4]
+    unsigned pending_mask = 0;
+    int flag_slot = 0;
+    std::vector<char> host_ring[8];  // host staging kept alive behind asynchronous uploads
+    int ring_pos = 0;
+    std::vector<char>& ring_next() { ring_pos = (ring_pos + 1) & 7; return host_ring[ring_pos]; }
+    int check_deferred();  // after a stream sync: PS_OK or PS_ESTATE with the message set
+    // small host->device uploads that never stall the host: the data is copied into a pinned ring slot first
+    struct PinSlot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; };
+    PinSlot pin[16];
+    int pin_pos = 0;
+    int upload_async(void* dst, const void* src, size_t bytes);
     // timing
     bool timing = false;
+    std::string timing_only;  // when non-empty only this stage records events (keeps the timed region undisturbed)
     std::vector<ps::StageTimer> stages;
     std::vector<hipEvent_t> event_pool;
     size_t event_next = 0;
@@ -101,13 +116,15 @@ namespace ps {
 struct Stage {
     ps_context* c;
     int n;
+    bool on = false;
     Stage(ps_context* ctx, const char* name, int launches = 1) : c(ctx), n(launches)
     {
-        if (c->timing) c->stage_begin(name);
+        on = c->timing && (c->timing_only.empty() || c->timing_only == name);
+        if (on) c->stage_begin(name);
     }
     ~Stage()
     {
-        if (c->timing) c->stage_end(n);
+        if (on) c->stage_end(n);
     }
 };
 

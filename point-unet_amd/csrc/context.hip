@@ -47,6 +47,53 @@ void DevBuf::release()
 
 }  // namespace ps
 
+int ps_context::check_deferred()
+{
+    int rc = PS_OK;
+    for (int s = 0; s < 8; ++s)
+        if (pending_mask & (1u << s)) {
+            const int32_t* f = h_flags + 4 * s;
+            if (f[2] != 0) {
+                ps::set_error("deferred check: a kd-tree build needed more levels than are launched blind (very unbalanced cloud); "
+                              "results of the calls since then are invalid -- rebuild with ps_set_deferred_checks(ctx, 0)");
+                rc = PS_ESTATE;
+            } else if (f[1] != 0) {
+                ps::set_error("deferred check: kd-tree builder queue overflow (degenerate cloud)");
+                rc = PS_ESTATE;
+            } else if (f[0] != 0) {
+                ps::set_error("deferred check: kd-tree deeper than the traversal stack");
+                rc = PS_ESTATE;
+            }
+        }
+    pending_mask = 0;
+    return rc;
+}
+
+int ps_context::upload_async(void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return PS_OK;
+    PinSlot& s = pin[pin_pos];
+    pin_pos = (pin_pos + 1) & 15;
+    if (s.busy) {
+        PS_HIP(hipEventSynchronize(s.ev));  // the copy that last used this slot has drained
+        s.busy = false;
+    }
+    if (s.cap < bytes) {
+        if (s.p) (void)hipHostFree(s.p);
+        s.p = nullptr;
+        s.cap = 0;
+        const size_t want = bytes < 16384 ? 16384 : bytes + bytes / 4;
+        PS_HIP(hipHostMalloc(&s.p, want));
+        s.cap = want;
+    }
+    if (!s.ev) PS_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    std::memcpy(s.p, src, bytes);
+    PS_HIP(hipMemcpyAsync(dst, s.p, bytes, hipMemcpyHostToDevice, stream));
+    PS_HIP(hipEventRecord(s.ev, stream));
+    s.busy = true;
+    return PS_OK;
+}
+
 hipEvent_t ps_context::get_event()
 {
     if (event_next == event_pool.size()) {
@@ -118,6 +165,11 @@ int ps_destroy(ps_context* c)
     c->stage_in.release();
     c->stage_out.release();
     c->ops_ws.release();
+    if (c->h_flags) (void)hipHostFree(c->h_flags);
+    for (auto& s : c->pin) {
+        if (s.p) (void)hipHostFree(s.p);
+        if (s.ev) (void)hipEventDestroy(s.ev);
+    }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -135,6 +187,18 @@ int ps_synchronize(ps_context* c)
 {
     PS_CHECK(c != nullptr, "ps_synchronize: ctx is NULL");
     PS_HIP(hipStreamSynchronize(c->stream));
+    return c->check_deferred();
+}
+
+int ps_set_deferred_checks(ps_context* c, int on)
+{
+    PS_CHECK(c != nullptr, "ps_set_deferred_checks: ctx is NULL");
+    if (on && !c->h_flags) PS_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_flags), 8 * 4 * sizeof(int32_t)));
+    if (!on && c->pending_mask) {
+        PS_HIP(hipStreamSynchronize(c->stream));
+        PS_TRY(c->check_deferred());
+    }
+    c->deferred = on != 0;
     return PS_OK;
 }
 
@@ -144,6 +208,13 @@ int ps_timing_begin(ps_context* c)
     c->stages.clear();
     c->event_next = 0;
     c->timing = true;
+    return PS_OK;
+}
+
+int ps_timing_select(ps_context* c, const char* stage_name)
+{
+    PS_CHECK(c != nullptr, "ps_timing_select: ctx is NULL");
+    c->timing_only = stage_name ? stage_name : "";
     return PS_OK;
 }
 

@@ -21,6 +21,7 @@ struct TreeSetPlan {
     int32_t* d_flags = nullptr;      // [16] error flags, zeroed by build_trees
     void* d_scratch = nullptr;       // builder scratch
     size_t scratch_bytes = 0;
+    int launches = 0;                // kernels launched by build_trees (for the stage timer)
     std::vector<char> host_blob;     // host staging of the builder's tables (must outlive the async copies)
 
     void add(int32_t count)

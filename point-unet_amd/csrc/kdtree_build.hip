@@ -948,8 +948,8 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
         }
     }
     hipStream_t st = c->stream;
-    PS_HIP(hipMemcpyAsync(d_trees, h_trees, sizeof(BuildTree) * T, hipMemcpyHostToDevice, st));
-    PS_HIP(hipMemcpyAsync(d_bbox, h_bbox, sizeof(unsigned) * 8 * T, hipMemcpyHostToDevice, st));
+    PS_TRY(c->upload_async(d_trees, h_trees, sizeof(BuildTree) * T));
+    PS_TRY(c->upload_async(d_bbox, h_bbox, sizeof(unsigned) * 8 * T));
     PS_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (kMaxLevels + 8), st));
     PS_HIP(hipMemsetAsync(d_hcnt, 0, sizeof(int32_t) * 2 * (kHugeLevels + 2), st));
     PS_HIP(hipMemsetAsync(plan.d_flags, 0, 16 * sizeof(int32_t), st));
@@ -1001,6 +1001,7 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     hipLaunchKernelGGL(pending_flag_kernel, dim3(1), dim3(1), 0, st, d_cnt, kFastLevels, plan.d_flags);
     hipLaunchKernelGGL(build_subtree_kernel, dim3(std::min<size_t>(ceil_div(small_cap, 4), 2048)), dim3(256), 0, st, d_trees, Q);
     PS_HIP(hipGetLastError());
+    plan.launches = 4 + kFastLevels + (tot > (size_t)kHuge ? 9 * kHugeLevels : 0);
     return PS_OK;
 }
 

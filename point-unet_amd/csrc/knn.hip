@@ -156,7 +156,7 @@ static int knn_batch_impl(ps_context* c, const float* support, const float* quer
         jobs[b].out = d_out32 + (size_t)b * n2 * K;
         jobs[b].overflow = plan.d_flags;
     }
-    PS_HIP(hipMemcpyAsync(plan.d_jobs, jobs.data(), sizeof(KnnJob) * B, hipMemcpyHostToDevice, c->stream));
+    PS_TRY(c->upload_async(plan.d_jobs, jobs.data(), sizeof(KnnJob) * B));
     int32_t flag[3] = {0, 0, 0};
     for (int attempt = 0;; ++attempt) {
         {
@@ -273,6 +273,7 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
     {
         Stage st(c, "kdtree_build", 1);
         PS_TRY(build_trees(c, plan));
+        st.n = plan.launches;
     }
 
     // jobs: K-NN self queries per level, then 1-NN up-sampling queries per level, both in the query set's own
@@ -306,7 +307,7 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
         }
     // NOTE: jobs is pageable host memory: the copy below is synchronous w.r.t. the host buffer by the time
     // hipMemcpyAsync returns for pageable sources, but we do not rely on it -- see the stream sync at the end.
-    PS_HIP(hipMemcpyAsync(plan.d_jobs, jobs.data(), sizeof(KnnJob) * jobs.size(), hipMemcpyHostToDevice, c->stream));
+    PS_TRY(c->upload_async(plan.d_jobs, jobs.data(), sizeof(KnnJob) * jobs.size()));
     const KnnJob* dj = reinterpret_cast<const KnnJob*>(plan.d_jobs);
     int32_t flag[3] = {0, 0, 0};
     for (int attempt = 0;; ++attempt) {
@@ -326,6 +327,18 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
                                    B, n[l], n[l + 1], K);
             }
             PS_HIP(hipGetLastError());
+        }
+        if (c->deferred) {
+            // no host synchronisation: the status words go to a pinned slot that ps_synchronize() validates; the host
+            // tables behind the asynchronous uploads move into the context's ring so they outlive this frame
+            if (c->pending_mask & (1u << c->flag_slot)) {
+                PS_HIP(hipStreamSynchronize(c->stream));
+                PS_TRY(c->check_deferred());
+            }
+            PS_HIP(hipMemcpyAsync(c->h_flags + 4 * c->flag_slot, plan.d_flags, 12, hipMemcpyDeviceToHost, c->stream));
+            c->pending_mask |= 1u << c->flag_slot;
+            c->flag_slot = (c->flag_slot + 1) & 7;
+            return PS_OK;  // (all host tables went through the context's pinned upload ring)
         }
         PS_HIP(hipMemcpyAsync(flag, plan.d_flags, 12, hipMemcpyDeviceToHost, c->stream));
         PS_HIP(hipStreamSynchronize(c->stream));

@@ -28,10 +28,16 @@ class Context:
         s = torch.cuda.current_stream(self.device)
         _lib.check(_lib.lib().ps_set_stream(self._h, ctypes.c_void_p(s.cuda_stream)))
 
+    def set_deferred_checks(self, on=True):
+        """ps_pyramid_build without host synchronisation; status validated by synchronize()."""
+        _lib.check(_lib.lib().ps_set_deferred_checks(self._h, 1 if on else 0))
+
     def synchronize(self):
         _lib.check(_lib.lib().ps_synchronize(self._h))
 
-    def timing_begin(self):
+    def timing_begin(self, only=None):
+        """Arm hipEvent stage timing; `only` restricts it to one stage name."""
+        _lib.check(_lib.lib().ps_timing_select(self._h, only.encode() if only else None))
         _lib.check(_lib.lib().ps_timing_begin(self._h))
 
     def timing_end(self):

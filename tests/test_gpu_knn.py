@@ -152,11 +152,42 @@ def test_device_tree_equals_host_tree(lib, case):
 
 
 def test_unbalanced_cloud_takes_the_slow_build_path(oracle):
-    """A geometric progression along x makes every bounding-box-midpoint split peel ~2 % of the node: far more
-    levels of big nodes than the builder launches blind, so the continue path runs.  Results stay bit-exact."""
+    """A geometric progression on a line (y = z = 0) makes every bounding-box-midpoint split peel ~2 % of the node:
+    ~37 levels of nodes above 256 points, far more than the builder launches blind, so the continue path runs.
+    Results stay bit-exact."""
     rng = np.random.default_rng(5)
     n = 1100
-    p = np.stack([0.97 ** np.arange(n), 1e-3 * rng.random(n), 1e-3 * rng.random(n)], 1).astype(np.float32)
+    p = np.stack([0.97 ** np.arange(n), np.zeros(n), np.zeros(n)], 1).astype(np.float32)
     p = p[rng.permutation(n)]
     for K in (1, 16):
         assert np.array_equal(_knn_gpu(p[None], p[None], K), oracle.knn_batch(p[None], p[None], K))
+
+
+def test_deferred_checks_flag_unbalanced_cloud_at_synchronize():
+    """With deferred checks the pyramid build does not synchronise; a cloud that needs the slow build path is reported
+    by the next synchronize() instead of silently yielding wrong indices."""
+    import torch
+    from point_unet_amd import PointSegError, runtime
+    from point_unet_amd.helper_tool import ConfigBraTS
+    from point_unet_amd.pyramid import build_pyramid
+
+    class Cfg(ConfigBraTS):
+        num_layers = 2
+        sub_sampling_ratio = [2, 2]
+
+    ctx = runtime.Context(0)
+    ctx.use_torch_stream()
+    ctx.set_deferred_checks(True)
+    good = torch.from_numpy(brats_cloud(8000, 3, grid=(40, 40, 30))[None]).cuda()
+    pyr = build_pyramid(good, Cfg, ctx=ctx)
+    ctx.synchronize()
+    ref = build_pyramid(good, Cfg)
+    assert torch.equal(pyr.neigh_idx[0], ref.neigh_idx[0]) and torch.equal(pyr.interp_idx[1], ref.interp_idx[1])
+    rng = np.random.default_rng(5)
+    n = 1100
+    p = np.stack([0.97 ** np.arange(n), np.zeros(n), np.zeros(n)], 1).astype(np.float32)[rng.permutation(n)]
+    build_pyramid(torch.from_numpy(p[None]).cuda(), Cfg, ctx=ctx)
+    with pytest.raises(PointSegError, match="unbalanced"):
+        ctx.synchronize()
+    ctx.synchronize()  # the failure is reported once
+    ctx.close()
