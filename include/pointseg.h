@@ -171,6 +171,46 @@ int ps_op_conv1x1(ps_context* ctx, const float* x, const float* w, const float* 
 int ps_op_att_pool(ps_context* ctx, const float* fset, const float* wfc, int64_t R, int64_t K, int64_t d,
                    float* agg);
 
+/* ---- training-step ops (device pointers; dense row-major fp32 [rows, channels]) --------------------------------------
+ * The reference trains with TF autodiff over the same graph with tf.layers.batch_normalization(training=True)
+ * (helper_tf_util.py:167,246; RandLANet.py:115), the class-weighted softmax cross-entropy of RandLANet.py:267-274 and
+ * tf.train.AdamOptimizer (RandLANet.py:89).  point-unet_amd/train.py records a tape of these ops. */
+/* dW[cin,cout] = x^T . dy (overwritten), db[cout] = column sums of dy (may be NULL) */
+int ps_op_linear_wgrad(ps_context* ctx, const float* x, const float* dy, int64_t R, int64_t cin, int64_t cout,
+                       float* dW, float* db);
+/* y = act(gamma * (x - mean_batch) * rsqrt(var_batch + eps) + beta); saves mean, invstd, var (population variance);
+ * scratch2C: 2*C floats */
+int ps_op_bn_train_fwd(ps_context* ctx, const float* x, const float* gamma, const float* beta, int64_t R, int64_t C,
+                       float eps, int leaky, float* y, float* mean, float* invstd, float* var, float* scratch2C);
+int ps_op_bn_train_bwd(ps_context* ctx, const float* dy, const float* x, const float* gamma, const float* beta,
+                       const float* mean, const float* invstd, int64_t R, int64_t C, int leaky, float* dx,
+                       float* dgamma, float* dbeta);
+/* backward of gather_neighbour / nearest_interpolation: dpc[b*N + idx[row], :] += drows[row, :] */
+int ps_op_scatter_add_rows(ps_context* ctx, const float* drows, const int32_t* idx, int64_t B, int64_t N,
+                           int64_t rows_per_cloud, int64_t d, float* dpc);
+/* att_pooling core: probs = softmax over K of scores, agg = sum_K fset * probs   (RandLANet.py:396-398) */
+int ps_op_softmax_pool_fwd(ps_context* ctx, const float* fset, const float* scores, int64_t R, int64_t K, int64_t d,
+                           float* probs, float* agg);
+int ps_op_softmax_pool_bwd(ps_context* ctx, const float* dagg, const float* fset, const float* probs, int64_t R,
+                           int64_t K, int64_t d, float* dfset, float* dscores);
+/* backward of random_sample (max over K); ties share the gradient evenly like tf.reduce_max; dfeature accumulates */
+int ps_op_random_sample_bwd(ps_context* ctx, const float* dout, const float* out, const float* feature,
+                            const int32_t* pool_idx, int64_t B, int64_t N, int64_t M, int64_t K, int64_t d,
+                            float* dfeature);
+/* y = LeakyReLU(a + b) (RandLANet.py:321) and its backward ds = dy * act'(y) */
+int ps_op_add_lrelu(ps_context* ctx, const float* a, const float* b, int64_t n, float* y);
+int ps_op_add_lrelu_bwd(ps_context* ctx, const float* dy, const float* y, int64_t n, float* ds);
+int ps_op_axpy(ps_context* ctx, float alpha, const float* x, int64_t n, float* y);
+int ps_op_mul(ps_context* ctx, const float* a, const float* b, int64_t n, float* y);
+/* mean over rows of class_weights[label] * softmax-CE; *loss is a device float; dlogits may be NULL */
+int ps_op_weighted_ce(ps_context* ctx, const float* logits, const int32_t* labels, const float* class_weights,
+                      int64_t R, int64_t C, float* loss, float* dlogits);
+/* tf.train.AdamOptimizer update, step >= 1 */
+int ps_op_adam(ps_context* ctx, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+               float beta2, float eps, int64_t step);
+/* tf.nn.dropout: y = x * mask, mask = (u < keep_prob) / keep_prob from a counter-based hash of (element, seed) */
+int ps_op_dropout(ps_context* ctx, const float* x, int64_t n, uint32_t seed, float keep_prob, float* y, float* mask);
+
 /* ---- host-only debug doors (CPU test-suite; never bound by the Python facade, never on the product path) ---- */
 /* The product's own kd-tree construction + the per-query search routine the HIP kernel instantiates, run on the
  * host.  K in {1,5,7,16,32}. */

@@ -73,6 +73,20 @@ PROTOTYPES = {
     "ps_op_nearest_interpolation": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 4 + [c_vp]),
     "ps_op_conv1x1": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [ctypes.c_int, c_vp]),
     "ps_op_att_pool": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp]),
+    "ps_op_linear_wgrad": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp, c_vp]),
+    "ps_op_bn_train_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int] + [c_vp] * 5),
+    "ps_op_bn_train_bwd": (ctypes.c_int, [c_vp] * 7 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int] + [c_vp] * 3),
+    "ps_op_scatter_add_rows": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 4 + [c_vp]),
+    "ps_op_softmax_pool_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp, c_vp]),
+    "ps_op_softmax_pool_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp, c_vp]),
+    "ps_op_random_sample_bwd": (ctypes.c_int, [c_vp] * 5 + [ctypes.c_int64] * 5 + [c_vp]),
+    "ps_op_add_lrelu": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int64, c_vp]),
+    "ps_op_add_lrelu_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int64, c_vp]),
+    "ps_op_axpy": (ctypes.c_int, [c_vp, ctypes.c_float, c_vp, ctypes.c_int64, c_vp]),
+    "ps_op_mul": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int64, c_vp]),
+    "ps_op_weighted_ce": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp]),
+    "ps_op_adam": (ctypes.c_int, [c_vp] * 5 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [ctypes.c_int64]),
+    "ps_op_dropout": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float, c_vp, c_vp]),
     # host-only debug doors (bound for the CPU test-suite only; the facade never calls them)
     "ps_debug_knn_host": (ctypes.c_int, [c_vp, c_vp] + [ctypes.c_int64] * 4 + [c_vp]),
     "ps_debug_kdtree_host": (ctypes.c_int, [c_vp, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp]),

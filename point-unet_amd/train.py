@@ -1,0 +1,319 @@
+"""Training step of the PointSegment RandLA-Net on MI355X: forward in training mode (batch-statistics BatchNorm,
+dropout), class-weighted cross-entropy, backward, Adam -- the device counterpart of
+
+    Network.__init__ loss / optimizer      PointSegment/RandLANet.py:62-90, 267-274
+    Network.train's sess.run([train_op, extra_update_ops, ...])   PointSegment/RandLANet.py:162-169
+    tf.layers.batch_normalization(..., training=True)             helper_tf_util.py:167,246; RandLANet.py:115
+
+The reference relies on TF autodiff; here the host records a tape of op-level HIP kernels (csrc/ops_train.hip,
+csrc/ops.hip, csrc/rowgemm.hip through the C ABI) and replays it backwards.  This is the straightforward, unfused
+formulation ([B,N,K,C] tensors are materialised like the reference does); PyTorch only provides device buffers,
+concatenation/slicing copies and -- for config 4 -- the RCCL all-reduce of the flat gradient buffer.
+
+Multi-GPU: one cloud per GPU, gradients averaged with ONE all-reduce of the flat fp32 buffer
+(4 992 852 floats for BraTS).  BatchNorm statistics are per-GPU (the reference itself never runs batch > 1).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, runtime, weights
+
+BN_EPS = 1e-6
+BN_MOMENTUM = 0.99
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class Tape:
+    """Records (output, backward closure) pairs; gradients are keyed by tensor identity and accumulated on the device."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.L = _lib.lib()
+        self.h = ctx.handle
+        self.ops = []
+        self.grads = {}
+
+    def accum(self, t, g):
+        k = id(t)
+        if k in self.grads:
+            _lib.check(self.L.ps_op_axpy(self.h, 1.0, _p(g), g.numel(), _p(self.grads[k])))
+        else:
+            self.grads[k] = g
+
+    def backward(self, out, dout):
+        self.grads[id(out)] = dout
+        for t, bw in reversed(self.ops):
+            g = self.grads.pop(id(t), None)
+            if g is not None:
+                bw(g)
+        self.ops = []
+        self.grads = {}
+
+    # ---- ops -------------------------------------------------------------------------------------------------------
+    def linear(self, x, W, b, gW, gb, transposed=False):
+        """y = x . W (+ b).  W is [cin,cout], or [cout,cin] when transposed (conv2d_transpose kernels)."""
+        Wm = W.t().contiguous() if transposed else W
+        R, cin = x.shape
+        cout = Wm.shape[1]
+        y = torch.empty((R, cout), dtype=torch.float32, device=x.device)
+        _lib.check(self.L.ps_op_conv1x1(self.h, _p(x), _p(Wm), _p(b), R, cin, cout, 0, _p(y)))
+
+        def bw(dy):
+            dy = dy.contiguous()
+            dW = torch.empty((cin, cout), dtype=torch.float32, device=x.device)
+            _lib.check(self.L.ps_op_linear_wgrad(self.h, _p(x), _p(dy), R, cin, cout, _p(dW), _p(gb) if gb is not None else None))
+            gW.copy_(dW.t() if transposed else dW)
+            if x.requires_grad_flag:
+                dx = torch.empty((R, cin), dtype=torch.float32, device=x.device)
+                Wt = Wm.t().contiguous()
+                _lib.check(self.L.ps_op_conv1x1(self.h, _p(dy), _p(Wt), None, R, cout, cin, 0, _p(dx)))
+                self.accum(x, dx)
+
+        y.requires_grad_flag = True
+        self.ops.append((y, bw))
+        return y
+
+    def bn_act(self, x, gamma, beta, ggamma, gbeta, mov_mean, mov_var, leaky):
+        R, C = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((5, C), dtype=torch.float32, device=x.device)  # mean, invstd, var, scratch x2
+        _lib.check(self.L.ps_op_bn_train_fwd(self.h, _p(x), _p(gamma), _p(beta), R, C, BN_EPS, 1 if leaky else 0, _p(y), _p(stats[0]), _p(stats[1]),
+                                             _p(stats[2]), _p(stats[3])))
+        # moving statistics (the reference's extra_update_ops, RandLANet.py:90,163)
+        mov_mean.mul_(BN_MOMENTUM).add_(stats[0], alpha=1 - BN_MOMENTUM)
+        mov_var.mul_(BN_MOMENTUM).add_(stats[2], alpha=1 - BN_MOMENTUM)
+
+        def bw(dy):
+            dx = torch.empty_like(x)
+            _lib.check(self.L.ps_op_bn_train_bwd(self.h, _p(dy.contiguous()), _p(x), _p(gamma), _p(beta), _p(stats[0]), _p(stats[1]), R, C,
+                                                 1 if leaky else 0, _p(dx), _p(ggamma), _p(gbeta)))
+            self.accum(x, dx)
+
+        y.requires_grad_flag = True
+        self.ops.append((y, bw))
+        return y
+
+    def gather(self, x, idx, B):
+        """x [B*N, d], idx [B, M, K] -> [B*M*K, d]"""
+        N, d = x.shape[0] // B, x.shape[1]
+        M, K = idx.shape[1], idx.shape[2]
+        out = torch.empty((B * M * K, d), dtype=torch.float32, device=x.device)
+        _lib.check(self.L.ps_op_gather_neighbour(self.h, _p(x), _p(idx), B, N, M, K, d, _p(out)))
+
+        def bw(dy):
+            dx = torch.zeros_like(x)
+            _lib.check(self.L.ps_op_scatter_add_rows(self.h, _p(dy.contiguous()), _p(idx), B, N, M * K, d, _p(dx)))
+            self.accum(x, dx)
+
+        out.requires_grad_flag = True
+        self.ops.append((out, bw))
+        return out
+
+    def cat(self, a, b):
+        out = torch.cat([a, b], dim=1)
+        ca = a.shape[1]
+
+        def bw(dy):
+            if getattr(a, "requires_grad_flag", False):
+                self.accum(a, dy[:, :ca].contiguous())
+            if getattr(b, "requires_grad_flag", False):
+                self.accum(b, dy[:, ca:].contiguous())
+
+        out.requires_grad_flag = True
+        self.ops.append((out, bw))
+        return out
+
+    def softpool(self, fset, scores, K):
+        RK, d = fset.shape
+        R = RK // K
+        probs = torch.empty_like(fset)
+        agg = torch.empty((R, d), dtype=torch.float32, device=fset.device)
+        _lib.check(self.L.ps_op_softmax_pool_fwd(self.h, _p(fset), _p(scores), R, K, d, _p(probs), _p(agg)))
+
+        def bw(dy):
+            dfset = torch.empty_like(fset)
+            dscores = torch.empty_like(fset)
+            _lib.check(self.L.ps_op_softmax_pool_bwd(self.h, _p(dy.contiguous()), _p(fset), _p(probs), R, K, d, _p(dfset), _p(dscores)))
+            self.accum(fset, dfset)
+            self.accum(scores, dscores)
+
+        agg.requires_grad_flag = True
+        self.ops.append((agg, bw))
+        return agg
+
+    def maxpool(self, x, pool_idx, B):
+        N, d = x.shape[0] // B, x.shape[1]
+        M, K = pool_idx.shape[1], pool_idx.shape[2]
+        out = torch.empty((B * M, d), dtype=torch.float32, device=x.device)
+        _lib.check(self.L.ps_op_random_sample(self.h, _p(x), _p(pool_idx), B, N, M, K, d, _p(out)))
+
+        def bw(dy):
+            dx = torch.zeros_like(x)
+            _lib.check(self.L.ps_op_random_sample_bwd(self.h, _p(dy.contiguous()), _p(out), _p(x), _p(pool_idx), B, N, M, K, d, _p(dx)))
+            self.accum(x, dx)
+
+        out.requires_grad_flag = True
+        self.ops.append((out, bw))
+        return out
+
+    def add_lrelu(self, a, b):
+        y = torch.empty_like(a)
+        _lib.check(self.L.ps_op_add_lrelu(self.h, _p(a), _p(b), a.numel(), _p(y)))
+
+        def bw(dy):
+            ds = torch.empty_like(a)
+            _lib.check(self.L.ps_op_add_lrelu_bwd(self.h, _p(dy.contiguous()), _p(y), a.numel(), _p(ds)))
+            self.accum(a, ds)
+            self.accum(b, ds.clone())
+
+        y.requires_grad_flag = True
+        self.ops.append((y, bw))
+        return y
+
+    def dropout(self, x, keep_prob, seed):
+        if keep_prob >= 1.0:
+            return x
+        y = torch.empty_like(x)
+        mask = torch.empty_like(x)
+        _lib.check(self.L.ps_op_dropout(self.h, _p(x), x.numel(), seed & 0xffffffff, keep_prob, _p(y), _p(mask)))
+
+        def bw(dy):
+            dx = torch.empty_like(x)
+            _lib.check(self.L.ps_op_mul(self.h, _p(dy.contiguous()), _p(mask), x.numel(), _p(dx)))
+            self.accum(x, dx)
+
+        y.requires_grad_flag = True
+        self.ops.append((y, bw))
+        return y
+
+
+class Trainer:
+    """Parameters (flat fp32 buffer + named views), Adam state and the train step."""
+
+    def __init__(self, config, params=None, device=0, seed=0, learning_rate=None, class_weights=None, keep_prob=0.5, ctx=None):
+        self.cfg = config
+        self.device = torch.device("cuda", device)
+        self.ctx = ctx or runtime.default_context(device)
+        self.keep_prob = keep_prob
+        params = params if params is not None else weights.init_params(config, seed=seed)
+        self.lr = float(learning_rate if learning_rate is not None else getattr(config, "learning_rate", 1e-4))
+        train_names, buf_names = [], []
+        for scope, kind, cin, cout in weights.layer_dims(config):
+            if kind in ("dense", "dense_nobias"):
+                train_names.append(scope + "/kernel")
+                if kind == "dense":
+                    train_names += [scope + "/bias", "batch_normalization/gamma", "batch_normalization/beta"]
+                    buf_names += ["batch_normalization/moving_mean", "batch_normalization/moving_variance"]
+            else:
+                train_names += [scope + "/weights", scope + "/biases"]
+                if kind != "conv_nobn":
+                    bn = scope + "/batch_normalization"
+                    train_names += [bn + "/gamma", bn + "/beta"]
+                    buf_names += [bn + "/moving_mean", bn + "/moving_variance"]
+        self.names = train_names
+        sizes = [int(np.prod(params[n].shape)) for n in train_names]
+        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros_like(self.flat)
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.P, self.G = {}, {}
+        off = 0
+        for n, sz in zip(train_names, sizes):
+            shape = tuple(params[n].shape)
+            self.P[n] = self.flat[off:off + sz].view(shape)
+            self.G[n] = self.grad[off:off + sz].view(shape)
+            self.P[n].copy_(torch.from_numpy(np.ascontiguousarray(params[n])))
+            off += sz
+        self.buffers = {n: torch.from_numpy(np.ascontiguousarray(params[n])).to(self.device) for n in buf_names}
+        cw = class_weights if class_weights is not None else np.ones(config.num_classes, np.float32)
+        self.class_weights = torch.from_numpy(np.asarray(cw, np.float32).reshape(-1)).to(self.device)
+        self.step = 0
+
+    def num_params(self):
+        return self.flat.numel()
+
+    def export_params(self):
+        out = {n: self.P[n].detach().cpu().numpy().copy() for n in self.names}
+        out.update({n: b.cpu().numpy().copy() for n, b in self.buffers.items()})
+        return out
+
+    # ---- graph pieces ------------------------------------------------------------------------------------------------
+    def _conv(self, t, x, scope, bn=True, act=True, transposed=False):
+        y = t.linear(x, self.P[scope + "/weights"], self.P[scope + "/biases"], self.G[scope + "/weights"], self.G[scope + "/biases"], transposed)
+        if bn:
+            s = scope + "/batch_normalization"
+            y = t.bn_act(y, self.P[s + "/gamma"], self.P[s + "/beta"], self.G[s + "/gamma"], self.G[s + "/beta"], self.buffers[s + "/moving_mean"],
+                         self.buffers[s + "/moving_variance"], act)
+        return y
+
+    def _att(self, t, fcat, name, K):
+        s = t.linear(fcat, self.P[name + "fc/kernel"], None, self.G[name + "fc/kernel"], None)
+        agg = t.softpool(fcat, s, K)
+        return self._conv(t, agg, name + "mlp")
+
+    def forward(self, t, pyr, features):
+        cfg, L = self.cfg, self.cfg.num_layers
+        B, K = features.shape[0], cfg.k_n
+        lib, h = t.L, t.h
+        x = features.reshape(-1, features.shape[-1]).contiguous()
+        x.requires_grad_flag = False
+        f = t.linear(x, self.P["fc0/kernel"], self.P["fc0/bias"], self.G["fc0/kernel"], self.G["fc0/bias"])
+        f = t.bn_act(f, self.P["batch_normalization/gamma"], self.P["batch_normalization/beta"], self.G["batch_normalization/gamma"],
+                     self.G["batch_normalization/beta"], self.buffers["batch_normalization/moving_mean"],
+                     self.buffers["batch_normalization/moving_variance"], True)
+        enc = []
+        for i in range(L):
+            n = "Encoder_layer_%d" % i
+            idx = pyr.neigh_idx[i]
+            N = idx.shape[1]
+            feature = f
+            f_pc = self._conv(t, feature, n + "mlp1")
+            rel = torch.empty((B * N * K, 10), dtype=torch.float32, device=x.device)
+            _lib.check(lib.ps_op_relative_pos_encoding(h, _p(pyr.xyz[i]), _p(idx), B, N, K, _p(rel)))
+            rel.requires_grad_flag = False
+            f_xyz = self._conv(t, rel, n + "LFAmlp1")
+            f_nb = t.gather(f_pc, idx, B)
+            f_agg = self._att(t, t.cat(f_nb, f_xyz), n + "LFAatt_pooling_1", K)
+            f_xyz2 = self._conv(t, f_xyz, n + "LFAmlp2")
+            f_nb2 = t.gather(f_agg, idx, B)
+            f_agg2 = self._att(t, t.cat(f_nb2, f_xyz2), n + "LFAatt_pooling_2", K)
+            a = self._conv(t, f_agg2, n + "mlp2", act=False)
+            b = self._conv(t, feature, n + "shortcut", act=False)
+            f_enc = t.add_lrelu(a, b)
+            f = t.maxpool(f_enc, pyr.sub_idx[i], B)
+            if i == 0:
+                enc.append(f_enc)
+            enc.append(f)
+        f = self._conv(t, enc[-1], "decoder_0")
+        for j in range(L):
+            up = t.gather(f, pyr.interp_idx[-j - 1], B)
+            f = self._conv(t, t.cat(enc[-j - 2], up), "Decoder_layer_%d" % j, transposed=True)
+        f = self._conv(t, f, "fc1")
+        f = self._conv(t, f, "fc2")
+        f = t.dropout(f, self.keep_prob, 0x9e3779b9 * (self.step + 1))
+        return self._conv(t, f, "fc", bn=False, act=False)
+
+    def train_step(self, pyr, features, labels, dist=None):
+        """One optimisation step on the batch; returns the loss (device scalar tensor).  With `dist` (an initialised
+        torch.distributed) the flat gradient buffer is averaged over ranks with one all-reduce before Adam."""
+        lib, h = _lib.lib(), self.ctx.handle
+        t = Tape(self.ctx)
+        logits = self.forward(t, pyr, features)
+        R, C = logits.shape
+        loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty_like(logits)
+        lab = labels.reshape(-1).to(torch.int32).contiguous()
+        _lib.check(lib.ps_op_weighted_ce(h, _p(logits), _p(lab), _p(self.class_weights), R, C, _p(loss), _p(dlogits)))
+        t.backward(logits, dlogits)
+        if dist is not None:
+            dist.all_reduce(self.grad)
+            _lib.check(lib.ps_op_axpy(h, 1.0 / dist.get_world_size() - 1.0, _p(self.grad), self.grad.numel(), _p(self.grad)))
+        self.step += 1
+        _lib.check(lib.ps_op_adam(h, _p(self.flat), _p(self.grad), _p(self.m), _p(self.v), self.flat.numel(), self.lr, 0.9, 0.999, 1e-8, self.step))
+        self.last_logits = logits
+        return loss

@@ -1,0 +1,136 @@
+"""GPU parity of the training step (BASELINE configs 3/4 path): forward in training mode, class-weighted CE, backward
+and one Adam step on the HIP tape vs the torch-CPU float64 autograd restatement (oracle/randla_train_oracle.py).
+Bars: loss relative 1e-5; every gradient max-abs error <= 2e-3 of that gradient's max magnitude (fp32 with atomically
+ordered reductions vs float64); updated parameters after one Adam step."""
+import numpy as np
+import pytest
+
+import netcase
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cfg, xyz, feats, seed=3, lr=1e-3, keep_prob=1.0):
+    import torch
+    from oracle import bindings as ob
+    from oracle import randla_oracle as ro
+    from point_unet_amd import weights
+    from point_unet_amd.pyramid import build_pyramid
+    from point_unet_amd.train import Trainer
+    params = weights.init_params(cfg, seed=seed, randomize_bn=True)
+    rng = np.random.default_rng(seed)
+    labels = rng.integers(0, cfg.num_classes, xyz.shape[:2]).astype(np.int32)
+    cw = np.linspace(1.0, 2.0, cfg.num_classes).astype(np.float32)
+    tr = Trainer(cfg, params=params, learning_rate=lr, class_weights=cw, keep_prob=keep_prob)
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: ob.knn_batch(s, q, k), xyz, cfg.k_n, cfg.sub_sampling_ratio)
+    return tr, pyr, params, labels, cw, (pts, nbr, pool, up)
+
+
+def test_one_training_step_matches_autograd(oracle):
+    import torch
+    from oracle import randla_train_oracle as rto
+    cfg, xyz, feats = netcase.small_deep(1500, seed=2, B=2)
+    cfg.d_out = [16, 32, 64, 32, 16]
+    tr, pyr, params, labels, cw, (pts, nbr, pool, up) = _setup(cfg, xyz, feats)
+    loss = tr.train_step(pyr, torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda())
+    torch.cuda.synchronize()
+    want = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, step=1)
+    assert abs(float(loss) - want["loss"]) <= 1e-5 * max(1.0, abs(want["loss"])), (float(loss), want["loss"])
+    assert np.abs(tr.last_logits.cpu().numpy().reshape(want["logits"].shape) - want["logits"]).max() < 1e-4
+    worst = []
+    for name in tr.names:
+        got = tr.G[name].cpu().numpy()
+        ref = want["grads"][name]
+        scale = max(np.abs(ref).max(), 1e-6)
+        worst.append((float(np.abs(got - ref).max() / scale), name))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 2e-3, worst[:5]
+    # moving statistics (the reference's extra_update_ops)
+    new = tr.export_params()
+    for k, v in want["new_params"].items():
+        if k.endswith(("moving_mean", "moving_variance")):
+            assert np.abs(new[k] - v).max() <= 1e-5 * max(1.0, np.abs(v).max()), k
+    # one Adam step: the first step moves every weight by about lr * sign(g); compare where the gradient is not tiny
+    for name in tr.names:
+        ref_g = want["grads"][name]
+        mask = np.abs(ref_g) > 1e-3 * np.abs(ref_g).max()
+        assert np.abs(new[name] - want["new_params"][name])[mask].max() <= 2e-5, name
+
+
+def test_loss_decreases_over_a_few_steps(oracle):
+    import torch
+    cfg, xyz, feats = netcase.small_deep(3000, seed=5)
+    cfg.d_out = [16, 32, 32, 16, 16]
+    tr, pyr, params, labels, cw, _ = _setup(cfg, xyz, feats, lr=5e-3, keep_prob=0.5)
+    # learnable target: label = sign pattern of the first modality
+    labels = (feats[..., 3] > 0).astype(np.int32) + 2 * (feats[..., 4] > 0).astype(np.int32)
+    f, l = torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
+    losses = [float(tr.train_step(pyr, f, l)) for _ in range(30)]
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-5:]) < 0.8 * np.mean(losses[:3]), losses
+
+
+def test_training_ops_against_torch(oracle):
+    """Op-level checks of the backward kernels on random tensors (shapes with awkward sizes)."""
+    import ctypes
+    import torch
+    from point_unet_amd import _lib, runtime
+    L, ctx = _lib.lib(), runtime.default_context(0)
+    h = ctx.handle
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(0)
+    # wgrad
+    for R, cin, cout in [(1000, 10, 8), (777, 24, 32), (301, 96, 128), (5000, 16, 16)]:
+        x = torch.randn(R, cin, generator=g).cuda()
+        dy = torch.randn(R, cout, generator=g).cuda()
+        dW = torch.empty(cin, cout).cuda()
+        db = torch.empty(cout).cuda()
+        _lib.check(L.ps_op_linear_wgrad(h, p(x), p(dy), R, cin, cout, p(dW), p(db)))
+        ref = x.double().T @ dy.double()
+        assert (dW.double() - ref).abs().max() <= 1e-4 * ref.abs().max()
+        assert (db.double() - dy.double().sum(0)).abs().max() <= 1e-4 * dy.double().sum(0).abs().max() + 1e-4
+    # bn forward/backward
+    R, C = 4097, 32
+    x = (torch.randn(R, C, generator=g) * 2 + 0.5).cuda().requires_grad_(True)
+    gamma = torch.rand(C, generator=g).cuda() + 0.5
+    beta = torch.randn(C, generator=g).cuda()
+    y = torch.empty(R, C).cuda()
+    st = torch.empty(5, C).cuda()
+    _lib.check(L.ps_op_bn_train_fwd(h, p(x), p(gamma), p(beta), R, C, 1e-6, 1, p(y), p(st[0]), p(st[1]), p(st[2]), p(st[3])))
+    xd = x.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.leaky_relu((xd - xd.mean(0)) / torch.sqrt(xd.var(0, unbiased=False) + 1e-6) * gamma.double() + beta.double(), 0.2)
+    assert (y.double() - ref).abs().max() < 1e-4
+    dy = torch.randn(R, C, generator=g).cuda()
+    ref.backward(dy.double())
+    dx = torch.empty(R, C).cuda()
+    dg = torch.empty(C).cuda()
+    dbt = torch.empty(C).cuda()
+    _lib.check(L.ps_op_bn_train_bwd(h, p(dy), p(x), p(gamma), p(beta), p(st[0]), p(st[1]), R, C, 1, p(dx), p(dg), p(dbt)))
+    assert (dx.double() - xd.grad).abs().max() < 1e-4
+    # softmax pool
+    Rr, K, d = 333, 16, 24
+    f = torch.randn(Rr, K, d, generator=g).cuda()
+    s = torch.randn(Rr, K, d, generator=g).cuda()
+    fd, sd = f.double().requires_grad_(True), s.double().requires_grad_(True)
+    ref = (fd * torch.softmax(sd, 1)).sum(1)
+    probs = torch.empty_like(f)
+    agg = torch.empty(Rr, d).cuda()
+    _lib.check(L.ps_op_softmax_pool_fwd(h, p(f), p(s), Rr, K, d, p(probs), p(agg)))
+    assert (agg.double() - ref).abs().max() < 1e-5
+    da = torch.randn(Rr, d, generator=g).cuda()
+    ref.backward(da.double())
+    df, ds = torch.empty_like(f), torch.empty_like(f)
+    _lib.check(L.ps_op_softmax_pool_bwd(h, p(da), p(f), p(probs), Rr, K, d, p(df), p(ds)))
+    assert (df.double() - fd.grad).abs().max() < 1e-5 and (ds.double() - sd.grad).abs().max() < 1e-5
+    # weighted CE
+    z = torch.randn(999, 4, generator=g).cuda()
+    yl = torch.randint(0, 4, (999,), generator=g).int().cuda()
+    cw = torch.tensor([1.0, 2.0, 0.5, 3.0]).cuda()
+    loss = torch.zeros(1).cuda()
+    dz = torch.empty_like(z)
+    _lib.check(L.ps_op_weighted_ce(h, p(z), p(yl), p(cw), 999, 4, p(loss), p(dz)))
+    zd = z.double().requires_grad_(True)
+    ref = (torch.nn.functional.cross_entropy(zd, yl.long(), reduction="none") * cw.double()[yl.long()]).mean()
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 and (dz.double() - zd.grad).abs().max() < 1e-6
