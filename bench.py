@@ -143,6 +143,50 @@ def whole_job_value(world, batch_per_gpu, points, steps, elapsed):
     return world * batch_per_gpu * points * steps / elapsed
 
 
+def bench_train(args, cfg, rank, local_rank, world, dist):
+    """BASELINE configs[2] (--batch 8, 1 GPU) / configs[3] (--gpus 8 --batch 1): one training step = index pyramid +
+    training-mode forward + class-weighted CE + backward + (all-reduce of the flat gradient buffer) + Adam, fp32."""
+    import torch
+    from point_unet_amd import runtime, weights
+    from point_unet_amd.pyramid import alloc_pyramid, build_pyramid
+    from point_unet_amd.train import Trainer
+    B, n0 = args.batch, args.points
+    xyz = np.stack([brats_cloud(n0, 1000 * rank + b) for b in range(B)])
+    rng = np.random.default_rng(7 + rank)
+    feats = np.concatenate([xyz, rng.standard_normal((B, n0, cfg.in_channels - 3)).astype(np.float32)], -1)
+    labels = rng.integers(0, cfg.num_classes, (B, n0)).astype(np.int32)
+    ctx = runtime.default_context(local_rank)
+    tr = Trainer(cfg, params=weights.init_params(cfg, seed=2), device=local_rank, ctx=ctx, keep_prob=0.5)
+    d_xyz, d_feats, d_lab = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
+    pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
+
+    def step():
+        build_pyramid(d_xyz, cfg, ctx=ctx, out=pyr)
+        return tr.train_step(pyr, d_feats, d_lab, dist=dist)
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    elapsed, loss = timed_region(step, args.steps, sync, dist)
+    assert bool(torch.isfinite(loss).all())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "points_per_sec_train_step", "value": whole_job_value(world, B, n0, args.steps, elapsed), "unit": "points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "training step (pyramid + train-mode forward + weighted CE + backward + Adam), %d-point BraTS-shaped "
+                                   "clouds, batch %d per GPU, K=16, 5 levels, fp32%s" % (n0, B, ", gradient all-reduce over RCCL" if world > 1 else ""),
+                       "points": n0, "batch_per_gpu": B, "parameters": tr.num_params()},
+            "loss": float(loss), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+        }))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +194,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=180000)
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--mode", choices=["forward", "train"], default="forward",
+                    help="forward = the headline metric (BASELINE configs[1]); train = forward+backward+Adam step (configs[2]/[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true", help="do not record hipEvents around the stages (A/B of their cost)")
     args = ap.parse_args()
@@ -173,6 +219,8 @@ def main():
 
     cfg = ConfigBraTS
     B, n0 = args.batch, args.points
+    if args.mode == "train":
+        return bench_train(args, cfg, rank, local_rank, world, dist)
     # one volume per GPU: rank r gets cloud(s) seeded by r
     xyz = np.stack([brats_cloud(n0, 1000 * rank + b) for b in range(B)])
     mods = np.random.default_rng(7 + rank).standard_normal((B, n0, cfg.in_channels - 3)).astype(np.float32)

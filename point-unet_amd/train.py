@@ -28,6 +28,14 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def allreduce_mean_(flat, dist):
+    """Gradient synchronisation of config 4: ONE all-reduce (RCCL over xGMI on the GPU box, gloo in the CPU tests) of the
+    flat fp32 gradient buffer, then the mean over ranks.  19.97 MB for the BraTS model: latency-bound, so no bucketing."""
+    dist.all_reduce(flat)
+    flat.div_(dist.get_world_size())
+    return flat
+
+
 class Tape:
     """Records (output, backward closure) pairs; gradients are keyed by tensor identity and accumulated on the device."""
 
@@ -311,8 +319,7 @@ class Trainer:
         _lib.check(lib.ps_op_weighted_ce(h, _p(logits), _p(lab), _p(self.class_weights), R, C, _p(loss), _p(dlogits)))
         t.backward(logits, dlogits)
         if dist is not None:
-            dist.all_reduce(self.grad)
-            _lib.check(lib.ps_op_axpy(h, 1.0 / dist.get_world_size() - 1.0, _p(self.grad), self.grad.numel(), _p(self.grad)))
+            allreduce_mean_(self.grad, dist)
         self.step += 1
         _lib.check(lib.ps_op_adam(h, _p(self.flat), _p(self.grad), _p(self.m), _p(self.v), self.flat.numel(), self.lr, 0.9, 0.999, 1e-8, self.step))
         self.last_logits = logits

@@ -59,3 +59,28 @@ def test_algorithmic_costs_match_the_survey_totals():
     c = bench.algorithmic_costs(ConfigBraTS, 180000, 1)
     net = sum(v["flops"] for k, v in c.items() if not k.startswith(("knn", "kdtree", "pyramid")))
     assert abs(net / 1e9 - 73.3) < 0.8
+
+
+GRAD_WORKER = textwrap.dedent("""
+    import json, sys
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    from point_unet_amd.train import allreduce_mean_
+    dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)      # rank 0: x, rank 1: 2x  -> mean 1.5x
+    allreduce_mean_(g, dist)
+    print(json.dumps({"rank": rank, "ok": bool(torch.allclose(g, torch.arange(1000, dtype=torch.float32) * 1.5))}), flush=True)
+    dist.destroy_process_group()
+""") % ROOT
+
+
+def test_gradient_allreduce_mean_two_ranks(tmp_path):
+    """Config 4's only collective: mean of the flat gradient buffer over ranks (gloo stand-in for RCCL)."""
+    script = tmp_path / "gworker.py"
+    script.write_text(GRAD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [json.loads(p.communicate(timeout=120)[0].strip().splitlines()[-1]) for p in procs]
+    assert all(p.returncode == 0 for p in procs) and all(o["ok"] for o in outs)

@@ -38,24 +38,33 @@ def test_one_training_step_matches_autograd(oracle):
     want = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, step=1)
     assert abs(float(loss) - want["loss"]) <= 1e-5 * max(1.0, abs(want["loss"])), (float(loss), want["loss"])
     assert np.abs(tr.last_logits.cpu().numpy().reshape(want["logits"].shape) - want["logits"]).max() < 1e-4
+    # Tolerance: 2e-3 of the parameter's own gradient scale plus 2e-5 of the global gradient scale.  The second term
+    # covers parameters whose true gradient is (near) zero -- biases in front of a BatchNorm (exactly 0) and the deepest
+    # level, whose gradient passes a BatchNorm over a few dozen rows and comes out ~1e-6 after heavy cancellation.
+    gscale = max(np.abs(g).max() for g in want["grads"].values())
     worst = []
     for name in tr.names:
         got = tr.G[name].cpu().numpy()
         ref = want["grads"][name]
-        scale = max(np.abs(ref).max(), 1e-6)
-        worst.append((float(np.abs(got - ref).max() / scale), name))
+        tol = 2e-3 * np.abs(ref).max() + 2e-5 * gscale
+        worst.append((float(np.abs(got - ref).max() / tol), name))
     worst.sort(reverse=True)
-    assert worst[0][0] <= 2e-3, worst[:5]
+    assert worst[0][0] <= 1.0, worst[:5]
     # moving statistics (the reference's extra_update_ops)
     new = tr.export_params()
     for k, v in want["new_params"].items():
         if k.endswith(("moving_mean", "moving_variance")):
             assert np.abs(new[k] - v).max() <= 1e-5 * max(1.0, np.abs(v).max()), k
-    # one Adam step: the first step moves every weight by about lr * sign(g); compare where the gradient is not tiny
+    # one Adam step: the first step moves every weight by about lr * sign(g), so entries whose gradient is rounding noise
+    # (|g| far below the global scale, e.g. biases in front of a BatchNorm) are excluded -- Adam normalises noise to O(lr)
+    checked = 0
     for name in tr.names:
         ref_g = want["grads"][name]
-        mask = np.abs(ref_g) > 1e-3 * np.abs(ref_g).max()
-        assert np.abs(new[name] - want["new_params"][name])[mask].max() <= 2e-5, name
+        mask = np.abs(ref_g) > 1e-3 * gscale
+        if mask.any():
+            checked += int(mask.sum())
+            assert np.abs(new[name] - want["new_params"][name])[mask].max() <= 2e-5, name
+    assert checked > 1000
 
 
 def test_loss_decreases_over_a_few_steps(oracle):
