@@ -196,6 +196,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = the headline metric (BASELINE configs[1]); train = forward+backward+Adam step (configs[2]/[3])")
+    ap.add_argument("--workload", choices=["config2", "config5"], default="config2",
+                    help="config2 = BASELINE configs[1] (180k BraTS-shaped, K=16); config5 = BASELINE configs[4] (262 144 points, K=32, "
+                         "4 input channels, 2 classes; features kept fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true", help="do not record hipEvents around the stages (A/B of their cost)")
     args = ap.parse_args()
@@ -218,6 +221,11 @@ def main():
     from point_unet_amd.pyramid import alloc_pyramid, build_pyramid
 
     cfg = ConfigBraTS
+    if args.workload == "config5":
+        class cfg(ConfigBraTS):  # Pancreas-shaped: runPancreas.py:118,125 (xyz + 1 CT value), 2 classes; K=32 per BASELINE configs[4]
+            k_n, num_classes, in_channels = 32, 2, 4
+        if args.points == 180000:
+            args.points = 262144
     B, n0 = args.batch, args.points
     if args.mode == "train":
         return bench_train(args, cfg, rank, local_rank, world, dist)
@@ -312,8 +320,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d-point BraTS-shaped cloud (4 modalities), K=16, 5-level RandLA-Net forward "
-                                   "incl. index pyramid, fp32, batch %d per GPU" % (n0, B),
+            "config": {"workload": "BASELINE configs[%d]: %d-point BraTS-shaped cloud (%d modalities), K=%d, 5-level RandLA-Net forward "
+                                   "incl. index pyramid, fp32, batch %d per GPU" % (1 if args.workload == "config2" else 4, n0, cfg.in_channels - 3,
+                                                                                  cfg.k_n, B),
                        "points": n0, "k_n": cfg.k_n, "num_layers": cfg.num_layers, "batch_per_gpu": B, "sharding": "one cloud per GPU, no collective"},
             "roofline": roofline,
             "device_ms_per_step": round(dev_ms, 4),
