@@ -211,7 +211,7 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or ("MASTER_ADDR" in os.environ and "RANK" in os.environ):  # launched by torch.distributed.run
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
