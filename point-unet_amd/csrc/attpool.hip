@@ -25,8 +25,9 @@ struct AttArgs {
     const float* w1p; const float* b1;
     const float* w2p; const float* b2;
     const float* wbp;
+    const float* wfp;  // full Wfc [d,d] packed (direct formulation)
     float* agg;
-    int n_total, n_cloud;
+    int n_total, n_cloud, ldf;
 };
 
 // SPLITN = false: every wave owns a point (its own LDS tiles).  SPLITN = true (deep levels: few points, wide d):
@@ -174,6 +175,182 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
     }
 }
 
+
+// ---- direct formulation (levels with many points, d <= 128) -----------------------------------------------------
+// scores = [f_nb | f_xyz] . Wfc on the full d x d weight, with the gathered neighbour features staged ONCE into the
+// LDS tile (they serve both as the A operand and as the values of the weighted sum).  The pre-product formulation above
+// gathers 3 x as many bytes per neighbour ([f | G] rows); at levels 0-2 that gather traffic, not the MFMA pipe, was
+// the limit (rocprofv3 FETCH_SIZE 617 / 242 / 89 MB per launch against 92 / 92 / 46 MB of feature rows).
+template <int D, int STAGE, int KN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
+{
+    constexpr int H = D / 2, RT = KN / 16, PA = D + 2, PT = H + 2;
+    constexpr int NTB_H = ntb_for(H), NTB_D = ntb_for(D);
+    constexpr int NT_H = (H + 15) / 16, NT_D = D / 16;
+    constexpr int CB_H = (NT_H + NTB_H - 1) / NTB_H, CB_D = (NT_D + NTB_D - 1) / NTB_D;
+    constexpr int KS_H = (H + 3) / 4, KS_D = D / 4;
+    constexpr int PER_WAVE = KN * PA + (STAGE == 2 ? KN * PT : 0);
+    using bfH = typename BFrag<NTB_H>::type;
+    using bfD = typename BFrag<NTB_D>::type;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, c16 = lane & 15;
+    float* A = smem + wave * PER_WAVE;
+    float* T1 = A + KN * PA;
+
+    for (int p = blockIdx.x * WAVES + wave; p < a.n_total; p += gridDim.x * WAVES) {
+        const int base = (p / a.n_cloud) * a.n_cloud;
+        const float cx = a.xyz[3 * (size_t)p], cy = a.xyz[3 * (size_t)p + 1], cz = a.xyz[3 * (size_t)p + 2];
+        int nb[RT];
+        float a0[RT], a1[RT], a2[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            nb[rt] = base + a.idx[(size_t)p * KN + rt * 16 + c16];
+            const float nx = a.xyz[3 * (size_t)nb[rt]], ny = a.xyz[3 * (size_t)nb[rt] + 1], nz = a.xyz[3 * (size_t)nb[rt] + 2];
+            const float rx = cx - nx, ry = cy - ny, rz = cz - nz;
+            const float dis = __fsqrt_rn(rx * rx + ry * ry + rz * rz);
+            a0[rt] = g == 0 ? dis : (g == 1 ? rx : (g == 2 ? ry : rz));
+            a1[rt] = g == 0 ? cx : (g == 1 ? cy : (g == 2 ? cz : nx));
+            a2[rt] = g == 0 ? ny : (g == 1 ? nz : 0.f);
+        }
+        // ---- neighbour features -> A[:, 0:H)  (16-byte loads, one row = H*4 contiguous bytes) ----
+        {
+            constexpr int Q = H / 4, TOT = KN * Q;
+#pragma unroll
+            for (int e0 = 0; e0 < TOT; e0 += 64) {
+                const int e = e0 + lane;
+                const int row = (e < TOT ? e : 0) / Q, q = (e < TOT ? e : 0) % Q;
+                int src = __shfl(nb[0], row & 15);
+                if constexpr (RT == 2) {
+                    const int src1 = __shfl(nb[1], row & 15);
+                    src = row >= 16 ? src1 : src;
+                }
+                if (e < TOT) {
+                    const float4 v = *reinterpret_cast<const float4*>(a.fg + (size_t)src * a.ldf + 4 * q);
+                    float* dst = A + row * PA + 4 * q;
+                    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                }
+            }
+        }
+        // ---- LFA mlp1 -> (stage 1) A[:, H:D)  /  (stage 2) T1 ----
+        float* X1 = STAGE == 2 ? T1 : A + H;
+        constexpr int P1 = STAGE == 2 ? PT : PA;
+#pragma unroll
+        for (int cb = 0; cb < CB_H; ++cb) {
+            f32x4 acc[RT][NTB_H];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int j = 0; j < NTB_H; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bfH* w = reinterpret_cast<const bfH*>(a.w1p) + (size_t)cb * 3 * 64 + lane;
+            const bfH b0 = w[0], b1v = w[64], b2v = w[128];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int j = 0; j < NTB_H; ++j) {
+                    acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[rt], bfrag_get<NTB_H>(b0, j), acc[rt][j], 0, 0, 0);
+                    acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rt], bfrag_get<NTB_H>(b1v, j), acc[rt][j], 0, 0, 0);
+                    acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[rt], bfrag_get<NTB_H>(b2v, j), acc[rt][j], 0, 0, 0);
+                }
+#pragma unroll
+            for (int j = 0; j < NTB_H; ++j) {
+                const int col = (cb * NTB_H + j) * 16 + c16;
+                if (col < H) {
+                    const float bb = a.b1[col];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) X1[(rt * 16 + g * 4 + r) * P1 + col] = leaky02(acc[rt][j][r] + bb);
+                }
+            }
+        }
+        wave_lds_sync();
+        if constexpr (STAGE == 2) {
+            for (int cb = 0; cb < CB_H; ++cb) {
+                f32x4 acc[RT][NTB_H];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int j = 0; j < NTB_H; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                tile_mma<NTB_H, RT>(T1, PT, KS_H, reinterpret_cast<const bfH*>(a.w2p) + (size_t)cb * KS_H * 64 + lane, acc, lane);
+#pragma unroll
+                for (int j = 0; j < NTB_H; ++j) {
+                    const int col = (cb * NTB_H + j) * 16 + c16;
+                    if (col < H) {
+                        const float bb = a.b2[col];
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) A[(rt * 16 + g * 4 + r) * PA + H + col] = leaky02(acc[rt][j][r] + bb);
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
+        // ---- scores on the full Wfc, softmax over the K rows, weighted sum ----
+        for (int cb = 0; cb < CB_D; ++cb) {
+            f32x4 acc[RT][NTB_D];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int j = 0; j < NTB_D; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            tile_mma<NTB_D, RT>(A, PA, KS_D, reinterpret_cast<const bfD*>(a.wfp) + (size_t)cb * KS_D * 64 + lane, acc, lane);
+#pragma unroll
+            for (int j = 0; j < NTB_D; ++j) {
+                const int col = (cb * NTB_D + j) * 16 + c16;
+                float m = acc[0][j][0];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[rt][j][r]);
+                m = xor_max(m);
+                float ssum = 0.f, num = 0.f;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __expf(acc[rt][j][r] - m);
+                        ssum += e;
+                        num += e * A[(rt * 16 + g * 4 + r) * PA + col];
+                    }
+                ssum = xor_sum(ssum);
+                num = xor_sum(num);
+                if (g == 0) a.agg[(size_t)p * D + col] = num / ssum;
+            }
+        }
+        wave_lds_sync();  // the tiles are overwritten by the next point
+    }
+}
+
+template <int D, int STAGE, int KN>
+static int launch_att_direct(ps_context* c, const AttArgs& a)
+{
+    constexpr int H = D / 2;
+    constexpr size_t per_wave = ((size_t)KN * (D + 2) + (STAGE == 2 ? (size_t)KN * (H + 2) : 0)) * sizeof(float);
+    constexpr int WAVES = per_wave * 4 <= 160 * 1024 ? 4 : (per_wave * 2 <= 160 * 1024 ? 2 : 1);
+    static_assert(per_wave * WAVES <= 160 * 1024, "attention tile does not fit the LDS");
+    const size_t smem = per_wave * WAVES;
+    auto kern = att_direct_kernel<D, STAGE, KN, WAVES>;
+    if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const int blocks = std::min(ceil_div(a.n_total, WAVES), 256 * 8);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+template <int STAGE, int KN>
+static int dispatch_direct(ps_context* c, int d, const AttArgs& a)
+{
+    switch (d) {
+        case 16: return launch_att_direct<16, STAGE, KN>(c, a);
+        case 32: return launch_att_direct<32, STAGE, KN>(c, a);
+        case 64: return launch_att_direct<64, STAGE, KN>(c, a);
+        case 128: return launch_att_direct<128, STAGE, KN>(c, a);
+        default: set_error("att_pool(direct): d_out %d is not a compiled size (16,32,64,128)", d); return PS_EINVAL;
+    }
+}
+
 template <int D, int STAGE, int KN>
 static int launch_att(ps_context* c, const AttArgs& a)
 {
@@ -221,11 +398,19 @@ int att_pool_stage(ps_context* c, const AttStage& s)
     a.xyz = s.xyz; a.idx = s.idx; a.fg = s.fg;
     a.w1p = s.lfa1->wp; a.b1 = s.lfa1->bias;
     a.w2p = s.lfa2 ? s.lfa2->wp : nullptr; a.b2 = s.lfa2 ? s.lfa2->bias : nullptr;
-    a.wbp = s.wbot->wp;
+    a.wbp = s.wbot ? s.wbot->wp : nullptr;
+    a.wfp = s.wfull ? s.wfull->wp : nullptr;
     a.agg = s.agg;
     a.n_total = (int)s.n_total; a.n_cloud = (int)s.n_cloud;
+    a.ldf = s.ldf;
     if (s.n_total <= 0) return PS_OK;
     const int stage = s.lfa2 ? 2 : 1;
+    if (s.wfull) {  // direct formulation: fg holds only the features (row stride ldf)
+        if (s.k == 16) return stage == 1 ? dispatch_direct<1, 16>(c, s.d, a) : dispatch_direct<2, 16>(c, s.d, a);
+        if (s.k == 32) return stage == 1 ? dispatch_direct<1, 32>(c, s.d, a) : dispatch_direct<2, 32>(c, s.d, a);
+        set_error("att_pool: k_n %d is not a compiled size (16, 32)", s.k);
+        return PS_EINVAL;
+    }
     if (s.k == 16) return stage == 1 ? dispatch_d<1, 16>(c, s.d, a) : dispatch_d<2, 16>(c, s.d, a);
     if (s.k == 32) return stage == 1 ? dispatch_d<1, 32>(c, s.d, a) : dispatch_d<2, 32>(c, s.d, a);
     set_error("att_pool: k_n %d is not a compiled size (16, 32)", s.k);

@@ -59,7 +59,7 @@ struct LayerSpec {
 };
 
 struct EncLevel {
-    PackedLinear mlp1, top1, lfa1, bot1, att1mlp, lfa2, top2, bot2, att2mlp, mlp2sc;
+    PackedLinear mlp1, top1, lfa1, bot1, full1, att1mlp, lfa2, top2, bot2, full2, att2mlp, mlp2sc;
     int d_in, d;
 };
 
@@ -207,11 +207,13 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
         emit(e.lfa1, W(si), Bv(si), 10, h, 1); ++si;
         emit(e.top1, W(si), nullptr, h, d, 0);                      // Wfc1[:h, :]
         emit(e.bot1, W(si) + (size_t)h * d, nullptr, h, d, 0);      // Wfc1[h:, :]
+        emit(e.full1, W(si), nullptr, d, d, 0);                     // Wfc1 (direct formulation)
         ++si;
         emit(e.att1mlp, W(si), Bv(si), d, h, 1); ++si;
         emit(e.lfa2, W(si), Bv(si), h, h, 1); ++si;
         emit(e.top2, W(si), nullptr, h, d, 0);
         emit(e.bot2, W(si) + (size_t)h * d, nullptr, h, d, 0);
+        emit(e.full2, W(si), nullptr, d, d, 0);
         ++si;
         emit(e.att2mlp, W(si), Bv(si), d, d, 1); ++si;
         // [mlp2 ; shortcut] over the concatenated K axis, biases summed, LeakyReLU on the sum (RandLANet.py:317-321)
@@ -306,34 +308,37 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
     int d_in = 8;
     for (int i = 0; i < L; ++i) {
         const EncLevel& e = net->enc[i];
-        const int d = e.d, h = d / 2, ldf = h + d;
+        const int d = e.d, h = d / 2;
         const int64_t R = B * n[i];
+        // pre-product formulation (fg = [f | G]) only where the MFMA pipe is the limit; the wide levels gather f alone
+        const bool use_g = d >= 64;
+        const int ldf = use_g ? h + d : h;
         char nm[48];
         AttStage s;
         s.xyz = pyr->xyz[i]; s.idx = pyr->neigh_idx[i]; s.fg = fg; s.lfa1 = &e.lfa1; s.agg = agg;
-        s.n_total = R; s.n_cloud = n[i]; s.d = d; s.k = cfg.k_n;
+        s.n_total = R; s.n_cloud = n[i]; s.d = d; s.k = cfg.k_n; s.ldf = ldf;
         {
             std::snprintf(nm, sizeof nm, "enc%d_dense", i);
-            Stage st(c, nm, 2);
+            Stage st(c, nm, use_g ? 2 : 1);
             PS_TRY(rowgemm(c, e.mlp1, src(X, d_in, d_in), none, R, fg, ldf));
-            PS_TRY(rowgemm(c, e.top1, src(fg, ldf, h), none, R, fg + h, ldf));
+            if (use_g) PS_TRY(rowgemm(c, e.top1, src(fg, ldf, h), none, R, fg + h, ldf));
         }
         {
             std::snprintf(nm, sizeof nm, "enc%d_att1", i);
             Stage st(c, nm, 1);
-            s.lfa2 = nullptr; s.wbot = &e.bot1;
+            s.lfa2 = nullptr; s.wbot = use_g ? &e.bot1 : nullptr; s.wfull = use_g ? nullptr : &e.full1;
             PS_TRY(att_pool_stage(c, s));
         }
         {
             std::snprintf(nm, sizeof nm, "enc%d_dense", i);
-            Stage st(c, nm, 2);
+            Stage st(c, nm, use_g ? 2 : 1);
             PS_TRY(rowgemm(c, e.att1mlp, src(agg, d, d), none, R, fg, ldf));
-            PS_TRY(rowgemm(c, e.top2, src(fg, ldf, h), none, R, fg + h, ldf));
+            if (use_g) PS_TRY(rowgemm(c, e.top2, src(fg, ldf, h), none, R, fg + h, ldf));
         }
         {
             std::snprintf(nm, sizeof nm, "enc%d_att2", i);
             Stage st(c, nm, 1);
-            s.lfa2 = &e.lfa2; s.wbot = &e.bot2;
+            s.lfa2 = &e.lfa2; s.wbot = use_g ? &e.bot2 : nullptr; s.wfull = use_g ? nullptr : &e.full2;
             PS_TRY(att_pool_stage(c, s));
         }
         {
