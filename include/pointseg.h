@@ -171,6 +171,14 @@ int ps_op_conv1x1(ps_context* ctx, const float* x, const float* w, const float* 
 int ps_op_att_pool(ps_context* ctx, const float* fset, const float* wfc, int64_t R, int64_t K, int64_t d,
                    float* agg);
 
+/* point -> volume scatter of the class probabilities (PointSegment/testBraTS.py:83-101, 226-231):
+ * volume f32[Z, Y, X, C] (the layout after the reference's np.moveaxis(volume, 1, 2)); out[z,y,x,:] = softmax(logits[j])
+ * for the LAST point i on voxel xyz_origin[i] = (x,y,z) and the LAST row j with p_idx[j] == i (p_idx NULL = identity),
+ * zeros elsewhere.  scratch: total + Z*X*Y int32.  Device pointers. */
+int ps_op_probs_to_volume(ps_context* ctx, const float* logits, int64_t n, int64_t C, const int32_t* p_idx,
+                          const int32_t* xyz_origin, int64_t total, int64_t Z, int64_t X, int64_t Y, float* volume,
+                          int32_t* scratch);
+
 /* ---- training-step ops (device pointers; dense row-major fp32 [rows, channels]) --------------------------------------
  * The reference trains with TF autodiff over the same graph with tf.layers.batch_normalization(training=True)
  * (helper_tf_util.py:167,246; RandLANet.py:115), the class-weighted softmax cross-entropy of RandLANet.py:267-274 and

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "ps_op_nearest_interpolation": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 4 + [c_vp]),
     "ps_op_conv1x1": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [ctypes.c_int, c_vp]),
     "ps_op_att_pool": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp]),
+    "ps_op_probs_to_volume": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp] + [ctypes.c_int64] * 4 + [c_vp, c_vp]),
     "ps_op_linear_wgrad": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp, c_vp]),
     "ps_op_bn_train_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int] + [c_vp] * 5),
     "ps_op_bn_train_bwd": (ctypes.c_int, [c_vp] * 7 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int] + [c_vp] * 3),

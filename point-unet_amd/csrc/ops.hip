@@ -206,3 +206,70 @@ extern "C" int ps_op_att_pool(ps_context* c, const float* fset, const float* wfc
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
+
+// --------------------------------------------------------------------------------------------------------
+// point -> volume scatter of the class probabilities (the post-processing loop of the reference's tester:
+// PointSegment/testBraTS.py:83-101 point2prod + :226-231; testPancreas.py:71-85):
+//     test_probs = zeros[total, C];  test_probs[p_idx] = softmax(logits)          (last duplicate wins)
+//     volume[z][x][y] = test_probs[i] for i in 0..total (last duplicate wins);  np.moveaxis(volume, 1, 2)
+// i.e. out[z, y, x, :] = softmax(logits[j]) where i is the LAST point sitting on voxel (x,y,z) and j the LAST sampled row
+// with p_idx[j] == i (zeros if the voxel's last point was not sampled).  Deterministic: winners by atomicMax.
+// --------------------------------------------------------------------------------------------------------
+namespace ps {
+
+__global__ __launch_bounds__(256) void winner_rows_kernel(const int32_t* __restrict__ p_idx, int n, int total, int32_t* __restrict__ winner_pt)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int i = p_idx ? p_idx[j] : j;
+    if (i >= 0 && i < total) atomicMax(&winner_pt[i], j);
+}
+
+__global__ __launch_bounds__(256) void winner_vox_kernel(const int32_t* __restrict__ xyz, int total, int Z, int X, int Y, int32_t* __restrict__ winner_vox)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    if (x < 0 || x >= X || y < 0 || y >= Y || z < 0 || z >= Z) return;
+    atomicMax(&winner_vox[((size_t)z * Y + y) * X + x], i);
+}
+
+__global__ __launch_bounds__(256) void fill_volume_kernel(const float* __restrict__ logits, const int32_t* __restrict__ winner_pt,
+                                                          const int32_t* __restrict__ winner_vox, size_t nvox, int C, float* __restrict__ out)
+{
+    const size_t v = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (v >= nvox) return;
+    const int i = winner_vox[v];
+    const int j = i >= 0 ? winner_pt[i] : -1;
+    float* o = out + v * C;
+    if (j < 0) {
+        for (int c = 0; c < C; ++c) o[c] = 0.f;
+        return;
+    }
+    const float* z = logits + (size_t)j * C;
+    float m = z[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(z[c] - m);
+    for (int c = 0; c < C; ++c) o[c] = expf(z[c] - m) / den;
+}
+
+}  // namespace ps
+
+extern "C" int ps_op_probs_to_volume(ps_context* c, const float* logits, int64_t n, int64_t C, const int32_t* p_idx, const int32_t* xyz_origin,
+                                     int64_t total, int64_t Z, int64_t X, int64_t Y, float* volume, int32_t* scratch)
+{
+    PS_CHECK(c && logits && xyz_origin && volume && scratch, "ps_op_probs_to_volume: NULL argument");
+    PS_CHECK(n >= 0 && total >= 1 && C >= 1 && Z >= 1 && X >= 1 && Y >= 1, "ps_op_probs_to_volume: bad shape");
+    PS_HIP(hipSetDevice(c->device));
+    const size_t nvox = (size_t)Z * X * Y;
+    int32_t* winner_pt = scratch;
+    int32_t* winner_vox = scratch + total;
+    Stage st(c, "op_probs_to_volume", 3);
+    PS_HIP(hipMemsetAsync(scratch, 0xff, sizeof(int32_t) * (total + nvox), c->stream));  // -1
+    if (n) hipLaunchKernelGGL(winner_rows_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, p_idx, (int)n, (int)total, winner_pt);
+    hipLaunchKernelGGL(winner_vox_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, c->stream, xyz_origin, (int)total, (int)Z, (int)X, (int)Y, winner_vox);
+    hipLaunchKernelGGL(fill_volume_kernel, dim3(ceil_div(nvox, 256)), dim3(256), 0, c->stream, logits, winner_pt, winner_vox, nvox, (int)C, volume);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}

@@ -142,3 +142,31 @@ def num_params(cfg):
         if kind in ("dense", "conv", "deconv"):
             n += 2 * cout
     return n
+
+
+def from_tf_variables(cfg, variables):
+    """Maps a dict of TF-1.x checkpoint variables of the reference model (as `tf.train.load_checkpoint(...)` would give
+    them: names under the 'layers/' scope, conv kernels [1,1,in,out] / [1,1,out,in], optimizer slots such as
+    '.../Adam' mixed in, RandLANet.py:56,101-102) onto this package's parameter dict.  Missing variables raise KeyError."""
+    out = {}
+    src = {}
+    for k, v in variables.items():
+        k = k[len("layers/"):] if k.startswith("layers/") else k
+        if k.endswith((":0",)):
+            k = k[:-2]
+        src[k] = np.asarray(v)
+    for scope, kind, cin, cout in layer_dims(cfg):
+        if kind in ("dense", "dense_nobias"):
+            out[scope + "/kernel"] = src[scope + "/kernel"].astype(np.float32).reshape(cin, cout)
+            if kind == "dense":
+                out[scope + "/bias"] = src[scope + "/bias"].astype(np.float32)
+                for n in ("gamma", "beta", "moving_mean", "moving_variance"):
+                    out["batch_normalization/" + n] = src["batch_normalization/" + n].astype(np.float32)
+        else:
+            w = src[scope + "/weights"].astype(np.float32)
+            out[scope + "/weights"] = w.reshape((cout, cin) if kind == "deconv" else (cin, cout))
+            out[scope + "/biases"] = src[scope + "/biases"].astype(np.float32)
+            if kind != "conv_nobn":
+                for n in ("gamma", "beta", "moving_mean", "moving_variance"):
+                    out[scope + "/batch_normalization/" + n] = src[scope + "/batch_normalization/" + n].astype(np.float32)
+    return out

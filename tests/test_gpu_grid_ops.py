@@ -90,3 +90,26 @@ def test_op_by_op_surface_vs_oracle(oracle):
     a = np.exp(a - a.max(2, keepdims=True))
     want = ro.leaky_relu((f64 * a / a.sum(2, keepdims=True)).sum(2) @ wm + bm)
     assert np.abs(got - want).max() < 1e-5
+
+
+def test_point_to_volume_scatter_matches_the_reference_loop():
+    """N3: testBraTS.py:83-101 + 226-231 semantics, including duplicate rows / duplicate voxels (last one wins) and
+    points that were not sampled (zeros)."""
+    import torch
+    from point_unet_amd.postprocess import point2prod
+    rng = np.random.default_rng(0)
+    Z, X, Y, C = 12, 20, 16, 4
+    total, n = 900, 700
+    xyz = np.stack([rng.integers(0, X, total), rng.integers(0, Y, total), rng.integers(0, Z, total)], 1).astype(np.int32)  # duplicates likely
+    p_idx = rng.integers(0, total, n).astype(np.int32)
+    logits = rng.standard_normal((n, C)).astype(np.float32)
+    e = np.exp(logits.astype(np.float64) - logits.max(1, keepdims=True))
+    probs = (e / e.sum(1, keepdims=True))
+    test_probs = np.zeros((total, C))
+    test_probs[p_idx] = probs                      # numpy fancy assignment: last duplicate wins
+    volume = np.zeros((Z, X, Y, C))
+    for i in range(total):                          # the reference's Python loop
+        volume[xyz[i][2]][xyz[i][0]][xyz[i][1]] = test_probs[i]
+    want = np.moveaxis(volume, 1, 2)
+    got = point2prod(torch.from_numpy(logits).cuda(), torch.from_numpy(p_idx).cuda(), torch.from_numpy(xyz).cuda(), (Z, X, Y)).cpu().numpy()
+    assert got.shape == want.shape and np.abs(got - want).max() < 1e-6

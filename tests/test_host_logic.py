@@ -176,3 +176,22 @@ def test_facade_validates_arguments():
         grid_subsampling.compute(np.zeros((5, 3), np.float32), features=np.zeros((4, 2), np.float32))
     with pytest.raises(RuntimeError, match="classes.shape is not"):
         grid_subsampling.compute(np.zeros((5, 3), np.float32), classes=np.zeros((4,), np.int32))
+
+
+def test_tf_variable_importer_round_trip():
+    """N1: TF-1.x checkpoint variable names/shapes -> parameter dict (names per SURVEY 8f N1)."""
+    from point_unet_amd import weights
+    from point_unet_amd.helper_tool import ConfigBraTS
+    p = weights.init_params(ConfigBraTS, seed=1, randomize_bn=True)
+    tf_vars = {}
+    for k, v in p.items():
+        if k.endswith("/weights"):
+            v = v.reshape((1, 1) + v.shape)  # conv kernels are 4-D in the checkpoint
+        tf_vars["layers/" + k] = v
+        if not k.endswith(("moving_mean", "moving_variance")):
+            tf_vars["layers/" + k + "/Adam"] = np.zeros_like(v)  # optimizer slots are saved too (RandLANet.py:101-102)
+    back = weights.from_tf_variables(ConfigBraTS, tf_vars)
+    assert set(back) == set(p)
+    for k in p:
+        assert np.array_equal(back[k], p[k]), k
+    assert np.array_equal(weights.fold_to_blob(ConfigBraTS, back), weights.fold_to_blob(ConfigBraTS, p))
