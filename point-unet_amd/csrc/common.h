@@ -82,7 +82,9 @@ struct ps_context {
     ps::Arena net_arena;     // activations of the forward pass
     ps::DevBuf stage_in;     // host<->device staging for device_ptrs == 0 calls
     ps::DevBuf stage_out;
-    ps::DevBuf ops_ws;       // packed weights of ps_op_conv1x1
+    ps::DevBuf red_ws;       // per-block partial sums of the per-channel reductions (ops_train.hip)
+    ps::DevBuf ops_ring[4];  // packed weights of ps_op_conv1x1 (same-stream calls are ordered; the ring is belt and braces)
+    int ops_ring_pos = 0;
     // deferred status checks (ps_set_deferred_checks): device flags land in pinned slots, validated at ps_synchronize
     bool deferred = false;
     int32_t* h_flags = nullptr;   // pinned [8][4]

@@ -164,7 +164,8 @@ int ps_destroy(ps_context* c)
     c->net_arena.buf.release();
     c->stage_in.release();
     c->stage_out.release();
-    c->ops_ws.release();
+    c->red_ws.release();
+    for (auto& b : c->ops_ring) b.release();
     if (c->h_flags) (void)hipHostFree(c->h_flags);
     for (auto& s : c->pin) {
         if (s.p) (void)hipHostFree(s.p);

@@ -66,6 +66,21 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, int cin, int co
     out[t] = (k < cin && col < cout) ? W[(size_t)k * cout + col] : 0.f;
 }
 
+__global__ void pack_weights_kperm_kernel(const float* __restrict__ W, int cin, int cout, int ntb, int nc, int cblocks, float* __restrict__ out)
+{
+    // k-permuted image of rowgemm.h: out[((((cb*nc + c)*16 + s)*64 + l)*ntb) + j] = W[c*64 + 16*(l>>4) + s][(cb*ntb + j)*16 + (l&15)]
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t total = (size_t)cblocks * nc * 16 * 64 * ntb;
+    if (t >= total) return;
+    const int j = (int)(t % ntb);
+    const int l = (int)((t / ntb) % 64);
+    const int s = (int)((t / ntb / 64) % 16);
+    const int c = (int)((t / ntb / 64 / 16) % nc);
+    const int cb = (int)(t / ntb / 64 / 16 / nc);
+    const int k = c * 64 + 16 * (l >> 4) + s, col = (cb * ntb + j) * 16 + (l & 15);
+    out[t] = (k < cin && col < cout) ? W[(size_t)k * cout + col] : 0.f;
+}
+
 // agg[r, col] = sum_k fset[r,k,col] * softmax_k( (fset[r] . wfc)[k, col] )    (RandLANet.py:394-398)
 template <int KMAX>
 __global__ __launch_bounds__(256) void att_pool_op_kernel(const float* __restrict__ fset, const float* __restrict__ wfc, float* __restrict__ agg,
@@ -172,12 +187,22 @@ extern "C" int ps_op_conv1x1(ps_context* c, const float* x, const float* w, cons
     L.ks = (L.cin + 3) / 4;
     L.ntb = choose_ntb(L.cout);
     L.cblocks = (L.cout + 16 * L.ntb - 1) / (16 * L.ntb);
-    PS_TRY(c->ops_ws.reserve(L.packed_floats() * sizeof(float)));
+    const bool kperm = (cin % 16) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;  // the direct-load kernel's layout (rowgemm.h)
+    const size_t need = (kperm ? L.kperm_floats() : L.packed_floats()) * sizeof(float);
+    // a small ring of packing buffers: consecutive calls on the stream must not overwrite weights still being read
+    ps::DevBuf& ws = c->ops_ring[c->ops_ring_pos];
+    c->ops_ring_pos = (c->ops_ring_pos + 1) & 3;
+    PS_TRY(ws.reserve(need));
     Stage st(c, "op_conv1x1", 2);
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(ceil_div(L.packed_floats(), 256)), dim3(256), 0, c->stream, w, L.cin, L.cout, L.ntb, L.ks, L.cblocks,
-                       c->ops_ws.as<float>());
+    if (kperm)
+        hipLaunchKernelGGL(pack_weights_kperm_kernel, dim3(ceil_div(L.kperm_floats(), 256)), dim3(256), 0, c->stream, w, L.cin, L.cout, L.ntb, L.nchunks(),
+                           L.cblocks, ws.as<float>());
+    else
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(ceil_div(L.packed_floats(), 256)), dim3(256), 0, c->stream, w, L.cin, L.cout, L.ntb, L.ks, L.cblocks,
+                           ws.as<float>());
     PS_HIP(hipGetLastError());
-    L.wp = c->ops_ws.as<float>();
+    L.wp = kperm ? nullptr : ws.as<float>();
+    L.wq = kperm ? ws.as<float>() : nullptr;
     L.bias = b;
     RowSrc s1, none;
     s1.x = x; s1.ld = L.cin; s1.c = L.cin;

@@ -4,8 +4,9 @@
 // softmax cross-entropy of RandLANet.py:267-274 and tf.train.AdamOptimizer (RandLANet.py:89).  The host graph
 // (point-unet_amd/train.py) records a tape of these ops; the kernels here are the op-level forward/backward pairs.
 //
-// All tensors are dense row-major fp32 [rows, channels] on the device.  Reductions over rows use block partials +
-// float atomics (summation order is not fixed; parity bars for gradients are relative 1e-3).
+// All tensors are dense row-major fp32 [rows, channels] on the device.  Per-channel reductions over rows (BatchNorm
+// statistics, bias / gamma / beta gradients) are two-stage with a fixed merge order, so the forward pass is run-to-run
+// bit-identical; the weight-gradient GEMM and the scatter-adds use float atomics (summation order not fixed, ~1e-6).
 // Bound: every kernel here is HBM-bound (one or two passes over [rows, C]) except linear_wgrad, which is an
 // MFMA GEMM with the row axis as K.
 #include "common.h"
@@ -17,9 +18,11 @@ namespace ps {
 // Layout trick: a block covers a contiguous slab of rows; thread t handles elements t, t+T, ... of the slab; with
 // T % C == 0 its channel never changes.  (C that does not divide T falls back to per-element modulo.)
 template <class F>
-__global__ __launch_bounds__(256) void colreduce2_kernel(F f, int64_t R, int C, int rows_per_block, float* __restrict__ out0,
-                                                         float* __restrict__ out1)
+__global__ __launch_bounds__(256) void colreduce2_kernel(F f, int64_t R, int C, int rows_per_block, float* __restrict__ part0,
+                                                         float* __restrict__ part1)
 {
+    // part{0,1}[block][c]: per-block partial sums, merged in a fixed order by colreduce_finish_kernel (no float atomics:
+    // the batch statistics, and with them which side of the leaky-ReLU kink an activation falls on, are run-to-run identical)
     __shared__ float s0[256], s1[256];
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
@@ -40,8 +43,8 @@ __global__ __launch_bounds__(256) void colreduce2_kernel(F f, int64_t R, int C, 
         if ((int)threadIdx.x < C) {
             float t0 = 0.f, t1 = 0.f;
             for (int i = threadIdx.x; i < 256; i += C) { t0 += s0[i]; t1 += s1[i]; }
-            atomicAdd(&out0[threadIdx.x], t0);
-            if (out1) atomicAdd(&out1[threadIdx.x], t1);
+            part0[(size_t)blockIdx.x * C + threadIdx.x] = t0;
+            if (part1) part1[(size_t)blockIdx.x * C + threadIdx.x] = t1;
         }
     } else {
         // generic: thread per channel group, rows strided
@@ -53,23 +56,50 @@ __global__ __launch_bounds__(256) void colreduce2_kernel(F f, int64_t R, int C, 
                 t0 += v0;
                 t1 += v1;
             }
-            atomicAdd(&out0[c], t0);
-            if (out1) atomicAdd(&out1[c], t1);
+            part0[(size_t)blockIdx.x * C + c] = t0;
+            if (part1) part1[(size_t)blockIdx.x * C + c] = t1;
         }
+    }
+}
+
+// out{0,1}[c] = sum_b part{0,1}[b][c]; one 64-lane wave per channel, lane-strided partials then a fixed shuffle tree
+__global__ __launch_bounds__(64) void colreduce_finish_kernel(const float* __restrict__ part0, const float* __restrict__ part1, int blocks, int C,
+                                                              float* __restrict__ out0, float* __restrict__ out1)
+{
+    const int c = blockIdx.x;
+    float t0 = 0.f, t1 = 0.f;
+    for (int b = threadIdx.x; b < blocks; b += 64) {
+        t0 += part0[(size_t)b * C + c];
+        if (part1) t1 += part1[(size_t)b * C + c];
+    }
+    for (int o = 32; o; o >>= 1) {
+        t0 += __shfl_down(t0, o);
+        t1 += __shfl_down(t1, o);
+    }
+    if (threadIdx.x == 0) {
+        out0[c] = t0;
+        if (out1) out1[c] = t1;
     }
 }
 
 template <class F>
 static int colreduce2(ps_context* c, F f, int64_t R, int C, float* out0, float* out1)
 {
-    PS_HIP(hipMemsetAsync(out0, 0, sizeof(float) * C, c->stream));
-    if (out1) PS_HIP(hipMemsetAsync(out1, 0, sizeof(float) * C, c->stream));
-    if (R <= 0) return PS_OK;
+    if (R <= 0) {
+        PS_HIP(hipMemsetAsync(out0, 0, sizeof(float) * C, c->stream));
+        if (out1) PS_HIP(hipMemsetAsync(out1, 0, sizeof(float) * C, c->stream));
+        return PS_OK;
+    }
     int64_t blocks = (R * C + 256 * 64 - 1) / (256 * 64);
-    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
     if ((256 % C) != 0) blocks = blocks > 512 ? 512 : blocks;
     const int rpb = (int)((R + blocks - 1) / blocks);
-    hipLaunchKernelGGL(colreduce2_kernel<F>, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(256), 0, c->stream, f, R, C, rpb, out0, out1);
+    const int nb = (int)((R + rpb - 1) / rpb);
+    PS_TRY(c->red_ws.reserve(sizeof(float) * 2 * (size_t)nb * C));
+    float* p0 = c->red_ws.as<float>();
+    float* p1 = out1 ? p0 + (size_t)nb * C : nullptr;
+    hipLaunchKernelGGL(colreduce2_kernel<F>, dim3((unsigned)nb), dim3(256), 0, c->stream, f, R, C, rpb, p0, p1);
+    hipLaunchKernelGGL(colreduce_finish_kernel, dim3((unsigned)C), dim3(64), 0, c->stream, p0, p1, nb, C, out0, out1);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
