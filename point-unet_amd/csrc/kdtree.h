@@ -14,10 +14,13 @@
 //                     coalescable run and needs no second indirection
 //   nodes[2n] int4    indexed by a deterministic node id:
 //                       leaf  over vind range [l, r)            id = 2*l      (even)  {l, r, 0, 0}
-//                       inner whose children meet at position m id = 2*m - 1  (odd)   {child1 | axis<<30,
-//                                                                                      child2, divlow, divhigh}
+//                       inner whose children meet at position m id = 2*m - 1  (odd)   {ref1 | axis<<30,
+//                                                                                      ref2, divlow, divhigh}
 //                     every split position belongs to exactly one inner node and every range start to exactly
 //                     one leaf, so ids never collide and do not depend on scheduling order.
+//                     A child REFERENCE (and TreeMeta::root) is the id plus, for a leaf, its point count in bits
+//                     26..29: the search gets a leaf's range [l, l+count) from the reference it already holds
+//                     and never loads the leaf record (one dependent memory round trip less per leaf visit).
 #pragma once
 
 #include <cfloat>
@@ -32,10 +35,15 @@ struct int4 { int x, y, z, w; };
 struct float4 { float x, y, z, w; };
 #endif
 
+#include "gmem.h"
+
 namespace ps {
 
 constexpr int kLeafMax = 10;   // KDTreeTableAdaptor(npts, dim, points, 10)  knn_.cxx:116
 constexpr int kStackMax = 64;  // deferred far-children per query; builders report the tree depth
+constexpr int kRefIdBits = 26;  // node ids < 2^26  =>  n < 2^25 points per tree
+constexpr int kRefIdMask = (1 << kRefIdBits) - 1;
+constexpr int kMaxTreePoints = 1 << 25;
 
 // Produced by the builder (on the device in production): root id, depth, root bounding box.
 struct TreeMeta {
@@ -67,6 +75,8 @@ PS_HD float as_f(int v) { float f; __builtin_memcpy(&f, &v, 4); return f; }
 PS_HD int as_i(float v) { int i; __builtin_memcpy(&i, &v, 4); return i; }
 #endif
 
+PS_HD int leaf_ref(int l, int count) { return 2 * l | (count << kRefIdBits); }
+
 PS_HD float sq_dist(float qx, float qy, float qz, float px, float py, float pz)
 {
     // ((dx*dx) + dy*dy) + dz*dz with diff = query - point   (nanoflann.hpp:343-346)
@@ -90,10 +100,38 @@ PS_HD void topk_insert(float (&dist)[K], int (&idx)[K], float d, int p)
     }
 }
 
+// Deferred far children of one query: (node id, lower bound m, per-axis offsets d0..d2).  PrivateStack keeps them in
+// per-lane arrays (host build: plain locals; device: scratch); knn.hip supplies an LDS-windowed variant with the same
+// interface for the search kernels.
+struct PrivateStack {
+    int id[kStackMax];
+    float m[kStackMax], d0[kStackMax], d1[kStackMax], d2[kStackMax];
+    int sp = 0;
+    PS_HD bool push(int node, float mm, float a, float b, float c)
+    {
+        if (sp >= kStackMax) return false;
+        id[sp] = node; m[sp] = mm; d0[sp] = a; d1[sp] = b; d2[sp] = c;
+        ++sp;
+        return true;
+    }
+    // most recent entry that still passes the prune test `m <= worst`; false when none is left
+    PS_HD bool pop(float worst, int& node, float& mm, float& a, float& b, float& c)
+    {
+        while (sp > 0) {
+            --sp;
+            if (m[sp] <= worst) {
+                node = id[sp]; mm = m[sp]; a = d0[sp]; b = d1[sp]; c = d2[sp];
+                return true;
+            }
+        }
+        return false;
+    }
+};
+
 // One query against one tree.  dist/idx must be initialised by the caller (FLT_MAX / 0).
 // Returns false if the deferred-node stack overflowed (tree deeper than kStackMax).
-template <int K>
-PS_HD bool knn_search_one(const TreeView& t, float qx, float qy, float qz, float (&dist)[K], int (&idx)[K])
+template <int K, class Stack>
+PS_HD bool knn_search_one(const TreeView& t, float qx, float qy, float qz, float (&dist)[K], int (&idx)[K], Stack& st)
 {
     if (t.n <= 0) return true;
     const TreeMeta mt = *t.meta;
@@ -106,15 +144,12 @@ PS_HD bool knn_search_one(const TreeView& t, float qx, float qy, float qz, float
     if (qz < mt.lo[2]) { d2 = f_mul(f_sub(qz, mt.lo[2]), f_sub(qz, mt.lo[2])); m = f_add(m, d2); }
     if (qz > mt.hi[2]) { d2 = f_mul(f_sub(qz, mt.hi[2]), f_sub(qz, mt.hi[2])); m = f_add(m, d2); }
 
-    int st_id[kStackMax];
-    float st_m[kStackMax], st_d0[kStackMax], st_d1[kStackMax], st_d2[kStackMax];
-    int sp = 0;
     bool ok = true;
     int cur = mt.root;
     for (;;) {
         // ---- descend to a leaf, deferring the far children (searchLevel, nanoflann.hpp:1372-1406) ----
         while (cur & 1) {
-            const int4 nd = t.nodes[cur];
+            const int4 nd = gload(t.nodes + cur);
             const int ax = (int)((unsigned)nd.x >> 30);
             const int c1 = nd.x & 0x3fffffff, c2 = nd.y;
             const float divlow = as_f(nd.z), divhigh = as_f(nd.w);
@@ -127,47 +162,47 @@ PS_HD bool knn_search_one(const TreeView& t, float qx, float qy, float qz, float
             const float m2 = f_sub(f_add(m, cut), dax);
             // The reference tests `m2 <= worstDist()` AFTER the near subtree returns; worstDist() only ever
             // decreases, so a far child that already fails now can never pass later: do not defer it.
-            if (m2 <= dist[K - 1]) {
-                if (sp < kStackMax) {
-                    st_id[sp] = left_first ? c2 : c1;
-                    st_m[sp] = m2;
-                    st_d0[sp] = ax == 0 ? cut : d0;
-                    st_d1[sp] = ax == 1 ? cut : d1;
-                    st_d2[sp] = ax == 2 ? cut : d2;
-                    ++sp;
-                } else
-                    ok = false;
-            }
+            if (m2 <= dist[K - 1])
+                ok &= st.push(left_first ? c2 : c1, m2, ax == 0 ? cut : d0, ax == 1 ? cut : d1, ax == 2 ? cut : d2);
             cur = left_first ? c1 : c2;
         }
         // ---- leaf: scan its points in vind order (nanoflann.hpp:1355-1369) ----
         {
-            const int4 lf = t.nodes[cur];
-            for (int i = lf.x; i < lf.y; ++i) {
+            const int lf_x = (cur & kRefIdMask) >> 1, lf_y = lf_x + (cur >> kRefIdBits);  // from the reference, no node load
+#if defined(__HIP_DEVICE_COMPILE__)
+            // all (<= kLeafMax) point loads are issued before the first distance is needed: one memory round trip per
+            // leaf instead of one per point
+            float4 pv[kLeafMax];
+#pragma unroll
+            for (int j = 0; j < kLeafMax; ++j) pv[j] = gload(t.pts + (lf_x + j < lf_y ? lf_x + j : lf_y - 1));
+#pragma unroll
+            for (int j = 0; j < kLeafMax; ++j) {
+                if (lf_x + j < lf_y) {
+                    const float d = sq_dist(qx, qy, qz, pv[j].x, pv[j].y, pv[j].z);
+                    if (d < dist[K - 1]) topk_insert<K>(dist, idx, d, as_i(pv[j].w));
+                }
+            }
+#else
+            for (int i = lf_x; i < lf_y; ++i) {
                 const float4 p = t.pts[i];
                 const float d = sq_dist(qx, qy, qz, p.x, p.y, p.z);
                 // the reference filters on a worst distance sampled once per leaf and lets addPoint drop the
                 // late-comers; both together accept exactly the points with d < current worst.
                 if (d < dist[K - 1]) topk_insert<K>(dist, idx, d, as_i(p.w));
             }
+#endif
         }
         // ---- resume at the most recent deferred child that still passes the prune test ----
-        bool found = false;
-        while (sp > 0) {
-            --sp;
-            if (st_m[sp] <= dist[K - 1]) {
-                cur = st_id[sp];
-                m = st_m[sp];
-                d0 = st_d0[sp];
-                d1 = st_d1[sp];
-                d2 = st_d2[sp];
-                found = true;
-                break;
-            }
-        }
-        if (!found) break;
+        if (!st.pop(dist[K - 1], cur, m, d0, d1, d2)) break;
     }
     return ok;
+}
+
+template <int K>
+PS_HD bool knn_search_one(const TreeView& t, float qx, float qy, float qz, float (&dist)[K], int (&idx)[K])
+{
+    PrivateStack st;
+    return knn_search_one<K, PrivateStack>(t, qx, qy, qz, dist, idx, st);
 }
 
 }  // namespace ps

@@ -511,9 +511,10 @@ __global__ __launch_bounds__(256) void build_subtree_kernel(const BuildTree* __r
                 const int id = 2 * (k.l + l);
                 if (lane == 0) {
                     t.nodes[id] = make_int4(k.l + l, k.l + u.r, 0, 0);
-                    if (u.parent < 0) t.meta->root = id;
-                    else if (u.side == 0) atomicOr(&t.nodes[u.parent].x, id);
-                    else t.nodes[u.parent].y = id;
+                    const int ref = leaf_ref(k.l + l, count);
+                    if (u.parent < 0) t.meta->root = ref;
+                    else if (u.side == 0) atomicOr(&t.nodes[u.parent].x, ref);
+                    else t.nodes[u.parent].y = ref;
                 }
                 max_level = max(max_level, (int)u.level);
                 continue;

@@ -54,7 +54,7 @@ struct Builder {
         return (int32_t)left;
     }
 
-    // Returns the id of the node built over vind[l, r); box is the incoming box and leaves as the tight box.
+    // Returns the reference (kdtree.h) of the node built over vind[l, r); box is the incoming box and leaves as the tight box.
     int32_t build(int32_t l, int32_t r, Box& box, int level)
     {
         depth = std::max(depth, level);
@@ -67,7 +67,7 @@ struct Builder {
                     if (box.hi[ax] < v) box.hi[ax] = v;
                 }
             nodes[2 * (size_t)l] = make_int4(l, r, 0, 0);
-            return 2 * l;
+            return leaf_ref(l, r - l);
         }
         int32_t* ind = vind.data() + l;
         const int32_t count = r - l;

@@ -26,23 +26,72 @@ struct KnnJob {
     int32_t* overflow;  // set to 1 if any query overflowed the deferred-node stack
 };
 
+// Deferred-node stack of the search kernels: the kWin most recent entries of every lane live in LDS
+// ([slot][word][thread]: a wave's access to one word is one conflict-free row), older ones spill to per-lane scratch
+// and come back only when the window has drained.  A pop is the head of the next dependent node load, so its latency
+// (LDS ~100 cycles vs a scratch round trip through L2/HBM) is on the critical path of every query; the first descent
+// pushes ~log2(n/10) entries, of which the shallow ones -- spilled -- are almost always pruned by their `m` alone.
+constexpr int kWin = 8;
+struct WindowStack {
+    typedef __attribute__((address_space(3))) float lds_float;
+    lds_float* w;  // LDS base of this thread (already offset by threadIdx.x); word stride = 256 threads
+    int sp = 0, lo = 0;  // entries [lo, sp) are in LDS at slot (depth % kWin); [0, lo) in scratch
+    int sid[kStackMax];
+    float sm[kStackMax], s0[kStackMax], s1[kStackMax], s2[kStackMax];
+    __device__ __forceinline__ bool push(int node, float mm, float a, float b, float c)
+    {
+        if (sp >= kStackMax) return false;
+        if (sp - lo == kWin) {  // spill the oldest windowed entry
+            const lds_float* e = w + (lo & (kWin - 1)) * 5 * 256;
+            sid[lo] = __float_as_int(e[0]); sm[lo] = e[256]; s0[lo] = e[512]; s1[lo] = e[768]; s2[lo] = e[1024];
+            ++lo;
+        }
+        lds_float* e = w + (sp & (kWin - 1)) * 5 * 256;
+        e[0] = __int_as_float(node); e[256] = mm; e[512] = a; e[768] = b; e[1024] = c;
+        ++sp;
+        return true;
+    }
+    __device__ __forceinline__ bool pop(float worst, int& node, float& mm, float& a, float& b, float& c)
+    {
+        while (sp > 0) {
+            --sp;
+            if (sp >= lo) {
+                const lds_float* e = w + (sp & (kWin - 1)) * 5 * 256;
+                const float em = e[256];
+                if (em <= worst) {
+                    node = __float_as_int(e[0]); mm = em; a = e[512]; b = e[768]; c = e[1024];
+                    return true;
+                }
+            } else {
+                lo = sp;  // the window is empty; this entry comes from scratch
+                if (sm[sp] <= worst) {
+                    node = sid[sp]; mm = sm[sp]; a = s0[sp]; b = s1[sp]; c = s2[sp];
+                    return true;
+                }
+            }
+        }
+        return false;
+    }
+};
+
 template <int K>
 __global__ __launch_bounds__(256) void knn_kernel(const KnnJob* __restrict__ jobs)
 {
+    __shared__ float win[kWin * 5 * 256];
     const KnnJob& job = jobs[blockIdx.y];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= job.nq) return;
-    if (job.overflow[2] != 0) return;  // the tree builder has not finished (unbalanced cloud): the host re-runs us
+    if (gload(job.overflow + 2) != 0) return;  // the tree builder has not finished (unbalanced cloud): the host re-runs us
     float qx, qy, qz;
     int row;
     if (job.q4) {
-        const float4 q = job.q4[t];
+        const float4 q = gload(job.q4 + t);
         qx = q.x; qy = q.y; qz = q.z;
         row = as_i(q.w);
     } else {
-        qx = job.q3[3 * (size_t)t];
-        qy = job.q3[3 * (size_t)t + 1];
-        qz = job.q3[3 * (size_t)t + 2];
+        qx = gload(job.q3 + 3 * (size_t)t);
+        qy = gload(job.q3 + 3 * (size_t)t + 1);
+        qz = gload(job.q3 + 3 * (size_t)t + 2);
         row = t;
     }
     float dist[K];
@@ -52,15 +101,17 @@ __global__ __launch_bounds__(256) void knn_kernel(const KnnJob* __restrict__ job
         dist[j] = FLT_MAX;
         idx[j] = 0;
     }
-    const bool ok = knn_search_one<K>(job.tree, qx, qy, qz, dist, idx);
-    if (!ok) *job.overflow = 1;
+    WindowStack st;
+    st.w = (WindowStack::lds_float*)(win + threadIdx.x);
+    const bool ok = knn_search_one<K, WindowStack>(job.tree, qx, qy, qz, dist, idx, st);
+    if (!ok) gstore(job.overflow, 1);
     int32_t* o = job.out + (size_t)row * K;
     if constexpr (K % 4 == 0) {
 #pragma unroll
-        for (int j = 0; j < K; j += 4) *reinterpret_cast<int4*>(o + j) = make_int4(idx[j], idx[j + 1], idx[j + 2], idx[j + 3]);
+        for (int j = 0; j < K; j += 4) gstore(reinterpret_cast<int4*>(o + j), make_int4(idx[j], idx[j + 1], idx[j + 2], idx[j + 3]));
     } else {
 #pragma unroll
-        for (int j = 0; j < K; ++j) o[j] = idx[j];
+        for (int j = 0; j < K; ++j) gstore(o + j, idx[j]);
     }
 }
 
@@ -104,7 +155,7 @@ static int knn_batch_impl(ps_context* c, const float* support, const float* quer
     PS_CHECK(c != nullptr, "ps_knn_batch: ctx is NULL");
     PS_CHECK(dim == 3, "ps_knn_batch: dim must be 3 (got %lld)", (long long)dim);
     PS_CHECK(B >= 0 && n1 >= 0 && n2 >= 0 && K >= 1, "ps_knn_batch: negative size or K < 1");
-    PS_CHECK(n1 < (1 << 29), "ps_knn_batch: n_support too large");
+    PS_CHECK(n1 < kMaxTreePoints, "ps_knn_batch: n_support too large (limit 2^25 points per cloud)");
     PS_CHECK(out32 != nullptr || out64 != nullptr, "ps_knn_batch: out_idx is NULL");
     if (B == 0 || n2 == 0) return PS_OK;
     PS_CHECK(support != nullptr || n1 == 0, "ps_knn_batch: support is NULL");
@@ -231,7 +282,7 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
 {
     PS_CHECK(c && xyz0 && ratios && pyr, "ps_pyramid_build: NULL argument");
     PS_CHECK(L >= 1 && L <= PS_MAX_LAYERS, "ps_pyramid_build: num_layers %d out of range", L);
-    PS_CHECK(B >= 1 && n0 >= 1 && n0 < (1 << 29), "ps_pyramid_build: bad B / n0");
+    PS_CHECK(B >= 1 && n0 >= 1 && n0 < kMaxTreePoints, "ps_pyramid_build: bad B / n0");
     PS_HIP(hipSetDevice(c->device));
     int64_t n[PS_MAX_LAYERS + 1];
     n[0] = n0;

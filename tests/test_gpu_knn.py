@@ -145,7 +145,7 @@ def test_device_tree_equals_host_tree(lib, case):
     # walk both node tables from the root
     stack = [int(h[3][0])]
     while stack:
-        i = stack.pop()
+        i = stack.pop() & ((1 << 26) - 1)  # reference -> node id (leaf references carry the point count above bit 26)
         assert np.array_equal(h[1][i], d[1][i]), i
         if i & 1:
             stack += [int(h[1][i, 0]) & 0x3fffffff, int(h[1][i, 1])]

@@ -53,11 +53,12 @@ def test_tree_layout_against_oracle_tree(lib, oracle):
     assert np.array_equal(bbox, t["bbox"])
     assert np.array_equal(pts[:, :3], p[vind]) and np.array_equal(pts[:, 3].view(np.int32), vind)
 
-    def walk(oid, pid, lo, hi):
+    def walk(oid, ref, lo, hi):
+        pid, cnt = ref & ((1 << 26) - 1), ref >> 26  # reference = node id | leaf point count << 26 (csrc/kdtree.h)
         if t["axis"][oid] < 0:
-            assert pid % 2 == 0 and pid // 2 == t["a"][oid] == lo and nodes[pid, 0] == lo and nodes[pid, 1] == t["b"][oid] == hi
+            assert cnt == hi - lo and pid % 2 == 0 and pid // 2 == t["a"][oid] == lo and nodes[pid, 0] == lo and nodes[pid, 1] == t["b"][oid] == hi
             return 1
-        assert pid % 2 == 1
+        assert cnt == 0 and pid % 2 == 1
         m = (pid + 1) // 2
         ax = (int(nodes[pid, 0]) & 0xffffffff) >> 30
         assert ax == t["axis"][oid]
