@@ -157,14 +157,39 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
                     for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[rt][j][r]);
                 m = xor_max(m);
                 float ssum = 0.f, num = 0.f;
+                // values of the weighted sum: columns < H are the gathered neighbour features (global), the rest f_xyz
+                // (LDS).  For H % 16 == 0 a 16-column tile lies on one side: a wave-uniform branch, so the compiler emits
+                // global_load / ds_read instead of a flat_load on a selected address.
+                float v[RT][4];
+                if constexpr (H % 16 == 0) {
+                    if ((cb * NTB_D + j) * 16 < H) {
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[rt][r] = a.fg[jr[rt][r] + col];
+                    } else {
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[rt][r] = TX[(rt * 16 + g * 4 + r) * PITCH + (col - H)];
+                    }
+                } else {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float vg = a.fg[jr[rt][r] + (col < H ? col : 0)];
+                            const float vl = TX[(rt * 16 + g * 4 + r) * PITCH + (col < H ? 0 : col - H)];
+                            v[rt][r] = col < H ? vg : vl;
+                        }
+                }
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float e = __expf(acc[rt][j][r] - m);
-                        const float v = col < H ? a.fg[jr[rt][r] + col] : TX[(rt * 16 + g * 4 + r) * PITCH + (col - H)];
                         ssum += e;
-                        num += e * v;
+                        num += e * v[rt][r];
                     }
                 ssum = xor_sum(ssum);
                 num = xor_sum(num);

@@ -21,6 +21,7 @@
 #include "kdtree_build.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace ps {
 
@@ -64,6 +65,14 @@ __device__ __forceinline__ float ord2f(unsigned u)
 }
 __device__ __forceinline__ float comp(const float4& p, int ax) { return ax == 0 ? p.x : (ax == 1 ? p.y : p.z); }
 
+// Global-address-space view of a device array reached through a descriptor in memory (gmem.h): reads a[i], writes a.set(i, v).
+template <class T>
+struct GArr {
+    T* p;
+    __device__ __forceinline__ typename std::remove_const<T>::type operator[](size_t i) const { return gload(static_cast<const T*>(p) + i); }
+    __device__ __forceinline__ void set(size_t i, const T& v) const { gstore(p + i, v); }
+};
+
 // ---- init -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void init_points_kernel(const BuildTree* __restrict__ trees, int chunks_x)
 {
@@ -71,8 +80,8 @@ __global__ __launch_bounds__(256) void init_points_kernel(const BuildTree* __res
     const BuildTree t = trees[blockIdx.y];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < t.n; i += chunks_x * 256) {
-        const float x = t.src[3 * (size_t)i], y = t.src[3 * (size_t)i + 1], z = t.src[3 * (size_t)i + 2];
-        t.pts[i] = make_float4(x, y, z, __int_as_float(i));
+        const float x = gload(t.src + 3 * (size_t)i), y = gload(t.src + 3 * (size_t)i + 1), z = gload(t.src + 3 * (size_t)i + 2);
+        gstore(t.pts + i, make_float4(x, y, z, __int_as_float(i)));
         mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
         mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
         mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTre
     if ((int)blockIdx.x >= n_tasks) return;
     const BuildTask k = Q.q[level & 1][blockIdx.x];
     const BuildTree t = trees[k.tree];
-    float4* a = t.pts + k.l;
+    const GArr<float4> a{t.pts + k.l};
     const int count = k.r - k.l;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
@@ -339,8 +348,8 @@ __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTre
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int p = wbase + e * 64 + lane;
-                if ((bL[e] >> lane) & 1ull) t.posL[k.l + rL + __popcll(bL[e] & lt_mask)] = p;
-                if ((bR[e] >> lane) & 1ull) t.posR[k.l + rR + __popcll(bR[e] & lt_mask)] = p;
+                if ((bL[e] >> lane) & 1ull) gstore(t.posL + k.l + rL + __popcll(bL[e] & lt_mask), p);
+                if ((bR[e] >> lane) & 1ull) gstore(t.posR + k.l + rR + __popcll(bR[e] & lt_mask), p);
                 rL += __popcll(bL[e]);
                 rR += __popcll(bR[e]);
             }
@@ -350,10 +359,10 @@ __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTre
         __syncthreads();  // posL / posR written by this workgroup are read below by other waves of it
         const int m = offL;  // == offR
         for (int i = tid; i < m; i += T) {
-            const int pl = t.posL[k.l + i], pr = t.posR[k.l + m - 1 - i];
+            const int pl = gload(t.posL + k.l + i), pr = gload(t.posR + k.l + m - 1 - i);
             const float4 x = a[pl], y = a[pr];
-            a[pl] = y;
-            a[pr] = x;
+            a.set(pl, y);
+            a.set(pr, x);
         }
         __syncthreads();
     }
@@ -493,7 +502,7 @@ __global__ __launch_bounds__(256) void build_subtree_kernel(const BuildTree* __r
         const BuildTask k = Q.small_q[ti];
         const BuildTree t = trees[k.tree];
         const int total = k.r - k.l;
-        for (int i = lane; i < total; i += 64) P[i] = t.pts[k.l + i];
+        for (int i = lane; i < total; i += 64) P[i] = gload(t.pts + k.l + i);
         if (lane == 0) {
             SubTask r;
             r.l = 0; r.r = (short)total; r.parent = k.parent; r.side = (short)k.side; r.level = (short)k.level;
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(256) void build_subtree_kernel(const BuildTree* __r
             sp += 2;
             wave_sync_lds();
         }
-        for (int i = lane; i < total; i += 64) t.pts[k.l + i] = P[i];
+        for (int i = lane; i < total; i += 64) gstore(t.pts + k.l + i, P[i]);
         if (lane == 0) atomicMax(&t.meta->depth, max_level);
         wave_sync_lds();
     }
@@ -661,7 +670,7 @@ __global__ __launch_bounds__(256) void huge_minmax_kernel(const BuildTree* __res
     const ChunkRef cr = find_chunk(H, level, blockIdx.x);
     if (cr.task < 0) return;
     HugeTask& t = H.tasks[level & 1][cr.task];
-    const float4* a = trees[t.k.tree].pts + t.k.l + cr.first;
+    const GArr<const float4> a{trees[t.k.tree].pts + t.k.l + cr.first};
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int e = 0; e < kChunk / 256; ++e) {
@@ -697,7 +706,7 @@ __global__ __launch_bounds__(256) void huge_count_kernel(const BuildTree* __rest
     if (cr.task < 0) return;
     HugeTask& t = H.tasks[level & 1][cr.task];
     const SplitChoice sc = huge_split(t);
-    const float4* a = trees[t.k.tree].pts + t.k.l + cr.first;
+    const GArr<const float4> a{trees[t.k.tree].pts + t.k.l + cr.first};
     int lt = 0, le = 0;
     float maxlt = -INFINITY, mingt = INFINITY;
 #pragma unroll
@@ -734,7 +743,7 @@ __global__ __launch_bounds__(256) void huge_count_kernel(const BuildTree* __rest
 
 // flags of one chunk for sweep S as E ballots per wave (wave w owns records [w*512, w*512+512) of the chunk, striped)
 template <int S>
-__device__ __forceinline__ void chunk_flags(const float4* a, const ChunkRef& cr, const SplitChoice& sc, int lim1, int lim2, int wave, int lane,
+__device__ __forceinline__ void chunk_flags(const GArr<const float4>& a, const ChunkRef& cr, const SplitChoice& sc, int lim1, int lim2, int wave, int lane,
                                             unsigned long long (&bL)[8], unsigned long long (&bR)[8])
 {
     const int from = S == 0 ? 0 : lim1, bound = S == 0 ? lim1 : lim2;
@@ -762,7 +771,7 @@ __global__ __launch_bounds__(256) void huge_sweepcount_kernel(const BuildTree* _
     if (cr.task < 0) return;
     const HugeTask& t = H.tasks[level & 1][cr.task];
     const SplitChoice sc = huge_split(t);
-    const float4* a = trees[t.k.tree].pts + t.k.l + cr.first;
+    const GArr<const float4> a{trees[t.k.tree].pts + t.k.l + cr.first};
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned long long bL[8], bR[8];
     chunk_flags<S>(a, cr, sc, t.lt, t.le, wave, lane, bL, bR);
@@ -787,7 +796,7 @@ __global__ __launch_bounds__(256) void huge_scatter_kernel(const BuildTree* __re
     const HugeTask& t = H.tasks[level & 1][cr.task];
     const BuildTree tr = trees[t.k.tree];
     const SplitChoice sc = huge_split(t);
-    const float4* a = tr.pts + t.k.l + cr.first;
+    const GArr<const float4> a{tr.pts + t.k.l + cr.first};
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // ranks before this chunk = misplaced counts of the node's earlier chunks
     int pl = 0, pr = 0;
@@ -813,8 +822,8 @@ __global__ __launch_bounds__(256) void huge_scatter_kernel(const BuildTree* __re
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int p = cr.first + wave * 512 + e * 64 + lane;
-        if ((bL[e] >> lane) & 1ull) tr.posL[t.k.l + rL + __popcll(bL[e] & lt_mask)] = p;
-        if ((bR[e] >> lane) & 1ull) tr.posR[t.k.l + rR + __popcll(bR[e] & lt_mask)] = p;
+        if ((bL[e] >> lane) & 1ull) gstore(tr.posL + t.k.l + rL + __popcll(bL[e] & lt_mask), p);
+        if ((bR[e] >> lane) & 1ull) gstore(tr.posR + t.k.l + rR + __popcll(bR[e] & lt_mask), p);
         rL += __popcll(bL[e]);
         rR += __popcll(bR[e]);
     }
@@ -828,7 +837,7 @@ __global__ __launch_bounds__(256) void huge_swap_kernel(const BuildTree* __restr
     if (cr.task < 0) return;
     const HugeTask& t = H.tasks[level & 1][cr.task];
     const BuildTree tr = trees[t.k.tree];
-    float4* a = tr.pts + t.k.l;
+    const GArr<float4> a{tr.pts + t.k.l};
     int m = 0;
     for (int c = t.chunk0 + threadIdx.x; c < t.chunk0 + t.nchunks; c += 256) m += H.c_mL[c];
     for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o);
@@ -839,10 +848,10 @@ __global__ __launch_bounds__(256) void huge_swap_kernel(const BuildTree* __restr
     m = s_m;
     // this chunk's share of the m swap pairs
     for (int i = cr.first + threadIdx.x; i < min(m, cr.first + kChunk); i += 256) {
-        const int pl = tr.posL[t.k.l + i], pr = tr.posR[t.k.l + m - 1 - i];
+        const int pl = gload(tr.posL + t.k.l + i), pr = gload(tr.posR + t.k.l + m - 1 - i);
         const float4 x = a[pl], y = a[pr];
-        a[pl] = y;
-        a[pr] = x;
+        a.set(pl, y);
+        a.set(pr, x);
     }
 }
 
