@@ -22,6 +22,7 @@ struct TreeSetPlan {
     void* d_scratch = nullptr;       // builder scratch
     size_t scratch_bytes = 0;
     int launches = 0;                // kernels launched by build_trees (for the stage timer)
+    int first_pending_level = 0;     // first level queue build_trees did not launch a kernel for (build_trees_continue starts there)
     std::vector<char> host_blob;     // host staging of the builder's tables (must outlive the async copies)
 
     void add(int32_t count)

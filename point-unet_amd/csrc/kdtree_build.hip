@@ -26,6 +26,8 @@
 namespace ps {
 
 constexpr int kSmall = 256;     // nodes up to this many points are finished by one wave in LDS
+constexpr int kMid = 8192;      // nodes up to this many points are split down to <= kSmall by one workgroup in LDS
+constexpr int kMidThreads = 1024;
 constexpr int kBigThreads = 512;
 constexpr int kMaxLevels = 96;  // per-level task counters
 
@@ -47,9 +49,10 @@ struct BuildTree {
 
 struct BuildQueues {
     BuildTask* q[2];
-    BuildTask* small_q;
+    BuildTask* mid_q;    // nodes of kSmall+1 .. kMid points (build_mid_kernel)
+    BuildTask* small_q;  // nodes of <= kSmall points (build_subtree_kernel)
     int32_t* level_cnt;  // [kMaxLevels]
-    int32_t* small_cnt;
+    int32_t* small_cnt;  // small_cnt[0] = pushed, [1] = mid pushed, [2] = mid done, [3] = small done
     int32_t* flags;      // flags[1] = queue overflow
     int32_t q_cap, small_cap;
 };
@@ -108,10 +111,16 @@ __global__ __launch_bounds__(256) void init_points_kernel(const BuildTree* __res
 
 __device__ __forceinline__ void push_task(const BuildQueues& Q, const BuildTask& t, int next_level)
 {
-    if (t.r - t.l > kSmall) {
+    if (t.r - t.l > kMid) {
         const int slot = atomicAdd(&Q.level_cnt[next_level], 1);
         if (slot < Q.q_cap && next_level < kMaxLevels - 1)
             Q.q[next_level & 1][slot] = t;
+        else
+            Q.flags[1] = 1;
+    } else if (t.r - t.l > kSmall) {
+        const int slot = atomicAdd(Q.small_cnt + 1, 1);
+        if (slot < Q.q_cap)
+            Q.mid_q[slot] = t;
         else
             Q.flags[1] = 1;
     } else {
@@ -191,12 +200,15 @@ __device__ __forceinline__ void emit_inner(const BuildQueues& Q, const BuildTree
         c.parent = id;
         c.side = s;
         c.level = k.level + 1;
+        // (compile-time indices only: a run-time index would push the task into scratch memory)
         if (s == 0) {
             c.r = m;
-            c.hi[ax] = cut;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) c.hi[a] = a == ax ? cut : c.hi[a];
         } else {
             c.l = m;
-            c.lo[ax] = cut;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) c.lo[a] = a == ax ? cut : c.lo[a];
         }
         kids[s] = c;
     }
@@ -378,7 +390,7 @@ __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTre
 }
 
 // ---- subtree kernel: one wave finishes a node of <= kSmall points -----------------------------------------------
-constexpr int kSubStack = kSmall;  // worst case: every split peels one point
+constexpr int kSubStack = 12;  // the smaller child is finished first: at most log2(kSmall) + 2 deferred siblings
 
 struct SubTask {
     short l, r;       // range relative to the node's first record
@@ -492,13 +504,13 @@ __global__ __launch_bounds__(256) void build_subtree_kernel(const BuildTree* __r
     __shared__ short s_posL[WPB][kSmall], s_posR[WPB][kSmall];
     __shared__ SubTask s_stack[WPB][kSubStack];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n_tasks = min(*Q.small_cnt, Q.small_cap);
+    const int n_tasks = min(Q.small_cnt[0], Q.small_cap);
     float4* P = s_pts[wave];
     short* posL = s_posL[wave];
     short* posR = s_posR[wave];
     SubTask* stack = s_stack[wave];
 
-    for (int ti = blockIdx.x * WPB + wave; ti < n_tasks; ti += gridDim.x * WPB) {
+    for (int ti = Q.small_cnt[3] + blockIdx.x * WPB + wave; ti < n_tasks; ti += gridDim.x * WPB) {
         const BuildTask k = Q.small_q[ti];
         const BuildTree t = trees[k.tree];
         const int total = k.r - k.l;
@@ -514,24 +526,29 @@ __global__ __launch_bounds__(256) void build_subtree_kernel(const BuildTree* __r
         wave_sync_lds();
         while (sp > 0) {
             --sp;
-            const SubTask u = stack[sp];
-            const int l = u.l, count = u.r - u.l;
+            // (fields are copied one by one with compile-time indices: a whole-struct copy indexed at run time lands in scratch)
+            const int l = stack[sp].l, u_r = stack[sp].r, count = u_r - l;
+            const int u_parent = stack[sp].parent, u_side = stack[sp].side, u_level = stack[sp].level;
+            float blo[3], bhi[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { blo[c] = stack[sp].lo[c]; bhi[c] = stack[sp].hi[c]; }
+            wave_sync_lds();  // every lane has its copy before lane 0 reuses the slot
             if (count <= kLeafMax) {
                 const int id = 2 * (k.l + l);
                 if (lane == 0) {
-                    t.nodes[id] = make_int4(k.l + l, k.l + u.r, 0, 0);
+                    t.nodes[id] = make_int4(k.l + l, k.l + u_r, 0, 0);
                     const int ref = leaf_ref(k.l + l, count);
-                    if (u.parent < 0) t.meta->root = ref;
-                    else if (u.side == 0) atomicOr(&t.nodes[u.parent].x, ref);
-                    else t.nodes[u.parent].y = ref;
+                    if (u_parent < 0) t.meta->root = ref;
+                    else if (u_side == 0) atomicOr(&t.nodes[u_parent].x, ref);
+                    else t.nodes[u_parent].y = ref;
                 }
-                max_level = max(max_level, (int)u.level);
+                max_level = max(max_level, u_level);
                 continue;
             }
             SubSplit sr;
-            if (count <= 64) sr = split_in_lds<1>(P + l, count, u.lo, u.hi, posL, posR, lane);
-            else if (count <= 128) sr = split_in_lds<2>(P + l, count, u.lo, u.hi, posL, posR, lane);
-            else sr = split_in_lds<4>(P + l, count, u.lo, u.hi, posL, posR, lane);
+            if (count <= 64) sr = split_in_lds<1>(P + l, count, blo, bhi, posL, posR, lane);
+            else if (count <= 128) sr = split_in_lds<2>(P + l, count, blo, bhi, posL, posR, lane);
+            else sr = split_in_lds<4>(P + l, count, blo, bhi, posL, posR, lane);
             const int half = count / 2;
             const int idx = sr.lim1 > half ? sr.lim1 : (sr.lim2 < half ? sr.lim2 : half);
             const int m = k.l + l + idx;
@@ -540,14 +557,23 @@ __global__ __launch_bounds__(256) void build_subtree_kernel(const BuildTree* __r
                 const float divlow = idx > sr.lim1 ? sr.cut : sr.maxlt;
                 const float divhigh = idx < sr.lim2 ? sr.cut : sr.mingt;
                 t.nodes[id] = make_int4((int)((unsigned)sr.ax << 30), 0, __float_as_int(divlow), __float_as_int(divhigh));
-                if (u.parent < 0) t.meta->root = id;
-                else if (u.side == 0) atomicOr(&t.nodes[u.parent].x, id);
-                else t.nodes[u.parent].y = id;
-                SubTask c0 = u, c1 = u;
-                c0.r = (short)(l + idx); c0.hi[sr.ax] = sr.cut; c0.parent = id; c0.side = 0; c0.level = (short)(u.level + 1);
-                c1.l = (short)(l + idx); c1.lo[sr.ax] = sr.cut; c1.parent = id; c1.side = 1; c1.level = (short)(u.level + 1);
-                stack[sp] = c1;
-                stack[sp + 1] = c0;
+                if (u_parent < 0) t.meta->root = id;
+                else if (u_side == 0) atomicOr(&t.nodes[u_parent].x, id);
+                else t.nodes[u_parent].y = id;
+                const bool left_small = idx <= count - idx;  // finish the smaller side first (order does not change the tree)
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int side = ((pass == 0) == left_small) ? 1 : 0;
+                    SubTask& ch = stack[sp + pass];
+                    ch.l = (short)(side == 0 ? l : l + idx);
+                    ch.r = (short)(side == 0 ? l + idx : u_r);
+                    ch.parent = id; ch.side = (short)side; ch.level = (short)(u_level + 1);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        ch.lo[c] = (side == 1 && c == sr.ax) ? sr.cut : blo[c];
+                        ch.hi[c] = (side == 0 && c == sr.ax) ? sr.cut : bhi[c];
+                    }
+                }
             }
             sp += 2;
             wave_sync_lds();
@@ -558,13 +584,290 @@ __global__ __launch_bounds__(256) void build_subtree_kernel(const BuildTree* __r
     }
 }
 
+// ---- mid kernel: one workgroup splits a node of <= kMid points down to <= kSmall-point pieces, entirely in LDS ------
+// The node's records are loaded once (128 KiB for 8 192 points) and go back to HBM once at the end; in between the
+// workgroup advances LEVEL BY LEVEL over all of the node's live segments (pieces still above kSmall points, at most
+// kMid / kSmall of them) at once, with __syncthreads() as the only synchronisation -- instead of one kernel launch and
+// several L2 round trips per pass per tree level.  Work unit: a SLAB = up to 512 consecutive positions of ONE segment,
+// handled by one wave (lane l owns positions  start + e*64 + l,  e < 8: position order is (e, l)-major, which is what
+// the order-preserving ranks of the closed-form Hoare sweeps need).  Same arithmetic as build_level_kernel.
+constexpr int kSlab = 512;
+constexpr int kMidSegs = kMid / kSmall;            // live segments are disjoint and longer than kSmall
+constexpr int kMidSlabs = kMid / kSlab + kMidSegs;  // sum of ceil(len / kSlab)
+
+struct MidSeg {
+    int start, end, parent, side, level, slab0;
+    float lo[3], hi[3];
+    unsigned mn[3], mx[3];  // ordered-uint accumulators (LDS atomics)
+    int lt, le;
+    unsigned maxlt, mingt;
+    int ax;
+    float cut;
+    int mis[2];  // misplaced records per sweep
+};
+struct MidSlab {
+    int seg, start, end;
+    int cnt[2];  // per sweep: misplaced-left | misplaced-right << 16
+};
+
+__device__ __forceinline__ void mid_seg_init(MidSeg& g, int start, int end, int parent, int side, int level, int slab0)
+{
+    g.start = start; g.end = end; g.parent = parent; g.side = side; g.level = level; g.slab0 = slab0;
+    for (int a = 0; a < 3; ++a) { g.mn[a] = 0xffffffffu; g.mx[a] = 0u; }
+    g.lt = 0; g.le = 0; g.maxlt = 0u; g.mingt = 0xffffffffu;
+    g.mis[0] = 0; g.mis[1] = 0;
+}
+
+// misplaced flags of one slab for sweep s as 8 ballots (positions relative to the segment start)
+__device__ __forceinline__ void mid_flags(const float4* A, int q0, int q1, int lane, int ax, float cut, int sweep, int lim1, int lim2,
+                                          unsigned long long (&bL)[8], unsigned long long (&bR)[8])
+{
+    const int from = sweep == 0 ? 0 : lim1, bound = sweep == 0 ? lim1 : lim2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int q = q0 + e * 64 + lane;
+        bool isL = false, isR = false;
+        if (q < q1 && q >= from) {
+            const float v = comp(A[q], ax);
+            const bool keep_left = sweep == 0 ? (v < cut) : (v <= cut);
+            isL = q < bound && !keep_left;
+            isR = q >= bound && keep_left;
+        }
+        bL[e] = __ballot(isL);
+        bR[e] = __ballot(isR);
+    }
+}
+
+__global__ __launch_bounds__(kMidThreads) void build_mid_kernel(const BuildTree* __restrict__ trees, BuildQueues Q)
+{
+    constexpr int T = kMidThreads, W = T / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mid_smem[];
+    float4* P = reinterpret_cast<float4*>(mid_smem);                           // [kMid]
+    short* posR = reinterpret_cast<short*>(mid_smem + sizeof(float4) * kMid);  // [kMid]
+    __shared__ MidSeg segs[2][kMidSegs];
+    __shared__ MidSlab slabs[2][kMidSlabs];
+    __shared__ int nseg[2], nslab[2];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int first = Q.small_cnt[2], n_tasks = min(Q.small_cnt[1], Q.q_cap);
+
+    for (int ti = first + blockIdx.x; ti < n_tasks; ti += gridDim.x) {
+        const BuildTask& k = Q.mid_q[ti];
+        const int k_l = k.l, k_tree = k.tree;
+        const BuildTree& t = trees[k_tree];
+        float4* const g_pts = t.pts + k_l;
+        const int total = k.r - k_l;
+        for (int i = tid; i < total; i += T) P[i] = gload(g_pts + i);
+        if (tid == 0) {
+            const int ns = (total + kSlab - 1) / kSlab;
+            mid_seg_init(segs[0][0], 0, total, k.parent, k.side, k.level, 0);
+            for (int c = 0; c < 3; ++c) { segs[0][0].lo[c] = k.lo[c]; segs[0][0].hi[c] = k.hi[c]; }
+            for (int j = 0; j < ns; ++j) {
+                MidSlab& sl = slabs[0][j];
+                sl.seg = 0; sl.start = j * kSlab; sl.end = min(total, (j + 1) * kSlab);
+            }
+            nseg[0] = 1; nslab[0] = ns;
+        }
+        __syncthreads();
+        int cur = 0;
+        while (nseg[cur] > 0) {
+            MidSeg* G = segs[cur];
+            const MidSlab* SL = slabs[cur];
+            const int n_sl = nslab[cur], n_sg = nseg[cur];
+            if (tid == 0) { nseg[cur ^ 1] = 0; nslab[cur ^ 1] = 0; }
+            // ---- A: tight extents of every segment ----
+            for (int si = wave; si < n_sl; si += W) {
+                const int gi = SL[si].seg, s0 = SL[si].start, s1 = SL[si].end;
+                float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = s0 + e * 64 + lane;
+                    if (i < s1) {
+                        const float4 p = P[i];
+                        mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+                        mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+                        mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    for (int o = 32; o > 0; o >>= 1) {
+                        mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+                        mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+                    }
+                if (lane < 3) {
+                    atomicMin(&G[gi].mn[lane], f2ord(lane == 0 ? mn[0] : (lane == 1 ? mn[1] : mn[2])));
+                    atomicMax(&G[gi].mx[lane], f2ord(lane == 0 ? mx[0] : (lane == 1 ? mx[1] : mx[2])));
+                }
+            }
+            __syncthreads();
+            // ---- B: split choice (recomputed by every wave of the segment, identical), counts against the cut ----
+            for (int si = wave; si < n_sl; si += W) {
+                const int gi = SL[si].seg, s0 = SL[si].start, s1 = SL[si].end;
+                float mn[3], mx[3], blo[3], bhi[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { mn[c] = ord2f(G[gi].mn[c]); mx[c] = ord2f(G[gi].mx[c]); blo[c] = G[gi].lo[c]; bhi[c] = G[gi].hi[c]; }
+                const SplitChoice sc = choose_split(blo, bhi, mn, mx);
+                const int ax = sc.ax;
+                const float cut = sc.cut;
+                int lt = 0, le = 0;
+                float maxlt = -INFINITY, mingt = INFINITY;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = s0 + e * 64 + lane;
+                    if (i < s1) {
+                        const float v = comp(P[i], ax);
+                        lt += v < cut;
+                        le += v <= cut;
+                        if (v < cut) maxlt = fmaxf(maxlt, v);
+                        if (v > cut) mingt = fminf(mingt, v);
+                    }
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    lt += __shfl_xor(lt, o);
+                    le += __shfl_xor(le, o);
+                    maxlt = fmaxf(maxlt, __shfl_xor(maxlt, o));
+                    mingt = fminf(mingt, __shfl_xor(mingt, o));
+                }
+                if (lane == 0) {
+                    atomicAdd(&G[gi].lt, lt);
+                    atomicAdd(&G[gi].le, le);
+                    atomicMax(&G[gi].maxlt, f2ord(maxlt));
+                    atomicMin(&G[gi].mingt, f2ord(mingt));
+                    G[gi].ax = ax;    // (same value from every slab of the segment)
+                    G[gi].cut = cut;
+                }
+            }
+            __syncthreads();
+            // ---- the two Hoare sweeps (planeSplit, nanoflann.hpp:1016-1043) in closed form ----
+            for (int sweep = 0; sweep < 2; ++sweep) {
+                // C: misplaced counts per slab
+                for (int si = wave; si < n_sl; si += W) {
+                    const int gi = SL[si].seg;
+                    const int g0 = G[gi].start;
+                    unsigned long long bL[8], bR[8];
+                    mid_flags(P + g0, SL[si].start - g0, SL[si].end - g0, lane, G[gi].ax, G[gi].cut, sweep, G[gi].lt, G[gi].le, bL, bR);
+                    int wL = 0, wR = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { wL += __popcll(bL[e]); wR += __popcll(bR[e]); }
+                    if (lane == 0) {
+                        slabs[cur][si].cnt[sweep] = wL | (wR << 16);
+                        if (wL) atomicAdd(&G[gi].mis[sweep], wL);
+                    }
+                }
+                __syncthreads();
+                // D: ranks -> positions of the misplaced-right records, in ascending order
+                for (int si = wave; si < n_sl; si += W) {
+                    const int gi = SL[si].seg;
+                    if (G[gi].mis[sweep] == 0) continue;
+                    const int g0 = G[gi].start, sl0 = G[gi].slab0;
+                    unsigned long long bL[8], bR[8];
+                    mid_flags(P + g0, SL[si].start - g0, SL[si].end - g0, lane, G[gi].ax, G[gi].cut, sweep, G[gi].lt, G[gi].le, bL, bR);
+                    const int mine = sl0 + lane < si ? SL[sl0 + lane].cnt[sweep] : 0;  // slabs of a segment are consecutive, in order
+                    int pre = 0;
+                    for (int j = 0; j < si - sl0; ++j) pre += __builtin_amdgcn_readlane(mine, j) >> 16;
+                    int rR = pre;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if ((bR[e] >> lane) & 1ull) posR[g0 + rR + __popcll(bR[e] & lt_mask)] = (short)(SL[si].start - g0 + e * 64 + lane);
+                        rR += __popcll(bR[e]);
+                    }
+                }
+                __syncthreads();
+                // E: i-th misplaced-left record (ascending) swaps with the i-th misplaced-right record counted from the right
+                for (int si = wave; si < n_sl; si += W) {
+                    const int gi = SL[si].seg;
+                    const int m = G[gi].mis[sweep];
+                    if (m == 0) continue;
+                    const int g0 = G[gi].start, sl0 = G[gi].slab0;
+                    float4* A = P + g0;
+                    unsigned long long bL[8], bR[8];
+                    mid_flags(A, SL[si].start - g0, SL[si].end - g0, lane, G[gi].ax, G[gi].cut, sweep, G[gi].lt, G[gi].le, bL, bR);
+                    const int mine = sl0 + lane < si ? SL[sl0 + lane].cnt[sweep] : 0;
+                    int rL = 0;
+                    for (int j = 0; j < si - sl0; ++j) rL += __builtin_amdgcn_readlane(mine, j) & 0xffff;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if ((bL[e] >> lane) & 1ull) {
+                            const int q = SL[si].start - g0 + e * 64 + lane;
+                            const int pr = posR[g0 + m - 1 - (rL + __popcll(bL[e] & lt_mask))];
+                            const float4 x = A[q], y = A[pr];
+                            A[pr] = x;
+                            A[q] = y;
+                        }
+                        rL += __popcll(bL[e]);
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- F: record the nodes, route the children (one thread per segment) ----
+            if (tid < n_sg) {
+                const MidSeg& g = G[tid];
+                const int count = g.end - g.start, lim1 = g.lt, lim2 = g.le, ax = g.ax;
+                const float cut = g.cut;
+                const int half = count / 2;
+                const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
+                const int id = 2 * (k_l + g.start + idx) - 1;
+                const float divlow = idx > lim1 ? cut : ord2f(g.maxlt);
+                const float divhigh = idx < lim2 ? cut : ord2f(g.mingt);
+                t.nodes[id] = make_int4((int)((unsigned)ax << 30), 0, __float_as_int(divlow), __float_as_int(divhigh));
+                if (g.parent < 0) t.meta->root = id;
+                else if (g.side == 0) atomicOr(&t.nodes[g.parent].x, id);
+                else t.nodes[g.parent].y = id;
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const int cl = side == 0 ? g.start : g.start + idx, cr = side == 0 ? g.start + idx : g.end;
+                    float clo[3], chi[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        clo[c] = (side == 1 && c == ax) ? cut : g.lo[c];
+                        chi[c] = (side == 0 && c == ax) ? cut : g.hi[c];
+                    }
+                    if (cr - cl > kSmall) {
+                        const int ns = (cr - cl + kSlab - 1) / kSlab;
+                        const int slot = atomicAdd(&nseg[cur ^ 1], 1), sl0 = atomicAdd(&nslab[cur ^ 1], ns);
+                        MidSeg& ch = segs[cur ^ 1][slot];
+                        mid_seg_init(ch, cl, cr, id, side, g.level + 1, sl0);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { ch.lo[c] = clo[c]; ch.hi[c] = chi[c]; }
+                        for (int j = 0; j < ns; ++j) {
+                            MidSlab& sl = slabs[cur ^ 1][sl0 + j];
+                            sl.seg = slot; sl.start = cl + j * kSlab; sl.end = min(cr, cl + (j + 1) * kSlab);
+                        }
+                    } else {
+                        const int slot = atomicAdd(Q.small_cnt, 1);
+                        if (slot < Q.small_cap) {
+                            BuildTask& b = Q.small_q[slot];
+                            b.tree = k_tree; b.l = k_l + cl; b.r = k_l + cr; b.parent = id; b.side = side; b.level = g.level + 1;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) { b.lo[c] = clo[c]; b.hi[c] = chi[c]; }
+                        } else
+                            Q.flags[1] = 1;
+                    }
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+        for (int i = tid; i < total; i += T) gstore(g_pts + i, P[i]);
+        __syncthreads();
+    }
+}
+
+// marks the mid / small queues as processed up to their current fill (the continue path only handles later additions)
+__global__ void queue_done_kernel(BuildQueues Q, int which)
+{
+    if (which == 0) Q.small_cnt[2] = min(Q.small_cnt[1], Q.q_cap);
+    else Q.small_cnt[3] = min(Q.small_cnt[0], Q.small_cap);
+}
+
 // ---- chunked levels: the first kHugeLevels levels of nodes above kHuge points ------------------------------------
 // One workgroup per node cannot pull more than one CU's bandwidth, which made the top three levels of a 180 000-point
 // tree cost ~0.5 ms.  Here every pass of such a node is spread over the chip in 2 048-record chunks, one small
 // kernel per pass (kernel boundaries are the global sync): min/max -> counts -> {flag counts -> ranks -> swaps} x 2
 // -> emit.  Exactly the same arithmetic and the same closed-form Hoare sweeps as build_level_kernel.
-constexpr int kHuge = 16384;
-constexpr int kHugeLevels = 4;
+constexpr int kHuge = kMid;       // everything smaller goes to build_mid_kernel
+constexpr int kHugeLevels = 8;    // at most; the host launches ceil(log2(n_max / kMid)) of them (HugeState::levels)
 constexpr int kChunk = 2048;
 
 struct HugeTask {
@@ -582,11 +885,12 @@ struct HugeState {
     int32_t* c_mL;         // [max_chunks] misplaced-left count of a chunk (current sweep)
     int32_t* c_mR;
     int32_t cap_tasks, cap_chunks;
+    int32_t levels;        // chunked levels launched by the host
 };
 
 __device__ __forceinline__ void route_task(const BuildQueues& Q, const HugeState& H, const BuildTask& t, int next_level)
 {
-    if (t.r - t.l > kHuge && next_level < kHugeLevels) {
+    if (t.r - t.l > kHuge && next_level < H.levels) {
         const int slot = atomicAdd(&H.ntasks[next_level], 1);
         if (slot < H.cap_tasks)
             H.tasks[next_level & 1][slot].k = t;
@@ -871,7 +1175,7 @@ __global__ void huge_emit_kernel(const BuildTree* __restrict__ trees, BuildQueue
         route_task(Q, H, kids[0], level + 1);
         route_task(Q, H, kids[1], level + 1);
     }
-    if (level + 1 < kHugeLevels) huge_plan(H, level + 1);
+    if (level + 1 < H.levels) huge_plan(H, level + 1);
 }
 
 __global__ void pending_flag_kernel(const int32_t* __restrict__ level_cnt, int level, int32_t* __restrict__ flags)
@@ -880,7 +1184,25 @@ __global__ void pending_flag_kernel(const int32_t* __restrict__ level_cnt, int l
     if (level < 0) flags[0] = 0;  // stack-overflow marks left by searches over the unfinished trees
 }
 
-constexpr int kFastLevels = 16;
+constexpr int kBlindLevels = 2;  // level kernels launched blind after the chunked levels (nodes still above kMid)
+
+static int launch_mid_and_subtrees(ps_context* c, const BuildTree* d_trees, const BuildQueues& Q, size_t tot, size_t T, size_t small_cap)
+{
+    static bool attr_set = false;
+    constexpr size_t mid_lds = sizeof(float4) * kMid + sizeof(short) * kMid;
+    if (!attr_set) {
+        PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(build_mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds));
+        attr_set = true;
+    }
+    hipStream_t st = c->stream;
+    const unsigned grid_mid = (unsigned)std::min<size_t>(tot / kSmall + T + 1, 1024);
+    hipLaunchKernelGGL(build_mid_kernel, dim3(grid_mid), dim3(kMidThreads), mid_lds, st, d_trees, Q);
+    hipLaunchKernelGGL(queue_done_kernel, dim3(1), dim3(1), 0, st, Q, 0);
+    hipLaunchKernelGGL(build_subtree_kernel, dim3((unsigned)std::min<size_t>(ceil_div(small_cap, 4), 2048)), dim3(256), 0, st, d_trees, Q);
+    hipLaunchKernelGGL(queue_done_kernel, dim3(1), dim3(1), 0, st, Q, 1);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
 
 // ---- host side -----------------------------------------------------------------------------------------------
 void TreeSetPlan::carve(Arena& a)
@@ -901,7 +1223,7 @@ void TreeSetPlan::carve(Arena& a)
     add(sizeof(BuildTree) * T);
     add(sizeof(unsigned) * 8 * T);
     add(sizeof(int32_t) * 2 * (tot + T));
-    add(sizeof(BuildTask) * q_cap * 2);
+    add(sizeof(BuildTask) * q_cap * 3);
     add(sizeof(BuildTask) * small_cap);
     add(sizeof(int32_t) * (kMaxLevels + 8));
     {   // chunked-level state (must stay AFTER everything build_trees_continue() re-derives)
@@ -926,7 +1248,7 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     BuildTree* d_trees = reinterpret_cast<BuildTree*>(take(sizeof(BuildTree) * T));
     unsigned* d_bbox = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * 8 * T));
     int32_t* d_pos = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 2 * (tot + T)));
-    BuildTask* d_q = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * q_cap * 2));
+    BuildTask* d_q = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * q_cap * 3));
     BuildTask* d_small = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * small_cap));
     int32_t* d_cnt = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (kMaxLevels + 8)));
     const size_t cap_tasks = tot / kHuge + T + 8, cap_chunks = tot / kChunk + cap_tasks + 8;
@@ -977,6 +1299,7 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     BuildQueues Q;
     Q.q[0] = d_q;
     Q.q[1] = d_q + q_cap;
+    Q.mid_q = d_q + 2 * q_cap;
     Q.small_q = d_small;
     Q.level_cnt = d_cnt;
     Q.small_cnt = d_cnt + kMaxLevels;
@@ -984,34 +1307,36 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     Q.q_cap = (int32_t)q_cap;
     Q.small_cap = (int32_t)small_cap;
 
+    // chunked levels until the nodes of a balanced tree are below kMid; stragglers (lopsided splits) get kBlindLevels
+    // level kernels, anything still above kMid after that is left to build_trees_continue()
+    int huge_levels = 0;
+    while (huge_levels < kHugeLevels && ((size_t)max_n >> huge_levels) > (size_t)kMid) ++huge_levels;
+    H.levels = huge_levels;
+    plan.first_pending_level = huge_levels + kBlindLevels;
+
     const int chunks_x = std::max(1, std::min(ceil_div(max_n, 256 * 4), 256));
     hipLaunchKernelGGL(init_points_kernel, dim3(chunks_x, (unsigned)T), dim3(256), 0, st, d_trees, chunks_x);
     hipLaunchKernelGGL(huge_root_kernel, dim3(1), dim3(64), 0, st, d_trees, (int)T, Q, H);
-    // big levels: the number of tasks per level is device-side data; a level holds at most tot/kSmall disjoint big
-    // nodes.  kFastLevels level kernels are launched blind (surplus ones find an empty queue and exit); the count of
-    // still-pending big nodes goes to flags[2], which the caller reads at its own final synchronisation and, if it is
-    // not zero (a very unbalanced cloud), answers with build_trees_continue().
-    const int grid_big = (int)std::min<size_t>(q_cap, tot / kSmall + T + 1);
+    const int grid_big = (int)std::min<size_t>(q_cap, tot / kMid + T + 1);
     const dim3 gc((unsigned)std::min<size_t>(cap_chunks, tot / kChunk + cap_tasks)), bc(256);
-    for (int level = 0; level < kFastLevels; ++level) {
-        if (level < kHugeLevels && tot > (size_t)kHuge) {
-            // nodes above kHuge points: every pass spread over the chip (see "chunked levels" above)
-            hipLaunchKernelGGL(huge_minmax_kernel, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_count_kernel, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_sweepcount_kernel<0>, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_scatter_kernel<0>, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_swap_kernel, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_sweepcount_kernel<1>, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_scatter_kernel<1>, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_swap_kernel, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_emit_kernel, dim3(1), dim3(64), 0, st, d_trees, Q, H, level);
-        }
-        hipLaunchKernelGGL(build_level_kernel, dim3(grid_big), dim3(kBigThreads), 0, st, d_trees, Q, level);
+    for (int level = 0; level < huge_levels; ++level) {
+        // nodes above kHuge points: every pass spread over the chip (see "chunked levels" above)
+        hipLaunchKernelGGL(huge_minmax_kernel, gc, bc, 0, st, d_trees, H, level);
+        hipLaunchKernelGGL(huge_count_kernel, gc, bc, 0, st, d_trees, H, level);
+        hipLaunchKernelGGL(huge_sweepcount_kernel<0>, gc, bc, 0, st, d_trees, H, level);
+        hipLaunchKernelGGL(huge_scatter_kernel<0>, gc, bc, 0, st, d_trees, H, level);
+        hipLaunchKernelGGL(huge_swap_kernel, gc, bc, 0, st, d_trees, H, level);
+        hipLaunchKernelGGL(huge_sweepcount_kernel<1>, gc, bc, 0, st, d_trees, H, level);
+        hipLaunchKernelGGL(huge_scatter_kernel<1>, gc, bc, 0, st, d_trees, H, level);
+        hipLaunchKernelGGL(huge_swap_kernel, gc, bc, 0, st, d_trees, H, level);
+        hipLaunchKernelGGL(huge_emit_kernel, dim3(1), dim3(64), 0, st, d_trees, Q, H, level);
     }
-    hipLaunchKernelGGL(pending_flag_kernel, dim3(1), dim3(1), 0, st, d_cnt, kFastLevels, plan.d_flags);
-    hipLaunchKernelGGL(build_subtree_kernel, dim3(std::min<size_t>(ceil_div(small_cap, 4), 2048)), dim3(256), 0, st, d_trees, Q);
-    PS_HIP(hipGetLastError());
-    plan.launches = 4 + kFastLevels + (tot > (size_t)kHuge ? 9 * kHugeLevels : 0);
+    // (the level queues are indexed by the level a task was pushed FOR: chunked level L pushes for L + 1, the roots for 0)
+    for (int level = huge_levels == 0 ? 0 : huge_levels; level < huge_levels + kBlindLevels; ++level)
+        hipLaunchKernelGGL(build_level_kernel, dim3(grid_big), dim3(kBigThreads), 0, st, d_trees, Q, level);
+    hipLaunchKernelGGL(pending_flag_kernel, dim3(1), dim3(1), 0, st, d_cnt, plan.first_pending_level, plan.d_flags);
+    PS_TRY(launch_mid_and_subtrees(c, d_trees, Q, tot, T, small_cap));
+    plan.launches = 7 + kBlindLevels + 9 * huge_levels;
     return PS_OK;
 }
 
@@ -1026,12 +1351,13 @@ int build_trees_continue(ps_context* c, TreeSetPlan& plan)
     BuildTree* d_trees = reinterpret_cast<BuildTree*>(take(sizeof(BuildTree) * T));
     take(sizeof(unsigned) * 8 * T);
     take(sizeof(int32_t) * 2 * (tot + T));
-    BuildTask* d_q = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * q_cap * 2));
+    BuildTask* d_q = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * q_cap * 3));
     BuildTask* d_small = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * small_cap));
     int32_t* d_cnt = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (kMaxLevels + 8)));
     BuildQueues Q;
     Q.q[0] = d_q;
     Q.q[1] = d_q + q_cap;
+    Q.mid_q = d_q + 2 * q_cap;
     Q.small_q = d_small;
     Q.level_cnt = d_cnt;
     Q.small_cnt = d_cnt + kMaxLevels;
@@ -1039,8 +1365,8 @@ int build_trees_continue(ps_context* c, TreeSetPlan& plan)
     Q.q_cap = (int32_t)q_cap;
     Q.small_cap = (int32_t)small_cap;
     hipStream_t st = c->stream;
-    const int grid_big = (int)std::min<size_t>(q_cap, tot / kSmall + T + 1);
-    int level = kFastLevels;
+    const int grid_big = (int)std::min<size_t>(q_cap, tot / kMid + T + 1);
+    int level = plan.first_pending_level;
     for (;;) {
         for (int i = 0; i < 8 && level < kMaxLevels - 1; ++i, ++level)
             hipLaunchKernelGGL(build_level_kernel, dim3(grid_big), dim3(kBigThreads), 0, st, d_trees, Q, level);
@@ -1048,13 +1374,11 @@ int build_trees_continue(ps_context* c, TreeSetPlan& plan)
         PS_HIP(hipMemcpyAsync(&pending, d_cnt + level, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         PS_HIP(hipStreamSynchronize(st));
         if (pending == 0) break;
-        PS_CHECK(level < kMaxLevels - 1, "kd-tree build: more than %d levels of nodes above %d points (degenerate cloud)", kMaxLevels, kSmall);
+        PS_CHECK(level < kMaxLevels - 1, "kd-tree build: more than %d levels of nodes above %d points (degenerate cloud)", kMaxLevels, kMid);
     }
-    // The subtree kernel walks the WHOLE small queue again: re-splitting an already partitioned range moves nothing
-    // (no misplaced records), so the subtrees finished by the first run come out identical.
+    // only the mid / small nodes queued since the first run are new work (queue_done_kernel recorded the old fill)
     hipLaunchKernelGGL(pending_flag_kernel, dim3(1), dim3(1), 0, st, d_cnt, -1, plan.d_flags);
-    hipLaunchKernelGGL(build_subtree_kernel, dim3(std::min<size_t>(ceil_div(small_cap, 4), 2048)), dim3(256), 0, st, d_trees, Q);
-    PS_HIP(hipGetLastError());
+    PS_TRY(launch_mid_and_subtrees(c, d_trees, Q, tot, T, small_cap));
     return PS_OK;
 }
 

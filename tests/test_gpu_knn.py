@@ -152,15 +152,16 @@ def test_device_tree_equals_host_tree(lib, case):
 
 
 def test_unbalanced_cloud_takes_the_slow_build_path(oracle):
-    """A geometric progression on a line (y = z = 0) makes every bounding-box-midpoint split peel ~2 % of the node:
-    ~37 levels of nodes above 256 points, far more than the builder launches blind, so the continue path runs.
-    Results stay bit-exact."""
+    """A geometric progression on a line (y = z = 0) makes every bounding-box-midpoint split peel ~ln2/0.0003 = 2 300
+    points off the node: ~14 levels of nodes above 8 192 points (the size one workgroup finishes in LDS), far more than
+    the builder launches blind, so the continue path runs.  The small variant (1 100 points, 50-deep tree) stays inside
+    the LDS kernels.  Results stay bit-exact."""
     rng = np.random.default_rng(5)
-    n = 1100
-    p = np.stack([0.97 ** np.arange(n), np.zeros(n), np.zeros(n)], 1).astype(np.float32)
-    p = p[rng.permutation(n)]
-    for K in (1, 16):
-        assert np.array_equal(_knn_gpu(p[None], p[None], K), oracle.knn_batch(p[None], p[None], K))
+    for n, r in ((40000, 0.9997), (1100, 0.97)):
+        p = np.stack([r ** np.arange(n), np.zeros(n), np.zeros(n)], 1).astype(np.float32)
+        p = p[rng.permutation(n)]
+        for K in (1, 16):
+            assert np.array_equal(_knn_gpu(p[None], p[None], K), oracle.knn_batch(p[None], p[None], K)), (n, K)
 
 
 def test_deferred_checks_flag_unbalanced_cloud_at_synchronize():
@@ -184,8 +185,8 @@ def test_deferred_checks_flag_unbalanced_cloud_at_synchronize():
     ref = build_pyramid(good, Cfg)
     assert torch.equal(pyr.neigh_idx[0], ref.neigh_idx[0]) and torch.equal(pyr.interp_idx[1], ref.interp_idx[1])
     rng = np.random.default_rng(5)
-    n = 1100
-    p = np.stack([0.97 ** np.arange(n), np.zeros(n), np.zeros(n)], 1).astype(np.float32)[rng.permutation(n)]
+    n = 40000
+    p = np.stack([0.9997 ** np.arange(n), np.zeros(n), np.zeros(n)], 1).astype(np.float32)[rng.permutation(n)]
     build_pyramid(torch.from_numpy(p[None]).cuda(), Cfg, ctx=ctx)
     with pytest.raises(PointSegError, match="unbalanced"):
         ctx.synchronize()
