@@ -900,27 +900,44 @@ __device__ __forceinline__ void route_task(const BuildQueues& Q, const HugeState
         push_task(Q, t, next_level);
 }
 
-// Serial plan of a level's chunk ranges + accumulator reset (a handful of tasks): run by one thread.
-__device__ void huge_plan(const HugeState& H, int level)
+// Plan of a level's chunk ranges + accumulator reset, by one workgroup: thread i takes task i, chunk0 is the prefix sum
+// of the chunk counts (tasks are few: a serial prefix per thread over an LDS copy).
+__device__ void huge_plan_block(const HugeState& H, int level)
 {
+    __shared__ int s_nc[256];
     const int n = min(H.ntasks[level], H.cap_tasks);
-    int c = 0;
-    for (int i = 0; i < n; ++i) {
-        HugeTask& t = H.tasks[level & 1][i];
-        t.chunk0 = c;
-        t.nchunks = (t.k.r - t.k.l + kChunk - 1) / kChunk;
-        c += t.nchunks;
-        for (int a = 0; a < 3; ++a) { t.mn[a] = 0xffffffffu; t.mx[a] = 0u; }
-        t.lt = 0; t.le = 0; t.maxlt = 0u; t.mingt = 0xffffffffu;
+    int carry = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + threadIdx.x;
+        int nc = 0;
+        if (i < n) {
+            const BuildTask& k = H.tasks[level & 1][i].k;
+            nc = (k.r - k.l + kChunk - 1) / kChunk;
+        }
+        s_nc[threadIdx.x] = nc;
+        __syncthreads();
+        int c0 = carry, tot = carry;
+        for (int j = 0; j < min(256, n - base); ++j) {
+            if (j < (int)threadIdx.x) c0 += s_nc[j];
+            tot += s_nc[j];
+        }
+        if (i < n) {
+            HugeTask& t = H.tasks[level & 1][i];
+            t.chunk0 = c0;
+            t.nchunks = nc;
+            for (int a = 0; a < 3; ++a) { t.mn[a] = 0xffffffffu; t.mx[a] = 0u; }
+            t.lt = 0; t.le = 0; t.maxlt = 0u; t.mingt = 0xffffffffu;
+        }
+        carry = tot;
+        __syncthreads();
     }
-    H.nchunks[level] = min(c, H.cap_chunks);
+    if (threadIdx.x == 0) H.nchunks[level] = min(carry, H.cap_chunks);
 }
 
-__global__ void huge_root_kernel(const BuildTree* __restrict__ trees, int n_trees, BuildQueues Q, HugeState H)
+// Root metadata + routing of every root + the plan of level 0; run by ONE workgroup.
+__device__ __forceinline__ void huge_root_block(const BuildTree* __restrict__ trees, int n_trees, const BuildQueues& Q, const HugeState& H)
 {
-    // (single thread: a few trees) root metadata + routing of every root + the plan of level 0
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    for (int i = 0; i < n_trees; ++i) {
+    for (int i = threadIdx.x; i < n_trees; i += blockDim.x) {
         const BuildTree t = trees[i];
         TreeMeta m;
         m.root = 0;
@@ -936,7 +953,9 @@ __global__ void huge_root_kernel(const BuildTree* __restrict__ trees, int n_tree
         for (int a = 0; a < 3; ++a) { k.lo[a] = m.lo[a]; k.hi[a] = m.hi[a]; }
         route_task(Q, H, k, 0);
     }
-    huge_plan(H, 0);
+    __threadfence();
+    __syncthreads();
+    huge_plan_block(H, 0);
 }
 
 struct ChunkRef {
@@ -968,10 +987,10 @@ __device__ __forceinline__ SplitChoice huge_split(const HugeTask& t)
     return choose_split(t.k.lo, t.k.hi, mn, mx);
 }
 
-__global__ __launch_bounds__(256) void huge_minmax_kernel(const BuildTree* __restrict__ trees, HugeState H, int level)
+__device__ __forceinline__ void huge_minmax_chunk(const BuildTree* __restrict__ trees, const HugeState& H, int level, int chunk)
 {
     __shared__ float s_mn[4][3], s_mx[4][3];
-    const ChunkRef cr = find_chunk(H, level, blockIdx.x);
+    const ChunkRef cr = find_chunk(H, level, chunk);
     if (cr.task < 0) return;
     HugeTask& t = H.tasks[level & 1][cr.task];
     const GArr<const float4> a{trees[t.k.tree].pts + t.k.l + cr.first};
@@ -1002,11 +1021,11 @@ __global__ __launch_bounds__(256) void huge_minmax_kernel(const BuildTree* __res
     }
 }
 
-__global__ __launch_bounds__(256) void huge_count_kernel(const BuildTree* __restrict__ trees, HugeState H, int level)
+__device__ __forceinline__ void huge_count_chunk(const BuildTree* __restrict__ trees, const HugeState& H, int level, int chunk)
 {
     __shared__ int s_i[4][2];
     __shared__ float s_f[4][2];
-    const ChunkRef cr = find_chunk(H, level, blockIdx.x);
+    const ChunkRef cr = find_chunk(H, level, chunk);
     if (cr.task < 0) return;
     HugeTask& t = H.tasks[level & 1][cr.task];
     const SplitChoice sc = huge_split(t);
@@ -1068,10 +1087,10 @@ __device__ __forceinline__ void chunk_flags(const GArr<const float4>& a, const C
 }
 
 template <int S>
-__global__ __launch_bounds__(256) void huge_sweepcount_kernel(const BuildTree* __restrict__ trees, HugeState H, int level)
+__device__ __forceinline__ void huge_sweepcount_chunk(const BuildTree* __restrict__ trees, const HugeState& H, int level, int chunk)
 {
     __shared__ int s_c[4][2];
-    const ChunkRef cr = find_chunk(H, level, blockIdx.x);
+    const ChunkRef cr = find_chunk(H, level, chunk);
     if (cr.task < 0) return;
     const HugeTask& t = H.tasks[level & 1][cr.task];
     const SplitChoice sc = huge_split(t);
@@ -1085,17 +1104,17 @@ __global__ __launch_bounds__(256) void huge_sweepcount_kernel(const BuildTree* _
     if (lane == 0) { s_c[wave][0] = wL; s_c[wave][1] = wR; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        H.c_mL[blockIdx.x] = s_c[0][0] + s_c[1][0] + s_c[2][0] + s_c[3][0];
-        H.c_mR[blockIdx.x] = s_c[0][1] + s_c[1][1] + s_c[2][1] + s_c[3][1];
+        H.c_mL[chunk] = s_c[0][0] + s_c[1][0] + s_c[2][0] + s_c[3][0];
+        H.c_mR[chunk] = s_c[0][1] + s_c[1][1] + s_c[2][1] + s_c[3][1];
     }
 }
 
 template <int S>
-__global__ __launch_bounds__(256) void huge_scatter_kernel(const BuildTree* __restrict__ trees, HugeState H, int level)
+__device__ __forceinline__ void huge_scatter_chunk(const BuildTree* __restrict__ trees, const HugeState& H, int level, int chunk)
 {
     __shared__ int s_c[4][2];
     __shared__ int s_off[2];
-    const ChunkRef cr = find_chunk(H, level, blockIdx.x);
+    const ChunkRef cr = find_chunk(H, level, chunk);
     if (cr.task < 0) return;
     const HugeTask& t = H.tasks[level & 1][cr.task];
     const BuildTree tr = trees[t.k.tree];
@@ -1104,7 +1123,7 @@ __global__ __launch_bounds__(256) void huge_scatter_kernel(const BuildTree* __re
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // ranks before this chunk = misplaced counts of the node's earlier chunks
     int pl = 0, pr = 0;
-    for (int c = t.chunk0 + threadIdx.x; c < (int)blockIdx.x; c += 256) { pl += H.c_mL[c]; pr += H.c_mR[c]; }
+    for (int c = t.chunk0 + threadIdx.x; c < chunk; c += 256) { pl += H.c_mL[c]; pr += H.c_mR[c]; }
     for (int o = 32; o > 0; o >>= 1) { pl += __shfl_xor(pl, o); pr += __shfl_xor(pr, o); }
     if (lane == 0) { s_c[wave][0] = pl; s_c[wave][1] = pr; }
     __syncthreads();
@@ -1133,11 +1152,11 @@ __global__ __launch_bounds__(256) void huge_scatter_kernel(const BuildTree* __re
     }
 }
 
-__global__ __launch_bounds__(256) void huge_swap_kernel(const BuildTree* __restrict__ trees, HugeState H, int level)
+__device__ __forceinline__ void huge_swap_chunk(const BuildTree* __restrict__ trees, const HugeState& H, int level, int chunk)
 {
     __shared__ int s_c[4];
     __shared__ int s_m;
-    const ChunkRef cr = find_chunk(H, level, blockIdx.x);
+    const ChunkRef cr = find_chunk(H, level, chunk);
     if (cr.task < 0) return;
     const HugeTask& t = H.tasks[level & 1][cr.task];
     const BuildTree tr = trees[t.k.tree];
@@ -1159,12 +1178,12 @@ __global__ __launch_bounds__(256) void huge_swap_kernel(const BuildTree* __restr
     }
 }
 
-__global__ void huge_emit_kernel(const BuildTree* __restrict__ trees, BuildQueues Q, HugeState H, int level)
+// Records the level's nodes, routes their children and plans the next level's chunk ranges; run by ONE workgroup
+// (thread i = task i; the plan is a prefix sum over the handful of next-level tasks).
+__device__ __forceinline__ void huge_emit_block(const BuildTree* __restrict__ trees, const BuildQueues& Q, const HugeState& H, int level)
 {
-    // (single thread: a handful of nodes) record the nodes, route the children, plan the next level
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const int n = min(H.ntasks[level], H.cap_tasks);
-    for (int i = 0; i < n; ++i) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const HugeTask& t = H.tasks[level & 1][i];
         const BuildTree tr = trees[t.k.tree];
         const SplitChoice sc = huge_split(t);
@@ -1175,7 +1194,34 @@ __global__ void huge_emit_kernel(const BuildTree* __restrict__ trees, BuildQueue
         route_task(Q, H, kids[0], level + 1);
         route_task(Q, H, kids[1], level + 1);
     }
-    if (level + 1 < H.levels) huge_plan(H, level + 1);
+    __threadfence();
+    __syncthreads();
+    if (level + 1 < H.levels) huge_plan_block(H, level + 1);
+}
+
+// ---- launch wrappers of the chunked passes ------------------------------------------------------------------------------
+// (One cooperative launch with grid-wide barriers between the passes was measured and rejected: every barrier needs an
+// agent-scope release/acquire -- an L2 write-back + invalidate per workgroup on this multi-XCD part -- and came to
+// ~12 us per pass against ~7 us for a dependent kernel launch.)
+__global__ __launch_bounds__(256) void huge_root_kernel(const BuildTree* __restrict__ trees, int n_trees, BuildQueues Q, HugeState H)
+{
+    huge_root_block(trees, n_trees, Q, H);
+}
+__global__ __launch_bounds__(256) void huge_emit_kernel(const BuildTree* __restrict__ trees, BuildQueues Q, HugeState H, int level)
+{
+    huge_emit_block(trees, Q, H, level);
+}
+template <int PHASE>
+__global__ __launch_bounds__(256) void huge_phase_kernel(const BuildTree* __restrict__ trees, HugeState H, int level)
+{
+    const int c = blockIdx.x;
+    if (PHASE == 0) huge_minmax_chunk(trees, H, level, c);
+    if (PHASE == 1) huge_count_chunk(trees, H, level, c);
+    if (PHASE == 2) huge_sweepcount_chunk<0>(trees, H, level, c);
+    if (PHASE == 3) huge_scatter_chunk<0>(trees, H, level, c);
+    if (PHASE == 4) huge_swap_chunk(trees, H, level, c);
+    if (PHASE == 5) huge_sweepcount_chunk<1>(trees, H, level, c);
+    if (PHASE == 6) huge_scatter_chunk<1>(trees, H, level, c);
 }
 
 __global__ void pending_flag_kernel(const int32_t* __restrict__ level_cnt, int level, int32_t* __restrict__ flags)
@@ -1316,20 +1362,23 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
 
     const int chunks_x = std::max(1, std::min(ceil_div(max_n, 256 * 4), 256));
     hipLaunchKernelGGL(init_points_kernel, dim3(chunks_x, (unsigned)T), dim3(256), 0, st, d_trees, chunks_x);
-    hipLaunchKernelGGL(huge_root_kernel, dim3(1), dim3(64), 0, st, d_trees, (int)T, Q, H);
     const int grid_big = (int)std::min<size_t>(q_cap, tot / kMid + T + 1);
-    const dim3 gc((unsigned)std::min<size_t>(cap_chunks, tot / kChunk + cap_tasks)), bc(256);
-    for (int level = 0; level < huge_levels; ++level) {
-        // nodes above kHuge points: every pass spread over the chip (see "chunked levels" above)
-        hipLaunchKernelGGL(huge_minmax_kernel, gc, bc, 0, st, d_trees, H, level);
-        hipLaunchKernelGGL(huge_count_kernel, gc, bc, 0, st, d_trees, H, level);
-        hipLaunchKernelGGL(huge_sweepcount_kernel<0>, gc, bc, 0, st, d_trees, H, level);
-        hipLaunchKernelGGL(huge_scatter_kernel<0>, gc, bc, 0, st, d_trees, H, level);
-        hipLaunchKernelGGL(huge_swap_kernel, gc, bc, 0, st, d_trees, H, level);
-        hipLaunchKernelGGL(huge_sweepcount_kernel<1>, gc, bc, 0, st, d_trees, H, level);
-        hipLaunchKernelGGL(huge_scatter_kernel<1>, gc, bc, 0, st, d_trees, H, level);
-        hipLaunchKernelGGL(huge_swap_kernel, gc, bc, 0, st, d_trees, H, level);
-        hipLaunchKernelGGL(huge_emit_kernel, dim3(1), dim3(64), 0, st, d_trees, Q, H, level);
+    const unsigned n_chunks_max = (unsigned)std::min<size_t>(cap_chunks, tot / kChunk + cap_tasks);
+    {
+        const dim3 gc(std::max(1u, n_chunks_max)), bc(256);
+        hipLaunchKernelGGL(huge_root_kernel, dim3(1), dim3(256), 0, st, d_trees, (int)T, Q, H);
+        for (int level = 0; level < huge_levels; ++level) {
+            // nodes above kHuge points: every pass spread over the chip (see "chunked levels" above)
+            hipLaunchKernelGGL(huge_phase_kernel<0>, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_phase_kernel<1>, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_phase_kernel<2>, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_phase_kernel<3>, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_phase_kernel<4>, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_phase_kernel<5>, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_phase_kernel<6>, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_phase_kernel<4>, gc, bc, 0, st, d_trees, H, level);
+            hipLaunchKernelGGL(huge_emit_kernel, dim3(1), dim3(256), 0, st, d_trees, Q, H, level);
+        }
     }
     // (the level queues are indexed by the level a task was pushed FOR: chunked level L pushes for L + 1, the roots for 0)
     for (int level = huge_levels == 0 ? 0 : huge_levels; level < huge_levels + kBlindLevels; ++level)
