@@ -199,6 +199,10 @@ def main():
     ap.add_argument("--workload", choices=["config2", "config5"], default="config2",
                     help="config2 = BASELINE configs[1] (180k BraTS-shaped, K=16); config5 = BASELINE configs[4] (262 144 points, K=32, "
                          "4 input channels, 2 classes; features kept fp32)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="serial steps on one stream (per-cloud latency) instead of several clouds in flight on separate HIP streams "
+                         "(point_unet_amd/pipeline.py)")
+    ap.add_argument("--lanes", type=int, default=3, help="clouds in flight per GPU (pipeline lanes, one HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true", help="do not record hipEvents around the stages (A/B of their cost)")
     args = ap.parse_args()
@@ -235,42 +239,76 @@ def main():
     feats = np.concatenate([xyz, mods], -1)
     params = weights.init_params(cfg, seed=2, randomize_bn=True)
 
-    ctx = runtime.default_context(local_rank)
-    ctx.set_deferred_checks(True)  # status words of the tree build are validated at ctx.synchronize()
-    net = Network(cfg, params=params, device=local_rank, ctx=ctx)
     d_xyz = torch.from_numpy(xyz).cuda()
     d_feats = torch.from_numpy(feats).cuda()
-    pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
+    if args.no_pipeline:
+        ctx = runtime.default_context(local_rank)
+        ctx.set_deferred_checks(True)  # status words of the tree build are validated at ctx.synchronize()
+        net = Network(cfg, params=params, device=local_rank, ctx=ctx)
+        pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
+        contexts = [ctx]
 
-    def step():
-        build_pyramid(d_xyz, cfg, ctx=ctx, out=pyr)
-        return net.inference({"pyramid": pyr, "features": d_feats})
+        def step(overlap=True):
+            build_pyramid(d_xyz, cfg, ctx=ctx, out=pyr)
+            return net.inference({"pyramid": pyr, "features": d_feats})
 
-    def sync():
-        ctx.synchronize()
-        torch.cuda.synchronize()
+        def sync():
+            ctx.synchronize()
+            torch.cuda.synchronize()
+    else:
+        # consecutive clouds on consecutive lanes (one HIP stream each): the latency-bound pyramid of one cloud shares the
+        # chip with the network kernels of the others; every step still does all of its work
+        from point_unet_amd.pipeline import ForwardPipeline
+        pipe = ForwardPipeline(cfg, params=params, device=local_rank, lanes=args.lanes)
+        contexts = pipe.contexts
+
+        def step(overlap=True):
+            return pipe.submit(d_xyz, d_feats, overlap=overlap)
+
+        def sync():
+            pipe.synchronize()
+            torch.cuda.synchronize()
+
+    def timing_begin(only=None):
+        for cx in contexts:
+            cx.timing_begin(only=only)
+
+    def timing_end():
+        merged = {}  # the lanes' contexts report the same stage names: one row per stage
+        for cx in contexts:
+            for name, ms, launches in cx.timing_end():
+                a = merged.setdefault(name, [0.0, 0])
+                a[0] += ms
+                a[1] += launches
+        return [(k, v[0], v[1]) for k, v in merged.items()]
 
     for _ in range(args.warmup):
         step()
     sync()
-    # Profile pass (outside the timed region): hipEvent pairs on the launch stream around EVERY stage.  Recording ~120
-    # events per step costs ~0.35 ms of stream time, so the timed region below keeps only the dominant stage's pair.
+    # Profile pass (outside the timed region): hipEvent pairs on the launch stream around EVERY stage, steps serialised so
+    # that no stage shares the chip with another stream's kernels.  Recording ~120 events per step costs ~0.35 ms of stream
+    # time, so the timed region below keeps only the dominant stage's pair.
     prof_steps = 0 if args.no_stage_timing else max(3, min(args.steps, 10))
     prof_rows = []
     if prof_steps:
-        ctx.timing_begin()
+        timing_begin()
         for _ in range(prof_steps):
-            step()
-        prof_rows = ctx.timing_end()
+            step(overlap=False)
+        sync()
+        prof_rows = timing_end()
     # dominant KERNEL = the single-launch stage with the largest time (composite stages such as kdtree_build, ~57 small
     # launches, are listed in "stages" but are not one kernel)
     single = [r for r in prof_rows if r[2] == prof_steps]
     dominant = max(single, key=lambda r: r[1])[0] if single else None
     if dominant:
-        ctx.timing_begin(only=dominant)
+        timing_begin(only=dominant)
     elapsed, logits = timed_region(step, args.steps, sync, dist)
-    dom_rows = ctx.timing_end() if dominant else []
+    dom_rows = [r for r in timing_end() if r[0] == dominant] if dominant else []
     assert bool(torch.isfinite(logits).all())
+    serial_ms = None
+    if not args.no_pipeline:  # per-cloud latency next to the pipelined throughput
+        t_serial, _ = timed_region(lambda: step(overlap=False), max(3, args.steps // 2), sync, None)
+        serial_ms = 1e3 * t_serial / max(3, args.steps // 2)
 
     if rank == 0:
         costs = algorithmic_costs(cfg, n0, B)
@@ -323,8 +361,11 @@ def main():
             "config": {"workload": "BASELINE configs[%d]: %d-point BraTS-shaped cloud (%d modalities), K=%d, 5-level RandLA-Net forward "
                                    "incl. index pyramid, fp32, batch %d per GPU" % (1 if args.workload == "config2" else 4, n0, cfg.in_channels - 3,
                                                                                   cfg.k_n, B),
-                       "points": n0, "k_n": cfg.k_n, "num_layers": cfg.num_layers, "batch_per_gpu": B, "sharding": "one cloud per GPU, no collective"},
+                       "points": n0, "k_n": cfg.k_n, "num_layers": cfg.num_layers, "batch_per_gpu": B, "sharding": "one cloud per GPU, no collective",
+                       "pipeline": "serial, one stream" if args.no_pipeline else
+                       "%d clouds in flight, one HIP stream each (pyramid + forward per cloud on its stream)" % args.lanes},
             "roofline": roofline,
+            "serial_ms_per_cloud": serial_ms,
             "device_ms_per_step": round(dev_ms, 4),
             "algorithmic": {"gflop_per_step": total_cost["flops"] / 1e9, "gbyte_per_step": total_cost["bytes"] / 1e9},
             "stages": stages,

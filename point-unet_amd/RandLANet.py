@@ -51,7 +51,7 @@ class Network:
         """inputs: dict with 'features' [B,N0,Cin] and either 'pyramid' (a pyramid.Pyramid) or the reference's
         'xyz','neigh_idx','sub_idx','interp_idx' lists (RandLANet.py:33-36).  Returns logits [B,N0,num_classes]."""
         if is_training:
-            raise NotImplementedError("training-mode forward (batch-stat BN, dropout) is not built yet")
+            raise NotImplementedError("training-mode forward (batch-statistics BN, dropout) lives in point_unet_amd.train.Trainer")
         pyr = inputs.get("pyramid")
         if pyr is None:
             pyr = Pyramid([t.contiguous() for t in inputs["xyz"]], [t.contiguous() for t in inputs["neigh_idx"]],

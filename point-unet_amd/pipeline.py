@@ -1,0 +1,82 @@
+"""Several clouds in flight on one GPU.
+
+The reference feeds its network through tf.data: `tf_map` (the CPU KNN pyramid, runBraTS.py:140-161) runs in the
+input pipeline's `.map(...)` workers and `.prefetch(...)` keeps the next clouds' pyramids ready while the GPU runs the
+current one (runBraTS.py:166-185).  Here both halves are on the device, and the overlap is between LANES: every lane
+owns a HIP stream, a context (workspace), a copy of the folded weights and a pyramid slot, and runs its cloud start to
+finish -- ps_pyramid_build then ps_randla_forward -- on its stream; consecutive clouds go to consecutive lanes.  The
+pyramid of one cloud (latency-bound tree build and searches that fill a fraction of the chip) and the deep, few-point
+levels of its network then share the chip with the wide MFMA / HBM-bound kernels of the clouds on the other lanes.
+Nothing is copied between lanes and the host never blocks.  Results are identical to the serial path (same kernels,
+same order per cloud) -- tests/test_gpu_network.py::test_pipeline_matches_serial.
+"""
+import torch
+
+from . import runtime
+from .pyramid import alloc_pyramid, build_pyramid
+from .RandLANet import Network
+
+
+class _Lane:
+    def __init__(self, config, params, device, seed):
+        self.stream = torch.cuda.Stream(torch.device("cuda", device))
+        self.ctx = runtime.Context(device)
+        self.ctx.set_stream(self.stream)
+        self.ctx.set_deferred_checks(True)  # tree-build status words are validated at synchronize()
+        self.net = Network(config, params=params, device=device, seed=seed, ctx=self.ctx)
+        self.pyramid = None
+        self.done = None
+
+
+class ForwardPipeline:
+    def __init__(self, config, params=None, device=0, seed=0, lanes=3):
+        self.cfg = config
+        self.device = torch.device("cuda", device)
+        if params is None:
+            from . import weights
+            params = weights.init_params(config, seed=seed)
+        self.lanes = [_Lane(config, params, device, seed) for _ in range(int(lanes))]
+        self._shape = None
+        self._i = 0
+        self.last_done = None
+
+    @property
+    def contexts(self):
+        return [ln.ctx for ln in self.lanes]
+
+    def submit(self, xyz, features, overlap=True):
+        """xyz [B,N0,3], features [B,N0,Cin]: float32 CUDA tensors (ready on torch's current stream).  Enqueues the
+        pyramid build and the forward on the next lane; returns the logits tensor [B,N0,classes], complete after
+        synchronize() (or after waiting on `last_done`).  overlap=False makes the lane wait for the previously submitted
+        cloud first: bench.py's per-stage profile pass uses it to time kernels without a neighbour on the chip."""
+        B, n0 = xyz.shape[0], xyz.shape[1]
+        if self._shape != (B, n0):
+            self.synchronize()
+            ratios = list(self.cfg.sub_sampling_ratio)[:self.cfg.num_layers]
+            for ln in self.lanes:
+                ln.pyramid = alloc_pyramid(B, n0, ratios, self.cfg.k_n, xyz.device)
+            self._shape = (B, n0)
+        ln = self.lanes[self._i % len(self.lanes)]
+        self._i += 1
+        ln.stream.wait_stream(torch.cuda.current_stream(self.device))  # the inputs were produced on the caller's stream
+        if not overlap and self.last_done is not None:
+            ln.stream.wait_event(self.last_done)
+        with torch.cuda.stream(ln.stream):  # the logits are allocated on (and belong to) the lane's stream
+            build_pyramid(xyz, self.cfg, ctx=ln.ctx, out=ln.pyramid)
+            logits = ln.net.inference({"pyramid": ln.pyramid, "features": features})
+            ln.done = torch.cuda.Event()
+            ln.done.record(ln.stream)
+        xyz.record_stream(ln.stream)
+        features.record_stream(ln.stream)
+        self.last_done = ln.done
+        return logits
+
+    def synchronize(self):
+        """Drains every lane and validates the deferred status words of the tree builds (raises PointSegError)."""
+        for ln in self.lanes:
+            ln.ctx.synchronize()
+
+    def close(self):
+        self.synchronize()
+        for ln in self.lanes:
+            ln.ctx.close()

@@ -28,6 +28,11 @@ class Context:
         s = torch.cuda.current_stream(self.device)
         _lib.check(_lib.lib().ps_set_stream(self._h, ctypes.c_void_p(s.cuda_stream)))
 
+    def set_stream(self, stream):
+        """Launch on a given torch.cuda.Stream (the context does not own it)."""
+        self._stream = stream  # keep it alive
+        _lib.check(_lib.lib().ps_set_stream(self._h, ctypes.c_void_p(stream.cuda_stream)))
+
     def set_deferred_checks(self, on=True):
         """ps_pyramid_build without host synchronisation; status validated by synchronize()."""
         _lib.check(_lib.lib().ps_set_deferred_checks(self._h, 1 if on else 0))

@@ -114,3 +114,35 @@ def test_full_size_config2_properties(oracle):
     enc0 = ro.dilated_res_block(fc0, xyz.astype(np.float64), nbr0, params, "Encoder_layer_0", np.float64)
     got = net.tap(10, (1, 180000, 32))
     assert np.abs(got - enc0).max() <= TOL
+
+
+def test_pipeline_matches_serial():
+    """ForwardPipeline (consecutive clouds on consecutive lanes, one HIP stream + context each, three in flight) returns,
+    for every cloud of a sequence, bit-identical logits to the serial one-stream path."""
+    import torch
+    from point_unet_amd import weights
+    from point_unet_amd.RandLANet import Network
+    from point_unet_amd.pipeline import ForwardPipeline
+    from point_unet_amd.pyramid import build_pyramid
+    cfg, _, _ = netcase.small_deep(6000, seed=0, B=1)
+    params = weights.init_params(cfg, seed=4, randomize_bn=True)
+    clouds = [netcase.small_deep(6000, seed=10 + i, B=1)[1:] for i in range(7)]
+    net = Network(cfg, params=params)
+    want = []
+    for xyz, feats in clouds:
+        pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+        want.append(net.inference({"pyramid": pyr, "features": torch.from_numpy(feats).cuda()}).cpu().numpy())
+    pipe = ForwardPipeline(cfg, params=params, lanes=3)
+    dev = [(torch.from_numpy(x).cuda(), torch.from_numpy(f).cuda()) for x, f in clouds]
+    torch.cuda.synchronize()
+    got = [pipe.submit(x, f) for x, f in dev]  # all seven enqueued before anything is read back
+    pipe.synchronize()
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(g.cpu().numpy(), w), i
+    # a different cloud size re-allocates the slots
+    cfg2, xyz2, feats2 = netcase.small_deep(3000, seed=3, B=2)
+    out = pipe.submit(torch.from_numpy(xyz2).cuda(), torch.from_numpy(feats2).cuda())
+    pipe.synchronize()
+    pyr = build_pyramid(torch.from_numpy(xyz2).cuda(), cfg)
+    assert np.array_equal(out.cpu().numpy(), net.inference({"pyramid": pyr, "features": torch.from_numpy(feats2).cuda()}).cpu().numpy())
+    pipe.close()
