@@ -41,6 +41,7 @@ class Network:
 
     def set_params(self, params):
         self.params = params
+        self.__dict__.pop("_folded", None)
         blob = weights.fold_to_blob(self.config, params)
         want = _lib.lib().ps_randla_weight_count(self._h)
         assert blob.size == want, (blob.size, want)
@@ -131,3 +132,46 @@ class Network:
         agg = torch.empty((B, N, d), dtype=torch.float32, device=f.device)
         _lib.check(_lib.lib().ps_op_att_pool(_ctx(f).handle, runtime.ptr(f), runtime.ptr(wfc.contiguous()), B * N, K, d, runtime.ptr(agg)))
         return Network.conv2d(agg.unsqueeze(2), w_mlp, b_mlp, leaky=True)
+
+    # ---- the reference's block methods, composed from the ops above with this network's (BN-folded) parameters ----------
+    def _layer(self, scope):
+        """(w [Cin,Cout], b [Cout]) of a conv2d scope with its BatchNorm folded in (inference mode), cached on the device."""
+        cache = self.__dict__.setdefault("_folded", {})
+        if scope not in cache:
+            p = self.params
+            w, b = weights._fold(p[scope + "/weights"], p[scope + "/biases"], p, scope + "/batch_normalization")
+            cache[scope] = (torch.from_numpy(w).to(self.device), torch.from_numpy(b).to(self.device))
+        return cache[scope]
+
+    def _att(self, feature_set, name):
+        wfc = self.__dict__.setdefault("_folded", {}).get(name + "fc")
+        if wfc is None:
+            wfc = torch.from_numpy(np.ascontiguousarray(self.params[name + "fc/kernel"])).to(self.device)
+            self._folded[name + "fc"] = wfc
+        w, b = self._layer(name + "mlp")
+        return Network.att_pooling(feature_set, wfc, w, b)
+
+    def building_block(self, xyz, feature, neigh_idx, d_out, name, is_training=False):
+        """Local feature aggregation: xyz [B,N,3], feature [B,N,1,d_out/2], neigh_idx [B,N,K] -> [B,N,1,d_out]
+        (RandLANet.py:323-335); `name` is the scope prefix, e.g. 'Encoder_layer_0LFA'."""
+        assert not is_training, "op-by-op blocks run in inference mode (training: point_unet_amd.train.Trainer)"
+        f_xyz = Network.relative_pos_encoding(xyz, neigh_idx)
+        f_xyz = Network.conv2d(f_xyz, *self._layer(name + "mlp1"))
+        f_nb = Network.gather_neighbour(feature.squeeze(2), neigh_idx)
+        f_agg = self._att(torch.cat([f_nb, f_xyz], dim=-1), name + "att_pooling_1")
+        f_xyz = Network.conv2d(f_xyz, *self._layer(name + "mlp2"))
+        f_nb = Network.gather_neighbour(f_agg.squeeze(2), neigh_idx)
+        return self._att(torch.cat([f_nb, f_xyz], dim=-1), name + "att_pooling_2")
+
+    def dilated_res_block(self, feature, xyz, neigh_idx, d_out, name, is_training=False):
+        """feature [B,N,1,d_in] -> [B,N,1,2*d_out]: mlp1, building_block, mlp2 (no activation), + shortcut, LeakyReLU(0.2)
+        (RandLANet.py:314-321); `name` e.g. 'Encoder_layer_0'."""
+        assert not is_training, "op-by-op blocks run in inference mode (training: point_unet_amd.train.Trainer)"
+        f_pc = Network.conv2d(feature, *self._layer(name + "mlp1"))
+        f_pc = self.building_block(xyz, f_pc, neigh_idx, d_out, name + "LFA")
+        f_pc = Network.conv2d(f_pc, *self._layer(name + "mlp2"), leaky=False)
+        shortcut = Network.conv2d(feature, *self._layer(name + "shortcut"), leaky=False)
+        out = torch.empty_like(f_pc)
+        _lib.check(_lib.lib().ps_op_add_lrelu(_ctx(f_pc).handle, runtime.ptr(f_pc.contiguous()), runtime.ptr(shortcut.contiguous()), f_pc.numel(),
+                                              runtime.ptr(out)))
+        return out

@@ -5,6 +5,7 @@ DataProcessing facade over the native ops, now served by the HIP library.
     DataProcessing.knn_search           helper_tool.py:84-94
     DataProcessing.grid_sub_sampling    helper_tool.py:123-143
     DataProcessing.get_class_weights    helper_tool.py:172-184
+    DataProcessing.shuffle_idx / shuffle_list / IoU_from_confusions   helper_tool.py:110-121, 146-170
 """
 import numpy as np
 
@@ -47,46 +48,55 @@ class ConfigPancreas:
 
 
 class DataProcessing:
+    """Same static-method facade as the reference's DataProcessing; the native calls land in libpointseg_hip.so."""
+
     @staticmethod
     def knn_search(support_pts, query_pts, k):
-        """
-        :param support_pts: points you have, B*N1*3
-        :param query_pts: points you want to know the neighbour index, B*N2*3
-        :param k: Number of neighbours in knn search
-        :return: neighbor_idx: neighboring points indexes, B*N2*k  (int32)
-        """
-        neighbor_idx = nearest_neighbors.knn_batch(support_pts, query_pts, k, omp=True)
-        return neighbor_idx.astype(np.int32)
+        """K nearest support points of every query point, per batch element.
+        support_pts [B,N1,3], query_pts [B,N2,3] float32 -> int32 [B,N2,k], ascending distance, nanoflann tie order
+        (helper_tool.py:84-94: knn_batch(..., omp=True) cast to int32)."""
+        return nearest_neighbors.knn_batch(support_pts, query_pts, k, omp=True).astype(np.int32)
 
     @staticmethod
     def grid_sub_sampling(points, features=None, labels=None, grid_size=0.1, verbose=0):
-        """Grid sub-sampling (barycentre for points and features, majority for labels).
-        :param points: (N, 3) matrix of input points
-        :param features: optional (N, d) matrix of features (floating number)
-        :param labels: optional (N,) matrix of integer labels
-        :param grid_size: parameter defining the size of grid voxels
-        :return: sub_sampled points, with features and/or labels depending of the input
-        """
-        if (features is None) and (labels is None):
-            return cpp_subsampling.compute(points, sampleDl=grid_size, verbose=verbose)
-        elif labels is None:
-            return cpp_subsampling.compute(points, features=features, sampleDl=grid_size, verbose=verbose)
-        elif features is None:
-            return cpp_subsampling.compute(points, classes=labels, sampleDl=grid_size, verbose=verbose)
-        else:
-            return cpp_subsampling.compute(points, features=features, classes=labels, sampleDl=grid_size,
-                                           verbose=verbose)
+        """Voxel-grid subsampling: barycentre of the points (and mean of the features) per cell of side `grid_size`,
+        majority vote for integer labels.  Returns points, then features and/or labels when they were given
+        (helper_tool.py:123-143)."""
+        extra = {}
+        if features is not None:
+            extra["features"] = features
+        if labels is not None:
+            extra["classes"] = labels
+        return cpp_subsampling.compute(points, sampleDl=grid_size, verbose=verbose, **extra)
+
+    # per-class point counts the reference hard-codes (helper_tool.py:172-184)
+    _POINTS_PER_CLASS = {"BraTS20": (1, 1, 1, 1), "BraTS_Block64": (1403, 22, 80, 11), "Pancreas": (1, 1)}
 
     @staticmethod
     def get_class_weights(dataset_name):
-        # pre-calculate the number of points in each category (helper_tool.py:172-184)
-        num_per_class = []
-        if dataset_name == 'BraTS20':
-            num_per_class = np.array([1, 1, 1, 1])
-        elif dataset_name == 'BraTS_Block64':
-            num_per_class = np.array([1403, 22, 80, 11])
-        elif dataset_name == 'Pancreas':
-            num_per_class = np.array([1, 1])
-        weight = num_per_class / float(sum(num_per_class))
-        ce_label_weight = 1 / (weight + 0.02)
-        return np.expand_dims(ce_label_weight, axis=0)
+        """Cross-entropy class weights 1 / (class frequency + 0.02), shape [1, C]."""
+        counts = np.asarray(DataProcessing._POINTS_PER_CLASS[dataset_name], dtype=np.float64)
+        return (1.0 / (counts / counts.sum() + 0.02))[None, :]
+
+    @staticmethod
+    def shuffle_idx(x):
+        """Random permutation of the rows of x (helper_tool.py:110-114)."""
+        return x[np.random.permutation(len(x))]
+
+    @staticmethod
+    def shuffle_list(data_list):
+        """Random permutation of a Python list, as a new list (helper_tool.py:117-121)."""
+        order = np.random.permutation(len(data_list))
+        return [data_list[i] for i in order]
+
+    @staticmethod
+    def IoU_from_confusions(confusions):
+        """Per-class IoU = TP / (TP + FP + FN) from confusion matrices [..., C, C] (rows = truth, columns = prediction);
+        classes absent from a matrix take the mean IoU of the present ones (helper_tool.py:146-170)."""
+        confusions = np.asarray(confusions)
+        tp = np.diagonal(confusions, axis1=-2, axis2=-1)
+        denom = confusions.sum(axis=-1) + confusions.sum(axis=-2) - tp
+        iou = tp / (denom + 1e-6)
+        present = confusions.sum(axis=-1) >= 1e-3
+        mean_present = (iou * present).sum(axis=-1, keepdims=True) / (present.sum(axis=-1, keepdims=True) + 1e-6)
+        return np.where(present, iou, mean_present)

@@ -83,3 +83,17 @@ tap = {}
 logits = ro.inference(params, cfg.num_layers, pts, nbr, pool, up, feats, np.float64, tap=tap)
 save("net_config1", logits=logits.astype(np.float32), enc0_rows=tap["enc0"][0, :64].astype(np.float32),
      pool1_rows=tap["pool1"][0, :64].astype(np.float32), neigh_0_rows=nbr[0][0, :256], interp_0_rows=up[0][0, :256])
+
+# binary PLY (N2): a small BraTS-shaped cloud written by the REAL reference writer (PointSegment/helper_ply.py write_ply,
+# imported here only) -- the committed .ply is data; tests check this package's reader against it and this package's writer
+# for byte equality with it.
+sys.path.insert(0, "/root/reference/PointSegment")
+import helper_ply as ref_ply  # noqa: E402
+
+prng = np.random.default_rng(21)
+pxyz = brats_cloud(500, 22, grid=(16, 16, 12))
+pmods = prng.standard_normal((500, 4)).astype(np.float32)
+pcls = (prng.random(500) < 0.2).astype(np.int32) * prng.integers(1, 4, 500).astype(np.int32)
+ref_ply.write_ply(os.path.join(HERE, "brats_example.ply"), [pxyz, pmods, pcls], ["x", "y", "z", "t1ce", "t1", "flair", "t2", "class"])
+back = ref_ply.read_ply(os.path.join(HERE, "brats_example.ply"))
+save("ply_example", xyz=pxyz, mods=pmods, cls=pcls, read_back_x=back["x"], read_back_class=back["class"])

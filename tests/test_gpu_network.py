@@ -146,3 +146,23 @@ def test_pipeline_matches_serial():
     pyr = build_pyramid(torch.from_numpy(xyz2).cuda(), cfg)
     assert np.array_equal(out.cpu().numpy(), net.inference({"pyramid": pyr, "features": torch.from_numpy(feats2).cuda()}).cpu().numpy())
     pipe.close()
+
+
+def test_block_methods_reproduce_the_fused_path(oracle):
+    """Network.dilated_res_block / building_block (the reference's call sites, RandLANet.py:314-335, composed from the op-level
+    kernels) against the fused forward's own encoder output for the same input."""
+    import torch
+    from point_unet_amd import weights
+    from point_unet_amd.RandLANet import Network
+    from point_unet_amd.pyramid import build_pyramid
+    cfg, xyz, feats = netcase.small_deep(3000, seed=5, B=2)
+    params = weights.init_params(cfg, seed=6, randomize_bn=True)
+    net = Network(cfg, params=params)
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    net.inference({"pyramid": pyr, "features": torch.from_numpy(feats).cuda()})
+    B, N = xyz.shape[:2]
+    fc0 = torch.from_numpy(net.tap(0, (B, N, 8))).cuda()
+    want = net.tap(10, (B, N, 2 * cfg.d_out[0]))
+    got = net.dilated_res_block(fc0.unsqueeze(2), pyr.xyz[0], pyr.neigh_idx[0], cfg.d_out[0], "Encoder_layer_0")
+    assert tuple(got.shape) == (B, N, 1, 2 * cfg.d_out[0])
+    assert np.abs(got.squeeze(2).cpu().numpy() - want).max() <= 2e-5 * max(1.0, np.abs(want).max())

@@ -196,3 +196,56 @@ def test_tf_variable_importer_round_trip():
     for k in p:
         assert np.array_equal(back[k], p[k]), k
     assert np.array_equal(weights.fold_to_blob(ConfigBraTS, back), weights.fold_to_blob(ConfigBraTS, p))
+
+
+def test_ply_reader_and_writer_against_the_reference_file(tmp_path):
+    """tests/golden/brats_example.ply was written by the reference's helper_ply.write_ply (make_golden.py): this package's
+    reader returns the same fields, and this package's writer reproduces the file byte for byte."""
+    import os
+    from point_unet_amd import dataset, helper_ply
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(here, "ply_example.npz"))
+    data = helper_ply.read_ply(os.path.join(here, "brats_example.ply"))
+    assert data.dtype.names == ("x", "y", "z", "t1ce", "t1", "flair", "t2", "class")
+    assert np.array_equal(np.stack([data["x"], data["y"], data["z"]], 1), g["xyz"]) and np.array_equal(data["class"], g["cls"])
+    assert np.array_equal(np.stack([data[m] for m in dataset.BRATS_MODALITIES], 1), g["mods"])
+    out = str(tmp_path / "mine")
+    assert helper_ply.write_ply(out, [g["xyz"], g["mods"], g["cls"]], ["x", "y", "z", "t1ce", "t1", "flair", "t2", "class"])
+    assert open(out + ".ply", "rb").read() == open(os.path.join(here, "brats_example.ply"), "rb").read()
+    assert helper_ply.write_ply(out, [g["xyz"], g["cls"][:10]], ["x", "y", "z", "class"]) is False  # ragged fields
+    # mesh variant round trip
+    tri = np.array([[0, 1, 2], [2, 3, 4]], np.int32)
+    assert helper_ply.write_ply(out + "_m.ply", g["xyz"][:5], ["x", "y", "z"], triangular_faces=tri)
+    v, f = helper_ply.read_ply(out + "_m.ply", triangular_mesh=True)
+    assert np.array_equal(f, tri) and np.array_equal(v["z"], g["xyz"][:5, 2])
+
+
+def test_brats_sampler_keeps_every_tumour_voxel_and_shuffles():
+    """runBraTS.py:107-114: all tumour voxels + a background sample up to num_points, shuffled; features = [xyz | modalities]."""
+    import os
+    from point_unet_amd import dataset, helper_ply
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    data = helper_ply.read_ply(os.path.join(here, "brats_example.ply"))
+    xyz, mods, labels, idx = dataset.sample_brats_cloud(data, 300, np.random.default_rng(0))
+    assert xyz.shape == (300, 3) and mods.shape == (300, 4) and idx.dtype == np.int32 and len(np.unique(idx)) == 300
+    assert set(np.flatnonzero(data["class"] > 0)) <= set(idx.tolist())
+    assert np.array_equal(labels, data["class"][idx]) and np.array_equal(xyz[:, 0], data["x"][idx])
+    assert not np.array_equal(idx, np.sort(idx))
+    assert dataset.network_features(xyz, mods).shape == (300, 7)
+    with pytest.raises(ValueError):
+        dataset.sample_brats_cloud(data, 501)
+
+
+def test_iou_from_confusions_matches_the_reference_formula():
+    from point_unet_amd.helper_tool import DataProcessing as DP
+    rng = np.random.default_rng(0)
+    c = rng.integers(0, 50, (3, 4, 4))
+    c[1, 2, :] = 0  # class 2 absent from matrix 1: takes the mean IoU of the present classes
+    got = DP.IoU_from_confusions(c)
+    tp = np.diagonal(c, axis1=-2, axis2=-1).astype(np.float64)
+    fn_tp, fp_tp = c.sum(-1), c.sum(-2)
+    iou = tp / (fp_tp + fn_tp - tp + 1e-6)
+    mask = fn_tp < 1e-3
+    want = iou + mask * (iou.sum(-1, keepdims=True) / ((1 - mask).sum(-1, keepdims=True) + 1e-6))
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+    assert np.allclose(DP.get_class_weights("BraTS_Block64"), 1 / (np.array([1403, 22, 80, 11]) / 1516.0 + 0.02))
