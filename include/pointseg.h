@@ -193,6 +193,19 @@ int ps_op_bn_train_fwd(ps_context* ctx, const float* x, const float* gamma, cons
 int ps_op_bn_train_bwd(ps_context* ctx, const float* dy, const float* x, const float* gamma, const float* beta,
                        const float* mean, const float* invstd, int64_t R, int64_t C, int leaky, float* dx,
                        float* dgamma, float* dbeta);
+/* The same two ops split at their per-channel reduction, for BatchNorm statistics shared by the GPUs of a data-parallel job
+ * (keeps "8 GPUs x 1 cloud" numerically equal to "1 GPU x 8 clouds"): the caller sums `sums2C` = [sum x | sum x^2]
+ * (resp. dbeta = sum g, dgamma = sum g*xhat) over the ranks between the halves and passes the global row count R_total. */
+int ps_op_bn_train_sums(ps_context* ctx, const float* x, int64_t R, int64_t C, float* sums2C);
+int ps_op_bn_train_apply(ps_context* ctx, const float* x, const float* gamma, const float* beta, const float* sums2C,
+                         int64_t R, int64_t R_total, int64_t C, float eps, int leaky, float* y, float* mean, float* invstd,
+                         float* var);
+int ps_op_bn_train_bwd_sums(ps_context* ctx, const float* dy, const float* x, const float* gamma, const float* beta,
+                            const float* mean, const float* invstd, int64_t R, int64_t C, int leaky, float* dgamma,
+                            float* dbeta);
+int ps_op_bn_train_bwd_apply(ps_context* ctx, const float* dy, const float* x, const float* gamma, const float* beta,
+                             const float* mean, const float* invstd, const float* sum_g, const float* sum_gx, int64_t R,
+                             int64_t R_total, int64_t C, int leaky, float* dx);
 /* backward of gather_neighbour / nearest_interpolation: dpc[b*N + idx[row], :] += drows[row, :] */
 int ps_op_scatter_add_rows(ps_context* ctx, const float* drows, const int32_t* idx, int64_t B, int64_t N,
                            int64_t rows_per_cloud, int64_t d, float* dpc);

@@ -420,6 +420,56 @@ int ps_op_bn_train_bwd(ps_context* c, const float* dy, const float* x, const flo
     return PS_OK;
 }
 
+// ---- the same two ops split at their reduction, for BatchNorm statistics shared by several GPUs (config 4): the caller
+// all-reduces the 2*C sums between the halves and passes the global row count.
+int ps_op_bn_train_sums(ps_context* c, const float* x, int64_t R, int64_t C, float* sums2C)
+{
+    PS_CHECK(c && x && sums2C, "ps_op_bn_train_sums: NULL argument");
+    PS_CHECK(R >= 1 && C >= 1, "ps_op_bn_train_sums: empty tensor");
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "train_bn_fwd", 1);
+    PS_TRY(colreduce2(c, SumSq{x}, R, (int)C, sums2C, sums2C + C));
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+int ps_op_bn_train_apply(ps_context* c, const float* x, const float* gamma, const float* beta, const float* sums2C, int64_t R, int64_t R_total,
+                         int64_t C, float eps, int leaky, float* y, float* mean, float* invstd, float* var)
+{
+    PS_CHECK(c && x && gamma && beta && sums2C && y && mean && invstd && var, "ps_op_bn_train_apply: NULL argument");
+    PS_CHECK(R >= 1 && C >= 1 && R_total >= R, "ps_op_bn_train_apply: bad row counts");
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "train_bn_fwd", 2);
+    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, c->stream, sums2C, sums2C + C, R_total, (int)C, eps, mean, invstd, var);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+int ps_op_bn_train_bwd_sums(ps_context* c, const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                            const float* invstd, int64_t R, int64_t C, int leaky, float* dgamma, float* dbeta)
+{
+    PS_CHECK(c && dy && x && gamma && beta && mean && invstd && dgamma && dbeta, "ps_op_bn_train_bwd_sums: NULL argument");
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "train_bn_bwd", 1);
+    PS_TRY(colreduce2(c, BnBwdSums{dy, x, gamma, beta, mean, invstd, leaky}, R, (int)C, dbeta, dgamma));
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+int ps_op_bn_train_bwd_apply(ps_context* c, const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                             const float* invstd, const float* sum_g, const float* sum_gx, int64_t R, int64_t R_total, int64_t C, int leaky, float* dx)
+{
+    PS_CHECK(c && dy && x && gamma && beta && mean && invstd && sum_g && sum_gx && dx, "ps_op_bn_train_bwd_apply: NULL argument");
+    PS_CHECK(R >= 1 && C >= 1 && R_total >= R, "ps_op_bn_train_bwd_apply: bad row counts");
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "train_bn_bwd", 1);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, dy, x, gamma, beta, mean, invstd, sum_g, sum_gx, R * C, (int)C,
+                       1.0f / (float)R_total, leaky, dx);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
 int ps_op_scatter_add_rows(ps_context* c, const float* drows, const int32_t* idx, int64_t B, int64_t N, int64_t rows_per_cloud, int64_t d, float* dpc)
 {
     PS_CHECK(c && drows && idx && dpc, "ps_op_scatter_add_rows: NULL argument");

@@ -11,7 +11,9 @@ formulation ([B,N,K,C] tensors are materialised like the reference does); PyTorc
 concatenation/slicing copies and -- for config 4 -- the RCCL all-reduce of the flat gradient buffer.
 
 Multi-GPU: one cloud per GPU, gradients averaged with ONE all-reduce of the flat fp32 buffer
-(4 992 852 floats for BraTS).  BatchNorm statistics are per-GPU (the reference itself never runs batch > 1).
+(4 992 852 floats for BraTS).  BatchNorm statistics are per-GPU by default (the reference itself never runs batch > 1);
+Trainer(sync_bn=True) shares them between the ranks (two 2*C-float all-reduces per BatchNorm layer and step), which makes
+8 GPUs x 1 cloud the same optimisation step as 1 GPU x 8 clouds.
 """
 import ctypes
 
@@ -39,12 +41,14 @@ def allreduce_mean_(flat, dist):
 class Tape:
     """Records (output, backward closure) pairs; gradients are keyed by tensor identity and accumulated on the device."""
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, sync=None):
+        """sync: an initialised torch.distributed module for BatchNorm statistics shared by all ranks (None: per-GPU)."""
         self.ctx = ctx
         self.L = _lib.lib()
         self.h = ctx.handle
         self.ops = []
         self.grads = {}
+        self.sync = sync
 
     def accum(self, t, g):
         k = id(t)
@@ -89,17 +93,37 @@ class Tape:
     def bn_act(self, x, gamma, beta, ggamma, gbeta, mov_mean, mov_var, leaky):
         R, C = x.shape
         y = torch.empty_like(x)
-        stats = torch.empty((5, C), dtype=torch.float32, device=x.device)  # mean, invstd, var, scratch x2
-        _lib.check(self.L.ps_op_bn_train_fwd(self.h, _p(x), _p(gamma), _p(beta), R, C, BN_EPS, 1 if leaky else 0, _p(y), _p(stats[0]), _p(stats[1]),
-                                             _p(stats[2]), _p(stats[3])))
+        stats = torch.empty((5, C), dtype=torch.float32, device=x.device)  # mean, invstd, var, [sum x | sum x^2]
+        sync = self.sync
+        if sync is None:
+            _lib.check(self.L.ps_op_bn_train_fwd(self.h, _p(x), _p(gamma), _p(beta), R, C, BN_EPS, 1 if leaky else 0, _p(y), _p(stats[0]), _p(stats[1]),
+                                                 _p(stats[2]), _p(stats[3])))
+            R_total = R
+        else:
+            # statistics over the rows of ALL ranks: two small all-reduces per layer (2*C floats forward, 2*C backward)
+            R_total = R * sync.get_world_size()
+            _lib.check(self.L.ps_op_bn_train_sums(self.h, _p(x), R, C, _p(stats[3])))
+            sync.all_reduce(stats[3:5])
+            _lib.check(self.L.ps_op_bn_train_apply(self.h, _p(x), _p(gamma), _p(beta), _p(stats[3]), R, R_total, C, BN_EPS, 1 if leaky else 0, _p(y),
+                                                   _p(stats[0]), _p(stats[1]), _p(stats[2])))
         # moving statistics (the reference's extra_update_ops, RandLANet.py:90,163)
         mov_mean.mul_(BN_MOMENTUM).add_(stats[0], alpha=1 - BN_MOMENTUM)
         mov_var.mul_(BN_MOMENTUM).add_(stats[2], alpha=1 - BN_MOMENTUM)
 
         def bw(dy):
             dx = torch.empty_like(x)
-            _lib.check(self.L.ps_op_bn_train_bwd(self.h, _p(dy.contiguous()), _p(x), _p(gamma), _p(beta), _p(stats[0]), _p(stats[1]), R, C,
-                                                 1 if leaky else 0, _p(dx), _p(ggamma), _p(gbeta)))
+            dyc = dy.contiguous()
+            if sync is None:
+                _lib.check(self.L.ps_op_bn_train_bwd(self.h, _p(dyc), _p(x), _p(gamma), _p(beta), _p(stats[0]), _p(stats[1]), R, C,
+                                                     1 if leaky else 0, _p(dx), _p(ggamma), _p(gbeta)))
+            else:
+                # local sums are this rank's dgamma / dbeta (averaged with every other gradient later); dx needs the global ones
+                _lib.check(self.L.ps_op_bn_train_bwd_sums(self.h, _p(dyc), _p(x), _p(gamma), _p(beta), _p(stats[0]), _p(stats[1]), R, C,
+                                                          1 if leaky else 0, _p(ggamma), _p(gbeta)))
+                tot = torch.stack([gbeta.reshape(-1), ggamma.reshape(-1)])
+                sync.all_reduce(tot)
+                _lib.check(self.L.ps_op_bn_train_bwd_apply(self.h, _p(dyc), _p(x), _p(gamma), _p(beta), _p(stats[0]), _p(stats[1]), _p(tot[0]),
+                                                           _p(tot[1]), R, R_total, C, 1 if leaky else 0, _p(dx)))
             self.accum(x, dx)
 
         y.requires_grad_flag = True
@@ -203,7 +227,10 @@ class Tape:
 class Trainer:
     """Parameters (flat fp32 buffer + named views), Adam state and the train step."""
 
-    def __init__(self, config, params=None, device=0, seed=0, learning_rate=None, class_weights=None, keep_prob=0.5, ctx=None):
+    def __init__(self, config, params=None, device=0, seed=0, learning_rate=None, class_weights=None, keep_prob=0.5, ctx=None, sync_bn=False):
+        """sync_bn: with a `dist` passed to train_step, BatchNorm uses the statistics of all ranks' rows, which makes "W GPUs x
+        one cloud" numerically the same step as "one GPU x W clouds" (SURVEY 8e); off = per-GPU statistics."""
+        self.sync_bn = bool(sync_bn)
         self.cfg = config
         self.device = torch.device("cuda", device)
         self.ctx = ctx or runtime.default_context(device)
@@ -310,7 +337,7 @@ class Trainer:
         """One optimisation step on the batch; returns the loss (device scalar tensor).  With `dist` (an initialised
         torch.distributed) the flat gradient buffer is averaged over ranks with one all-reduce before Adam."""
         lib, h = _lib.lib(), self.ctx.handle
-        t = Tape(self.ctx)
+        t = Tape(self.ctx, sync=dist if (self.sync_bn and dist is not None) else None)
         logits = self.forward(t, pyr, features)
         R, C = logits.shape
         loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
