@@ -301,20 +301,31 @@ def main():
     # launches, are listed in "stages" but are not one kernel)
     single = [r for r in prof_rows if r[2] == prof_steps]
     dominant = max(single, key=lambda r: r[1])[0] if single else None
-    if dominant:
+    # The dominant stage is re-measured LIVE with its own event pair only: inside the timed region when steps are serial
+    # (--no-pipeline); with several clouds in flight a kernel's event pair would also time the other lanes' kernels it shares
+    # the chip with (and rocprofv3 --kernel-trace serialises dispatches, so its average could not agree), so the pair is armed
+    # over the serial pass that follows the timed region instead (one cloud in flight, same kernels, same inputs).
+    if dominant and args.no_pipeline:
         timing_begin(only=dominant)
     elapsed, logits = timed_region(step, args.steps, sync, dist)
-    dom_rows = [r for r in timing_end() if r[0] == dominant] if dominant else []
+    dom_rows, dom_steps, dom_where = [], args.steps, "timed region"
+    if dominant and args.no_pipeline:
+        dom_rows = [r for r in timing_end() if r[0] == dominant]
     assert bool(torch.isfinite(logits).all())
     serial_ms = None
     if not args.no_pipeline:  # per-cloud latency next to the pipelined throughput
-        t_serial, _ = timed_region(lambda: step(overlap=False), max(3, args.steps // 2), sync, None)
-        serial_ms = 1e3 * t_serial / max(3, args.steps // 2)
+        dom_steps, dom_where = max(3, args.steps // 2), "serial pass after the timed region (one cloud in flight)"
+        if dominant:
+            timing_begin(only=dominant)
+        t_serial, _ = timed_region(lambda: step(overlap=False), dom_steps, sync, None)
+        if dominant:
+            dom_rows = [r for r in timing_end() if r[0] == dominant]
+        serial_ms = 1e3 * t_serial / dom_steps
 
     if rank == 0:
         costs = algorithmic_costs(cfg, n0, B)
         stages = []
-        live = {name: (ms / args.steps, launches / args.steps) for name, ms, launches in dom_rows}
+        live = {name: (ms / dom_steps, launches / dom_steps) for name, ms, launches in dom_rows}
         for name, ms, launches in prof_rows:
             per_step = ms / prof_steps
             launches = launches * args.steps / prof_steps
@@ -340,7 +351,7 @@ def main():
                             peak=F32_MFMA_PEAK_TF if mf else HBM_PEAK_GBS, unit="TFLOP/s" if mf else "GB/s",
                             frac=round(max(tfs / F32_MFMA_PEAK_TF, gbs / HBM_PEAK_GBS), 5), traffic=None,
                             ms_per_step=round(t_ms, 4), launches_per_step=n_launch, avg_launch_ms=round(t_ms / max(n_launch, 1), 5),
-                            algorithmic_bytes_per_step=cst["bytes"], algorithmic_flops_per_step=cst["flops"])
+                            algorithmic_bytes_per_step=cst["bytes"], algorithmic_flops_per_step=cst["flops"], measured=dom_where)
             pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
             if os.path.exists(pmc):  # HBM bytes per launch from committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
                 roofline["traffic"] = json.load(open(pmc)).get(dominant)
