@@ -57,8 +57,54 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
         else wave_lds_sync();
     };
 
+    // d = 64 (level 1, 45 000 points): all three weight matrices fit in ~56 registers per lane; loading them once takes an
+    // exposed L2 round trip per MFMA group out of the per-point loop.  Wider levels stream them (L2-resident).
+    constexpr bool HOIST = !SPLITN && D <= 64;
+    bfH w1r[HOIST ? CB_H : 1][3];
+    bfH w2r[HOIST && STAGE == 2 ? CB_H : 1][HOIST && STAGE == 2 ? KS_H : 1];
+    bfD wbr[HOIST ? CB_D : 1][HOIST ? KS_H : 1];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int cb = 0; cb < CB_H; ++cb) {
+            const bfH* w = reinterpret_cast<const bfH*>(a.w1p) + (size_t)cb * 3 * 64 + lane;
+            w1r[cb][0] = w[0]; w1r[cb][1] = w[64]; w1r[cb][2] = w[128];
+            if constexpr (STAGE == 2) {
+#pragma unroll
+                for (int ks = 0; ks < KS_H; ++ks) w2r[cb][ks] = (reinterpret_cast<const bfH*>(a.w2p) + (size_t)cb * KS_H * 64 + lane)[(size_t)ks * 64];
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < CB_D; ++cb)
+#pragma unroll
+            for (int ks = 0; ks < KS_H; ++ks) wbr[cb][ks] = (reinterpret_cast<const bfD*>(a.wbp) + (size_t)cb * KS_H * 64 + lane)[(size_t)ks * 64];
+    }
+    // A-fragment product from an LDS tile with register-resident B fragments
+    auto reg_mma_H = [&](const float* tile, const bfH (&w)[HOIST && STAGE == 2 ? KS_H : 1], f32x4 (&acc)[RT][NTB_H]) {
+        const float* t0 = tile + (lane & 15) * PITCH + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < (HOIST && STAGE == 2 ? KS_H : 1); ++ks)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float av = t0[rt * 16 * PITCH + ks * 4];
+#pragma unroll
+                for (int j = 0; j < NTB_H; ++j) acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bfrag_get<NTB_H>(w[ks], j), acc[rt][j], 0, 0, 0);
+            }
+    };
+    auto reg_mma_D = [&](const float* tile, const bfD (&w)[HOIST ? KS_H : 1], f32x4 (&acc)[RT][NTB_D]) {
+        const float* t0 = tile + (lane & 15) * PITCH + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < (HOIST ? KS_H : 1); ++ks)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float av = t0[rt * 16 * PITCH + ks * 4];
+#pragma unroll
+                for (int j = 0; j < NTB_D; ++j) acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bfrag_get<NTB_D>(w[ks], j), acc[rt][j], 0, 0, 0);
+            }
+    };
+
+    int base = 0, base_end = a.n_cloud;  // cloud of the current point, tracked incrementally (no integer division per point)
     for (int p = SPLITN ? blockIdx.x : blockIdx.x * WAVES + wave; p < a.n_total; p += SPLITN ? gridDim.x : gridDim.x * WAVES) {
-        const int base = (p / a.n_cloud) * a.n_cloud;
+        while (p >= base_end) { base = base_end; base_end += a.n_cloud; }
         const float cx = a.xyz[3 * (size_t)p], cy = a.xyz[3 * (size_t)p + 1], cz = a.xyz[3 * (size_t)p + 2];
         int nb[RT];
         float a0[RT], a1[RT], a2[RT];
@@ -80,8 +126,13 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int j = 0; j < NTB_H; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const bfH* w = reinterpret_cast<const bfH*>(a.w1p) + (size_t)cb * 3 * 64 + lane;
-            const bfH b0 = w[0], b1v = w[64], b2v = w[128];
+            bfH b0, b1v, b2v;
+            if constexpr (HOIST) {
+                b0 = w1r[cb][0]; b1v = w1r[cb][1]; b2v = w1r[cb][2];
+            } else {
+                const bfH* w = reinterpret_cast<const bfH*>(a.w1p) + (size_t)cb * 3 * 64 + lane;
+                b0 = w[0]; b1v = w[64]; b2v = w[128];
+            }
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -112,7 +163,8 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int j = 0; j < NTB_H; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                tile_mma<NTB_H, RT>(T1, PITCH, KS_H, reinterpret_cast<const bfH*>(a.w2p) + (size_t)cb * KS_H * 64 + lane, acc, lane);
+                if constexpr (HOIST) reg_mma_H(T1, w2r[cb], acc);
+                else tile_mma<NTB_H, RT>(T1, PITCH, KS_H, reinterpret_cast<const bfH*>(a.w2p) + (size_t)cb * KS_H * 64 + lane, acc, lane);
 #pragma unroll
                 for (int j = 0; j < NTB_H; ++j) {
                     const int col = (cb * NTB_H + j) * 16 + c16;
@@ -146,7 +198,8 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[rt][j][r] = a.fg[jr[rt][r] + H + col];
             }
-            tile_mma<NTB_D, RT>(TX, PITCH, KS_H, reinterpret_cast<const bfD*>(a.wbp) + (size_t)cb * KS_H * 64 + lane, acc, lane);
+            if constexpr (HOIST) reg_mma_D(TX, wbr[cb], acc);
+            else tile_mma<NTB_D, RT>(TX, PITCH, KS_H, reinterpret_cast<const bfD*>(a.wbp) + (size_t)cb * KS_H * 64 + lane, acc, lane);
 #pragma unroll
             for (int j = 0; j < NTB_D; ++j) {
                 const int col = (cb * NTB_D + j) * 16 + c16;
@@ -193,7 +246,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
                     }
                 ssum = xor_sum(ssum);
                 num = xor_sum(num);
-                if (g == 0) a.agg[(size_t)p * D + col] = num / ssum;
+                if (g == 0) a.agg[(size_t)p * D + col] = num * __frcp_rn(ssum);
             }
         }
         phase_sync();  // T1/T2 are overwritten by the next point
@@ -224,8 +277,38 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
     float* A = smem + wave * PER_WAVE;
     float* T1 = A + KN * PA;
 
+    // Every B fragment and bias this wave will ever need, loaded ONCE: at d <= 32 the three weight matrices are a few dozen
+    // registers, and re-reading them per point put an exposed L2 round trip in front of every MFMA group.
+    bfH w1r[CB_H][3];
+    float b1r[CB_H][NTB_H];
+    bfH w2r[STAGE == 2 ? CB_H : 1][STAGE == 2 ? KS_H : 1];
+    float b2r[STAGE == 2 ? CB_H : 1][NTB_H];
+    bfD wfr[CB_D][KS_D];
+#pragma unroll
+    for (int cb = 0; cb < CB_H; ++cb) {
+        const bfH* w = reinterpret_cast<const bfH*>(a.w1p) + (size_t)cb * 3 * 64 + lane;
+        w1r[cb][0] = w[0]; w1r[cb][1] = w[64]; w1r[cb][2] = w[128];
+#pragma unroll
+        for (int j = 0; j < NTB_H; ++j) {
+            const int col = (cb * NTB_H + j) * 16 + c16;
+            b1r[cb][j] = col < H ? a.b1[col] : 0.f;
+            if constexpr (STAGE == 2) b2r[cb][j] = col < H ? a.b2[col] : 0.f;
+        }
+        if constexpr (STAGE == 2) {
+#pragma unroll
+            for (int ks = 0; ks < KS_H; ++ks) w2r[cb][ks] = (reinterpret_cast<const bfH*>(a.w2p) + (size_t)cb * KS_H * 64 + lane)[(size_t)ks * 64];
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < CB_D; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < KS_D; ++ks) wfr[cb][ks] = (reinterpret_cast<const bfD*>(a.wfp) + (size_t)cb * KS_D * 64 + lane)[(size_t)ks * 64];
+    const float* a_lane = A + (lane & 15) * PA + (lane >> 4);    // A-fragment base of this lane in the [KN x PA] tile
+    const float* t_lane = T1 + (lane & 15) * PT + (lane >> 4);
+
+    int base = 0, base_end = a.n_cloud;  // cloud of the current point, tracked incrementally (no integer division per point)
     for (int p = blockIdx.x * WAVES + wave; p < a.n_total; p += gridDim.x * WAVES) {
-        const int base = (p / a.n_cloud) * a.n_cloud;
+        while (p >= base_end) { base = base_end; base_end += a.n_cloud; }
         const float cx = a.xyz[3 * (size_t)p], cy = a.xyz[3 * (size_t)p + 1], cz = a.xyz[3 * (size_t)p + 2];
         int nb[RT];
         float a0[RT], a1[RT], a2[RT];
@@ -268,21 +351,19 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int j = 0; j < NTB_H; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const bfH* w = reinterpret_cast<const bfH*>(a.w1p) + (size_t)cb * 3 * 64 + lane;
-            const bfH b0 = w[0], b1v = w[64], b2v = w[128];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int j = 0; j < NTB_H; ++j) {
-                    acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[rt], bfrag_get<NTB_H>(b0, j), acc[rt][j], 0, 0, 0);
-                    acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rt], bfrag_get<NTB_H>(b1v, j), acc[rt][j], 0, 0, 0);
-                    acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[rt], bfrag_get<NTB_H>(b2v, j), acc[rt][j], 0, 0, 0);
+                    acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[rt], bfrag_get<NTB_H>(w1r[cb][0], j), acc[rt][j], 0, 0, 0);
+                    acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rt], bfrag_get<NTB_H>(w1r[cb][1], j), acc[rt][j], 0, 0, 0);
+                    acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[rt], bfrag_get<NTB_H>(w1r[cb][2], j), acc[rt][j], 0, 0, 0);
                 }
 #pragma unroll
             for (int j = 0; j < NTB_H; ++j) {
                 const int col = (cb * NTB_H + j) * 16 + c16;
                 if (col < H) {
-                    const float bb = a.b1[col];
+                    const float bb = b1r[cb][j];
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -292,18 +373,27 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
         }
         wave_lds_sync();
         if constexpr (STAGE == 2) {
+#pragma unroll
             for (int cb = 0; cb < CB_H; ++cb) {
                 f32x4 acc[RT][NTB_H];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int j = 0; j < NTB_H; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                tile_mma<NTB_H, RT>(T1, PT, KS_H, reinterpret_cast<const bfH*>(a.w2p) + (size_t)cb * KS_H * 64 + lane, acc, lane);
+#pragma unroll
+                for (int ks = 0; ks < KS_H; ++ks)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const float av = t_lane[rt * 16 * PT + ks * 4];
+#pragma unroll
+                        for (int j = 0; j < NTB_H; ++j)
+                            acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bfrag_get<NTB_H>(w2r[cb][ks], j), acc[rt][j], 0, 0, 0);
+                    }
 #pragma unroll
                 for (int j = 0; j < NTB_H; ++j) {
                     const int col = (cb * NTB_H + j) * 16 + c16;
                     if (col < H) {
-                        const float bb = a.b2[col];
+                        const float bb = b2r[cb][j];
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -314,13 +404,22 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
             wave_lds_sync();
         }
         // ---- scores on the full Wfc, softmax over the K rows, weighted sum ----
+#pragma unroll
         for (int cb = 0; cb < CB_D; ++cb) {
             f32x4 acc[RT][NTB_D];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int j = 0; j < NTB_D; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            tile_mma<NTB_D, RT>(A, PA, KS_D, reinterpret_cast<const bfD*>(a.wfp) + (size_t)cb * KS_D * 64 + lane, acc, lane);
+#pragma unroll
+            for (int ks = 0; ks < KS_D; ++ks)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const float av = a_lane[rt * 16 * PA + ks * 4];
+#pragma unroll
+                    for (int j = 0; j < NTB_D; ++j)
+                        acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bfrag_get<NTB_D>(wfr[cb][ks], j), acc[rt][j], 0, 0, 0);
+                }
 #pragma unroll
             for (int j = 0; j < NTB_D; ++j) {
                 const int col = (cb * NTB_D + j) * 16 + c16;
@@ -341,7 +440,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
                     }
                 ssum = xor_sum(ssum);
                 num = xor_sum(num);
-                if (g == 0) a.agg[(size_t)p * D + col] = num / ssum;
+                if (g == 0) a.agg[(size_t)p * D + col] = num * __frcp_rn(ssum);
             }
         }
         wave_lds_sync();  // the tiles are overwritten by the next point
@@ -370,9 +469,7 @@ static int dispatch_direct(ps_context* c, int d, const AttArgs& a)
     switch (d) {
         case 16: return launch_att_direct<16, STAGE, KN>(c, a);
         case 32: return launch_att_direct<32, STAGE, KN>(c, a);
-        case 64: return launch_att_direct<64, STAGE, KN>(c, a);
-        case 128: return launch_att_direct<128, STAGE, KN>(c, a);
-        default: set_error("att_pool(direct): d_out %d is not a compiled size (16,32,64,128)", d); return PS_EINVAL;
+        default: set_error("att_pool(direct): d_out %d is not a compiled size (16, 32: the weights live in registers)", d); return PS_EINVAL;
     }
 }
 
