@@ -77,6 +77,17 @@ struct GArr {
 };
 
 // ---- init -----------------------------------------------------------------------------------------------------
+// zeroes the counters / flags and primes the ordered-uint bounding-box accumulators (one launch instead of an upload and
+// three memsets on the stream)
+__global__ void build_prep_kernel(int32_t* cnt, int n_cnt, int32_t* hcnt, int n_hcnt, int32_t* flags, unsigned* bbox, int n_trees)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_cnt) cnt[i] = 0;
+    if (i < n_hcnt) hcnt[i] = 0;
+    if (i < 16) flags[i] = 0;
+    if (i < 8 * n_trees) bbox[i] = (i & 7) < 3 ? 0xffffffffu : 0u;
+}
+
 __global__ __launch_bounds__(256) void init_points_kernel(const BuildTree* __restrict__ trees, int chunks_x)
 {
     __shared__ float s_mn[4][3], s_mx[4][3];
@@ -854,13 +865,6 @@ __global__ __launch_bounds__(kMidThreads) void build_mid_kernel(const BuildTree*
     }
 }
 
-// marks the mid / small queues as processed up to their current fill (the continue path only handles later additions)
-__global__ void queue_done_kernel(BuildQueues Q, int which)
-{
-    if (which == 0) Q.small_cnt[2] = min(Q.small_cnt[1], Q.q_cap);
-    else Q.small_cnt[3] = min(Q.small_cnt[0], Q.small_cap);
-}
-
 // ---- chunked levels: the first kHugeLevels levels of nodes above kHuge points ------------------------------------
 // One workgroup per node cannot pull more than one CU's bandwidth, which made the top three levels of a 180 000-point
 // tree cost ~0.5 ms.  Here every pass of such a node is spread over the chip in 2 048-record chunks, one small
@@ -1224,15 +1228,20 @@ __global__ __launch_bounds__(256) void huge_phase_kernel(const BuildTree* __rest
     if (PHASE == 6) huge_scatter_chunk<1>(trees, H, level, c);
 }
 
-__global__ void pending_flag_kernel(const int32_t* __restrict__ level_cnt, int level, int32_t* __restrict__ flags)
+// Last launch of a build: flags[2] = big nodes still waiting (level >= 0: the first level queue no kernel was launched for;
+// -1: none, and the stack-overflow marks left by searches over the unfinished trees are cleared), and the mid / small queues
+// are marked as processed up to their current fill (the continue path only handles later additions).
+__global__ void build_finish_kernel(BuildQueues Q, int level)
 {
-    flags[2] = level >= 0 ? level_cnt[level] : 0;
-    if (level < 0) flags[0] = 0;  // stack-overflow marks left by searches over the unfinished trees
+    Q.flags[2] = level >= 0 ? Q.level_cnt[level] : 0;
+    if (level < 0) Q.flags[0] = 0;
+    Q.small_cnt[2] = min(Q.small_cnt[1], Q.q_cap);
+    Q.small_cnt[3] = min(Q.small_cnt[0], Q.small_cap);
 }
 
 constexpr int kBlindLevels = 2;  // level kernels launched blind after the chunked levels (nodes still above kMid)
 
-static int launch_mid_and_subtrees(ps_context* c, const BuildTree* d_trees, const BuildQueues& Q, size_t tot, size_t T, size_t small_cap)
+static int launch_mid_and_subtrees(ps_context* c, const BuildTree* d_trees, const BuildQueues& Q, size_t tot, size_t T, size_t small_cap, int pending_level)
 {
     static bool attr_set = false;
     constexpr size_t mid_lds = sizeof(float4) * kMid + sizeof(short) * kMid;
@@ -1243,9 +1252,8 @@ static int launch_mid_and_subtrees(ps_context* c, const BuildTree* d_trees, cons
     hipStream_t st = c->stream;
     const unsigned grid_mid = (unsigned)std::min<size_t>(tot / kSmall + T + 1, 1024);
     hipLaunchKernelGGL(build_mid_kernel, dim3(grid_mid), dim3(kMidThreads), mid_lds, st, d_trees, Q);
-    hipLaunchKernelGGL(queue_done_kernel, dim3(1), dim3(1), 0, st, Q, 0);
     hipLaunchKernelGGL(build_subtree_kernel, dim3((unsigned)std::min<size_t>(ceil_div(small_cap, 4), 2048)), dim3(256), 0, st, d_trees, Q);
-    hipLaunchKernelGGL(queue_done_kernel, dim3(1), dim3(1), 0, st, Q, 1);
+    hipLaunchKernelGGL(build_finish_kernel, dim3(1), dim3(1), 0, st, Q, pending_level);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -1303,9 +1311,8 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     int32_t* d_cm = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 2 * cap_chunks));
 
     // host staging lives in the plan (the caller keeps the plan alive until its final stream synchronisation)
-    plan.host_blob.resize(sizeof(BuildTree) * T + sizeof(unsigned) * 8 * T);
+    plan.host_blob.resize(sizeof(BuildTree) * T);
     BuildTree* h_trees = reinterpret_cast<BuildTree*>(plan.host_blob.data());
-    unsigned* h_bbox = reinterpret_cast<unsigned*>(plan.host_blob.data() + sizeof(BuildTree) * T);
     size_t pos_off = 0;
     int32_t max_n = 0;
     for (size_t i = 0; i < T; ++i) {
@@ -1320,17 +1327,14 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
         t.bbox_ord = d_bbox + 8 * i;
         t.n = plan.n[i];
         max_n = std::max(max_n, t.n);
-        for (int a = 0; a < 3; ++a) {
-            h_bbox[8 * i + a] = 0xffffffffu;
-            h_bbox[8 * i + 3 + a] = 0u;
-        }
     }
     hipStream_t st = c->stream;
     PS_TRY(c->upload_async(d_trees, h_trees, sizeof(BuildTree) * T));
-    PS_TRY(c->upload_async(d_bbox, h_bbox, sizeof(unsigned) * 8 * T));
-    PS_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (kMaxLevels + 8), st));
-    PS_HIP(hipMemsetAsync(d_hcnt, 0, sizeof(int32_t) * 2 * (kHugeLevels + 2), st));
-    PS_HIP(hipMemsetAsync(plan.d_flags, 0, 16 * sizeof(int32_t), st));
+    {
+        const int n_prep = std::max<int>({kMaxLevels + 8, 2 * (kHugeLevels + 2), 16, (int)(8 * T)});
+        hipLaunchKernelGGL(build_prep_kernel, dim3(ceil_div(n_prep, 256)), dim3(256), 0, st, d_cnt, kMaxLevels + 8, d_hcnt, 2 * (kHugeLevels + 2),
+                           plan.d_flags, d_bbox, (int)T);
+    }
 
     HugeState H;
     H.tasks[0] = d_huge;
@@ -1383,9 +1387,8 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     // (the level queues are indexed by the level a task was pushed FOR: chunked level L pushes for L + 1, the roots for 0)
     for (int level = huge_levels == 0 ? 0 : huge_levels; level < huge_levels + kBlindLevels; ++level)
         hipLaunchKernelGGL(build_level_kernel, dim3(grid_big), dim3(kBigThreads), 0, st, d_trees, Q, level);
-    hipLaunchKernelGGL(pending_flag_kernel, dim3(1), dim3(1), 0, st, d_cnt, plan.first_pending_level, plan.d_flags);
-    PS_TRY(launch_mid_and_subtrees(c, d_trees, Q, tot, T, small_cap));
-    plan.launches = 7 + kBlindLevels + 9 * huge_levels;
+    PS_TRY(launch_mid_and_subtrees(c, d_trees, Q, tot, T, small_cap, plan.first_pending_level));
+    plan.launches = 6 + kBlindLevels + 9 * huge_levels;
     return PS_OK;
 }
 
@@ -1425,9 +1428,8 @@ int build_trees_continue(ps_context* c, TreeSetPlan& plan)
         if (pending == 0) break;
         PS_CHECK(level < kMaxLevels - 1, "kd-tree build: more than %d levels of nodes above %d points (degenerate cloud)", kMaxLevels, kMid);
     }
-    // only the mid / small nodes queued since the first run are new work (queue_done_kernel recorded the old fill)
-    hipLaunchKernelGGL(pending_flag_kernel, dim3(1), dim3(1), 0, st, d_cnt, -1, plan.d_flags);
-    PS_TRY(launch_mid_and_subtrees(c, d_trees, Q, tot, T, small_cap));
+    // only the mid / small nodes queued since the first run are new work (build_finish_kernel recorded the old fill)
+    PS_TRY(launch_mid_and_subtrees(c, d_trees, Q, tot, T, small_cap, -1));
     return PS_OK;
 }
 

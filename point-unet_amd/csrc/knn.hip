@@ -254,25 +254,24 @@ extern "C" int ps_knn_batch_i64(ps_context* c, const float* support, const float
 // --------------------------------------------------------------------------------------------------------
 namespace ps {
 
-__global__ void slice_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t B, int64_t n_src, int64_t n_dst,
-                                  int width)
+// dst[b, i, :] = src[b, i, :] for i < n_dst (prefix slice of every cloud), for all pyramid levels in ONE launch
+// (blockIdx.y = level): ten dependent 4-us launches per cloud otherwise.
+struct SliceTable {
+    const int32_t* src[PS_MAX_LAYERS];  // (float rows are copied as 32-bit words)
+    int32_t* dst[PS_MAX_LAYERS];
+    int64_t n_src[PS_MAX_LAYERS], n_dst[PS_MAX_LAYERS];
+    int64_t B;
+    int width;
+};
+__global__ void slice_rows_kernel(SliceTable t)
 {
-    // dst[b, i, :] = src[b, i, :] for i < n_dst  (prefix slice of every cloud)
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    size_t per = (size_t)n_dst * width;
-    if (i >= (size_t)B * per) return;
-    size_t b = i / per, r = i % per;
-    dst[i] = src[b * (size_t)n_src * width + r];
-}
-
-__global__ void slice_rows_i32_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int64_t B, int64_t n_src,
-                                      int64_t n_dst, int width)
-{
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    size_t per = (size_t)n_dst * width;
-    if (i >= (size_t)B * per) return;
-    size_t b = i / per, r = i % per;
-    dst[i] = src[b * (size_t)n_src * width + r];
+    const int l = blockIdx.y;
+    if (!t.dst[l]) return;
+    const size_t per = (size_t)t.n_dst[l] * t.width, total = (size_t)t.B * per;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per, r = i % per;
+        t.dst[l][i] = t.src[l][b * (size_t)t.n_src[l] * t.width + r];
+    }
 }
 
 }  // namespace ps
@@ -300,12 +299,20 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
 
     // xyz[i] = prefix slices (xyz[0] is a plain copy unless the caller aliased it)
     {
-        Stage st(c, "pyramid_slices", L);
+        Stage st(c, "pyramid_slices", 1);
+        SliceTable t = {};
+        size_t most = 0;
         for (int i = 0; i < L; ++i) {
             if (i == 0 && pyr->xyz[0] == xyz0) continue;
-            size_t tot = (size_t)B * n[i] * 3;
-            hipLaunchKernelGGL(slice_rows_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, c->stream, xyz0, pyr->xyz[i], B, n0, n[i], 3);
+            t.src[i] = reinterpret_cast<const int32_t*>(xyz0);
+            t.dst[i] = reinterpret_cast<int32_t*>(pyr->xyz[i]);
+            t.n_src[i] = n0;
+            t.n_dst[i] = n[i];
+            most = std::max(most, (size_t)B * n[i] * 3);
         }
+        t.B = B;
+        t.width = 3;
+        hipLaunchKernelGGL(slice_rows_kernel, dim3((unsigned)std::min<size_t>(ceil_div(most, 256), 2048), L), dim3(256), 0, c->stream, t);
         PS_HIP(hipGetLastError());
     }
 
@@ -371,12 +378,19 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
             PS_TRY(launch_knn(c, dj + n_self, (int)(jobs.size() - n_self), max_nq, 1));
         }
         {
-            Stage st(c, "pyramid_slices", L);
+            Stage st(c, "pyramid_slices", 1);
+            SliceTable t = {};
+            size_t most = 0;
             for (int l = 0; l < L; ++l) {
-                size_t tot = (size_t)B * n[l + 1] * K;
-                hipLaunchKernelGGL(slice_rows_i32_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, c->stream, pyr->neigh_idx[l], pyr->sub_idx[l],
-                                   B, n[l], n[l + 1], K);
+                t.src[l] = pyr->neigh_idx[l];
+                t.dst[l] = pyr->sub_idx[l];
+                t.n_src[l] = n[l];
+                t.n_dst[l] = n[l + 1];
+                most = std::max(most, (size_t)B * n[l + 1] * K);
             }
+            t.B = B;
+            t.width = K;
+            hipLaunchKernelGGL(slice_rows_kernel, dim3((unsigned)std::min<size_t>(ceil_div(most, 256), 2048), L), dim3(256), 0, c->stream, t);
             PS_HIP(hipGetLastError());
         }
         if (c->deferred) {
