@@ -262,6 +262,7 @@ def main():
         from point_unet_amd.pipeline import ForwardPipeline
         pipe = ForwardPipeline(cfg, params=params, device=local_rank, lanes=args.lanes)
         contexts = pipe.contexts
+        pipe.prime(d_xyz, d_feats)  # every lane's workspace allocated before the warmup / timed steps
 
         def step(overlap=True):
             return pipe.submit(d_xyz, d_feats, overlap=overlap)

@@ -71,6 +71,13 @@ class ForwardPipeline:
         self.last_done = ln.done
         return logits
 
+    def prime(self, xyz, features):
+        """Runs one cloud through EVERY lane and drains: workspaces grow to their high-water mark (the only hipMalloc calls
+        of the library) before anything is timed or latency-sensitive."""
+        for _ in self.lanes:
+            self.submit(xyz, features, overlap=False)
+        self.synchronize()
+
     def synchronize(self):
         """Drains every lane and validates the deferred status words of the tree builds (raises PointSegError)."""
         for ln in self.lanes:
