@@ -325,6 +325,11 @@ def main():
 
     if rank == 0:
         costs = algorithmic_costs(cfg, n0, B)
+        last_dec = "dec%d" % (cfg.num_layers - 1)
+        if prof_rows and last_dec not in {r[0] for r in prof_rows}:
+            # the last decoder step runs inside the head's layer chain (csrc/rowgemm.hip: rowchain): one stage, both costs
+            costs["head"] = {k: costs["head"][k] + costs[last_dec][k] for k in ("flops", "bytes")}
+            costs[last_dec] = dict(flops=0, bytes=0)
         stages = []
         live = {name: (ms / dom_steps, launches / dom_steps) for name, ms, launches in dom_rows}
         for name, ms, launches in prof_rows:

@@ -298,9 +298,27 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
         return s;
     };
 
+    // Layer chains (rowgemm.h: rowchain) wherever the channel counts allow it -- the wide-N / narrow-C end of the network;
+    // otherwise one GEMM launch per layer.
+    auto step = [](const PackedLinear& Lr, float* y, int ldy) {
+        ChainStep st;
+        st.L = &Lr; st.y = y; st.ldy = ldy;
+        return st;
+    };
+    const int d0 = net->enc[0].d, ldf0 = d0 >= 64 ? d0 / 2 + d0 : d0 / 2;
+    bool mlp1_0_done = false;
     {
-        Stage st(c, "fc0", 1);
-        PS_TRY(rowgemm(c, net->fc0, src(features, cfg.in_channels, cfg.in_channels), none, B * n[0], fc0, 8));
+        // fc0 -> Encoder_layer_0 mlp1: fc0's rows are kept (shortcut input of the level), mlp1's go to the gather buffer
+        ChainStep ch[2] = {step(net->fc0, fc0, 8), step(net->enc[0].mlp1, fg, ldf0)};
+        const RowSrc in = src(features, cfg.in_channels, cfg.in_channels);
+        if (rowchain_fits(ch, 2, in, none)) {
+            Stage st(c, "fc0", 1);
+            PS_TRY(rowchain(c, ch, 2, in, none, B * n[0]));
+            mlp1_0_done = true;
+        } else {
+            Stage st(c, "fc0", 1);
+            PS_TRY(rowgemm(c, net->fc0, in, none, B * n[0], fc0, 8));
+        }
     }
     tap(0, fc0, B * n[0] * 8);
 
@@ -317,11 +335,19 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
         AttStage s;
         s.xyz = pyr->xyz[i]; s.idx = pyr->neigh_idx[i]; s.fg = fg; s.lfa1 = &e.lfa1; s.agg = agg;
         s.n_total = R; s.n_cloud = n[i]; s.d = d; s.k = cfg.k_n; s.ldf = ldf;
-        {
+        // f = act(x . W + b) [-> G = f . Wfc[:h]]: one chained launch when it fits
+        auto feature_rows = [&](const PackedLinear& mlp, const PackedLinear& top, const RowSrc& in) -> int {
+            ChainStep ch[2] = {step(mlp, fg, ldf), step(top, fg + h, ldf)};
+            const int nsteps = use_g ? 2 : 1;
+            if (nsteps == 2 && rowchain_fits(ch, 2, in, none)) return rowchain(c, ch, 2, in, none, R);
+            PS_TRY(rowgemm(c, mlp, in, none, R, fg, ldf));
+            if (use_g) PS_TRY(rowgemm(c, top, src(fg, ldf, h), none, R, fg + h, ldf));
+            return PS_OK;
+        };
+        if (!(i == 0 && mlp1_0_done)) {
             std::snprintf(nm, sizeof nm, "enc%d_dense", i);
-            Stage st(c, nm, use_g ? 2 : 1);
-            PS_TRY(rowgemm(c, e.mlp1, src(X, d_in, d_in), none, R, fg, ldf));
-            if (use_g) PS_TRY(rowgemm(c, e.top1, src(fg, ldf, h), none, R, fg + h, ldf));
+            Stage st(c, nm, 1);
+            PS_TRY(feature_rows(e.mlp1, e.top1, src(X, d_in, d_in)));
         }
         {
             std::snprintf(nm, sizeof nm, "enc%d_att1", i);
@@ -331,9 +357,8 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
         }
         {
             std::snprintf(nm, sizeof nm, "enc%d_dense", i);
-            Stage st(c, nm, use_g ? 2 : 1);
-            PS_TRY(rowgemm(c, e.att1mlp, src(agg, d, d), none, R, fg, ldf));
-            if (use_g) PS_TRY(rowgemm(c, e.top2, src(fg, ldf, h), none, R, fg + h, ldf));
+            Stage st(c, nm, 1);
+            PS_TRY(feature_rows(e.att1mlp, e.top2, src(agg, d, d)));
         }
         {
             std::snprintf(nm, sizeof nm, "enc%d_att2", i);
@@ -343,9 +368,17 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
         }
         {
             std::snprintf(nm, sizeof nm, "enc%d_dense", i);
-            Stage st(c, nm, 2);
-            PS_TRY(rowgemm(c, e.att2mlp, src(agg, d, d), none, R, tmp, d));
-            PS_TRY(rowgemm(c, e.mlp2sc, src(tmp, d, d), src(X, d_in, d_in), R, encb[i], 2 * d));
+            Stage st(c, nm, 1);
+            // att_pooling_2's mlp -> [mlp2 ; shortcut] over [that | X]
+            ChainStep ch[2] = {step(e.att2mlp, nullptr, 0), step(e.mlp2sc, encb[i], 2 * d)};
+            ch[1].extra = src(X, d_in, d_in);
+            const RowSrc in = src(agg, d, d);
+            if (rowchain_fits(ch, 2, in, none)) {
+                PS_TRY(rowchain(c, ch, 2, in, none, R));
+            } else {
+                PS_TRY(rowgemm(c, e.att2mlp, in, none, R, tmp, d));
+                PS_TRY(rowgemm(c, e.mlp2sc, src(tmp, d, d), src(X, d_in, d_in), R, encb[i], 2 * d));
+            }
         }
         {
             std::snprintf(nm, sizeof nm, "enc%d_pool", i);
@@ -376,6 +409,18 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
         s2.gn = (int)n[lvl + 1];
         char nm[48];
         std::snprintf(nm, sizeof nm, "dec%d", j);
+        if (j == L - 1) {
+            // last decoder step + the whole head as one chain over the level-0 rows: [skip | up] -> dec -> fc1 -> fc2 -> fc
+            ChainStep ch[4] = {step(net->dec[j], decb[j], skip_c), step(net->fc1, nullptr, 0), step(net->fc2, nullptr, 0),
+                               step(net->fc, logits, cfg.num_classes)};
+            const RowSrc s1 = src(skip, skip_c, skip_c);
+            if (rowchain_fits(ch, 4, s1, s2)) {
+                Stage st(c, "head", 1);
+                PS_TRY(rowchain(c, ch, 4, s1, s2, B * n[lvl]));
+                tap(40 + j, decb[j], B * n[lvl] * skip_c);
+                return PS_OK;
+            }
+        }
         Stage st(c, nm, 1);
         PS_TRY(rowgemm(c, net->dec[j], src(skip, skip_c, skip_c), s2, B * n[lvl], decb[j], skip_c));
         tap(40 + j, decb[j], B * n[lvl] * skip_c);

@@ -53,4 +53,20 @@ struct RowSrc {
 // y[r, 0:cout] (row stride ldy) for r in [0, R)
 int rowgemm(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc& s2, int64_t R, float* y, int ldy);
 
+// A chain of up to kChainMaxSteps dense layers evaluated per 16-row tile, the activations staying in LDS between the
+// layers: for the wide-N / narrow-C end of the network (level 0, last decoder step, head) every separate layer is a full
+// HBM round trip of [N, C] and a ~5 us dependent launch; chained, only the rows that somebody else reads are written.
+//   step k: act_k = act([act_{k-1} | extra_k] . W_k + b_k)      act_{-1} = [s1 | s2] (gather allowed, as in rowgemm)
+// All channel counts (inputs incl. extras, outputs) must be <= kChainMaxC.
+constexpr int kChainMaxC = 96;
+constexpr int kChainMaxSteps = 4;
+struct ChainStep {
+    const PackedLinear* L = nullptr;
+    float* y = nullptr;  // also store this step's output rows here (nullptr: the output only feeds the next step)
+    int ldy = 0;
+    RowSrc extra;        // extra.x != nullptr: `extra.c` channels of plain rows appended after the previous activations
+};
+bool rowchain_fits(const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2);
+int rowchain(ps_context* c, const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2, int64_t R);
+
 }  // namespace ps

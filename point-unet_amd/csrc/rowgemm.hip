@@ -13,6 +13,8 @@
 // Bound: HBM for the wide-N / narrow-C layers (level 0, decoder tail, head), fp32 MFMA for the deep layers.
 #include "rowgemm.h"
 
+#include <algorithm>
+
 #include "mfma_tile.h"
 
 namespace ps {
@@ -225,6 +227,198 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a)
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rowchain: see rowgemm.h.  One wave per 16-row tile; two LDS tiles per wave (pitch = 2 mod 32: conflict-free A-fragment
+// reads) that the layers ping-pong between.
+struct ChainArgs {
+    const float* x1; const int32_t* g1; int ld1, c1; int g1m, g1n;
+    const float* x2; const int32_t* g2; int ld2, c2; int g2m, g2n;
+    int n, R;
+    struct Lyr {
+        const float* wp; const float* bias; float* y; const float* ex;
+        int cout, ks, ntb, cblocks, leaky, ldy, ldex, cex;
+        int w_off, w_floats, b_off, b_floats;  // this layer's packed weights / bias inside the workgroup's LDS image
+    } l[kChainMaxSteps];
+    int tile_off;  // float offset of the activation tiles behind the weight image
+};
+constexpr int kChainPitch = kChainMaxC + 2;
+
+template <int NTB>
+__device__ __forceinline__ void chain_layer(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ wl,
+                                            const float* __restrict__ bl, const ChainArgs::Lyr& y, int row0, int R, int lane)
+{
+    using bfrag = typename BFrag<NTB>::type;
+    const int arow = lane & 15, ag = lane >> 4;
+    for (int cb = 0; cb < y.cblocks; ++cb) {
+        f32x4 acc[NTB];
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bfrag* wp = reinterpret_cast<const bfrag*>(wl) + (size_t)cb * y.ks * 64 + lane;  // B fragments from LDS
+#pragma unroll 4
+        for (int s = 0; s < y.ks; ++s) {
+            const float av = in[arow * kChainPitch + s * 4 + ag];
+            const bfrag bv = wp[(size_t)s * 64];
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bfrag_get<NTB>(bv, j), acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) {
+            const int col = (cb * NTB + j) * 16 + (lane & 15);
+            if (col >= y.cout) continue;
+            const float b = bl[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = ag * 4 + r;
+                float v = acc[j][r] + b;
+                if (y.leaky) v = leaky02(v);
+                out[rr * kChainPitch + col] = v;
+                if (y.y && row0 + rr < R) y.y[(size_t)(row0 + rr) * y.ldy + col] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rowchain_kernel(ChainArgs a)
+{
+    // LDS: [packed weights + biases of every layer | 4 waves x 2 activation tiles].  The weights are read once per
+    // workgroup (a few tens of KB) and serve every row tile it processes: B fragments then cost an LDS read instead of
+    // an exposed L2 round trip per k-step.
+    extern __shared__ __attribute__((aligned(16))) float chain_lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int l = 0; l < a.n; ++l) {
+        const ChainArgs::Lyr& y = a.l[l];
+        for (int i = threadIdx.x; i < y.w_floats; i += 256) chain_lds[y.w_off + i] = y.wp[i];
+        for (int i = threadIdx.x; i < y.b_floats; i += 256) chain_lds[y.b_off + i] = y.bias[i];
+    }
+    __syncthreads();
+    float* const tiles = chain_lds + a.tile_off + wave * (2 * 16 * kChainPitch);
+    for (int tile = blockIdx.x * 4 + wave; tile * 16 < a.R; tile += gridDim.x * 4) {
+        const int row0 = tile * 16;
+        float* in = tiles;
+        float* out = tiles + 16 * kChainPitch;
+        // ---- the chain's input rows: [s1 | s2], gathered ----
+        int src1 = 0, src2 = 0;
+        {
+            const int r = row0 + (lane & 15);
+            if (r < a.R) {
+                src1 = a.g1 ? (a.g1m ? (r / a.g1m) * a.g1n : 0) + a.g1[r] : r;
+                src2 = a.g2 ? (a.g2m ? (r / a.g2m) * a.g2n : 0) + a.g2[r] : r;
+            }
+        }
+        int cur = a.c1 + a.c2;
+        {
+            // eight loads in flight per lane before the first LDS store (a load-store-per-iteration loop would expose one
+            // HBM round trip per element); 16 * kc4 is a multiple of 64, so every lane is active at the shuffles
+            const int kc4 = (cur + 3) & ~3;
+            for (int e0 = 0; e0 < 16 * kc4; e0 += 8 * 64) {
+                float v[8];
+                int at[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * 64 + lane;
+                    const bool on = e < 16 * kc4;  // (wave-uniform per u)
+                    const int r = on ? e / kc4 : 0, k = on ? e - r * kc4 : 0;
+                    const int sr1 = __shfl(src1, r), sr2 = __shfl(src2, r);
+                    v[u] = 0.f;
+                    at[u] = on ? r * kChainPitch + k : -1;
+                    if (on && row0 + r < a.R && k < cur) v[u] = k < a.c1 ? a.x1[(size_t)sr1 * a.ld1 + k] : a.x2[(size_t)sr2 * a.ld2 + (k - a.c1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (at[u] >= 0) in[at[u]] = v[u];
+            }
+        }
+        for (int l = 0; l < a.n; ++l) {
+            const ChainArgs::Lyr& y = a.l[l];
+            if (y.ex) {  // appended plain-row source (+ zero padding of the K axis to a multiple of 4)
+                const int w4 = ((cur + y.cex + 3) & ~3) - cur;
+                for (int e0 = 0; e0 < 16 * w4; e0 += 8 * 64) {
+                    float v[8];
+                    int at[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int e = e0 + u * 64 + lane;
+                        const bool on = e < 16 * w4;
+                        const int r = on ? e / w4 : 0, k = on ? e - r * w4 : 0;
+                        at[u] = on ? r * kChainPitch + cur + k : -1;
+                        v[u] = (on && row0 + r < a.R && k < y.cex) ? y.ex[(size_t)(row0 + r) * y.ldex + k] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (at[u] >= 0) in[at[u]] = v[u];
+                }
+                cur += y.cex;
+            } else if (l > 0 && (cur & 3)) {
+                for (int e = lane; e < 16 * (4 - (cur & 3)); e += 64) {
+                    const int w = 4 - (cur & 3), r = e / w, k = e - r * w;
+                    in[r * kChainPitch + cur + k] = 0.f;
+                }
+            }
+            wave_lds_sync();
+            switch (y.ntb) {
+                case 1: chain_layer<1>(in, out, chain_lds + y.w_off, chain_lds + y.b_off, y, row0, a.R, lane); break;
+                case 2: chain_layer<2>(in, out, chain_lds + y.w_off, chain_lds + y.b_off, y, row0, a.R, lane); break;
+                default: chain_layer<4>(in, out, chain_lds + y.w_off, chain_lds + y.b_off, y, row0, a.R, lane); break;
+            }
+            wave_lds_sync();
+            float* t = in; in = out; out = t;
+            cur = y.cout;
+        }
+    }
+}
+
+bool rowchain_fits(const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2)
+{
+    if (n_steps < 1 || n_steps > kChainMaxSteps) return false;
+    int cur = s1.c + s2.c;
+    for (int i = 0; i < n_steps; ++i) {
+        const PackedLinear* L = steps[i].L;
+        if (!L || !L->wp) return false;
+        cur += steps[i].extra.x ? steps[i].extra.c : 0;
+        if (cur != L->cin || ((cur + 3) & ~3) > kChainMaxC || L->cout > kChainMaxC) return false;
+        if (steps[i].extra.x && steps[i].extra.gather) return false;
+        cur = L->cout;
+    }
+    return true;
+}
+
+int rowchain(ps_context* c, const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2, int64_t R)
+{
+    if (R <= 0) return PS_OK;
+    PS_CHECK(rowchain_fits(steps, n_steps, s1, s2), "rowchain: the layer chain does not fit (channels above %d or mismatched)", kChainMaxC);
+    PS_CHECK(R < (int64_t)1 << 31, "rowchain: too many rows");
+    ChainArgs a = {};
+    a.x1 = s1.x; a.g1 = s1.gather; a.ld1 = s1.ld; a.c1 = s1.c; a.g1m = s1.gm; a.g1n = s1.gn;
+    a.x2 = s2.x; a.g2 = s2.gather; a.ld2 = s2.ld; a.c2 = s2.c; a.g2m = s2.gm; a.g2n = s2.gn;
+    a.n = n_steps;
+    a.R = (int)R;
+    int off = 0;
+    for (int i = 0; i < n_steps; ++i) {
+        const PackedLinear& L = *steps[i].L;
+        ChainArgs::Lyr& y = a.l[i];
+        y.wp = L.wp; y.bias = L.bias; y.y = steps[i].y; y.ldy = steps[i].ldy;
+        y.ex = steps[i].extra.x; y.ldex = steps[i].extra.ld; y.cex = steps[i].extra.x ? steps[i].extra.c : 0;
+        y.cout = L.cout; y.ks = L.ks; y.ntb = L.ntb; y.cblocks = L.cblocks; y.leaky = L.leaky;
+        y.w_off = off; y.w_floats = (int)L.packed_floats(); off += (y.w_floats + 3) & ~3;
+        y.b_off = off; y.b_floats = L.cout_pad(); off += (y.b_floats + 3) & ~3;
+    }
+    a.tile_off = off;
+    const size_t lds_bytes = sizeof(float) * ((size_t)off + 4 * 2 * 16 * kChainPitch);
+    PS_CHECK(lds_bytes <= 160 * 1024, "rowchain: weights of the chain do not fit the LDS (%zu bytes)", lds_bytes);
+    static size_t lds_allowed = 48 * 1024;
+    if (lds_bytes > lds_allowed) {
+        PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rowchain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        lds_allowed = lds_bytes;
+    }
+    // few, long-lived workgroups: the weight image is loaded once per workgroup
+    const int tiles = (int)((R + 15) / 16);
+    const int per_cu = std::max(1, (int)(160 * 1024 / lds_bytes));
+    const int blocks = std::max(1, std::min((tiles + 3) / 4, 256 * std::min(per_cu, 4)));
+    hipLaunchKernelGGL(rowchain_kernel, dim3(blocks), dim3(256), lds_bytes, c->stream, a);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
 }
 
 void pack_weights(const float* W, int cin, int cout, int ntb, float* out)
