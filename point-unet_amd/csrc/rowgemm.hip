@@ -229,6 +229,8 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a)
     }
 }
 
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 // ---------------------------------------------------------------------------------------------------------------
 // rowchain: see rowgemm.h.  One wave per 16-row tile; two LDS tiles per wave (pitch = 2 mod 32: conflict-free A-fragment
 // reads) that the layers ping-pong between.
@@ -242,6 +244,7 @@ struct ChainArgs {
         int w_off, w_floats, b_off, b_floats;  // this layer's packed weights / bias inside the workgroup's LDS image
     } l[kChainMaxSteps];
     int tile_off;  // float offset of the activation tiles behind the weight image
+    int fast_in;   // log2(float4s per input row) when the float4 staging path applies, else 0
 };
 constexpr int kChainPitch = kChainMaxC + 2;
 
@@ -256,9 +259,20 @@ __device__ __forceinline__ void chain_layer(const float* __restrict__ in, float*
 #pragma unroll
         for (int j = 0; j < NTB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const bfrag* wp = reinterpret_cast<const bfrag*>(wl) + (size_t)cb * y.ks * 64 + lane;  // B fragments from LDS
-#pragma unroll 4
-        for (int s = 0; s < y.ks; ++s) {
-            const float av = in[arow * kChainPitch + s * 4 + ag];
+        const float* ap = in + arow * kChainPitch + ag;
+        int s = 0;
+        for (; s + 4 <= y.ks; s += 4) {  // four k-steps' operands in flight before the first MFMA needs them
+            float av[4];
+            bfrag bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { av[u] = ap[(s + u) * 4]; bv[u] = wp[(size_t)(s + u) * 64]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bfrag_get<NTB>(bv[u], j), acc[j], 0, 0, 0);
+        }
+        for (; s < y.ks; ++s) {
+            const float av = ap[s * 4];
             const bfrag bv = wp[(size_t)s * 64];
 #pragma unroll
             for (int j = 0; j < NTB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bfrag_get<NTB>(bv, j), acc[j], 0, 0, 0);
@@ -308,7 +322,35 @@ __global__ __launch_bounds__(256) void rowchain_kernel(ChainArgs a)
             }
         }
         int cur = a.c1 + a.c2;
-        {
+        if (a.fast_in) {
+            // both sources are multiples of 4 channels, 16-byte aligned rows, and a row is a power-of-two number of float4s:
+            // float4 loads, shifts instead of divisions, all of a lane's loads in flight together
+            const int q_shift = a.fast_in, qn = 1 << q_shift;  // float4s per row
+            const int c1q = a.c1 >> 2;
+            for (int f0 = 0; f0 < 16 * qn; f0 += 4 * 64) {
+                float4 v[4];
+                int at[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = f0 + u * 64 + lane;
+                    const bool on = f < 16 * qn;
+                    const int r = on ? f >> q_shift : 0, q = f & (qn - 1);
+                    const int sr1 = __shfl(src1, r), sr2 = __shfl(src2, r);
+                    at[u] = on ? r * kChainPitch + 4 * q : -1;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (on && row0 + r < a.R)
+                        v[u] = q < c1q ? *reinterpret_cast<const float4*>(a.x1 + (size_t)sr1 * a.ld1 + 4 * q)
+                                       : *reinterpret_cast<const float4*>(a.x2 + (size_t)sr2 * a.ld2 + 4 * (q - c1q));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (at[u] >= 0) {
+                        float* d = in + at[u];  // (pitch 98: rows are only 8-byte aligned)
+                        *reinterpret_cast<float2*>(d) = make_float2(v[u].x, v[u].y);
+                        *reinterpret_cast<float2*>(d + 2) = make_float2(v[u].z, v[u].w);
+                    }
+            }
+        } else {
             // eight loads in flight per lane before the first LDS store (a load-store-per-iteration loop would expose one
             // HBM round trip per element); 16 * kc4 is a multiple of 64, so every lane is active at the shuffles
             const int kc4 = (cur + 3) & ~3;
@@ -405,6 +447,14 @@ int rowchain(ps_context* c, const ChainStep* steps, int n_steps, const RowSrc& s
         y.b_off = off; y.b_floats = L.cout_pad(); off += (y.b_floats + 3) & ~3;
     }
     a.tile_off = off;
+    {
+        const int cin0 = s1.c + s2.c, q = cin0 / 4;
+        const bool pow2 = cin0 % 4 == 0 && q >= 2 && (q & (q - 1)) == 0;
+        const bool al = s1.c % 4 == 0 && s2.c % 4 == 0 && s1.ld % 4 == 0 && (s2.c == 0 || s2.ld % 4 == 0) && aligned16(s1.x) && (s2.c == 0 || aligned16(s2.x));
+        a.fast_in = 0;
+        if (pow2 && al)
+            while ((1 << a.fast_in) < q) ++a.fast_in;
+    }
     const size_t lds_bytes = sizeof(float) * ((size_t)off + 4 * 2 * 16 * kChainPitch);
     PS_CHECK(lds_bytes <= 160 * 1024, "rowchain: weights of the chain do not fit the LDS (%zu bytes)", lds_bytes);
     static size_t lds_allowed = 48 * 1024;
@@ -452,7 +502,6 @@ void pack_weights_kperm(const float* W, int cin, int cout, int ntb, float* out)
                     }
 }
 
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int rowgemm(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc& s2, int64_t R, float* y, int ldy)
 {
