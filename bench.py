@@ -198,7 +198,7 @@ def main():
                     help="forward = the headline metric (BASELINE configs[1]); train = forward+backward+Adam step (configs[2]/[3])")
     ap.add_argument("--workload", choices=["config2", "config5"], default="config2",
                     help="config2 = BASELINE configs[1] (180k BraTS-shaped, K=16); config5 = BASELINE configs[4] (262 144 points, K=32, "
-                         "4 input channels, 2 classes; features kept fp32)")
+                         "4 input channels, 2 classes; features handed over as fp16 and widened on the device, int32 indices)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="serial steps on one stream (per-cloud latency) instead of several clouds in flight on separate HIP streams "
                          "(point_unet_amd/pipeline.py)")
@@ -241,7 +241,7 @@ def main():
     params = weights.init_params(cfg, seed=2, randomize_bn=True)
 
     d_xyz = torch.from_numpy(xyz).cuda()
-    d_feats = torch.from_numpy(feats).cuda()
+    d_feats = torch.from_numpy(feats.astype(np.float16) if args.workload == "config5" else feats).cuda()  # configs[4]: fp16 feature input
     if args.no_pipeline:
         ctx = runtime.default_context(local_rank)
         ctx.set_deferred_checks(True)  # status words of the tree build are validated at ctx.synchronize()

@@ -171,6 +171,11 @@ int ps_op_conv1x1(ps_context* ctx, const float* x, const float* w, const float* 
 int ps_op_att_pool(ps_context* ctx, const float* fset, const float* wfc, int64_t R, int64_t K, int64_t d,
                    float* agg);
 
+/* Widening of binary16 features to fp32 (BASELINE configs[4]: "mixed fp16 features / int32 KNN indices" -- the reference feeds
+ * tf.float32 everywhere, runPancreas.py:110-118; a half-precision feature file is an input-format variant of this build).
+ * Network.inference accepts float16 feature tensors and calls this in front of fc0.  Device pointers. */
+int ps_op_half_to_float(ps_context* ctx, const uint16_t* in, int64_t n, float* out);
+
 /* point -> volume scatter of the class probabilities (PointSegment/testBraTS.py:83-101, 226-231):
  * volume f32[Z, Y, X, C] (the layout after the reference's np.moveaxis(volume, 1, 2)); out[z,y,x,:] = softmax(logits[j])
  * for the LAST point i on voxel xyz_origin[i] = (x,y,z) and the LAST row j with p_idx[j] == i (p_idx NULL = identity),

@@ -59,6 +59,10 @@ class Network:
                           [t.contiguous() for t in inputs["sub_idx"]], [t.contiguous() for t in inputs["interp_idx"]],
                           self.config.k_n)
         feats = inputs["features"].contiguous()
+        if feats.dtype == torch.float16:  # half-precision feature files (BASELINE configs[4]): widened on the device
+            wide = torch.empty(feats.shape, dtype=torch.float32, device=feats.device)
+            _lib.check(_lib.lib().ps_op_half_to_float(self.ctx.handle, runtime.ptr(feats), feats.numel(), runtime.ptr(wide)))
+            feats = wide
         B, n0 = feats.shape[0], feats.shape[1]
         logits = torch.empty((B, n0, self.config.num_classes), dtype=torch.float32, device=feats.device)
         _lib.check(_lib.lib().ps_randla_forward(self._h, ctypes.byref(pyr.struct), runtime.ptr(feats), runtime.ptr(logits)))

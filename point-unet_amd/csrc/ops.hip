@@ -3,6 +3,10 @@
 // materialise the [B,N,K,C] tensors exactly like the reference does; the fused production path is randla.hip.
 // All of them are gather / elementwise kernels: HBM-bound, coalesced along the channel axis.
 #include "common.h"
+
+#include <algorithm>
+
+#include <hip/hip_fp16.h>
 #include "rowgemm.h"
 
 namespace ps {
@@ -280,6 +284,25 @@ __global__ __launch_bounds__(256) void fill_volume_kernel(const float* __restric
 }
 
 }  // namespace ps
+
+namespace ps {
+__global__ void half_to_float_kernel(const __half* __restrict__ in, float* __restrict__ out, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = __half2float(in[i]);
+}
+}  // namespace ps
+
+extern "C" int ps_op_half_to_float(ps_context* c, const uint16_t* in, int64_t n, float* out)
+{
+    PS_CHECK(c && in && out && n >= 0, "ps_op_half_to_float: bad argument");
+    if (!n) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "op_half_to_float", 1);
+    hipLaunchKernelGGL(half_to_float_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                       reinterpret_cast<const __half*>(in), out, n);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
 
 extern "C" int ps_op_probs_to_volume(ps_context* c, const float* logits, int64_t n, int64_t C, const int32_t* p_idx, const int32_t* xyz_origin,
                                      int64_t total, int64_t Z, int64_t X, int64_t Y, float* volume, int32_t* scratch)

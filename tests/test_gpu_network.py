@@ -166,3 +166,24 @@ def test_block_methods_reproduce_the_fused_path(oracle):
     got = net.dilated_res_block(fc0.unsqueeze(2), pyr.xyz[0], pyr.neigh_idx[0], cfg.d_out[0], "Encoder_layer_0")
     assert tuple(got.shape) == (B, N, 1, 2 * cfg.d_out[0])
     assert np.abs(got.squeeze(2).cpu().numpy() - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+
+
+def test_half_precision_feature_input(oracle):
+    """BASELINE configs[4]: features handed over as float16 (K = 32, 4 input channels, 2 classes) are widened on the device;
+    the result equals the fp32 path fed with the same rounded values bit for bit, and the oracle within the bar."""
+    import torch
+    from oracle import randla_oracle as ro
+    from point_unet_amd import weights
+    from point_unet_amd.RandLANet import Network
+    from point_unet_amd.pyramid import build_pyramid
+    cfg, xyz, feats = netcase.small_deep(4096, seed=9, k_n=32, classes=2, mods=1)
+    f16 = feats.astype(np.float16)
+    params = weights.init_params(cfg, seed=7, randomize_bn=True)
+    net = Network(cfg, params=params)
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    got = net.inference({"pyramid": pyr, "features": torch.from_numpy(f16).cuda()}).cpu().numpy()
+    same = net.inference({"pyramid": pyr, "features": torch.from_numpy(f16.astype(np.float32)).cuda()}).cpu().numpy()
+    assert np.array_equal(got, same)
+    pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: oracle.knn_batch(s, q, k), xyz, cfg.k_n, cfg.sub_sampling_ratio)
+    want = ro.inference(params, cfg.num_layers, pts, nbr, pool, up, f16.astype(np.float32), np.float64)
+    assert np.abs(got - want).max() <= TOL
