@@ -5,7 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one cloud per GPU: ps_pyramid_build (kd-tree build, K-NN and 1-NN
-search for all 5 levels) followed by ps_randla_forward, with the cloud already resident in HBM.  Workload =
+search for all 5 levels) followed by ps_randla_forward, with the cloud already resident in HBM.  By default --lanes (3)
+clouds are in flight per GPU, each on its own HIP stream (point-unet_amd/pipeline.py, the counterpart of the reference's
+tf.data map + prefetch); every timed step still does all of its work inside the timed region, and the line also carries the
+serial per-cloud latency ("serial_ms_per_cloud").  --no-pipeline times serial steps on one stream.  Workload =
 BASELINE.json configs[1]: a 180 000-point BraTS-shaped cloud (voxel-lattice coordinates inside an ellipsoid of a
 240x240x155 grid, shuffled; 4 z-scored modalities), K=16, 5 levels (ratios 4,4,4,4,2; d_out 16..512), fp32,
 random-init weights of the reference architecture (synthetic data: no datasets/checkpoints are reachable).

@@ -3,21 +3,22 @@
 // (PointSegment/utils/nearest_neighbors/nanoflann.hpp:916-1043 divideTree / middleSplit_ / planeSplit, :1321-1343
 // computeBoundingBox; leaf_max_size 10, knn_.cxx:116).
 //
-// The recursion is replaced by a level-synchronous task queue (kernel boundaries are the only global sync):
+// The recursion is replaced by task queues over three tiers of node size (kernel boundaries are the only global sync):
 //   init kernels     points -> (x,y,z,index) records; root bounding boxes by block reduction + ordered-uint atomics
-//   level kernel     one 1024-thread workgroup per node with more than kSmall points: min/max of the three axes,
-//                    split choice, counts, then nanoflann's two Hoare sweeps reproduced in CLOSED FORM -- the i-th
-//                    misplaced element from the left swaps with the i-th misplaced element from the right, so ranks
-//                    from a block scan of two flag vectors give every swap pair; children go to the next level's
-//                    queue (or to the small queue)
-//   subtree kernel   one wave per node with <= kSmall points: the node's points live in LDS and the wave builds the
-//                    whole subtree with ballot-based ranks
+//   chunked levels   nodes above kMid points: every pass of a level (min/max, counts, two Hoare sweeps as
+//                    count -> rank -> swap, emit) is one small kernel over 2 048-record chunks spread over the chip
+//   mid kernel       nodes of kSmall+1 .. kMid points: ONE workgroup loads the node into LDS and advances level by level
+//                    over all of its live segments at once, with __syncthreads() only
+//   subtree kernel   nodes of <= kSmall points: one wave builds the whole subtree in LDS with ballot-based ranks
+//   level kernel     (stragglers / very unbalanced clouds) one workgroup per node above kMid after the chunked levels
+// nanoflann's two Hoare sweeps are reproduced in CLOSED FORM everywhere -- the i-th misplaced element from the left swaps
+// with the i-th misplaced element from the right, so ranks from scans of two flag vectors give every swap pair.
 // Node ids are position-derived (kdtree.h), so the result does not depend on scheduling.  divlow / divhigh are the
 // children's tight extents on the split axis, which the parent can compute at split time as max{v < cut-side} /
 // min{v > cut-side} (the children's bounding boxes are never needed otherwise).
 //
-// Bound: latency / L2 bandwidth of one CU for the top few levels (one workgroup per node), otherwise launch-bound;
-// HBM traffic is a few passes over 16 B per point per level.
+// Bound: launch latency for the chunked levels (~60 us per level), LDS / barrier latency below; HBM traffic is a few
+// passes over 16 B per point per chunked level plus one read and one write per LDS tier.
 #include "kdtree_build.h"
 
 #include <algorithm>
