@@ -889,6 +889,7 @@ struct HugeState {
     int32_t* nchunks;      // [kHugeLevels + 1] total chunks of the level
     int32_t* c_mL;         // [max_chunks] misplaced-left count of a chunk (current sweep)
     int32_t* c_mR;
+    int32_t* c_task[2];    // [max_chunks] task of a chunk, by level parity (written by the plan: one load instead of a search)
     int32_t cap_tasks, cap_chunks;
     int32_t levels;        // chunked levels launched by the host
 };
@@ -930,6 +931,7 @@ __device__ void huge_plan_block(const HugeState& H, int level)
             HugeTask& t = H.tasks[level & 1][i];
             t.chunk0 = c0;
             t.nchunks = nc;
+            for (int j = 0; j < nc && c0 + j < H.cap_chunks; ++j) H.c_task[level & 1][c0 + j] = i;
             for (int a = 0; a < 3; ++a) { t.mn[a] = 0xffffffffu; t.mx[a] = 0u; }
             t.lt = 0; t.le = 0; t.maxlt = 0u; t.mingt = 0xffffffffu;
         }
@@ -973,15 +975,11 @@ __device__ __forceinline__ ChunkRef find_chunk(const HugeState& H, int level, in
     r.first = 0;
     r.count = 0;
     if (c >= H.nchunks[level]) return r;
-    const int n = min(H.ntasks[level], H.cap_tasks);
-    const HugeTask* T = H.tasks[level & 1];
-    for (int i = 0; i < n; ++i)
-        if (c >= T[i].chunk0 && c < T[i].chunk0 + T[i].nchunks) {
-            r.task = i;
-            r.first = (c - T[i].chunk0) * kChunk;
-            r.count = min(kChunk, T[i].k.r - T[i].k.l - r.first);
-            return r;
-        }
+    const int i = H.c_task[level & 1][c];
+    const HugeTask& t = H.tasks[level & 1][i];
+    r.task = i;
+    r.first = (c - t.chunk0) * kChunk;
+    r.count = min(kChunk, t.k.r - t.k.l - r.first);
     return r;
 }
 
@@ -1212,13 +1210,16 @@ __global__ __launch_bounds__(256) void huge_root_kernel(const BuildTree* __restr
 {
     huge_root_block(trees, n_trees, Q, H);
 }
-__global__ __launch_bounds__(256) void huge_emit_kernel(const BuildTree* __restrict__ trees, BuildQueues Q, HugeState H, int level)
-{
-    huge_emit_block(trees, Q, H, level);
-}
+// PHASE 2 carries one extra workgroup (the last one) that records the level's nodes, routes their children and plans the
+// next level while the others count: everything it needs (extents, counts) is final after PHASE 1, and what it writes (node
+// records, queues, the next level's task / chunk tables) is read by nobody before the next level's first pass.
 template <int PHASE>
-__global__ __launch_bounds__(256) void huge_phase_kernel(const BuildTree* __restrict__ trees, HugeState H, int level)
+__global__ __launch_bounds__(256) void huge_phase_kernel(const BuildTree* __restrict__ trees, BuildQueues Q, HugeState H, int level)
 {
+    if (PHASE == 2 && blockIdx.x == gridDim.x - 1) {
+        huge_emit_block(trees, Q, H, level);
+        return;
+    }
     const int c = blockIdx.x;
     if (PHASE == 0) huge_minmax_chunk(trees, H, level, c);
     if (PHASE == 1) huge_count_chunk(trees, H, level, c);
@@ -1285,7 +1286,7 @@ void TreeSetPlan::carve(Arena& a)
         const size_t cap_tasks = tot / kHuge + T + 8, cap_chunks = tot / kChunk + cap_tasks + 8;
         add(sizeof(HugeTask) * cap_tasks * 2);
         add(sizeof(int32_t) * 2 * (kHugeLevels + 2));
-        add(sizeof(int32_t) * 2 * cap_chunks);
+        add(sizeof(int32_t) * 4 * cap_chunks);
     }
     scratch_bytes = bytes;
     d_scratch = a.take<char>(bytes);
@@ -1309,7 +1310,7 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     const size_t cap_tasks = tot / kHuge + T + 8, cap_chunks = tot / kChunk + cap_tasks + 8;
     HugeTask* d_huge = reinterpret_cast<HugeTask*>(take(sizeof(HugeTask) * cap_tasks * 2));
     int32_t* d_hcnt = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 2 * (kHugeLevels + 2)));
-    int32_t* d_cm = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 2 * cap_chunks));
+    int32_t* d_cm = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 4 * cap_chunks));
 
     // host staging lives in the plan (the caller keeps the plan alive until its final stream synchronisation)
     plan.host_blob.resize(sizeof(BuildTree) * T);
@@ -1344,6 +1345,8 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     H.nchunks = d_hcnt + (kHugeLevels + 2);
     H.c_mL = d_cm;
     H.c_mR = d_cm + cap_chunks;
+    H.c_task[0] = d_cm + 2 * cap_chunks;
+    H.c_task[1] = d_cm + 3 * cap_chunks;
     H.cap_tasks = (int32_t)cap_tasks;
     H.cap_chunks = (int32_t)cap_chunks;
 
@@ -1374,22 +1377,21 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
         hipLaunchKernelGGL(huge_root_kernel, dim3(1), dim3(256), 0, st, d_trees, (int)T, Q, H);
         for (int level = 0; level < huge_levels; ++level) {
             // nodes above kHuge points: every pass spread over the chip (see "chunked levels" above)
-            hipLaunchKernelGGL(huge_phase_kernel<0>, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_phase_kernel<1>, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_phase_kernel<2>, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_phase_kernel<3>, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_phase_kernel<4>, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_phase_kernel<5>, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_phase_kernel<6>, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_phase_kernel<4>, gc, bc, 0, st, d_trees, H, level);
-            hipLaunchKernelGGL(huge_emit_kernel, dim3(1), dim3(256), 0, st, d_trees, Q, H, level);
+            hipLaunchKernelGGL(huge_phase_kernel<0>, gc, bc, 0, st, d_trees, Q, H, level);
+            hipLaunchKernelGGL(huge_phase_kernel<1>, gc, bc, 0, st, d_trees, Q, H, level);
+            hipLaunchKernelGGL(huge_phase_kernel<2>, dim3(gc.x + 1), bc, 0, st, d_trees, Q, H, level);  // + the emit workgroup
+            hipLaunchKernelGGL(huge_phase_kernel<3>, gc, bc, 0, st, d_trees, Q, H, level);
+            hipLaunchKernelGGL(huge_phase_kernel<4>, gc, bc, 0, st, d_trees, Q, H, level);
+            hipLaunchKernelGGL(huge_phase_kernel<5>, gc, bc, 0, st, d_trees, Q, H, level);
+            hipLaunchKernelGGL(huge_phase_kernel<6>, gc, bc, 0, st, d_trees, Q, H, level);
+            hipLaunchKernelGGL(huge_phase_kernel<4>, gc, bc, 0, st, d_trees, Q, H, level);
         }
     }
     // (the level queues are indexed by the level a task was pushed FOR: chunked level L pushes for L + 1, the roots for 0)
     for (int level = huge_levels == 0 ? 0 : huge_levels; level < huge_levels + kBlindLevels; ++level)
         hipLaunchKernelGGL(build_level_kernel, dim3(grid_big), dim3(kBigThreads), 0, st, d_trees, Q, level);
     PS_TRY(launch_mid_and_subtrees(c, d_trees, Q, tot, T, small_cap, plan.first_pending_level));
-    plan.launches = 6 + kBlindLevels + 9 * huge_levels;
+    plan.launches = 6 + kBlindLevels + 8 * huge_levels;
     return PS_OK;
 }
 
