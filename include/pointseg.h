@@ -13,6 +13,8 @@
  *   ps_grid_subsample                  grid_subsampling(), .../cpp_subsampling/grid_subsampling/
  *                                      grid_subsampling.h:84-91, as bound by wrapper.cpp:58-286 and
  *                                      DataProcessing.grid_sub_sampling (helper_tool.py:123-143)
+ *   ps_volume_to_cloud                 load_volume's normalisation + convert_pc2ply's voxel -> point extraction,
+ *                                      PointSegment/utils/dataPrepareBraTS.py:33-49, 75-89
  *   ps_randla_*                        Network.inference, PointSegment/RandLANet.py:110-152, and the blocks it
  *                                      calls (:314-401) with helper_tf_util.conv2d / conv2d_transpose
  *                                      (PointSegment/helper_tf_util.py:115-250) in inference mode
@@ -126,6 +128,16 @@ int ps_pyramid_build(ps_context* ctx, const float* xyz0, int64_t B, int64_t n0, 
 int ps_grid_subsample(ps_context* ctx, const float* points, int64_t n, const float* features, int64_t fdim,
                       const int32_t* classes, int64_t ldim, float sampleDl, int64_t* M, float* out_points,
                       float* out_features, int32_t* out_classes);
+
+/* ---- volume -> point cloud ------------------------------------------------------------------------------ */
+/* First half of the reference's dataset preparation (PointSegment/utils/dataPrepareBraTS.py:33-49 itensity_normalize_one_volume,
+ * :75-89 convert_pc2ply): `volumes` f32[4, X, Y, Z] (the four MR modalities, raw intensities), optional `seg` i32[X, Y, Z].
+ * Every voxel where any z-scored modality (mean / population std of its voxels > 0, float64) is non-zero becomes a point, in
+ * x-major order: xyz f32[n,3] = index / shape, colors f32[n,4], labels i32[n] (may be NULL), xyz_origin i32[n,3] (may be
+ * NULL).  Two-call protocol like ps_grid_subsample: xyz == colors == NULL returns the count in *n; the second call takes
+ * the row capacity in *n and returns the count.  Host pointers only. */
+int ps_volume_to_cloud(ps_context* ctx, const float* volumes, const int32_t* seg, int64_t X, int64_t Y, int64_t Z, int64_t* n,
+                       float* xyz, float* colors, int32_t* labels, int32_t* xyz_origin);
 
 /* ---- RandLA-Net forward ------------------------------------------------------------------------------- */
 typedef struct {

@@ -97,3 +97,60 @@ pcls = (prng.random(500) < 0.2).astype(np.int32) * prng.integers(1, 4, 500).asty
 ref_ply.write_ply(os.path.join(HERE, "brats_example.ply"), [pxyz, pmods, pcls], ["x", "y", "z", "t1ce", "t1", "flair", "t2", "class"])
 back = ref_ply.read_ply(os.path.join(HERE, "brats_example.ply"))
 save("ply_example", xyz=pxyz, mods=pmods, cls=pcls, read_back_x=back["x"], read_back_class=back["class"])
+
+# volume -> cloud (N4): the REAL reference functions itensity_normalize_one_volume and convert_pc2ply, cut out of
+# PointSegment/utils/dataPrepareBraTS.py with ast (the module itself needs nibabel) and run on a small synthetic case with
+# their file output captured.  Only the resulting arrays are committed.
+import ast  # noqa: E402
+import pickle  # noqa: E402
+import tempfile  # noqa: E402
+
+from sklearn.neighbors import KDTree  # noqa: E402
+
+ref_src = open("/root/reference/PointSegment/utils/dataPrepareBraTS.py").read()
+tree = ast.parse(ref_src)
+wanted = {}
+for node in ast.walk(tree):
+    if isinstance(node, ast.FunctionDef) and node.name in ("itensity_normalize_one_volume", "convert_pc2ply"):
+        wanted[node.name] = ast.Module(body=[node], type_ignores=[])
+captured = {}
+tmpd = tempfile.mkdtemp()
+
+
+class _DP:
+    @staticmethod
+    def grid_sub_sampling(points, features, labels, dl):
+        return ob.ref_grid_subsample(points, features, labels.astype(np.int32), dl)
+
+
+def _write_ply(path, fields, names):
+    captured[os.path.basename(os.path.dirname(path))] = [np.asarray(f) for f in fields]
+    return True
+
+
+env = dict(np=np, os=os, pickle=pickle, KDTree=KDTree, DP=_DP, write_ply=_write_ply, out_format=".ply", sub_grid_size=0.11,
+           original_pc_folder=os.path.join(tmpd, "full"), sub_pc_folder=os.path.join(tmpd, "sub"), print=lambda *a, **k: None)
+os.makedirs(env["original_pc_folder"]); os.makedirs(env["sub_pc_folder"])
+for name in ("itensity_normalize_one_volume", "convert_pc2ply"):
+    exec(compile(wanted[name], "dataPrepareBraTS.py", "exec"), env)
+vrng = np.random.default_rng(31)
+raw = (vrng.random((4, 22, 18, 14)) * 900).astype(np.int16)   # BraTS NIfTI files hold int16 intensities: NumPy reduces them in float64
+hole = vrng.random((22, 18, 14)) < 0.45
+raw[:, hole] = 0                                      # background voxels
+raw[1, vrng.random((22, 18, 14)) < 0.1] = 0           # a modality may be zero where the others are not
+# labels constant inside every sub-sampling cell (slabs cut at multiples of the 0.11 cell size): no majority ties, whose
+# resolution the reference leaves to unordered_map iteration order (grid_subsampling.cpp:100-101)
+segv = (np.select([np.arange(22) < 5, np.arange(22) < 10, np.arange(22) < 15], [0, 1, 2], 4)[:, None, None] * np.ones((1, 18, 14), np.int64) * (~hole)).astype(np.int32)
+vol5 = np.empty((5, 22, 18, 14))
+for m in range(4):
+    vol5[m] = env["itensity_normalize_one_volume"](raw[m])
+seg3 = segv.copy(); seg3[seg3 == 4] = 3
+vol5[4] = seg3
+env["convert_pc2ply"](vol5, "case")
+full, sub = captured["full"], captured["sub"]
+origin = np.load(os.path.join(env["sub_pc_folder"], "case_xyz_origin.npy"))
+proj_idx, proj_labels = pickle.load(open(os.path.join(env["sub_pc_folder"], "case_proj.pkl"), "rb"))
+sp, sf, sl = ob.canonical_rows(sub[0], sub[1], np.asarray(sub[2]).reshape(-1, 1).astype(np.int32))
+proj_d = np.linalg.norm(full[0].astype(np.float64) - sub[0][proj_idx].astype(np.float64), axis=1)
+save("volume_to_cloud", raw=raw, seg=segv, xyz=full[0], colors=full[1], labels=full[2], xyz_origin=origin.astype(np.int32),
+     sub_grid_size=np.float32(0.11), sub_xyz=sp, sub_colors=sf, sub_labels=sl, proj_dist=proj_d)

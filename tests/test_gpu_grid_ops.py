@@ -113,3 +113,26 @@ def test_point_to_volume_scatter_matches_the_reference_loop():
     want = np.moveaxis(volume, 1, 2)
     got = point2prod(torch.from_numpy(logits).cuda(), torch.from_numpy(p_idx).cuda(), torch.from_numpy(xyz).cuda(), (Z, X, Y)).cpu().numpy()
     assert got.shape == want.shape and np.abs(got - want).max() < 1e-6
+
+
+def test_volume_to_cloud_against_the_reference_functions():
+    """tests/golden/volume_to_cloud.npz was produced by the reference's own itensity_normalize_one_volume + convert_pc2ply
+    (dataPrepareBraTS.py:33-49, 75-116, run by make_golden.py): same points in the same order, same coordinates / labels /
+    voxel indices; normalised intensities within one float32 ulp (float64 sums in a different order, then one cast); the
+    sub-cloud equal after the canonical row sort; projection distances equal (indices may differ among exact ties)."""
+    import os
+    from oracle import bindings as ob
+    from point_unet_amd.prepare import prepare_brats_volume, volume_to_cloud
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "volume_to_cloud.npz"))
+    xyz, colors, labels, origin = volume_to_cloud(g["raw"], np.where(g["seg"] == 4, 3, g["seg"]))
+    assert np.array_equal(xyz, g["xyz"]) and np.array_equal(origin, g["xyz_origin"]) and np.array_equal(labels, g["labels"])
+    assert np.abs(colors - g["colors"]).max() <= 2e-7 * np.abs(g["colors"]).max()
+    out = prepare_brats_volume(g["raw"], g["seg"], sub_grid_size=float(g["sub_grid_size"]))
+    sp, sf, sl = ob.canonical_rows(out["sub_xyz"], out["sub_colors"], out["sub_labels"].reshape(-1, 1).astype(np.int32))
+    assert np.array_equal(sp, g["sub_xyz"]) and np.array_equal(sl, g["sub_labels"])
+    assert np.abs(sf - g["sub_colors"]).max() <= 1e-6
+    d = np.linalg.norm(out["xyz"].astype(np.float64) - out["sub_xyz"][out["proj_idx"]].astype(np.float64), axis=1)
+    assert np.abs(d - g["proj_dist"]).max() <= 1e-6
+    # count-only call, missing-modality error
+    with pytest.raises(Exception, match="no voxel above zero"):
+        volume_to_cloud(np.zeros((4, 4, 4, 4), np.float32))
