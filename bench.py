@@ -206,6 +206,9 @@ def main():
                     help="serial steps on one stream (per-cloud latency) instead of several clouds in flight on separate HIP streams "
                          "(point_unet_amd/pipeline.py)")
     ap.add_argument("--lanes", type=int, default=3, help="clouds in flight per GPU (pipeline lanes, one HIP stream each)")
+    ap.add_argument("--include-pcie", action="store_true",
+                    help="every step also copies its inputs (xyz, features) from pinned host memory and its logits back: the "
+                         "PCIe-inclusive rate DESIGN.md quotes next to the headline (which keeps inputs resident in HBM)")
     ap.add_argument("--local-bn", action="store_true", help="train mode, N > 1: per-GPU BatchNorm statistics instead of statistics shared by all ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true", help="do not record hipEvents around the stages (A/B of their cost)")
@@ -267,8 +270,31 @@ def main():
         contexts = pipe.contexts
         pipe.prime(d_xyz, d_feats)  # every lane's workspace allocated before the warmup / timed steps
 
-        def step(overlap=True):
-            return pipe.submit(d_xyz, d_feats, overlap=overlap)
+        if args.include_pcie:
+            h_xyz, h_feats = torch.from_numpy(xyz).pin_memory(), torch.from_numpy(feats).pin_memory()
+            h_out = [torch.empty((B, n0, cfg.num_classes), dtype=torch.float32).pin_memory() for _ in range(args.lanes)]
+            copy_streams = [torch.cuda.Stream() for _ in range(args.lanes)]
+            d_in = [(torch.empty_like(d_xyz), torch.empty_like(d_feats)) for _ in range(args.lanes)]  # per-lane device input slots
+            state = {"i": 0}
+
+            def step(overlap=True):
+                # host -> device on the lane's copy stream, compute on the lane, device -> host behind it; nothing blocks the host
+                k = state["i"] % args.lanes
+                state["i"] += 1
+                dx, df = d_in[k]
+                with torch.cuda.stream(copy_streams[k]):  # (ordered behind this slot's previous read-back, which waited for its forward)
+                    dx.copy_(h_xyz, non_blocking=True)
+                    df.copy_(h_feats, non_blocking=True)
+                torch.cuda.current_stream().wait_stream(copy_streams[k])
+                out = pipe.submit(dx, df, overlap=overlap)
+                copy_streams[k].wait_event(pipe.last_done)
+                with torch.cuda.stream(copy_streams[k]):
+                    h_out[k].copy_(out, non_blocking=True)
+                    out.record_stream(copy_streams[k])
+                return out
+        else:
+            def step(overlap=True):
+                return pipe.submit(d_xyz, d_feats, overlap=overlap)
 
         def sync():
             pipe.synchronize()
@@ -384,7 +410,8 @@ def main():
                                                                                   cfg.k_n, B),
                        "points": n0, "k_n": cfg.k_n, "num_layers": cfg.num_layers, "batch_per_gpu": B, "sharding": "one cloud per GPU, no collective",
                        "pipeline": "serial, one stream" if args.no_pipeline else
-                       "%d clouds in flight, one HIP stream each (pyramid + forward per cloud on its stream)" % args.lanes},
+                       "%d clouds in flight, one HIP stream each (pyramid + forward per cloud on its stream)" % args.lanes,
+                       "inputs": "pinned host memory, copied per step (PCIe-inclusive)" if args.include_pcie else "resident in HBM"},
             "roofline": roofline,
             "serial_ms_per_cloud": serial_ms,
             "device_ms_per_step": round(dev_ms, 4),
