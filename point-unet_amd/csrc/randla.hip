@@ -344,7 +344,13 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
             if (use_g) PS_TRY(rowgemm(c, top, src(fg, ldf, h), none, R, fg + h, ldf));
             return PS_OK;
         };
-        if (!(i == 0 && mlp1_0_done)) {
+        if (i == 0 && mlp1_0_done) {
+            if (use_g) {  // mlp1's rows came out of the fc0 chain; the score pre-product still has to be formed
+                std::snprintf(nm, sizeof nm, "enc%d_dense", i);
+                Stage st(c, nm, 1);
+                PS_TRY(rowgemm(c, e.top1, src(fg, ldf, h), none, R, fg + h, ldf));
+            }
+        } else {
             std::snprintf(nm, sizeof nm, "enc%d_dense", i);
             Stage st(c, nm, 1);
             PS_TRY(feature_rows(e.mlp1, e.top1, src(X, d_in, d_in)));
