@@ -254,7 +254,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
 }
 
 
-// ---- direct formulation (levels with many points, d <= 128) -----------------------------------------------------
+// ---- direct formulation (wide levels: d <= 32, weights register-resident) -------------------------------------------
 // scores = [f_nb | f_xyz] . Wfc on the full d x d weight, with the gathered neighbour features staged ONCE into the
 // LDS tile (they serve both as the A operand and as the values of the weighted sum).  The pre-product formulation above
 // gathers 3 x as many bytes per neighbour ([f | G] rows); at levels 0-2 that gather traffic, not the MFMA pipe, was

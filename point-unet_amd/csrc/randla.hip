@@ -1,18 +1,18 @@
 // randla.hip -- RandLA-Net inference forward (ps_randla_*): the device form of Network.inference
 // (PointSegment/RandLANet.py:110-152) and the blocks it calls (:314-401), inference-mode BatchNorm folded.
 //
-// Launch plan per encoder level (rows R = B*N_i, h = d/2):
-//   rowgemm  mlp1            X[R,d_in]            -> FG1[:, 0:h]          (RandLANet.py:315)
-//   rowgemm  Wfc1[:h,:]      FG1[:, 0:h]          -> FG1[:, h:h+d]        (score pre-product, see attpool.hip)
-//   att<1>   LocSE+gather+att-pool 1              -> AGG[R,d]             (:325-329, :337-343, :394-398)
-//   rowgemm  att_pooling_1 mlp  AGG               -> FG2[:, 0:h]          (:400)
-//   rowgemm  Wfc2[:h,:]      FG2[:, 0:h]          -> FG2[:, h:h+d]
-//   att<2>   LocSE+mlp2+gather+att-pool 2         -> AGG[R,d]             (:331-334)
-//   rowgemm  att_pooling_2 mlp  AGG               -> TMP[R,d]             (:400)
-//   rowgemm  [mlp2 ; shortcut] [TMP | X]          -> ENC_i[R,2d]  (+LeakyReLU)   (:317-321)
-//   pool_max random_sample                        -> POOL_i[B*N_{i+1},2d] (:345-360)
-// decoder: rowgemm decoder_0 (:130-132); per level rowgemm over [skip | up[interp_idx]] (:137-141);
-// head: rowgemm fc1, fc2, fc (:146-151; dropout is the identity in inference).
+// Launch plan per encoder level (rows R = B*N_i, h = d/2); "chain" = one rowchain launch (rowgemm.h) where every channel
+// count is <= 96, otherwise one rowgemm launch per layer:
+//   chain    mlp1 [-> Wfc1[:h,:]]   X[R,d_in]        -> FG1[:, 0:h] [, FG1[:, h:h+d]]   (RandLANet.py:315; the second step is the
+//                                                       score pre-product G = f . Wfc[:h,:], only for d >= 64, see attpool.hip;
+//                                                       at level 0 mlp1 rides on fc0's chain)
+//   att<1>   LocSE+gather+att-pool 1                  -> AGG[R,d]             (:325-329, :337-343, :394-398)
+//   chain    att_pooling_1 mlp [-> Wfc2[:h,:]]  AGG   -> FG2[:, 0:h] [, FG2[:, h:h+d]]   (:400)
+//   att<2>   LocSE+mlp2+gather+att-pool 2             -> AGG[R,d]             (:331-334)
+//   chain    att_pooling_2 mlp -> [mlp2 ; shortcut] over [that | X]   -> ENC_i[R,2d]  (+LeakyReLU)   (:400, :317-321)
+//   pool_max random_sample                            -> POOL_i[B*N_{i+1},2d] (:345-360)
+// decoder: rowgemm decoder_0 (:130-132); per level rowgemm over [skip | up[interp_idx]] (:137-141); the last decoder step and
+// the head (fc1, fc2, fc, :146-151; dropout is the identity in inference) are one chain over the level-0 rows.
 #include "attpool.h"
 #include "common.h"
 #include "rowgemm.h"
