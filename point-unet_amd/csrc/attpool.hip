@@ -428,7 +428,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[rt][j][r]);
-                m = xor_max(m);
+                m = xor_max_lds(m);
                 float ssum = 0.f, num = 0.f;
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
@@ -438,8 +438,8 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
                         ssum += e;
                         num += e * A[(rt * 16 + g * 4 + r) * PA + col];
                     }
-                ssum = xor_sum(ssum);
-                num = xor_sum(num);
+                ssum = xor_sum_lds(ssum);
+                num = xor_sum_lds(num);
                 if (g == 0) a.agg[(size_t)p * D + col] = num * __frcp_rn(ssum);
             }
         }

@@ -63,16 +63,35 @@ __device__ __forceinline__ void tile_mma(const float* __restrict__ tileA, int pi
 
 __device__ __forceinline__ float leaky02(float v) { return v >= 0.f ? v : 0.2f * v; }
 
-// reductions across the four 16-lane groups (rows of a C column live in lanes l, l^16, l^32, l^48)
-__device__ __forceinline__ float xor_max(float v)
+// reductions across the four 16-lane groups (rows of a C column live in lanes l, l^16, l^32, l^48).
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane halves between two registers in one VALU
+// instruction: swapping a register with itself leaves {own value, partner's value} in the result pair (which is which
+// depends on the lane, but max and + are symmetric), so a butterfly step is one swap and one op, with no LDS round trip
+// (ds_bpermute) in the softmax's dependent chain.
+// (ds_bpermute forms: fewer issue slots; the level-0 kernels are issue-bound and measured 6 % faster with these)
+__device__ __forceinline__ float xor_max_lds(float v)
 {
     v = fmaxf(v, __shfl_xor(v, 16));
     return fmaxf(v, __shfl_xor(v, 32));
 }
-__device__ __forceinline__ float xor_sum(float v)
+__device__ __forceinline__ float xor_sum_lds(float v)
 {
     v += __shfl_xor(v, 16);
     return v + __shfl_xor(v, 32);
+}
+__device__ __forceinline__ float xor_max(float v)
+{
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float xor_sum(float v)
+{
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 }  // namespace ps
