@@ -20,6 +20,7 @@
 // Bound: launch latency for the chunked levels (~60 us per level), LDS / barrier latency below; HBM traffic is a few
 // passes over 16 B per point per chunked level plus one read and one write per LDS tier.
 #include "kdtree_build.h"
+#include "wave_ops.h"
 
 #include <algorithm>
 #include <type_traits>
@@ -103,9 +104,9 @@ __global__ __launch_bounds__(256) void init_points_kernel(const BuildTree* __res
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        for (int o = 32; o > 0; o >>= 1) {
-            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
-            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+        {
+            mn[a] = wave_min(mn[a]);
+            mx[a] = wave_max(mx[a]);
         }
         if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6][a] = mn[a]; s_mx[threadIdx.x >> 6][a] = mx[a]; }
     }
@@ -278,9 +279,9 @@ __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTre
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        for (int o = 32; o > 0; o >>= 1) {
-            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
-            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        {
+            mn[c] = wave_min(mn[c]);
+            mx[c] = wave_max(mx[c]);
         }
         if (lane == 0) { S.mn[wave][c] = mn[c]; S.mx[wave][c] = mx[c]; }
     }
@@ -311,11 +312,11 @@ __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTre
                 if (v[e] > cut) mingt = fminf(mingt, v[e]);
             }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        lt += __shfl_xor(lt, o);
-        le += __shfl_xor(le, o);
-        maxlt = fmaxf(maxlt, __shfl_xor(maxlt, o));
-        mingt = fminf(mingt, __shfl_xor(mingt, o));
+    {
+        lt = wave_sum(lt);
+        le = wave_sum(le);
+        maxlt = wave_max(maxlt);
+        mingt = wave_min(mingt);
     }
     if (lane == 0) { S.ia[wave] = lt; S.ib[wave] = le; S.fa[wave] = maxlt; S.fb[wave] = mingt; }
     __syncthreads();
@@ -442,9 +443,9 @@ __device__ __forceinline__ SubSplit split_in_lds(float4* P, int count, const flo
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-        for (int o = 32; o > 0; o >>= 1) {
-            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
-            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        {
+            mn[c] = wave_min(mn[c]);
+            mx[c] = wave_max(mx[c]);
         }
     const SplitChoice sc = choose_split(lo, hi, mn, mx);
     SubSplit r;
@@ -465,9 +466,9 @@ __device__ __forceinline__ SubSplit split_in_lds(float4* P, int count, const flo
         if (in && v[e] < cut) r.maxlt = fmaxf(r.maxlt, v[e]);
         if (in && v[e] > cut) r.mingt = fminf(r.mingt, v[e]);
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        r.maxlt = fmaxf(r.maxlt, __shfl_xor(r.maxlt, o));
-        r.mingt = fminf(r.mingt, __shfl_xor(r.mingt, o));
+    {
+        r.maxlt = wave_max(r.maxlt);
+        r.mingt = wave_min(r.mingt);
     }
     for (int sweep = 0; sweep < 2; ++sweep) {
         const int from = sweep == 0 ? 0 : r.lim1, bound = sweep == 0 ? r.lim1 : r.lim2;
@@ -703,9 +704,9 @@ __global__ __launch_bounds__(kMidThreads) void build_mid_kernel(const BuildTree*
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    for (int o = 32; o > 0; o >>= 1) {
-                        mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
-                        mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+                    {
+                        mn[c] = wave_min(mn[c]);
+                        mx[c] = wave_max(mx[c]);
                     }
                 if (lane < 3) {
                     atomicMin(&G[gi].mn[lane], f2ord(lane == 0 ? mn[0] : (lane == 1 ? mn[1] : mn[2])));
@@ -735,11 +736,11 @@ __global__ __launch_bounds__(kMidThreads) void build_mid_kernel(const BuildTree*
                         if (v > cut) mingt = fminf(mingt, v);
                     }
                 }
-                for (int o = 32; o > 0; o >>= 1) {
-                    lt += __shfl_xor(lt, o);
-                    le += __shfl_xor(le, o);
-                    maxlt = fmaxf(maxlt, __shfl_xor(maxlt, o));
-                    mingt = fminf(mingt, __shfl_xor(mingt, o));
+                {
+                    lt = wave_sum(lt);
+                    le = wave_sum(le);
+                    maxlt = wave_max(maxlt);
+                    mingt = wave_min(mingt);
                 }
                 if (lane == 0) {
                     atomicAdd(&G[gi].lt, lt);
@@ -1010,9 +1011,9 @@ __device__ __forceinline__ void huge_minmax_chunk(const BuildTree* __restrict__ 
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        for (int o = 32; o > 0; o >>= 1) {
-            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
-            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        {
+            mn[c] = wave_min(mn[c]);
+            mx[c] = wave_max(mx[c]);
         }
         if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6][c] = mn[c]; s_mx[threadIdx.x >> 6][c] = mx[c]; }
     }
@@ -1046,11 +1047,11 @@ __device__ __forceinline__ void huge_count_chunk(const BuildTree* __restrict__ t
             if (v > sc.cut) mingt = fminf(mingt, v);
         }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        lt += __shfl_xor(lt, o);
-        le += __shfl_xor(le, o);
-        maxlt = fmaxf(maxlt, __shfl_xor(maxlt, o));
-        mingt = fminf(mingt, __shfl_xor(mingt, o));
+    {
+        lt = wave_sum(lt);
+        le = wave_sum(le);
+        maxlt = wave_max(maxlt);
+        mingt = wave_min(mingt);
     }
     if ((threadIdx.x & 63) == 0) {
         s_i[threadIdx.x >> 6][0] = lt; s_i[threadIdx.x >> 6][1] = le;
@@ -1127,7 +1128,8 @@ __device__ __forceinline__ void huge_scatter_chunk(const BuildTree* __restrict__
     // ranks before this chunk = misplaced counts of the node's earlier chunks
     int pl = 0, pr = 0;
     for (int c = t.chunk0 + threadIdx.x; c < chunk; c += 256) { pl += H.c_mL[c]; pr += H.c_mR[c]; }
-    for (int o = 32; o > 0; o >>= 1) { pl += __shfl_xor(pl, o); pr += __shfl_xor(pr, o); }
+    pl = wave_sum(pl);
+    pr = wave_sum(pr);
     if (lane == 0) { s_c[wave][0] = pl; s_c[wave][1] = pr; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1166,7 +1168,7 @@ __device__ __forceinline__ void huge_swap_chunk(const BuildTree* __restrict__ tr
     const GArr<float4> a{tr.pts + t.k.l};
     int m = 0;
     for (int c = t.chunk0 + threadIdx.x; c < t.chunk0 + t.nchunks; c += 256) m += H.c_mL[c];
-    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o);
+    m = wave_sum(m);
     if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) s_m = s_c[0] + s_c[1] + s_c[2] + s_c[3];
