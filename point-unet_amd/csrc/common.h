@@ -85,6 +85,9 @@ struct ps_context {
     ps::DevBuf red_ws;       // per-block partial sums of the per-channel reductions (ops_train.hip)
     ps::DevBuf ops_ring[4];  // packed weights of ps_op_conv1x1 (same-stream calls are ordered; the ring is belt and braces)
     int ops_ring_pos = 0;
+    // per-device kernel attributes already raised by this context (dynamic LDS above the default limit)
+    bool mid_lds_attr = false;
+    size_t chain_lds_attr = 48 * 1024;
     // deferred status checks (ps_set_deferred_checks): device flags land in pinned slots, validated at ps_synchronize
     bool deferred = false;
     int32_t* h_flags = nullptr;   // pinned [8][4]

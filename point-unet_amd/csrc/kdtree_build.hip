@@ -1247,11 +1247,10 @@ constexpr int kBlindLevels = 2;  // level kernels launched blind after the chunk
 
 static int launch_mid_and_subtrees(ps_context* c, const BuildTree* d_trees, const BuildQueues& Q, size_t tot, size_t T, size_t small_cap, int pending_level)
 {
-    static bool attr_set = false;
     constexpr size_t mid_lds = sizeof(float4) * kMid + sizeof(short) * kMid;
-    if (!attr_set) {
+    if (!c->mid_lds_attr) {  // (per context = per device: function attributes do not carry over to another GPU)
         PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(build_mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds));
-        attr_set = true;
+        c->mid_lds_attr = true;
     }
     hipStream_t st = c->stream;
     const unsigned grid_mid = (unsigned)std::min<size_t>(tot / kSmall + T + 1, 1024);

@@ -457,10 +457,9 @@ int rowchain(ps_context* c, const ChainStep* steps, int n_steps, const RowSrc& s
     }
     const size_t lds_bytes = sizeof(float) * ((size_t)off + 4 * 2 * 16 * kChainPitch);
     PS_CHECK(lds_bytes <= 160 * 1024, "rowchain: weights of the chain do not fit the LDS (%zu bytes)", lds_bytes);
-    static size_t lds_allowed = 48 * 1024;
-    if (lds_bytes > lds_allowed) {
+    if (lds_bytes > c->chain_lds_attr) {  // (per context = per device)
         PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rowchain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        lds_allowed = lds_bytes;
+        c->chain_lds_attr = lds_bytes;
     }
     // few, long-lived workgroups: the weight image is loaded once per workgroup
     const int tiles = (int)((R + 15) / 16);
