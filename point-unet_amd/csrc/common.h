@@ -83,7 +83,7 @@ struct ps_context {
     ps::DevBuf stage_in;     // host<->device staging for device_ptrs == 0 calls
     ps::DevBuf stage_out;
     ps::DevBuf red_ws;       // per-block partial sums of the per-channel reductions (ops_train.hip)
-    ps::DevBuf ops_ring[4];  // packed weights of ps_op_conv1x1 (same-stream calls are ordered; the ring is belt and braces)
+    ps::DevBuf ops_ring[4];  // packed weights of ps_op_conv1x1 (a ring: consecutive calls never repack into the buffer the previous GEMM is still reading)
     int ops_ring_pos = 0;
     // per-device kernel attributes already raised by this context (dynamic LDS above the default limit)
     bool mid_lds_attr = false;

@@ -145,26 +145,6 @@ __device__ __forceinline__ void push_task(const BuildQueues& Q, const BuildTask&
     }
 }
 
-__global__ void root_tasks_kernel(const BuildTree* __restrict__ trees, int n_trees, BuildQueues Q)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_trees) return;
-    const BuildTree t = trees[i];
-    TreeMeta m;
-    m.root = 0;
-    m.depth = 0;
-    for (int a = 0; a < 3; ++a) {
-        m.lo[a] = t.n > 0 ? ord2f(t.bbox_ord[a]) : 0.f;
-        m.hi[a] = t.n > 0 ? ord2f(t.bbox_ord[3 + a]) : 0.f;
-    }
-    *t.meta = m;
-    if (t.n <= 0) return;
-    BuildTask k;
-    k.tree = i; k.l = 0; k.r = t.n; k.parent = -1; k.side = 0; k.level = 0;
-    for (int a = 0; a < 3; ++a) { k.lo[a] = m.lo[a]; k.hi[a] = m.hi[a]; }
-    push_task(Q, k, 0);
-}
-
 // ---- the split decision shared by both kernels (middleSplit_, nanoflann.hpp:966-1005) -------------------------
 struct SplitChoice {
     int ax;
