@@ -79,7 +79,13 @@ __global__ __launch_bounds__(256) void knn_kernel(const KnnJob* __restrict__ job
 {
     __shared__ float win[kWin * 5 * 256];
     const KnnJob& job = jobs[blockIdx.y];
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware order: workgroups go to the 8 XCDs round-robin, and queries are in leaf order, so workgroup b takes the
+    // (b / 8)-th block of the (b % 8)-th eighth of the queries -- every XCD's L2 then serves one contiguous eighth of the tree's
+    // leaves (plus the shared top levels) instead of all of it.
+    const int per_xcd = (((job.nq + (int)blockDim.x - 1) / (int)blockDim.x) + 7) >> 3;  // of THIS job's workgroups
+    if ((int)(blockIdx.x >> 3) >= per_xcd) return;
+    const int bx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int t = bx * blockDim.x + threadIdx.x;
     if (t >= job.nq) return;
     if (gload(job.overflow + 2) != 0) return;  // the tree builder has not finished (unbalanced cloud): the host re-runs us
     float qx, qy, qz;
@@ -123,7 +129,7 @@ __global__ void widen_kernel(const int32_t* __restrict__ in, int64_t* __restrict
 
 static int launch_knn(ps_context* c, const KnnJob* d_jobs, int n_jobs, int max_nq, int K)
 {
-    dim3 grid(ceil_div(max_nq, 256), n_jobs);
+    dim3 grid((ceil_div(max_nq, 256) + 7) & ~7, n_jobs);  // a multiple of 8: the XCD remap in the kernel covers [0, grid) exactly
     if (grid.x == 0 || n_jobs == 0) return PS_OK;
     switch (K) {
 #define PS_KCASE(k)                                                             \
