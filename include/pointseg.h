@@ -115,6 +115,10 @@ typedef struct {
     int32_t* neigh_idx[PS_MAX_LAYERS];
     int32_t* sub_idx[PS_MAX_LAYERS];
     int32_t* interp_idx[PS_MAX_LAYERS];
+    /* optional, may be NULL per layer: i32[B, n_l], a spatially coherent processing order of the layer's points -- the row of
+     * the t-th point in kd-tree leaf order.  ps_pyramid_build fills it when a buffer is given; ps_randla_forward then walks the
+     * points of the attentive-pooling kernels in that order, XCD by XCD (neighbour gathers hit the XCD's L2). */
+    int32_t* order[PS_MAX_LAYERS];
 } ps_pyramid;
 int ps_pyramid_build(ps_context* ctx, const float* xyz0, int64_t B, int64_t n0, int32_t num_layers,
                      const int32_t* ratios, int32_t K, ps_pyramid* pyr);

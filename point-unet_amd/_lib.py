@@ -26,6 +26,7 @@ class PsPyramid(ctypes.Structure):
         ("neigh_idx", c_vp * PS_MAX_LAYERS),
         ("sub_idx", c_vp * PS_MAX_LAYERS),
         ("interp_idx", c_vp * PS_MAX_LAYERS),
+        ("order", c_vp * PS_MAX_LAYERS),
     ]
 
 

@@ -9,6 +9,7 @@ namespace ps {
 struct AttStage {
     const float* xyz = nullptr;      // [n_total, 3]
     const int32_t* idx = nullptr;    // [n_total, k] cloud-local neighbour indices
+    const int32_t* order = nullptr;  // optional [n_total]: cloud-local row of the t-th point in a spatially coherent order (ps_pyramid.order)
     const float* fg = nullptr;       // [n_total, d/2 + d]: features f | G = f . Wfc[:d/2, :]
     const PackedLinear* lfa1 = nullptr;  // 10 -> d/2 (bias + folded BN, LeakyReLU)
     const PackedLinear* lfa2 = nullptr;  // d/2 -> d/2, stage 2 only (nullptr = stage 1)

@@ -21,6 +21,7 @@ namespace ps {
 struct AttArgs {
     const float* xyz;
     const int32_t* idx;
+    const int32_t* order;
     const float* fg;
     const float* w1p; const float* b1;
     const float* w2p; const float* b2;
@@ -29,6 +30,26 @@ struct AttArgs {
     float* agg;
     int n_total, n_cloud, ldf;
 };
+
+// Point iteration shared by the kernels below.  Unit u = workgroup-slot * units-per-workgroup + unit-in-workgroup walks a
+// contiguous EIGHTH of the points per XCD (workgroups go to the 8 XCDs round-robin, so workgroup b serves eighth b % 8); with
+// AttArgs::order the t-th point is the t-th in kd-tree leaf order, which makes that eighth a compact region of space: the
+// neighbour gathers (coordinates, feature rows) of an XCD then mostly hit its own L2 instead of touching the whole cloud.
+struct PointWalk {
+    int t, end, stride;
+    __device__ __forceinline__ PointWalk(int n_total, int units_per_wg, int unit_in_wg)
+    {
+        const int per_xcd = (n_total + 7) >> 3;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;  // the host launches a multiple of 8
+        t = xcd * per_xcd + slot * units_per_wg + unit_in_wg;
+        end = min(n_total, (xcd + 1) * per_xcd);
+        stride = slots * units_per_wg;
+    }
+};
+__device__ __forceinline__ int walk_point(const AttArgs& a, int t)
+{
+    return a.order ? (t / a.n_cloud) * a.n_cloud + a.order[t] : t;
+}
 
 // SPLITN = false: every wave owns a point (its own LDS tiles).  SPLITN = true (deep levels: few points, wide d):
 // the WAVES waves of a workgroup share ONE point and one pair of LDS tiles and split the output-column blocks of every
@@ -102,9 +123,10 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
             }
     };
 
-    int base = 0, base_end = a.n_cloud;  // cloud of the current point, tracked incrementally (no integer division per point)
-    for (int p = SPLITN ? blockIdx.x : blockIdx.x * WAVES + wave; p < a.n_total; p += SPLITN ? gridDim.x : gridDim.x * WAVES) {
-        while (p >= base_end) { base = base_end; base_end += a.n_cloud; }
+    PointWalk walk(a.n_total, SPLITN ? 1 : WAVES, SPLITN ? 0 : wave);
+    for (int t = walk.t; t < walk.end; t += walk.stride) {
+        const int p = walk_point(a, t);
+        const int base = (p / a.n_cloud) * a.n_cloud;
         const float cx = a.xyz[3 * (size_t)p], cy = a.xyz[3 * (size_t)p + 1], cz = a.xyz[3 * (size_t)p + 2];
         int nb[RT];
         float a0[RT], a1[RT], a2[RT];
@@ -306,9 +328,10 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
     const float* a_lane = A + (lane & 15) * PA + (lane >> 4);    // A-fragment base of this lane in the [KN x PA] tile
     const float* t_lane = T1 + (lane & 15) * PT + (lane >> 4);
 
-    int base = 0, base_end = a.n_cloud;  // cloud of the current point, tracked incrementally (no integer division per point)
-    for (int p = blockIdx.x * WAVES + wave; p < a.n_total; p += gridDim.x * WAVES) {
-        while (p >= base_end) { base = base_end; base_end += a.n_cloud; }
+    PointWalk walk(a.n_total, WAVES, wave);
+    for (int t = walk.t; t < walk.end; t += walk.stride) {
+        const int p = walk_point(a, t);
+        const int base = (p / a.n_cloud) * a.n_cloud;
         const float cx = a.xyz[3 * (size_t)p], cy = a.xyz[3 * (size_t)p + 1], cz = a.xyz[3 * (size_t)p + 2];
         int nb[RT];
         float a0[RT], a1[RT], a2[RT];
@@ -457,7 +480,7 @@ static int launch_att_direct(ps_context* c, const AttArgs& a)
     const size_t smem = per_wave * WAVES;
     auto kern = att_direct_kernel<D, STAGE, KN, WAVES>;
     if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    const int blocks = std::min(ceil_div(a.n_total, WAVES), 256 * 8);
+    const int blocks = (std::min(ceil_div(a.n_total, WAVES), 256 * 8) + 7) & ~7;  // a multiple of 8 (PointWalk)
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
     PS_HIP(hipGetLastError());
     return PS_OK;
@@ -484,7 +507,7 @@ static int launch_att(ps_context* c, const AttArgs& a)
         const size_t smem = per_wave;
         auto kern = att_kernel<D, STAGE, KN, WAVES, true>;
         if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        const int blocks = std::min(a.n_total, 256 * 16);
+        const int blocks = (std::min(a.n_total, 256 * 16) + 7) & ~7;
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
         PS_HIP(hipGetLastError());
         return PS_OK;
@@ -494,7 +517,7 @@ static int launch_att(ps_context* c, const AttArgs& a)
     const size_t smem = per_wave * WAVES;
     auto kern = att_kernel<D, STAGE, KN, WAVES, false>;
     if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    const int blocks = std::min(ceil_div(a.n_total, WAVES), 256 * 8);
+    const int blocks = (std::min(ceil_div(a.n_total, WAVES), 256 * 8) + 7) & ~7;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
     PS_HIP(hipGetLastError());
     return PS_OK;
@@ -517,7 +540,7 @@ static int dispatch_d(ps_context* c, int d, const AttArgs& a)
 int att_pool_stage(ps_context* c, const AttStage& s)
 {
     AttArgs a;
-    a.xyz = s.xyz; a.idx = s.idx; a.fg = s.fg;
+    a.xyz = s.xyz; a.idx = s.idx; a.order = s.order; a.fg = s.fg;
     a.w1p = s.lfa1->wp; a.b1 = s.lfa1->bias;
     a.w2p = s.lfa2 ? s.lfa2->wp : nullptr; a.b2 = s.lfa2 ? s.lfa2->bias : nullptr;
     a.wbp = s.wbot ? s.wbot->wp : nullptr;

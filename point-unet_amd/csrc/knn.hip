@@ -24,6 +24,7 @@ struct KnnJob {
     int32_t nq;
     int32_t* out;       // [nq, K]
     int32_t* overflow;  // set to 1 if any query overflowed the deferred-node stack
+    int32_t* order;     // optional [nq]: order[t] = row of the t-th query (self queries: the tree's leaf order, for ps_pyramid.order)
 };
 
 // Deferred-node stack of the search kernels: the kWin most recent entries of every lane live in LDS
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const KnnJob* __restrict__ job
         const float4 q = gload(job.q4 + t);
         qx = q.x; qy = q.y; qz = q.z;
         row = as_i(q.w);
+        if (job.order) gstore(job.order + t, row);
     } else {
         qx = gload(job.q3 + 3 * (size_t)t);
         qy = gload(job.q3 + 3 * (size_t)t + 1);
@@ -212,6 +214,7 @@ static int knn_batch_impl(ps_context* c, const float* support, const float* quer
         jobs[b].nq = (int32_t)n2;
         jobs[b].out = d_out32 + (size_t)b * n2 * K;
         jobs[b].overflow = plan.d_flags;
+        jobs[b].order = nullptr;
     }
     PS_TRY(c->upload_async(plan.d_jobs, jobs.data(), sizeof(KnnJob) * B));
     int32_t flag[3] = {0, 0, 0};
@@ -354,6 +357,7 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
             j.nq = (int32_t)n[l];
             j.out = pyr->neigh_idx[l] + (size_t)b * n[l] * K;
             j.overflow = plan.d_flags;
+            j.order = pyr->order[l] ? pyr->order[l] + (size_t)b * n[l] : nullptr;
             jobs.push_back(j);
             max_nq = std::max(max_nq, j.nq);
         }
@@ -367,6 +371,7 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
             j.nq = (int32_t)n[l];
             j.out = pyr->interp_idx[l] + (size_t)b * n[l];
             j.overflow = plan.d_flags;
+            j.order = nullptr;
             jobs.push_back(j);
         }
     // NOTE: jobs is pageable host memory: the copy below is synchronous w.r.t. the host buffer by the time

@@ -22,33 +22,39 @@
 namespace ps {
 
 // ---- random_sample: out[b,m,:] = max_k feature[b, pool_idx[b,m,k], :]  (RandLANet.py:345-360) ----------------
-__global__ __launch_bounds__(256) void pool_max_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx, float* __restrict__ out,
-                                                       int rows_out, int m_cloud, int n_cloud, int K, int c4 /* channels / 4 */)
+__global__ __launch_bounds__(256) void pool_max_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx, const int32_t* __restrict__ order,
+                                                       float* __restrict__ out, int rows_out, int m_cloud, int n_cloud, int K, int c4 /* channels / 4 */)
 {
-    // one thread per (output row, float4 of channels)
-    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (t >= (size_t)rows_out * c4) return;
-    const int row = (int)(t / c4), q = (int)(t - (size_t)row * c4);
-    const int base = (row / m_cloud) * n_cloud;
-    const int32_t* ix = idx + (size_t)row * K;
-    const float4* f4 = reinterpret_cast<const float4*>(feat);
-    float4 m = f4[(size_t)(base + ix[0]) * c4 + q];
-    for (int k = 1; k < K; ++k) {
-        const float4 v = f4[(size_t)(base + ix[k]) * c4 + q];
-        m.x = fmaxf(m.x, v.x);
-        m.y = fmaxf(m.y, v.y);
-        m.z = fmaxf(m.z, v.z);
-        m.w = fmaxf(m.w, v.w);
+    // one thread per (output row, float4 of channels).  Output rows are walked XCD by XCD in `order` (the kd-tree leaf order of
+    // the output level, when the pyramid carries it): the K gathered rows of neighbouring outputs overlap and stay in that XCD's L2.
+    const int per_xcd = (rows_out + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    const size_t lim = (size_t)min(rows_out, (xcd + 1) * per_xcd) * c4;
+    for (size_t t = (size_t)xcd * per_xcd * c4 + (size_t)(blockIdx.x >> 3) * 256 + threadIdx.x; t < lim; t += (size_t)(gridDim.x >> 3) * 256) {
+        const int r = (int)(t / c4), q = (int)(t - (size_t)r * c4);
+        const int row = order ? (r / m_cloud) * m_cloud + order[r] : r;
+        const int base = (row / m_cloud) * n_cloud;
+        const int32_t* ix = idx + (size_t)row * K;
+        const float4* f4 = reinterpret_cast<const float4*>(feat);
+        float4 m = f4[(size_t)(base + ix[0]) * c4 + q];
+        for (int k = 1; k < K; ++k) {
+            const float4 v = f4[(size_t)(base + ix[k]) * c4 + q];
+            m.x = fmaxf(m.x, v.x);
+            m.y = fmaxf(m.y, v.y);
+            m.z = fmaxf(m.z, v.z);
+            m.w = fmaxf(m.w, v.w);
+        }
+        reinterpret_cast<float4*>(out)[(size_t)row * c4 + q] = m;
     }
-    reinterpret_cast<float4*>(out)[t] = m;
 }
 
-int pool_max(ps_context* c, const float* feat, const int32_t* idx, float* out, int64_t B, int64_t n, int64_t m, int K, int ch)
+int pool_max(ps_context* c, const float* feat, const int32_t* idx, const int32_t* order, float* out, int64_t B, int64_t n, int64_t m, int K, int ch)
 {
     PS_CHECK(ch % 4 == 0, "pool_max: channel count %d is not a multiple of 4", ch);
     const size_t tot = (size_t)B * m * (ch / 4);
     if (!tot) return PS_OK;
-    hipLaunchKernelGGL(pool_max_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, c->stream, feat, idx, out, (int)(B * m), (int)m, (int)n, K, ch / 4);
+    const unsigned blocks = (unsigned)((std::min<size_t>(ceil_div(tot, 256), 256 * 16) + 7) & ~size_t(7));  // a multiple of 8 (XCD walk)
+    hipLaunchKernelGGL(pool_max_kernel, dim3(blocks), dim3(256), 0, c->stream, feat, idx, order, out, (int)(B * m), (int)m, (int)n, K, ch / 4);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -333,7 +339,7 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
         const int ldf = use_g ? h + d : h;
         char nm[48];
         AttStage s;
-        s.xyz = pyr->xyz[i]; s.idx = pyr->neigh_idx[i]; s.fg = fg; s.lfa1 = &e.lfa1; s.agg = agg;
+        s.xyz = pyr->xyz[i]; s.idx = pyr->neigh_idx[i]; s.order = pyr->order[i]; s.fg = fg; s.lfa1 = &e.lfa1; s.agg = agg;
         s.n_total = R; s.n_cloud = n[i]; s.d = d; s.k = cfg.k_n; s.ldf = ldf;
         // f = act(x . W + b) [-> G = f . Wfc[:h]]: one chained launch when it fits
         auto feature_rows = [&](const PackedLinear& mlp, const PackedLinear& top, const RowSrc& in) -> int {
@@ -389,7 +395,7 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
         {
             std::snprintf(nm, sizeof nm, "enc%d_pool", i);
             Stage st(c, nm, 1);
-            PS_TRY(pool_max(c, encb[i], pyr->sub_idx[i], poolb[i], B, n[i], n[i + 1], cfg.k_n, 2 * d));
+            PS_TRY(pool_max(c, encb[i], pyr->sub_idx[i], i + 1 < L ? pyr->order[i + 1] : nullptr, poolb[i], B, n[i], n[i + 1], cfg.k_n, 2 * d));
         }
         tap(10 + i, encb[i], R * 2 * d);
         tap(20 + i, poolb[i], B * n[i + 1] * 2 * d);

@@ -11,8 +11,9 @@ from . import _lib, runtime
 class Pyramid:
     """Holds the device tensors and the ps_pyramid struct that points at them."""
 
-    def __init__(self, xyz, neigh_idx, sub_idx, interp_idx, K):
+    def __init__(self, xyz, neigh_idx, sub_idx, interp_idx, K, order=None):
         self.xyz, self.neigh_idx, self.sub_idx, self.interp_idx = xyz, neigh_idx, sub_idx, interp_idx
+        self.order = order  # optional per-layer int32 [B, n_l]: kd-tree leaf order of the layer's points (ps_pyramid.order)
         L = len(xyz)
         s = _lib.PsPyramid()
         s.num_layers = L
@@ -24,6 +25,7 @@ class Pyramid:
             s.neigh_idx[i] = neigh_idx[i].data_ptr()
             s.sub_idx[i] = sub_idx[i].data_ptr()
             s.interp_idx[i] = interp_idx[i].data_ptr()
+            s.order[i] = order[i].data_ptr() if order is not None else None
         s.n[L] = sub_idx[L - 1].shape[1]
         self.struct = s
 
@@ -41,7 +43,8 @@ def alloc_pyramid(B, n0, ratios, K, device):
     nbr = [torch.empty((B, n[i], K), dtype=torch.int32, device=device) for i in range(L)]
     sub = [torch.empty((B, n[i + 1], K), dtype=torch.int32, device=device) for i in range(L)]
     up = [torch.empty((B, n[i], 1), dtype=torch.int32, device=device) for i in range(L)]
-    return Pyramid(xyz, nbr, sub, up, K)
+    order = [torch.empty((B, n[i]), dtype=torch.int32, device=device) for i in range(L)]
+    return Pyramid(xyz, nbr, sub, up, K, order)
 
 
 def build_pyramid(batch_xyz, cfg, ctx=None, out=None):
