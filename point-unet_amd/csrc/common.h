@@ -93,10 +93,12 @@ struct ps_context {
     int32_t* h_flags = nullptr;   // pinned [8][4]
     unsigned pending_mask = 0;
     int flag_slot = 0;
+    hipEvent_t flag_ev[8] = {};   // recorded behind the copy into each slot: reusing a slot waits for THAT copy, not for the stream
     std::vector<char> host_ring[8];  // host staging kept alive behind asynchronous uploads
     int ring_pos = 0;
     std::vector<char>& ring_next() { ring_pos = (ring_pos + 1) & 7; return host_ring[ring_pos]; }
-    int check_deferred();  // after a stream sync: PS_OK or PS_ESTATE with the message set
+    int check_deferred();
+    int check_flag_slot(int s);  // after a stream sync: PS_OK or PS_ESTATE with the message set
     // small host->device uploads that never stall the host: the data is copied into a pinned ring slot first
     struct PinSlot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; };
     PinSlot pin[16];

@@ -47,25 +47,34 @@ void DevBuf::release()
 
 }  // namespace ps
 
+int ps_context::check_flag_slot(int s)
+{
+    int rc = PS_OK;
+    if (pending_mask & (1u << s)) {
+        const int32_t* f = h_flags + 4 * s;
+        if (f[2] != 0) {
+            ps::set_error("deferred check: a kd-tree build needed more levels than are launched blind (very unbalanced cloud); "
+                          "results of the calls since then are invalid -- rebuild with ps_set_deferred_checks(ctx, 0)");
+            rc = PS_ESTATE;
+        } else if (f[1] != 0) {
+            ps::set_error("deferred check: kd-tree builder queue overflow (degenerate cloud)");
+            rc = PS_ESTATE;
+        } else if (f[0] != 0) {
+            ps::set_error("deferred check: kd-tree deeper than the traversal stack");
+            rc = PS_ESTATE;
+        }
+        pending_mask &= ~(1u << s);
+    }
+    return rc;
+}
+
 int ps_context::check_deferred()
 {
     int rc = PS_OK;
-    for (int s = 0; s < 8; ++s)
-        if (pending_mask & (1u << s)) {
-            const int32_t* f = h_flags + 4 * s;
-            if (f[2] != 0) {
-                ps::set_error("deferred check: a kd-tree build needed more levels than are launched blind (very unbalanced cloud); "
-                              "results of the calls since then are invalid -- rebuild with ps_set_deferred_checks(ctx, 0)");
-                rc = PS_ESTATE;
-            } else if (f[1] != 0) {
-                ps::set_error("deferred check: kd-tree builder queue overflow (degenerate cloud)");
-                rc = PS_ESTATE;
-            } else if (f[0] != 0) {
-                ps::set_error("deferred check: kd-tree deeper than the traversal stack");
-                rc = PS_ESTATE;
-            }
-        }
-    pending_mask = 0;
+    for (int s = 0; s < 8; ++s) {
+        const int r = check_flag_slot(s);
+        if (r != PS_OK) rc = r;
+    }
     return rc;
 }
 
@@ -167,6 +176,8 @@ int ps_destroy(ps_context* c)
     c->red_ws.release();
     for (auto& b : c->ops_ring) b.release();
     if (c->h_flags) (void)hipHostFree(c->h_flags);
+    for (auto& e : c->flag_ev)
+        if (e) (void)hipEventDestroy(e);
     for (auto& s : c->pin) {
         if (s.p) (void)hipHostFree(s.p);
         if (s.ev) (void)hipEventDestroy(s.ev);

@@ -407,11 +407,16 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
         if (c->deferred) {
             // no host synchronisation: the status words go to a pinned slot that ps_synchronize() validates; the host
             // tables behind the asynchronous uploads move into the context's ring so they outlive this frame
+            hipEvent_t& ev = c->flag_ev[c->flag_slot];
+            if (!ev) PS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             if (c->pending_mask & (1u << c->flag_slot)) {
-                PS_HIP(hipStreamSynchronize(c->stream));
-                PS_TRY(c->check_deferred());
+                // the slot still holds the status words of the build eight calls ago: wait for THAT copy (long done), not for
+                // the stream -- a stream synchronisation here would serialise the host with the GPU every eighth cloud
+                PS_HIP(hipEventSynchronize(ev));
+                PS_TRY(c->check_flag_slot(c->flag_slot));
             }
             PS_HIP(hipMemcpyAsync(c->h_flags + 4 * c->flag_slot, plan.d_flags, 12, hipMemcpyDeviceToHost, c->stream));
+            PS_HIP(hipEventRecord(ev, c->stream));
             c->pending_mask |= 1u << c->flag_slot;
             c->flag_slot = (c->flag_slot + 1) & 7;
             return PS_OK;  // (all host tables went through the context's pinned upload ring)
