@@ -91,6 +91,14 @@ def test_pyramid_matches_reference_loop(oracle, B):
         assert np.array_equal(pyr.neigh_idx[i].cpu().numpy(), nbr[i]), i
         assert np.array_equal(pyr.sub_idx[i].cpu().numpy(), pool[i]), i
         assert np.array_equal(pyr.interp_idx[i].cpu().numpy(), up[i]), i
+        # ps_pyramid.order: per cloud a permutation of the level's rows, spatially coherent (kd-tree leaf order): consecutive
+        # entries are much closer to each other than consecutive rows of the shuffled cloud
+        order = pyr.order[i].cpu().numpy()
+        for b in range(B):
+            assert np.array_equal(np.sort(order[b]), np.arange(pts[i].shape[1]))
+            walk = np.linalg.norm(np.diff(pts[i][b][order[b]], axis=0), axis=1).mean()
+            shuffled = np.linalg.norm(np.diff(pts[i][b], axis=0), axis=1).mean()
+            assert walk < 0.5 * shuffled, (i, b, walk, shuffled)
 
 
 def test_full_size_properties():
