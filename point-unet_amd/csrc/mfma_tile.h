@@ -47,7 +47,7 @@ __device__ __forceinline__ void tile_mma(const float* __restrict__ tileA, int pi
                                          const typename BFrag<NTB>::type* __restrict__ wp_cb, f32x4 (&acc)[RT][NTB], int lane)
 {
     const float* a0 = tileA + (lane & 15) * pitch + (lane >> 4);
-#pragma unroll 4
+#pragma unroll 8
     for (int s = 0; s < ksteps; ++s) {
         const typename BFrag<NTB>::type bv = wp_cb[(size_t)s * 64];
         float av[RT];
