@@ -7,7 +7,12 @@ owns a HIP stream, a context (workspace), a copy of the folded weights and a pyr
 finish -- ps_pyramid_build then ps_randla_forward -- on its stream; consecutive clouds go to consecutive lanes.  The
 pyramid of one cloud (latency-bound tree build and searches that fill a fraction of the chip) and the deep, few-point
 levels of its network then share the chip with the wide MFMA / HBM-bound kernels of the clouds on the other lanes.
-Nothing is copied between lanes and the host never blocks.  Results are identical to the serial path (same kernels,
+Nothing is copied between lanes and the host never blocks.
+
+Hardware queues: HIP multiplexes streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, default 4) in creation order.
+Three lanes plus the null stream fit; streams created BEFORE the lanes by somebody else (RCCL's internal streams after
+`init_process_group("nccl")`) push two lanes onto one queue, which serialises them (measured 1.72 instead of 1.31 ms/step).
+Create and prime() the pipeline first, the process group afterwards (bench.py does).  Results are identical to the serial path (same kernels,
 same order per cloud) -- tests/test_gpu_network.py::test_pipeline_matches_serial.
 """
 import torch
