@@ -34,6 +34,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The lanes need one each, next to the null stream
+# and RCCL's: 6 measured best with 4 lanes (1.23 ms/step; 4 queues / 3 lanes: 1.33; 7 or more queues get slower again).  Must be
+# in the environment before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* = fp32 vector peak
@@ -205,7 +209,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="serial steps on one stream (per-cloud latency) instead of several clouds in flight on separate HIP streams "
                          "(point_unet_amd/pipeline.py)")
-    ap.add_argument("--lanes", type=int, default=3, help="clouds in flight per GPU (pipeline lanes, one HIP stream each)")
+    ap.add_argument("--lanes", type=int, default=4, help="clouds in flight per GPU (pipeline lanes, one HIP stream each)")
     ap.add_argument("--include-pcie", action="store_true",
                     help="every step also copies its inputs (xyz, features) from pinned host memory and its logits back: the "
                          "PCIe-inclusive rate DESIGN.md quotes next to the headline (which keeps inputs resident in HBM)")

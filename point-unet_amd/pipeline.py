@@ -9,10 +9,12 @@ pyramid of one cloud (latency-bound tree build and searches that fill a fraction
 levels of its network then share the chip with the wide MFMA / HBM-bound kernels of the clouds on the other lanes.
 Nothing is copied between lanes and the host never blocks.
 
-Hardware queues: HIP multiplexes streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, default 4) in creation order.
-Three lanes plus the null stream fit; streams created BEFORE the lanes by somebody else (RCCL's internal streams after
-`init_process_group("nccl")`) push two lanes onto one queue, which serialises them (measured 1.72 instead of 1.31 ms/step).
-Create and prime() the pipeline first, the process group afterwards (bench.py does).  Results are identical to the serial path (same kernels,
+Hardware queues: HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and two lanes
+on one queue run one after the other.  With the default, three lanes plus the null stream fit (1.33 ms per 180 000-point cloud);
+GPU_MAX_HW_QUEUES=6 in the environment (before the HIP runtime starts) and four lanes measured 1.23 ms, seven or more queues
+get slower again.  Streams created BEFORE the lanes by somebody else (RCCL's internal streams after
+`init_process_group("nccl")`) shift the assignment and can put two lanes on one queue (measured 1.72 ms): create and prime()
+the pipeline first, the process group afterwards (bench.py does both).  Results are identical to the serial path (same kernels,
 same order per cloud) -- tests/test_gpu_network.py::test_pipeline_matches_serial.
 """
 import torch
@@ -34,7 +36,7 @@ class _Lane:
 
 
 class ForwardPipeline:
-    def __init__(self, config, params=None, device=0, seed=0, lanes=3):
+    def __init__(self, config, params=None, device=0, seed=0, lanes=4):
         self.cfg = config
         self.device = torch.device("cuda", device)
         if params is None:
