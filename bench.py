@@ -285,24 +285,19 @@ def main():
         if args.include_pcie:
             h_xyz, h_feats = torch.from_numpy(xyz).pin_memory(), torch.from_numpy(feats).pin_memory()
             h_out = [torch.empty((B, n0, cfg.num_classes), dtype=torch.float32).pin_memory() for _ in range(args.lanes)]
-            copy_streams = [torch.cuda.Stream() for _ in range(args.lanes)]
             d_in = [(torch.empty_like(d_xyz), torch.empty_like(d_feats)) for _ in range(args.lanes)]  # per-lane device input slots
-            state = {"i": 0}
 
             def step(overlap=True):
-                # host -> device on the lane's copy stream, compute on the lane, device -> host behind it; nothing blocks the host
-                k = state["i"] % args.lanes
-                state["i"] += 1
+                # host -> device, compute, device -> host all on the lane's own stream (no extra streams: they would compete with the
+                # lanes for hardware queues); the copies of one lane overlap the kernels of the others
+                k = pipe._i % len(pipe.lanes)
+                lane = pipe.lanes[k]
                 dx, df = d_in[k]
-                with torch.cuda.stream(copy_streams[k]):  # (ordered behind this slot's previous read-back, which waited for its forward)
+                with torch.cuda.stream(lane.stream):
                     dx.copy_(h_xyz, non_blocking=True)
                     df.copy_(h_feats, non_blocking=True)
-                torch.cuda.current_stream().wait_stream(copy_streams[k])
-                out = pipe.submit(dx, df, overlap=overlap)
-                copy_streams[k].wait_event(pipe.last_done)
-                with torch.cuda.stream(copy_streams[k]):
+                    out = pipe.submit(dx, df, overlap=overlap)
                     h_out[k].copy_(out, non_blocking=True)
-                    out.record_stream(copy_streams[k])
                 return out
         else:
             def step(overlap=True):
