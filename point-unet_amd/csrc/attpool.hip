@@ -135,7 +135,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
             nb[rt] = base + a.idx[(size_t)p * KN + rt * 16 + c16];
             const float nx = a.xyz[3 * (size_t)nb[rt]], ny = a.xyz[3 * (size_t)nb[rt] + 1], nz = a.xyz[3 * (size_t)nb[rt] + 2];
             const float rx = cx - nx, ry = cy - ny, rz = cz - nz;
-            const float dis = __fsqrt_rn(rx * rx + ry * ry + rz * rz);
+            const float dis = __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz);
             a0[rt] = g == 0 ? dis : (g == 1 ? rx : (g == 2 ? ry : rz));
             a1[rt] = g == 0 ? cx : (g == 1 ? cy : (g == 2 ? cz : nx));
             a2[rt] = g == 0 ? ny : (g == 1 ? nz : 0.f);
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
                     }
                 ssum = xor_sum(ssum);
                 num = xor_sum(num);
-                if (g == 0) a.agg[(size_t)p * D + col] = num * __frcp_rn(ssum);
+                if (g == 0) a.agg[(size_t)p * D + col] = num * __builtin_amdgcn_rcpf(ssum);
             }
         }
         phase_sync();  // T1/T2 are overwritten by the next point
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
             nb[rt] = base + a.idx[(size_t)p * KN + rt * 16 + c16];
             const float nx = a.xyz[3 * (size_t)nb[rt]], ny = a.xyz[3 * (size_t)nb[rt] + 1], nz = a.xyz[3 * (size_t)nb[rt] + 2];
             const float rx = cx - nx, ry = cy - ny, rz = cz - nz;
-            const float dis = __fsqrt_rn(rx * rx + ry * ry + rz * rz);
+            const float dis = __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz);
             a0[rt] = g == 0 ? dis : (g == 1 ? rx : (g == 2 ? ry : rz));
             a1[rt] = g == 0 ? cx : (g == 1 ? cy : (g == 2 ? cz : nx));
             a2[rt] = g == 0 ? ny : (g == 1 ? nz : 0.f);
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
                     }
                 ssum = xor_sum_lds(ssum);
                 num = xor_sum_lds(num);
-                if (g == 0) a.agg[(size_t)p * D + col] = num * __frcp_rn(ssum);
+                if (g == 0) a.agg[(size_t)p * D + col] = num * __builtin_amdgcn_rcpf(ssum);
             }
         }
         wave_lds_sync();  // the tiles are overwritten by the next point
