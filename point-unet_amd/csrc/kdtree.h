@@ -177,10 +177,12 @@ PS_HD bool knn_search_one(const TreeView& t, float qx, float qy, float qz, float
             for (int j = 0; j < kLeafMax; ++j) pv[j] = gload(t.pts + (lf_x + j < lf_y ? lf_x + j : lf_y - 1));
 #pragma unroll
             for (int j = 0; j < kLeafMax; ++j) {
-                if (lf_x + j < lf_y) {
-                    const float d = sq_dist(qx, qy, qz, pv[j].x, pv[j].y, pv[j].z);
-                    if (d < dist[K - 1]) topk_insert<K>(dist, idx, d, as_i(pv[j].w));
-                }
+                // A slot past the leaf's end gets d = FLT_MAX, which never beats the current worst.  The insertion then runs
+                // UNPREDICATED whenever any lane of the wave has a candidate: a lane whose d is not below its worst distance has
+                // no list slot with dist[s] > d, so the selects leave its list untouched -- one wave-uniform branch instead of a
+                // second layer of per-lane selects around every slot of the list.
+                const float d = lf_x + j < lf_y ? sq_dist(qx, qy, qz, pv[j].x, pv[j].y, pv[j].z) : FLT_MAX;
+                if (__ballot(d < dist[K - 1]) != 0ull) topk_insert<K>(dist, idx, d, as_i(pv[j].w));
             }
 #else
             for (int i = lf_x; i < lf_y; ++i) {
