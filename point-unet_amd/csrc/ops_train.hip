@@ -9,6 +9,8 @@
 // bit-identical; the weight-gradient GEMM and the scatter-adds use float atomics (summation order not fixed, ~1e-6).
 // Bound: every kernel here is HBM-bound (one or two passes over [rows, C]) except linear_wgrad, which is an
 // MFMA GEMM with the row axis as K.
+#include <type_traits>
+
 #include "common.h"
 #include "mfma_tile.h"
 
@@ -18,7 +20,7 @@ namespace ps {
 // Layout trick: a block covers a contiguous slab of rows; thread t handles elements t, t+T, ... of the slab; with
 // T % C == 0 its channel never changes.  (C that does not divide T falls back to per-element modulo.)
 template <class F>
-__global__ __launch_bounds__(256) void colreduce2_kernel(F f, int64_t R, int C, int rows_per_block, float* __restrict__ part0,
+__global__ __launch_bounds__(256) void colreduce2_kernel(F f, int64_t R, int C, int rows_per_block, int vec, float* __restrict__ part0,
                                                          float* __restrict__ part1)
 {
     // part{0,1}[block][c]: per-block partial sums, merged in a fixed order by colreduce_finish_kernel (no float atomics:
@@ -28,6 +30,39 @@ __global__ __launch_bounds__(256) void colreduce2_kernel(F f, int64_t R, int C, 
     const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
     const int64_t e0 = r0 * C, e1 = r1 * C;
     const bool fixed = (256 % C) == 0;
+    if (vec) {
+        // float4 path: thread t owns elements 4t..4t+3 of every 1024-element stripe of the slab, i.e. four fixed channels
+        __shared__ float v0s[1024], v1s[1024];
+        const int c = (4 * threadIdx.x) % C;
+        f.init4(c);
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+        int64_t e = e0 + 4 * threadIdx.x;
+        for (; e + 1024 < e1; e += 2048) {
+            float p0[4], p1[4], q0[4], q1[4];
+            f.load4(e, c, p0, p1);
+            f.load4(e + 1024, c, q0, q1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[j] += p0[j]; b[j] += p1[j]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[j] += q0[j]; b[j] += q1[j]; }
+        }
+        if (e < e1) {
+            float p0[4], p1[4];
+            f.load4(e, c, p0, p1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[j] += p0[j]; b[j] += p1[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v0s[4 * threadIdx.x + j] = a[j]; v1s[4 * threadIdx.x + j] = b[j]; }
+        __syncthreads();
+        for (int ch = threadIdx.x; ch < C; ch += 256) {
+            float t0 = 0.f, t1 = 0.f;
+            for (int i = ch; i < 1024; i += C) { t0 += v0s[i]; t1 += v1s[i]; }
+            part0[(size_t)blockIdx.x * C + ch] = t0;
+            if (part1) part1[(size_t)blockIdx.x * C + ch] = t1;
+        }
+        return;
+    }
     float a0 = 0.f, a1 = 0.f;
     if (fixed) {
         const int c = threadIdx.x % C;
@@ -98,7 +133,8 @@ static int colreduce2(ps_context* c, F f, int64_t R, int C, float* out0, float* 
     PS_TRY(c->red_ws.reserve(sizeof(float) * 2 * (size_t)nb * C));
     float* p0 = c->red_ws.as<float>();
     float* p1 = out1 ? p0 + (size_t)nb * C : nullptr;
-    hipLaunchKernelGGL(colreduce2_kernel<F>, dim3((unsigned)nb), dim3(256), 0, c->stream, f, R, C, rpb, p0, p1);
+    const int vec = (C & 3) == 0 && (1024 % C) == 0 && f.aligned16();
+    hipLaunchKernelGGL(colreduce2_kernel<F>, dim3((unsigned)nb), dim3(256), 0, c->stream, f, R, C, rpb, vec, p0, p1);
     hipLaunchKernelGGL(colreduce_finish_kernel, dim3((unsigned)C), dim3(64), 0, c->stream, p0, p1, nb, C, out0, out1);
     PS_HIP(hipGetLastError());
     return PS_OK;
@@ -107,10 +143,27 @@ static int colreduce2(ps_context* c, F f, int64_t R, int C, float* out0, float* 
 struct SumSq {
     const float* x;
     __device__ void operator()(int64_t e, int, float& a, float& b) const { const float v = x[e]; a = v; b = v * v; }
+    bool aligned16() const { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; }
+    __device__ void init4(int) {}
+    __device__ void load4(int64_t e, int, float (&a)[4], float (&b)[4]) const
+    {
+        const float4 v = *reinterpret_cast<const float4*>(x + e);
+        a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = a[j] * a[j];
+    }
 };
 struct SumOnly {
     const float* x;
     __device__ void operator()(int64_t e, int, float& a, float& b) const { a = x[e]; b = 0.f; }
+    bool aligned16() const { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; }
+    __device__ void init4(int) {}
+    __device__ void load4(int64_t e, int, float (&a)[4], float (&b)[4]) const
+    {
+        const float4 v = *reinterpret_cast<const float4*>(x + e);
+        a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+        b[0] = b[1] = b[2] = b[3] = 0.f;
+    }
 };
 // BatchNorm backward sums: g = dy * act'(z), z = gamma*xhat + beta;  a = sum g, b = sum g*xhat
 struct BnBwdSums {
@@ -123,6 +176,26 @@ struct BnBwdSums {
         if (leaky && gamma[c] * xh + beta[c] < 0.f) g *= 0.2f;
         a = g;
         b = g * xh;
+    }
+    float ms[4], ss[4], gm[4], bt[4];  // the thread's four channels (float4 path)
+    bool aligned16() const { return ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0; }
+    __device__ void init4(int c)
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ms[j] = mean[c + j]; ss[j] = invstd[c + j]; gm[j] = gamma[c + j]; bt[j] = beta[c + j]; }
+    }
+    __device__ void load4(int64_t e, int, float (&a)[4], float (&b)[4]) const
+    {
+        const float4 xv = *reinterpret_cast<const float4*>(x + e), gv = *reinterpret_cast<const float4*>(dy + e);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (xs[j] - ms[j]) * ss[j];
+            float g = gs[j];
+            if (leaky && gm[j] * xh + bt[j] < 0.f) g *= 0.2f;
+            a[j] = g;
+            b[j] = g * xh;
+        }
     }
 };
 
@@ -139,10 +212,34 @@ __global__ void bn_finish_stats_kernel(const float* __restrict__ sum, const floa
     invstd[c] = rsqrtf(v + eps);
 }
 
+// Elementwise BatchNorm kernels.  VEC: float4 per thread with a grid stride that is a multiple of C (1024 % C == 0), so a
+// thread's four channels never change and their parameters are loaded once.
+template <bool VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd, int64_t total, int C, int leaky,
                                                        float* __restrict__ y)
 {
+    if (VEC) {
+        const int64_t first = 4 * (blockIdx.x * (int64_t)256 + threadIdx.x);
+        const int c = (int)(first % C);
+        float sc[4], sh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sc[j] = invstd[c + j]; sh[j] = mean[c + j]; }
+        float ga[4], be[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ga[j] = gamma[c + j]; be[j] = beta[c + j]; }
+        for (int64_t e = first; e < total; e += (int64_t)gridDim.x * 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(x + e);
+            float z[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                z[j] = ga[j] * ((z[j] - sh[j]) * sc[j]) + be[j];
+                if (leaky && z[j] < 0.f) z[j] *= 0.2f;
+            }
+            *reinterpret_cast<float4*>(y + e) = float4{z[0], z[1], z[2], z[3]};
+        }
+        return;
+    }
     for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int c = (int)(e % C);
         float z = gamma[c] * ((x[e] - mean[c]) * invstd[c]) + beta[c];
@@ -151,12 +248,36 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ sg, const float* __restrict__ sgx,
                                                            int64_t total, int C, float invR, int leaky, float* __restrict__ dx)
 {
     // dx = gamma*invstd * (g - mean_r(g) - xhat*mean_r(g*xhat))
+    if (VEC) {
+        const int64_t first = 4 * (blockIdx.x * (int64_t)256 + threadIdx.x);
+        const int c = (int)(first % C);
+        float sc[4], sh[4], ga[4], be[4], mg[4], mgx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sc[j] = invstd[c + j]; sh[j] = mean[c + j]; ga[j] = gamma[c + j]; be[j] = beta[c + j];
+            mg[j] = sg[c + j] * invR; mgx[j] = sgx[c + j] * invR;
+        }
+        for (int64_t e = first; e < total; e += (int64_t)gridDim.x * 1024) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + e), gv = *reinterpret_cast<const float4*>(dy + e);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            float g[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xs[j] - sh[j]) * sc[j];
+                if (leaky && ga[j] * xh + be[j] < 0.f) g[j] *= 0.2f;
+                g[j] = ga[j] * sc[j] * (g[j] - mg[j] - xh * mgx[j]);
+            }
+            *reinterpret_cast<float4*>(dx + e) = float4{g[0], g[1], g[2], g[3]};
+        }
+        return;
+    }
     for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int c = (int)(e % C);
         const float xh = (x[e] - mean[c]) * invstd[c];
@@ -166,42 +287,155 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
-// ---- dW[cin,cout] += X^T . dY over a slab of rows; MFMA with the row axis as K -----------------------------------
-// A[i][k] = X[r0+k][c0+i], B[k][j] = dY[r0+k][n0+j]: both read straight from global (16 consecutive channels per
-// 16-lane group, 4 consecutive rows per k-step).
-template <int NTB>
-__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t R, int cin, int cout,
-                                                    int64_t rows_per_wave, float* __restrict__ dW)
+static inline bool bn_vec_ok(int64_t C, const void* a, const void* b, const void* c3)
 {
+    return (C & 3) == 0 && (1024 % C) == 0 &&
+           ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c3)) & 15) == 0;
+}
+
+// ---- dW[cin,cout] += X^T . dY over a slab of rows; MFMA with the row axis as K -----------------------------------
+// A workgroup of 4 waves owns a [(TI*WI*16) x (TJ*16)] block of dW (WI = 4/WK waves side by side along cin, each holding
+// TI x TJ accumulator tiles) and a slab of rows.  The slab goes through LDS in chunks of wg_chunk() rows: both operands are
+// read from HBM once per workgroup with full-row coalesced loads, and every A fragment feeds TJ MFMAs, every B fragment TI.
+// When the block has fewer tiles than waves (narrow layers: 10->8, 16->16 ...) the WK wave groups split the k-steps of a
+// chunk instead.  A[i][k] = X[r0+k][c0+i], B[k][j] = dY[r0+k][n0+j]; the LDS row strides are = 16 (mod 32) floats, so the
+// four rows of a k-step land on disjoint banks.  The bias gradient (column sums of dY) rides along on the staged dY chunk.
+__host__ __device__ constexpr int wg_chunk(int cols) { return cols <= 32 ? 256 : (cols <= 64 ? 128 : (cols <= 128 ? 64 : 32)); }  // ~8k staged floats
+__host__ __device__ constexpr int wg_stride(int cols) { return ((cols + 15) / 32) * 32 + 16; }
+
+// One operand's share of a chunk in flight between HBM and LDS: thread t holds items t, t+256, ... of the [CH x COLS] block
+// (an item = one float4 with VEC, one float without); 256 % (items per row) == 0, so a thread's column never changes.
+template <int COLS, int CH, bool VEC>
+struct WgStage {
+    static constexpr int Q = VEC ? COLS / 4 : COLS;
+    static constexpr int N = (CH * Q + 255) / 256;
+    using item = typename std::conditional<VEC, float4, float>::type;
+    item v[N];
+    __device__ __forceinline__ void load(const float* __restrict__ src, int ld, int c0, int w, int live, int64_t r)
+    {
+        const int q = threadIdx.x % Q;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int row = (threadIdx.x + 256 * i) / Q;
+            const bool ok = row < live && (VEC ? 4 * q : q) < w;
+            if constexpr (VEC) v[i] = ok ? *reinterpret_cast<const float4*>(src + (r + row) * ld + c0 + 4 * q) : float4{0.f, 0.f, 0.f, 0.f};
+            else v[i] = ok ? src[(r + row) * ld + c0 + q] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void store(float* dst, int stride) const
+    {
+        const int q = threadIdx.x % Q;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int row = (threadIdx.x + 256 * i) / Q;
+            if (row < CH) {
+                if constexpr (VEC) *reinterpret_cast<float4*>(dst + row * stride + 4 * q) = v[i];
+                else dst[row * stride + q] = v[i];
+            }
+        }
+    }
+};
+
+template <int TI, int TJ, int WK, bool VEC>
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t R, int cin, int cout,
+                                                    int64_t rows_per_block, float* __restrict__ dW, float* __restrict__ db)
+{
+    constexpr int WI = 4 / WK;
+    constexpr int CI = TI * WI * 16, CJ = TJ * 16;
+    constexpr int SX = wg_stride(CI), SD = wg_stride(CJ);
+    constexpr int CH = wg_chunk(CI + CJ);
+    __shared__ float xs[CH * SX], ds[CH * SD];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i16 = lane & 15, k4 = lane >> 4;
-    const int c0 = blockIdx.y * 16, n0 = blockIdx.z * (16 * NTB);
-    const int64_t w = (int64_t)blockIdx.x * 4 + wave;
-    int64_t r = w * rows_per_wave;
-    const int64_t rend = r + rows_per_wave < R ? r + rows_per_wave : R;
-    if (r >= R) return;
-    f32x4 acc[NTB];
+    const int wi = wave % WI, wk = wave / WI;
+    const int c0 = blockIdx.y * CI, n0 = blockIdx.z * CJ;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    const int wx = min(CI, cin - c0), wd = min(CJ, cout - n0);  // live columns of the two staged blocks
+    f32x4 acc[TI][TJ];
 #pragma unroll
-    for (int j = 0; j < NTB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool cok = c0 + i16 < cin;
-    for (; r < rend; r += 4) {
-        const int64_t row = r + k4;
-        const bool rok = row < rend;
-        const float a = (rok && cok) ? x[row * cin + c0 + i16] : 0.f;
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < NTB; ++j) {
-            const int n = n0 + j * 16 + i16;
-            const float b = (rok && n < cout) ? dy[row * cout + n] : 0.f;
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    WgStage<CI, CH, VEC> gx;
+    WgStage<CJ, CH, VEC> gd;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};  // column sums of the thread's dY items (its column is fixed)
+    gx.load(x, cin, c0, wx, (int)min<int64_t>(CH, r1 - r0), r0);
+    gd.load(dy, cout, n0, wd, (int)min<int64_t>(CH, r1 - r0), r0);
+    for (int64_t r = r0; r < r1; r += CH) {
+        __syncthreads();  // the previous chunk's fragments have been read
+        gx.store(xs, SX);
+        gd.store(ds, SD);
+#pragma unroll
+        for (int i = 0; i < gd.N; ++i) {
+            if constexpr (VEC) { bsum[0] += gd.v[i].x; bsum[1] += gd.v[i].y; bsum[2] += gd.v[i].z; bsum[3] += gd.v[i].w; }
+            else bsum[0] += gd.v[i];
+        }
+        __syncthreads();
+        if (r + CH < r1) {  // next chunk's loads fly while this one feeds the MFMAs
+            const int live = (int)min<int64_t>(CH, r1 - r - CH);
+            gx.load(x, cin, c0, wx, live, r + CH);
+            gd.load(dy, cout, n0, wd, live, r + CH);
+        }
+#pragma unroll
+        for (int s = wk; s < CH / 4; s += WK) {
+            float a[TI], b[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) a[i] = xs[(4 * s + k4) * SX + (wi * TI + i) * 16 + i16];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) b[j] = ds[(4 * s + k4) * SD + j * 16 + i16];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int j = 0; j < NTB; ++j)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ci = c0 + k4 * 4 + q, n = n0 + j * 16 + i16;  // C layout: row = (lane>>4)*4 + q, col = lane&15
-            if (ci < cin && n < cout) atomicAdd(&dW[(size_t)ci * cout + n], acc[j][q]);
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // C layout: row = (lane>>4)*4 + q, col = lane&15
+                const int ci = c0 + (wi * TI + i) * 16 + k4 * 4 + q, n = n0 + j * 16 + i16;
+                if (ci < cin && n < cout) atomicAdd(&dW[(size_t)ci * cout + n], acc[i][j][q]);
+            }
+    if (db != nullptr && blockIdx.y == 0) {
+        // threads sharing a column merge through LDS (the dY block is dead by now); one atomic per column and workgroup
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < (VEC ? 4 : 1); ++j) ds[threadIdx.x * (VEC ? 4 : 1) + j] = bsum[j];
+        __syncthreads();
+        if ((int)threadIdx.x < wd) {
+            constexpr int Q = gd.Q;
+            float t = 0.f;
+            if constexpr (VEC) {
+                for (int m = 0; m < 256 / Q; ++m) t += ds[((threadIdx.x >> 2) + Q * m) * 4 + (threadIdx.x & 3)];
+            } else {
+                for (int m = 0; m < 256 / Q; ++m) t += ds[threadIdx.x + Q * m];
+            }
+            atomicAdd(&db[n0 + threadIdx.x], t);
         }
+    }
+}
+
+template <int TI, int TJ, int WK>
+static void launch_wgrad(ps_context* c, const float* x, const float* dy, int64_t R, int cin, int cout, float* dW, float* db)
+{
+    constexpr int CI = TI * (4 / WK) * 16, CJ = TJ * 16;
+    constexpr int kWgChunk = wg_chunk(CI + CJ);
+    const int ty = (cin + CI - 1) / CI, tz = (cout + CJ - 1) / CJ;
+    // ~3 workgroups per CU; fewer, longer slabs when the dW block is large (every workgroup ends with CI*CJ float atomics)
+    int64_t slabs = 768 / ((int64_t)ty * tz);
+    slabs = slabs < 1 ? 1 : slabs;
+    int64_t rpb = (R + slabs - 1) / slabs;
+    rpb = ((rpb + kWgChunk - 1) / kWgChunk) * kWgChunk;
+    rpb = rpb < 4 * kWgChunk ? 4 * kWgChunk : rpb;
+    const int64_t nb = (R + rpb - 1) / rpb;
+    // float4 staging needs every row start and block origin on a 16-byte boundary (CI, CJ are multiples of 16 already)
+    const bool vec = ((cin | cout) & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+    if (vec) hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WK, true>), dim3((unsigned)nb, ty, tz), dim3(256), 0, c->stream, x, dy, R, cin, cout, rpb, dW, db);
+    else hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WK, false>), dim3((unsigned)nb, ty, tz), dim3(256), 0, c->stream, x, dy, R, cin, cout, rpb, dW, db);
 }
 
 // ---- scatter-add of gathered rows (backward of tf.batch_gather) ---------------------------------------------------
@@ -217,6 +451,8 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(const float* __restric
 }
 
 // ---- softmax over K + weighted sum (att_pooling core, RandLANet.py:396-398) --------------------------------------
+// KK > 0: K known at compile time, the K scores / features of a (row, channel) stay in registers (one pass over HBM)
+template <int KK>
 __global__ __launch_bounds__(256) void softpool_fwd_kernel(const float* __restrict__ fset, const float* __restrict__ scores, int64_t R, int K, int d,
                                                            float* __restrict__ probs, float* __restrict__ agg)
 {
@@ -226,6 +462,26 @@ __global__ __launch_bounds__(256) void softpool_fwd_kernel(const float* __restri
     const int c = (int)(t - r * d);
     const float* s = scores + r * K * d + c;
     const float* f = fset + r * K * d + c;
+    if (KK > 0) {
+        float sv[KK > 0 ? KK : 1], fv[KK > 0 ? KK : 1];
+#pragma unroll
+        for (int k = 0; k < KK; ++k) { sv[k] = s[(size_t)k * d]; fv[k] = f[(size_t)k * d]; }
+        float m = sv[0];
+#pragma unroll
+        for (int k = 1; k < KK; ++k) m = fmaxf(m, sv[k]);
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < KK; ++k) { sv[k] = expf(sv[k] - m); den += sv[k]; }
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            const float p = sv[k] / den;
+            probs[r * K * d + (size_t)k * d + c] = p;
+            a += fv[k] * p;
+        }
+        agg[t] = a;
+        return;
+    }
     float m = s[0];
     for (int k = 1; k < K; ++k) m = fmaxf(m, s[(size_t)k * d]);
     float den = 0.f;
@@ -239,6 +495,7 @@ __global__ __launch_bounds__(256) void softpool_fwd_kernel(const float* __restri
     agg[t] = a;
 }
 
+template <int KK>
 __global__ __launch_bounds__(256) void softpool_bwd_kernel(const float* __restrict__ dagg, const float* __restrict__ fset, const float* __restrict__ probs,
                                                            int64_t R, int K, int d, float* __restrict__ dfset, float* __restrict__ dscores)
 {
@@ -249,6 +506,19 @@ __global__ __launch_bounds__(256) void softpool_bwd_kernel(const float* __restri
     const size_t base = (size_t)r * K * d + c;
     const float g = dagg[t];
     float dot = 0.f;  // sum_j p_j * dp_j,  dp_j = g * f_j
+    if (KK > 0) {
+        float pv[KK > 0 ? KK : 1], fv[KK > 0 ? KK : 1];
+#pragma unroll
+        for (int k = 0; k < KK; ++k) { pv[k] = probs[base + (size_t)k * d]; fv[k] = fset[base + (size_t)k * d]; }
+#pragma unroll
+        for (int k = 0; k < KK; ++k) dot += pv[k] * g * fv[k];
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            dfset[base + (size_t)k * d] = g * pv[k];
+            dscores[base + (size_t)k * d] = pv[k] * (g * fv[k] - dot);
+        }
+        return;
+    }
     for (int k = 0; k < K; ++k) dot += probs[base + (size_t)k * d] * g * fset[base + (size_t)k * d];
     for (int k = 0; k < K; ++k) {
         const float p = probs[base + (size_t)k * d], f = fset[base + (size_t)k * d];
@@ -373,22 +643,33 @@ int ps_op_linear_wgrad(ps_context* c, const float* x, const float* dy, int64_t R
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_wgrad", 2);
     PS_HIP(hipMemsetAsync(dW, 0, sizeof(float) * cin * cout, c->stream));
+    if (db) PS_HIP(hipMemsetAsync(db, 0, sizeof(float) * cout, c->stream));
     if (R > 0) {
-        const int ntb = cout >= 64 ? 4 : (cout >= 32 ? 2 : 1);
-        const int ty = (int)((cin + 15) / 16), tz = (int)((cout + 16 * ntb - 1) / (16 * ntb));
-        int64_t waves = 4096 / ((int64_t)ty * tz);
-        waves = waves < 4 ? 4 : waves;
-        int64_t rpw = (R + waves - 1) / waves;
-        rpw = (rpw + 3) & ~int64_t(3);
-        rpw = rpw < 64 ? 64 : rpw;
-        const int64_t nw = (R + rpw - 1) / rpw;
-        dim3 grid((unsigned)((nw + 3) / 4), ty, tz);
-        if (ntb == 4) hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), 0, c->stream, x, dy, R, (int)cin, (int)cout, rpw, dW);
-        else if (ntb == 2) hipLaunchKernelGGL(wgrad_kernel<2>, grid, dim3(256), 0, c->stream, x, dy, R, (int)cin, (int)cout, rpw, dW);
-        else hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, c->stream, x, dy, R, (int)cin, (int)cout, rpw, dW);
+        const int ti = (int)((cin + 15) / 16), tj = (int)((cout + 15) / 16);
+        const int ci = (int)cin, co = (int)cout;
+        // per-wave tile block TI x TJ and the number of wave groups splitting the k-steps (WK); see wgrad_kernel
+#define PS_WG(TI, TJ, WK) launch_wgrad<TI, TJ, WK>(c, x, dy, R, ci, co, dW, db)
+        if (tj >= 8) {
+            if (ti >= 8) PS_WG(2, 8, 1);
+            else if (ti >= 3) PS_WG(1, 8, 1);
+            else if (ti == 2) PS_WG(1, 8, 2);
+            else PS_WG(1, 8, 4);
+        } else if (tj >= 3) {
+            if (ti >= 3) PS_WG(1, 4, 1);
+            else if (ti == 2) PS_WG(1, 4, 2);
+            else PS_WG(1, 4, 4);
+        } else if (tj == 2) {
+            if (ti >= 3) PS_WG(1, 2, 1);
+            else if (ti == 2) PS_WG(1, 2, 2);
+            else PS_WG(1, 2, 4);
+        } else {
+            if (ti >= 3) PS_WG(1, 1, 1);
+            else if (ti == 2) PS_WG(1, 1, 2);
+            else PS_WG(1, 1, 4);
+        }
+#undef PS_WG
         PS_HIP(hipGetLastError());
     }
-    if (db) PS_TRY(colreduce2(c, SumOnly{dy}, R, (int)cout, db, nullptr));
     return PS_OK;
 }
 
@@ -401,7 +682,10 @@ int ps_op_bn_train_fwd(ps_context* c, const float* x, const float* gamma, const 
     Stage st(c, "train_bn_fwd", 3);
     PS_TRY(colreduce2(c, SumSq{x}, R, (int)C, scratch2C, scratch2C + C));
     hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, c->stream, scratch2C, scratch2C + C, R, (int)C, eps, mean, invstd, var);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y);
+    if (bn_vec_ok(C, x, y, x))
+        hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(ew_grid(R * C / 4)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -414,8 +698,12 @@ int ps_op_bn_train_bwd(ps_context* c, const float* dy, const float* x, const flo
     Stage st(c, "train_bn_bwd", 2);
     // dbeta = sum g, dgamma = sum g*xhat
     PS_TRY(colreduce2(c, BnBwdSums{dy, x, gamma, beta, mean, invstd, leaky}, R, (int)C, dbeta, dgamma));
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, dy, x, gamma, beta, mean, invstd, dbeta, dgamma, R * C, (int)C,
-                       1.0f / (float)R, leaky, dx);
+    if (bn_vec_ok(C, x, dy, dx))
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(R * C / 4)), dim3(256), 0, c->stream, dy, x, gamma, beta, mean, invstd, dbeta, dgamma,
+                           R * C, (int)C, 1.0f / (float)R, leaky, dx);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, dy, x, gamma, beta, mean, invstd, dbeta, dgamma,
+                           R * C, (int)C, 1.0f / (float)R, leaky, dx);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -441,7 +729,10 @@ int ps_op_bn_train_apply(ps_context* c, const float* x, const float* gamma, cons
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_bn_fwd", 2);
     hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, c->stream, sums2C, sums2C + C, R_total, (int)C, eps, mean, invstd, var);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y);
+    if (bn_vec_ok(C, x, y, x))
+        hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(ew_grid(R * C / 4)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -464,8 +755,12 @@ int ps_op_bn_train_bwd_apply(ps_context* c, const float* dy, const float* x, con
     PS_CHECK(R >= 1 && C >= 1 && R_total >= R, "ps_op_bn_train_bwd_apply: bad row counts");
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_bn_bwd", 1);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, dy, x, gamma, beta, mean, invstd, sum_g, sum_gx, R * C, (int)C,
-                       1.0f / (float)R_total, leaky, dx);
+    if (bn_vec_ok(C, x, dy, dx))
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(R * C / 4)), dim3(256), 0, c->stream, dy, x, gamma, beta, mean, invstd, sum_g, sum_gx,
+                           R * C, (int)C, 1.0f / (float)R_total, leaky, dx);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, dy, x, gamma, beta, mean, invstd, sum_g, sum_gx,
+                           R * C, (int)C, 1.0f / (float)R_total, leaky, dx);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -488,7 +783,10 @@ int ps_op_softmax_pool_fwd(ps_context* c, const float* fset, const float* scores
     if (!R) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_softpool_fwd", 1);
-    hipLaunchKernelGGL(softpool_fwd_kernel, dim3(ceil_div(R * d, 256)), dim3(256), 0, c->stream, fset, scores, R, (int)K, (int)d, probs, agg);
+    const dim3 grid(ceil_div(R * d, 256));
+    if (K == 16) hipLaunchKernelGGL(softpool_fwd_kernel<16>, grid, dim3(256), 0, c->stream, fset, scores, R, (int)K, (int)d, probs, agg);
+    else if (K == 32) hipLaunchKernelGGL(softpool_fwd_kernel<32>, grid, dim3(256), 0, c->stream, fset, scores, R, (int)K, (int)d, probs, agg);
+    else hipLaunchKernelGGL(softpool_fwd_kernel<0>, grid, dim3(256), 0, c->stream, fset, scores, R, (int)K, (int)d, probs, agg);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -500,7 +798,10 @@ int ps_op_softmax_pool_bwd(ps_context* c, const float* dagg, const float* fset, 
     if (!R) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_softpool_bwd", 1);
-    hipLaunchKernelGGL(softpool_bwd_kernel, dim3(ceil_div(R * d, 256)), dim3(256), 0, c->stream, dagg, fset, probs, R, (int)K, (int)d, dfset, dscores);
+    const dim3 grid(ceil_div(R * d, 256));
+    if (K == 16) hipLaunchKernelGGL(softpool_bwd_kernel<16>, grid, dim3(256), 0, c->stream, dagg, fset, probs, R, (int)K, (int)d, dfset, dscores);
+    else if (K == 32) hipLaunchKernelGGL(softpool_bwd_kernel<32>, grid, dim3(256), 0, c->stream, dagg, fset, probs, R, (int)K, (int)d, dfset, dscores);
+    else hipLaunchKernelGGL(softpool_bwd_kernel<0>, grid, dim3(256), 0, c->stream, dagg, fset, probs, R, (int)K, (int)d, dfset, dscores);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }

@@ -31,7 +31,9 @@ def _setup(cfg, xyz, feats, seed=3, lr=1e-3, keep_prob=1.0, labels=None, sync_bn
 
 
 def syncbn_case():
-    cfg, xyz, feats = netcase.small_deep(3000, seed=8, B=2)
+    # 12000 points: the deepest level still has more points (23) than K, so no BatchNorm column is constant over its rows
+    # (a constant column puts every row of it exactly on the leaky-ReLU kink, where the summation order decides the branch)
+    cfg, xyz, feats = netcase.small_deep(12000, seed=8, B=2)
     cfg.d_out = [16, 32, 64, 32, 16]
     return cfg, xyz, feats
 
@@ -68,12 +70,15 @@ def test_sync_bn_two_ranks_equal_one_rank_batch_two(tmp_path):
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-2000:] for l in logs)
     got = [np.load(out + ".rank%d.npz" % r) for r in range(2)]
     gscale = np.abs(want_grad).max()
-    # every rank holds the same averaged gradient and takes the same Adam step.  Bar: 3e-3 of the gradient scale -- the two runs
-    # sum the statistics in a different order (per-rank partials first), which moves a handful of activations that sit within
-    # an ulp of a leaky-ReLU kink to the other side (a discontinuity of the gradient, measured at 2e-4..1e-3 here); a wrong row
-    # count or a missing reduction would show up at 1e-1
+    # every rank holds the same averaged gradient and takes the same Adam step.  The two runs sum the statistics in a different
+    # order (per-rank partials first), which moves a handful of activations that sit within an ulp of a leaky-ReLU kink to the
+    # other side -- a discontinuity of the gradient: single entries move by 2e-4..5e-3 of the gradient scale depending on which
+    # activations happen to sit on a kink.  So the bar is on the whole vector (relative L2 <= 2e-3) with a loose cap on single
+    # entries (2e-2 of the scale); a wrong row count or a missing reduction shows up at 1e-1 in both.
     for g in got:
-        assert np.abs(g["grad"] - want_grad).max() <= 3e-3 * gscale, np.abs(g["grad"] - want_grad).max() / gscale
+        diff = g["grad"] - want_grad
+        assert np.linalg.norm(diff) <= 2e-3 * np.linalg.norm(want_grad), np.linalg.norm(diff) / np.linalg.norm(want_grad)
+        assert np.abs(diff).max() <= 2e-2 * gscale, np.abs(diff).max() / gscale
     assert np.array_equal(got[0]["grad"], got[1]["grad"]) and np.array_equal(got[0]["flat"], got[1]["flat"])
     assert abs(0.5 * (float(got[0]["loss"]) + float(got[1]["loss"])) - want_loss) <= 1e-5 * max(1.0, abs(want_loss))
     big = np.abs(want_grad) > 5e-2 * gscale  # Adam normalises rounding-noise gradients to O(lr): compare where g is signal
