@@ -57,6 +57,14 @@ class Tape:
         else:
             self.grads[k] = g
 
+    def accum_buffer(self, t):
+        """The gradient buffer of t for ops that ADD into their output (scatter-add, max-pool backward): the one already
+        recorded, or a fresh zero tensor that becomes it -- no temporary, no axpy."""
+        k = id(t)
+        if k not in self.grads:
+            self.grads[k] = torch.zeros_like(t)
+        return self.grads[k]
+
     def backward(self, out, dout):
         self.grads[id(out)] = dout
         for t, bw in reversed(self.ops):
@@ -77,9 +85,12 @@ class Tape:
 
         def bw(dy):
             dy = dy.contiguous()
-            dW = torch.empty((cin, cout), dtype=torch.float32, device=x.device)
-            _lib.check(self.L.ps_op_linear_wgrad(self.h, _p(x), _p(dy), R, cin, cout, _p(dW), _p(gb) if gb is not None else None))
-            gW.copy_(dW.t() if transposed else dW)
+            if transposed or not gW.is_contiguous():
+                dW = torch.empty((cin, cout), dtype=torch.float32, device=x.device)
+                _lib.check(self.L.ps_op_linear_wgrad(self.h, _p(x), _p(dy), R, cin, cout, _p(dW), _p(gb) if gb is not None else None))
+                gW.copy_(dW.t() if transposed else dW)
+            else:  # straight into the parameter's slice of the flat gradient buffer
+                _lib.check(self.L.ps_op_linear_wgrad(self.h, _p(x), _p(dy), R, cin, cout, _p(gW), _p(gb) if gb is not None else None))
             if x.requires_grad_flag:
                 dx = torch.empty((R, cin), dtype=torch.float32, device=x.device)
                 Wt = Wm.t().contiguous()
@@ -138,9 +149,7 @@ class Tape:
         _lib.check(self.L.ps_op_gather_neighbour(self.h, _p(x), _p(idx), B, N, M, K, d, _p(out)))
 
         def bw(dy):
-            dx = torch.zeros_like(x)
-            _lib.check(self.L.ps_op_scatter_add_rows(self.h, _p(dy.contiguous()), _p(idx), B, N, M * K, d, _p(dx)))
-            self.accum(x, dx)
+            _lib.check(self.L.ps_op_scatter_add_rows(self.h, _p(dy.contiguous()), _p(idx), B, N, M * K, d, _p(self.accum_buffer(x))))
 
         out.requires_grad_flag = True
         self.ops.append((out, bw))
@@ -185,9 +194,8 @@ class Tape:
         _lib.check(self.L.ps_op_random_sample(self.h, _p(x), _p(pool_idx), B, N, M, K, d, _p(out)))
 
         def bw(dy):
-            dx = torch.zeros_like(x)
-            _lib.check(self.L.ps_op_random_sample_bwd(self.h, _p(dy.contiguous()), _p(out), _p(x), _p(pool_idx), B, N, M, K, d, _p(dx)))
-            self.accum(x, dx)
+            _lib.check(self.L.ps_op_random_sample_bwd(self.h, _p(dy.contiguous()), _p(out), _p(x), _p(pool_idx), B, N, M, K, d,
+                                                      _p(self.accum_buffer(x))))
 
         out.requires_grad_flag = True
         self.ops.append((out, bw))
