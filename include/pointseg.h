@@ -230,6 +230,34 @@ int ps_op_bn_train_bwd_apply(ps_context* ctx, const float* dy, const float* x, c
 /* backward of gather_neighbour / nearest_interpolation: dpc[b*N + idx[row], :] += drows[row, :] */
 int ps_op_scatter_add_rows(ps_context* ctx, const float* drows, const int32_t* idx, int64_t B, int64_t N,
                            int64_t rows_per_cloud, int64_t d, float* dpc);
+/* ---- row-strided variants of the ops above (ld* = row stride in floats, >= the channel count).  tf.concat of two
+ * [B,N,K,C/2] tensors (RandLANet.py:328,332) and the split of its gradient are copies in the reference; here the two
+ * producers write straight into the left / right columns of the concat buffer and the consumers of the gradient read its
+ * column blocks in place.  `accumulate` != 0: y += act(x.w + b) (gradient accumulation in the GEMM epilogue instead of a
+ * separate add pass). */
+int ps_op_gather_neighbour_ex(ps_context* ctx, const float* pc, const int32_t* idx, int64_t B, int64_t N, int64_t M,
+                              int64_t K, int64_t d, float* out, int64_t ldo);
+int ps_op_conv1x1_ex(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R,
+                     int64_t cin, int64_t cout, int leaky, int accumulate, float* y, int64_t ldy);
+int ps_op_linear_wgrad_ex(ps_context* ctx, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R,
+                          int64_t cin, int64_t cout, float* dW, float* db);
+int ps_op_bn_train_fwd_ex(ps_context* ctx, const float* x, const float* gamma, const float* beta, int64_t R, int64_t C,
+                          float eps, int leaky, float* y, int64_t ldy, float* mean, float* invstd, float* var,
+                          float* scratch2C);
+int ps_op_bn_train_bwd_ex(ps_context* ctx, const float* dy, int64_t lddy, const float* x, const float* gamma,
+                          const float* beta, const float* mean, const float* invstd, int64_t R, int64_t C, int leaky,
+                          float* dx, float* dgamma, float* dbeta);
+int ps_op_bn_train_apply_ex(ps_context* ctx, const float* x, const float* gamma, const float* beta, const float* sums2C,
+                            int64_t R, int64_t R_total, int64_t C, float eps, int leaky, float* y, int64_t ldy,
+                            float* mean, float* invstd, float* var);
+int ps_op_bn_train_bwd_sums_ex(ps_context* ctx, const float* dy, int64_t lddy, const float* x, const float* gamma,
+                               const float* beta, const float* mean, const float* invstd, int64_t R, int64_t C,
+                               int leaky, float* dgamma, float* dbeta);
+int ps_op_bn_train_bwd_apply_ex(ps_context* ctx, const float* dy, int64_t lddy, const float* x, const float* gamma,
+                                const float* beta, const float* mean, const float* invstd, const float* sum_g,
+                                const float* sum_gx, int64_t R, int64_t R_total, int64_t C, int leaky, float* dx);
+int ps_op_scatter_add_rows_ex(ps_context* ctx, const float* drows, int64_t ldd, const int32_t* idx, int64_t B,
+                              int64_t N, int64_t rows_per_cloud, int64_t d, float* dpc);
 /* att_pooling core: probs = softmax over K of scores, agg = sum_K fset * probs   (RandLANet.py:396-398) */
 int ps_op_softmax_pool_fwd(ps_context* ctx, const float* fset, const float* scores, int64_t R, int64_t K, int64_t d,
                            float* probs, float* agg);

@@ -95,6 +95,17 @@ PROTOTYPES = {
     "ps_op_weighted_ce": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp]),
     "ps_op_adam": (ctypes.c_int, [c_vp] * 5 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [ctypes.c_int64]),
     "ps_op_dropout": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float, c_vp, c_vp]),
+    # row-strided / accumulating variants (the training step's concat buffers, include/pointseg.h)
+    "ps_op_gather_neighbour_ex": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 5 + [c_vp, ctypes.c_int64]),
+    "ps_op_conv1x1_ex": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp] + [ctypes.c_int64] * 3 + [ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int64]),
+    "ps_op_linear_wgrad_ex": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, ctypes.c_int64] + [ctypes.c_int64] * 3 + [c_vp, c_vp]),
+    "ps_op_bn_train_fwd_ex": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int, c_vp, ctypes.c_int64]
+                              + [c_vp] * 4),
+    "ps_op_bn_train_bwd_ex": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64] + [c_vp] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int] + [c_vp] * 3),
+    "ps_op_bn_train_apply_ex": (ctypes.c_int, [c_vp] * 5 + [ctypes.c_int64] * 3 + [ctypes.c_float, ctypes.c_int, c_vp, ctypes.c_int64] + [c_vp] * 3),
+    "ps_op_bn_train_bwd_sums_ex": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64] + [c_vp] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int] + [c_vp] * 2),
+    "ps_op_bn_train_bwd_apply_ex": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64] + [c_vp] * 7 + [ctypes.c_int64] * 3 + [ctypes.c_int, c_vp]),
+    "ps_op_scatter_add_rows_ex": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp] + [ctypes.c_int64] * 4 + [c_vp]),
     # host-only debug doors (bound for the CPU test-suite only; the facade never calls them)
     "ps_debug_knn_host": (ctypes.c_int, [c_vp, c_vp] + [ctypes.c_int64] * 4 + [c_vp]),
     "ps_debug_kdtree_host": (ctypes.c_int, [c_vp, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -11,16 +11,37 @@
 
 namespace ps {
 
-// out[row, :] = pc[batch(row)*N + idx[row], :]   rows = B*M*K
+// out[row, 0:d] = pc[batch(row)*N + idx[row], :]   rows = B*M*K; out rows are ldo floats apart (ldo > d: the rows land in the
+// left columns of a wider tensor, the training step's concat buffer)
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ pc, const int32_t* __restrict__ idx, float* __restrict__ out,
-                                                          size_t rows, int rows_per_cloud, int n_cloud, int d)
+                                                          size_t rows, int rows_per_cloud, int n_cloud, int d, int ldo)
 {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= rows * d) return;
     const size_t row = t / d;
     const int ch = (int)(t - row * d);
     const size_t b = row / rows_per_cloud;
-    out[t] = pc[(b * n_cloud + idx[row]) * d + ch];
+    out[row * ldo + ch] = pc[(b * n_cloud + idx[row]) * d + ch];
+}
+// the same with one float4 per thread (d, ldo multiples of 4, 16-byte aligned bases)
+__global__ __launch_bounds__(256) void gather_rows4_kernel(const float* __restrict__ pc, const int32_t* __restrict__ idx, float* __restrict__ out,
+                                                           size_t rows, int rows_per_cloud, int n_cloud, int d4, int ldo)
+{
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= rows * d4) return;
+    const size_t row = t / d4;
+    const int q = (int)(t - row * d4);
+    const size_t b = row / rows_per_cloud;
+    *reinterpret_cast<float4*>(out + row * ldo + 4 * q) = *reinterpret_cast<const float4*>(pc + (b * n_cloud + idx[row]) * (size_t)(4 * d4) + 4 * q);
+}
+
+static void launch_gather_rows(ps_context* c, const float* pc, const int32_t* idx, float* out, size_t rows, int rows_per_cloud, int n_cloud, int d, int ldo)
+{
+    if ((d & 3) == 0 && (ldo & 3) == 0 && ((reinterpret_cast<uintptr_t>(pc) | reinterpret_cast<uintptr_t>(out)) & 15) == 0)
+        hipLaunchKernelGGL(gather_rows4_kernel, dim3(ceil_div(rows * (d / 4), 256)), dim3(256), 0, c->stream, pc, idx, out, rows, rows_per_cloud, n_cloud,
+                           d / 4, ldo);
+    else
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div(rows * d, 256)), dim3(256), 0, c->stream, pc, idx, out, rows, rows_per_cloud, n_cloud, d, ldo);
 }
 
 // out[b,n,k,0:10] = [dis, rel(3), centre(3), nbr(3)]   (RandLANet.py:337-343)
@@ -126,18 +147,24 @@ __global__ __launch_bounds__(256) void att_pool_op_kernel(const float* __restric
 
 using namespace ps;
 
-extern "C" int ps_op_gather_neighbour(ps_context* c, const float* pc, const int32_t* idx, int64_t B, int64_t N, int64_t M, int64_t K, int64_t d,
-                                      float* out)
+extern "C" int ps_op_gather_neighbour_ex(ps_context* c, const float* pc, const int32_t* idx, int64_t B, int64_t N, int64_t M, int64_t K, int64_t d,
+                                         float* out, int64_t ldo)
 {
     PS_CHECK(c && pc && idx && out, "ps_op_gather_neighbour: NULL argument");
-    PS_CHECK(B >= 0 && N >= 1 && M >= 0 && K >= 1 && d >= 1, "ps_op_gather_neighbour: bad shape");
+    PS_CHECK(B >= 0 && N >= 1 && M >= 0 && K >= 1 && d >= 1 && ldo >= d, "ps_op_gather_neighbour: bad shape");
     const size_t rows = (size_t)B * M * K;
     if (!rows) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "op_gather_neighbour", 1);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div(rows * d, 256)), dim3(256), 0, c->stream, pc, idx, out, rows, (int)(M * K), (int)N, (int)d);
+    launch_gather_rows(c, pc, idx, out, rows, (int)(M * K), (int)N, (int)d, (int)ldo);
     PS_HIP(hipGetLastError());
     return PS_OK;
+}
+
+extern "C" int ps_op_gather_neighbour(ps_context* c, const float* pc, const int32_t* idx, int64_t B, int64_t N, int64_t M, int64_t K, int64_t d,
+                                      float* out)
+{
+    return ps_op_gather_neighbour_ex(c, pc, idx, B, N, M, K, d, out, d);
 }
 
 extern "C" int ps_op_relative_pos_encoding(ps_context* c, const float* xyz, const int32_t* idx, int64_t B, int64_t N, int64_t K, float* out)
@@ -174,24 +201,24 @@ extern "C" int ps_op_nearest_interpolation(ps_context* c, const float* feature, 
     if (!rows) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "op_nearest_interpolation", 1);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div(rows * d, 256)), dim3(256), 0, c->stream, feature, interp_idx, out, rows, (int)M, (int)N,
-                       (int)d);
+    launch_gather_rows(c, feature, interp_idx, out, rows, (int)M, (int)N, (int)d, (int)d);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
 
-extern "C" int ps_op_conv1x1(ps_context* c, const float* x, const float* w, const float* b, int64_t R, int64_t cin, int64_t cout, int leaky, float* y)
+extern "C" int ps_op_conv1x1_ex(ps_context* c, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t cin, int64_t cout, int leaky,
+                                int accumulate, float* y, int64_t ldy)
 {
     PS_CHECK(c && x && w && y, "ps_op_conv1x1: NULL argument");
-    PS_CHECK(R >= 0 && cin >= 1 && cout >= 1, "ps_op_conv1x1: bad shape");
+    PS_CHECK(R >= 0 && cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout, "ps_op_conv1x1: bad shape");
     if (!R) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
     PackedLinear L;
-    L.cin = (int)cin; L.cout = (int)cout; L.leaky = leaky;
+    L.cin = (int)cin; L.cout = (int)cout; L.leaky = leaky; L.accum = accumulate ? 1 : 0;
     L.ks = (L.cin + 3) / 4;
     L.ntb = choose_ntb(L.cout);
     L.cblocks = (L.cout + 16 * L.ntb - 1) / (16 * L.ntb);
-    const bool kperm = (cin % 16) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;  // the direct-load kernel's layout (rowgemm.h)
+    const bool kperm = (cin % 16) == 0 && (ldx % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;  // the direct-load kernel's layout (rowgemm.h)
     const size_t need = (kperm ? L.kperm_floats() : L.packed_floats()) * sizeof(float);
     // a small ring of packing buffers: consecutive calls on the stream must not overwrite weights still being read
     ps::DevBuf& ws = c->ops_ring[c->ops_ring_pos];
@@ -209,8 +236,13 @@ extern "C" int ps_op_conv1x1(ps_context* c, const float* x, const float* w, cons
     L.wq = kperm ? ws.as<float>() : nullptr;
     L.bias = b;
     RowSrc s1, none;
-    s1.x = x; s1.ld = L.cin; s1.c = L.cin;
-    return rowgemm(c, L, s1, none, R, y, L.cout);
+    s1.x = x; s1.ld = (int)ldx; s1.c = L.cin;
+    return rowgemm(c, L, s1, none, R, y, (int)ldy);
+}
+
+extern "C" int ps_op_conv1x1(ps_context* c, const float* x, const float* w, const float* b, int64_t R, int64_t cin, int64_t cout, int leaky, float* y)
+{
+    return ps_op_conv1x1_ex(c, x, cin, w, b, R, cin, cout, leaky, 0, y, cout);
 }
 
 extern "C" int ps_op_att_pool(ps_context* c, const float* fset, const float* wfc, int64_t R, int64_t K, int64_t d, float* agg)

@@ -169,24 +169,29 @@ struct SumOnly {
 struct BnBwdSums {
     const float* dy; const float* x; const float* gamma; const float* beta; const float* mean; const float* invstd;
     int leaky;
+    int C;          // channels: element e of x is (row e / C, channel e % C)
+    int64_t lddy;   // row stride of dy in floats (>= C; dy may be a column block of a wider tensor)
     __device__ void operator()(int64_t e, int c, float& a, float& b) const
     {
         const float xh = (x[e] - mean[c]) * invstd[c];
-        float g = dy[e];
+        float g = dy[(e / C) * lddy + c];
         if (leaky && gamma[c] * xh + beta[c] < 0.f) g *= 0.2f;
         a = g;
         b = g * xh;
     }
     float ms[4], ss[4], gm[4], bt[4];  // the thread's four channels (float4 path)
-    bool aligned16() const { return ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0; }
+    int c4, cshift;
+    bool aligned16() const { return ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0 && (lddy & 3) == 0; }
     __device__ void init4(int c)
     {
+        c4 = c;
+        cshift = 31 - __clz(C);  // the float4 path runs only for power-of-two C
 #pragma unroll
         for (int j = 0; j < 4; ++j) { ms[j] = mean[c + j]; ss[j] = invstd[c + j]; gm[j] = gamma[c + j]; bt[j] = beta[c + j]; }
     }
     __device__ void load4(int64_t e, int, float (&a)[4], float (&b)[4]) const
     {
-        const float4 xv = *reinterpret_cast<const float4*>(x + e), gv = *reinterpret_cast<const float4*>(dy + e);
+        const float4 xv = *reinterpret_cast<const float4*>(x + e), gv = *reinterpret_cast<const float4*>(dy + (e >> cshift) * lddy + c4);
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -217,11 +222,12 @@ __global__ void bn_finish_stats_kernel(const float* __restrict__ sum, const floa
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd, int64_t total, int C, int leaky,
-                                                       float* __restrict__ y)
+                                                       float* __restrict__ y, int64_t ldy)
 {
     if (VEC) {
         const int64_t first = 4 * (blockIdx.x * (int64_t)256 + threadIdx.x);
         const int c = (int)(first % C);
+        const int cshift = 31 - __clz(C);  // power-of-two C on this path
         float sc[4], sh[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { sc[j] = invstd[c + j]; sh[j] = mean[c + j]; }
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                 z[j] = ga[j] * ((z[j] - sh[j]) * sc[j]) + be[j];
                 if (leaky && z[j] < 0.f) z[j] *= 0.2f;
             }
-            *reinterpret_cast<float4*>(y + e) = float4{z[0], z[1], z[2], z[3]};
+            *reinterpret_cast<float4*>(y + (e >> cshift) * ldy + c) = float4{z[0], z[1], z[2], z[3]};
         }
         return;
     }
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         const int c = (int)(e % C);
         float z = gamma[c] * ((x[e] - mean[c]) * invstd[c]) + beta[c];
         if (leaky && z < 0.f) z *= 0.2f;
-        y[e] = z;
+        y[(e / C) * ldy + c] = z;
     }
 }
 
@@ -252,12 +258,13 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ sg, const float* __restrict__ sgx,
-                                                           int64_t total, int C, float invR, int leaky, float* __restrict__ dx)
+                                                           int64_t total, int C, float invR, int leaky, float* __restrict__ dx, int64_t lddy)
 {
     // dx = gamma*invstd * (g - mean_r(g) - xhat*mean_r(g*xhat))
     if (VEC) {
         const int64_t first = 4 * (blockIdx.x * (int64_t)256 + threadIdx.x);
         const int c = (int)(first % C);
+        const int cshift = 31 - __clz(C);  // power-of-two C on this path
         float sc[4], sh[4], ga[4], be[4], mg[4], mgx[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             mg[j] = sg[c + j] * invR; mgx[j] = sgx[c + j] * invR;
         }
         for (int64_t e = first; e < total; e += (int64_t)gridDim.x * 1024) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + e), gv = *reinterpret_cast<const float4*>(dy + e);
+            const float4 xv = *reinterpret_cast<const float4*>(x + e), gv = *reinterpret_cast<const float4*>(dy + (e >> cshift) * lddy + c);
             const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
             float g[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
@@ -281,15 +288,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int c = (int)(e % C);
         const float xh = (x[e] - mean[c]) * invstd[c];
-        float g = dy[e];
+        float g = dy[(e / C) * lddy + c];
         if (leaky && gamma[c] * xh + beta[c] < 0.f) g *= 0.2f;
         dx[e] = gamma[c] * invstd[c] * (g - sg[c] * invR - xh * sgx[c] * invR);
     }
 }
 
-static inline bool bn_vec_ok(int64_t C, const void* a, const void* b, const void* c3)
+static inline bool bn_vec_ok(int64_t C, const void* a, const void* b, const void* c3, int64_t ld = 0)
 {
-    return (C & 3) == 0 && (1024 % C) == 0 &&
+    return (C & 3) == 0 && (1024 % C) == 0 && (ld & 3) == 0 &&
            ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c3)) & 15) == 0;
 }
 
@@ -337,8 +344,8 @@ struct WgStage {
 };
 
 template <int TI, int TJ, int WK, bool VEC>
-__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t R, int cin, int cout,
-                                                    int64_t rows_per_block, float* __restrict__ dW, float* __restrict__ db)
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy, int64_t R, int cin,
+                                                    int cout, int64_t rows_per_block, float* __restrict__ dW, float* __restrict__ db)
 {
     constexpr int WI = 4 / WK;
     constexpr int CI = TI * WI * 16, CJ = TJ * 16;
@@ -360,8 +367,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x,
     WgStage<CI, CH, VEC> gx;
     WgStage<CJ, CH, VEC> gd;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};  // column sums of the thread's dY items (its column is fixed)
-    gx.load(x, cin, c0, wx, (int)min<int64_t>(CH, r1 - r0), r0);
-    gd.load(dy, cout, n0, wd, (int)min<int64_t>(CH, r1 - r0), r0);
+    gx.load(x, ldx, c0, wx, (int)min<int64_t>(CH, r1 - r0), r0);
+    gd.load(dy, lddy, n0, wd, (int)min<int64_t>(CH, r1 - r0), r0);
     for (int64_t r = r0; r < r1; r += CH) {
         __syncthreads();  // the previous chunk's fragments have been read
         gx.store(xs, SX);
@@ -374,8 +381,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x,
         __syncthreads();
         if (r + CH < r1) {  // next chunk's loads fly while this one feeds the MFMAs
             const int live = (int)min<int64_t>(CH, r1 - r - CH);
-            gx.load(x, cin, c0, wx, live, r + CH);
-            gd.load(dy, cout, n0, wd, live, r + CH);
+            gx.load(x, ldx, c0, wx, live, r + CH);
+            gd.load(dy, lddy, n0, wd, live, r + CH);
         }
 #pragma unroll
         for (int s = wk; s < CH / 4; s += WK) {
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x,
 }
 
 template <int TI, int TJ, int WK>
-static void launch_wgrad(ps_context* c, const float* x, const float* dy, int64_t R, int cin, int cout, float* dW, float* db)
+static void launch_wgrad(ps_context* c, const float* x, int ldx, const float* dy, int lddy, int64_t R, int cin, int cout, float* dW, float* db)
 {
     constexpr int CI = TI * (4 / WK) * 16, CJ = TJ * 16;
     constexpr int kWgChunk = wg_chunk(CI + CJ);
@@ -433,21 +440,24 @@ static void launch_wgrad(ps_context* c, const float* x, const float* dy, int64_t
     rpb = rpb < 4 * kWgChunk ? 4 * kWgChunk : rpb;
     const int64_t nb = (R + rpb - 1) / rpb;
     // float4 staging needs every row start and block origin on a 16-byte boundary (CI, CJ are multiples of 16 already)
-    const bool vec = ((cin | cout) & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
-    if (vec) hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WK, true>), dim3((unsigned)nb, ty, tz), dim3(256), 0, c->stream, x, dy, R, cin, cout, rpb, dW, db);
-    else hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WK, false>), dim3((unsigned)nb, ty, tz), dim3(256), 0, c->stream, x, dy, R, cin, cout, rpb, dW, db);
+    const bool vec = ((cin | cout | ldx | lddy) & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WK, true>), dim3((unsigned)nb, ty, tz), dim3(256), 0, c->stream, x, ldx, dy, lddy, R, cin, cout, rpb, dW, db);
+    else
+        hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WK, false>), dim3((unsigned)nb, ty, tz), dim3(256), 0, c->stream, x, ldx, dy, lddy, R, cin, cout, rpb, dW,
+                           db);
 }
 
 // ---- scatter-add of gathered rows (backward of tf.batch_gather) ---------------------------------------------------
 __global__ __launch_bounds__(256) void scatter_add_kernel(const float* __restrict__ drows, const int32_t* __restrict__ idx, float* __restrict__ dpc,
-                                                          size_t rows, int rows_per_cloud, int n_cloud, int d)
+                                                          size_t rows, int rows_per_cloud, int n_cloud, int d, int64_t ldd)
 {
     const size_t t = blockIdx.x * (size_t)256 + threadIdx.x;
     if (t >= rows * d) return;
     const size_t row = t / d;
     const int ch = (int)(t - row * d);
     const size_t b = row / rows_per_cloud;
-    atomicAdd(&dpc[(b * n_cloud + idx[row]) * d + ch], drows[t]);
+    atomicAdd(&dpc[(b * n_cloud + idx[row]) * d + ch], drows[row * ldd + ch]);
 }
 
 // ---- softmax over K + weighted sum (att_pooling core, RandLANet.py:396-398) --------------------------------------
@@ -639,7 +649,14 @@ extern "C" {
 
 int ps_op_linear_wgrad(ps_context* c, const float* x, const float* dy, int64_t R, int64_t cin, int64_t cout, float* dW, float* db)
 {
+    return ps_op_linear_wgrad_ex(c, x, cin, dy, cout, R, cin, cout, dW, db);
+}
+
+int ps_op_linear_wgrad_ex(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout, float* dW,
+                          float* db)
+{
     PS_CHECK(c && x && dy && dW, "ps_op_linear_wgrad: NULL argument");
+    PS_CHECK(ldx >= cin && lddy >= cout, "ps_op_linear_wgrad: row stride below the channel count");
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_wgrad", 2);
     PS_HIP(hipMemsetAsync(dW, 0, sizeof(float) * cin * cout, c->stream));
@@ -648,7 +665,7 @@ int ps_op_linear_wgrad(ps_context* c, const float* x, const float* dy, int64_t R
         const int ti = (int)((cin + 15) / 16), tj = (int)((cout + 15) / 16);
         const int ci = (int)cin, co = (int)cout;
         // per-wave tile block TI x TJ and the number of wave groups splitting the k-steps (WK); see wgrad_kernel
-#define PS_WG(TI, TJ, WK) launch_wgrad<TI, TJ, WK>(c, x, dy, R, ci, co, dW, db)
+#define PS_WG(TI, TJ, WK) launch_wgrad<TI, TJ, WK>(c, x, (int)ldx, dy, (int)lddy, R, ci, co, dW, db)
         if (tj >= 8) {
             if (ti >= 8) PS_WG(2, 8, 1);
             else if (ti >= 3) PS_WG(1, 8, 1);
@@ -676,16 +693,24 @@ int ps_op_linear_wgrad(ps_context* c, const float* x, const float* dy, int64_t R
 int ps_op_bn_train_fwd(ps_context* c, const float* x, const float* gamma, const float* beta, int64_t R, int64_t C, float eps, int leaky, float* y,
                        float* mean, float* invstd, float* var, float* scratch2C)
 {
+    return ps_op_bn_train_fwd_ex(c, x, gamma, beta, R, C, eps, leaky, y, C, mean, invstd, var, scratch2C);
+}
+
+int ps_op_bn_train_fwd_ex(ps_context* c, const float* x, const float* gamma, const float* beta, int64_t R, int64_t C, float eps, int leaky, float* y,
+                          int64_t ldy, float* mean, float* invstd, float* var, float* scratch2C)
+{
     PS_CHECK(c && x && gamma && beta && y && mean && invstd && var && scratch2C, "ps_op_bn_train_fwd: NULL argument");
-    PS_CHECK(R >= 1 && C >= 1, "ps_op_bn_train_fwd: empty tensor");
+    PS_CHECK(R >= 1 && C >= 1 && ldy >= C, "ps_op_bn_train_fwd: empty tensor");
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_bn_fwd", 3);
     PS_TRY(colreduce2(c, SumSq{x}, R, (int)C, scratch2C, scratch2C + C));
     hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, c->stream, scratch2C, scratch2C + C, R, (int)C, eps, mean, invstd, var);
-    if (bn_vec_ok(C, x, y, x))
-        hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(ew_grid(R * C / 4)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y);
+    if (bn_vec_ok(C, x, y, x, ldy))
+        hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(ew_grid(R * C / 4)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y,
+                           ldy);
     else
-        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y);
+        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y,
+                           ldy);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -693,17 +718,24 @@ int ps_op_bn_train_fwd(ps_context* c, const float* x, const float* gamma, const 
 int ps_op_bn_train_bwd(ps_context* c, const float* dy, const float* x, const float* gamma, const float* beta, const float* mean, const float* invstd,
                        int64_t R, int64_t C, int leaky, float* dx, float* dgamma, float* dbeta)
 {
+    return ps_op_bn_train_bwd_ex(c, dy, C, x, gamma, beta, mean, invstd, R, C, leaky, dx, dgamma, dbeta);
+}
+
+int ps_op_bn_train_bwd_ex(ps_context* c, const float* dy, int64_t lddy, const float* x, const float* gamma, const float* beta, const float* mean,
+                          const float* invstd, int64_t R, int64_t C, int leaky, float* dx, float* dgamma, float* dbeta)
+{
     PS_CHECK(c && dy && x && gamma && beta && mean && invstd && dx && dgamma && dbeta, "ps_op_bn_train_bwd: NULL argument");
+    PS_CHECK(lddy >= C, "ps_op_bn_train_bwd: row stride of dy below the channel count");
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_bn_bwd", 2);
     // dbeta = sum g, dgamma = sum g*xhat
-    PS_TRY(colreduce2(c, BnBwdSums{dy, x, gamma, beta, mean, invstd, leaky}, R, (int)C, dbeta, dgamma));
-    if (bn_vec_ok(C, x, dy, dx))
+    PS_TRY(colreduce2(c, BnBwdSums{dy, x, gamma, beta, mean, invstd, leaky, (int)C, lddy}, R, (int)C, dbeta, dgamma));
+    if (bn_vec_ok(C, x, dy, dx, lddy))
         hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(R * C / 4)), dim3(256), 0, c->stream, dy, x, gamma, beta, mean, invstd, dbeta, dgamma,
-                           R * C, (int)C, 1.0f / (float)R, leaky, dx);
+                           R * C, (int)C, 1.0f / (float)R, leaky, dx, lddy);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, dy, x, gamma, beta, mean, invstd, dbeta, dgamma,
-                           R * C, (int)C, 1.0f / (float)R, leaky, dx);
+                           R * C, (int)C, 1.0f / (float)R, leaky, dx, lddy);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -724,15 +756,23 @@ int ps_op_bn_train_sums(ps_context* c, const float* x, int64_t R, int64_t C, flo
 int ps_op_bn_train_apply(ps_context* c, const float* x, const float* gamma, const float* beta, const float* sums2C, int64_t R, int64_t R_total,
                          int64_t C, float eps, int leaky, float* y, float* mean, float* invstd, float* var)
 {
+    return ps_op_bn_train_apply_ex(c, x, gamma, beta, sums2C, R, R_total, C, eps, leaky, y, C, mean, invstd, var);
+}
+
+int ps_op_bn_train_apply_ex(ps_context* c, const float* x, const float* gamma, const float* beta, const float* sums2C, int64_t R, int64_t R_total,
+                            int64_t C, float eps, int leaky, float* y, int64_t ldy, float* mean, float* invstd, float* var)
+{
     PS_CHECK(c && x && gamma && beta && sums2C && y && mean && invstd && var, "ps_op_bn_train_apply: NULL argument");
-    PS_CHECK(R >= 1 && C >= 1 && R_total >= R, "ps_op_bn_train_apply: bad row counts");
+    PS_CHECK(R >= 1 && C >= 1 && R_total >= R && ldy >= C, "ps_op_bn_train_apply: bad row counts");
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_bn_fwd", 2);
     hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, c->stream, sums2C, sums2C + C, R_total, (int)C, eps, mean, invstd, var);
-    if (bn_vec_ok(C, x, y, x))
-        hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(ew_grid(R * C / 4)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y);
+    if (bn_vec_ok(C, x, y, x, ldy))
+        hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(ew_grid(R * C / 4)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y,
+                           ldy);
     else
-        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y);
+        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y,
+                           ldy);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -740,10 +780,17 @@ int ps_op_bn_train_apply(ps_context* c, const float* x, const float* gamma, cons
 int ps_op_bn_train_bwd_sums(ps_context* c, const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
                             const float* invstd, int64_t R, int64_t C, int leaky, float* dgamma, float* dbeta)
 {
+    return ps_op_bn_train_bwd_sums_ex(c, dy, C, x, gamma, beta, mean, invstd, R, C, leaky, dgamma, dbeta);
+}
+
+int ps_op_bn_train_bwd_sums_ex(ps_context* c, const float* dy, int64_t lddy, const float* x, const float* gamma, const float* beta, const float* mean,
+                               const float* invstd, int64_t R, int64_t C, int leaky, float* dgamma, float* dbeta)
+{
     PS_CHECK(c && dy && x && gamma && beta && mean && invstd && dgamma && dbeta, "ps_op_bn_train_bwd_sums: NULL argument");
+    PS_CHECK(lddy >= C, "ps_op_bn_train_bwd_sums: row stride of dy below the channel count");
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_bn_bwd", 1);
-    PS_TRY(colreduce2(c, BnBwdSums{dy, x, gamma, beta, mean, invstd, leaky}, R, (int)C, dbeta, dgamma));
+    PS_TRY(colreduce2(c, BnBwdSums{dy, x, gamma, beta, mean, invstd, leaky, (int)C, lddy}, R, (int)C, dbeta, dgamma));
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -751,28 +798,43 @@ int ps_op_bn_train_bwd_sums(ps_context* c, const float* dy, const float* x, cons
 int ps_op_bn_train_bwd_apply(ps_context* c, const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
                              const float* invstd, const float* sum_g, const float* sum_gx, int64_t R, int64_t R_total, int64_t C, int leaky, float* dx)
 {
+    return ps_op_bn_train_bwd_apply_ex(c, dy, C, x, gamma, beta, mean, invstd, sum_g, sum_gx, R, R_total, C, leaky, dx);
+}
+
+int ps_op_bn_train_bwd_apply_ex(ps_context* c, const float* dy, int64_t lddy, const float* x, const float* gamma, const float* beta, const float* mean,
+                                const float* invstd, const float* sum_g, const float* sum_gx, int64_t R, int64_t R_total, int64_t C, int leaky,
+                                float* dx)
+{
     PS_CHECK(c && dy && x && gamma && beta && mean && invstd && sum_g && sum_gx && dx, "ps_op_bn_train_bwd_apply: NULL argument");
-    PS_CHECK(R >= 1 && C >= 1 && R_total >= R, "ps_op_bn_train_bwd_apply: bad row counts");
+    PS_CHECK(R >= 1 && C >= 1 && R_total >= R && lddy >= C, "ps_op_bn_train_bwd_apply: bad row counts");
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_bn_bwd", 1);
-    if (bn_vec_ok(C, x, dy, dx))
+    if (bn_vec_ok(C, x, dy, dx, lddy))
         hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(R * C / 4)), dim3(256), 0, c->stream, dy, x, gamma, beta, mean, invstd, sum_g, sum_gx,
-                           R * C, (int)C, 1.0f / (float)R_total, leaky, dx);
+                           R * C, (int)C, 1.0f / (float)R_total, leaky, dx, lddy);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, dy, x, gamma, beta, mean, invstd, sum_g, sum_gx,
-                           R * C, (int)C, 1.0f / (float)R_total, leaky, dx);
+                           R * C, (int)C, 1.0f / (float)R_total, leaky, dx, lddy);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
 
 int ps_op_scatter_add_rows(ps_context* c, const float* drows, const int32_t* idx, int64_t B, int64_t N, int64_t rows_per_cloud, int64_t d, float* dpc)
 {
+    return ps_op_scatter_add_rows_ex(c, drows, d, idx, B, N, rows_per_cloud, d, dpc);
+}
+
+int ps_op_scatter_add_rows_ex(ps_context* c, const float* drows, int64_t ldd, const int32_t* idx, int64_t B, int64_t N, int64_t rows_per_cloud, int64_t d,
+                              float* dpc)
+{
     PS_CHECK(c && drows && idx && dpc, "ps_op_scatter_add_rows: NULL argument");
+    PS_CHECK(ldd >= d, "ps_op_scatter_add_rows: row stride below the channel count");
     const size_t rows = (size_t)B * rows_per_cloud;
     if (!rows) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_scatter_add", 1);
-    hipLaunchKernelGGL(scatter_add_kernel, dim3(ceil_div(rows * d, 256)), dim3(256), 0, c->stream, drows, idx, dpc, rows, (int)rows_per_cloud, (int)N, (int)d);
+    hipLaunchKernelGGL(scatter_add_kernel, dim3(ceil_div(rows * d, 256)), dim3(256), 0, c->stream, drows, idx, dpc, rows, (int)rows_per_cloud, (int)N, (int)d,
+                       ldd);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }

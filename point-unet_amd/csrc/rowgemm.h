@@ -30,6 +30,7 @@ struct PackedLinear {
     int ntb = 0;      // 1, 2 or 4
     int cblocks = 0;  // ceil(cout / (16*ntb))
     int leaky = 0;
+    int accum = 0;    // add the result to what y already holds (training: gradient accumulation in the GEMM epilogue)
     size_t packed_floats() const { return (size_t)cblocks * ks * 64 * ntb; }
     int nchunks() const { return (cin + 63) / 64; }
     size_t kperm_floats() const { return (size_t)cblocks * nchunks() * 16 * 64 * ntb; }

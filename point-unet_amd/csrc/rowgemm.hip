@@ -28,6 +28,7 @@ struct RowGemmArgs {
     const float* wp; const float* bias;
     float* y; int ldy;
     int cin, cout, ks, R, leaky;
+    int accum;  // y += act(x.W + b) instead of y = ...  (gradient accumulation of the training step)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(256) void rowgemm_direct_kernel(RowGemmArgs a)
 #pragma unroll
                     for (int w = 0; w < 4; ++w) v += red[((w * NTB + j) * 4 + r) * 64 + lane];
                     if (a.leaky) v = leaky02(v);
+                    if (a.accum) v += a.y[(size_t)row * a.ldy + col];
                     a.y[(size_t)row * a.ldy + col] = v;
                 }
             }
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(256) void rowgemm_direct_kernel(RowGemmArgs a)
                     if (row < a.R) {
                         float v = acc[rt][j][r] + bb;
                         if (a.leaky) v = leaky02(v);
+                        if (a.accum) v += a.y[(size_t)row * a.ldy + col];
                         a.y[(size_t)row * a.ldy + col] = v;
                     }
                 }
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a)
             if (row < a.R) {
                 float v = acc[j][r] + b;
                 if (a.leaky) v = leaky02(v);
+                if (a.accum) v += a.y[(size_t)row * a.ldy + col];
                 a.y[(size_t)row * a.ldy + col] = v;
             }
         }
@@ -513,6 +517,7 @@ int rowgemm(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc
     a.wp = L.wp; a.bias = L.bias;
     a.y = y; a.ldy = ldy;
     a.cin = L.cin; a.cout = L.cout; a.ks = L.ks; a.R = (int)R; a.leaky = L.leaky;
+    a.accum = L.accum;
 
     const bool direct = L.wq && L.cin % 16 == 0 && s1.c % 16 == 0 && s1.ld % 4 == 0 && aligned16(s1.x) &&
                         (s2.c == 0 || (s2.ld % 4 == 0 && aligned16(s2.x)));

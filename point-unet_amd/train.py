@@ -30,6 +30,12 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def _rowmajor(t):
+    """t as a 2-D tensor with contiguous rows (any row stride): column blocks of a wider tensor pass through untouched,
+    the strided entry points (ps_op_*_ex) take the row stride."""
+    return t if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous()
+
+
 def allreduce_mean_(flat, dist):
     """Gradient synchronisation of config 4: ONE all-reduce (RCCL over xGMI on the GPU box, gloo in the CPU tests) of the
     flat fp32 gradient buffer, then the mean over ranks.  19.97 MB for the BraTS model: latency-bound, so no bucketing."""
@@ -53,7 +59,11 @@ class Tape:
     def accum(self, t, g):
         k = id(t)
         if k in self.grads:
-            _lib.check(self.L.ps_op_axpy(self.h, 1.0, _p(g), g.numel(), _p(self.grads[k])))
+            have = self.grads[k]
+            if have.is_contiguous() and g.is_contiguous():
+                _lib.check(self.L.ps_op_axpy(self.h, 1.0, _p(g), g.numel(), _p(have)))
+            else:  # one of them is a column block of a concat buffer
+                have.add_(g)
         else:
             self.grads[k] = g
 
@@ -78,78 +88,93 @@ class Tape:
     def linear(self, x, W, b, gW, gb, transposed=False):
         """y = x . W (+ b).  W is [cin,cout], or [cout,cin] when transposed (conv2d_transpose kernels)."""
         Wm = W.t().contiguous() if transposed else W
+        x_in = x  # the tensor the tape knows (gradients are keyed by identity)
+        x = _rowmajor(x)
         R, cin = x.shape
+        ldx = x.stride(0)
         cout = Wm.shape[1]
         y = torch.empty((R, cout), dtype=torch.float32, device=x.device)
-        _lib.check(self.L.ps_op_conv1x1(self.h, _p(x), _p(Wm), _p(b), R, cin, cout, 0, _p(y)))
+        _lib.check(self.L.ps_op_conv1x1_ex(self.h, _p(x), ldx, _p(Wm), _p(b), R, cin, cout, 0, 0, _p(y), cout))
 
         def bw(dy):
-            dy = dy.contiguous()
+            dy = _rowmajor(dy)
+            lddy = dy.stride(0)
+            pgb = _p(gb) if gb is not None else None
             if transposed or not gW.is_contiguous():
                 dW = torch.empty((cin, cout), dtype=torch.float32, device=x.device)
-                _lib.check(self.L.ps_op_linear_wgrad(self.h, _p(x), _p(dy), R, cin, cout, _p(dW), _p(gb) if gb is not None else None))
+                _lib.check(self.L.ps_op_linear_wgrad_ex(self.h, _p(x), ldx, _p(dy), lddy, R, cin, cout, _p(dW), pgb))
                 gW.copy_(dW.t() if transposed else dW)
             else:  # straight into the parameter's slice of the flat gradient buffer
-                _lib.check(self.L.ps_op_linear_wgrad(self.h, _p(x), _p(dy), R, cin, cout, _p(gW), _p(gb) if gb is not None else None))
-            if x.requires_grad_flag:
-                dx = torch.empty((R, cin), dtype=torch.float32, device=x.device)
+                _lib.check(self.L.ps_op_linear_wgrad_ex(self.h, _p(x), ldx, _p(dy), lddy, R, cin, cout, _p(gW), pgb))
+            if x_in.requires_grad_flag:
                 Wt = Wm.t().contiguous()
-                _lib.check(self.L.ps_op_conv1x1(self.h, _p(dy), _p(Wt), None, R, cout, cin, 0, _p(dx)))
-                self.accum(x, dx)
+                have = self.grads.get(id(x_in))
+                if have is not None and have.dim() == 2 and have.stride(1) == 1:
+                    # x already has a gradient from another consumer: add this one in the GEMM epilogue
+                    _lib.check(self.L.ps_op_conv1x1_ex(self.h, _p(dy), lddy, _p(Wt), None, R, cout, cin, 0, 1, _p(have), have.stride(0)))
+                else:
+                    dx = torch.empty((R, cin), dtype=torch.float32, device=x.device)
+                    _lib.check(self.L.ps_op_conv1x1_ex(self.h, _p(dy), lddy, _p(Wt), None, R, cout, cin, 0, 0, _p(dx), cin))
+                    self.accum(x_in, dx)
 
         y.requires_grad_flag = True
         self.ops.append((y, bw))
         return y
 
-    def bn_act(self, x, gamma, beta, ggamma, gbeta, mov_mean, mov_var, leaky):
+    def bn_act(self, x, gamma, beta, ggamma, gbeta, mov_mean, mov_var, leaky, out=None):
+        """out: optional [R, C] column block of a wider tensor (rows contiguous) that receives y."""
         R, C = x.shape
-        y = torch.empty_like(x)
+        y = torch.empty_like(x) if out is None else out
+        ldy = y.stride(0)
         stats = torch.empty((5, C), dtype=torch.float32, device=x.device)  # mean, invstd, var, [sum x | sum x^2]
         sync = self.sync
         if sync is None:
-            _lib.check(self.L.ps_op_bn_train_fwd(self.h, _p(x), _p(gamma), _p(beta), R, C, BN_EPS, 1 if leaky else 0, _p(y), _p(stats[0]), _p(stats[1]),
-                                                 _p(stats[2]), _p(stats[3])))
+            _lib.check(self.L.ps_op_bn_train_fwd_ex(self.h, _p(x), _p(gamma), _p(beta), R, C, BN_EPS, 1 if leaky else 0, _p(y), ldy, _p(stats[0]),
+                                                    _p(stats[1]), _p(stats[2]), _p(stats[3])))
             R_total = R
         else:
             # statistics over the rows of ALL ranks: two small all-reduces per layer (2*C floats forward, 2*C backward)
             R_total = R * sync.get_world_size()
             _lib.check(self.L.ps_op_bn_train_sums(self.h, _p(x), R, C, _p(stats[3])))
             sync.all_reduce(stats[3:5])
-            _lib.check(self.L.ps_op_bn_train_apply(self.h, _p(x), _p(gamma), _p(beta), _p(stats[3]), R, R_total, C, BN_EPS, 1 if leaky else 0, _p(y),
-                                                   _p(stats[0]), _p(stats[1]), _p(stats[2])))
+            _lib.check(self.L.ps_op_bn_train_apply_ex(self.h, _p(x), _p(gamma), _p(beta), _p(stats[3]), R, R_total, C, BN_EPS, 1 if leaky else 0,
+                                                      _p(y), ldy, _p(stats[0]), _p(stats[1]), _p(stats[2])))
         # moving statistics (the reference's extra_update_ops, RandLANet.py:90,163)
         mov_mean.mul_(BN_MOMENTUM).add_(stats[0], alpha=1 - BN_MOMENTUM)
         mov_var.mul_(BN_MOMENTUM).add_(stats[2], alpha=1 - BN_MOMENTUM)
 
         def bw(dy):
             dx = torch.empty_like(x)
-            dyc = dy.contiguous()
+            dyc = _rowmajor(dy)
+            lddy = dyc.stride(0)
             if sync is None:
-                _lib.check(self.L.ps_op_bn_train_bwd(self.h, _p(dyc), _p(x), _p(gamma), _p(beta), _p(stats[0]), _p(stats[1]), R, C,
-                                                     1 if leaky else 0, _p(dx), _p(ggamma), _p(gbeta)))
+                _lib.check(self.L.ps_op_bn_train_bwd_ex(self.h, _p(dyc), lddy, _p(x), _p(gamma), _p(beta), _p(stats[0]), _p(stats[1]), R, C,
+                                                        1 if leaky else 0, _p(dx), _p(ggamma), _p(gbeta)))
             else:
                 # local sums are this rank's dgamma / dbeta (averaged with every other gradient later); dx needs the global ones
-                _lib.check(self.L.ps_op_bn_train_bwd_sums(self.h, _p(dyc), _p(x), _p(gamma), _p(beta), _p(stats[0]), _p(stats[1]), R, C,
-                                                          1 if leaky else 0, _p(ggamma), _p(gbeta)))
+                _lib.check(self.L.ps_op_bn_train_bwd_sums_ex(self.h, _p(dyc), lddy, _p(x), _p(gamma), _p(beta), _p(stats[0]), _p(stats[1]), R, C,
+                                                             1 if leaky else 0, _p(ggamma), _p(gbeta)))
                 tot = torch.stack([gbeta.reshape(-1), ggamma.reshape(-1)])
                 sync.all_reduce(tot)
-                _lib.check(self.L.ps_op_bn_train_bwd_apply(self.h, _p(dyc), _p(x), _p(gamma), _p(beta), _p(stats[0]), _p(stats[1]), _p(tot[0]),
-                                                           _p(tot[1]), R, R_total, C, 1 if leaky else 0, _p(dx)))
+                _lib.check(self.L.ps_op_bn_train_bwd_apply_ex(self.h, _p(dyc), lddy, _p(x), _p(gamma), _p(beta), _p(stats[0]), _p(stats[1]),
+                                                              _p(tot[0]), _p(tot[1]), R, R_total, C, 1 if leaky else 0, _p(dx)))
             self.accum(x, dx)
 
         y.requires_grad_flag = True
         self.ops.append((y, bw))
         return y
 
-    def gather(self, x, idx, B):
-        """x [B*N, d], idx [B, M, K] -> [B*M*K, d]"""
+    def gather(self, x, idx, B, out=None):
+        """x [B*N, d], idx [B, M, K] -> [B*M*K, d]; out: optional column block of a wider tensor that receives the rows"""
         N, d = x.shape[0] // B, x.shape[1]
         M, K = idx.shape[1], idx.shape[2]
-        out = torch.empty((B * M * K, d), dtype=torch.float32, device=x.device)
-        _lib.check(self.L.ps_op_gather_neighbour(self.h, _p(x), _p(idx), B, N, M, K, d, _p(out)))
+        if out is None:
+            out = torch.empty((B * M * K, d), dtype=torch.float32, device=x.device)
+        _lib.check(self.L.ps_op_gather_neighbour_ex(self.h, _p(x), _p(idx), B, N, M, K, d, _p(out), out.stride(0)))
 
         def bw(dy):
-            _lib.check(self.L.ps_op_scatter_add_rows(self.h, _p(dy.contiguous()), _p(idx), B, N, M * K, d, _p(self.accum_buffer(x))))
+            dy = _rowmajor(dy)
+            _lib.check(self.L.ps_op_scatter_add_rows_ex(self.h, _p(dy), dy.stride(0), _p(idx), B, N, M * K, d, _p(self.accum_buffer(x))))
 
         out.requires_grad_flag = True
         self.ops.append((out, bw))
@@ -168,6 +193,22 @@ class Tape:
         out.requires_grad_flag = True
         self.ops.append((out, bw))
         return out
+
+    def concat_views(self, buf, a, b):
+        """buf [R, ca+cb] whose left / right column blocks a and b were written in place by their producers (gather /
+        bn_act with out=): the concat costs nothing, and its backward hands the column blocks of the gradient on as views."""
+        ca = a.shape[1]
+
+        def bw(dy):
+            dy = _rowmajor(dy)
+            if getattr(a, "requires_grad_flag", False):
+                self.accum(a, dy[:, :ca])
+            if getattr(b, "requires_grad_flag", False):
+                self.accum(b, dy[:, ca:])
+
+        buf.requires_grad_flag = True
+        self.ops.append((buf, bw))
+        return buf
 
     def softpool(self, fset, scores, K):
         RK, d = fset.shape
@@ -286,12 +327,12 @@ class Trainer:
         return out
 
     # ---- graph pieces ------------------------------------------------------------------------------------------------
-    def _conv(self, t, x, scope, bn=True, act=True, transposed=False):
+    def _conv(self, t, x, scope, bn=True, act=True, transposed=False, out=None):
         y = t.linear(x, self.P[scope + "/weights"], self.P[scope + "/biases"], self.G[scope + "/weights"], self.G[scope + "/biases"], transposed)
         if bn:
             s = scope + "/batch_normalization"
             y = t.bn_act(y, self.P[s + "/gamma"], self.P[s + "/beta"], self.G[s + "/gamma"], self.G[s + "/beta"], self.buffers[s + "/moving_mean"],
-                         self.buffers[s + "/moving_variance"], act)
+                         self.buffers[s + "/moving_variance"], act, out=out)
         return y
 
     def _att(self, t, fcat, name, K):
@@ -319,12 +360,17 @@ class Trainer:
             rel = torch.empty((B * N * K, 10), dtype=torch.float32, device=x.device)
             _lib.check(lib.ps_op_relative_pos_encoding(h, _p(pyr.xyz[i]), _p(idx), B, N, K, _p(rel)))
             rel.requires_grad_flag = False
-            f_xyz = self._conv(t, rel, n + "LFAmlp1")
-            f_nb = t.gather(f_pc, idx, B)
-            f_agg = self._att(t, t.cat(f_nb, f_xyz), n + "LFAatt_pooling_1", K)
-            f_xyz2 = self._conv(t, f_xyz, n + "LFAmlp2")
-            f_nb2 = t.gather(f_agg, idx, B)
-            f_agg2 = self._att(t, t.cat(f_nb2, f_xyz2), n + "LFAatt_pooling_2", K)
+            # tf.concat([f_neighbours, f_xyz]) (RandLANet.py:328,332): both producers write their column block of the concat
+            # buffer directly (no concat copy forward, no split copies backward)
+            hc = f_pc.shape[1]
+            cat1 = torch.empty((B * N * K, 2 * hc), dtype=torch.float32, device=x.device)
+            f_xyz = self._conv(t, rel, n + "LFAmlp1", out=cat1[:, hc:])
+            f_nb = t.gather(f_pc, idx, B, out=cat1[:, :hc])
+            f_agg = self._att(t, t.concat_views(cat1, f_nb, f_xyz), n + "LFAatt_pooling_1", K)
+            cat2 = torch.empty((B * N * K, 2 * hc), dtype=torch.float32, device=x.device)
+            f_xyz2 = self._conv(t, f_xyz, n + "LFAmlp2", out=cat2[:, hc:])
+            f_nb2 = t.gather(f_agg, idx, B, out=cat2[:, :hc])
+            f_agg2 = self._att(t, t.concat_views(cat2, f_nb2, f_xyz2), n + "LFAatt_pooling_2", K)
             a = self._conv(t, f_agg2, n + "mlp2", act=False)
             b = self._conv(t, feature, n + "shortcut", act=False)
             f_enc = t.add_lrelu(a, b)

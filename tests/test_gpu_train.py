@@ -218,3 +218,70 @@ def test_training_ops_against_torch(oracle):
     ref = (torch.nn.functional.cross_entropy(zd, yl.long(), reduction="none") * cw.double()[yl.long()]).mean()
     ref.backward()
     assert abs(float(loss) - float(ref)) < 1e-5 and (dz.double() - zd.grad).abs().max() < 1e-6
+
+
+def test_row_strided_variants_match_the_dense_ops():
+    """ps_op_*_ex on column blocks of a wider tensor (the training step's concat buffers) give what the dense entry points give
+    on contiguous copies; conv1x1_ex with accumulate adds in the epilogue."""
+    import ctypes
+    import torch
+    from point_unet_amd import _lib, runtime
+    L, ctx = _lib.lib(), runtime.default_context(0)
+    h = ctx.handle
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(5)
+    for R, C, wide, off in [(4099, 16, 32, 16), (1237, 8, 16, 8), (530, 10, 23, 7), (2048, 64, 128, 64)]:
+        buf = torch.randn(R, wide, generator=g).cuda()
+        blk = buf[:, off:off + C]            # rows contiguous, row stride = wide
+        dense = blk.contiguous()
+        # conv1x1: strided input, strided output, then the accumulate epilogue
+        cout = 24
+        W = torch.randn(C, cout, generator=g).cuda()
+        b = torch.randn(cout, generator=g).cuda()
+        y_ref = torch.empty(R, cout).cuda()
+        _lib.check(L.ps_op_conv1x1(h, p(dense), p(W), p(b), R, C, cout, 1, p(y_ref)))
+        ybuf = torch.full((R, cout + 9), 7.0).cuda()
+        yv = ybuf[:, 4:4 + cout]
+        _lib.check(L.ps_op_conv1x1_ex(h, p(blk), wide, p(W), p(b), R, C, cout, 1, 0, p(yv), cout + 9))
+        assert torch.equal(yv, y_ref) and float(ybuf[:, :4].min()) == 7.0 and float(ybuf[:, 4 + cout:].max()) == 7.0
+        _lib.check(L.ps_op_conv1x1_ex(h, p(blk), wide, p(W), p(b), R, C, cout, 1, 1, p(yv), cout + 9))
+        assert torch.allclose(yv, 2 * y_ref, rtol=0, atol=1e-6 * float(y_ref.abs().max()))
+        # wgrad with both operands strided
+        dybuf = torch.randn(R, cout + 5, generator=g).cuda()
+        dyv = dybuf[:, 5:]
+        dW, db = torch.empty(C, cout).cuda(), torch.empty(cout).cuda()
+        _lib.check(L.ps_op_linear_wgrad_ex(h, p(blk), wide, p(dyv), cout + 5, R, C, cout, p(dW), p(db)))
+        ref = dense.double().T @ dyv.double()
+        assert (dW.double() - ref).abs().max() <= 1e-4 * ref.abs().max()
+        assert (db.double() - dyv.double().sum(0)).abs().max() <= 1e-4 * dyv.double().sum(0).abs().max() + 1e-4
+        # BatchNorm: y into a column block, dy read from a column block
+        gamma, beta = torch.rand(C, generator=g).cuda() + 0.5, torch.randn(C, generator=g).cuda()
+        x = (torch.randn(R, C, generator=g) * 2 + 0.5).cuda()
+        st, st2 = torch.empty(5, C).cuda(), torch.empty(5, C).cuda()
+        y_ref = torch.empty(R, C).cuda()
+        _lib.check(L.ps_op_bn_train_fwd(h, p(x), p(gamma), p(beta), R, C, 1e-6, 1, p(y_ref), p(st[0]), p(st[1]), p(st[2]), p(st[3])))
+        out = torch.zeros(R, wide).cuda()
+        _lib.check(L.ps_op_bn_train_fwd_ex(h, p(x), p(gamma), p(beta), R, C, 1e-6, 1, p(out[:, off:off + C]), wide, p(st2[0]), p(st2[1]), p(st2[2]),
+                                           p(st2[3])))
+        assert torch.equal(out[:, off:off + C], y_ref) and torch.equal(st[:3], st2[:3])
+        assert float(out[:, :off].abs().max()) == 0.0 and (off + C == wide or float(out[:, off + C:].abs().max()) == 0.0)
+        dx_ref, dg_ref, db_ref = torch.empty(R, C).cuda(), torch.empty(C).cuda(), torch.empty(C).cuda()
+        _lib.check(L.ps_op_bn_train_bwd(h, p(dense), p(x), p(gamma), p(beta), p(st[0]), p(st[1]), R, C, 1, p(dx_ref), p(dg_ref), p(db_ref)))
+        dx, dg, dbt = torch.empty(R, C).cuda(), torch.empty(C).cuda(), torch.empty(C).cuda()
+        _lib.check(L.ps_op_bn_train_bwd_ex(h, p(blk), wide, p(x), p(gamma), p(beta), p(st[0]), p(st[1]), R, C, 1, p(dx), p(dg), p(dbt)))
+        assert torch.equal(dx, dx_ref) and torch.equal(dg, dg_ref) and torch.equal(dbt, db_ref)
+    # gather into a column block / scatter-add from a column block
+    B, N, M, K, d = 2, 300, 170, 5, 12
+    pc = torch.randn(B * N, d, generator=g).cuda()
+    idx = torch.randint(0, N, (B, M, K), generator=g).int().cuda()
+    ref = torch.empty(B * M * K, d).cuda()
+    _lib.check(L.ps_op_gather_neighbour(h, p(pc), p(idx), B, N, M, K, d, p(ref)))
+    wide = torch.zeros(B * M * K, 2 * d).cuda()
+    _lib.check(L.ps_op_gather_neighbour_ex(h, p(pc), p(idx), B, N, M, K, d, p(wide[:, :d]), 2 * d))
+    assert torch.equal(wide[:, :d], ref) and float(wide[:, d:].abs().max()) == 0.0
+    drows = torch.randn(B * M * K, 2 * d, generator=g).cuda()
+    acc_ref, acc = torch.zeros(B * N, d).cuda(), torch.zeros(B * N, d).cuda()
+    _lib.check(L.ps_op_scatter_add_rows(h, p(drows[:, d:].contiguous()), p(idx), B, N, M * K, d, p(acc_ref)))
+    _lib.check(L.ps_op_scatter_add_rows_ex(h, p(drows[:, d:]), 2 * d, p(idx), B, N, M * K, d, p(acc)))
+    assert torch.allclose(acc, acc_ref, rtol=0, atol=1e-5)
+    torch.cuda.synchronize()
