@@ -163,7 +163,8 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
     feats = np.concatenate([xyz, rng.standard_normal((B, n0, cfg.in_channels - 3)).astype(np.float32)], -1)
     labels = rng.integers(0, cfg.num_classes, (B, n0)).astype(np.int32)
     ctx = runtime.default_context(local_rank)
-    tr = Trainer(cfg, params=weights.init_params(cfg, seed=2), device=local_rank, ctx=ctx, keep_prob=0.5, sync_bn=world > 1 and not args.local_bn)
+    tr = Trainer(cfg, params=weights.init_params(cfg, seed=2), device=local_rank, ctx=ctx, keep_prob=0.5, sync_bn=world > 1 and not args.local_bn,
+                 mlp_dtype="bf16" if args.bf16_mlp else "fp32")
     d_xyz, d_feats, d_lab = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
     pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
 
@@ -183,7 +184,9 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
         print(json.dumps({
             "metric": "points_per_sec_train_step", "value": whole_job_value(world, B, n0, args.steps, elapsed), "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # bf16: BASELINE configs[2]'s "bf16 MLPs" -- the shared-MLP GEMMs on bf16 operands with fp32 accumulate, the rest fp32
+            "dtype": "bf16" if args.bf16_mlp else "f32", "data": "synthetic",
             "config": {"workload": "training step (pyramid + train-mode forward + weighted CE + backward + Adam), %d-point BraTS-shaped "
                                    "clouds, batch %d per GPU, K=16, 5 levels, fp32%s" % (n0, B, (", gradient all-reduce over RCCL, BatchNorm statistics %s" % ("per GPU" if args.local_bn else "shared by all ranks")) if world > 1 else ""),
                        "points": n0, "batch_per_gpu": B, "parameters": tr.num_params()},
@@ -213,6 +216,7 @@ def main():
     ap.add_argument("--include-pcie", action="store_true",
                     help="every step also copies its inputs (xyz, features) from pinned host memory and its logits back: the "
                          "PCIe-inclusive rate DESIGN.md quotes next to the headline (which keeps inputs resident in HBM)")
+    ap.add_argument("--bf16-mlp", action="store_true", help="train mode: shared-MLP GEMMs on bf16 operands with fp32 accumulate (BASELINE configs[2])")
     ap.add_argument("--local-bn", action="store_true", help="train mode, N > 1: per-GPU BatchNorm statistics instead of statistics shared by all ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true", help="do not record hipEvents around the stages (A/B of their cost)")

@@ -68,6 +68,12 @@ int ps_synchronize(ps_context* ctx);
  * and validated by the next ps_synchronize(), which then returns PS_ESTATE.  Lets the host enqueue the forward while
  * the pyramid is still being built.  Default off (every call validates before returning). */
 int ps_set_deferred_checks(ps_context* ctx, int on);
+/* on != 0: the op-level GEMMs of the training step -- ps_op_conv1x1[_ex] (forward and input-gradient GEMMs) on layers whose
+ * channel count is a multiple of 16, and ps_op_linear_wgrad[_ex] -- round both operands to bf16 (round-to-nearest-even) as
+ * they are loaded and accumulate in fp32 on v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16: BASELINE configs[2]'s "bf16 MLPs"
+ * (SURVEY 8d, config 3).  Activations, gradients, BatchNorm, softmax, loss and Adam stay fp32.  Default off (fp32 MFMA).
+ * The fused inference path (ps_randla_forward) is never affected. */
+int ps_set_train_gemm_bf16(ps_context* ctx, int on);
 const char* ps_last_error(void);
 /* "pointseg-hip <version> gfx950" */
 const char* ps_version(void);

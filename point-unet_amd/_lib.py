@@ -53,6 +53,7 @@ PROTOTYPES = {
     "ps_set_deferred_checks": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "ps_last_error": (ctypes.c_char_p, []),
     "ps_version": (ctypes.c_char_p, []),
+    "ps_set_train_gemm_bf16": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "ps_timing_begin": (ctypes.c_int, [c_vp]),
     "ps_timing_select": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
     "ps_timing_end": (ctypes.c_int, [c_vp, ctypes.POINTER(PsTimingRow), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),

@@ -85,6 +85,7 @@ struct ps_context {
     ps::DevBuf red_ws;       // per-block partial sums of the per-channel reductions (ops_train.hip)
     ps::DevBuf ops_ring[4];  // packed weights of ps_op_conv1x1 (a ring: consecutive calls never repack into the buffer the previous GEMM is still reading)
     int ops_ring_pos = 0;
+    bool train_bf16 = false;  // ps_set_train_gemm_bf16: the op-level GEMMs round their operands to bf16 (fp32 accumulate)
     // per-device kernel attributes already raised by this context (dynamic LDS above the default limit)
     bool mid_lds_attr = false;
     size_t chain_lds_attr = 48 * 1024;

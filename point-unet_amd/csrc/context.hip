@@ -202,6 +202,13 @@ int ps_synchronize(ps_context* c)
     return c->check_deferred();
 }
 
+int ps_set_train_gemm_bf16(ps_context* c, int on)
+{
+    PS_CHECK(c != nullptr, "ps_set_train_gemm_bf16: ctx is NULL");
+    c->train_bf16 = on != 0;
+    return PS_OK;
+}
+
 int ps_set_deferred_checks(ps_context* c, int on)
 {
     PS_CHECK(c != nullptr, "ps_set_deferred_checks: ctx is NULL");

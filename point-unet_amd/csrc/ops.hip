@@ -106,6 +106,22 @@ __global__ void pack_weights_kperm_kernel(const float* __restrict__ W, int cin, 
     out[t] = (k < cin && col < cout) ? W[(size_t)k * cout + col] : 0.f;
 }
 
+// bf16 image of rowgemm.h (PackedLinear::wb): one thread per bf16 element
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ W, int cin, int cout, int ntb, int nc, int cblocks, __bf16* __restrict__ out)
+{
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t total = (size_t)cblocks * nc * 2 * 64 * ntb * 8;
+    if (t >= total) return;
+    const int e = (int)(t % 8);
+    const int j = (int)((t / 8) % ntb);
+    const int l = (int)((t / 8 / ntb) % 64);
+    const int s = (int)((t / 8 / ntb / 64) % 2);
+    const int c = (int)((t / 8 / ntb / 64 / 2) % nc);
+    const int cb = (int)(t / 8 / ntb / 64 / 2 / nc);
+    const int k = c * 64 + 16 * (l >> 4) + 8 * s + e, col = (cb * ntb + j) * 16 + (l & 15);
+    out[t] = (__bf16)((k < cin && col < cout) ? W[(size_t)k * cout + col] : 0.f);
+}
+
 // agg[r, col] = sum_k fset[r,k,col] * softmax_k( (fset[r] . wfc)[k, col] )    (RandLANet.py:394-398)
 template <int KMAX>
 __global__ __launch_bounds__(256) void att_pool_op_kernel(const float* __restrict__ fset, const float* __restrict__ wfc, float* __restrict__ agg,
@@ -219,13 +235,17 @@ extern "C" int ps_op_conv1x1_ex(ps_context* c, const float* x, int64_t ldx, cons
     L.ntb = choose_ntb(L.cout);
     L.cblocks = (L.cout + 16 * L.ntb - 1) / (16 * L.ntb);
     const bool kperm = (cin % 16) == 0 && (ldx % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;  // the direct-load kernel's layout (rowgemm.h)
-    const size_t need = (kperm ? L.kperm_floats() : L.packed_floats()) * sizeof(float);
+    const bool bf16 = kperm && c->train_bf16;
+    const size_t need = bf16 ? L.bf16_bytes() : (kperm ? L.kperm_floats() : L.packed_floats()) * sizeof(float);
     // a small ring of packing buffers: consecutive calls on the stream must not overwrite weights still being read
     ps::DevBuf& ws = c->ops_ring[c->ops_ring_pos];
     c->ops_ring_pos = (c->ops_ring_pos + 1) & 3;
     PS_TRY(ws.reserve(need));
     Stage st(c, "op_conv1x1", 2);
-    if (kperm)
+    if (bf16)
+        hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(ceil_div(L.bf16_bytes() / 2, 256)), dim3(256), 0, c->stream, w, L.cin, L.cout, L.ntb, L.nchunks(),
+                           L.cblocks, ws.as<__bf16>());
+    else if (kperm)
         hipLaunchKernelGGL(pack_weights_kperm_kernel, dim3(ceil_div(L.kperm_floats(), 256)), dim3(256), 0, c->stream, w, L.cin, L.cout, L.ntb, L.nchunks(),
                            L.cblocks, ws.as<float>());
     else
@@ -233,7 +253,8 @@ extern "C" int ps_op_conv1x1_ex(ps_context* c, const float* x, int64_t ldx, cons
                            ws.as<float>());
     PS_HIP(hipGetLastError());
     L.wp = kperm ? nullptr : ws.as<float>();
-    L.wq = kperm ? ws.as<float>() : nullptr;
+    L.wq = (kperm && !bf16) ? ws.as<float>() : nullptr;
+    L.wb = bf16 ? ws.as<void>() : nullptr;
     L.bias = b;
     RowSrc s1, none;
     s1.x = x; s1.ld = (int)ldx; s1.c = L.cin;

@@ -343,14 +343,27 @@ struct WgStage {
     }
 };
 
-template <int TI, int TJ, int WK, bool VEC>
+// BF16: the k-step is 16 rows on v_mfma_f32_16x16x16_bf16 (lane (i, g) supplies rows 4g..4g+3 of the step), operands rounded to
+// bf16 as they leave LDS; the LDS row strides are then = 4 (mod 16) floats so that the four row groups hit disjoint banks.
+typedef short bf16x4s __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2t __attribute__((ext_vector_type(2)));
+typedef float f32x2t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x4s to_bf16x4(float a, float b, float c, float d)
+{
+    union { bf16x2t h[2]; bf16x4s s; } u;
+    u.h[0] = __builtin_convertvector(f32x2t{a, b}, bf16x2t);
+    u.h[1] = __builtin_convertvector(f32x2t{c, d}, bf16x2t);
+    return u.s;
+}
+
+template <int TI, int TJ, int WK, bool VEC, bool BF16>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy, int64_t R, int cin,
                                                     int cout, int64_t rows_per_block, float* __restrict__ dW, float* __restrict__ db)
 {
     constexpr int WI = 4 / WK;
     constexpr int CI = TI * WI * 16, CJ = TJ * 16;
-    constexpr int SX = wg_stride(CI), SD = wg_stride(CJ);
-    constexpr int CH = wg_chunk(CI + CJ);
+    constexpr int SX = BF16 ? CI + 4 : wg_stride(CI), SD = BF16 ? CJ + 4 : wg_stride(CJ);
+    constexpr int CH = BF16 ? (wg_chunk(CI + CJ) > 16 * WK ? wg_chunk(CI + CJ) : 16 * WK) : wg_chunk(CI + CJ);
     __shared__ float xs[CH * SX], ds[CH * SD];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i16 = lane & 15, k4 = lane >> 4;
@@ -384,6 +397,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x,
             gx.load(x, ldx, c0, wx, live, r + CH);
             gd.load(dy, lddy, n0, wd, live, r + CH);
         }
+        if constexpr (BF16) {
+#pragma unroll
+            for (int s = wk; s < CH / 16; s += WK) {
+                bf16x4s a[TI], b[TJ];
+                const int rb = 16 * s + 4 * k4;
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const float* q = xs + rb * SX + (wi * TI + i) * 16 + i16;
+                    a[i] = to_bf16x4(q[0], q[SX], q[2 * SX], q[3 * SX]);
+                }
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const float* q = ds + rb * SD + j * 16 + i16;
+                    b[j] = to_bf16x4(q[0], q[SD], q[2 * SD], q[3 * SD]);
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int s = wk; s < CH / 4; s += WK) {
             float a[TI], b[TJ];
@@ -430,7 +464,7 @@ template <int TI, int TJ, int WK>
 static void launch_wgrad(ps_context* c, const float* x, int ldx, const float* dy, int lddy, int64_t R, int cin, int cout, float* dW, float* db)
 {
     constexpr int CI = TI * (4 / WK) * 16, CJ = TJ * 16;
-    constexpr int kWgChunk = wg_chunk(CI + CJ);
+    constexpr int kWgChunk = wg_chunk(CI + CJ) > 16 * WK ? wg_chunk(CI + CJ) : 16 * WK;  // >= either flavour's chunk
     const int ty = (cin + CI - 1) / CI, tz = (cout + CJ - 1) / CJ;
     // ~3 workgroups per CU; fewer, longer slabs when the dW block is large (every workgroup ends with CI*CJ float atomics)
     int64_t slabs = 768 / ((int64_t)ty * tz);
@@ -441,11 +475,14 @@ static void launch_wgrad(ps_context* c, const float* x, int ldx, const float* dy
     const int64_t nb = (R + rpb - 1) / rpb;
     // float4 staging needs every row start and block origin on a 16-byte boundary (CI, CJ are multiples of 16 already)
     const bool vec = ((cin | cout | ldx | lddy) & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
-    if (vec)
-        hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WK, true>), dim3((unsigned)nb, ty, tz), dim3(256), 0, c->stream, x, ldx, dy, lddy, R, cin, cout, rpb, dW, db);
-    else
-        hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WK, false>), dim3((unsigned)nb, ty, tz), dim3(256), 0, c->stream, x, ldx, dy, lddy, R, cin, cout, rpb, dW,
-                           db);
+    const dim3 grid((unsigned)nb, ty, tz);
+#define PS_WGK(V, B) hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WK, V, B>), grid, dim3(256), 0, c->stream, x, ldx, dy, lddy, R, cin, cout, rpb, dW, db)
+    if (c->train_bf16) {
+        if (vec) PS_WGK(true, true); else PS_WGK(false, true);
+    } else {
+        if (vec) PS_WGK(true, false); else PS_WGK(false, false);
+    }
+#undef PS_WGK
 }
 
 // ---- scatter-add of gathered rows (backward of tf.batch_gather) ---------------------------------------------------

@@ -24,6 +24,10 @@ namespace ps {
 struct PackedLinear {
     const float* wp = nullptr;  // device
     const float* wq = nullptr;  // device, k-permuted image (nullptr when cin % 16 != 0)
+    // device, bf16 image for the training step's "bf16 MLP" mode (BASELINE configs[2]); when set, the direct-load kernel rounds the
+    // activations to bf16 on the fly and runs v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  8 bf16 per (column block cb, chunk c,
+    // half s, lane l, tile j):  wb[(((cb*NC + c)*2 + s)*64 + l)*NTB + j][t] = bf16(W[c*64 + 16*(l>>4) + 8s + t][(cb*NTB + j)*16 + (l&15)])
+    const void* wb = nullptr;
     const float* bias = nullptr;  // device [cout_pad] (zeros when the layer has no bias)
     int cin = 0, cout = 0;
     int ks = 0;       // k-steps = ceil(cin/4)
@@ -34,6 +38,7 @@ struct PackedLinear {
     size_t packed_floats() const { return (size_t)cblocks * ks * 64 * ntb; }
     int nchunks() const { return (cin + 63) / 64; }
     size_t kperm_floats() const { return (size_t)cblocks * nchunks() * 16 * 64 * ntb; }
+    size_t bf16_bytes() const { return (size_t)cblocks * nchunks() * 2 * 64 * ntb * 16; }
     int cout_pad() const { return cblocks * ntb * 16; }
 };
 

@@ -158,6 +158,109 @@ __global__ __launch_bounds__(256) void rowgemm_direct_kernel(RowGemmArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// bf16 flavour of the direct-load kernel (training step, "bf16 MLPs"): same row ownership and epilogue; a lane's 16 channels of a
+// chunk are two 8-wide k-groups of v_mfma_f32_16x16x32_bf16 (lane (row, g) supplies k = 8g..8g+7), rounded to bf16 (RNE,
+// v_cvt_pk_bf16_f32) as they leave the load registers; the weights come pre-rounded in the matching order (PackedLinear::wb).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bf16x8 to_bf16x8(const float4& a, const float4& b)
+{
+    const bf16x2 p0 = __builtin_convertvector(f32x2v{a.x, a.y}, bf16x2), p1 = __builtin_convertvector(f32x2v{a.z, a.w}, bf16x2);
+    const bf16x2 p2 = __builtin_convertvector(f32x2v{b.x, b.y}, bf16x2), p3 = __builtin_convertvector(f32x2v{b.z, b.w}, bf16x2);
+    bf16x8 r;
+    r[0] = p0[0]; r[1] = p0[1]; r[2] = p1[0]; r[3] = p1[1]; r[4] = p2[0]; r[5] = p2[1]; r[6] = p3[0]; r[7] = p3[1];
+    return r;
+}
+
+template <int NTB, int RT>
+__global__ __launch_bounds__(256) void rowgemm_direct_bf16_kernel(RowGemmArgs a)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int arow = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x * 4 + wave;
+    const int row0 = tile * (16 * RT);
+    if (row0 >= a.R) return;
+    const int cb = blockIdx.y;
+    const int nchunks = (a.cin + 63) >> 6;
+    const float* p1[RT];
+    const float* p2[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int r = min(row0 + rt * 16 + arow, a.R - 1);
+        const int s1 = a.g1 ? (a.g1m ? (r / a.g1m) * a.g1n : 0) + a.g1[r] : r;
+        p1[rt] = a.x1 + (size_t)s1 * a.ld1;
+        if (a.c2) {
+            const int s2 = a.g2 ? (a.g2m ? (r / a.g2m) * a.g2n : 0) + a.g2[r] : r;
+            p2[rt] = a.x2 + (size_t)s2 * a.ld2 - a.c1;
+        } else
+            p2[rt] = p1[rt];
+    }
+    auto load_chunk = [&](int c, float4 (&v)[RT][4]) {
+        const int k = c * 64 + g * 16;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            if (k < a.cin) {
+                const float4* src = reinterpret_cast<const float4*>((k < a.c1 ? p1[rt] : p2[rt]) + k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[rt][i] = src[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[rt][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    f32x4 acc[RT][NTB];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8* wb = reinterpret_cast<const bf16x8*>(a.wp) + ((size_t)cb * nchunks * 2 * 64 + lane) * NTB;
+    float4 cur[RT][4], nxt[RT][4];
+    load_chunk(0, cur);
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) load_chunk(c + 1, nxt);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 b[NTB];
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) b[j] = wb[((size_t)(c * 2 + s) * 64) * NTB + j];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const bf16x8 av = to_bf16x8(cur[rt][2 * s], cur[rt][2 * s + 1]);
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[j], acc[rt][j], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur[rt][i] = nxt[rt][i];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) {
+        const int col = (cb * NTB + j) * 16 + (lane & 15);
+        if (col >= a.cout) continue;
+        const float bb = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + rt * 16 + g * 4 + r;
+                if (row < a.R) {
+                    float v = acc[rt][j][r] + bb;
+                    if (a.leaky) v = leaky02(v);
+                    if (a.accum) v += a.y[(size_t)row * a.ldy + col];
+                    a.y[(size_t)row * a.ldy + col] = v;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 template <int NTB>
 __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a)
 {
@@ -519,9 +622,28 @@ int rowgemm(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc
     a.cin = L.cin; a.cout = L.cout; a.ks = L.ks; a.R = (int)R; a.leaky = L.leaky;
     a.accum = L.accum;
 
-    const bool direct = L.wq && L.cin % 16 == 0 && s1.c % 16 == 0 && s1.ld % 4 == 0 && aligned16(s1.x) &&
+    const bool direct = (L.wq || L.wb) && L.cin % 16 == 0 && s1.c % 16 == 0 && s1.ld % 4 == 0 && aligned16(s1.x) &&
                         (s2.c == 0 || (s2.ld % 4 == 0 && aligned16(s2.x)));
-    if (direct) {
+    if (direct && L.wb) {
+        a.wp = static_cast<const float*>(L.wb);
+        const int64_t tiles16 = (R + 15) / 16;
+        const bool rt2 = tiles16 * L.cblocks >= 8192;
+#define PS_LAUNCH_BF(NTB, RT, GX) hipLaunchKernelGGL((rowgemm_direct_bf16_kernel<NTB, RT>), dim3((unsigned)(GX), L.cblocks), dim3(256), 0, c->stream, a)
+#define PS_BF_BY_NTB(RT, GX)                                                 \
+    switch (L.ntb) {                                                         \
+        case 1: PS_LAUNCH_BF(1, RT, GX); break;                              \
+        case 2: PS_LAUNCH_BF(2, RT, GX); break;                              \
+        case 4: PS_LAUNCH_BF(4, RT, GX); break;                              \
+        default: set_error("rowgemm: bad ntb %d", L.ntb); return PS_EINVAL;  \
+    }
+        if (rt2) {
+            PS_BF_BY_NTB(2, (tiles16 + 7) / 8)
+        } else {
+            PS_BF_BY_NTB(1, (tiles16 + 3) / 4)
+        }
+#undef PS_BF_BY_NTB
+#undef PS_LAUNCH_BF
+    } else if (direct) {
         a.wp = L.wq;
         const int64_t tiles16 = (R + 15) / 16;
         const bool splitk = L.cin >= 256 && tiles16 * L.cblocks < 2048;

@@ -276,9 +276,15 @@ class Tape:
 class Trainer:
     """Parameters (flat fp32 buffer + named views), Adam state and the train step."""
 
-    def __init__(self, config, params=None, device=0, seed=0, learning_rate=None, class_weights=None, keep_prob=0.5, ctx=None, sync_bn=False):
+    def __init__(self, config, params=None, device=0, seed=0, learning_rate=None, class_weights=None, keep_prob=0.5, ctx=None, sync_bn=False,
+                 mlp_dtype="fp32"):
         """sync_bn: with a `dist` passed to train_step, BatchNorm uses the statistics of all ranks' rows, which makes "W GPUs x
-        one cloud" numerically the same step as "one GPU x W clouds" (SURVEY 8e); off = per-GPU statistics."""
+        one cloud" numerically the same step as "one GPU x W clouds" (SURVEY 8e); off = per-GPU statistics.
+        mlp_dtype: "fp32" (default) or "bf16" -- BASELINE configs[2]'s "bf16 MLPs": the shared-MLP GEMMs (forward, input gradient,
+        weight gradient) round their operands to bf16 and accumulate in fp32 (ps_set_train_gemm_bf16); everything else stays fp32."""
+        if mlp_dtype not in ("fp32", "bf16"):
+            raise ValueError("mlp_dtype must be 'fp32' or 'bf16'")
+        self.mlp_bf16 = mlp_dtype == "bf16"
         self.sync_bn = bool(sync_bn)
         self.cfg = config
         self.device = torch.device("cuda", device)
@@ -392,13 +398,19 @@ class Trainer:
         torch.distributed) the flat gradient buffer is averaged over ranks with one all-reduce before Adam."""
         lib, h = _lib.lib(), self.ctx.handle
         t = Tape(self.ctx, sync=dist if (self.sync_bn and dist is not None) else None)
-        logits = self.forward(t, pyr, features)
-        R, C = logits.shape
-        loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
-        dlogits = torch.empty_like(logits)
-        lab = labels.reshape(-1).to(torch.int32).contiguous()
-        _lib.check(lib.ps_op_weighted_ce(h, _p(logits), _p(lab), _p(self.class_weights), R, C, _p(loss), _p(dlogits)))
-        t.backward(logits, dlogits)
+        if self.mlp_bf16:
+            _lib.check(lib.ps_set_train_gemm_bf16(h, 1))
+        try:
+            logits = self.forward(t, pyr, features)
+            R, C = logits.shape
+            loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
+            dlogits = torch.empty_like(logits)
+            lab = labels.reshape(-1).to(torch.int32).contiguous()
+            _lib.check(lib.ps_op_weighted_ce(h, _p(logits), _p(lab), _p(self.class_weights), R, C, _p(loss), _p(dlogits)))
+            t.backward(logits, dlogits)
+        finally:
+            if self.mlp_bf16:  # the context may be shared with inference-side op calls: never leave the mode on
+                _lib.check(lib.ps_set_train_gemm_bf16(h, 0))
         if dist is not None:
             allreduce_mean_(self.grad, dist)
         self.step += 1

@@ -11,7 +11,7 @@ pairs = {"prof_pipe/pipe_kernel_stats.csv": "r1_bench_kernel_stats.csv", "prof_s
          "r1_pmc_per_kernel.json": "r1_pmc_per_kernel.json", "r1_pmc_traffic.json": "r1_pmc_traffic.json", "r1_sq_counters.txt": "r1_sq_counters.txt",
          "r1_bench_line.json": "r1_bench_line.json", "r1_bench_line_serial.json": "r1_bench_line_serial.json",
          "r1_bench_line_config5.json": "r1_bench_line_config5.json", "r1_bench_line_train_b8.json": "r1_bench_line_train_b8.json",
-         "r1_bench_line_train_b1.json": "r1_bench_line_train_b1.json"}
+         "r1_bench_line_train_b1.json": "r1_bench_line_train_b1.json", "r1_bench_line_train_b8_bf16.json": "r1_bench_line_train_b8_bf16.json"}
 for s, d in pairs.items():
     cand = glob.glob(os.path.join(src, "**", os.path.basename(s)), recursive=True) if not os.path.exists(os.path.join(src, s)) else [os.path.join(src, s)]
     if not cand:

@@ -17,5 +17,6 @@ python3 bench.py --steps 200 --warmup 20 2>/dev/null | tail -1 > gpurun_out/r1_b
 python3 bench.py --steps 30 --warmup 3 --no-pipeline --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_bench_line_serial.json
 python3 bench.py --workload config5 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_bench_line_config5.json
 python3 bench.py --mode train --batch 8 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_bench_line_train_b8.json
+python3 bench.py --mode train --batch 8 --bf16-mlp --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_bench_line_train_b8_bf16.json
 python3 bench.py --mode train --batch 1 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_bench_line_train_b1.json
 ls -la gpurun_out | head -40

@@ -10,7 +10,7 @@ import netcase
 pytestmark = pytest.mark.gpu
 
 
-def _setup(cfg, xyz, feats, seed=3, lr=1e-3, keep_prob=1.0, labels=None, sync_bn=False, oracle_pyramid=True):
+def _setup(cfg, xyz, feats, seed=3, lr=1e-3, keep_prob=1.0, labels=None, sync_bn=False, oracle_pyramid=True, mlp_dtype="fp32"):
     import torch
     from oracle import bindings as ob
     from oracle import randla_oracle as ro
@@ -22,7 +22,7 @@ def _setup(cfg, xyz, feats, seed=3, lr=1e-3, keep_prob=1.0, labels=None, sync_bn
     if labels is None:
         labels = rng.integers(0, cfg.num_classes, xyz.shape[:2]).astype(np.int32)
     cw = np.linspace(1.0, 2.0, cfg.num_classes).astype(np.float32)
-    tr = Trainer(cfg, params=params, learning_rate=lr, class_weights=cw, keep_prob=keep_prob, sync_bn=sync_bn)
+    tr = Trainer(cfg, params=params, learning_rate=lr, class_weights=cw, keep_prob=keep_prob, sync_bn=sync_bn, mlp_dtype=mlp_dtype)
     pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
     host_pyr = None
     if oracle_pyramid:
@@ -285,3 +285,54 @@ def test_row_strided_variants_match_the_dense_ops():
     _lib.check(L.ps_op_scatter_add_rows_ex(h, p(drows[:, d:]), 2 * d, p(idx), B, N, M * K, d, p(acc)))
     assert torch.allclose(acc, acc_ref, rtol=0, atol=1e-5)
     torch.cuda.synchronize()
+
+
+def test_bf16_mlp_mode_rounds_operands_and_accumulates_in_fp32():
+    """ps_set_train_gemm_bf16: the GEMM ops equal a float64 GEMM of the bf16-rounded operands (so the only error left is the fp32
+    accumulation), they differ from the fp32 result by bf16 rounding, and a whole training step in that mode stays close to the
+    fp32 step (loss within 1 %, gradient direction cosine > 0.99)."""
+    import ctypes
+    import torch
+    from point_unet_amd import _lib, runtime
+    L, ctx = _lib.lib(), runtime.default_context(0)
+    h = ctx.handle
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(9)
+    rb = lambda t: t.bfloat16().double()  # noqa: E731  (round-to-nearest-even, like v_cvt_pk_bf16_f32)
+    try:
+        _lib.check(L.ps_set_train_gemm_bf16(h, 1))
+        for R, cin, cout in [(5000, 64, 64), (777, 128, 256), (333, 16, 32), (4099, 32, 16), (100, 512, 128)]:
+            x, W = torch.randn(R, cin, generator=g).cuda(), (torch.randn(cin, cout, generator=g) / cin ** 0.5).cuda()
+            b = torch.randn(cout, generator=g).cuda()
+            y = torch.empty(R, cout).cuda()
+            _lib.check(L.ps_op_conv1x1(h, p(x), p(W), p(b), R, cin, cout, 0, p(y)))
+            ref = rb(x) @ rb(W) + b.double()
+            assert (y.double() - ref).abs().max() <= 2e-5 * ref.abs().max(), (R, cin, cout)
+            full = x.double() @ W.double() + b.double()
+            assert 1e-5 * full.abs().max() < (y.double() - full).abs().max() < 3e-2 * full.abs().max()  # it IS a bf16 product
+            dy = torch.randn(R, cout, generator=g).cuda()
+            dW, db = torch.empty(cin, cout).cuda(), torch.empty(cout).cuda()
+            _lib.check(L.ps_op_linear_wgrad(h, p(x), p(dy), R, cin, cout, p(dW), p(db)))
+            ref = rb(x).T @ rb(dy)
+            assert (dW.double() - ref).abs().max() <= 1e-4 * ref.abs().max(), (R, cin, cout)
+            assert (db.double() - dy.double().sum(0)).abs().max() <= 1e-4 * dy.double().sum(0).abs().max() + 1e-4   # bias sums stay fp32
+        # layers the bf16 kernel does not cover (channel count not a multiple of 16) stay exact fp32
+        x, W = torch.randn(1000, 10, generator=g).cuda(), torch.randn(10, 8, generator=g).cuda()
+        y = torch.empty(1000, 8).cuda()
+        _lib.check(L.ps_op_conv1x1(h, p(x), p(W), None, 1000, 10, 8, 0, p(y)))
+        assert (y.double() - x.double() @ W.double()).abs().max() < 1e-5
+    finally:
+        _lib.check(L.ps_set_train_gemm_bf16(h, 0))
+    from point_unet_amd.train import Trainer
+    cfg, xyz, feats = netcase.small_deep(12000, seed=4, B=1)
+    labels = np.random.default_rng(3).integers(0, cfg.num_classes, xyz.shape[:2]).astype(np.int32)
+    out = {}
+    for mode in ("fp32", "bf16"):
+        tr, pyr, params, _, cw, _ = _setup(cfg, xyz, feats, labels=labels, oracle_pyramid=False, mlp_dtype=mode)
+        loss = tr.train_step(pyr, torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda())
+        torch.cuda.synchronize()
+        out[mode] = (float(loss), tr.grad.double().cpu())
+    assert abs(out["bf16"][0] - out["fp32"][0]) <= 1e-2 * abs(out["fp32"][0])
+    cos = float((out["bf16"][1] * out["fp32"][1]).sum() / (out["bf16"][1].norm() * out["fp32"][1].norm()))
+    assert cos > 0.99, cos
+    assert not torch.equal(out["bf16"][1], out["fp32"][1])
