@@ -261,6 +261,119 @@ __global__ __launch_bounds__(256) void rowgemm_direct_bf16_kernel(RowGemmArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Streaming flavour for the training step's [N*K, d] GEMMs (millions of rows, <= 128 input channels, one plain source): these
+// are HBM-bound, and the one-shot kernels above (a wave loads 32 rows, multiplies, stores, exits) leave the loads exposed.
+// Here a workgroup keeps the column block's packed weights in LDS and its waves walk the row tiles persistently with the
+// NEXT tile's rows (and, when accumulating, this tile's old output) in flight under the current tile's MFMAs and stores.
+template <int NTB, bool BF16>
+__global__ __launch_bounds__(256) void rowgemm_stream_kernel(RowGemmArgs a)
+{
+    using bfrag = typename BFrag<NTB>::type;
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    __shared__ __attribute__((aligned(16))) float wl[2 * 16 * 64 * 4];  // 32 KiB: fp32 image of <= 128 channels x 64 columns
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int arow = lane & 15, g = lane >> 4;
+    const int cb = blockIdx.y;
+    const int nchunks = (a.cin + 63) >> 6;  // 1 or 2
+    {
+        // this column block's weights: fp32 [nchunks][16][64][NTB] floats, bf16 [nchunks][2][64][NTB] x 8 bf16 (= 4 floats)
+        const int nf = BF16 ? nchunks * 2 * 64 * NTB * 4 : nchunks * 16 * 64 * NTB;
+        const float4* src = reinterpret_cast<const float4*>(a.wp + (size_t)cb * nf);
+        for (int i = threadIdx.x; i < nf / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = src[i];
+    }
+    __syncthreads();
+    const int ntiles = (a.R + 15) >> 4;
+    const int stride = gridDim.x * 4;
+    auto load_tile = [&](int t, float4 (&v)[2][4]) {
+        const int r = min(t * 16 + arow, a.R - 1);
+        const float* p = a.x1 + (size_t)r * a.ld1 + g * 16;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (c < nchunks) {
+                if (c * 64 + g * 16 < a.cin) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[c][i] = reinterpret_cast<const float4*>(p + c * 64)[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[c][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+    };
+    float bias[NTB];
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) {
+        const int col = (cb * NTB + j) * 16 + (lane & 15);
+        bias[j] = (a.bias && col < a.cout) ? a.bias[col] : 0.f;
+    }
+    int t = blockIdx.x * 4 + wave;
+    float4 cur[2][4], nxt[2][4];
+    if (t < ntiles) load_tile(t, cur);
+    for (; t < ntiles; t += stride) {
+        const int row0 = t * 16;
+        float old[NTB][4];
+        if (a.accum) {
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) {
+                const int col = (cb * NTB + j) * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + g * 4 + r;
+                    old[j][r] = (row < a.R && col < a.cout) ? a.y[(size_t)row * a.ldy + col] : 0.f;
+                }
+            }
+        }
+        if (t + stride < ntiles) load_tile(t + stride, nxt);
+        f32x4 acc[NTB];
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (c < nchunks) {
+                if constexpr (BF16) {
+                    const bf16x8* w = reinterpret_cast<const bf16x8*>(wl) + ((size_t)c * 2 * 64 + lane) * NTB;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8 av = to_bf16x8(cur[c][2 * s2], cur[c][2 * s2 + 1]);
+#pragma unroll
+                        for (int j = 0; j < NTB; ++j)
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[(size_t)s2 * 64 * NTB + j], acc[j], 0, 0, 0);
+                    }
+                } else {
+                    const bfrag* w = reinterpret_cast<const bfrag*>(wl) + (size_t)c * 16 * 64 + lane;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bfrag b = w[(size_t)(i * 4 + q) * 64];
+                            const float av = q == 0 ? cur[c][i].x : (q == 1 ? cur[c][i].y : (q == 2 ? cur[c][i].z : cur[c][i].w));
+#pragma unroll
+                            for (int j = 0; j < NTB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bfrag_get<NTB>(b, j), acc[j], 0, 0, 0);
+                        }
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) {
+            const int col = (cb * NTB + j) * 16 + (lane & 15);
+            if (col >= a.cout) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + g * 4 + r;
+                if (row < a.R) {
+                    float v = acc[j][r] + bias[j];
+                    if (a.leaky) v = leaky02(v);
+                    if (a.accum) v += old[j][r];
+                    a.y[(size_t)row * a.ldy + col] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cur[c][i] = nxt[c][i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 template <int NTB>
 __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a)
 {
@@ -624,7 +737,22 @@ int rowgemm(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc
 
     const bool direct = (L.wq || L.wb) && L.cin % 16 == 0 && s1.c % 16 == 0 && s1.ld % 4 == 0 && aligned16(s1.x) &&
                         (s2.c == 0 || (s2.ld % 4 == 0 && aligned16(s2.x)));
-    if (direct && L.wb) {
+    // the training step's [N*K, d] GEMMs: persistent streaming kernel (never reached by inference-sized calls)
+    const bool stream = direct && !s1.gather && s2.c == 0 && L.cin <= 128 && ((R + 15) / 16) * L.cblocks >= 32768;
+    if (stream) {
+        a.wp = L.wb ? static_cast<const float*>(L.wb) : L.wq;
+        const dim3 grid(1024, L.cblocks);  // 4 workgroups per CU, every wave walks ~(tiles / 4096) row tiles
+#define PS_STREAM(NTB)                                                                                                      \
+    if (L.wb) hipLaunchKernelGGL((rowgemm_stream_kernel<NTB, true>), grid, dim3(256), 0, c->stream, a);                       \
+    else hipLaunchKernelGGL((rowgemm_stream_kernel<NTB, false>), grid, dim3(256), 0, c->stream, a)
+        switch (L.ntb) {
+            case 1: PS_STREAM(1); break;
+            case 2: PS_STREAM(2); break;
+            case 4: PS_STREAM(4); break;
+            default: set_error("rowgemm: bad ntb %d", L.ntb); return PS_EINVAL;
+        }
+#undef PS_STREAM
+    } else if (direct && L.wb) {
         a.wp = static_cast<const float*>(L.wb);
         const int64_t tiles16 = (R + 15) / 16;
         const bool rt2 = tiles16 * L.cblocks >= 8192;

@@ -336,3 +336,36 @@ def test_bf16_mlp_mode_rounds_operands_and_accumulates_in_fp32():
     cos = float((out["bf16"][1] * out["fp32"][1]).sum() / (out["bf16"][1].norm() * out["fp32"][1].norm()))
     assert cos > 0.99, cos
     assert not torch.equal(out["bf16"][1], out["fp32"][1])
+
+
+def test_streaming_gemm_for_millions_of_rows():
+    """The [N*K, d] GEMMs of the training step (>= 524 288 rows x column blocks, <= 128 input channels) run the persistent
+    streaming kernel: fp32 and bf16 flavours, strided input, the accumulate epilogue, ragged last tile."""
+    import ctypes
+    import torch
+    from point_unet_amd import _lib, runtime
+    L, ctx = _lib.lib(), runtime.default_context(0)
+    h = ctx.handle
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for R, cin, cout, wide in [(600_007, 64, 64, 64), (530_001, 16, 16, 32), (300_011, 128, 128, 128), (540_000, 32, 64, 48)]:
+        buf = torch.randn(R, wide, generator=g, device="cuda")
+        x = buf[:, wide - cin:]
+        W = torch.randn(cin, cout, generator=g, device="cuda") / cin ** 0.5
+        b = torch.randn(cout, generator=g, device="cuda")
+        ref = x.double() @ W.double() + b.double()
+        y = torch.empty(R, cout, device="cuda")
+        _lib.check(L.ps_op_conv1x1_ex(h, p(x), wide, p(W), p(b), R, cin, cout, 0, 0, p(y), cout))
+        assert (y.double() - ref).abs().max() <= 2e-5 * ref.abs().max(), (R, cin, cout)
+        _lib.check(L.ps_op_conv1x1_ex(h, p(x), wide, p(W), p(b), R, cin, cout, 1, 1, p(y), cout))   # y += lrelu(...)
+        want = ref + torch.nn.functional.leaky_relu(ref, 0.2)
+        assert (y.double() - want).abs().max() <= 4e-5 * want.abs().max(), (R, cin, cout)
+        try:
+            _lib.check(L.ps_set_train_gemm_bf16(h, 1))
+            _lib.check(L.ps_op_conv1x1_ex(h, p(x), wide, p(W), p(b), R, cin, cout, 0, 0, p(y), cout))
+        finally:
+            _lib.check(L.ps_set_train_gemm_bf16(h, 0))
+        refb = x.bfloat16().double() @ W.bfloat16().double() + b.double()
+        assert (y.double() - refb).abs().max() <= 2e-5 * refb.abs().max(), (R, cin, cout)
+        del buf, x, y, ref, refb, want
+    torch.cuda.synchronize()
