@@ -109,17 +109,24 @@ def cpu_baseline(cfg, xyz, feats, params):
     runs it at batch 1 (knn_.cxx:108 parallelises over the batch only), then the NumPy fp32 forward."""
     from oracle import bindings as ob
     from oracle import randla_oracle as ro
-    t0 = time.perf_counter()
-    pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: ob.knn_batch(s, q, k, threads=1), xyz, cfg.k_n,
-                                          cfg.sub_sampling_ratio[:cfg.num_layers])
-    t1 = time.perf_counter()
-    ro.inference(params, cfg.num_layers, pts, nbr, pool, up, feats, np.float32)
-    t2 = time.perf_counter()
+    t_knn = t_net = 0.0
+    clouds = 0
+    while clouds < 4 and (clouds == 0 or t_knn + t_net < 10.0):  # the same cloud again: ~10-15 s of CPU work for a steadier rate
+        t0 = time.perf_counter()
+        pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: ob.knn_batch(s, q, k, threads=1), xyz, cfg.k_n,
+                                              cfg.sub_sampling_ratio[:cfg.num_layers])
+        t1 = time.perf_counter()
+        ro.inference(params, cfg.num_layers, pts, nbr, pool, up, feats, np.float32)
+        t2 = time.perf_counter()
+        t_knn += t1 - t0
+        t_net += t2 - t1
+        clouds += 1
     n = xyz.shape[0] * xyz.shape[1]
-    return dict(value=n / (t2 - t0), unit="points/s", cores=os.cpu_count(), kind="port",
-                sample="1 cloud of %d points, full pyramid + forward: KNN pyramid %.2f s on 1 thread (reference threading at "
-                       "batch 1), NumPy fp32 forward %.2f s on up to %d BLAS threads" % (xyz.shape[1], t1 - t0, t2 - t1, os.cpu_count()),
-                knn_seconds=t1 - t0, net_seconds=t2 - t1)
+    return dict(value=clouds * n / (t_knn + t_net), unit="points/s", cores=os.cpu_count(), kind="port",
+                sample="%d x (1 cloud of %d points, full pyramid + forward): KNN pyramid %.2f s per cloud on 1 thread (reference threading "
+                       "at batch 1), NumPy fp32 forward %.2f s per cloud on up to %d BLAS threads" % (clouds, xyz.shape[1], t_knn / clouds,
+                                                                                                    t_net / clouds, os.cpu_count()),
+                knn_seconds=t_knn / clouds, net_seconds=t_net / clouds)
 
 
 def timed_region(step, steps, sync, dist=None):
@@ -200,8 +207,10 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # 200 timed steps = ~0.25 s of forward work: the fill and drain of the four-cloud pipeline (about one serial step, 2 ms) stay
+    # inside the timed region and are amortised to < 1 % instead of ~8 % at 20 steps
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--points", type=int, default=180000)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
