@@ -104,9 +104,25 @@ __global__ __launch_bounds__(256) void knn_kernel(const KnnJob* __restrict__ job
     }
     float dist[K];
     int idx[K];
+    // Self-queries (the queries ARE this tree's points, lanes in leaf order): the K points around the query in leaf order are K
+    // distinct tree points, so the K-th neighbour distance is at most the largest of their distances m.  The list then starts as K
+    // phantom entries at a distance just above m instead of +inf: every true neighbour (d <= m) still enters in visit order and
+    // pushes the phantoms out -- the result, ties included, is that of the same search on a tree with K extra far points --
+    // but sub-trees beyond m are pruned from the first step and the early fill-the-list insertions disappear.
+    float seed = FLT_MAX;
+    if (K > 1 && job.q4 == job.tree.pts && job.nq >= K) {
+        const int w0 = min(max(t - K / 2, 0), job.nq - K);
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float4 p = gload(job.q4 + w0 + j);
+            m = fmaxf(m, sq_dist(qx, qy, qz, p.x, p.y, p.z));
+        }
+        seed = __fadd_rn(__fadd_rn(m, __fmul_rn(m, 1e-6f)), 1e-30f);  // strictly above m (m >= 0)
+    }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        dist[j] = FLT_MAX;
+        dist[j] = seed;
         idx[j] = 0;
     }
     WindowStack st;
