@@ -200,3 +200,40 @@ def test_deferred_checks_flag_unbalanced_cloud_at_synchronize():
         ctx.synchronize()
     ctx.synchronize()  # the failure is reported once
     ctx.close()
+
+
+@pytest.mark.parametrize("K", [4, 16])
+def test_seeded_searches_at_their_size_thresholds(oracle, K):
+    """The seeded bounds of the pyramid's searches (K-NN: K phantom entries above the tightest K-window of the 2K-1 leaf-order
+    neighbours; 1-NN: nearest prefix-subset point among 32 neighbours) switch form at n = K, 2K-1 and 32: clouds around those sizes,
+    on a coarse lattice (ubiquitous equal distances) with duplicated points, must still match the reference loop index for index."""
+    import torch
+    from oracle import randla_oracle as ro
+    from point_unet_amd.helper_tool import ConfigBraTS
+    from point_unet_amd.pyramid import build_pyramid
+
+    class Cfg(ConfigBraTS):
+        num_layers = 2
+        sub_sampling_ratio = [2, 2]
+        k_n = K
+
+    rng = np.random.default_rng(17)
+    sizes = sorted({2 * K, 2 * K + 1, 4 * K - 3, 4 * K - 2, 4 * K - 1, 4 * K, 31, 32, 33, 62, 63, 64, 65, 66, 67, 129, 257})
+    for n0 in [s for s in sizes if s // 2 >= K]:
+        for variant in range(3):
+            if variant == 0:    # coarse lattice: many exactly equal distances
+                xyz = rng.integers(0, 5, (1, n0, 3)).astype(np.float32) / 4
+            elif variant == 1:  # a third of the points duplicated
+                base = rng.random((1, n0, 3)).astype(np.float32)
+                dup = rng.integers(0, n0, n0 // 3)
+                base[0, rng.permutation(n0)[:n0 // 3]] = base[0, dup]
+                xyz = base
+            else:               # a thin line: leaf order is spatial order, the window bound is as tight as it gets
+                xyz = np.zeros((1, n0, 3), np.float32)
+                xyz[0, :, 0] = rng.permutation(n0).astype(np.float32) / n0
+            pyr = build_pyramid(torch.from_numpy(xyz).cuda(), Cfg)
+            torch.cuda.synchronize()
+            pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: oracle.knn_batch(s, q, k), xyz, K, Cfg.sub_sampling_ratio)
+            for i in range(2):
+                assert np.array_equal(pyr.neigh_idx[i].cpu().numpy(), nbr[i]), (n0, variant, i)
+                assert np.array_equal(pyr.interp_idx[i].cpu().numpy(), up[i]), (n0, variant, i)
