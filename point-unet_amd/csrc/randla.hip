@@ -80,6 +80,7 @@ struct ps_randla {
     int64_t blob_floats = 0;
     bool have_weights = false;
     DevBuf wbuf;
+    ChainCache chains;  // re-ordered weight images of the register-resident layer chains (regchain.hip)
     PackedLinear fc0, decoder0, fc1, fc2, fc;
     std::vector<EncLevel> enc;
     std::vector<PackedLinear> dec;
@@ -161,6 +162,7 @@ extern "C" int ps_randla_destroy(ps_randla* net)
     (void)hipSetDevice(net->ctx->device);
     (void)hipStreamSynchronize(net->ctx->stream);
     net->wbuf.release();
+    net->chains.clear();
     delete net;
     return PS_OK;
 }
@@ -173,6 +175,10 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
     PS_CHECK(count == net->blob_floats, "ps_randla_set_weights: blob has %lld floats, expected %lld", (long long)count, (long long)net->blob_floats);
     ps_context* c = net->ctx;
     PS_HIP(hipSetDevice(c->device));
+    if (!net->chains.entries.empty()) {  // images derived from the old weights: drop them once nothing in flight reads them
+        PS_HIP(hipStreamSynchronize(c->stream));
+        net->chains.clear();
+    }
     std::vector<float> host;  // packed image of everything, then one upload
     struct Pending { PackedLinear* L; size_t wp_off, b_off, wq_off; };
     std::vector<Pending> pend;
@@ -319,7 +325,7 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
         const RowSrc in = src(features, cfg.in_channels, cfg.in_channels);
         if (rowchain_fits(ch, 2, in, none)) {
             Stage st(c, "fc0", 1);
-            PS_TRY(rowchain(c, ch, 2, in, none, B * n[0]));
+            PS_TRY(rowchain(c, ch, 2, in, none, B * n[0], &net->chains));
             mlp1_0_done = true;
         } else {
             Stage st(c, "fc0", 1);
@@ -345,7 +351,8 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
         auto feature_rows = [&](const PackedLinear& mlp, const PackedLinear& top, const RowSrc& in) -> int {
             ChainStep ch[2] = {step(mlp, fg, ldf), step(top, fg + h, ldf)};
             const int nsteps = use_g ? 2 : 1;
-            if (nsteps == 2 && rowchain_fits(ch, 2, in, none)) return rowchain(c, ch, 2, in, none, R);
+            if (nsteps == 2 && rowchain_fits(ch, 2, in, none)) return rowchain(c, ch, 2, in, none, R, &net->chains);
+            if (nsteps == 1 && regchain_fits(ch, 1, in, none)) return rowchain(c, ch, 1, in, none, R, &net->chains);
             PS_TRY(rowgemm(c, mlp, in, none, R, fg, ldf));
             if (use_g) PS_TRY(rowgemm(c, top, src(fg, ldf, h), none, R, fg + h, ldf));
             return PS_OK;
@@ -386,7 +393,7 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
             ch[1].extra = src(X, d_in, d_in);
             const RowSrc in = src(agg, d, d);
             if (rowchain_fits(ch, 2, in, none)) {
-                PS_TRY(rowchain(c, ch, 2, in, none, R));
+                PS_TRY(rowchain(c, ch, 2, in, none, R, &net->chains));
             } else {
                 PS_TRY(rowgemm(c, e.att2mlp, in, none, R, tmp, d));
                 PS_TRY(rowgemm(c, e.mlp2sc, src(tmp, d, d), src(X, d_in, d_in), R, encb[i], 2 * d));
@@ -428,7 +435,7 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
             const RowSrc s1 = src(skip, skip_c, skip_c);
             if (rowchain_fits(ch, 4, s1, s2)) {
                 Stage st(c, "head", 1);
-                PS_TRY(rowchain(c, ch, 4, s1, s2, B * n[lvl]));
+                PS_TRY(rowchain(c, ch, 4, s1, s2, B * n[lvl], &net->chains));
                 tap(40 + j, decb[j], B * n[lvl] * skip_c);
                 return PS_OK;
             }

@@ -9,6 +9,8 @@
 // without materialising the concatenation.
 #pragma once
 
+#include <vector>
+
 #include "common.h"
 
 namespace ps {
@@ -73,6 +75,20 @@ struct ChainStep {
     RowSrc extra;        // extra.x != nullptr: `extra.c` channels of plain rows appended after the previous activations
 };
 bool rowchain_fits(const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2);
-int rowchain(ps_context* c, const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2, int64_t R);
+// register-resident evaluation of the network's own chain shapes (regchain.hip); rowchain() prefers it when the shape matches
+bool regchain_fits(const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2);
+// per-network cache of the chains' re-ordered weight images (built on first use on the caller's stream; clear() when the
+// weights change).  Entries are keyed by the first / last layer's packed weights and the split of the first K axis.
+struct ChainCache {
+    struct Entry { const float* wp0 = nullptr; const float* wp_last = nullptr; int n = 0, ca = 0, cb = 0; DevBuf img; };
+    std::vector<Entry> entries;
+    void clear()
+    {
+        for (auto& e : entries) e.img.release();
+        entries.clear();
+    }
+};
+int regchain(ps_context* c, const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2, int64_t R, ChainCache* cache);
+int rowchain(ps_context* c, const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2, int64_t R, ChainCache* cache = nullptr);
 
 }  // namespace ps

@@ -14,6 +14,7 @@
 #include "rowgemm.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "mfma_tile.h"
 
@@ -631,7 +632,20 @@ __global__ __launch_bounds__(256) void rowchain_kernel(ChainArgs a)
     }
 }
 
+static bool use_regchain()
+{
+    static const bool on = std::getenv("PS_OLD_CHAIN") == nullptr;
+    return on;
+}
+
+static bool lds_chain_fits(const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2);
+
 bool rowchain_fits(const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2)
+{
+    return (use_regchain() && regchain_fits(steps, n_steps, s1, s2)) || lds_chain_fits(steps, n_steps, s1, s2);
+}
+
+static bool lds_chain_fits(const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2)
 {
     if (n_steps < 1 || n_steps > kChainMaxSteps) return false;
     int cur = s1.c + s2.c;
@@ -646,10 +660,11 @@ bool rowchain_fits(const ChainStep* steps, int n_steps, const RowSrc& s1, const 
     return true;
 }
 
-int rowchain(ps_context* c, const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2, int64_t R)
+int rowchain(ps_context* c, const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2, int64_t R, ChainCache* cache)
 {
     if (R <= 0) return PS_OK;
-    PS_CHECK(rowchain_fits(steps, n_steps, s1, s2), "rowchain: the layer chain does not fit (channels above %d or mismatched)", kChainMaxC);
+    if (use_regchain() && regchain_fits(steps, n_steps, s1, s2)) return regchain(c, steps, n_steps, s1, s2, R, cache);
+    PS_CHECK(lds_chain_fits(steps, n_steps, s1, s2), "rowchain: the layer chain does not fit (channels above %d or mismatched)", kChainMaxC);
     PS_CHECK(R < (int64_t)1 << 31, "rowchain: too many rows");
     ChainArgs a = {};
     a.x1 = s1.x; a.g1 = s1.gather; a.ld1 = s1.ld; a.c1 = s1.c; a.g1m = s1.gm; a.g1n = s1.gn;
