@@ -34,18 +34,23 @@ struct KnnJob {
 // (LDS ~100 cycles vs a scratch round trip through L2/HBM) is on the critical path of every query; the first descent
 // pushes ~log2(n/10) entries, of which the shallow ones -- spilled -- are almost always pruned by their `m` alone.
 constexpr int kWin = 8;
+// the spill arrays live in their own object: indexed dynamically, they stay in scratch memory, and as members of WindowStack they
+// kept its sp / lo counters there too (a scratch store per push, a scratch load in front of every pop)
+struct SpillStore {
+    int sid[kStackMax];
+    float sm[kStackMax], s0[kStackMax], s1[kStackMax], s2[kStackMax];
+};
 struct WindowStack {
     typedef __attribute__((address_space(3))) float lds_float;
     lds_float* w;  // LDS base of this thread (already offset by threadIdx.x); word stride = 256 threads
+    SpillStore* sp_;  // entries [0, lo)
     int sp = 0, lo = 0;  // entries [lo, sp) are in LDS at slot (depth % kWin); [0, lo) in scratch
-    int sid[kStackMax];
-    float sm[kStackMax], s0[kStackMax], s1[kStackMax], s2[kStackMax];
     __device__ __forceinline__ bool push(int node, float mm, float a, float b, float c)
     {
         if (sp >= kStackMax) return false;
         if (sp - lo == kWin) {  // spill the oldest windowed entry
             const lds_float* e = w + (lo & (kWin - 1)) * 5 * 256;
-            sid[lo] = __float_as_int(e[0]); sm[lo] = e[256]; s0[lo] = e[512]; s1[lo] = e[768]; s2[lo] = e[1024];
+            sp_->sid[lo] = __float_as_int(e[0]); sp_->sm[lo] = e[256]; sp_->s0[lo] = e[512]; sp_->s1[lo] = e[768]; sp_->s2[lo] = e[1024];
             ++lo;
         }
         lds_float* e = w + (sp & (kWin - 1)) * 5 * 256;
@@ -66,8 +71,8 @@ struct WindowStack {
                 }
             } else {
                 lo = sp;  // the window is empty; this entry comes from scratch
-                if (sm[sp] <= worst) {
-                    node = sid[sp]; mm = sm[sp]; a = s0[sp]; b = s1[sp]; c = s2[sp];
+                if (sp_->sm[sp] <= worst) {
+                    node = sp_->sid[sp]; mm = sp_->sm[sp]; a = sp_->s0[sp]; b = sp_->s1[sp]; c = sp_->s2[sp];
                     return true;
                 }
             }
@@ -167,7 +172,9 @@ __global__ __launch_bounds__(256) void knn_kernel(const KnnJob* __restrict__ job
         dist[j] = seed;
         idx[j] = 0;
     }
+    SpillStore spill;
     WindowStack st;
+    st.sp_ = &spill;
     st.w = (WindowStack::lds_float*)(win + threadIdx.x);
     const bool ok = knn_search_one<K, WindowStack>(job.tree, qx, qy, qz, dist, idx, st);
     if (!ok) gstore(job.overflow, 1);
