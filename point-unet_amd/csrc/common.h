@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -89,7 +90,7 @@ struct ps_context {
     // per-device kernel attributes already raised by this context (dynamic LDS above the default limit)
     bool mid_lds_attr = false;
     size_t chain_lds_attr = 48 * 1024;
-    size_t regchain_lds_attr = 48 * 1024;  // only one regchain shape (level-1 att2-mlp chain) needs more than the default limit
+    std::map<const void*, size_t> regchain_lds_attr;  // per chain kernel (regchain.hip): dynamic-LDS limit already raised on this device
     // deferred status checks (ps_set_deferred_checks): device flags land in pinned slots, validated at ps_synchronize
     bool deferred = false;
     int32_t* h_flags = nullptr;   // pinned [8][4]

@@ -273,9 +273,11 @@ bool regchain_fits(const ChainStep* steps, int n_steps, const RowSrc& s1, const 
 template <class S>
 static int rc_launch(ps_context* c, const RcArgs& a, size_t lds_bytes, int blocks)
 {
-    if (lds_bytes > 48 * 1024 && lds_bytes > c->regchain_lds_attr) {  // (one limit for all shapes: raised to the largest seen)
+    // dynamic LDS above the default limit: raised once per shape and device (a context is bound to one device)
+    size_t& have = c->regchain_lds_attr[reinterpret_cast<const void*>(regchain_kernel<S>)];
+    if (lds_bytes > 48 * 1024 && lds_bytes > have) {
         PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(regchain_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        c->regchain_lds_attr = lds_bytes;
+        have = lds_bytes;
     }
     hipLaunchKernelGGL(regchain_kernel<S>, dim3(blocks), dim3(256), lds_bytes, c->stream, a);
     return PS_OK;
