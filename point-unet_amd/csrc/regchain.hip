@@ -93,15 +93,22 @@ __device__ __forceinline__ void rc_layer(const RcArgs& a, float (&act)[S::maxt()
         f32x4 acc[OT];
 #pragma unroll
         for (int to = 0; to < OT; ++to) acc[to] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (L > 0) __builtin_amdgcn_sched_barrier(0);  // keep this layer's weight reads behind the previous layer's MFMAs
         const float* w = lds + y.w_off + lane;
-        // k-steps outermost: consecutive MFMAs go to different accumulators
+        // k-steps outermost: consecutive MFMAs go to different accumulators.  Wide layers go four output tiles at a time with a
+        // scheduling fence between the groups: the compiler otherwise hoists every weight read of the layer in front of the first
+        // MFMA (394 VGPRs, one wave per SIMD, for the 128-channel layer)
 #pragma unroll
-        for (int ti = 0; ti < IT; ++ti)
+        for (int t0 = 0; t0 < OT; t0 += 4) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int ti = 0; ti < IT; ++ti)
 #pragma unroll
-                for (int to = 0; to < OT; ++to)
-                    acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[((to * IT + ti) * 4 + q) * 64], act[ti][q], acc[to], 0, 0, 0);
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int to = t0; to < (t0 + 4 < OT ? t0 + 4 : OT); ++to)
+                        acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[((to * IT + ti) * 4 + q) * 64], act[ti][q], acc[to], 0, 0, 0);
+            if (t0 + 4 < OT) __builtin_amdgcn_sched_barrier(0);
+        }
         const bool vy = y.y && (y.cout & 3) == 0 && (y.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y.y) & 15) == 0;
 #pragma unroll
         for (int to = 0; to < OT; ++to) {
