@@ -129,6 +129,64 @@ def cpu_baseline(cfg, xyz, feats, params):
                 knn_seconds=t_knn / clouds, net_seconds=t_net / clouds)
 
 
+def spawn_ranks(n, argv, script=None, extra_env=None, poll_s=0.05):
+    """`python bench.py --gpus N` without a launcher: start N FRESH child processes (one rank per GPU) with the rendezvous
+    variables torch.distributed.run would set, relay rank 0's stdout (the JSON line), return the worst child exit code.  The
+    parent has made no GPU call at this point (it never initialises HIP) and nothing is exec'ed: the children are ordinary
+    subprocesses.  A rank that dies takes the others down (they would otherwise wait at a barrier forever): each child is
+    terminated by its own PID."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = script or os.path.abspath(__file__)
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    base.update(extra_env or {})
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout is the line the driver parses; the other ranks print nothing there, anything they do goes to stderr
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    worst = 0
+    alive = set(range(n))
+    out0 = b""
+    try:
+        import threading
+        chunks = []
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        while alive:
+            for r in sorted(alive):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                alive.discard(r)
+                if rc != 0:
+                    worst = worst or rc
+                    for q in sorted(alive):  # a failed rank strands the others at their next barrier
+                        procs[q].terminate()
+            if alive:
+                time.sleep(poll_s)
+        reader.join(timeout=10)
+        out0 = b"".join(chunks)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return worst
+
+
+def ranks_seen(dist, device):
+    """Number of ranks that took part, counted by the collective itself (an all-reduce of ones: RCCL on the GPU box)."""
+    import torch
+    t = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(t)
+    return int(round(float(t.item())))
+
+
 def timed_region(step, steps, sync, dist=None):
     """Times exactly `steps` calls of `step` bracketed by barrier + device sync on both sides; returns the MAX over ranks
     (seconds) and the last step's result.  `sync()` drains the device; `dist` is torch.distributed or None."""
@@ -229,20 +287,37 @@ def main():
     ap.add_argument("--local-bn", action="store_true", help="train mode, N > 1: per-GPU BatchNorm statistics instead of statistics shared by all ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true", help="do not record hipEvents around the stages (A/B of their cost)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend (nccl = RCCL, the default; gloo lets several ranks share ONE GPU for a functional check "
+                         "of the N > 1 path on a single-GPU box together with --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="map every rank onto the GPUs that exist (local_rank %% device_count)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: no launcher set the rendezvous up, so this process (which has not touched the GPU and
+        # never will) starts the N ranks itself and relays rank 0's line
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.share_gpu:
+        local_rank %= max(torch.cuda.device_count(), 1)
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d needs GPU %d but this node exposes %d (use --share-gpu --dist-backend gloo for a functional "
+                         "check on fewer GPUs)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     want_dist = world > 1 or ("MASTER_ADDR" in os.environ and "RANK" in os.environ)  # launched by torch.distributed.run
 
     def init_dist():
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
         return dist
 
     # Training needs the process group from the start.  The forward path has no data-path collective; its process group (the

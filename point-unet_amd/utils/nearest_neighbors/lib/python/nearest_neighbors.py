@@ -12,8 +12,25 @@ import ctypes
 
 import numpy as np
 
-from .....  import _lib
-from ..... import runtime
+def _bind(levels_up):
+    """The ctypes binding and the runtime of the package this file ships in.  Works on both import routes: as
+    `point_unet_amd.utils.nearest_neighbors.lib.python.nearest_neighbors` and -- the reference's own route, PointSegment/helper_tool.py:13-17:
+    `sys.path.append(<package>/utils)` + `import nearest_neighbors.lib.python.nearest_neighbors` -- as a top-level module, where a relative import would
+    climb out of the top-level package: the package is then loaded by its path."""
+    import importlib
+    import importlib.util
+    import os
+    import sys
+    if "point_unet_amd" not in sys.modules:
+        pkg = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), *[os.pardir] * levels_up))
+        spec = importlib.util.spec_from_file_location("point_unet_amd", os.path.join(pkg, "__init__.py"), submodule_search_locations=[pkg])
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["point_unet_amd"] = mod
+        spec.loader.exec_module(mod)
+    return importlib.import_module("point_unet_amd._lib"), importlib.import_module("point_unet_amd.runtime")
+
+
+_lib, runtime = _bind(4)
 
 
 def _run(pts, queries, K):
