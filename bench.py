@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one cloud per GPU: ps_pyramid_build (kd-tree build, K-NN and 1-NN
-search for all 5 levels) followed by ps_randla_forward, with the cloud already resident in HBM.  By default --lanes (3)
+search for all 5 levels) followed by ps_randla_forward, with the cloud already resident in HBM.  By default --lanes (4)
 clouds are in flight per GPU, each on its own HIP stream (point-unet_amd/pipeline.py, the counterpart of the reference's
 tf.data map + prefetch); every timed step still does all of its work inside the timed region, and the line also carries the
 serial per-cloud latency ("serial_ms_per_cloud").  --no-pipeline times serial steps on one stream.  Workload =
@@ -105,28 +105,46 @@ def algorithmic_costs(cfg, n0, B):
 
 
 def cpu_baseline(cfg, xyz, feats, params):
-    """The oracle (port of the reference CPU path) on this host: KNN pyramid single-threaded exactly as the reference
-    runs it at batch 1 (knn_.cxx:108 parallelises over the batch only), then the NumPy fp32 forward."""
+    """The oracle (a port of the reference CPU path) timed on this host's cores, on ONE cloud of the workload.  Two figures
+    (BASELINE.md section 3):
+      value / as shipped   the KNN pyramid on ONE thread -- the reference's own threading at batch 1 (knn_.cxx:108 parallelises over the
+                           batch only) -- plus the network forward on every core (TF-CPU's intra-op pool; here torch-CPU fp32)
+      all_cores            the same with the KNN queries spread over every core as well (OpenMP over queries in the oracle)
+    The NumPy fp32 forward of round 1 is timed once more for continuity ("numpy_net_seconds")."""
+    import torch
     from oracle import bindings as ob
     from oracle import randla_oracle as ro
-    t_knn = t_net = 0.0
-    clouds = 0
-    while clouds < 4 and (clouds == 0 or t_knn + t_net < 10.0):  # the same cloud again: ~10-15 s of CPU work for a steadier rate
-        t0 = time.perf_counter()
-        pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: ob.knn_batch(s, q, k, threads=1), xyz, cfg.k_n,
-                                              cfg.sub_sampling_ratio[:cfg.num_layers])
-        t1 = time.perf_counter()
-        ro.inference(params, cfg.num_layers, pts, nbr, pool, up, feats, np.float32)
-        t2 = time.perf_counter()
-        t_knn += t1 - t0
-        t_net += t2 - t1
-        clouds += 1
+    from oracle import randla_train_oracle as rto
+    cores = os.cpu_count()
+    ratios = cfg.sub_sampling_ratio[:cfg.num_layers]
     n = xyz.shape[0] * xyz.shape[1]
-    return dict(value=clouds * n / (t_knn + t_net), unit="points/s", cores=os.cpu_count(), kind="port",
-                sample="%d x (1 cloud of %d points, full pyramid + forward): KNN pyramid %.2f s per cloud on 1 thread (reference threading "
-                       "at batch 1), NumPy fp32 forward %.2f s per cloud on up to %d BLAS threads" % (clouds, xyz.shape[1], t_knn / clouds,
-                                                                                                    t_net / clouds, os.cpu_count()),
-                knn_seconds=t_knn / clouds, net_seconds=t_net / clouds)
+
+    def knn_leg(threads, qpar):
+        t0 = time.perf_counter()
+        pyr = ro.build_pyramid(lambda s, q, k: ob.knn_batch(s, q, k, threads=threads, qpar=qpar), xyz, cfg.k_n, ratios)
+        return time.perf_counter() - t0, pyr
+
+    t_knn1, (pts, nbr, pool, up) = knn_leg(1, False)
+    t_knn_all, _ = knn_leg(cores, True)
+    torch.set_num_threads(cores)
+    rto.forward(params, cfg.num_layers, pts, nbr, pool, up, feats, torch.float32)  # first call: thread pool start-up, page faults
+    reps, t_net = 0, 0.0
+    while reps < 3 and (reps == 0 or t_net < 6.0):
+        t0 = time.perf_counter()
+        rto.forward(params, cfg.num_layers, pts, nbr, pool, up, feats, torch.float32)
+        t_net += time.perf_counter() - t0
+        reps += 1
+    t_net /= reps
+    t0 = time.perf_counter()
+    ro.inference(params, cfg.num_layers, pts, nbr, pool, up, feats, np.float32)
+    t_numpy = time.perf_counter() - t0
+    return dict(value=n / (t_knn1 + t_net), unit="points/s", cores=cores, kind="port",
+                sample="1 cloud of %d points, full pyramid + forward: KNN pyramid %.2f s on 1 thread (the reference's threading at batch 1, "
+                       "knn_.cxx:108) + torch-CPU fp32 forward %.2f s on %d threads (mean of %d)" % (xyz.shape[1], t_knn1, t_net, cores, reps),
+                knn_seconds=t_knn1, net_seconds=t_net, numpy_net_seconds=t_numpy,
+                all_cores=dict(value=n / (t_knn_all + t_net), unit="points/s", cores=cores,
+                               sample="same cloud: KNN pyramid %.2f s with the queries spread over %d threads + the same forward" % (t_knn_all, cores),
+                               knn_seconds=t_knn_all, net_seconds=t_net))
 
 
 def spawn_ranks(n, argv, script=None, extra_env=None, poll_s=0.05):
@@ -147,7 +165,7 @@ def spawn_ranks(n, argv, script=None, extra_env=None, poll_s=0.05):
     for r in range(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         # rank 0's stdout is the line the driver parses; the other ranks print nothing there, anything they do goes to stderr
-        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else 2))  # 2 = this process's stderr fd
     worst = 0
     alive = set(range(n))
     out0 = b""
@@ -174,7 +192,9 @@ def spawn_ranks(n, argv, script=None, extra_env=None, poll_s=0.05):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    sys.stdout.write(out0.decode(errors="replace"))
+    for line in out0.decode(errors="replace").splitlines():
+        # only rank 0's JSON line goes to stdout; library chatter on its stdout ("[Gloo] Rank 0 is connected ...") goes to stderr
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return worst
 
@@ -215,9 +235,36 @@ def whole_job_value(world, batch_per_gpu, points, steps, elapsed):
     return world * batch_per_gpu * points * steps / elapsed
 
 
+BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
+
+
+def cpu_baseline_train(cfg, params, points, seed=0):
+    """The oracle's training step (torch-CPU fp32 autograd over the reference graph + the oracle KNN pyramid on one thread, as
+    the reference runs it) on ONE cloud of `points` points -- a bounded sample of the B x 180 000-point step."""
+    import torch
+    from oracle import bindings as ob
+    from oracle import randla_oracle as ro
+    from oracle import randla_train_oracle as rto
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    xyz = brats_cloud(points, 4242 + seed)[None]
+    rng = np.random.default_rng(seed)
+    feats = np.concatenate([xyz, rng.standard_normal((1, points, cfg.in_channels - 3)).astype(np.float32)], -1)
+    labels = rng.integers(0, cfg.num_classes, (1, points))
+    t0 = time.perf_counter()
+    pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: ob.knn_batch(s, q, k, threads=1), xyz, cfg.k_n, cfg.sub_sampling_ratio[:cfg.num_layers])
+    t1 = time.perf_counter()
+    rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, np.ones(cfg.num_classes), lr=1e-4, dtype=torch.float32)
+    t2 = time.perf_counter()
+    return dict(value=points / (t2 - t0), unit="points/s", cores=cores, kind="port",
+                sample="one training step (pyramid + forward + backward + Adam) on 1 cloud of %d points: KNN pyramid %.2f s on 1 thread + torch-CPU "
+                       "fp32 autograd step %.2f s on %d threads" % (points, t1 - t0, t2 - t1, cores),
+                knn_seconds=t1 - t0, step_seconds=t2 - t1)
+
+
 def bench_train(args, cfg, rank, local_rank, world, dist):
     """BASELINE configs[2] (--batch 8, 1 GPU) / configs[3] (--gpus 8 --batch 1): one training step = index pyramid +
-    training-mode forward + class-weighted CE + backward + (all-reduce of the flat gradient buffer) + Adam, fp32."""
+    training-mode forward + class-weighted CE + backward + (all-reduce of the flat gradient buffer) + Adam."""
     import torch
     from point_unet_amd import runtime, weights
     from point_unet_amd.pyramid import alloc_pyramid, build_pyramid
@@ -228,10 +275,12 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
     feats = np.concatenate([xyz, rng.standard_normal((B, n0, cfg.in_channels - 3)).astype(np.float32)], -1)
     labels = rng.integers(0, cfg.num_classes, (B, n0)).astype(np.int32)
     ctx = runtime.default_context(local_rank)
-    tr = Trainer(cfg, params=weights.init_params(cfg, seed=2), device=local_rank, ctx=ctx, keep_prob=0.5, sync_bn=world > 1 and not args.local_bn,
+    params = weights.init_params(cfg, seed=2)
+    tr = Trainer(cfg, params=params, device=local_rank, ctx=ctx, keep_prob=0.5, sync_bn=world > 1 and not args.local_bn,
                  mlp_dtype="bf16" if args.bf16_mlp else "fp32")
     d_xyz, d_feats, d_lab = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
     pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
+    seen = ranks_seen(dist, "cuda" if args.dist_backend == "nccl" else "cpu") if dist is not None else 1
 
     def step():
         build_pyramid(d_xyz, cfg, ctx=ctx, out=pyr)
@@ -243,20 +292,54 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
 
     for _ in range(args.warmup):
         step()
+    sync()
+    prof_rows, prof_steps = [], 0
+    if not args.no_stage_timing:  # hipEvent pairs around every op group of two steps, outside the timed region
+        prof_steps = 2
+        ctx.timing_begin()
+        for _ in range(prof_steps):
+            step()
+        sync()
+        prof_rows = ctx.timing_end()
     elapsed, loss = timed_region(step, args.steps, sync, dist)
     assert bool(torch.isfinite(loss).all())
     if rank == 0:
-        print(json.dumps({
+        ms = 1e3 * elapsed / args.steps
+        fwd = algorithmic_costs(cfg, n0, B)
+        net_flops = sum(v["flops"] for k, v in fwd.items() if not k.startswith(("knn", "kdtree", "pyramid")))
+        net_bytes = sum(v["bytes"] for k, v in fwd.items() if not k.startswith(("knn", "kdtree", "pyramid")))
+        # forward + input-gradient + weight-gradient GEMMs: 3 x the forward FLOPs (SURVEY 8d figure x 3); bytes: forward + backward read
+        # every activation once more and write its gradient (x 3)
+        step_flops, step_bytes = 3 * net_flops, 3 * net_bytes
+        peak = BF16_MFMA_PEAK_TF if args.bf16_mlp else F32_MFMA_PEAK_TF
+        tfs, gbs = step_flops / (ms * 1e-3) / 1e12, step_bytes / (ms * 1e-3) / 1e9
+        stages = sorted(({"name": nm, "ms_per_step": round(t / prof_steps, 4), "launches_per_step": ln / prof_steps} for nm, t, ln in prof_rows),
+                        key=lambda r: -r["ms_per_step"])
+        dom = stages[0] if stages else None
+        roofline = {"bound": "mfma" if tfs / peak > gbs / HBM_PEAK_GBS else "hbm", "kernel": "whole training step",
+                    "achieved": round(tfs if tfs / peak > gbs / HBM_PEAK_GBS else gbs, 3), "peak": peak if tfs / peak > gbs / HBM_PEAK_GBS else HBM_PEAK_GBS,
+                    "unit": "TFLOP/s" if tfs / peak > gbs / HBM_PEAK_GBS else "GB/s", "frac": round(max(tfs / peak, gbs / HBM_PEAK_GBS), 5), "traffic": None,
+                    "algorithmic_flops_per_step": step_flops, "algorithmic_bytes_per_step": step_bytes,
+                    "mfma_frac": round(tfs / peak, 5), "hbm_frac": round(gbs / HBM_PEAK_GBS, 5),
+                    "dominant_stage": dom, "measured": "timed region (whole step); stages: hipEvent pairs over %d extra steps" % prof_steps}
+        out = {
             "metric": "points_per_sec_train_step", "value": whole_job_value(world, B, n0, args.steps, elapsed), "unit": "points/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             # bf16: BASELINE configs[2]'s "bf16 MLPs" -- the shared-MLP GEMMs on bf16 operands with fp32 accumulate, the rest fp32
             "dtype": "bf16" if args.bf16_mlp else "f32", "data": "synthetic",
-            "config": {"workload": "training step (pyramid + train-mode forward + weighted CE + backward + Adam), %d-point BraTS-shaped "
-                                   "clouds, batch %d per GPU, K=16, 5 levels, fp32%s" % (n0, B, (", gradient all-reduce over RCCL, BatchNorm statistics %s" % ("per GPU" if args.local_bn else "shared by all ranks")) if world > 1 else ""),
+            "config": {"workload": "BASELINE configs[%d]: training step (pyramid + train-mode forward + weighted CE + backward + Adam), %d-point "
+                                   "BraTS-shaped clouds, batch %d per GPU, K=16, 5 levels, %s%s" % (
+                                       2 if world == 1 else 3, n0, B, "bf16 MLP GEMMs (fp32 accumulate), rest fp32" if args.bf16_mlp else "fp32",
+                                       (", gradient all-reduce over RCCL, BatchNorm statistics %s" % ("per GPU" if args.local_bn else "shared by all ranks")) if world > 1 else ""),
                        "points": n0, "batch_per_gpu": B, "parameters": tr.num_params()},
+            "roofline": roofline, "stages": stages,
             "loss": float(loss), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
-        }))
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_train(cfg, params, min(n0, 45000))
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -285,6 +368,8 @@ def main():
                          "PCIe-inclusive rate DESIGN.md quotes next to the headline (which keeps inputs resident in HBM)")
     ap.add_argument("--bf16-mlp", action="store_true", help="train mode: shared-MLP GEMMs on bf16 operands with fp32 accumulate (BASELINE configs[2])")
     ap.add_argument("--local-bn", action="store_true", help="train mode, N > 1: per-GPU BatchNorm statistics instead of statistics shared by all ranks")
+    ap.add_argument("--clouds", type=int, default=8, help="distinct resident clouds every rank rotates through (one per step)")
+    ap.add_argument("--no-sub-results", action="store_true", help="skip the PCIe-inclusive sub-result of the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true", help="do not record hipEvents around the stages (A/B of their cost)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
@@ -340,14 +425,25 @@ def main():
     B, n0 = args.batch, args.points
     if args.mode == "train":
         return bench_train(args, cfg, rank, local_rank, world, dist)
-    # one volume per GPU: rank r gets cloud(s) seeded by r
-    xyz = np.stack([brats_cloud(n0, 1000 * rank + b) for b in range(B)])
-    mods = np.random.default_rng(7 + rank).standard_normal((B, n0, cfg.in_channels - 3)).astype(np.float32)
-    feats = np.concatenate([xyz, mods], -1)
+    # one volume per GPU and step; every rank rotates through `--clouds` DISTINCT resident clouds (seeded by rank), so a step never
+    # finds its own inputs, trees or index tables from the previous step in L2 / MALL
+    n_clouds = max(1, args.clouds)
+    xyz_all = [np.stack([brats_cloud(n0, 1000 * rank + 17 * i + b) for b in range(B)]) for i in range(n_clouds)]
+    feats_all = [np.concatenate([x, np.random.default_rng(7 + rank + 31 * i).standard_normal((B, n0, cfg.in_channels - 3)).astype(np.float32)], -1)
+                 for i, x in enumerate(xyz_all)]
+    xyz, feats = xyz_all[0], feats_all[0]
     params = weights.init_params(cfg, seed=2, randomize_bn=True)
+    half = args.workload == "config5"  # configs[4]: fp16 feature input
+    d_clouds = [(torch.from_numpy(x).cuda(), torch.from_numpy(f.astype(np.float16) if half else f).cuda()) for x, f in zip(xyz_all, feats_all)]
+    d_xyz, d_feats = d_clouds[0]
+    counter = [0]
 
-    d_xyz = torch.from_numpy(xyz).cuda()
-    d_feats = torch.from_numpy(feats.astype(np.float16) if args.workload == "config5" else feats).cuda()  # configs[4]: fp16 feature input
+    def next_cloud():
+        k = counter[0] % n_clouds
+        counter[0] += 1
+        return k
+
+    pipe = None
     if args.no_pipeline:
         ctx = runtime.default_context(local_rank)
         ctx.set_deferred_checks(True)  # status words of the tree build are validated at ctx.synchronize()
@@ -356,8 +452,9 @@ def main():
         contexts = [ctx]
 
         def step(overlap=True):
-            build_pyramid(d_xyz, cfg, ctx=ctx, out=pyr)
-            return net.inference({"pyramid": pyr, "features": d_feats})
+            x, f = d_clouds[next_cloud()]
+            build_pyramid(x, cfg, ctx=ctx, out=pyr)
+            return net.inference({"pyramid": pyr, "features": f})
 
         def sync():
             ctx.synchronize()
@@ -370,33 +467,40 @@ def main():
         contexts = pipe.contexts
         pipe.prime(d_xyz, d_feats)  # every lane's workspace allocated before the warmup / timed steps
 
-        if args.include_pcie:
-            h_xyz, h_feats = torch.from_numpy(xyz).pin_memory(), torch.from_numpy(feats).pin_memory()
-            h_out = [torch.empty((B, n0, cfg.num_classes), dtype=torch.float32).pin_memory() for _ in range(args.lanes)]
-            d_in = [(torch.empty_like(d_xyz), torch.empty_like(d_feats)) for _ in range(args.lanes)]  # per-lane device input slots
-
-            def step(overlap=True):
-                # host -> device, compute, device -> host all on the lane's own stream (no extra streams: they would compete with the
-                # lanes for hardware queues); the copies of one lane overlap the kernels of the others
-                k = pipe._i % len(pipe.lanes)
-                lane = pipe.lanes[k]
-                dx, df = d_in[k]
-                with torch.cuda.stream(lane.stream):
-                    dx.copy_(h_xyz, non_blocking=True)
-                    df.copy_(h_feats, non_blocking=True)
-                    out = pipe.submit(dx, df, overlap=overlap)
-                    h_out[k].copy_(out, non_blocking=True)
-                return out
-        else:
-            def step(overlap=True):
-                return pipe.submit(d_xyz, d_feats, overlap=overlap)
+        def step(overlap=True):
+            x, f = d_clouds[next_cloud()]
+            return pipe.submit(x, f, overlap=overlap)
 
         def sync():
             pipe.synchronize()
             torch.cuda.synchronize()
 
+    pcie_step = None
+    if pipe is not None and (args.include_pcie or not args.no_sub_results):
+        h_in = [(torch.from_numpy(x).pin_memory(), torch.from_numpy(f.astype(np.float16) if half else f).pin_memory()) for x, f in zip(xyz_all, feats_all)]
+        h_out = [torch.empty((B, n0, cfg.num_classes), dtype=torch.float32).pin_memory() for _ in range(args.lanes)]
+        d_in = [(torch.empty_like(d_xyz), torch.empty_like(d_feats)) for _ in range(args.lanes)]  # per-lane device input slots
+
+        def pcie_step(overlap=True):
+            # host -> device, compute, device -> host all on the lane's own stream (no extra streams: they would compete with the
+            # lanes for hardware queues); the copies of one lane overlap the kernels of the others
+            k = pipe._i % len(pipe.lanes)
+            lane = pipe.lanes[k]
+            dx, df = d_in[k]
+            hx, hf = h_in[next_cloud()]
+            with torch.cuda.stream(lane.stream):
+                dx.copy_(hx, non_blocking=True)
+                df.copy_(hf, non_blocking=True)
+                out = pipe.submit(dx, df, overlap=overlap)
+                h_out[k].copy_(out, non_blocking=True)
+            return out
+    main_step = pcie_step if args.include_pcie else step
+    if args.include_pcie and pcie_step is None:
+        raise SystemExit("--include-pcie needs the pipelined mode")
+
     if want_dist and dist is None:
         dist = init_dist()
+    seen = ranks_seen(dist, "cuda" if args.dist_backend == "nccl" else "cpu") if dist is not None else 1
 
     def timing_begin(only=None):
         for cx in contexts:
@@ -412,7 +516,7 @@ def main():
         return [(k, v[0], v[1]) for k, v in merged.items()]
 
     for _ in range(args.warmup):
-        step()
+        main_step()
     sync()
     # Profile pass (outside the timed region): hipEvent pairs on the launch stream around EVERY stage, steps serialised so
     # that no stage shares the chip with another stream's kernels.  Recording ~120 events per step costs ~0.35 ms of stream
@@ -425,7 +529,7 @@ def main():
             step(overlap=False)
         sync()
         prof_rows = timing_end()
-    # dominant KERNEL = the single-launch stage with the largest time (composite stages such as kdtree_build, ~57 small
+    # dominant KERNEL = the single-launch stage with the largest time (composite stages such as kdtree_build, ~46 small
     # launches, are listed in "stages" but are not one kernel)
     single = [r for r in prof_rows if r[2] == prof_steps]
     dominant = max(single, key=lambda r: r[1])[0] if single else None
@@ -435,12 +539,13 @@ def main():
     # over the serial pass that follows the timed region instead (one cloud in flight, same kernels, same inputs).
     if dominant and args.no_pipeline:
         timing_begin(only=dominant)
-    elapsed, logits = timed_region(step, args.steps, sync, dist)
+    elapsed, logits = timed_region(main_step, args.steps, sync, dist)
     dom_rows, dom_steps, dom_where = [], args.steps, "timed region"
     if dominant and args.no_pipeline:
         dom_rows = [r for r in timing_end() if r[0] == dominant]
     assert bool(torch.isfinite(logits).all())
     serial_ms = None
+    sub = {}
     if not args.no_pipeline:  # per-cloud latency next to the pipelined throughput
         dom_steps, dom_where = max(3, args.steps // 2), "serial pass after the timed region (one cloud in flight)"
         if dominant:
@@ -449,6 +554,13 @@ def main():
         if dominant:
             dom_rows = [r for r in timing_end() if r[0] == dominant]
         serial_ms = 1e3 * t_serial / dom_steps
+        sub["serial"] = {"ms_per_cloud": serial_ms, "points_per_s": B * n0 / (serial_ms * 1e-3), "steps": dom_steps,
+                         "what": "one cloud in flight: every step waits for the previous cloud (per-cloud latency of pyramid + forward on this rank)"}
+        if not args.no_sub_results and not args.include_pcie:
+            t_pcie, _ = timed_region(pcie_step, args.steps, sync, None)
+            sub["include_pcie"] = {"ms_per_step": 1e3 * t_pcie / args.steps, "points_per_s": B * n0 * args.steps / t_pcie, "steps": args.steps,
+                                   "what": "every step also copies its cloud (xyz + features) from pinned host memory and its logits back, on the "
+                                           "lane's stream (this rank only; the service rate -- never the headline value)"}
 
     if rank == 0:
         costs = algorithmic_costs(cfg, n0, B)
@@ -485,9 +597,16 @@ def main():
                             frac=round(max(tfs / F32_MFMA_PEAK_TF, gbs / HBM_PEAK_GBS), 5), traffic=None,
                             ms_per_step=round(t_ms, 4), launches_per_step=n_launch, avg_launch_ms=round(t_ms / max(n_launch, 1), 5),
                             algorithmic_bytes_per_step=cst["bytes"], algorithmic_flops_per_step=cst["flops"], measured=dom_where)
-            pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-            if os.path.exists(pmc):  # HBM bytes per launch from committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-                roofline["traffic"] = json.load(open(pmc)).get(dominant)
+            # HBM bytes per launch cannot be counted from inside this process: they come from separate rocprofv3 --pmc passes of this
+            # same command (profiles/run_pmc.sh; FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), committed with the commit they
+            # were taken at.  The number is labelled with that source; null when no such file exists for this round.
+            pmc = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+            if os.path.exists(pmc):
+                t = json.load(open(pmc))
+                roofline["traffic"] = t.get(dominant)
+                roofline["traffic_source"] = "profiles/r2_pmc_traffic.json: rocprofv3 --pmc passes of `%s` at commit %s (not measured in this run)" % (
+                    t.get("_command", "python bench.py"), t.get("_commit", "?"))
+                roofline["traffic_top_kernels"] = t.get("_top_kernels")
         total_cost = {k: sum(v[k] for v in costs.values()) for k in ("flops", "bytes")}
         dev_ms = sum(s["ms_per_step"] for s in stages)
         # the metric split into its index-pyramid and network halves (serial device time of the profile pass)
@@ -507,6 +626,7 @@ def main():
             "value": whole_job_value(world, B, n0, args.steps, elapsed),
             "unit": "points/s",
             "n_gpus": world,
+            "ranks_seen": seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -521,10 +641,13 @@ def main():
                        "points": n0, "k_n": cfg.k_n, "num_layers": cfg.num_layers, "batch_per_gpu": B, "sharding": "one cloud per GPU, no collective",
                        "pipeline": "serial, one stream" if args.no_pipeline else
                        "%d clouds in flight, one HIP stream each (pyramid + forward per cloud on its stream)" % args.lanes,
-                       "inputs": "pinned host memory, copied per step (PCIe-inclusive)" if args.include_pcie else "resident in HBM"},
+                       "inputs": "pinned host memory, copied per step (PCIe-inclusive)" if args.include_pcie else "resident in HBM",
+                       "distinct_clouds": n_clouds},
             "roofline": roofline,
             "roofline_network": roofline_network,
             "serial_ms_per_cloud": serial_ms,
+            "serial": sub.get("serial"),
+            "include_pcie": sub.get("include_pcie"),
             "device_ms_per_step": round(dev_ms, 4),
             "split": split,
             "algorithmic": {"gflop_per_step": total_cost["flops"] / 1e9, "gbyte_per_step": total_cost["bytes"] / 1e9},

@@ -278,7 +278,9 @@ int ps_op_add_lrelu(ps_context* ctx, const float* a, const float* b, int64_t n, 
 int ps_op_add_lrelu_bwd(ps_context* ctx, const float* dy, const float* y, int64_t n, float* ds);
 int ps_op_axpy(ps_context* ctx, float alpha, const float* x, int64_t n, float* y);
 int ps_op_mul(ps_context* ctx, const float* a, const float* b, int64_t n, float* y);
-/* mean over rows of class_weights[label] * softmax-CE; *loss is a device float; dlogits may be NULL */
+/* class_weights[label] * softmax-CE averaged over the VALID rows (RandLANet.py:62-84, 267-274); a label outside [0, C) marks an
+ * ignored point (cfg.ignored_label_inds: dropped before the loss by the reference): zero weight, zero gradient row, not counted in
+ * the mean.  *loss is a device float; dlogits may be NULL.  Deterministic (no float atomics). */
 int ps_op_weighted_ce(ps_context* ctx, const float* logits, const int32_t* labels, const float* class_weights,
                       int64_t R, int64_t C, float* loss, float* dlogits);
 /* tf.train.AdamOptimizer update, step >= 1 */

@@ -39,6 +39,19 @@ class Network:
         _lib.check(_lib.lib().ps_randla_create(self.ctx.handle, ctypes.byref(cfg), ctypes.byref(self._h)))
         self.set_params(self.params)
 
+    def close(self):
+        """Frees the packed weights and chain caches on the device (ps_randla_destroy); the context stays open."""
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.lib().ps_randla_destroy(h)
+
+    def __del__(self):
+        try:
+            if getattr(self.ctx, "handle", None):  # a closed context has already released everything it owned
+                self.close()
+        except Exception:
+            pass
+
     def set_params(self, params):
         self.params = params
         self.__dict__.pop("_folded", None)

@@ -6,6 +6,16 @@
 
 namespace ps {
 
+// Weight images of one encoder level for the 32x32x2 kernels (attpool32.hip: pack_p32 / pack_p32_locse), device pointers.
+struct Att32Weights {
+    const float* w1 = nullptr;   // LocSE mlp1 (10 -> h)
+    const float* w2 = nullptr;   // LFA mlp2 (h -> h)
+    const float* wb1 = nullptr;  // att_pooling_1 Wfc[h:, :] (h -> d)
+    const float* wb2 = nullptr;  // att_pooling_2 Wfc[h:, :]
+};
+void pack_p32(const float* W, int cin, int cout, float* out);   // [cin, cout] row-major, cin % 8 == 0, cout % 32 == 0 -> cin*cout floats
+void pack_p32_locse(const float* W1, int cout, float* out);     // [10, cout] -> (cout/32)*5*64 floats
+
 struct AttStage {
     const float* xyz = nullptr;      // [n_total, 3]
     const int32_t* idx = nullptr;    // [n_total, k] cloud-local neighbour indices
@@ -19,7 +29,11 @@ struct AttStage {
     float* agg = nullptr;            // [n_total, d]
     int64_t n_total = 0, n_cloud = 0;
     int d = 0, k = 16;
+    const Att32Weights* p32 = nullptr;  // when set (d >= 64, pre-product formulation): the 32x32x2 kernels (attpool32.hip)
 };
+
+bool att_pool32_fits(const AttStage& s);
+int att_pool32_stage(ps_context* c, const AttStage& s);
 
 int att_pool_stage(ps_context* c, const AttStage& s);
 

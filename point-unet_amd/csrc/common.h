@@ -95,6 +95,8 @@ struct ps_context {
     bool deferred = false;
     int32_t* h_flags = nullptr;   // pinned [8][4]
     unsigned pending_mask = 0;
+    uint64_t builds = 0;          // ps_pyramid_build calls on this context so far (error messages name the failing one)
+    uint64_t flag_serial[8] = {}; // which build each pending slot belongs to
     int flag_slot = 0;
     hipEvent_t flag_ev[8] = {};   // recorded behind the copy into each slot: reusing a slot waits for THAT copy, not for the stream
     std::vector<char> host_ring[8];  // host staging kept alive behind asynchronous uploads

@@ -52,15 +52,14 @@ int ps_context::check_flag_slot(int s)
     int rc = PS_OK;
     if (pending_mask & (1u << s)) {
         const int32_t* f = h_flags + 4 * s;
-        if (f[2] != 0) {
-            ps::set_error("deferred check: a kd-tree build needed more levels than are launched blind (very unbalanced cloud); "
-                          "results of the calls since then are invalid -- rebuild with ps_set_deferred_checks(ctx, 0)");
-            rc = PS_ESTATE;
-        } else if (f[1] != 0) {
-            ps::set_error("deferred check: kd-tree builder queue overflow (degenerate cloud)");
+        // (f[2], the "unfinished build" word of the first builder, is always 0: the straggler kernel finishes every tree)
+        if (f[1] != 0) {
+            ps::set_error("deferred check: pyramid build #%llu of this context: kd-tree builder queue overflow (degenerate cloud); its index "
+                          "tables were filled with index 0", (unsigned long long)flag_serial[s]);
             rc = PS_ESTATE;
         } else if (f[0] != 0) {
-            ps::set_error("deferred check: kd-tree deeper than the traversal stack");
+            ps::set_error("deferred check: pyramid build #%llu of this context: kd-tree deeper than the traversal stack (degenerate cloud); "
+                          "its neighbour lists are valid indices but may not be the nearest", (unsigned long long)flag_serial[s]);
             rc = PS_ESTATE;
         }
         pending_mask &= ~(1u << s);

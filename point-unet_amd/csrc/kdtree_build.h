@@ -22,7 +22,6 @@ struct TreeSetPlan {
     void* d_scratch = nullptr;       // builder scratch
     size_t scratch_bytes = 0;
     int launches = 0;                // kernels launched by build_trees (for the stage timer)
-    int first_pending_level = 0;     // first level queue build_trees did not launch a kernel for (build_trees_continue starts there)
     std::vector<char> host_blob;     // host staging of the builder's tables (must outlive the async copies)
 
     void add(int32_t count)
@@ -50,10 +49,10 @@ struct TreeSetPlan {
     }
 };
 
-// Builds every tree of the plan on the context's stream WITHOUT synchronising.  d_flags[2] receives the number of
-// nodes still waiting after the blind level launches; if the caller finds it non-zero after its own synchronisation it
-// must call build_trees_continue() and redo whatever it ran on the unfinished trees.
+// Builds every tree of the plan on the context's stream WITHOUT synchronising.  The build always completes on the device
+// (very unbalanced clouds included: kdtree_build.hip, straggler kernel); d_flags[1] / d_flags[0] report the two degenerate
+// cases that remain (builder queue overflow, tree deeper than the traversal stack) -- even then every search writes valid
+// point indices, so whatever is enqueued behind the build never reads out of bounds.
 int build_trees(ps_context* c, TreeSetPlan& plan);
-int build_trees_continue(ps_context* c, TreeSetPlan& plan);
 
 }  // namespace ps

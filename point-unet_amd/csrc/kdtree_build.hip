@@ -232,13 +232,52 @@ struct BlockRed {
     int scan[2][T / 64];
 };
 
+// Stragglers: a node that is still above kMid points after the chunked levels (lopsided bounding-box-midpoint splits: very
+// unbalanced clouds, dense clusters).  One workgroup takes the node and finishes EVERYTHING above kMid points below it depth
+// first: after a split it keeps one big child and parks the other on a stack in LDS; children of <= kMid points go to the
+// mid / small queues of the kernels that follow.  One launch therefore completes the top of every tree however unbalanced the
+// cloud is -- there is no "unfinished build" state for the host to detect and repair, which is what makes ps_pyramid_build
+// safe to run without host synchronisation (deferred checks): the searches and the network that are enqueued right behind
+// it always see complete trees and write every index.  Stack entries are disjoint ranges of more than kMid points inside
+// the node, so kStragglerStack of them cover a 2^25-point tree with room to spare.
+constexpr int kStragglerStack = 96;
+
+__device__ __forceinline__ void push_small_task(const BuildQueues& Q, const BuildTask& t)
+{
+    if (t.r - t.l > kSmall) {
+        const int slot = atomicAdd(Q.small_cnt + 1, 1);
+        if (slot < Q.q_cap)
+            Q.mid_q[slot] = t;
+        else
+            Q.flags[1] = 1;
+    } else {
+        const int slot = atomicAdd(Q.small_cnt, 1);
+        if (slot < Q.small_cap)
+            Q.small_q[slot] = t;
+        else
+            Q.flags[1] = 1;
+    }
+}
+
 __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTree* __restrict__ trees, BuildQueues Q, int level)
 {
     constexpr int T = kBigThreads, W = T / 64, E = kE;
     __shared__ BlockRed<T> S;
+    __shared__ BuildTask s_stack[kStragglerStack];
+    __shared__ BuildTask s_cur;
+    __shared__ int s_sp;
     const int n_tasks = min(Q.level_cnt[level], Q.q_cap);
     if ((int)blockIdx.x >= n_tasks) return;
-    const BuildTask k = Q.q[level & 1][blockIdx.x];
+    if (threadIdx.x == 0) {
+        s_cur = Q.q[level & 1][blockIdx.x];
+        s_sp = 0;
+    }
+    __syncthreads();
+  for (;;) {
+    BuildTask k;
+    k.tree = s_cur.tree; k.l = s_cur.l; k.r = s_cur.r; k.parent = s_cur.parent; k.side = s_cur.side; k.level = s_cur.level;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { k.lo[c] = s_cur.lo[c]; k.hi[c] = s_cur.hi[c]; }
     const BuildTree t = trees[k.tree];
     const GArr<float4> a{t.pts + k.l};
     const int count = k.r - k.l;
@@ -377,9 +416,31 @@ __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTre
         int id;
         emit_inner(Q, t, k, ax, cut, lim1, lim2, maxlt, mingt, kids, &id);
         link_to_parent(t, k, id);
-        push_task(Q, kids[0], level + 1);
-        push_task(Q, kids[1], level + 1);
+        int sp = s_sp;
+        bool have = false;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (kids[s].r - kids[s].l <= kMid)
+                push_small_task(Q, kids[s]);
+            else if (!have) {
+                s_cur = kids[s];  // carry on with this child
+                have = true;
+            } else if (sp < kStragglerStack)
+                s_stack[sp++] = kids[s];
+            else
+                Q.flags[1] = 1;
+        }
+        if (!have) {
+            if (sp > 0)
+                s_cur = s_stack[--sp];
+            else
+                sp = -1;  // this node is finished down to kMid
+        }
+        s_sp = sp;
     }
+    __syncthreads();
+    if (s_sp < 0) break;
+  }
 }
 
 // ---- subtree kernel: one wave finishes a node of <= kSmall points -----------------------------------------------
@@ -503,7 +564,7 @@ __global__ __launch_bounds__(256) void build_subtree_kernel(const BuildTree* __r
     short* posR = s_posR[wave];
     SubTask* stack = s_stack[wave];
 
-    for (int ti = Q.small_cnt[3] + blockIdx.x * WPB + wave; ti < n_tasks; ti += gridDim.x * WPB) {
+    for (int ti = blockIdx.x * WPB + wave; ti < n_tasks; ti += gridDim.x * WPB) {
         const BuildTask k = Q.small_q[ti];
         const BuildTree t = trees[k.tree];
         const int total = k.r - k.l;
@@ -642,9 +703,9 @@ __global__ __launch_bounds__(kMidThreads) void build_mid_kernel(const BuildTree*
     __shared__ int nseg[2], nslab[2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const int first = Q.small_cnt[2], n_tasks = min(Q.small_cnt[1], Q.q_cap);
+    const int n_tasks = min(Q.small_cnt[1], Q.q_cap);
 
-    for (int ti = first + blockIdx.x; ti < n_tasks; ti += gridDim.x) {
+    for (int ti = blockIdx.x; ti < n_tasks; ti += gridDim.x) {
         const BuildTask& k = Q.mid_q[ti];
         const int k_l = k.l, k_tree = k.tree;
         const BuildTree& t = trees[k_tree];
@@ -1212,20 +1273,13 @@ __global__ __launch_bounds__(256) void huge_phase_kernel(const BuildTree* __rest
     if (PHASE == 6) huge_scatter_chunk<1>(trees, H, level, c);
 }
 
-// Last launch of a build: flags[2] = big nodes still waiting (level >= 0: the first level queue no kernel was launched for;
-// -1: none, and the stack-overflow marks left by searches over the unfinished trees are cleared), and the mid / small queues
-// are marked as processed up to their current fill (the continue path only handles later additions).
-__global__ void build_finish_kernel(BuildQueues Q, int level)
+// Last launch of a build: clears the "unfinished" word (kept in the flag layout; the straggler kernel leaves nothing unfinished).
+__global__ void build_finish_kernel(BuildQueues Q)
 {
-    Q.flags[2] = level >= 0 ? Q.level_cnt[level] : 0;
-    if (level < 0) Q.flags[0] = 0;
-    Q.small_cnt[2] = min(Q.small_cnt[1], Q.q_cap);
-    Q.small_cnt[3] = min(Q.small_cnt[0], Q.small_cap);
+    Q.flags[2] = 0;
 }
 
-constexpr int kBlindLevels = 2;  // level kernels launched blind after the chunked levels (nodes still above kMid)
-
-static int launch_mid_and_subtrees(ps_context* c, const BuildTree* d_trees, const BuildQueues& Q, size_t tot, size_t T, size_t small_cap, int pending_level)
+static int launch_mid_and_subtrees(ps_context* c, const BuildTree* d_trees, const BuildQueues& Q, size_t tot, size_t T, size_t small_cap)
 {
     constexpr size_t mid_lds = sizeof(float4) * kMid + sizeof(short) * kMid;
     if (!c->mid_lds_attr) {  // (per context = per device: function attributes do not carry over to another GPU)
@@ -1236,7 +1290,6 @@ static int launch_mid_and_subtrees(ps_context* c, const BuildTree* d_trees, cons
     const unsigned grid_mid = (unsigned)std::min<size_t>(tot / kSmall + T + 1, 1024);
     hipLaunchKernelGGL(build_mid_kernel, dim3(grid_mid), dim3(kMidThreads), mid_lds, st, d_trees, Q);
     hipLaunchKernelGGL(build_subtree_kernel, dim3((unsigned)std::min<size_t>(ceil_div(small_cap, 4), 2048)), dim3(256), 0, st, d_trees, Q);
-    hipLaunchKernelGGL(build_finish_kernel, dim3(1), dim3(1), 0, st, Q, pending_level);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -1342,12 +1395,11 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     Q.q_cap = (int32_t)q_cap;
     Q.small_cap = (int32_t)small_cap;
 
-    // chunked levels until the nodes of a balanced tree are below kMid; stragglers (lopsided splits) get kBlindLevels
-    // level kernels, anything still above kMid after that is left to build_trees_continue()
+    // chunked levels until the nodes of a balanced tree are below kMid; whatever is still above kMid after them (lopsided
+    // splits) is finished by ONE straggler launch (build_level_kernel, depth first per node)
     int huge_levels = 0;
     while (huge_levels < kHugeLevels && ((size_t)max_n >> huge_levels) > (size_t)kMid) ++huge_levels;
     H.levels = huge_levels;
-    plan.first_pending_level = huge_levels + kBlindLevels;
 
     const int chunks_x = std::max(1, std::min(ceil_div(max_n, 256 * 4), 256));
     hipLaunchKernelGGL(init_points_kernel, dim3(chunks_x, (unsigned)T), dim3(256), 0, st, d_trees, chunks_x);
@@ -1369,51 +1421,9 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
         }
     }
     // (the level queues are indexed by the level a task was pushed FOR: chunked level L pushes for L + 1, the roots for 0)
-    for (int level = huge_levels == 0 ? 0 : huge_levels; level < huge_levels + kBlindLevels; ++level)
-        hipLaunchKernelGGL(build_level_kernel, dim3(grid_big), dim3(kBigThreads), 0, st, d_trees, Q, level);
-    PS_TRY(launch_mid_and_subtrees(c, d_trees, Q, tot, T, small_cap, plan.first_pending_level));
-    plan.launches = 6 + kBlindLevels + 8 * huge_levels;
-    return PS_OK;
-}
-
-int build_trees_continue(ps_context* c, TreeSetPlan& plan)
-{
-    const size_t T = plan.n.size();
-    const size_t tot = plan.total_points();
-    const size_t q_cap = tot / kSmall + 2 * T + 64, small_cap = tot / 4 + 2 * T + 1024;
-    char* base = static_cast<char*>(plan.d_scratch);
-    size_t off = 0;
-    auto take = [&](size_t b) { char* p = base + off; off += (b + 255) & ~size_t(255); return p; };
-    BuildTree* d_trees = reinterpret_cast<BuildTree*>(take(sizeof(BuildTree) * T));
-    take(sizeof(unsigned) * 8 * T);
-    take(sizeof(int32_t) * 2 * (tot + T));
-    BuildTask* d_q = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * q_cap * 3));
-    BuildTask* d_small = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * small_cap));
-    int32_t* d_cnt = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (kMaxLevels + 8)));
-    BuildQueues Q;
-    Q.q[0] = d_q;
-    Q.q[1] = d_q + q_cap;
-    Q.mid_q = d_q + 2 * q_cap;
-    Q.small_q = d_small;
-    Q.level_cnt = d_cnt;
-    Q.small_cnt = d_cnt + kMaxLevels;
-    Q.flags = plan.d_flags;
-    Q.q_cap = (int32_t)q_cap;
-    Q.small_cap = (int32_t)small_cap;
-    hipStream_t st = c->stream;
-    const int grid_big = (int)std::min<size_t>(q_cap, tot / kMid + T + 1);
-    int level = plan.first_pending_level;
-    for (;;) {
-        for (int i = 0; i < 8 && level < kMaxLevels - 1; ++i, ++level)
-            hipLaunchKernelGGL(build_level_kernel, dim3(grid_big), dim3(kBigThreads), 0, st, d_trees, Q, level);
-        int32_t pending = 0;
-        PS_HIP(hipMemcpyAsync(&pending, d_cnt + level, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        PS_HIP(hipStreamSynchronize(st));
-        if (pending == 0) break;
-        PS_CHECK(level < kMaxLevels - 1, "kd-tree build: more than %d levels of nodes above %d points (degenerate cloud)", kMaxLevels, kMid);
-    }
-    // only the mid / small nodes queued since the first run are new work (build_finish_kernel recorded the old fill)
-    PS_TRY(launch_mid_and_subtrees(c, d_trees, Q, tot, T, small_cap, -1));
+    hipLaunchKernelGGL(build_level_kernel, dim3(grid_big), dim3(kBigThreads), 0, st, d_trees, Q, huge_levels);
+    PS_TRY(launch_mid_and_subtrees(c, d_trees, Q, tot, T, small_cap));
+    plan.launches = 6 + 8 * huge_levels;
     return PS_OK;
 }
 

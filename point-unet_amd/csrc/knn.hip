@@ -94,19 +94,26 @@ __global__ __launch_bounds__(256) void knn_kernel(const KnnJob* __restrict__ job
     const int bx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int t = bx * blockDim.x + threadIdx.x;
     if (t >= job.nq) return;
-    if (gload(job.overflow + 2) != 0) return;  // the tree builder has not finished (unbalanced cloud): the host re-runs us
+    // (degenerate cloud: a builder queue overflowed and the tree has holes.  Unreachable for real clouds -- the queues are sized
+    // for the worst disjoint-range count -- but whatever runs behind this kernel without a host check must still find valid
+    // indices: the rows are filled with index 0 instead of walking a broken tree; the status word reports the failure.)
+    const bool broken = gload(job.overflow + 1) != 0;
     float qx, qy, qz;
     int row;
     if (job.q4) {
         const float4 q = gload(job.q4 + t);
         qx = q.x; qy = q.y; qz = q.z;
-        row = as_i(q.w);
+        row = broken ? t : as_i(q.w);
         if (job.order) gstore(job.order + t, row);
     } else {
         qx = gload(job.q3 + 3 * (size_t)t);
         qy = gload(job.q3 + 3 * (size_t)t + 1);
         qz = gload(job.q3 + 3 * (size_t)t + 2);
         row = t;
+    }
+    if (broken) {
+        for (int j = 0; j < K; ++j) gstore(job.out + (size_t)row * K + j, 0);
+        return;
     }
     float dist[K];
     int idx[K];
@@ -283,29 +290,24 @@ static int knn_batch_impl(ps_context* c, const float* support, const float* quer
     }
     PS_TRY(c->upload_async(plan.d_jobs, jobs.data(), sizeof(KnnJob) * B));
     int32_t flag[3] = {0, 0, 0};
-    for (int attempt = 0;; ++attempt) {
-        {
-            Stage st(c, "knn_search", 1);
-            PS_TRY(launch_knn(c, reinterpret_cast<const KnnJob*>(plan.d_jobs), (int)B, (int)n2, (int)K));
-        }
-        if (out64) {
-            hipLaunchKernelGGL(widen_kernel, dim3(ceil_div(out_count, 256)), dim3(256), 0, c->stream, d_out32, d_out64 ? d_out64 : out64,
-                               out_count);
-            PS_HIP(hipGetLastError());
-        }
-        if (!device_ptrs) {
-            if (out64)
-                PS_HIP(hipMemcpyAsync(out64, d_out64, out_count * 8, hipMemcpyDeviceToHost, c->stream));
-            else
-                PS_HIP(hipMemcpyAsync(out32, d_out32, out_count * 4, hipMemcpyDeviceToHost, c->stream));
-        }
-        PS_HIP(hipMemcpyAsync(flag, plan.d_flags, 12, hipMemcpyDeviceToHost, c->stream));
-        // (the job table and the plan's staging live in host memory of this frame: wait before returning)
-        PS_HIP(hipStreamSynchronize(c->stream));
-        if (flag[2] == 0 || attempt > 0) break;
-        PS_TRY(build_trees_continue(c, plan));  // very unbalanced cloud: finish the remaining levels, search again
+    {
+        Stage st(c, "knn_search", 1);
+        PS_TRY(launch_knn(c, reinterpret_cast<const KnnJob*>(plan.d_jobs), (int)B, (int)n2, (int)K));
     }
-    PS_CHECK(flag[2] == 0, "ps_knn_batch: kd-tree build did not finish");
+    if (out64) {
+        hipLaunchKernelGGL(widen_kernel, dim3(ceil_div(out_count, 256)), dim3(256), 0, c->stream, d_out32, d_out64 ? d_out64 : out64,
+                           out_count);
+        PS_HIP(hipGetLastError());
+    }
+    if (!device_ptrs) {
+        if (out64)
+            PS_HIP(hipMemcpyAsync(out64, d_out64, out_count * 8, hipMemcpyDeviceToHost, c->stream));
+        else
+            PS_HIP(hipMemcpyAsync(out32, d_out32, out_count * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    PS_HIP(hipMemcpyAsync(flag, plan.d_flags, 12, hipMemcpyDeviceToHost, c->stream));
+    // (the job table and the plan's staging live in host memory of this frame: wait before returning)
+    PS_HIP(hipStreamSynchronize(c->stream));
     PS_CHECK(flag[1] == 0, "ps_knn_batch: kd-tree builder queue overflow (degenerate cloud)");
     PS_CHECK(flag[0] == 0, "ps_knn_batch: kd-tree deeper than the %d-entry traversal stack", kStackMax);
     return PS_OK;
@@ -386,8 +388,10 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
         }
         t.B = B;
         t.width = 3;
-        hipLaunchKernelGGL(slice_rows_kernel, dim3((unsigned)std::min<size_t>(ceil_div(most, 256), 2048), L), dim3(256), 0, c->stream, t);
-        PS_HIP(hipGetLastError());
+        if (most > 0) {  // (one layer whose xyz[0] is the caller's own buffer: nothing to copy)
+            hipLaunchKernelGGL(slice_rows_kernel, dim3((unsigned)std::min<size_t>(ceil_div(most, 256), 2048), L), dim3(256), 0, c->stream, t);
+            PS_HIP(hipGetLastError());
+        }
     }
 
     // trees: (level l in 0..L) x (cloud b).  Level l's point set is the first n[l] points of every cloud.
@@ -445,7 +449,7 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
     PS_TRY(c->upload_async(plan.d_jobs, jobs.data(), sizeof(KnnJob) * jobs.size()));
     const KnnJob* dj = reinterpret_cast<const KnnJob*>(plan.d_jobs);
     int32_t flag[3] = {0, 0, 0};
-    for (int attempt = 0;; ++attempt) {
+    {
         {
             Stage st(c, "knn_search_k", 1);
             PS_TRY(launch_knn(c, dj, (int)n_self, max_nq, K));
@@ -484,15 +488,15 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
             PS_HIP(hipMemcpyAsync(c->h_flags + 4 * c->flag_slot, plan.d_flags, 12, hipMemcpyDeviceToHost, c->stream));
             PS_HIP(hipEventRecord(ev, c->stream));
             c->pending_mask |= 1u << c->flag_slot;
+            c->flag_serial[c->flag_slot] = c->builds;
+            ++c->builds;
             c->flag_slot = (c->flag_slot + 1) & 7;
             return PS_OK;  // (all host tables went through the context's pinned upload ring)
         }
         PS_HIP(hipMemcpyAsync(flag, plan.d_flags, 12, hipMemcpyDeviceToHost, c->stream));
         PS_HIP(hipStreamSynchronize(c->stream));
-        if (flag[2] == 0 || attempt > 0) break;
-        PS_TRY(build_trees_continue(c, plan));  // very unbalanced cloud: finish the remaining levels, search again
     }
-    PS_CHECK(flag[2] == 0, "ps_pyramid_build: kd-tree build did not finish");
+    ++c->builds;
     PS_CHECK(flag[1] == 0, "ps_pyramid_build: kd-tree builder queue overflow (degenerate cloud)");
     PS_CHECK(flag[0] == 0, "ps_pyramid_build: kd-tree deeper than the %d-entry traversal stack", kStackMax);
     return PS_OK;
@@ -521,7 +525,6 @@ extern "C" int ps_debug_kdtree_device(ps_context* c, const float* support, int64
     int32_t flag[3] = {0, 0, 0};
     PS_HIP(hipMemcpyAsync(flag, plan.d_flags, 12, hipMemcpyDeviceToHost, c->stream));
     PS_HIP(hipStreamSynchronize(c->stream));
-    if (flag[2] != 0) PS_TRY(build_trees_continue(c, plan));
     PS_CHECK(flag[1] == 0, "ps_debug_kdtree_device: builder queue overflow");
     TreeMeta m;
     PS_HIP(hipMemcpyAsync(nodes, plan.d_nodes[0], sizeof(int4) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));

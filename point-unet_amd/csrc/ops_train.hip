@@ -13,6 +13,7 @@
 
 #include "common.h"
 #include "mfma_tile.h"
+#include "wave_ops.h"
 
 namespace ps {
 
@@ -610,23 +611,46 @@ __global__ __launch_bounds__(256) void axpy_kernel(float alpha, const float* __r
     for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) y[e] += alpha * x[e];
 }
 
-// ---- class-weighted softmax cross-entropy, mean over rows (RandLANet.py:267-274) + its gradient ------------------
+// ---- class-weighted softmax cross-entropy, mean over the VALID rows (RandLANet.py:62-84, 267-274) + its gradient -------
+// A label outside [0, C) marks an ignored point (the reference drops the rows whose label is in cfg.ignored_label_inds before the
+// loss and averages over the remaining ones; the host maps its ignored labels to -1 and the others to 0..C-1 like the reference's
+// `reducing_list`): weight 0, zero gradient row, not counted in the mean.  Three small launches: count, per-workgroup partial
+// sums, ordered final sum -- no float atomics, so the loss is bit-identical from run to run.
+__global__ __launch_bounds__(256) void wce_count_kernel(const int32_t* __restrict__ labels, int64_t R, int C, int32_t* __restrict__ n_valid)
+{
+    int cnt = 0;
+    for (int64_t r = blockIdx.x * (int64_t)256 + threadIdx.x; r < R; r += (int64_t)gridDim.x * 256) {
+        const int y = labels[r];
+        cnt += (y >= 0 && y < C) ? 1 : 0;
+    }
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(n_valid, cnt);
+}
+
 __global__ __launch_bounds__(256) void wce_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels, const float* __restrict__ cw,
-                                                  int64_t R, int C, float* __restrict__ loss, float* __restrict__ dlogits)
+                                                  int64_t R, int C, const int32_t* __restrict__ n_valid, float* __restrict__ partial,
+                                                  float* __restrict__ dlogits)
 {
     __shared__ float s[256];
     float acc = 0.f;
+    const float inv = 1.f / (float)n_valid[0];
     for (int64_t r = blockIdx.x * (int64_t)256 + threadIdx.x; r < R; r += (int64_t)gridDim.x * 256) {
+        const int y = labels[r];
+        const bool valid = y >= 0 && y < C;
+        if (!valid) {
+            if (dlogits)
+                for (int c = 0; c < C; ++c) dlogits[r * C + c] = 0.f;
+            continue;
+        }
         const float* z = logits + r * C;
         float m = z[0];
         for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
         float den = 0.f;
         for (int c = 0; c < C; ++c) den += expf(z[c] - m);
-        const int y = labels[r];
         const float w = cw[y];
         acc += w * (logf(den) - (z[y] - m));
         if (dlogits)
-            for (int c = 0; c < C; ++c) dlogits[r * C + c] = w * (expf(z[c] - m) / den - (c == y ? 1.f : 0.f)) / (float)R;
+            for (int c = 0; c < C; ++c) dlogits[r * C + c] = w * (expf(z[c] - m) / den - (c == y ? 1.f : 0.f)) * inv;
     }
     s[threadIdx.x] = acc;
     __syncthreads();
@@ -634,7 +658,21 @@ __global__ __launch_bounds__(256) void wce_kernel(const float* __restrict__ logi
         if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(loss, s[0] / (float)R);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(256) void wce_finish_kernel(const float* __restrict__ partial, int n, const int32_t* __restrict__ n_valid, float* __restrict__ loss)
+{
+    __shared__ float s[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = s[0] / (float)n_valid[0];  // no valid row: 0/0 = NaN, tf.reduce_mean of an empty tensor
 }
 
 // ---- Adam (tf.train.AdamOptimizer: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t * m / (sqrt(v) + eps)) -------------
@@ -952,9 +990,15 @@ int ps_op_weighted_ce(ps_context* c, const float* logits, const int32_t* labels,
     PS_CHECK(c && logits && labels && class_weights && loss, "ps_op_weighted_ce: NULL argument");
     PS_CHECK(R >= 1 && C >= 1 && C <= 64, "ps_op_weighted_ce: bad shape");
     PS_HIP(hipSetDevice(c->device));
-    Stage st(c, "train_loss", 1);
-    PS_HIP(hipMemsetAsync(loss, 0, sizeof(float), c->stream));
-    hipLaunchKernelGGL(wce_kernel, dim3(ew_grid(R) > 1024 ? 1024 : ew_grid(R)), dim3(256), 0, c->stream, logits, labels, class_weights, R, (int)C, loss, dlogits);
+    Stage st(c, "train_loss", 3);
+    const unsigned blocks = (unsigned)(ew_grid(R) > 1024 ? 1024 : ew_grid(R));
+    PS_TRY(c->red_ws.reserve(sizeof(float) * (blocks + 64)));
+    int32_t* n_valid = c->red_ws.as<int32_t>();
+    float* partial = c->red_ws.as<float>() + 64;
+    PS_HIP(hipMemsetAsync(n_valid, 0, sizeof(int32_t), c->stream));
+    hipLaunchKernelGGL(wce_count_kernel, dim3(blocks), dim3(256), 0, c->stream, labels, R, (int)C, n_valid);
+    hipLaunchKernelGGL(wce_kernel, dim3(blocks), dim3(256), 0, c->stream, logits, labels, class_weights, R, (int)C, n_valid, partial, dlogits);
+    hipLaunchKernelGGL(wce_finish_kernel, dim3(1), dim3(256), 0, c->stream, partial, (int)blocks, n_valid, loss);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }

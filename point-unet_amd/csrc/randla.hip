@@ -66,6 +66,8 @@ struct LayerSpec {
 
 struct EncLevel {
     PackedLinear mlp1, top1, lfa1, bot1, full1, att1mlp, lfa2, top2, bot2, full2, att2mlp, mlp2sc;
+    Att32Weights p32;  // d >= 64: weight images of the 32x32x2 attentive-pooling kernels
+    bool has_p32 = false;
     int d_in, d;
 };
 
@@ -202,6 +204,14 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
         }
         pend.push_back({&L, off, boff, qoff});
     };
+    struct PendingRaw { const float** dst; size_t off; };
+    std::vector<PendingRaw> pend_raw;
+    auto emit_raw = [&](const float** dst, size_t floats) -> float* {
+        const size_t off = (host.size() + 63) & ~size_t(63);
+        host.resize(off + floats);
+        pend_raw.push_back({dst, off});
+        return host.data() + off;  // (valid until the next resize: fill it before emitting anything else)
+    };
     size_t si = 0;
     auto W = [&](size_t i) { return blob + net->specs[i].w_off; };
     auto Bv = [&](size_t i) { return blob + net->specs[i].b_off; };
@@ -215,6 +225,13 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
         EncLevel& e = net->enc[i];
         const int d = cfg.d_out[i], h = d / 2;
         e.d = d; e.d_in = d_in;
+        e.has_p32 = d >= 64;
+        if (e.has_p32) {  // (spec order: mlp1, lfa1, att1 fc, att1 mlp, lfa2, att2 fc, ...)
+            pack_p32_locse(W(si + 1), h, emit_raw(&e.p32.w1, (size_t)(h / 32) * 5 * 64));
+            pack_p32(W(si + 2) + (size_t)h * d, h, d, emit_raw(&e.p32.wb1, (size_t)h * d));
+            pack_p32(W(si + 4), h, h, emit_raw(&e.p32.w2, (size_t)h * h));
+            pack_p32(W(si + 5) + (size_t)h * d, h, d, emit_raw(&e.p32.wb2, (size_t)h * d));
+        }
         emit(e.mlp1, W(si), Bv(si), d_in, h, 1); ++si;
         emit(e.lfa1, W(si), Bv(si), 10, h, 1); ++si;
         emit(e.top1, W(si), nullptr, h, d, 0);                      // Wfc1[:h, :]
@@ -256,6 +273,7 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
         p.L->bias = net->wbuf.as<float>() + p.b_off;
         p.L->wq = p.wq_off ? net->wbuf.as<float>() + p.wq_off : nullptr;
     }
+    for (auto& p : pend_raw) *p.dst = net->wbuf.as<float>() + p.off;
     net->have_weights = true;
     return PS_OK;
 }
@@ -347,6 +365,7 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
         AttStage s;
         s.xyz = pyr->xyz[i]; s.idx = pyr->neigh_idx[i]; s.order = pyr->order[i]; s.fg = fg; s.lfa1 = &e.lfa1; s.agg = agg;
         s.n_total = R; s.n_cloud = n[i]; s.d = d; s.k = cfg.k_n; s.ldf = ldf;
+        s.p32 = e.has_p32 ? &e.p32 : nullptr;
         // f = act(x . W + b) [-> G = f . Wfc[:h]]: one chained launch when it fits
         auto feature_rows = [&](const PackedLinear& mlp, const PackedLinear& top, const RowSrc& in) -> int {
             ChainStep ch[2] = {step(mlp, fg, ldf), step(top, fg + h, ldf)};

@@ -93,4 +93,5 @@ class ForwardPipeline:
     def close(self):
         self.synchronize()
         for ln in self.lanes:
+            ln.net.close()
             ln.ctx.close()

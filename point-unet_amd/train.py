@@ -277,7 +277,7 @@ class Trainer:
     """Parameters (flat fp32 buffer + named views), Adam state and the train step."""
 
     def __init__(self, config, params=None, device=0, seed=0, learning_rate=None, class_weights=None, keep_prob=0.5, ctx=None, sync_bn=False,
-                 mlp_dtype="fp32"):
+                 mlp_dtype="fp32", ignored_label_inds=None):
         """sync_bn: with a `dist` passed to train_step, BatchNorm uses the statistics of all ranks' rows, which makes "W GPUs x
         one cloud" numerically the same step as "one GPU x W clouds" (SURVEY 8e); off = per-GPU statistics.
         mlp_dtype: "fp32" (default) or "bf16" -- BASELINE configs[2]'s "bf16 MLPs": the shared-MLP GEMMs (forward, input gradient,
@@ -322,12 +322,37 @@ class Trainer:
         self.buffers = {n: torch.from_numpy(np.ascontiguousarray(params[n])).to(self.device) for n in buf_names}
         cw = class_weights if class_weights is not None else np.ones(config.num_classes, np.float32)
         self.class_weights = torch.from_numpy(np.asarray(cw, np.float32).reshape(-1)).to(self.device)
+        ign = ignored_label_inds if ignored_label_inds is not None else getattr(config, "ignored_label_inds", [])
+        self.ignored_label_inds = sorted(int(v) for v in ign)
+        self.label_map = None
+        if self.ignored_label_inds:
+            # RandLANet.py:77-81: reducing_list = range(C) with a 0 inserted at every ignored index; ignored entries become -1 here
+            red = list(range(config.num_classes))
+            for v in self.ignored_label_inds:
+                red = red[:v] + [-1] + red[v:]
+            self.label_map = torch.tensor(red, dtype=torch.int32, device=self.device)
         self.step = 0
+        self._rank = 0
 
     def num_params(self):
         return self.flat.numel()
 
-    def export_params(self):
+    def sync_buffers(self, dist):
+        """BatchNorm moving statistics averaged over the ranks (they differ between GPUs when sync_bn is off: every rank has
+        seen its own clouds).  Call before export_params() / checkpointing in a multi-GPU run."""
+        if dist is None or not self.buffers:
+            return
+        names = sorted(self.buffers)
+        flat = torch.cat([self.buffers[n].reshape(-1) for n in names])
+        allreduce_mean_(flat, dist)
+        off = 0
+        for n in names:
+            k = self.buffers[n].numel()
+            self.buffers[n].copy_(flat[off:off + k].view_as(self.buffers[n]))
+            off += k
+
+    def export_params(self, dist=None):
+        self.sync_buffers(dist)
         out = {n: self.P[n].detach().cpu().numpy().copy() for n in self.names}
         out.update({n: b.cpu().numpy().copy() for n, b in self.buffers.items()})
         return out
@@ -390,13 +415,24 @@ class Trainer:
             f = self._conv(t, t.cat(enc[-j - 2], up), "Decoder_layer_%d" % j, transposed=True)
         f = self._conv(t, f, "fc1")
         f = self._conv(t, f, "fc2")
-        f = t.dropout(f, self.keep_prob, 0x9e3779b9 * (self.step + 1))
+        # every rank draws its own mask (N GPUs x 1 cloud behaves like 1 GPU x N clouds, where the clouds sit at different element offsets)
+        f = t.dropout(f, self.keep_prob, 0x9e3779b9 * (self.step + 1) + 0x85ebca6b * self._rank)
         return self._conv(t, f, "fc", bn=False, act=False)
 
     def train_step(self, pyr, features, labels, dist=None):
         """One optimisation step on the batch; returns the loss (device scalar tensor).  With `dist` (an initialised
         torch.distributed) the flat gradient buffer is averaged over ranks with one all-reduce before Adam."""
+        own = getattr(self.ctx, "_stream", None)
+        if own is None:
+            # torch's helper ops (cat, add_, mul_) run on torch's current stream: the kernels behind the C ABI must run there too
+            self.ctx.use_torch_stream()
+            return self._train_step(pyr, features, labels, dist)
+        with torch.cuda.stream(own):  # a context with its own stream (a pipeline lane): torch's helper ops follow it
+            return self._train_step(pyr, features, labels, dist)
+
+    def _train_step(self, pyr, features, labels, dist):
         lib, h = _lib.lib(), self.ctx.handle
+        self._rank = dist.get_rank() if dist is not None else 0
         t = Tape(self.ctx, sync=dist if (self.sync_bn and dist is not None) else None)
         if self.mlp_bf16:
             _lib.check(lib.ps_set_train_gemm_bf16(h, 1))
@@ -406,6 +442,9 @@ class Trainer:
             loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
             dlogits = torch.empty_like(logits)
             lab = labels.reshape(-1).to(torch.int32).contiguous()
+            if self.label_map is not None:
+                inside = (lab >= 0) & (lab < self.label_map.numel())
+                lab = torch.where(inside, self.label_map[lab.clamp(0, self.label_map.numel() - 1).long()], torch.full_like(lab, -1)).contiguous()
             _lib.check(lib.ps_op_weighted_ce(h, _p(logits), _p(lab), _p(self.class_weights), R, C, _p(loss), _p(dlogits)))
             t.backward(logits, dlogits)
         finally:

@@ -84,3 +84,52 @@ def test_gradient_allreduce_mean_two_ranks(tmp_path):
              for r in range(2)]
     outs = [json.loads(p.communicate(timeout=120)[0].strip().splitlines()[-1]) for p in procs]
     assert all(p.returncode == 0 for p in procs) and all(o["ok"] for o in outs)
+
+
+SPAWN_CHILD = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if "--die" in sys.argv and rank == 1:
+        sys.exit(3)                                    # a rank that fails before the rendezvous
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo")
+    seen = bench.ranks_seen(dist, "cpu")
+    print("rank %%d noise on stdout" %% rank if rank else json.dumps({"n_gpus": world, "ranks_seen": seen, "argv": sys.argv[1:]}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+""") % ROOT
+
+
+def test_bench_spawns_its_own_ranks_and_relays_rank0(tmp_path, capsys):
+    """`python bench.py --gpus N` without a launcher (the driver's form): the parent starts N fresh rank processes, only rank 0's
+    stdout (the JSON line) reaches the parent's stdout, the exit code is the worst child's."""
+    sys.path.insert(0, ROOT)
+    import bench
+    child = tmp_path / "child.py"
+    child.write_text(SPAWN_CHILD)
+    rc = bench.spawn_ranks(2, ["--gpus", "2", "--steps", "3"], script=str(child))
+    out = capsys.readouterr().out.strip().splitlines()
+    assert rc == 0 and len(out) == 1
+    line = json.loads(out[0])
+    assert line == {"n_gpus": 2, "ranks_seen": 2, "argv": ["--gpus", "2", "--steps", "3"]}
+
+
+def test_bench_spawner_reports_a_dead_rank_and_stops_the_others(tmp_path, capsys):
+    sys.path.insert(0, ROOT)
+    import bench
+    child = tmp_path / "child.py"
+    child.write_text(SPAWN_CHILD)
+    t0 = __import__("time").time()
+    rc = bench.spawn_ranks(2, ["--die"], script=str(child))
+    assert rc == 3 and __import__("time").time() - t0 < 60          # rank 0 was stopped, not left at the rendezvous
+    capsys.readouterr()
+
+
+def test_bench_parent_never_touches_the_gpu_before_spawning():
+    """The spawning branch sits before `import torch` / any device call in main()."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("spawn_ranks(args.gpus") < main.index("import torch")
+    assert "os.exec" not in src and "execv" not in src

@@ -159,11 +159,11 @@ def test_device_tree_equals_host_tree(lib, case):
             stack += [int(h[1][i, 0]) & 0x3fffffff, int(h[1][i, 1])]
 
 
-def test_unbalanced_cloud_takes_the_slow_build_path(oracle):
+def test_unbalanced_cloud_is_finished_by_the_straggler_kernel(oracle):
     """A geometric progression on a line (y = z = 0) makes every bounding-box-midpoint split peel ~ln2/0.0003 = 2 300
     points off the node: ~14 levels of nodes above 8 192 points (the size one workgroup finishes in LDS), far more than
-    the builder launches blind, so the continue path runs.  The small variant (1 100 points, 50-deep tree) stays inside
-    the LDS kernels.  Results stay bit-exact."""
+    the chunked levels cover, so the depth-first straggler kernel does them.  The small variant (1 100 points, 50-deep tree)
+    stays inside the LDS kernels.  Results stay bit-exact."""
     rng = np.random.default_rng(5)
     for n, r in ((40000, 0.9997), (1100, 0.97)):
         p = np.stack([r ** np.arange(n), np.zeros(n), np.zeros(n)], 1).astype(np.float32)
@@ -172,11 +172,34 @@ def test_unbalanced_cloud_takes_the_slow_build_path(oracle):
             assert np.array_equal(_knn_gpu(p[None], p[None], K), oracle.knn_batch(p[None], p[None], K)), (n, K)
 
 
-def test_deferred_checks_flag_unbalanced_cloud_at_synchronize():
-    """With deferred checks the pyramid build does not synchronise; a cloud that needs the slow build path is reported
-    by the next synchronize() instead of silently yielding wrong indices."""
+def _tumour_dense_cloud(n, seed):
+    """BraTS-like density skew (runBraTS.py:108-110 keeps ALL tumour voxels plus a sparse background sample): 60 % of the points
+    fill a small lattice ball at full density, the rest are spread thinly over the whole volume."""
+    rng = np.random.default_rng(seed)
+    g = np.array([240, 240, 155])
+    r = 1
+    while True:  # smallest ball around (150, 100, 80) with enough lattice voxels
+        ii = np.stack(np.meshgrid(*[np.arange(-r, r + 1)] * 3, indexing="ij"), -1).reshape(-1, 3)
+        ball = ii[(ii * ii).sum(1) <= r * r]
+        if len(ball) >= int(0.6 * n):
+            break
+        r += 1
+    dense = ball[rng.permutation(len(ball))[:int(0.6 * n)]] + np.array([150, 100, 80])
+    sparse = rng.integers(0, g, (4 * n, 3))
+    allp = np.unique(np.concatenate([dense, sparse]), axis=0)
+    keep = np.concatenate([dense, allp[rng.permutation(len(allp))]])
+    _, first = np.unique(keep, axis=0, return_index=True)
+    keep = keep[np.sort(first)][:n]
+    return (keep[rng.permutation(len(keep))] / g).astype(np.float32)
+
+
+def test_deferred_checks_finish_unbalanced_clouds_on_the_device(oracle):
+    """Deferred checks = ps_pyramid_build never synchronises with the host (ForwardPipeline's mode).  The build must therefore
+    always complete on the device: the geometric-progression cloud (14 levels of stragglers) and a tumour-dense BraTS-shaped
+    cloud come out index for index like the reference loop, with nothing reported at synchronize()."""
     import torch
-    from point_unet_amd import PointSegError, runtime
+    from oracle import randla_oracle as ro
+    from point_unet_amd import runtime
     from point_unet_amd.helper_tool import ConfigBraTS
     from point_unet_amd.pyramid import build_pyramid
 
@@ -187,18 +210,17 @@ def test_deferred_checks_flag_unbalanced_cloud_at_synchronize():
     ctx = runtime.Context(0)
     ctx.use_torch_stream()
     ctx.set_deferred_checks(True)
-    good = torch.from_numpy(brats_cloud(8000, 3, grid=(40, 40, 30))[None]).cuda()
-    pyr = build_pyramid(good, Cfg, ctx=ctx)
-    ctx.synchronize()
-    ref = build_pyramid(good, Cfg)
-    assert torch.equal(pyr.neigh_idx[0], ref.neigh_idx[0]) and torch.equal(pyr.interp_idx[1], ref.interp_idx[1])
     rng = np.random.default_rng(5)
     n = 40000
-    p = np.stack([0.9997 ** np.arange(n), np.zeros(n), np.zeros(n)], 1).astype(np.float32)[rng.permutation(n)]
-    build_pyramid(torch.from_numpy(p[None]).cuda(), Cfg, ctx=ctx)
-    with pytest.raises(PointSegError, match="unbalanced"):
-        ctx.synchronize()
-    ctx.synchronize()  # the failure is reported once
+    line = np.stack([0.9997 ** np.arange(n), np.zeros(n), np.zeros(n)], 1).astype(np.float32)[rng.permutation(n)]
+    for cloud in (brats_cloud(8000, 3, grid=(40, 40, 30)), line, _tumour_dense_cloud(60000, 1)):
+        pyr = build_pyramid(torch.from_numpy(cloud[None]).cuda(), Cfg, ctx=ctx)
+        ctx.synchronize()  # raises if any status word was set
+        _, nbr, pool, up = ro.build_pyramid(lambda s, q, k: oracle.knn_batch(s, q, k), cloud[None], Cfg.k_n, Cfg.sub_sampling_ratio)
+        for i in range(2):
+            assert np.array_equal(pyr.neigh_idx[i].cpu().numpy(), nbr[i])
+            assert np.array_equal(pyr.sub_idx[i].cpu().numpy(), pool[i])
+            assert np.array_equal(pyr.interp_idx[i].cpu().numpy(), up[i])
     ctx.close()
 
 

@@ -148,6 +148,47 @@ def test_pipeline_matches_serial():
     pipe.close()
 
 
+def test_pipeline_runs_density_skewed_clouds_between_good_ones(oracle):
+    """ForwardPipeline never synchronises the tree build with the host (deferred checks).  Clouds whose bounding-box-midpoint
+    splits are very lopsided -- the geometric-progression line and a tumour-dense BraTS-shaped cloud (runBraTS.py:108-110 keeps
+    every tumour voxel plus a sparse background) -- submitted between ordinary clouds must come out exactly like the serial,
+    host-checked path, and within the logits bar of the oracle; synchronize() reports nothing."""
+    import torch
+    from oracle import randla_oracle as ro
+    from test_gpu_knn import _tumour_dense_cloud
+    from point_unet_amd import weights
+    from point_unet_amd.RandLANet import Network
+    from point_unet_amd.pipeline import ForwardPipeline
+    from point_unet_amd.pyramid import build_pyramid
+    from conftest import brats_cloud
+    n = 40000
+    cfg = netcase.make_cfg(5, (16, 64, 128, 256, 512), (4, 4, 4, 4, 2), 16, 4, 7)
+    params = weights.init_params(cfg, seed=4, randomize_bn=True)
+    rng = np.random.default_rng(5)
+    line = np.stack([0.9997 ** np.arange(n), np.zeros(n), np.zeros(n)], 1).astype(np.float32)[rng.permutation(n)]
+    good = brats_cloud(n, 21, grid=(80, 80, 60))
+    clouds = [good, line, _tumour_dense_cloud(n, 2), good, _tumour_dense_cloud(n, 3)]
+    feats = [np.concatenate([c, rng.standard_normal((n, 4)).astype(np.float32)], -1)[None] for c in clouds]
+    net = Network(cfg, params=params)
+    want = []
+    for c, f in zip(clouds, feats):
+        pyr = build_pyramid(torch.from_numpy(c[None]).cuda(), cfg)
+        want.append(net.inference({"pyramid": pyr, "features": torch.from_numpy(f).cuda()}).cpu().numpy())
+    pipe = ForwardPipeline(cfg, params=params, lanes=3)
+    dev = [(torch.from_numpy(c[None]).cuda(), torch.from_numpy(f).cuda()) for c, f in zip(clouds, feats)]
+    torch.cuda.synchronize()
+    got = [pipe.submit(x, f) for x, f in dev]
+    pipe.synchronize()
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(g.cpu().numpy(), w), i
+    # the tumour-dense cloud against the oracle
+    c, f = clouds[2][None], feats[2]
+    pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: oracle.knn_batch(s, q, k), c, cfg.k_n, cfg.sub_sampling_ratio)
+    ref = ro.inference(params, cfg.num_layers, pts, nbr, pool, up, f, np.float64)
+    assert np.abs(want[2] - ref).max() <= TOL
+    pipe.close()
+
+
 def test_block_methods_reproduce_the_fused_path(oracle):
     """Network.dilated_res_block / building_block (the reference's call sites, RandLANet.py:314-335, composed from the op-level
     kernels) against the fused forward's own encoder output for the same input."""
@@ -187,3 +228,56 @@ def test_half_precision_feature_input(oracle):
     pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: oracle.knn_batch(s, q, k), xyz, cfg.k_n, cfg.sub_sampling_ratio)
     want = ro.inference(params, cfg.num_layers, pts, nbr, pool, up, f16.astype(np.float32), np.float64)
     assert np.abs(got - want).max() <= TOL
+
+
+def test_tf_named_checkpoint_variables_run_on_the_device(oracle):
+    """N1: a variable dict as `tf.train.load_checkpoint(...)` of the reference model would give it -- names under the
+    'layers/' scope with the scope strings concatenated without separators (RandLANet.py:56, 121, 315-334, 395, 400;
+    helper_tf_util.py:51,162), conv kernels [1,1,in,out], transposed-conv kernels [1,1,out,in] (helper_tf_util.py:208-212), fc0's
+    un-scoped BatchNorm, plus everything else the Saver stores (Adam slots, beta powers, the learning rate: RandLANet.py:87-89,
+    101-102) -- goes through weights.from_tf_variables into ps_randla_set_weights / ps_randla_forward.  The oracle is fed the SAME
+    dict through a mapping written here (strip the scope, squeeze the 1x1 axes), independent of from_tf_variables."""
+    import torch
+    from oracle import randla_oracle as ro
+    from point_unet_amd import weights
+    from point_unet_amd.RandLANet import Network
+    from point_unet_amd.pyramid import build_pyramid
+    cfg, xyz, feats = netcase.small_deep(6000, seed=31)
+    base = weights.init_params(cfg, seed=9, randomize_bn=True)
+    rng = np.random.default_rng(0)
+    ckpt = {}
+    for scope, kind, cin, cout in weights.layer_dims(cfg):
+        if kind in ("dense", "dense_nobias"):
+            ckpt["layers/%s/kernel" % scope] = base[scope + "/kernel"]
+            if kind == "dense":
+                ckpt["layers/%s/bias" % scope] = base[scope + "/bias"] + 0.01 * rng.standard_normal(cout).astype(np.float32)
+        else:
+            w = base[scope + "/weights"]  # [in,out], or [out,in] for the transposed convs
+            ckpt["layers/%s/weights" % scope] = w.reshape((1, 1) + w.shape)
+            ckpt["layers/%s/biases" % scope] = base[scope + "/biases"] + 0.01 * rng.standard_normal(cout).astype(np.float32)
+    for k, v in base.items():
+        if "batch_normalization" in k:
+            ckpt["layers/" + k] = v
+    assert ckpt["layers/Decoder_layer_0/weights"].shape == (1, 1, 512, 1536)      # [1,1,out,in]
+    assert ckpt["layers/Encoder_layer_4LFAatt_pooling_2fc/kernel"].shape == (512, 512)
+    assert "layers/batch_normalization/gamma" in ckpt                              # fc0's BN, un-scoped (RandLANet.py:115)
+    model_vars = dict(ckpt)
+    for k, v in model_vars.items():  # what else the Saver holds: optimizer state
+        if not k.endswith(("moving_mean", "moving_variance")):
+            ckpt["optimizer/" + k + "/Adam"] = np.zeros_like(v)      # slots created inside variable_scope('optimizer') (RandLANet.py:86-89)
+            ckpt["optimizer/" + k + "/Adam_1"] = np.zeros_like(v)
+            ckpt[k + "/Adam"] = np.ones_like(v)                       # ... and the un-nested spelling some TF versions produce
+    ckpt["optimizer/beta1_power"] = np.float32(0.9)
+    ckpt["optimizer/beta2_power"] = np.float32(0.999)
+    ckpt["optimizer/learning_rate"] = np.float32(1e-4)
+    params = weights.from_tf_variables(cfg, ckpt)
+    net = Network(cfg, params=params)
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    logits = net.inference({"pyramid": pyr, "features": torch.from_numpy(feats).cuda()}).cpu().numpy()
+    oracle_params = {k[len("layers/"):]: np.squeeze(v, (0, 1)) if np.ndim(v) == 4 else np.asarray(v) for k, v in model_vars.items()}
+    pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: oracle.knn_batch(s, q, k), xyz, cfg.k_n, cfg.sub_sampling_ratio)
+    want = ro.inference(oracle_params, cfg.num_layers, pts, nbr, pool, up, feats, np.float64)
+    assert np.abs(logits - want).max() <= TOL
+    with pytest.raises(KeyError):  # a checkpoint of another architecture: missing variables are an error, not zeros
+        weights.from_tf_variables(cfg, {k: v for k, v in ckpt.items() if "Encoder_layer_3mlp2" not in k})
+    net.close()

@@ -79,3 +79,35 @@ def test_loss_restatement():
     w = np.array([2.0, 3.0, 4.0, 5.0])
     want = float((F.cross_entropy(torch.from_numpy(z), torch.from_numpy(y), reduction="none") * torch.from_numpy(w)[y]).mean())
     assert abs(ro.weighted_ce_loss(z, y, w) - want) < 1e-12
+
+
+def test_torch_oracle_forward_and_training_variants(oracle):
+    """oracle/randla_train_oracle.py: (1) its eval-mode forward (bench.py's all-cores CPU-baseline leg runs it in float32) equals the
+    NumPy restatement; (2) ignored labels drop out of the loss and its mean (RandLANet.py:62-84); (3) the bf16 operand rounding
+    changes the step by bf16-sized amounts only where the rule says so."""
+    from oracle import randla_oracle as ro
+    from oracle import randla_train_oracle as rto
+    from point_unet_amd import weights
+    cfg, xyz, feats = netcase.small_deep(1200, seed=4)
+    cfg.d_out = [16, 32, 32, 16, 16]
+    params = weights.init_params(cfg, seed=9, randomize_bn=True)
+    pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: oracle.knn_batch(s, q, k), xyz, cfg.k_n, cfg.sub_sampling_ratio)
+    a = ro.inference(params, cfg.num_layers, pts, nbr, pool, up, feats, np.float64)
+    assert np.abs(rto.forward(params, cfg.num_layers, pts, nbr, pool, up, feats, torch.float64) - a).max() < 1e-10
+    assert np.abs(rto.forward(params, cfg.num_layers, pts, nbr, pool, up, feats, torch.float32) - a).max() < 1e-3
+    rng = np.random.default_rng(1)
+    labels = rng.integers(0, 4, xyz.shape[:2])
+    cw = np.array([1.0, 2.0, 0.5, 3.0])
+    full = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3)
+    masked = labels.copy()
+    masked[:, ::3] = -1
+    part = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, masked, cw, lr=1e-3)
+    z = torch.from_numpy(part["logits"].reshape(-1, 4))
+    y = torch.from_numpy(masked.reshape(-1))
+    keep = y >= 0
+    want = float((F.cross_entropy(z[keep], y[keep], reduction="none") * torch.from_numpy(cw)[y[keep]]).mean())
+    assert abs(part["loss"] - want) < 1e-12 and abs(part["loss"] - full["loss"]) > 1e-6
+    none = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, bf16_rule=lambda kind, cin, cout: False)
+    assert none["loss"] == full["loss"]
+    bf = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, bf16_rule=lambda kind, cin, cout: True)
+    assert 1e-6 < abs(bf["loss"] - full["loss"]) < 3e-2 * abs(full["loss"])
