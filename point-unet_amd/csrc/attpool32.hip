@@ -93,25 +93,47 @@ __global__ __launch_bounds__(WAVES * 64) void att32_kernel(Att32Args a)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const int tiles_per_wg = SPLITN ? 1 : WAVES;
     const int t_end = min(a.n_total, (xcd + 1) * per_xcd);
-    for (int t0 = xcd * per_xcd + (slot * tiles_per_wg + (SPLITN ? 0 : wave)) * PPT; t0 < t_end; t0 += slots * tiles_per_wg * PPT) {
+    // Geometry of a tile = three dependent gathers (leaf order -> neighbour index -> coordinates): the NEXT tile's chain is issued
+    // in pieces between the phases of the current tile (gstage 0..2), so none of its latency is exposed.
+    const int t_first = xcd * per_xcd + (slot * tiles_per_wg + (SPLITN ? 0 : wave)) * PPT, t_step = slots * tiles_per_wg * PPT;
+    int n_pp[PPT], n_nl = 0;
+    float n_c[3], n_n[3];
+    auto gstage = [&](int st, int t0n) {
+        if (t0n >= t_end) return;
+        if (st == 0) {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const int t = min(t0n + i, t_end - 1);
+                n_pp[i] = a.order ? (t / a.n_cloud) * a.n_cloud + a.order[t] : t;
+            }
+        } else if (st == 1) {
+            const int p = PPT == 2 ? (c32 >= KN ? n_pp[PPT - 1] : n_pp[0]) : n_pp[0];
+            n_nl = a.idx[(size_t)p * KN + (c32 & (KN - 1))];
+            n_c[0] = a.xyz[3 * (size_t)p]; n_c[1] = a.xyz[3 * (size_t)p + 1]; n_c[2] = a.xyz[3 * (size_t)p + 2];
+        } else {
+            const int p = PPT == 2 ? (c32 >= KN ? n_pp[PPT - 1] : n_pp[0]) : n_pp[0];
+            n_nl += (p / a.n_cloud) * a.n_cloud;
+            n_n[0] = a.xyz[3 * (size_t)n_nl]; n_n[1] = a.xyz[3 * (size_t)n_nl + 1]; n_n[2] = a.xyz[3 * (size_t)n_nl + 2];
+        }
+    };
+    gstage(0, t_first);
+    gstage(1, t_first);
+    gstage(2, t_first);
+    for (int t0 = t_first; t0 < t_end; t0 += t_step) {
         // ---- geometry of this lane's row: (point t0 + row / KN, neighbour row % KN) ----
         int pp[PPT];
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const int t = min(t0 + i, t_end - 1);
-            pp[i] = a.order ? (t / a.n_cloud) * a.n_cloud + a.order[t] : t;
-        }
-        const int p = PPT == 2 ? (c32 >= KN ? pp[PPT - 1] : pp[0]) : pp[0];
-        const int base = (p / a.n_cloud) * a.n_cloud;
-        const int nbr = base + a.idx[(size_t)p * KN + (c32 & (KN - 1))];
-        const float cx = a.xyz[3 * (size_t)p], cy = a.xyz[3 * (size_t)p + 1], cz = a.xyz[3 * (size_t)p + 2];
-        const float nx = a.xyz[3 * (size_t)nbr], ny = a.xyz[3 * (size_t)nbr + 1], nz = a.xyz[3 * (size_t)nbr + 2];
+        for (int i = 0; i < PPT; ++i) pp[i] = n_pp[i];
+        const int nbr = n_nl;
+        const float cx = n_c[0], cy = n_c[1], cz = n_c[2];
+        const float nx = n_n[0], ny = n_n[1], nz = n_n[2];
         const float rx = cx - nx, ry = cy - ny, rz = cz - nz;
         const float dis = __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz);
         // enc10 = [dis, rx, ry, rz, cx, cy, cz, nx, ny, nz]; MFMA step s takes elements 2s (lanes 0-31) and 2s + 1 (lanes 32-63)
         float e[5];
         e[0] = hl ? rx : dis; e[1] = hl ? rz : ry; e[2] = hl ? cy : cx; e[3] = hl ? nx : cz; e[4] = hl ? nz : ny;
         if (hl == 0 && (!SPLITN || wave == 0)) NB[c32] = nbr;
+        gstage(0, t0 + t_step);
 
         // ---- LFA mlp1 (transposed: C[channel][row]): f_xyz1 = lrelu(enc10 . W1 + b1) -> T1 ----
 #pragma unroll
@@ -132,6 +154,7 @@ __global__ __launch_bounds__(WAVES * 64) void att32_kernel(Att32Args a)
             }
         }
         phase_sync();
+        gstage(1, t0 + t_step);
         if constexpr (STAGE == 2) {
             // ---- LFA mlp2 (transposed): f_xyz2 = lrelu(f_xyz1 . W2 + b2) ----
             constexpr int NACC = SPLITN ? 1 : CBH;
@@ -143,7 +166,7 @@ __global__ __launch_bounds__(WAVES * 64) void att32_kernel(Att32Args a)
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                 const float4* wq = reinterpret_cast<const float4*>(w2) + (size_t)cb * NQ * 64 + lane;
                 const float* xr = T1 + c32 * PITCH + 4 * hl;
-#pragma unroll 4
+#pragma unroll 8
                 for (int q = 0; q < NQ; ++q) {
                     const float4 aw = wq[(size_t)q * 64];
                     const float4 bx = *reinterpret_cast<const float4*>(xr + 8 * q);
@@ -192,21 +215,32 @@ __global__ __launch_bounds__(WAVES * 64) void att32_kernel(Att32Args a)
             off[4 * g4 + 2] = (unsigned)nb4.z * (LDF * 4u); off[4 * g4 + 3] = (unsigned)nb4.w * (LDF * 4u);
         }
         const char* fgb = reinterpret_cast<const char*>(a.fg);
-        for (int cb = cb0; cb < CBD; cb += CBSTEP) {
-            f32x16 acc;
+        // The gathers of column block i + 1 (G rows for the scores, f rows for the values) are issued before the MFMAs of block i
+        // and consumed after them: their latency hides behind ~2 000 cycles of matrix work.  G is ADDED after the product
+        // (instead of seeding the accumulator) for the same reason.
+        constexpr int NCB = CBD / CBSTEP;
+        float gq[2][16], v[2][16];
+        auto gather = [&](int cb, float (&gdst)[16], float (&vdst)[16]) {
             const unsigned colb = (unsigned)(cb * 32 + c32) * 4u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = *reinterpret_cast<const float*>(fgb + (size_t)(off[r] + (colb + H * 4u)));
-            // values of the weighted sum: columns < H are the gathered neighbour features (global), the rest f_xyz (LDS)
-            float v[16];
-            const bool feat = cb * 32 < H;  // wave-uniform
-            if (feat) {
+            for (int r = 0; r < 16; ++r) gdst[r] = *reinterpret_cast<const float*>(fgb + (size_t)(off[r] + (colb + H * 4u)));
+            if (cb * 32 < H) {  // wave-uniform: columns < H take their values from the gathered neighbour features
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = *reinterpret_cast<const float*>(fgb + (size_t)(off[r] + colb));
+                for (int r = 0; r < 16; ++r) vdst[r] = *reinterpret_cast<const float*>(fgb + (size_t)(off[r] + colb));
             }
+        };
+        gather(cb0, gq[0], v[0]);
+#pragma unroll
+        for (int i = 0; i < NCB; ++i) {
+            const int cb = cb0 + i * CBSTEP;
+            if (i + 1 < NCB) gather(cb + CBSTEP, gq[(i + 1) & 1], v[(i + 1) & 1]);
+            if (i == 0) gstage(2, t0 + t_step);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const float4* wq = reinterpret_cast<const float4*>(wb) + (size_t)cb * NQ * 64 + lane;
             const float* xr = TX + c32 * PITCH + 4 * hl;
-#pragma unroll 4
+#pragma unroll 8
             for (int q = 0; q < NQ; ++q) {
                 const float4 ax = *reinterpret_cast<const float4*>(xr + 8 * q);
                 const float4 bw = wq[(size_t)q * 64];
@@ -215,27 +249,30 @@ __global__ __launch_bounds__(WAVES * 64) void att32_kernel(Att32Args a)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax.z, bw.z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax.w, bw.w, acc, 0, 0, 0);
             }
-            if (!feat) {
+            float (&vv)[16] = v[i & 1];
+            if (cb * 32 >= H) {  // values = f_xyz (LDS tile)
                 const float* tv = TX + (cb * 32 - H + c32) + 4 * hl * PITCH;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = tv[((r & 3) + 8 * (r >> 2)) * PITCH];
+                for (int r = 0; r < 16; ++r) vv[r] = tv[((r & 3) + 8 * (r >> 2)) * PITCH];
             }
 #pragma unroll
-            for (int i = 0; i < PPT; ++i) {
-                float m = acc[i * RP];
+            for (int r = 0; r < 16; ++r) acc[r] += gq[i & 1][r];
 #pragma unroll
-                for (int r = 1; r < RP; ++r) m = fmaxf(m, acc[i * RP + r]);
+            for (int pi = 0; pi < PPT; ++pi) {
+                float m = acc[pi * RP];
+#pragma unroll
+                for (int r = 1; r < RP; ++r) m = fmaxf(m, acc[pi * RP + r]);
                 m = swap32_max(m);
                 float ssum = 0.f, num = 0.f;
 #pragma unroll
                 for (int r = 0; r < RP; ++r) {
-                    const float ex = __expf(acc[i * RP + r] - m);
+                    const float ex = __expf(acc[pi * RP + r] - m);
                     ssum += ex;
-                    num += ex * v[i * RP + r];
+                    num += ex * vv[pi * RP + r];
                 }
                 ssum = swap32_sum(ssum);
                 num = swap32_sum(num);
-                if (hl == 0 && t0 + i < t_end) a.agg[(size_t)pp[i] * D + cb * 32 + c32] = num * __builtin_amdgcn_rcpf(ssum);
+                if (hl == 0 && t0 + pi < t_end) a.agg[(size_t)pp[pi] * D + cb * 32 + c32] = num * __builtin_amdgcn_rcpf(ssum);
             }
         }
         phase_sync();  // the tile and the neighbour rows are overwritten by the next tile
@@ -266,13 +303,16 @@ static int launch_att32(ps_context* c, const Att32Args& a)
 {
     constexpr int H = D / 2, PITCH = H + 4, TILE = 32 * PITCH;
     if constexpr (D <= 128) {
-        constexpr int WAVES = 8;
+        // d = 128: 52 KB of weights + twelve 8.8 KB tiles = 158 KB: one workgroup of twelve waves per CU (three per SIMD);
+        // d = 64: 14 KB + eight 4.7 KB tiles: two workgroups of eight waves per CU (register-limited)
+        constexpr int WAVES = D == 128 ? 12 : 8;
+        constexpr int PER_CU = D == 128 ? 1 : 2;
         constexpr size_t smem = sizeof(float) * ((size_t)(H / 32) * 5 * 64 + (STAGE == 2 ? H * H : 0) + H * D + 2 * H + (size_t)WAVES * (32 + TILE));
         static_assert(smem <= 160 * 1024, "att32: weights + tiles exceed the LDS");
         auto kern = att32_kernel<D, STAGE, KN, WAVES, false>;
         PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         const int tiles = ceil_div(a.n_total, 32 / KN);
-        const int blocks = (std::min(ceil_div(tiles, WAVES), 256 * 2) + 7) & ~7;  // persistent: the weights are staged once per workgroup
+        const int blocks = (std::min(ceil_div(tiles, WAVES), 256 * PER_CU) + 7) & ~7;  // persistent: the weights are staged once per workgroup
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
     } else {
         constexpr int WAVES = D >= 512 ? 8 : 4;

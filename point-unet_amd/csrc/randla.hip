@@ -22,11 +22,14 @@
 namespace ps {
 
 // ---- random_sample: out[b,m,:] = max_k feature[b, pool_idx[b,m,k], :]  (RandLANet.py:345-360) ----------------
+template <int KN>
 __global__ __launch_bounds__(256) void pool_max_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx, const int32_t* __restrict__ order,
                                                        float* __restrict__ out, int rows_out, int m_cloud, int n_cloud, int K, int c4 /* channels / 4 */)
 {
     // one thread per (output row, float4 of channels).  Output rows are walked XCD by XCD in `order` (the kd-tree leaf order of
     // the output level, when the pyramid carries it): the K gathered rows of neighbouring outputs overlap and stay in that XCD's L2.
+    // KN > 0: K is a compile-time constant -- the K index loads and then the K row loads are all in flight together (with a run-time
+    // K the loop waited for every row in turn: 10 us for the 351 rows of the deepest level).
     const int per_xcd = (rows_out + 7) >> 3;
     const int xcd = blockIdx.x & 7;
     const size_t lim = (size_t)min(rows_out, (xcd + 1) * per_xcd) * c4;
@@ -36,13 +39,31 @@ __global__ __launch_bounds__(256) void pool_max_kernel(const float* __restrict__
         const int base = (row / m_cloud) * n_cloud;
         const int32_t* ix = idx + (size_t)row * K;
         const float4* f4 = reinterpret_cast<const float4*>(feat);
-        float4 m = f4[(size_t)(base + ix[0]) * c4 + q];
-        for (int k = 1; k < K; ++k) {
-            const float4 v = f4[(size_t)(base + ix[k]) * c4 + q];
-            m.x = fmaxf(m.x, v.x);
-            m.y = fmaxf(m.y, v.y);
-            m.z = fmaxf(m.z, v.z);
-            m.w = fmaxf(m.w, v.w);
+        float4 m;
+        if constexpr (KN > 0) {
+            int nb[KN];
+#pragma unroll
+            for (int k = 0; k < KN; k += 4) {
+                const int4 i4 = *reinterpret_cast<const int4*>(ix + k);
+                nb[k] = i4.x; nb[k + 1] = i4.y; nb[k + 2] = i4.z; nb[k + 3] = i4.w;
+            }
+            float4 v[KN];
+#pragma unroll
+            for (int k = 0; k < KN; ++k) v[k] = f4[(size_t)(base + nb[k]) * c4 + q];
+            m = v[0];
+#pragma unroll
+            for (int k = 1; k < KN; ++k) {
+                m.x = fmaxf(m.x, v[k].x); m.y = fmaxf(m.y, v[k].y); m.z = fmaxf(m.z, v[k].z); m.w = fmaxf(m.w, v[k].w);
+            }
+        } else {
+            m = f4[(size_t)(base + ix[0]) * c4 + q];
+            for (int k = 1; k < K; ++k) {
+                const float4 v = f4[(size_t)(base + ix[k]) * c4 + q];
+                m.x = fmaxf(m.x, v.x);
+                m.y = fmaxf(m.y, v.y);
+                m.z = fmaxf(m.z, v.z);
+                m.w = fmaxf(m.w, v.w);
+            }
         }
         reinterpret_cast<float4*>(out)[(size_t)row * c4 + q] = m;
     }
@@ -54,7 +75,12 @@ int pool_max(ps_context* c, const float* feat, const int32_t* idx, const int32_t
     const size_t tot = (size_t)B * m * (ch / 4);
     if (!tot) return PS_OK;
     const unsigned blocks = (unsigned)((std::min<size_t>(ceil_div(tot, 256), 256 * 16) + 7) & ~size_t(7));  // a multiple of 8 (XCD walk)
-    hipLaunchKernelGGL(pool_max_kernel, dim3(blocks), dim3(256), 0, c->stream, feat, idx, order, out, (int)(B * m), (int)m, (int)n, K, ch / 4);
+    const bool al = (reinterpret_cast<uintptr_t>(idx) & 15) == 0;
+#define PS_POOL(KN) hipLaunchKernelGGL(pool_max_kernel<KN>, dim3(blocks), dim3(256), 0, c->stream, feat, idx, order, out, (int)(B * m), (int)m, (int)n, K, ch / 4)
+    if (K == 16 && al) PS_POOL(16);
+    else if (K == 32 && al) PS_POOL(32);
+    else PS_POOL(0);
+#undef PS_POOL
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -182,7 +208,7 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
         net->chains.clear();
     }
     std::vector<float> host;  // packed image of everything, then one upload
-    struct Pending { PackedLinear* L; size_t wp_off, b_off, wq_off; };
+    struct Pending { PackedLinear* L; size_t wp_off, b_off, wq_off, w32_off; };
     std::vector<Pending> pend;
     auto emit = [&](PackedLinear& L, const float* W, const float* b, int cin, int cout, int leaky) {
         L = PackedLinear();
@@ -202,7 +228,13 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
             host.resize(qoff + L.kperm_floats());
             pack_weights_kperm(W, cin, cout, L.ntb, host.data() + qoff);
         }
-        pend.push_back({&L, off, boff, qoff});
+        size_t roff = 0;
+        if (cin % 8 == 0 && cout % 32 == 0 && (size_t)cin * cout >= 4096) {  // 32x32x2 image for the few-rows / wide-channel shapes (gemm32.hip)
+            roff = (host.size() + 63) & ~size_t(63);
+            host.resize(roff + (size_t)cin * cout);
+            pack_p32(W, cin, cout, host.data() + roff);
+        }
+        pend.push_back({&L, off, boff, qoff, roff});
     };
     struct PendingRaw { const float** dst; size_t off; };
     std::vector<PendingRaw> pend_raw;
@@ -272,6 +304,7 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
         p.L->wp = net->wbuf.as<float>() + p.wp_off;
         p.L->bias = net->wbuf.as<float>() + p.b_off;
         p.L->wq = p.wq_off ? net->wbuf.as<float>() + p.wq_off : nullptr;
+        p.L->w32 = p.w32_off ? net->wbuf.as<float>() + p.w32_off : nullptr;
     }
     for (auto& p : pend_raw) *p.dst = net->wbuf.as<float>() + p.off;
     net->have_weights = true;

@@ -229,6 +229,7 @@ using RcOne0 = RcShape<1, 1, 0, 1>;                   // level 0: att1-mlp 16 ->
 using RcPair1 = RcShape<2, 2, 0, 2, 0, 4>;            // level 1: mlp1 32 -> 32, G = f . Wfc[:32] 32 -> 64
 using RcPair1b = RcShape<2, 4, 0, 2, 0, 4>;           // level 1: att1-mlp 64 -> 32, G 32 -> 64
 using RcEnc1 = RcShape<2, 4, 0, 4, 2, 8>;             // level 1: att2-mlp 64 -> 64, then [64 | shortcut 32] -> 128
+using RcPair2 = RcShape<2, 8, 0, 4, 0, 8>;            // level 2: mlp1 / att1-mlp 128 -> 64, G = f . Wfc[:64] 64 -> 128 (64 KB of weights)
 using RcHead = RcShape<4, 2, 2, 2, 0, 4, 0, 2, 0, 1>;  // [skip 32 | up 32] -> 32 -> 64 -> 32 -> classes
 
 template <class S>
@@ -267,7 +268,7 @@ static bool rc_build(const ChainStep* steps, int n_steps, const RowSrc& s1, cons
     }
     lds_bytes = (size_t)off * sizeof(float);
     return rc_matches<RcFc0>(a) || rc_matches<RcEnc0>(a) || rc_matches<RcOne0>(a) || rc_matches<RcPair1>(a) || rc_matches<RcPair1b>(a) ||
-           rc_matches<RcEnc1>(a) || rc_matches<RcHead>(a);
+           rc_matches<RcEnc1>(a) || rc_matches<RcPair2>(a) || rc_matches<RcHead>(a);
 }
 
 bool regchain_fits(const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2)
@@ -323,6 +324,7 @@ int regchain(ps_context* c, const ChainStep* steps, int n_steps, const RowSrc& s
     else if (rc_matches<RcPair1>(a)) PS_TRY(rc_launch<RcPair1>(c, a, lds_bytes, blocks));
     else if (rc_matches<RcPair1b>(a)) PS_TRY(rc_launch<RcPair1b>(c, a, lds_bytes, blocks));
     else if (rc_matches<RcEnc1>(a)) PS_TRY(rc_launch<RcEnc1>(c, a, lds_bytes, blocks));
+    else if (rc_matches<RcPair2>(a)) PS_TRY(rc_launch<RcPair2>(c, a, lds_bytes, blocks));
     else PS_TRY(rc_launch<RcHead>(c, a, lds_bytes, blocks));
     PS_HIP(hipGetLastError());
     return PS_OK;

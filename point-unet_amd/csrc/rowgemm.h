@@ -30,6 +30,8 @@ struct PackedLinear {
     // activations to bf16 on the fly and runs v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  8 bf16 per (column block cb, chunk c,
     // half s, lane l, tile j):  wb[(((cb*NC + c)*2 + s)*64 + l)*NTB + j][t] = bf16(W[c*64 + 16*(l>>4) + 8s + t][(cb*NTB + j)*16 + (l&15)])
     const void* wb = nullptr;
+    // device, pack_p32 image (attpool.h) for the 32x32x2 kernel of the deep levels (gemm32.hip); nullptr when not built
+    const float* w32 = nullptr;
     const float* bias = nullptr;  // device [cout_pad] (zeros when the layer has no bias)
     int cin = 0, cout = 0;
     int ks = 0;       // k-steps = ceil(cin/4)
@@ -57,6 +59,11 @@ struct RowSrc {
     int c = 0;                        // channels taken from this source
     int gm = 0, gn = 0;               // batched gather: row r reads x[(r / gm) * gn + gather[r]] when gm != 0
 };
+
+// the same layer on 32x32x2 tiles (gemm32.hip): few rows x wide channels (encoder levels 2-4, decoder); rowgemm() takes this
+// route by itself when the layer carries a w32 image and the shape qualifies
+bool gemm32_fits(const PackedLinear& L, const RowSrc& s1, const RowSrc& s2, int64_t R, int ldy);
+int gemm32(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc& s2, int64_t R, float* y, int ldy);
 
 // y[r, 0:cout] (row stride ldy) for r in [0, R)
 int rowgemm(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc& s2, int64_t R, float* y, int ldy);

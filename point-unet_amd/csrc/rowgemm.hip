@@ -743,6 +743,7 @@ int rowgemm(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc
 {
     if (R <= 0) return PS_OK;
     PS_CHECK(s1.c + s2.c == L.cin, "rowgemm: sources give %d channels, layer expects %d", s1.c + s2.c, L.cin);
+    if (gemm32_fits(L, s1, s2, R, ldy)) return gemm32(c, L, s1, s2, R, y, ldy);  // deep levels: 32x32x2 tiles (gemm32.hip)
     PS_CHECK(R < (1ll << 31), "rowgemm: too many rows");
     RowGemmArgs a;
     a.x1 = s1.x; a.g1 = s1.gather; a.ld1 = s1.ld; a.c1 = s1.c; a.g1m = s1.gm; a.g1n = s1.gn;

@@ -125,6 +125,135 @@ def test_one_training_step_matches_autograd(oracle):
     assert checked > 1000
 
 
+def _bf16_rule(kind, cin, cout):
+    """Which GEMMs of Trainer(mlp_dtype="bf16") run on bf16-rounded operands (csrc/ops.hip: ps_op_conv1x1_ex takes the bf16 kernel
+    when its K axis is a multiple of 16 -- for the input-gradient GEMM dy . W^T that axis is cout --; the weight-gradient kernel
+    rounds every shape)."""
+    return True if kind == "wgrad" else ((cin if kind == "fwd" else cout) % 16 == 0)
+
+
+def _grad_stats(got, ref, names):
+    """(relative L2 over the whole gradient, worst per-tensor max error in units of 3e-2 of the tensor's own max + 1e-4 of the global max)"""
+    gscale = max(np.abs(ref[n]).max() for n in names)
+    num = den = 0.0
+    worst = []
+    for n in names:
+        d = np.asarray(got[n], np.float64) - ref[n]
+        num += float((d ** 2).sum())
+        den += float((ref[n] ** 2).sum())
+        worst.append((float(np.abs(d).max() / (3e-2 * np.abs(ref[n]).max() + 1e-4 * gscale)), n))
+    worst.sort(reverse=True)
+    return (num / den) ** 0.5, worst
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_training_step_at_the_true_width_ladder(oracle, mode):
+    """BASELINE configs[2] at the real widths d_out = 16, 64, 128, 256, 512 (two clouds of 6 000 points: no level has fewer rows
+    than K): loss, logits, EVERY gradient and the Adam update of one step against the torch-CPU float64 autograd oracle.
+
+    fp32.  Bars: loss 2e-5 relative, logits 1e-4; every gradient tensor max |diff| <= 3e-2 of its own max + 1e-4 of the global max;
+    relative L2 over the whole flat gradient <= 5e-3.  Measured: loss 1.2e-7, logits 3.6e-5, rel L2 2.3e-3, worst tensor 1.5e-2 of its
+    own max (one entry of a BatchNorm beta of the decoder: a sum over 186 rows in which ONE leaky-ReLU decision on a pre-activation
+    within rounding noise of zero changes a term by a factor of five).  For scale: torch-CPU float32 autograd against its own float64
+    run on the same inputs gives rel L2 2.9e-4 and an outlier of the same kind at 0.7e-2.
+
+    mlp_dtype="bf16".  The yardstick is the float64 oracle with the operands of exactly the GEMMs the product rounds (see _bf16_rule)
+    rounded to bfloat16.  That MODEL is itself sensitive at the 1e-1 level: an activation within rounding noise of a bf16 boundary
+    rounds the other way, a 4e-3 relative change that flips max-pool / leaky-ReLU decisions downstream -- evaluating the same rounded
+    model in float32 instead of float64 moves its gradient by rel L2 0.125 and its logits by 0.18 (of 15.5).  So the bar is that
+    spread, measured in the test: the product may differ from the float64 evaluation by at most 2x what the float32 evaluation of the
+    same model differs by (plus 1e-3), for the loss, the logits and the whole gradient.  The GEMMs themselves are held to 2e-5 against
+    the rounded-operand product in test_bf16_mlp_mode_rounds_operands_and_accumulates_in_fp32."""
+    import torch
+    from oracle import randla_train_oracle as rto
+    cfg, xyz, feats = netcase.small_deep(6000, seed=12, B=2)
+    assert list(cfg.d_out) == [16, 64, 128, 256, 512]
+    tr, pyr, params, labels, cw, (pts, nbr, pool, up) = _setup(cfg, xyz, feats, mlp_dtype=mode)
+    loss = tr.train_step(pyr, torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda())
+    torch.cuda.synchronize()
+    rule = _bf16_rule if mode == "bf16" else None
+    want = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, step=1, bf16_rule=rule)
+    got = {n: tr.G[n].cpu().numpy() for n in tr.names}
+    rel_loss = abs(float(loss) - want["loss"]) / max(1.0, abs(want["loss"]))
+    logit_err = float(np.abs(tr.last_logits.cpu().numpy().reshape(want["logits"].shape) - want["logits"]).max())
+    rel_l2, worst = _grad_stats(got, want["grads"], tr.names)
+    print("mode %s: loss rel %.2e, logits %.2e, grad rel L2 %.2e, worst tensors %s" % (mode, rel_loss, logit_err, rel_l2, worst[:3]))
+    gscale = max(np.abs(g).max() for g in want["grads"].values())
+    new = tr.export_params()
+    if mode == "fp32":
+        assert rel_loss <= 2e-5 and logit_err < 1e-4
+        assert worst[0][0] <= 1.0, worst[:5]
+        assert rel_l2 <= 5e-3
+        checked = 0
+        for name in tr.names:  # one Adam step where the gradient is signal (Adam normalises rounding noise to O(lr))
+            mask = np.abs(want["grads"][name]) > 2e-2 * gscale
+            if mask.any():
+                checked += int(mask.sum())
+                assert np.abs(new[name] - want["new_params"][name])[mask].max() <= 5e-5, name
+        assert checked > 1000
+    else:
+        alt = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, step=1, bf16_rule=rule, dtype=torch.float32)
+        s_loss = abs(alt["loss"] - want["loss"]) / max(1.0, abs(want["loss"]))
+        s_logit = float(np.abs(alt["logits"] - want["logits"]).max())
+        s_l2, _ = _grad_stats(alt["grads"], want["grads"], tr.names)
+        print("model sensitivity (float32 vs float64 evaluation of the rounded model): loss %.2e, logits %.2e, grad rel L2 %.2e" % (s_loss, s_logit, s_l2))
+        assert rel_loss <= 2 * s_loss + 1e-3
+        assert logit_err <= 2 * s_logit + 1e-3
+        assert rel_l2 <= 2 * s_l2 + 1e-3
+        # and the mode is not a no-op: the fp32 oracle is further away than the rounded one
+        full = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, step=1)
+        assert _grad_stats(got, full["grads"], tr.names)[0] > 0.5 * _grad_stats(want["grads"], full["grads"], tr.names)[0]
+
+
+def test_ignored_labels_leave_the_loss_and_its_mean(oracle):
+    """RandLANet.py:62-84: points whose label is in ignored_label_inds are dropped before the loss (mean over the valid ones) and
+    the remaining raw labels are renumbered 0..C-1.  Trainer(ignored_label_inds=[0]) on raw labels 0..4 against the oracle fed the
+    renumbered labels with -1 for the ignored points; the op alone against torch; an out-of-range label is ignored, never indexed."""
+    import ctypes
+    import torch
+    from oracle import randla_train_oracle as rto
+    from point_unet_amd import _lib, runtime, weights
+    from point_unet_amd.pyramid import build_pyramid
+    from point_unet_amd.train import Trainer
+    from oracle import bindings as ob
+    from oracle import randla_oracle as ro
+    cfg, xyz, feats = netcase.small_deep(1500, seed=2, B=2)
+    cfg.d_out = [16, 32, 64, 32, 16]
+    params = weights.init_params(cfg, seed=3, randomize_bn=True)
+    rng = np.random.default_rng(4)
+    raw = rng.integers(0, cfg.num_classes + 1, xyz.shape[:2]).astype(np.int32)  # 0 = unlabeled, 1..4 = classes
+    cw = np.linspace(1.0, 2.0, cfg.num_classes).astype(np.float32)
+    tr = Trainer(cfg, params=params, learning_rate=1e-3, class_weights=cw, keep_prob=1.0, ignored_label_inds=[0])
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    loss = tr.train_step(pyr, torch.from_numpy(feats).cuda(), torch.from_numpy(raw).cuda())
+    torch.cuda.synchronize()
+    pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: ob.knn_batch(s, q, k), xyz, cfg.k_n, cfg.sub_sampling_ratio)
+    want = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, raw - 1, cw, lr=1e-3, step=1)
+    assert abs(float(loss) - want["loss"]) <= 1e-5 * max(1.0, abs(want["loss"]))
+    gscale = max(np.abs(g).max() for g in want["grads"].values())
+    for name in ("fc/weights", "fc1/weights", "Encoder_layer_0mlp1/weights", "decoder_0/weights"):
+        ref = want["grads"][name]
+        assert np.abs(tr.G[name].cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 2e-5 * gscale, name
+    # the op alone, labels outside [0, C) in both directions
+    L, h = _lib.lib(), runtime.default_context(0).handle
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(1001, 4, generator=g).cuda()
+    y = torch.randint(-2, 7, (1001,), generator=g).int().cuda()
+    w = torch.tensor([1.0, 2.0, 0.5, 3.0]).cuda()
+    out, dz = torch.zeros(1).cuda(), torch.empty_like(z)
+    _lib.check(L.ps_op_weighted_ce(h, p(z), p(y), p(w), 1001, 4, p(out), p(dz)))
+    keep = (y >= 0) & (y < 4)
+    zd = z.double().requires_grad_(True)
+    ref = (torch.nn.functional.cross_entropy(zd[keep], y[keep].long(), reduction="none") * w.double()[y[keep].long()]).mean()
+    ref.backward()
+    assert abs(float(out) - float(ref)) < 1e-5 and (dz.double() - zd.grad).abs().max() < 1e-6
+    assert float(dz[~keep].abs().max()) == 0.0
+    out2 = torch.zeros(1).cuda()
+    _lib.check(L.ps_op_weighted_ce(h, p(z), p(y), p(w), 1001, 4, p(out2), None))
+    assert float(out2) == float(out)  # no float atomics: bit-identical from run to run
+
+
 def test_training_forward_is_run_to_run_identical(oracle):
     """The forward pass has no float atomics (two-stage BatchNorm statistics with a fixed merge order): logits and loss
     inputs are bit-identical between runs, so which side of a leaky-ReLU kink / max-pool tie an activation falls on --
