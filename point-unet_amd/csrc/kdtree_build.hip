@@ -672,8 +672,16 @@ __device__ __forceinline__ void mid_seg_init(MidSeg& g, int start, int end, int 
     g.mis[0] = 0; g.mis[1] = 0;
 }
 
-// misplaced flags of one slab for sweep s as 8 ballots (positions relative to the segment start)
-__device__ __forceinline__ void mid_flags(const float4* A, int q0, int q1, int lane, int ax, float cut, int sweep, int lim1, int lim2,
+// The node's records live in LDS as FOUR planes (x | y | z | index bits), kMid floats each: a pass that only needs the split-axis
+// value reads 4 bytes per record with a conflict-free ds_read_b32 instead of the whole 16-byte record (the passes are LDS-bandwidth
+// bound: eight of them per tree level, each over the whole node).
+struct MidPlanes {
+    float* c[4];
+    __device__ __forceinline__ const float* axis(int ax) const { return ax == 0 ? c[0] : (ax == 1 ? c[1] : c[2]); }
+};
+
+// misplaced flags of one slab for sweep s as 8 ballots (positions q relative to the segment start g0)
+__device__ __forceinline__ void mid_flags(const float* V /* split-axis plane + g0 */, int q0, int q1, int lane, float cut, int sweep, int lim1, int lim2,
                                           unsigned long long (&bL)[8], unsigned long long (&bR)[8])
 {
     const int from = sweep == 0 ? 0 : lim1, bound = sweep == 0 ? lim1 : lim2;
@@ -682,7 +690,7 @@ __device__ __forceinline__ void mid_flags(const float4* A, int q0, int q1, int l
         const int q = q0 + e * 64 + lane;
         bool isL = false, isR = false;
         if (q < q1 && q >= from) {
-            const float v = comp(A[q], ax);
+            const float v = V[q];
             const bool keep_left = sweep == 0 ? (v < cut) : (v <= cut);
             isL = q < bound && !keep_left;
             isR = q >= bound && keep_left;
@@ -696,11 +704,14 @@ __global__ __launch_bounds__(kMidThreads) void build_mid_kernel(const BuildTree*
 {
     constexpr int T = kMidThreads, W = T / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char mid_smem[];
-    float4* P = reinterpret_cast<float4*>(mid_smem);                           // [kMid]
-    short* posR = reinterpret_cast<short*>(mid_smem + sizeof(float4) * kMid);  // [kMid]
+    MidPlanes P;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) P.c[c] = reinterpret_cast<float*>(mid_smem) + c * kMid;                    // 4 x [kMid]
+    short* posR = reinterpret_cast<short*>(mid_smem + sizeof(float4) * kMid);                             // [kMid]
     __shared__ MidSeg segs[2][kMidSegs];
     __shared__ MidSlab slabs[2][kMidSlabs];
-    __shared__ int nseg[2], nslab[2];
+    __shared__ unsigned long long s_ball[kMidSlabs][16];  // the slab's 8 + 8 flag ballots of the current sweep (written in C, reused in D and E)
+    __shared__ int nseg[2], nslab[2], s_mis[2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int n_tasks = min(Q.small_cnt[1], Q.q_cap);
@@ -711,7 +722,10 @@ __global__ __launch_bounds__(kMidThreads) void build_mid_kernel(const BuildTree*
         const BuildTree& t = trees[k_tree];
         float4* const g_pts = t.pts + k_l;
         const int total = k.r - k_l;
-        for (int i = tid; i < total; i += T) P[i] = gload(g_pts + i);
+        for (int i = tid; i < total; i += T) {
+            const float4 p = gload(g_pts + i);
+            P.c[0][i] = p.x; P.c[1][i] = p.y; P.c[2][i] = p.z; P.c[3][i] = p.w;
+        }
         if (tid == 0) {
             const int ns = (total + kSlab - 1) / kSlab;
             mid_seg_init(segs[0][0], 0, total, k.parent, k.side, k.level, 0);
@@ -721,6 +735,7 @@ __global__ __launch_bounds__(kMidThreads) void build_mid_kernel(const BuildTree*
                 sl.seg = 0; sl.start = j * kSlab; sl.end = min(total, (j + 1) * kSlab);
             }
             nseg[0] = 1; nslab[0] = ns;
+            s_mis[0] = 0; s_mis[1] = 0;
         }
         __syncthreads();
         int cur = 0;
@@ -737,10 +752,10 @@ __global__ __launch_bounds__(kMidThreads) void build_mid_kernel(const BuildTree*
                 for (int e = 0; e < 8; ++e) {
                     const int i = s0 + e * 64 + lane;
                     if (i < s1) {
-                        const float4 p = P[i];
-                        mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
-                        mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
-                        mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+                        const float x = P.c[0][i], y = P.c[1][i], z = P.c[2][i];
+                        mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+                        mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+                        mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
                     }
                 }
 #pragma unroll
@@ -764,13 +779,14 @@ __global__ __launch_bounds__(kMidThreads) void build_mid_kernel(const BuildTree*
                 const SplitChoice sc = choose_split(blo, bhi, mn, mx);
                 const int ax = sc.ax;
                 const float cut = sc.cut;
+                const float* V = P.axis(ax);
                 int lt = 0, le = 0;
                 float maxlt = -INFINITY, mingt = INFINITY;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int i = s0 + e * 64 + lane;
                     if (i < s1) {
-                        const float v = comp(P[i], ax);
+                        const float v = V[i];
                         lt += v < cut;
                         le += v <= cut;
                         if (v < cut) maxlt = fmaxf(maxlt, v);
@@ -795,36 +811,41 @@ __global__ __launch_bounds__(kMidThreads) void build_mid_kernel(const BuildTree*
             __syncthreads();
             // ---- the two Hoare sweeps (planeSplit, nanoflann.hpp:1016-1043) in closed form ----
             for (int sweep = 0; sweep < 2; ++sweep) {
-                // C: misplaced counts per slab
+                // C: misplaced flags per slab (kept in LDS for D and E) and their counts
                 for (int si = wave; si < n_sl; si += W) {
                     const int gi = SL[si].seg;
                     const int g0 = G[gi].start;
                     unsigned long long bL[8], bR[8];
-                    mid_flags(P + g0, SL[si].start - g0, SL[si].end - g0, lane, G[gi].ax, G[gi].cut, sweep, G[gi].lt, G[gi].le, bL, bR);
+                    mid_flags(P.axis(G[gi].ax) + g0, SL[si].start - g0, SL[si].end - g0, lane, G[gi].cut, sweep, G[gi].lt, G[gi].le, bL, bR);
                     int wL = 0, wR = 0;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { wL += __popcll(bL[e]); wR += __popcll(bR[e]); }
                     if (lane == 0) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { s_ball[si][e] = bL[e]; s_ball[si][8 + e] = bR[e]; }
                         slabs[cur][si].cnt[sweep] = wL | (wR << 16);
-                        if (wL) atomicAdd(&G[gi].mis[sweep], wL);
+                        if (wL) {
+                            atomicAdd(&G[gi].mis[sweep], wL);
+                            atomicAdd(&s_mis[sweep], wL);
+                        }
                     }
                 }
                 __syncthreads();
+                if (s_mis[sweep] == 0) continue;  // (uniform: nothing misplaced anywhere in this sweep -- the usual case for sweep 1)
                 // D: ranks -> positions of the misplaced-right records, in ascending order
                 for (int si = wave; si < n_sl; si += W) {
                     const int gi = SL[si].seg;
                     if (G[gi].mis[sweep] == 0) continue;
                     const int g0 = G[gi].start, sl0 = G[gi].slab0;
-                    unsigned long long bL[8], bR[8];
-                    mid_flags(P + g0, SL[si].start - g0, SL[si].end - g0, lane, G[gi].ax, G[gi].cut, sweep, G[gi].lt, G[gi].le, bL, bR);
                     const int mine = sl0 + lane < si ? SL[sl0 + lane].cnt[sweep] : 0;  // slabs of a segment are consecutive, in order
                     int pre = 0;
                     for (int j = 0; j < si - sl0; ++j) pre += __builtin_amdgcn_readlane(mine, j) >> 16;
                     int rR = pre;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        if ((bR[e] >> lane) & 1ull) posR[g0 + rR + __popcll(bR[e] & lt_mask)] = (short)(SL[si].start - g0 + e * 64 + lane);
-                        rR += __popcll(bR[e]);
+                        const unsigned long long b = s_ball[si][8 + e];
+                        if ((b >> lane) & 1ull) posR[g0 + rR + __popcll(b & lt_mask)] = (short)(SL[si].start - g0 + e * 64 + lane);
+                        rR += __popcll(b);
                     }
                 }
                 __syncthreads();
@@ -834,27 +855,29 @@ __global__ __launch_bounds__(kMidThreads) void build_mid_kernel(const BuildTree*
                     const int m = G[gi].mis[sweep];
                     if (m == 0) continue;
                     const int g0 = G[gi].start, sl0 = G[gi].slab0;
-                    float4* A = P + g0;
-                    unsigned long long bL[8], bR[8];
-                    mid_flags(A, SL[si].start - g0, SL[si].end - g0, lane, G[gi].ax, G[gi].cut, sweep, G[gi].lt, G[gi].le, bL, bR);
                     const int mine = sl0 + lane < si ? SL[sl0 + lane].cnt[sweep] : 0;
                     int rL = 0;
                     for (int j = 0; j < si - sl0; ++j) rL += __builtin_amdgcn_readlane(mine, j) & 0xffff;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        if ((bL[e] >> lane) & 1ull) {
-                            const int q = SL[si].start - g0 + e * 64 + lane;
-                            const int pr = posR[g0 + m - 1 - (rL + __popcll(bL[e] & lt_mask))];
-                            const float4 x = A[q], y = A[pr];
-                            A[pr] = x;
-                            A[q] = y;
+                        const unsigned long long b = s_ball[si][e];
+                        if ((b >> lane) & 1ull) {
+                            const int q = g0 + SL[si].start - g0 + e * 64 + lane;
+                            const int pr = g0 + posR[g0 + m - 1 - (rL + __popcll(b & lt_mask))];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float x = P.c[c][q], y = P.c[c][pr];
+                                P.c[c][pr] = x;
+                                P.c[c][q] = y;
+                            }
                         }
-                        rL += __popcll(bL[e]);
+                        rL += __popcll(b);
                     }
                 }
                 __syncthreads();
             }
             // ---- F: record the nodes, route the children (one thread per segment) ----
+            if (tid == 0) { s_mis[0] = 0; s_mis[1] = 0; }
             if (tid < n_sg) {
                 const MidSeg& g = G[tid];
                 const int count = g.end - g.start, lim1 = g.lt, lim2 = g.le, ax = g.ax;
@@ -903,7 +926,7 @@ __global__ __launch_bounds__(kMidThreads) void build_mid_kernel(const BuildTree*
             __syncthreads();
             cur ^= 1;
         }
-        for (int i = tid; i < total; i += T) gstore(g_pts + i, P[i]);
+        for (int i = tid; i < total; i += T) gstore(g_pts + i, make_float4(P.c[0][i], P.c[1][i], P.c[2][i], P.c[3][i]));
         __syncthreads();
     }
 }

@@ -205,6 +205,51 @@ def test_training_step_at_the_true_width_ladder(oracle, mode):
         assert _grad_stats(got, full["grads"], tr.names)[0] > 0.5 * _grad_stats(want["grads"], full["grads"], tr.names)[0]
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_full_size_config3_step_properties(mode):
+    """BASELINE configs[2] at FULL size: batch 8 x 180 000-point BraTS-shaped clouds, true widths, one training step (the oracle cannot
+    run this size, so size-independent properties): (1) the loss is finite and equals the class-weighted cross-entropy re-evaluated
+    on the host in float64 from the step's own logits (1e-5 relative); (2) the logits of two runs from the same state are
+    bit-identical (no float atomics in the forward); (3) the flat gradient buffer repeats between the two runs within the
+    atomic-summation tolerance (relative L2 <= 1e-4 fp32; the bf16 mode rounds the same operands both times, same bar) and is
+    non-trivial (no NaN, norm > 0); (4) after Adam every parameter moved by at most lr * (1 + 1e-3) (|m / sqrt(v)| = 1 at step 1)."""
+    import torch
+    from conftest import brats_cloud
+    from point_unet_amd import weights
+    from point_unet_amd.helper_tool import ConfigBraTS as cfg
+    from point_unet_amd.pyramid import build_pyramid
+    from point_unet_amd.train import Trainer
+    B, n0 = 8, 180000
+    xyz = np.stack([brats_cloud(n0, 50 + b) for b in range(B)])
+    rng = np.random.default_rng(9)
+    feats = np.concatenate([xyz, rng.standard_normal((B, n0, 4)).astype(np.float32)], -1)
+    labels = rng.integers(0, cfg.num_classes, (B, n0)).astype(np.int32)
+    cw = np.array([1.0, 2.5, 0.7, 1.8], np.float32)
+    params = weights.init_params(cfg, seed=2)
+    d_xyz, d_f, d_l = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
+    pyr = build_pyramid(d_xyz, cfg)
+    runs = []
+    for _ in range(2):
+        tr = Trainer(cfg, params=params, learning_rate=1e-4, class_weights=cw, keep_prob=1.0, mlp_dtype=mode)
+        before = tr.flat.clone()
+        loss = tr.train_step(pyr, d_f, d_l)
+        torch.cuda.synchronize()
+        runs.append((float(loss), tr.last_logits.clone(), tr.grad.clone(), (tr.flat - before).abs().max().item()))
+        del tr
+    loss, logits, grad, step = runs[0]
+    assert np.isfinite(loss)
+    z = logits.double().reshape(-1, cfg.num_classes)
+    y = d_l.reshape(-1).long()
+    ce = torch.nn.functional.cross_entropy(z, y, reduction="none") * torch.from_numpy(cw).cuda().double()[y]
+    assert abs(loss - float(ce.mean())) <= 1e-5 * max(1.0, abs(loss))
+    assert torch.equal(runs[1][1], logits) and runs[1][0] == loss
+    assert bool(torch.isfinite(grad).all()) and float(grad.norm()) > 0
+    rel = float((runs[1][2].double() - grad.double()).norm() / grad.double().norm())
+    print("config3 %s: loss %.5f, grad norm %.4e, run-to-run rel L2 %.2e, max |step| %.3e" % (mode, loss, float(grad.norm()), rel, step))
+    assert rel <= (1e-5 if mode == "fp32" else 2e-3)
+    assert 0 < step <= 1e-4 * (1 + 1e-3)
+
+
 def test_ignored_labels_leave_the_loss_and_its_mean(oracle):
     """RandLANet.py:62-84: points whose label is in ignored_label_inds are dropped before the loss (mean over the valid ones) and
     the remaining raw labels are renumbered 0..C-1.  Trainer(ignored_label_inds=[0]) on raw labels 0..4 against the oracle fed the
