@@ -26,6 +26,7 @@
 namespace ps {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 struct Att32Args {
     const float* xyz;
@@ -98,22 +99,28 @@ __global__ __launch_bounds__(WAVES * 64) void att32_kernel(Att32Args a)
     const int t_first = xcd * per_xcd + (slot * tiles_per_wg + (SPLITN ? 0 : wave)) * PPT, t_step = slots * tiles_per_wg * PPT;
     int n_pp[PPT], n_nl = 0;
     float n_c[3], n_n[3];
+    // (the kernel is VALU-issue bound at d <= 128 -- one VALU instruction per SIMD every four cycles --, so the index arithmetic is
+    //  kept lean: no integer division for a single cloud, 24-bit multiplies, 32-bit element offsets from uniform bases)
+    const bool one_cloud = a.n_total == a.n_cloud;
+    auto cloud_base = [&](int row) { return one_cloud ? 0 : (row / a.n_cloud) * a.n_cloud; };
     auto gstage = [&](int st, int t0n) {
         if (t0n >= t_end) return;
         if (st == 0) {
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
                 const int t = min(t0n + i, t_end - 1);
-                n_pp[i] = a.order ? (t / a.n_cloud) * a.n_cloud + a.order[t] : t;
+                n_pp[i] = a.order ? cloud_base(t) + a.order[t] : t;
             }
         } else if (st == 1) {
-            const int p = PPT == 2 ? (c32 >= KN ? n_pp[PPT - 1] : n_pp[0]) : n_pp[0];
-            n_nl = a.idx[(size_t)p * KN + (c32 & (KN - 1))];
-            n_c[0] = a.xyz[3 * (size_t)p]; n_c[1] = a.xyz[3 * (size_t)p + 1]; n_c[2] = a.xyz[3 * (size_t)p + 2];
+            const unsigned p = PPT == 2 ? (c32 >= KN ? n_pp[PPT - 1] : n_pp[0]) : n_pp[0];
+            n_nl = a.idx[p * (unsigned)KN + (unsigned)(c32 & (KN - 1))];
+            const float* cp = a.xyz + 3u * p;
+            n_c[0] = cp[0]; n_c[1] = cp[1]; n_c[2] = cp[2];
         } else {
             const int p = PPT == 2 ? (c32 >= KN ? n_pp[PPT - 1] : n_pp[0]) : n_pp[0];
-            n_nl += (p / a.n_cloud) * a.n_cloud;
-            n_n[0] = a.xyz[3 * (size_t)n_nl]; n_n[1] = a.xyz[3 * (size_t)n_nl + 1]; n_n[2] = a.xyz[3 * (size_t)n_nl + 2];
+            n_nl += cloud_base(p);
+            const float* np = a.xyz + 3u * (unsigned)n_nl;
+            n_n[0] = np[0]; n_n[1] = np[1]; n_n[2] = np[2];
         }
     };
     gstage(0, t_first);
@@ -138,18 +145,20 @@ __global__ __launch_bounds__(WAVES * 64) void att32_kernel(Att32Args a)
         // ---- LFA mlp1 (transposed: C[channel][row]): f_xyz1 = lrelu(enc10 . W1 + b1) -> T1 ----
 #pragma unroll
         for (int cb = cb0; cb < CBH; cb += CBSTEP) {
-            f32x16 acc;
+            f32x16 acc;  // seeded with the bias (register r of this lane = channel 32 cb + 8 (r >> 2) + 4 hl + (r & 3))
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 bb = *reinterpret_cast<const float4*>(b1 + cb * 32 + g4 * 8 + hl * 4);
+                acc[4 * g4] = bb.x; acc[4 * g4 + 1] = bb.y; acc[4 * g4 + 2] = bb.z; acc[4 * g4 + 3] = bb.w;
+            }
 #pragma unroll
             for (int s = 0; s < 5; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[(cb * 5 + s) * 64 + lane], e[s], acc, 0, 0, 0);
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int ch = cb * 32 + g4 * 8 + hl * 4;
-                const float4 bb = *reinterpret_cast<const float4*>(b1 + ch);
                 float4 o;
-                o.x = leaky02(acc[4 * g4] + bb.x); o.y = leaky02(acc[4 * g4 + 1] + bb.y);
-                o.z = leaky02(acc[4 * g4 + 2] + bb.z); o.w = leaky02(acc[4 * g4 + 3] + bb.w);
+                o.x = leaky02(acc[4 * g4]); o.y = leaky02(acc[4 * g4 + 1]);
+                o.z = leaky02(acc[4 * g4 + 2]); o.w = leaky02(acc[4 * g4 + 3]);
                 *reinterpret_cast<float4*>(T1 + c32 * PITCH + ch) = o;
             }
         }
@@ -163,7 +172,10 @@ __global__ __launch_bounds__(WAVES * 64) void att32_kernel(Att32Args a)
             for (int cb = cb0; cb < CBH; cb += CBSTEP) {
                 f32x16& acc = acc2[SPLITN ? 0 : cb];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int g4 = 0; g4 < 4; ++g4) {  // seeded with the bias
+                    const float4 bb = *reinterpret_cast<const float4*>(b2 + cb * 32 + g4 * 8 + hl * 4);
+                    acc[4 * g4] = bb.x; acc[4 * g4 + 1] = bb.y; acc[4 * g4 + 2] = bb.z; acc[4 * g4 + 3] = bb.w;
+                }
                 const float4* wq = reinterpret_cast<const float4*>(w2) + (size_t)cb * NQ * 64 + lane;
                 const float* xr = T1 + c32 * PITCH + 4 * hl;
 #pragma unroll 8
@@ -179,10 +191,9 @@ __global__ __launch_bounds__(WAVES * 64) void att32_kernel(Att32Args a)
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int ch = cb * 32 + g4 * 8 + hl * 4;
-                        const float4 bb = *reinterpret_cast<const float4*>(b2 + ch);
                         float4 o;
-                        o.x = leaky02(acc[4 * g4] + bb.x); o.y = leaky02(acc[4 * g4 + 1] + bb.y);
-                        o.z = leaky02(acc[4 * g4 + 2] + bb.z); o.w = leaky02(acc[4 * g4 + 3] + bb.w);
+                        o.x = leaky02(acc[4 * g4]); o.y = leaky02(acc[4 * g4 + 1]);
+                        o.z = leaky02(acc[4 * g4 + 2]); o.w = leaky02(acc[4 * g4 + 3]);
                         *reinterpret_cast<float4*>(T2 + c32 * PITCH + ch) = o;
                     }
                 }
@@ -194,10 +205,9 @@ __global__ __launch_bounds__(WAVES * 64) void att32_kernel(Att32Args a)
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int ch = cb * 32 + g4 * 8 + hl * 4;
-                        const float4 bb = *reinterpret_cast<const float4*>(b2 + ch);
                         float4 o;
-                        o.x = leaky02(acc2[cb][4 * g4] + bb.x); o.y = leaky02(acc2[cb][4 * g4 + 1] + bb.y);
-                        o.z = leaky02(acc2[cb][4 * g4 + 2] + bb.z); o.w = leaky02(acc2[cb][4 * g4 + 3] + bb.w);
+                        o.x = leaky02(acc2[cb][4 * g4]); o.y = leaky02(acc2[cb][4 * g4 + 1]);
+                        o.z = leaky02(acc2[cb][4 * g4 + 2]); o.w = leaky02(acc2[cb][4 * g4 + 3]);
                         *reinterpret_cast<float4*>(T1 + c32 * PITCH + ch) = o;
                     }
             }
@@ -207,33 +217,38 @@ __global__ __launch_bounds__(WAVES * 64) void att32_kernel(Att32Args a)
 
         // ---- scores (C[row][channel]) = G[nbr] + f_xyz . Wfc[H:, :], softmax over the K rows of a point, weighted sum ----
         // accumulator register r of this lane is row (r & 3) + 8 * (r >> 2) + 4 * hl of the tile
-        unsigned off[16];  // byte offset of that row's neighbour in fg
+        // byte offset of (that row's neighbour, this lane's column of the wave's first column block) in fg: the column blocks that
+        // follow are compile-time byte offsets of the loads (instruction immediates): no address arithmetic per gather
+        unsigned off[16];
+        {
+            const unsigned col0 = (unsigned)(cb0 * 32 + c32) * 4u;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int4 nb4 = *reinterpret_cast<const int4*>(NB + 8 * g4 + 4 * hl);
-            off[4 * g4] = (unsigned)nb4.x * (LDF * 4u); off[4 * g4 + 1] = (unsigned)nb4.y * (LDF * 4u);
-            off[4 * g4 + 2] = (unsigned)nb4.z * (LDF * 4u); off[4 * g4 + 3] = (unsigned)nb4.w * (LDF * 4u);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int4 nb4 = *reinterpret_cast<const int4*>(NB + 8 * g4 + 4 * hl);
+                off[4 * g4] = __umul24(nb4.x, LDF * 4u) + col0; off[4 * g4 + 1] = __umul24(nb4.y, LDF * 4u) + col0;  // rows < 2^24 (att_pool32_fits)
+                off[4 * g4 + 2] = __umul24(nb4.z, LDF * 4u) + col0; off[4 * g4 + 3] = __umul24(nb4.w, LDF * 4u) + col0;
+            }
         }
         const char* fgb = reinterpret_cast<const char*>(a.fg);
         // The gathers of column block i + 1 (G rows for the scores, f rows for the values) are issued before the MFMAs of block i
         // and consumed after them: their latency hides behind ~2 000 cycles of matrix work.  G is ADDED after the product
         // (instead of seeding the accumulator) for the same reason.
         constexpr int NCB = CBD / CBSTEP;
-        float gq[2][16], v[2][16];
-        auto gather = [&](int cb, float (&gdst)[16], float (&vdst)[16]) {
-            const unsigned colb = (unsigned)(cb * 32 + c32) * 4u;
+        f32x2 gq[2][8], v[2][8];  // register pairs: the softmax arithmetic below runs on v_pk_*_f32 (two scores per instruction)
+        auto gather = [&](int i, f32x2 (&gdst)[8], f32x2 (&vdst)[8]) {
+            const int rel = i * CBSTEP * 32 * 4;  // compile-time (the loop below is fully unrolled)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gdst[r] = *reinterpret_cast<const float*>(fgb + (size_t)(off[r] + (colb + H * 4u)));
-            if (cb * 32 < H) {  // wave-uniform: columns < H take their values from the gathered neighbour features
+            for (int r = 0; r < 16; ++r) gdst[r >> 1][r & 1] = *reinterpret_cast<const float*>(fgb + off[r] + (rel + H * 4));
+            if ((cb0 + i * CBSTEP) * 32 < H) {  // wave-uniform: columns < H take their values from the gathered neighbour features
 #pragma unroll
-                for (int r = 0; r < 16; ++r) vdst[r] = *reinterpret_cast<const float*>(fgb + (size_t)(off[r] + colb));
+                for (int r = 0; r < 16; ++r) vdst[r >> 1][r & 1] = *reinterpret_cast<const float*>(fgb + off[r] + rel);
             }
         };
-        gather(cb0, gq[0], v[0]);
+        gather(0, gq[0], v[0]);
 #pragma unroll
         for (int i = 0; i < NCB; ++i) {
             const int cb = cb0 + i * CBSTEP;
-            if (i + 1 < NCB) gather(cb + CBSTEP, gq[(i + 1) & 1], v[(i + 1) & 1]);
+            if (i + 1 < NCB) gather(i + 1, gq[(i + 1) & 1], v[(i + 1) & 1]);
             if (i == 0) gstage(2, t0 + t_step);
             f32x16 acc;
 #pragma unroll
@@ -249,30 +264,37 @@ __global__ __launch_bounds__(WAVES * 64) void att32_kernel(Att32Args a)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax.z, bw.z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax.w, bw.w, acc, 0, 0, 0);
             }
-            float (&vv)[16] = v[i & 1];
+            f32x2 (&vv)[8] = v[i & 1];
             if (cb * 32 >= H) {  // values = f_xyz (LDS tile)
                 const float* tv = TX + (cb * 32 - H + c32) + 4 * hl * PITCH;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) vv[r] = tv[((r & 3) + 8 * (r >> 2)) * PITCH];
+                for (int r = 0; r < 16; ++r) vv[r >> 1][r & 1] = tv[((r & 3) + 8 * (r >> 2)) * PITCH];
             }
+            // the Wfc[H:, :] image is pre-multiplied by log2(e) (pack_p32 call in randla.hip), the gathered G joins with the same factor:
+            // softmax(s) = exp2(s' - max s') with s' = s log2(e) -- one multiply per score less than expf
+            f32x2 sc[8];
+            const f32x2 l2e = {1.4426950408889634f, 1.4426950408889634f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += gq[i & 1][r];
+            for (int j = 0; j < 8; ++j) sc[j] = __builtin_elementwise_fma(gq[i & 1][j], l2e, f32x2{acc[2 * j], acc[2 * j + 1]});
+            constexpr int PP = RP / 2;  // register pairs per point
 #pragma unroll
             for (int pi = 0; pi < PPT; ++pi) {
-                float m = acc[pi * RP];
+                float m = fmaxf(sc[pi * PP][0], sc[pi * PP][1]);
 #pragma unroll
-                for (int r = 1; r < RP; ++r) m = fmaxf(m, acc[pi * RP + r]);
+                for (int j = 1; j < PP; ++j) m = fmaxf(m, fmaxf(sc[pi * PP + j][0], sc[pi * PP + j][1]));
                 m = swap32_max(m);
-                float ssum = 0.f, num = 0.f;
+                const f32x2 mm = {m, m};
+                f32x2 ssum2 = {0.f, 0.f}, num2 = {0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < RP; ++r) {
-                    const float ex = __expf(acc[pi * RP + r] - m);
-                    ssum += ex;
-                    num += ex * vv[pi * RP + r];
+                for (int j = 0; j < PP; ++j) {
+                    const f32x2 dd = sc[pi * PP + j] - mm;
+                    const f32x2 ex = {__builtin_amdgcn_exp2f(dd[0]), __builtin_amdgcn_exp2f(dd[1])};
+                    ssum2 += ex;
+                    num2 = __builtin_elementwise_fma(ex, vv[pi * PP + j], num2);
                 }
-                ssum = swap32_sum(ssum);
-                num = swap32_sum(num);
-                if (hl == 0 && t0 + pi < t_end) a.agg[(size_t)pp[pi] * D + cb * 32 + c32] = num * __builtin_amdgcn_rcpf(ssum);
+                const float ssum = swap32_sum(ssum2[0] + ssum2[1]);
+                const float num = swap32_sum(num2[0] + num2[1]);
+                if (hl == 0 && t0 + pi < t_end) a.agg[__umul24(pp[pi], D) + (unsigned)(cb * 32 + c32)] = num * __builtin_amdgcn_rcpf(ssum);
             }
         }
         phase_sync();  // the tile and the neighbour rows are overwritten by the next tile
@@ -342,7 +364,7 @@ static int dispatch32(ps_context* c, int d, const Att32Args& a)
 bool att_pool32_fits(const AttStage& s)
 {
     // 32-bit byte offsets into fg: rows * (h + d) * 4 bytes must stay below 4 GiB
-    return s.p32 && s.wbot && s.d >= 64 && (s.k == 16 || s.k == 32) && s.ldf == s.d / 2 + s.d &&
+    return s.p32 && s.wbot && s.d >= 64 && (s.k == 16 || s.k == 32) && s.ldf == s.d / 2 + s.d && s.n_total < (1 << 24) &&
            (uint64_t)s.n_total * (uint64_t)(s.d / 2 + s.d) * 4u < (1ull << 32);
 }
 

@@ -260,9 +260,15 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
         e.has_p32 = d >= 64;
         if (e.has_p32) {  // (spec order: mlp1, lfa1, att1 fc, att1 mlp, lfa2, att2 fc, ...)
             pack_p32_locse(W(si + 1), h, emit_raw(&e.p32.w1, (size_t)(h / 32) * 5 * 64));
-            pack_p32(W(si + 2) + (size_t)h * d, h, d, emit_raw(&e.p32.wb1, (size_t)h * d));
+            // the score weights carry log2(e): the kernel's softmax is exp2(s' - max s') (attpool32.hip)
+            auto scaled = [&](const float* src, size_t count) {
+                tmp.resize(count);
+                for (size_t t = 0; t < count; ++t) tmp[t] = (float)((double)src[t] * 1.4426950408889634);
+                return tmp.data();
+            };
+            pack_p32(scaled(W(si + 2) + (size_t)h * d, (size_t)h * d), h, d, emit_raw(&e.p32.wb1, (size_t)h * d));
             pack_p32(W(si + 4), h, h, emit_raw(&e.p32.w2, (size_t)h * h));
-            pack_p32(W(si + 5) + (size_t)h * d, h, d, emit_raw(&e.p32.wb2, (size_t)h * d));
+            pack_p32(scaled(W(si + 5) + (size_t)h * d, (size_t)h * d), h, d, emit_raw(&e.p32.wb2, (size_t)h * d));
         }
         emit(e.mlp1, W(si), Bv(si), d_in, h, 1); ++si;
         emit(e.lfa1, W(si), Bv(si), 10, h, 1); ++si;
