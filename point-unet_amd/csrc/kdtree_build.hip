@@ -638,6 +638,200 @@ __global__ __launch_bounds__(256) void build_subtree_kernel(const BuildTree* __r
     }
 }
 
+// ---- flat subtree kernel: one workgroup per node of <= kSmall points, ONE THREAD PER POINT POSITION --------------------------------
+// The wave-per-node kernel above runs a subtree's ~31 splits one after the other (80-90 us for the ~1 400 subtrees of a 180 000-point
+// pyramid: a chain of LDS round trips at one or two waves per SIMD).  Here every round advances ALL live segments of the node at
+// once: thread i owns position i, carries its segment's descriptor (range, incoming box, parent link) in registers, and the
+// per-segment facts (tight extents, counts against the cut, misplaced counts) are LDS accumulators indexed by the segment's first
+// position.  The two Hoare sweeps use the same closed form as everywhere else (i-th misplaced-left <-> i-th misplaced-right from the
+// right); the order-preserving ranks are one block-wide exclusive scan of the two flags (ballot prefix inside a wave, wave totals
+// through LDS) minus the scan value at the segment's first position.  A round is ~12 workgroup barriers whatever the number of
+// segments, and a subtree is finished in (height + 1) rounds: 6-7 for the balanced trees of real clouds.
+struct FlatAcc {
+    unsigned mn[3], mx[3];     // ordered-uint extents
+    int lt, le;
+    unsigned maxlt, mingt;     // ordered-uint
+    int base[2], endL[2];      // per sweep: packed exclusive scan (L | R << 16) at the segment start; inclusive L rank at its last position
+};
+
+__global__ __launch_bounds__(kSmall) void build_flat_kernel(const BuildTree* __restrict__ trees, BuildQueues Q)
+{
+    constexpr int T = kSmall, W = T / 64;
+    __shared__ float s_p[4][T];
+    __shared__ short s_posR[T];
+    __shared__ FlatAcc s_acc[T];
+    __shared__ int s_wtot[2][W];
+    __shared__ int s_live[2];  // "some segment is still live after this round", by round parity (a flag is reset a full round after its last read)
+    __shared__ int s_mis[2];   // misplaced records per sweep of the current round
+    __shared__ int s_depth;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int n_tasks = min(Q.small_cnt[0], Q.small_cap);
+
+    for (int ti = blockIdx.x; ti < n_tasks; ti += gridDim.x) {
+        const BuildTask k = Q.small_q[ti];
+        const BuildTree t = trees[k.tree];
+        const int total = k.r - k.l;
+        if (tid < total) {
+            const float4 p = gload(t.pts + k.l + tid);
+            s_p[0][tid] = p.x; s_p[1][tid] = p.y; s_p[2][tid] = p.z; s_p[3][tid] = p.w;
+        }
+        // this thread's segment (registers): [s, e) relative to the node, incoming box, link to the parent node
+        int s = 0, e = total, parent = k.parent, side = k.side, level = k.level;
+        float lo[3], hi[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lo[c] = k.lo[c]; hi[c] = k.hi[c]; }
+        bool live = tid < total;
+        int round = 0;
+        if (tid == 0) s_depth = 0;
+        if (total <= kLeafMax) {  // the node itself is a leaf
+            if (tid == 0) {
+                t.nodes[2 * k.l] = make_int4(k.l, k.l + total, 0, 0);
+                const int ref = leaf_ref(k.l, total);
+                if (parent < 0) t.meta->root = ref;
+                else if (side == 0) atomicOr(&t.nodes[parent].x, ref);
+                else t.nodes[parent].y = ref;
+                atomicMax(&t.meta->depth, level);
+            }
+            __syncthreads();
+            continue;
+        }
+        for (;;) {
+            // ---- 0: leaders reset their segment's accumulators ----
+            if (live && tid == s) {
+                FlatAcc& a = s_acc[s];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { a.mn[c] = 0xffffffffu; a.mx[c] = 0u; }
+                a.lt = 0; a.le = 0; a.maxlt = 0u; a.mingt = 0xffffffffu;
+            }
+            if (tid == 0) { s_live[round & 1] = 0; s_mis[0] = 0; s_mis[1] = 0; }
+            __syncthreads();
+            // ---- 1: tight extents ----
+            float px = 0.f, py = 0.f, pz = 0.f;
+            if (live) {
+                px = s_p[0][tid]; py = s_p[1][tid]; pz = s_p[2][tid];
+                FlatAcc& a = s_acc[s];
+                atomicMin(&a.mn[0], f2ord(px)); atomicMax(&a.mx[0], f2ord(px));
+                atomicMin(&a.mn[1], f2ord(py)); atomicMax(&a.mx[1], f2ord(py));
+                atomicMin(&a.mn[2], f2ord(pz)); atomicMax(&a.mx[2], f2ord(pz));
+            }
+            __syncthreads();
+            // ---- 2: split choice (every thread of the segment, identical), counts against the cut ----
+            int ax = 0;
+            float cut = 0.f, v = 0.f;
+            if (live) {
+                const FlatAcc& a = s_acc[s];
+                float mn[3], mx[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { mn[c] = ord2f(a.mn[c]); mx[c] = ord2f(a.mx[c]); }
+                const SplitChoice sc = choose_split(lo, hi, mn, mx);
+                ax = sc.ax;
+                cut = sc.cut;
+                v = ax == 0 ? px : (ax == 1 ? py : pz);
+                FlatAcc& w = s_acc[s];
+                if (v < cut) { atomicAdd(&w.lt, 1); atomicMax(&w.maxlt, f2ord(v)); }
+                if (v <= cut) atomicAdd(&w.le, 1);
+                if (v > cut) atomicMin(&w.mingt, f2ord(v));
+            }
+            __syncthreads();
+            int lim1 = 0, lim2 = 0;
+            float maxlt = 0.f, mingt = 0.f;
+            if (live) {
+                const FlatAcc& a = s_acc[s];
+                lim1 = a.lt; lim2 = a.le; maxlt = ord2f(a.maxlt); mingt = ord2f(a.mingt);
+            }
+            const int q = tid - s;
+            // ---- the two Hoare sweeps (planeSplit, nanoflann.hpp:1016-1043) in closed form ----
+#pragma unroll
+            for (int sweep = 0; sweep < 2; ++sweep) {
+                const int from = sweep == 0 ? 0 : lim1, bound = sweep == 0 ? lim1 : lim2;
+                bool isL = false, isR = false;
+                if (live && q >= from) {
+                    const bool keep_left = sweep == 0 ? (v < cut) : (v <= cut);
+                    isL = q < bound && !keep_left;
+                    isR = q >= bound && keep_left;
+                }
+                const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
+                if (lane == 0) {
+                    s_wtot[sweep][wave] = __popcll(bL) | (__popcll(bR) << 16);
+                    if (bL) atomicAdd(&s_mis[sweep], (int)__popcll(bL));
+                }
+                __syncthreads();
+                if (s_mis[sweep] == 0) continue;  // (uniform) nothing misplaced anywhere in this sweep
+                int pre = 0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) pre += w < wave ? s_wtot[sweep][w] : 0;
+                const int excl = pre + (__popcll(bL & lt_mask) | (__popcll(bR & lt_mask) << 16));  // packed exclusive ranks (L | R << 16)
+                if (live && tid == s) s_acc[s].base[sweep] = excl;
+                if (live && tid == e - 1) s_acc[s].endL[sweep] = (excl & 0xffff) + (isL ? 1 : 0);
+                __syncthreads();
+                int m = 0, baseL = 0;
+                if (live) {
+                    const FlatAcc& a = s_acc[s];
+                    baseL = a.base[sweep] & 0xffff;
+                    m = a.endL[sweep] - baseL;
+                    if (isR) s_posR[s + ((excl >> 16) - (a.base[sweep] >> 16))] = (short)tid;
+                }
+                __syncthreads();
+                if (isL) {  // i-th misplaced-left record (ascending) swaps with the i-th misplaced-right record counted from the right
+                    const int pr = s_posR[s + m - 1 - ((excl & 0xffff) - baseL)];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float x = s_p[c][tid], y = s_p[c][pr];
+                        s_p[c][pr] = x;
+                        s_p[c][tid] = y;
+                    }
+                }
+                __syncthreads();
+                if (live) v = s_p[ax][tid];  // (the record at this position may have changed)
+            }
+            // ---- emit the node, descend into the child this position now belongs to ----
+            if (live) {
+                const int count = e - s, half = count / 2;
+                const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
+                const int id = 2 * (k.l + s + idx) - 1;
+                if (tid == s) {
+                    const float divlow = idx > lim1 ? cut : maxlt;
+                    const float divhigh = idx < lim2 ? cut : mingt;
+                    t.nodes[id] = make_int4((int)((unsigned)ax << 30), 0, __float_as_int(divlow), __float_as_int(divhigh));
+                    if (parent < 0) t.meta->root = id;
+                    else if (side == 0) atomicOr(&t.nodes[parent].x, id);
+                    else t.nodes[parent].y = id;
+                }
+                if (q < idx) {
+                    e = s + idx; side = 0;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) hi[c] = c == ax ? cut : hi[c];
+                } else {
+                    s = s + idx; side = 1;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) lo[c] = c == ax ? cut : lo[c];
+                }
+                parent = id;
+                level += 1;
+            }
+            __syncthreads();  // the parents' records are in memory before any child links to them
+            if (live && e - s <= kLeafMax) {
+                if (tid == s) {
+                    t.nodes[2 * (k.l + s)] = make_int4(k.l + s, k.l + e, 0, 0);
+                    const int ref = leaf_ref(k.l + s, e - s);
+                    if (side == 0) atomicOr(&t.nodes[parent].x, ref);
+                    else t.nodes[parent].y = ref;
+                    atomicMax(&s_depth, level);
+                }
+                live = false;
+            }
+            if (live && tid == s) s_live[round & 1] = 1;
+            __syncthreads();
+            if (s_live[round & 1] == 0) break;
+            ++round;
+        }
+        if (tid < total) gstore(t.pts + k.l + tid, make_float4(s_p[0][tid], s_p[1][tid], s_p[2][tid], s_p[3][tid]));
+        if (tid == 0) atomicMax(&t.meta->depth, s_depth);
+        __syncthreads();
+    }
+}
+
 // ---- mid kernel: one workgroup splits a node of <= kMid points down to <= kSmall-point pieces, entirely in LDS ------
 // The node's records are loaded once (128 KiB for 8 192 points) and go back to HBM once at the end; in between the
 // workgroup advances LEVEL BY LEVEL over all of the node's live segments (pieces still above kSmall points, at most
@@ -1312,7 +1506,7 @@ static int launch_mid_and_subtrees(ps_context* c, const BuildTree* d_trees, cons
     hipStream_t st = c->stream;
     const unsigned grid_mid = (unsigned)std::min<size_t>(tot / kSmall + T + 1, 1024);
     hipLaunchKernelGGL(build_mid_kernel, dim3(grid_mid), dim3(kMidThreads), mid_lds, st, d_trees, Q);
-    hipLaunchKernelGGL(build_subtree_kernel, dim3((unsigned)std::min<size_t>(ceil_div(small_cap, 4), 2048)), dim3(256), 0, st, d_trees, Q);
+    hipLaunchKernelGGL(build_flat_kernel, dim3((unsigned)std::min<size_t>(small_cap, 4096)), dim3(kSmall), 0, st, d_trees, Q);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
