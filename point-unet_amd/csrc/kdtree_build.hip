@@ -659,8 +659,10 @@ __global__ __launch_bounds__(kSmall) void build_flat_kernel(const BuildTree* __r
     constexpr int T = kSmall, W = T / 64;
     __shared__ float s_p[4][T];
     __shared__ short s_posR[T];
-    __shared__ FlatAcc s_acc[T];
+    __shared__ FlatAcc s_accs[T / 8];  // one per live segment, indexed by start / 8 (live segments are longer than kLeafMax >= 8: unique)
     __shared__ int s_wtot[2][W];
+    // (node records go straight to global memory: assembling them in LDS and writing them out once at the end was measured
+    //  SLOWER, 53 vs 44 us -- the kernel is bound by the instruction count of its rounds, not by the stores' latency)
     __shared__ int s_live[2];  // "some segment is still live after this round", by round parity (a flag is reset a full round after its last read)
     __shared__ int s_mis[2];   // misplaced records per sweep of the current round
     __shared__ int s_depth;
@@ -699,7 +701,7 @@ __global__ __launch_bounds__(kSmall) void build_flat_kernel(const BuildTree* __r
         for (;;) {
             // ---- 0: leaders reset their segment's accumulators ----
             if (live && tid == s) {
-                FlatAcc& a = s_acc[s];
+                FlatAcc& a = s_accs[s >> 3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { a.mn[c] = 0xffffffffu; a.mx[c] = 0u; }
                 a.lt = 0; a.le = 0; a.maxlt = 0u; a.mingt = 0xffffffffu;
@@ -707,10 +709,19 @@ __global__ __launch_bounds__(kSmall) void build_flat_kernel(const BuildTree* __r
             if (tid == 0) { s_live[round & 1] = 0; s_mis[0] = 0; s_mis[1] = 0; }
             __syncthreads();
             // ---- 1: tight extents ----
+            // (LDS atomics of a wave to ONE address are served one lane after the other: while a wave lies inside a single segment --
+            //  the first rounds, where the segments are long -- it reduces in registers and sends one atomic per quantity)
+            const bool uni = __all(live) && __all(s == __builtin_amdgcn_readfirstlane(s));
             float px = 0.f, py = 0.f, pz = 0.f;
-            if (live) {
-                px = s_p[0][tid]; py = s_p[1][tid]; pz = s_p[2][tid];
-                FlatAcc& a = s_acc[s];
+            if (live) { px = s_p[0][tid]; py = s_p[1][tid]; pz = s_p[2][tid]; }
+            if (uni) {
+                const float mnx = wave_min(px), mxx = wave_max(px), mny = wave_min(py), mxy = wave_max(py), mnz = wave_min(pz), mxz = wave_max(pz);
+                if (lane < 3) {
+                    atomicMin(&s_accs[s >> 3].mn[lane], f2ord(lane == 0 ? mnx : (lane == 1 ? mny : mnz)));
+                    atomicMax(&s_accs[s >> 3].mx[lane], f2ord(lane == 0 ? mxx : (lane == 1 ? mxy : mxz)));
+                }
+            } else if (live) {
+                FlatAcc& a = s_accs[s >> 3];
                 atomicMin(&a.mn[0], f2ord(px)); atomicMax(&a.mx[0], f2ord(px));
                 atomicMin(&a.mn[1], f2ord(py)); atomicMax(&a.mx[1], f2ord(py));
                 atomicMin(&a.mn[2], f2ord(pz)); atomicMax(&a.mx[2], f2ord(pz));
@@ -720,7 +731,7 @@ __global__ __launch_bounds__(kSmall) void build_flat_kernel(const BuildTree* __r
             int ax = 0;
             float cut = 0.f, v = 0.f;
             if (live) {
-                const FlatAcc& a = s_acc[s];
+                const FlatAcc& a = s_accs[s >> 3];
                 float mn[3], mx[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { mn[c] = ord2f(a.mn[c]); mx[c] = ord2f(a.mx[c]); }
@@ -728,7 +739,18 @@ __global__ __launch_bounds__(kSmall) void build_flat_kernel(const BuildTree* __r
                 ax = sc.ax;
                 cut = sc.cut;
                 v = ax == 0 ? px : (ax == 1 ? py : pz);
-                FlatAcc& w = s_acc[s];
+            }
+            if (uni) {
+                const int lt = (int)__popcll(__ballot(v < cut)), le = (int)__popcll(__ballot(v <= cut));
+                const float ml = wave_max(v < cut ? v : -INFINITY), mg = wave_min(v > cut ? v : INFINITY);
+                if (lane == 0) {
+                    FlatAcc& w = s_accs[s >> 3];
+                    if (lt) { atomicAdd(&w.lt, lt); atomicMax(&w.maxlt, f2ord(ml)); }
+                    if (le) atomicAdd(&w.le, le);
+                    if (mg < INFINITY) atomicMin(&w.mingt, f2ord(mg));
+                }
+            } else if (live) {
+                FlatAcc& w = s_accs[s >> 3];
                 if (v < cut) { atomicAdd(&w.lt, 1); atomicMax(&w.maxlt, f2ord(v)); }
                 if (v <= cut) atomicAdd(&w.le, 1);
                 if (v > cut) atomicMin(&w.mingt, f2ord(v));
@@ -737,7 +759,7 @@ __global__ __launch_bounds__(kSmall) void build_flat_kernel(const BuildTree* __r
             int lim1 = 0, lim2 = 0;
             float maxlt = 0.f, mingt = 0.f;
             if (live) {
-                const FlatAcc& a = s_acc[s];
+                const FlatAcc& a = s_accs[s >> 3];
                 lim1 = a.lt; lim2 = a.le; maxlt = ord2f(a.maxlt); mingt = ord2f(a.mingt);
             }
             const int q = tid - s;
@@ -762,12 +784,12 @@ __global__ __launch_bounds__(kSmall) void build_flat_kernel(const BuildTree* __r
 #pragma unroll
                 for (int w = 0; w < W; ++w) pre += w < wave ? s_wtot[sweep][w] : 0;
                 const int excl = pre + (__popcll(bL & lt_mask) | (__popcll(bR & lt_mask) << 16));  // packed exclusive ranks (L | R << 16)
-                if (live && tid == s) s_acc[s].base[sweep] = excl;
-                if (live && tid == e - 1) s_acc[s].endL[sweep] = (excl & 0xffff) + (isL ? 1 : 0);
+                if (live && tid == s) s_accs[s >> 3].base[sweep] = excl;
+                if (live && tid == e - 1) s_accs[s >> 3].endL[sweep] = (excl & 0xffff) + (isL ? 1 : 0);
                 __syncthreads();
                 int m = 0, baseL = 0;
                 if (live) {
-                    const FlatAcc& a = s_acc[s];
+                    const FlatAcc& a = s_accs[s >> 3];
                     baseL = a.base[sweep] & 0xffff;
                     m = a.endL[sweep] - baseL;
                     if (isR) s_posR[s + ((excl >> 16) - (a.base[sweep] >> 16))] = (short)tid;
