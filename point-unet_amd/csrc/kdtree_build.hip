@@ -9,8 +9,10 @@
 //                    count -> rank -> swap, emit) is one small kernel over 2 048-record chunks spread over the chip
 //   mid kernel       nodes of kSmall+1 .. kMid points: ONE workgroup loads the node into LDS and advances level by level
 //                    over all of its live segments at once, with __syncthreads() only
-//   subtree kernel   nodes of <= kSmall points: one wave builds the whole subtree in LDS with ballot-based ranks
-//   level kernel     (stragglers / very unbalanced clouds) one workgroup per node above kMid after the chunked levels
+//   flat kernel      nodes of <= kSmall points: one workgroup, one thread per point position; every round advances all live
+//                    segments of the node at once (block-wide flag scans for the ranks of the closed-form Hoare sweeps)
+//   straggler kernel (very unbalanced clouds) one workgroup per node still above kMid after the chunked levels finishes
+//                    everything above kMid below it depth first -- ONE launch, nothing left for the host to repair
 // nanoflann's two Hoare sweeps are reproduced in CLOSED FORM everywhere -- the i-th misplaced element from the left swaps
 // with the i-th misplaced element from the right, so ranks from scans of two flag vectors give every swap pair.
 // Node ids are position-derived (kdtree.h), so the result does not depend on scheduling.  divlow / divhigh are the
@@ -27,7 +29,8 @@
 
 namespace ps {
 
-constexpr int kSmall = 256;     // nodes up to this many points are finished by one wave in LDS
+constexpr int kSmall = 256;     // nodes up to this many points are finished by one workgroup, one thread per point (build_flat_kernel;
+                                // 1 024 was measured: flat kernel 44 -> 88 us, mid kernel 106 -> 73 us, no gain)
 constexpr int kMid = 8192;      // nodes up to this many points are split down to <= kSmall by one workgroup in LDS
 constexpr int kMidThreads = 1024;
 constexpr int kBigThreads = 512;
@@ -52,7 +55,7 @@ struct BuildTree {
 struct BuildQueues {
     BuildTask* q[2];
     BuildTask* mid_q;    // nodes of kSmall+1 .. kMid points (build_mid_kernel)
-    BuildTask* small_q;  // nodes of <= kSmall points (build_subtree_kernel)
+    BuildTask* small_q;  // nodes of <= kSmall points (build_flat_kernel)
     int32_t* level_cnt;  // [kMaxLevels]
     int32_t* small_cnt;  // small_cnt[0] = pushed, [1] = mid pushed, [2] = mid done, [3] = small done
     int32_t* flags;      // flags[1] = queue overflow
@@ -176,6 +179,34 @@ __device__ __forceinline__ SplitChoice choose_split(const float* lo, const float
     return c;
 }
 
+// The same decision with the chosen axis' values carried along as scalars: in the straggler kernel, whose box lives in LDS, the
+// run-time index `lo[cutfeat]` above put the arrays into scratch memory (16 bytes per lane -- and a kernel that needs scratch pays
+// for the private-segment set-up on every dispatch).  (Used only there: the same body inside build_flat_kernel crashes hipcc 7.2's
+// instruction selection.)
+__device__ __forceinline__ SplitChoice choose_split_scalar(const float* lo, const float* hi, const float* mn, const float* mx)
+{
+    float max_span = __fsub_rn(hi[0], lo[0]);
+    for (int a = 1; a < 3; ++a) {
+        const float s = __fsub_rn(hi[a], lo[a]);
+        if (s > max_span) max_span = s;
+    }
+    const float thresh = __fmul_rn(__fsub_rn(1.0f, 0.00001f), max_span);
+    int cutfeat = 0;
+    float max_spread = -1.f, lo_c = lo[0], hi_c = hi[0], mn_c = mn[0], mx_c = mx[0];
+    {
+        const bool in0 = __fsub_rn(hi[0], lo[0]) > thresh, in1 = __fsub_rn(hi[1], lo[1]) > thresh, in2 = __fsub_rn(hi[2], lo[2]) > thresh;
+        const float sp0 = __fsub_rn(mx[0], mn[0]), sp1 = __fsub_rn(mx[1], mn[1]), sp2 = __fsub_rn(mx[2], mn[2]);
+        if (in0 && sp0 > max_spread) { cutfeat = 0; max_spread = sp0; }
+        if (in1 && sp1 > max_spread) { cutfeat = 1; max_spread = sp1; lo_c = lo[1]; hi_c = hi[1]; mn_c = mn[1]; mx_c = mx[1]; }
+        if (in2 && sp2 > max_spread) { cutfeat = 2; max_spread = sp2; lo_c = lo[2]; hi_c = hi[2]; mn_c = mn[2]; mx_c = mx[2]; }
+    }
+    const float split = __fmul_rn(__fadd_rn(lo_c, hi_c), 0.5f);
+    SplitChoice c;
+    c.ax = cutfeat;
+    c.cut = split < mn_c ? mn_c : (split > mx_c ? mx_c : split);
+    return c;
+}
+
 // Everything the parent must record once the partition is known.
 __device__ __forceinline__ void emit_inner(const BuildQueues& Q, const BuildTree& t, const BuildTask& k, int ax, float cut, int lim1, int lim2,
                                            float maxlt, float mingt, BuildTask* kids /* [2] out */, int* node_id)
@@ -188,6 +219,7 @@ __device__ __forceinline__ void emit_inner(const BuildQueues& Q, const BuildTree
     const float divlow = idx > lim1 ? cut : maxlt;
     const float divhigh = idx < lim2 ? cut : mingt;
     t.nodes[id] = make_int4((int)((unsigned)ax << 30), 0, __float_as_int(divlow), __float_as_int(divhigh));
+#pragma unroll
     for (int s = 0; s < 2; ++s) {
         BuildTask c = k;
         c.parent = id;
@@ -311,7 +343,7 @@ __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTre
         for (int w = 1; w < W; ++w) { lo = fminf(lo, S.mn[w][c]); hi = fmaxf(hi, S.mx[w][c]); }
         mn[c] = lo; mx[c] = hi;
     }
-    const SplitChoice sc = choose_split(k.lo, k.hi, mn, mx);
+    const SplitChoice sc = choose_split_scalar(k.lo, k.hi, mn, mx);
     const int ax = sc.ax;
     const float cut = sc.cut;
 
@@ -443,203 +475,8 @@ __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTre
   }
 }
 
-// ---- subtree kernel: one wave finishes a node of <= kSmall points -----------------------------------------------
-constexpr int kSubStack = 12;  // the smaller child is finished first: at most log2(kSmall) + 2 deferred siblings
-
-struct SubTask {
-    short l, r;       // range relative to the node's first record
-    int parent;       // node id or -1
-    short side, level;
-    float lo[3], hi[3];
-};
-
-__device__ __forceinline__ void wave_sync_lds()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-struct SubSplit {
-    int ax, lim1, lim2;
-    float cut, maxlt, mingt;
-};
-
-// Partitions P[0, count) (count <= 64*E) in place exactly like planeSplit and returns the split facts.
-template <int E>
-__device__ __forceinline__ SubSplit split_in_lds(float4* P, int count, const float* lo, const float* hi, short* posL, short* posR, int lane)
-{
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    float4 rec[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = e * 64 + lane;
-        if (i < count) {
-            rec[e] = P[i];
-            mn[0] = fminf(mn[0], rec[e].x); mx[0] = fmaxf(mx[0], rec[e].x);
-            mn[1] = fminf(mn[1], rec[e].y); mx[1] = fmaxf(mx[1], rec[e].y);
-            mn[2] = fminf(mn[2], rec[e].z); mx[2] = fmaxf(mx[2], rec[e].z);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-        {
-            mn[c] = wave_min(mn[c]);
-            mx[c] = wave_max(mx[c]);
-        }
-    const SplitChoice sc = choose_split(lo, hi, mn, mx);
-    SubSplit r;
-    r.ax = sc.ax;
-    r.cut = sc.cut;
-    const float cut = sc.cut;
-    float v[E];
-    r.lim1 = 0;
-    r.lim2 = 0;
-    r.maxlt = -INFINITY;
-    r.mingt = INFINITY;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const bool in = e * 64 + lane < count;
-        v[e] = in ? comp(rec[e], sc.ax) : 0.f;
-        r.lim1 += __popcll(__ballot(in && v[e] < cut));
-        r.lim2 += __popcll(__ballot(in && v[e] <= cut));
-        if (in && v[e] < cut) r.maxlt = fmaxf(r.maxlt, v[e]);
-        if (in && v[e] > cut) r.mingt = fminf(r.mingt, v[e]);
-    }
-    {
-        r.maxlt = wave_max(r.maxlt);
-        r.mingt = wave_min(r.mingt);
-    }
-    for (int sweep = 0; sweep < 2; ++sweep) {
-        const int from = sweep == 0 ? 0 : r.lim1, bound = sweep == 0 ? r.lim1 : r.lim2;
-        int offL = 0, offR = 0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int i = e * 64 + lane;
-            bool isL = false, isR = false;
-            if (i < count && i >= from) {
-                const bool keep_left = sweep == 0 ? (v[e] < cut) : (v[e] <= cut);
-                isL = i < bound && !keep_left;
-                isR = i >= bound && keep_left;
-            }
-            const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
-            if (isL) posL[offL + __popcll(bL & lt_mask)] = (short)i;
-            if (isR) posR[offR + __popcll(bR & lt_mask)] = (short)i;
-            offL += __popcll(bL);
-            offR += __popcll(bR);
-        }
-        if (offL == 0) continue;  // wave-uniform: nothing misplaced in this sweep
-        wave_sync_lds();
-        const int m = offL;
-        for (int i = lane; i < m; i += 64) {
-            const int pl = posL[i], pr = posR[m - 1 - i];
-            const float4 x = P[pl], y = P[pr];
-            P[pl] = y;
-            P[pr] = x;
-        }
-        wave_sync_lds();
-        if (sweep == 0) {
-            // the records moved: refresh the cached split-axis values for the second sweep
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int i = e * 64 + lane;
-                v[e] = i < count ? comp(P[i], sc.ax) : 0.f;
-            }
-        }
-    }
-    return r;
-}
-
-__global__ __launch_bounds__(256) void build_subtree_kernel(const BuildTree* __restrict__ trees, BuildQueues Q)
-{
-    constexpr int WPB = 4;
-    __shared__ float4 s_pts[WPB][kSmall];
-    __shared__ short s_posL[WPB][kSmall], s_posR[WPB][kSmall];
-    __shared__ SubTask s_stack[WPB][kSubStack];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n_tasks = min(Q.small_cnt[0], Q.small_cap);
-    float4* P = s_pts[wave];
-    short* posL = s_posL[wave];
-    short* posR = s_posR[wave];
-    SubTask* stack = s_stack[wave];
-
-    for (int ti = blockIdx.x * WPB + wave; ti < n_tasks; ti += gridDim.x * WPB) {
-        const BuildTask k = Q.small_q[ti];
-        const BuildTree t = trees[k.tree];
-        const int total = k.r - k.l;
-        for (int i = lane; i < total; i += 64) P[i] = gload(t.pts + k.l + i);
-        if (lane == 0) {
-            SubTask r;
-            r.l = 0; r.r = (short)total; r.parent = k.parent; r.side = (short)k.side; r.level = (short)k.level;
-            for (int c = 0; c < 3; ++c) { r.lo[c] = k.lo[c]; r.hi[c] = k.hi[c]; }
-            stack[0] = r;
-        }
-        int sp = 1;
-        int max_level = 0;
-        wave_sync_lds();
-        while (sp > 0) {
-            --sp;
-            // (fields are copied one by one with compile-time indices: a whole-struct copy indexed at run time lands in scratch)
-            const int l = stack[sp].l, u_r = stack[sp].r, count = u_r - l;
-            const int u_parent = stack[sp].parent, u_side = stack[sp].side, u_level = stack[sp].level;
-            float blo[3], bhi[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { blo[c] = stack[sp].lo[c]; bhi[c] = stack[sp].hi[c]; }
-            wave_sync_lds();  // every lane has its copy before lane 0 reuses the slot
-            if (count <= kLeafMax) {
-                const int id = 2 * (k.l + l);
-                if (lane == 0) {
-                    t.nodes[id] = make_int4(k.l + l, k.l + u_r, 0, 0);
-                    const int ref = leaf_ref(k.l + l, count);
-                    if (u_parent < 0) t.meta->root = ref;
-                    else if (u_side == 0) atomicOr(&t.nodes[u_parent].x, ref);
-                    else t.nodes[u_parent].y = ref;
-                }
-                max_level = max(max_level, u_level);
-                continue;
-            }
-            SubSplit sr;
-            if (count <= 64) sr = split_in_lds<1>(P + l, count, blo, bhi, posL, posR, lane);
-            else if (count <= 128) sr = split_in_lds<2>(P + l, count, blo, bhi, posL, posR, lane);
-            else sr = split_in_lds<4>(P + l, count, blo, bhi, posL, posR, lane);
-            const int half = count / 2;
-            const int idx = sr.lim1 > half ? sr.lim1 : (sr.lim2 < half ? sr.lim2 : half);
-            const int m = k.l + l + idx;
-            const int id = 2 * m - 1;
-            if (lane == 0) {
-                const float divlow = idx > sr.lim1 ? sr.cut : sr.maxlt;
-                const float divhigh = idx < sr.lim2 ? sr.cut : sr.mingt;
-                t.nodes[id] = make_int4((int)((unsigned)sr.ax << 30), 0, __float_as_int(divlow), __float_as_int(divhigh));
-                if (u_parent < 0) t.meta->root = id;
-                else if (u_side == 0) atomicOr(&t.nodes[u_parent].x, id);
-                else t.nodes[u_parent].y = id;
-                const bool left_small = idx <= count - idx;  // finish the smaller side first (order does not change the tree)
-#pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {
-                    const int side = ((pass == 0) == left_small) ? 1 : 0;
-                    SubTask& ch = stack[sp + pass];
-                    ch.l = (short)(side == 0 ? l : l + idx);
-                    ch.r = (short)(side == 0 ? l + idx : u_r);
-                    ch.parent = id; ch.side = (short)side; ch.level = (short)(u_level + 1);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        ch.lo[c] = (side == 1 && c == sr.ax) ? sr.cut : blo[c];
-                        ch.hi[c] = (side == 0 && c == sr.ax) ? sr.cut : bhi[c];
-                    }
-                }
-            }
-            sp += 2;
-            wave_sync_lds();
-        }
-        for (int i = lane; i < total; i += 64) gstore(t.pts + k.l + i, P[i]);
-        if (lane == 0) atomicMax(&t.meta->depth, max_level);
-        wave_sync_lds();
-    }
-}
-
 // ---- flat subtree kernel: one workgroup per node of <= kSmall points, ONE THREAD PER POINT POSITION --------------------------------
-// The wave-per-node kernel above runs a subtree's ~31 splits one after the other (80-90 us for the ~1 400 subtrees of a 180 000-point
+// A wave-per-node kernel ran a subtree's ~31 splits one after the other (80-90 us for the ~1 400 subtrees of a 180 000-point
 // pyramid: a chain of LDS round trips at one or two waves per SIMD).  Here every round advances ALL live segments of the node at
 // once: thread i owns position i, carries its segment's descriptor (range, incoming box, parent link) in registers, and the
 // per-segment facts (tight extents, counts against the cut, misplaced counts) are LDS accumulators indexed by the segment's first
