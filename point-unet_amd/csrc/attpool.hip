@@ -328,17 +328,22 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
     const float* a_lane = A + (lane & 15) * PA + (lane >> 4);    // A-fragment base of this lane in the [KN x PA] tile
     const float* t_lane = T1 + (lane & 15) * PT + (lane >> 4);
 
+    // (the kernel is VALU-issue bound -- one VALU instruction per SIMD every four cycles, ~180 of them per point, half of them index
+    //  arithmetic --: no integer division for a single cloud, 32-bit element offsets from uniform bases)
+    const bool one_cloud = a.n_total == a.n_cloud;
     PointWalk walk(a.n_total, WAVES, wave);
     for (int t = walk.t; t < walk.end; t += walk.stride) {
-        const int p = walk_point(a, t);
-        const int base = (p / a.n_cloud) * a.n_cloud;
-        const float cx = a.xyz[3 * (size_t)p], cy = a.xyz[3 * (size_t)p + 1], cz = a.xyz[3 * (size_t)p + 2];
+        const unsigned p = one_cloud ? (a.order ? (unsigned)a.order[t] : (unsigned)t) : (unsigned)walk_point(a, t);
+        const unsigned base = one_cloud ? 0u : (p / (unsigned)a.n_cloud) * (unsigned)a.n_cloud;
+        const float* cp = a.xyz + 3u * p;
+        const float cx = cp[0], cy = cp[1], cz = cp[2];
         int nb[RT];
         float a0[RT], a1[RT], a2[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            nb[rt] = base + a.idx[(size_t)p * KN + rt * 16 + c16];
-            const float nx = a.xyz[3 * (size_t)nb[rt]], ny = a.xyz[3 * (size_t)nb[rt] + 1], nz = a.xyz[3 * (size_t)nb[rt] + 2];
+            nb[rt] = (int)(base + (unsigned)a.idx[p * (unsigned)KN + (unsigned)(rt * 16 + c16)]);
+            const float* np = a.xyz + 3u * (unsigned)nb[rt];
+            const float nx = np[0], ny = np[1], nz = np[2];
             const float rx = cx - nx, ry = cy - ny, rz = cz - nz;
             const float dis = __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz);
             a0[rt] = g == 0 ? dis : (g == 1 ? rx : (g == 2 ? ry : rz));
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
                     src = row >= 16 ? src1 : src;
                 }
                 if (e < TOT) {
-                    const float4 v = *reinterpret_cast<const float4*>(a.fg + (size_t)src * a.ldf + 4 * q);
+                    const float4 v = *reinterpret_cast<const float4*>(a.fg + (unsigned)src * (unsigned)a.ldf + (unsigned)(4 * q));
                     float* dst = A + row * PA + 4 * q;
                     dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
                 }
@@ -457,13 +462,13 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = __expf(acc[rt][j][r] - m);
+                        const float e = __builtin_amdgcn_exp2f(acc[rt][j][r] - m);  // the Wfc image carries log2(e) (randla.hip)
                         ssum += e;
-                        num += e * A[(rt * 16 + g * 4 + r) * PA + col];
+                        num = __builtin_fmaf(e, A[(rt * 16 + g * 4 + r) * PA + col], num);
                     }
                 ssum = xor_sum_lds(ssum);
                 num = xor_sum_lds(num);
-                if (g == 0) a.agg[(size_t)p * D + col] = num * __builtin_amdgcn_rcpf(ssum);
+                if (g == 0) a.agg[p * (unsigned)D + (unsigned)col] = num * __builtin_amdgcn_rcpf(ssum);
             }
         }
         wave_lds_sync();  // the tiles are overwritten by the next point
@@ -552,6 +557,8 @@ int att_pool_stage(ps_context* c, const AttStage& s)
     if (s.n_total <= 0) return PS_OK;
     const int stage = s.lfa2 ? 2 : 1;
     if (s.wfull) {  // direct formulation: fg holds only the features (row stride ldf)
+        PS_CHECK((uint64_t)s.n_total * (uint64_t)std::max(s.d, std::max(s.ldf, 3 * 1)) < (1ull << 32) && (uint64_t)s.n_total * s.k < (1ull << 32),
+                 "att_pool: level too large for 32-bit element offsets");
         if (s.k == 16) return stage == 1 ? dispatch_direct<1, 16>(c, s.d, a) : dispatch_direct<2, 16>(c, s.d, a);
         if (s.k == 32) return stage == 1 ? dispatch_direct<1, 32>(c, s.d, a) : dispatch_direct<2, 32>(c, s.d, a);
         set_error("att_pool: k_n %d is not a compiled size (16, 32)", s.k);

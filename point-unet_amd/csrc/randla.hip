@@ -274,13 +274,21 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
         emit(e.lfa1, W(si), Bv(si), 10, h, 1); ++si;
         emit(e.top1, W(si), nullptr, h, d, 0);                      // Wfc1[:h, :]
         emit(e.bot1, W(si) + (size_t)h * d, nullptr, h, d, 0);      // Wfc1[h:, :]
-        emit(e.full1, W(si), nullptr, d, d, 0);                     // Wfc1 (direct formulation)
+        {   // Wfc1 (direct formulation, d <= 32): pre-multiplied by log2(e), att_direct_kernel's softmax is exp2(s' - max s')
+            std::vector<float> sc((size_t)d * d);
+            for (size_t t = 0; t < sc.size(); ++t) sc[t] = (float)((double)W(si)[t] * 1.4426950408889634);
+            emit(e.full1, sc.data(), nullptr, d, d, 0);
+        }
         ++si;
         emit(e.att1mlp, W(si), Bv(si), d, h, 1); ++si;
         emit(e.lfa2, W(si), Bv(si), h, h, 1); ++si;
         emit(e.top2, W(si), nullptr, h, d, 0);
         emit(e.bot2, W(si) + (size_t)h * d, nullptr, h, d, 0);
-        emit(e.full2, W(si), nullptr, d, d, 0);
+        {
+            std::vector<float> sc((size_t)d * d);
+            for (size_t t = 0; t < sc.size(); ++t) sc[t] = (float)((double)W(si)[t] * 1.4426950408889634);
+            emit(e.full2, sc.data(), nullptr, d, d, 0);
+        }
         ++si;
         emit(e.att2mlp, W(si), Bv(si), d, d, 1); ++si;
         // [mlp2 ; shortcut] over the concatenated K axis, biases summed, LeakyReLU on the sum (RandLANet.py:317-321)
