@@ -289,21 +289,6 @@ int ps_op_adam(ps_context* ctx, float* p, const float* g, float* m, float* v, in
 /* tf.nn.dropout: y = x * mask, mask = (u < keep_prob) / keep_prob from a counter-based hash of (element, seed) */
 int ps_op_dropout(ps_context* ctx, const float* x, int64_t n, uint32_t seed, float keep_prob, float* y, float* mask);
 
-/* ---- host-only debug doors (CPU test-suite; never bound by the Python facade, never on the product path) ---- */
-/* The product's own kd-tree construction + the per-query search routine the HIP kernel instantiates, run on the
- * host.  K in {1,5,7,16,32}. */
-int ps_debug_knn_host(const float* support, const float* queries, int64_t B, int64_t n_support,
-                      int64_t n_queries, int64_t K, int32_t* out_idx);
-/* vind i32[n], nodes i32[2n,4], pts f32[n,4], root_depth i32[2], bbox f32[6] (layout: csrc/kdtree.h). */
-int ps_debug_kdtree_host(const float* support, int64_t n, int32_t* vind, int32_t* nodes, float* pts,
-                         int32_t* root_depth, float* bbox);
-/* The same arrays from the DEVICE builder (csrc/kdtree_build.hip); needs a GPU.  Unreached node slots are
- * unspecified: compare by walking from the root. */
-int ps_debug_kdtree_device(ps_context* ctx, const float* support, int64_t n, int32_t* vind, int32_t* nodes,
-                           float* pts, int32_t* root_depth, float* bbox);
-/* MFMA B-fragment packing of a row-major W[cin,cout] (csrc/rowgemm.h). */
-int ps_debug_pack_weights(const float* W, int cin, int cout, int ntb, float* out);
-
 #ifdef __cplusplus
 }
 #endif

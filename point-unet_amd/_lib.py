@@ -107,11 +107,6 @@ PROTOTYPES = {
     "ps_op_bn_train_bwd_sums_ex": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64] + [c_vp] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int] + [c_vp] * 2),
     "ps_op_bn_train_bwd_apply_ex": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64] + [c_vp] * 7 + [ctypes.c_int64] * 3 + [ctypes.c_int, c_vp]),
     "ps_op_scatter_add_rows_ex": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp] + [ctypes.c_int64] * 4 + [c_vp]),
-    # host-only debug doors (bound for the CPU test-suite only; the facade never calls them)
-    "ps_debug_knn_host": (ctypes.c_int, [c_vp, c_vp] + [ctypes.c_int64] * 4 + [c_vp]),
-    "ps_debug_kdtree_host": (ctypes.c_int, [c_vp, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "ps_debug_kdtree_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "ps_debug_pack_weights": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp]),
 }
 
 _lib = None

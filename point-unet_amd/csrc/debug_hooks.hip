@@ -1,8 +1,10 @@
-// debug_hooks.hip -- host-only doors used by the CPU test-suite (tests/ -m "not gpu") to exercise the product's
-// OWN host logic without a GPU: the kd-tree construction rules (kdtree_host.hip) and the per-query search routine
-// that the HIP kernel instantiates (kdtree.h, __host__ __device__).  Nothing in the product path calls these; the
-// Python facade never binds them (point-unet_amd/_lib.py) -- they are not a CPU fallback.
+// debug_hooks.hip -- the TEST-ONLY library libpointseg_debug.so (declarations: debug_hooks.h): doors used by the test-suite to
+// exercise the product's OWN host logic without a GPU -- the kd-tree construction rules (kdtree_host.hip) and the per-query
+// search routine that the HIP kernel instantiates (kdtree.h, __host__ __device__) -- and to read a device-built tree back.
+// Built next to the product library and linked against it; nothing in the product library or the Python package refers to it
+// (tests/conftest.py binds it) -- it is not a CPU fallback.
 #include "common.h"
+#include "kdtree_build.h"
 #include "kdtree_host.h"
 #include "rowgemm.h"
 
@@ -68,5 +70,44 @@ extern "C" int ps_debug_pack_weights(const float* W, int cin, int cout, int ntb,
 {
     PS_CHECK(W && out && (ntb == 1 || ntb == 2 || ntb == 4), "ps_debug_pack_weights: bad argument");
     pack_weights(W, cin, cout, ntb, out);
+    return PS_OK;
+}
+
+// --------------------------------------------------------------------------------------------------------
+// white-box door for the GPU test-suite: build one tree on the DEVICE and copy its arrays back (same layout as
+// ps_debug_kdtree_host) so the two builders can be compared array for array.
+// --------------------------------------------------------------------------------------------------------
+extern "C" int ps_debug_kdtree_device(ps_context* c, const float* support, int64_t n, int32_t* vind, int32_t* nodes, float* pts,
+                                      int32_t* root_depth, float* bbox)
+{
+    PS_CHECK(c && support && vind && nodes && pts && root_depth && bbox && n >= 1, "ps_debug_kdtree_device: bad argument");
+    PS_HIP(hipSetDevice(c->device));
+    PS_TRY(c->stage_in.reserve(sizeof(float) * 3 * (size_t)n));
+    PS_HIP(hipMemcpyAsync(c->stage_in.p, support, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    TreeSetPlan plan;
+    plan.add((int32_t)n);
+    for (int pass = 0; pass < 2; ++pass) {
+        c->knn_arena.begin(pass == 0);
+        plan.carve(c->knn_arena);
+        if (pass == 0) PS_TRY(c->knn_arena.buf.reserve(c->knn_arena.off));
+    }
+    plan.src[0] = c->stage_in.as<float>();
+    PS_TRY(build_trees(c, plan));
+    int32_t flag[3] = {0, 0, 0};
+    PS_HIP(hipMemcpyAsync(flag, plan.d_flags, 12, hipMemcpyDeviceToHost, c->stream));
+    PS_HIP(hipStreamSynchronize(c->stream));
+    PS_CHECK(flag[1] == 0, "ps_debug_kdtree_device: builder queue overflow");
+    TreeMeta m;
+    PS_HIP(hipMemcpyAsync(nodes, plan.d_nodes[0], sizeof(int4) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    PS_HIP(hipMemcpyAsync(pts, plan.d_pts[0], sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    PS_HIP(hipMemcpyAsync(&m, plan.d_meta, sizeof(TreeMeta), hipMemcpyDeviceToHost, c->stream));
+    PS_HIP(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < n; ++i) std::memcpy(&vind[i], &pts[4 * i + 3], 4);
+    root_depth[0] = m.root;
+    root_depth[1] = m.depth;
+    for (int a = 0; a < 3; ++a) {
+        bbox[a] = m.lo[a];
+        bbox[3 + a] = m.hi[a];
+    }
     return PS_OK;
 }

@@ -19,7 +19,7 @@ same order per cloud) -- tests/test_gpu_network.py::test_pipeline_matches_serial
 """
 import torch
 
-from . import runtime
+from . import _lib, runtime
 from .pyramid import alloc_pyramid, build_pyramid
 from .RandLANet import Network
 
@@ -33,6 +33,7 @@ class _Lane:
         self.net = Network(config, params=params, device=device, seed=seed, ctx=self.ctx)
         self.pyramid = None
         self.done = None
+        self.submissions = []  # global submission index of every pyramid build this lane's context has run, in order
 
 
 class ForwardPipeline:
@@ -64,6 +65,7 @@ class ForwardPipeline:
                 ln.pyramid = alloc_pyramid(B, n0, ratios, self.cfg.k_n, xyz.device)
             self._shape = (B, n0)
         ln = self.lanes[self._i % len(self.lanes)]
+        ln.submissions.append(self._i)
         self._i += 1
         ln.stream.wait_stream(torch.cuda.current_stream(self.device))  # the inputs were produced on the caller's stream
         if not overlap and self.last_done is not None:
@@ -86,9 +88,22 @@ class ForwardPipeline:
         self.synchronize()
 
     def synchronize(self):
-        """Drains every lane and validates the deferred status words of the tree builds (raises PointSegError)."""
-        for ln in self.lanes:
-            ln.ctx.synchronize()
+        """Drains every lane and validates the status words of the tree builds.  The build itself always completes on the device
+        (very unbalanced clouds included: csrc/kdtree_build.hip, straggler kernel), so nothing needs to be re-run; what can still
+        be reported are the two degenerate cases (builder queue overflow, tree deeper than the traversal stack) -- the error then
+        names the submission (0-based index over submit() calls, prime() included) whose logits are affected; every other
+        submission's results are valid."""
+        import re
+        first = None
+        for k, ln in enumerate(self.lanes):
+            try:
+                ln.ctx.synchronize()
+            except _lib.PointSegError as e:
+                m = re.search(r"pyramid build #(\d+)", str(e))
+                which = ln.submissions[int(m.group(1))] if m and int(m.group(1)) < len(ln.submissions) else None
+                first = first or _lib.PointSegError("%s [ForwardPipeline: lane %d, submission %s]" % (e, k, which))
+        if first is not None:
+            raise first
 
     def close(self):
         self.synchronize()

@@ -27,6 +27,26 @@ def lib():
     return _lib.lib()
 
 
+@pytest.fixture(scope="session")
+def dbg(lib):
+    """The TEST-ONLY library point-unet_amd/libpointseg_debug.so (csrc/debug_hooks.h): the product's own host logic behind C doors.
+    It links against the product library (loaded first, by the `lib` fixture); the package itself never loads it."""
+    import ctypes
+    c_vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    h = ctypes.CDLL(os.path.join(ROOT, "point-unet_amd", "libpointseg_debug.so"))
+    protos = {
+        "ps_debug_knn_host": [c_vp, c_vp, i64, i64, i64, i64, c_vp],
+        "ps_debug_kdtree_host": [c_vp, i64, c_vp, c_vp, c_vp, c_vp, c_vp],
+        "ps_debug_kdtree_device": [c_vp, c_vp, i64, c_vp, c_vp, c_vp, c_vp, c_vp],
+        "ps_debug_pack_weights": [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp],
+    }
+    for name, args in protos.items():
+        fn = getattr(h, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = args
+    return h
+
+
 # ---- synthetic clouds shared by CPU and GPU tests (SURVEY 8d) ---------------------------------------------
 def uniform_cloud(n, seed=0):
     return np.random.default_rng(seed).random((n, 3), dtype=np.float32)

@@ -26,8 +26,16 @@ def test_prototype_table_matches_header():
 
 def test_version_and_error_strings(lib):
     assert lib.ps_version().decode().startswith("pointseg-hip")
-    assert lib.ps_debug_knn_host(None, None, 1, 1, 1, 16, None) != 0
+    assert lib.ps_knn_batch(None, None, None, 1, 1, 1, 3, 16, None, 0) != 0   # argument check fails before any GPU call
     assert b"NULL" in lib.ps_last_error()
+
+
+def test_debug_doors_live_in_their_own_library(lib, dbg):
+    """The ps_debug_* test doors are not in the product library (and not in its header): csrc/debug_hooks.h / libpointseg_debug.so."""
+    for name in ("ps_debug_knn_host", "ps_debug_kdtree_host", "ps_debug_kdtree_device", "ps_debug_pack_weights"):
+        assert not hasattr(lib, name) and hasattr(dbg, name)
+    assert "ps_debug" not in open(os.path.join(ROOT, "include", "pointseg.h")).read()
+    assert dbg.ps_debug_knn_host(None, None, 1, 1, 1, 16, None) != 0 and b"NULL" in lib.ps_last_error()
 
 
 def test_product_never_imports_the_oracle():

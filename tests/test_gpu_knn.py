@@ -122,7 +122,7 @@ def test_full_size_properties():
 
 
 @pytest.mark.parametrize("case", ["lattice", "uniform", "duplicates", "tiny"])
-def test_device_tree_equals_host_tree(lib, case):
+def test_device_tree_equals_host_tree(lib, dbg, case):
     """White box: the device builder (level-synchronous, closed-form Hoare sweeps) produces the same permutation,
     splits, child order, root box and depth as the host restatement of nanoflann's recursive builder."""
     import ctypes
@@ -143,10 +143,10 @@ def test_device_tree_equals_host_tree(lib, case):
         return (np.zeros(n, np.int32), np.zeros((2 * n, 4), np.int32), np.zeros((n, 4), np.float32), np.zeros(2, np.int32), np.zeros(6, np.float32))
 
     h = arrays()
-    assert lib.ps_debug_kdtree_host(p.ctypes.data, n, *[a.ctypes.data for a in h]) == 0
+    assert dbg.ps_debug_kdtree_host(p.ctypes.data, n, *[a.ctypes.data for a in h]) == 0
     d = arrays()
     ctx = runtime.default_context(0)
-    rc = lib.ps_debug_kdtree_device(ctx.handle, p.ctypes.data, n, *[a.ctypes.data for a in d])
+    rc = dbg.ps_debug_kdtree_device(ctx.handle, p.ctypes.data, n, *[a.ctypes.data for a in d])
     assert rc == 0, lib.ps_last_error()
     assert np.array_equal(h[0], d[0]), "vind permutation differs"
     assert np.array_equal(h[2], d[2]) and np.array_equal(h[3], d[3]) and np.array_equal(h[4], d[4])

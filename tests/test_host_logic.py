@@ -10,34 +10,34 @@ import netcase
 from conftest import brats_cloud, uniform_cloud
 
 
-def _host_knn(lib, s, q, K):
+def _host_knn(dbg, lib, s, q, K):
     s = np.ascontiguousarray(s, np.float32)
     q = np.ascontiguousarray(q, np.float32)
     out = np.zeros((s.shape[0], q.shape[1], K), np.int32)
-    rc = lib.ps_debug_knn_host(s.ctypes.data, q.ctypes.data, s.shape[0], s.shape[1], q.shape[1], K, out.ctypes.data)
+    rc = dbg.ps_debug_knn_host(s.ctypes.data, q.ctypes.data, s.shape[0], s.shape[1], q.shape[1], K, out.ctypes.data)
     assert rc == 0, lib.ps_last_error()
     return out
 
 
 @pytest.mark.parametrize("K", [1, 16, 32])
 @pytest.mark.parametrize("kind", ["uniform", "lattice"])
-def test_search_routine_matches_oracle(lib, oracle, kind, K):
+def test_search_routine_matches_oracle(dbg, lib, oracle, kind, K):
     p = uniform_cloud(6000, 1) if kind == "uniform" else brats_cloud(6000, 1, grid=(40, 40, 30))
-    assert np.array_equal(_host_knn(lib, p[None], p[None], K), oracle.knn_batch(p[None], p[None], K))
+    assert np.array_equal(_host_knn(dbg, lib, p[None], p[None], K), oracle.knn_batch(p[None], p[None], K))
 
 
-def test_search_routine_upsampling_and_small(lib, oracle):
+def test_search_routine_upsampling_and_small(dbg, lib, oracle):
     p = brats_cloud(8000, 2, grid=(40, 40, 30))
     sub = p[:2000]
-    assert np.array_equal(_host_knn(lib, sub[None], p[None], 1), oracle.knn_batch(sub[None], p[None], 1))
+    assert np.array_equal(_host_knn(dbg, lib, sub[None], p[None], 1), oracle.knn_batch(sub[None], p[None], 1))
     rng = np.random.default_rng(0)
     for n in (1, 3, 10, 11, 25):
         q = rng.random((n, 3), dtype=np.float32)
         for K in (1, 5, 16):
-            assert np.array_equal(_host_knn(lib, q[None], q[None], K), oracle.knn_batch(q[None], q[None], K)), (n, K)
+            assert np.array_equal(_host_knn(dbg, lib, q[None], q[None], K), oracle.knn_batch(q[None], q[None], K)), (n, K)
 
 
-def test_tree_layout_against_oracle_tree(lib, oracle):
+def test_tree_layout_against_oracle_tree(dbg, lib, oracle):
     """Same permutation, same splits, same child order as the oracle's tree, in the product's id scheme."""
     p = brats_cloud(5000, 4, grid=(32, 32, 24))
     n = len(p)
@@ -46,7 +46,7 @@ def test_tree_layout_against_oracle_tree(lib, oracle):
     pts = np.zeros((n, 4), np.float32)
     rd = np.zeros(2, np.int32)
     bbox = np.zeros(6, np.float32)
-    assert lib.ps_debug_kdtree_host(p.ctypes.data, n, vind.ctypes.data, nodes.ctypes.data, pts.ctypes.data, rd.ctypes.data,
+    assert dbg.ps_debug_kdtree_host(p.ctypes.data, n, vind.ctypes.data, nodes.ctypes.data, pts.ctypes.data, rd.ctypes.data,
                                     bbox.ctypes.data) == 0
     t = oracle.kdtree_export(p)
     assert np.array_equal(vind, t["vind"])
@@ -70,13 +70,13 @@ def test_tree_layout_against_oracle_tree(lib, oracle):
     assert depth - 1 == rd[1]
 
 
-def test_weight_packing_is_the_mfma_b_fragment_order(lib):
+def test_weight_packing_is_the_mfma_b_fragment_order(dbg, lib):
     rng = np.random.default_rng(0)
     for cin, cout, ntb in [(7, 8, 1), (10, 32, 2), (96, 128, 4), (24, 32, 2)]:
         W = rng.standard_normal((cin, cout)).astype(np.float32)
         ks, cb = (cin + 3) // 4, (cout + 16 * ntb - 1) // (16 * ntb)
         out = np.zeros(cb * ks * 64 * ntb, np.float32)
-        assert lib.ps_debug_pack_weights(W.ctypes.data, cin, cout, ntb, out.ctypes.data) == 0
+        assert dbg.ps_debug_pack_weights(W.ctypes.data, cin, cout, ntb, out.ctypes.data) == 0
         out = out.reshape(cb, ks, 64, ntb)
         Wp = np.zeros((ks * 4, cb * ntb * 16), np.float32)
         Wp[:cin, :cout] = W
