@@ -269,6 +269,16 @@ int ps_op_softmax_pool_fwd(ps_context* ctx, const float* fset, const float* scor
                            float* probs, float* agg);
 int ps_op_softmax_pool_bwd(ps_context* ctx, const float* dagg, const float* fset, const float* probs, int64_t R,
                            int64_t K, int64_t d, float* dfset, float* dscores);
+/* att_pooling's score product + softmax + weighted sum FUSED per point for the training step (csrc/attpool_train.hip):
+ * agg[n,c] = sum_k softmax_k(fset . wfc)[n,k,c] * fset[n,k,c]   (RandLANet.py:394-398, wfc = the dense kernel [d,d], no bias).
+ * fset rows have stride ld (a column block of a wider buffer is fine).  Neither the scores nor the probabilities are written; the
+ * backward recomputes them from fset and returns dfset (row stride lddf, overwritten) and dwfc [d,d] (overwritten; summed in a
+ * fixed order: deterministic).  K = 16, d in {16, 32, 64} (ps_op_att_pool_train_supported); follows ps_set_train_gemm_bf16. */
+int ps_op_att_pool_train_supported(int64_t K, int64_t d);
+int ps_op_att_pool_train_fwd(ps_context* ctx, const float* fset, int64_t ld, const float* wfc, int64_t R, int64_t K, int64_t d,
+                             float* agg);
+int ps_op_att_pool_train_bwd(ps_context* ctx, const float* fset, int64_t ld, const float* wfc, const float* dagg, int64_t R,
+                             int64_t K, int64_t d, float* dfset, int64_t lddf, float* dwfc);
 /* backward of random_sample (max over K); ties share the gradient evenly like tf.reduce_max; dfeature accumulates */
 int ps_op_random_sample_bwd(ps_context* ctx, const float* dout, const float* out, const float* feature,
                             const int32_t* pool_idx, int64_t B, int64_t N, int64_t M, int64_t K, int64_t d,

@@ -1,0 +1,317 @@
+// attpool_train.hip -- attentive pooling of the TRAINING step, forward and backward, fused per point.
+//
+//   att_pooling (PointSegment/RandLANet.py:388-398):   s = F . Wfc   (F = [N*K, d] neighbour set, no bias)
+//                                                      p = softmax over the K rows of a point, per channel
+//                                                      agg[n, c] = sum_k p[n,k,c] * F[n,k,c]
+//
+// The op-by-op formulation writes s and p ([N*K, d] each: 1.5 GB at levels 0 and 1 of a batch of 8 x 180 000 points), reads them
+// back in the backward together with dscores / dF, and runs the three d x d GEMMs (scores, input gradient, weight gradient) as
+// separate passes over those tensors.  Here a wave takes one point (its K x d tile of F goes to LDS once):
+//   forward   scores on fp32 MFMA from the LDS tile, softmax with wave shuffles, weighted sum -> only agg is written
+//   backward  scores and softmax RECOMPUTED from the tile; with a = agg (recomputed), g = dagg:
+//                 dS[k,c] = p[k,c] g[c] (F[k,c] - a[c])
+//                 dF      = p . g  +  dS . Wfc^T          (second MFMA product, seeded with the direct term)
+//                 dWfc   += F^T . dS                       (third MFMA product, accumulated over the wave's points in registers)
+//             -> reads F and dagg, writes dF; per-workgroup dWfc partials go to a workspace that a second tiny kernel sums in
+//                a fixed order (deterministic, no float atomics)
+// Traffic per attention stage: forward 1 read of F (was: F read twice, s written + read, p written); backward 1 read of F + 1 write
+// of dF (was ~8 passes).  The d x d weights (and their transpose) live in LDS; compiled for d = 16, 32, 64 (encoder levels 0 and 1,
+// where the [N*K, d] tensors are large); wider levels keep the op-by-op path, whose tensors are small there.
+// bf16 mode (Trainer(mlp_dtype="bf16")): the operands of the three products are rounded to bfloat16 (RNE) -- F and Wfc for the
+// scores, dS and Wfc^T for the input gradient, F and dS for the weight gradient -- and multiplied on the fp32 MFMA (a product of
+// two bfloat16 values is exact in fp32), accumulation in fp32: the same values as a bf16 MFMA with fp32 accumulate.
+#include "common.h"
+#include "mfma_tile.h"
+
+namespace ps {
+
+__device__ __forceinline__ float round_bf16(float x)
+{
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (finite inputs)
+    return __uint_as_float(u & 0xffff0000u);
+}
+
+struct AttTrainArgs {
+    const float* f;     // [R*K, ld]
+    const float* w;     // [D, D] row-major
+    const float* dagg;  // [R, D] (backward)
+    float* agg;         // [R, D] (forward)
+    float* df;          // [R*K, lddf] (backward)
+    float* dw_part;     // [gridDim.x, D*D] (backward)
+    int64_t R;
+    int ld, lddf, bf16;
+};
+
+template <int D>
+struct AttTrainGeom {
+    static constexpr int PW = D + 16 + (D % 32 == 16 ? 16 : 0);  // weight pitch = 16 (mod 32): conflict-free B-fragment reads
+    static constexpr int PA = D + 2;                               // tile pitch = 2 (mod 32): conflict-free A-fragment reads
+    static constexpr int NT = D / 16;
+};
+
+// stages W (row-major [D,D]) and optionally its transpose into LDS with pitch PW, rounded to bf16 when asked
+template <int D, int THREADS>
+__device__ __forceinline__ void stage_weights(const float* __restrict__ w, float* W, float* WT, bool bf16)
+{
+    constexpr int PW = AttTrainGeom<D>::PW;
+    for (int i = threadIdx.x; i < D * D; i += THREADS) {
+        const int r = i / D, c = i - r * D;
+        float v = w[i];
+        if (bf16) v = round_bf16(v);
+        W[r * PW + c] = v;
+        if (WT) WT[c * PW + r] = v;
+    }
+}
+
+// the K x D tile of point p -> LDS (pitch PA), 16-byte loads; `Ab` receives the bf16-rounded copy when non-null
+template <int D, int KN>
+__device__ __forceinline__ void load_tile(const float* __restrict__ f, int ld, int64_t p, float* A, float* Ab, int lane)
+{
+    constexpr int PA = AttTrainGeom<D>::PA, Q = D / 4, TOT = KN * Q;
+#pragma unroll
+    for (int e0 = 0; e0 < TOT; e0 += 64) {
+        const int e = e0 + lane;
+        if (TOT % 64 == 0 || e < TOT) {
+            const int row = e / Q, q = e - row * Q;
+            const float4 v = *reinterpret_cast<const float4*>(f + (size_t)(p * KN + row) * ld + 4 * q);
+            float* dst = A + row * PA + 4 * q;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            if (Ab) {
+                float* db = Ab + row * PA + 4 * q;
+                db[0] = round_bf16(v.x); db[1] = round_bf16(v.y); db[2] = round_bf16(v.z); db[3] = round_bf16(v.w);
+            }
+        }
+    }
+}
+
+// scores of column tile ct: C[k][c] = sum_j X[k][j] W[j][16 ct + c]   (X = tile with pitch PA, W in LDS with pitch PW)
+template <int D>
+__device__ __forceinline__ f32x4 score_tile(const float* X, const float* W, int ct, int lane)
+{
+    constexpr int PW = AttTrainGeom<D>::PW, PA = AttTrainGeom<D>::PA;
+    const float* xa = X + (lane & 15) * PA + (lane >> 4);
+    const float* wb = W + (lane >> 4) * PW + ct * 16 + (lane & 15);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < D / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[4 * s], wb[4 * s * PW], acc, 0, 0, 0);
+    return acc;
+}
+
+template <int D, int KN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void att_train_fwd_kernel(AttTrainArgs a)
+{
+    static_assert(KN == 16, "one 16-row tile per point");
+    constexpr int PW = AttTrainGeom<D>::PW, PA = AttTrainGeom<D>::PA, NT = D / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* W = smem;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    float* A = smem + D * PW + wave * (a.bf16 ? 2 : 1) * KN * PA;
+    float* Ab = a.bf16 ? A + KN * PA : nullptr;
+    stage_weights<D, WAVES * 64>(a.w, W, nullptr, a.bf16 != 0);
+    __syncthreads();
+    for (int64_t p = (int64_t)blockIdx.x * WAVES + wave; p < a.R; p += (int64_t)gridDim.x * WAVES) {
+        load_tile<D, KN>(a.f, a.ld, p, A, Ab, lane);
+        wave_lds_sync();
+        const float* X = a.bf16 ? Ab : A;
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            const f32x4 s = score_tile<D>(X, W, ct, lane);
+            float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+            m = xor_max(m);
+            float ssum = 0.f, num = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[r] - m);
+                ssum += e;
+                num = __builtin_fmaf(e, A[(4 * g + r) * PA + ct * 16 + c16], num);
+            }
+            ssum = xor_sum(ssum);
+            num = xor_sum(num);
+            if (g == 0) a.agg[(size_t)p * D + ct * 16 + c16] = num / ssum;
+        }
+        wave_lds_sync();
+    }
+}
+
+template <int D, int KN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs a)
+{
+    static_assert(KN == 16, "one 16-row tile per point");
+    constexpr int PW = AttTrainGeom<D>::PW, PA = AttTrainGeom<D>::PA, NT = D / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* W = smem;
+    float* WT = smem + D * PW;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int per_wave = (a.bf16 ? 3 : 2) * KN * PA;
+    float* A = smem + 2 * D * PW + wave * per_wave;
+    float* T = A + KN * PA;                            // dS (rounded in bf16 mode: it only ever feeds the two products)
+    float* Ab = a.bf16 ? T + KN * PA : nullptr;
+    stage_weights<D, WAVES * 64>(a.w, W, WT, a.bf16 != 0);
+    __syncthreads();
+
+    f32x4 dw[NT][NT];  // this wave's share of dWfc: tile (ti, tj) = rows 16 ti.., columns 16 tj..
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) dw[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t p = (int64_t)blockIdx.x * WAVES + wave; p < a.R; p += (int64_t)gridDim.x * WAVES) {
+        load_tile<D, KN>(a.f, a.ld, p, A, Ab, lane);
+        wave_lds_sync();
+        const float* X = a.bf16 ? Ab : A;
+        f32x4 dfd[NT];  // direct term p * g of every column tile (seeds the second product)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            const f32x4 s = score_tile<D>(X, W, ct, lane);
+            float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+            m = xor_max(m);
+            float e[4], fv[4], ssum = 0.f, num = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[r] = __expf(s[r] - m);
+                fv[r] = A[(4 * g + r) * PA + ct * 16 + c16];
+                ssum += e[r];
+                num = __builtin_fmaf(e[r], fv[r], num);
+            }
+            ssum = xor_sum(ssum);
+            num = xor_sum(num);
+            const float inv = 1.f / ssum, agg = num * inv;
+            const float gch = a.dagg[(size_t)p * D + ct * 16 + c16];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = e[r] * inv;
+                dfd[ct][r] = pr * gch;
+                float ds = pr * gch * (fv[r] - agg);
+                if (a.bf16) ds = round_bf16(ds);
+                T[(4 * g + r) * PA + ct * 16 + c16] = ds;
+            }
+        }
+        wave_lds_sync();
+        // ---- dF = p . g + dS . Wfc^T  -> global ----
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+            const float* xa = T + c16 * PA + g;
+            const float* wb = WT + g * PW + tj * 16 + c16;
+            f32x4 acc = dfd[tj];
+#pragma unroll
+            for (int s = 0; s < D / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[4 * s], wb[4 * s * PW], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.df[(size_t)(p * KN + 4 * g + r) * a.lddf + tj * 16 + c16] = acc[r];
+        }
+        // ---- dWfc += F^T . dS  (contraction over the K = 16 rows: four MFMA steps per tile pair) ----
+#pragma unroll
+        for (int s = 0; s < KN / 4; ++s) {
+            float fa[NT], db[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                fa[t] = X[(4 * s + g) * PA + t * 16 + c16];  // A operand: F^T[i = 16 t + c16][k = 4 s + g]
+                db[t] = T[(4 * s + g) * PA + t * 16 + c16];  // B operand: dS[k][j = 16 t + c16]
+            }
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) dw[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ti], db[tj], dw[ti][tj], 0, 0, 0);
+        }
+        wave_lds_sync();
+    }
+    // ---- the workgroup's dWfc partial: waves add up through LDS (fixed order), one plain store per element ----
+    __syncthreads();
+    float* red = smem;  // weights and tiles are dead: the whole buffer holds the WAVES partials (sized for it on the host)
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(size_t)wave * D * D + (ti * 16 + 4 * g + r) * D + tj * 16 + c16] = dw[ti][tj][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < D * D; i += WAVES * 64) {
+        float sum = 0.f;
+        for (int w = 0; w < WAVES; ++w) sum += red[(size_t)w * D * D + i];
+        a.dw_part[(size_t)blockIdx.x * D * D + i] = sum;
+    }
+}
+
+__global__ __launch_bounds__(256) void att_train_dw_reduce_kernel(const float* __restrict__ part, int n_part, int dd, float* __restrict__ dw)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= dd) return;
+    float sum = 0.f;
+    for (int b = 0; b < n_part; ++b) sum += part[(size_t)b * dd + i];
+    dw[i] = sum;
+}
+
+template <int D>
+static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float* dW)
+{
+    constexpr int KN = 16, WAVES = 8;
+    constexpr int PW = AttTrainGeom<D>::PW, PA = AttTrainGeom<D>::PA;
+    const size_t tiles = (size_t)WAVES * (a.bf16 ? (backward ? 3 : 2) : (backward ? 2 : 1)) * KN * PA;
+    size_t smem = sizeof(float) * ((backward ? 2 : 1) * (size_t)D * PW + tiles);
+    if (backward) smem = std::max(smem, sizeof(float) * (size_t)WAVES * D * D);
+    PS_CHECK(smem <= 160 * 1024, "att_pool_train: %zu bytes of LDS needed", smem);
+    const int per_cu = std::max(1, std::min(4, (int)(160 * 1024 / smem)));
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + WAVES - 1) / WAVES, 256 * per_cu));
+    if (!backward) {
+        auto kern = att_train_fwd_kernel<D, KN, WAVES>;
+        if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
+    } else {
+        PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * D * D + 256));
+        a.dw_part = c->red_ws.as<float>();
+        auto kern = att_train_bwd_kernel<D, KN, WAVES>;
+        if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
+        hipLaunchKernelGGL(att_train_dw_reduce_kernel, dim3(ceil_div(D * D, 256)), dim3(256), 0, c->stream, a.dw_part, blocks, D * D, dW);
+    }
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+static bool att_train_ok(int64_t K, int64_t d, int64_t ld, const void* f)
+{
+    return K == 16 && (d == 16 || d == 32 || d == 64) && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(f) & 15) == 0;
+}
+
+}  // namespace ps
+
+using namespace ps;
+
+extern "C" int ps_op_att_pool_train_supported(int64_t K, int64_t d) { return K == 16 && (d == 16 || d == 32 || d == 64) ? 1 : 0; }
+
+extern "C" int ps_op_att_pool_train_fwd(ps_context* c, const float* fset, int64_t ld, const float* wfc, int64_t R, int64_t K, int64_t d, float* agg)
+{
+    PS_CHECK(c && fset && wfc && agg, "ps_op_att_pool_train_fwd: NULL argument");
+    PS_CHECK(att_train_ok(K, d, ld, fset), "ps_op_att_pool_train_fwd: K = 16, d in {16, 32, 64}, rows 16-byte aligned (got K %lld, d %lld, ld %lld)",
+             (long long)K, (long long)d, (long long)ld);
+    if (R <= 0) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "train_att_fused_fwd", 1);
+    AttTrainArgs a = {};
+    a.f = fset; a.w = wfc; a.agg = agg; a.R = R; a.ld = (int)ld; a.bf16 = c->train_bf16 ? 1 : 0;
+    switch (d) {
+        case 16: return launch_att_train<16>(c, a, false, nullptr);
+        case 32: return launch_att_train<32>(c, a, false, nullptr);
+        default: return launch_att_train<64>(c, a, false, nullptr);
+    }
+}
+
+extern "C" int ps_op_att_pool_train_bwd(ps_context* c, const float* fset, int64_t ld, const float* wfc, const float* dagg, int64_t R, int64_t K, int64_t d,
+                                        float* dfset, int64_t lddf, float* dwfc)
+{
+    PS_CHECK(c && fset && wfc && dagg && dfset && dwfc, "ps_op_att_pool_train_bwd: NULL argument");
+    PS_CHECK(att_train_ok(K, d, ld, fset) && lddf >= d, "ps_op_att_pool_train_bwd: K = 16, d in {16, 32, 64}, rows 16-byte aligned");
+    PS_HIP(hipSetDevice(c->device));
+    if (R <= 0) {
+        PS_HIP(hipMemsetAsync(dwfc, 0, sizeof(float) * d * d, c->stream));
+        return PS_OK;
+    }
+    Stage st(c, "train_att_fused_bwd", 2);
+    AttTrainArgs a = {};
+    a.f = fset; a.w = wfc; a.dagg = dagg; a.df = dfset; a.R = R; a.ld = (int)ld; a.lddf = (int)lddf; a.bf16 = c->train_bf16 ? 1 : 0;
+    switch (d) {
+        case 16: return launch_att_train<16>(c, a, true, dwfc);
+        case 32: return launch_att_train<32>(c, a, true, dwfc);
+        default: return launch_att_train<64>(c, a, true, dwfc);
+    }
+}

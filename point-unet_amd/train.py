@@ -228,6 +228,31 @@ class Tape:
         self.ops.append((agg, bw))
         return agg
 
+    def attpool(self, fset, W, gW, K):
+        """att_pooling's score product + softmax over K + weighted sum as ONE kernel per direction (csrc/attpool_train.hip): neither
+        the scores nor the probabilities reach HBM, the backward recomputes them from fset.  fset [R*K, d] may be a concat buffer
+        whose column blocks were written in place; W [d, d]."""
+        RK, d = fset.shape
+        R = RK // K
+        fs = _rowmajor(fset)
+        agg = torch.empty((R, d), dtype=torch.float32, device=fset.device)
+        _lib.check(self.L.ps_op_att_pool_train_fwd(self.h, _p(fs), fs.stride(0), _p(W), R, K, d, _p(agg)))
+
+        def bw(dy):
+            dfset = torch.empty((RK, d), dtype=torch.float32, device=fset.device)
+            dyc = dy.contiguous()
+            if gW.is_contiguous():
+                _lib.check(self.L.ps_op_att_pool_train_bwd(self.h, _p(fs), fs.stride(0), _p(W), _p(dyc), R, K, d, _p(dfset), d, _p(gW)))
+            else:
+                tmp = torch.empty((d, d), dtype=torch.float32, device=fset.device)
+                _lib.check(self.L.ps_op_att_pool_train_bwd(self.h, _p(fs), fs.stride(0), _p(W), _p(dyc), R, K, d, _p(dfset), d, _p(tmp)))
+                gW.copy_(tmp)
+            self.accum(fset, dfset)
+
+        agg.requires_grad_flag = True
+        self.ops.append((agg, bw))
+        return agg
+
     def maxpool(self, x, pool_idx, B):
         N, d = x.shape[0] // B, x.shape[1]
         M, K = pool_idx.shape[1], pool_idx.shape[2]
@@ -277,7 +302,7 @@ class Trainer:
     """Parameters (flat fp32 buffer + named views), Adam state and the train step."""
 
     def __init__(self, config, params=None, device=0, seed=0, learning_rate=None, class_weights=None, keep_prob=0.5, ctx=None, sync_bn=False,
-                 mlp_dtype="fp32", ignored_label_inds=None):
+                 mlp_dtype="fp32", ignored_label_inds=None, fused_att=True):
         """sync_bn: with a `dist` passed to train_step, BatchNorm uses the statistics of all ranks' rows, which makes "W GPUs x
         one cloud" numerically the same step as "one GPU x W clouds" (SURVEY 8e); off = per-GPU statistics.
         mlp_dtype: "fp32" (default) or "bf16" -- BASELINE configs[2]'s "bf16 MLPs": the shared-MLP GEMMs (forward, input gradient,
@@ -285,6 +310,7 @@ class Trainer:
         if mlp_dtype not in ("fp32", "bf16"):
             raise ValueError("mlp_dtype must be 'fp32' or 'bf16'")
         self.mlp_bf16 = mlp_dtype == "bf16"
+        self.fused_att = bool(fused_att)  # False: the op-by-op attentive pooling everywhere (A/B switch of bench.py --no-fused-att)
         self.sync_bn = bool(sync_bn)
         self.cfg = config
         self.device = torch.device("cuda", device)
@@ -367,8 +393,12 @@ class Trainer:
         return y
 
     def _att(self, t, fcat, name, K):
-        s = t.linear(fcat, self.P[name + "fc/kernel"], None, self.G[name + "fc/kernel"], None)
-        agg = t.softpool(fcat, s, K)
+        W, gW = self.P[name + "fc/kernel"], self.G[name + "fc/kernel"]
+        if self.fused_att and t.L.ps_op_att_pool_train_supported(K, fcat.shape[1]):
+            agg = t.attpool(fcat, W, gW, K)   # levels whose [N*K, d] tensors are large: one kernel per direction
+        else:
+            s = t.linear(fcat, W, None, gW, None)
+            agg = t.softpool(fcat, s, K)
         return self._conv(t, agg, name + "mlp")
 
     def forward(self, t, pyr, features):

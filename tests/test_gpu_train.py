@@ -394,6 +394,61 @@ def test_training_ops_against_torch(oracle):
     assert abs(float(loss) - float(ref)) < 1e-5 and (dz.double() - zd.grad).abs().max() < 1e-6
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_fused_attentive_pooling_forward_backward(mode):
+    """ps_op_att_pool_train_fwd / _bwd (score product + softmax over K + weighted sum in one kernel per direction; the backward
+    recomputes scores and probabilities) against torch float64 autograd of  agg = sum_K softmax_K(F.W) * F  -- for the bf16 mode with
+    the operands of the three products rounded exactly as the kernel rounds them (F, W for the scores; dS, W^T for dF; F, dS for dW).
+    Strided input (a column block of a wider buffer), ragged point counts, d = 16 / 32 / 64.  Bars: agg 2e-6 (fp32) / 2e-5 (bf16) of its
+    max; dF and dW 2e-5 of their max in fp32; in the bf16 mode 2e-3 / 1e-3: dS is rounded to bfloat16 from its fp32 value in the
+    kernel and from its float64 value here, and an element within fp32 noise of a rounding boundary lands on the neighbouring
+    bfloat16 (a 4e-3 relative change of that one term).  The weight gradient is bit-identical from run to run (fixed summation order)."""
+    import ctypes
+    import torch
+    from point_unet_amd import _lib, runtime
+    L, ctx = _lib.lib(), runtime.default_context(0)
+    h = ctx.handle
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(11)
+    rb = (lambda t: t.float().bfloat16().double()) if mode == "bf16" else (lambda t: t)
+    K = 16
+    try:
+        _lib.check(L.ps_set_train_gemm_bf16(h, 1 if mode == "bf16" else 0))
+        for R, d, wide in [(1000, 16, 16), (4097, 16, 32), (777, 32, 32), (2049, 64, 64), (300, 64, 128)]:
+            assert L.ps_op_att_pool_train_supported(K, d) == 1
+            buf = torch.randn(R * K, wide, generator=g).cuda()
+            F = buf[:, wide - d:]
+            W = (torch.randn(d, d, generator=g) / d ** 0.5).cuda()
+            dagg = torch.randn(R, d, generator=g).cuda()
+            agg = torch.empty(R, d).cuda()
+            _lib.check(L.ps_op_att_pool_train_fwd(h, p(F), wide, p(W), R, K, d, p(agg)))
+            dF = torch.empty(R * K, d).cuda()
+            dW, dW2 = torch.empty(d, d).cuda(), torch.empty(d, d).cuda()
+            _lib.check(L.ps_op_att_pool_train_bwd(h, p(F), wide, p(W), p(dagg), R, K, d, p(dF), d, p(dW)))
+            _lib.check(L.ps_op_att_pool_train_bwd(h, p(F), wide, p(W), p(dagg), R, K, d, p(dF), d, p(dW2)))
+            assert torch.equal(dW, dW2)
+            # float64 yardstick with the same operand rounding
+            Fd, Wd = F.double().reshape(R, K, d), W.double()
+            S = rb(Fd) @ rb(Wd)
+            P = torch.softmax(S, 1)
+            ref = (P * Fd).sum(1)
+            assert (agg.double() - ref).abs().max() <= (2e-6 if mode == "fp32" else 2e-5) * ref.abs().max(), (R, d)
+            gd = dagg.double()[:, None, :]
+            dS = P * gd * (Fd - ref[:, None, :])
+            dF_ref = P * gd + rb(dS) @ rb(Wd).T
+            dW_ref = rb(Fd).reshape(-1, d).T @ rb(dS).reshape(-1, d)
+            assert (dF.double().reshape(R, K, d) - dF_ref).abs().max() <= (2e-5 if mode == "fp32" else 2e-3) * dF_ref.abs().max(), (R, d)
+            assert (dW.double() - dW_ref).abs().max() <= (2e-5 if mode == "fp32" else 1e-3) * dW_ref.abs().max(), (R, d)
+            if mode == "fp32":  # and the closed form agrees with autograd
+                Fa, Wa = F.double().reshape(R, K, d).clone().requires_grad_(True), W.double().clone().requires_grad_(True)
+                ((torch.softmax(Fa @ Wa, 1) * Fa).sum(1) * dagg.double()).sum().backward()
+                assert (dF_ref - Fa.grad).abs().max() < 1e-10 and (dW_ref - Wa.grad).abs().max() < 1e-9
+        assert L.ps_op_att_pool_train_supported(K, 128) == 0 and L.ps_op_att_pool_train_supported(32, 16) == 0
+    finally:
+        _lib.check(L.ps_set_train_gemm_bf16(h, 0))
+    torch.cuda.synchronize()
+
+
 def test_row_strided_variants_match_the_dense_ops():
     """ps_op_*_ex on column blocks of a wider tensor (the training step's concat buffers) give what the dense entry points give
     on contiguous copies; conv1x1_ex with accumulate adds in the epilogue."""
