@@ -53,6 +53,8 @@ PS_GM void gstore(float4* p, float4 v)
 }
 PS_GM void gstore(float* p, float v) { *(PS_AS1 float*)p = v; }
 PS_GM void gstore(int* p, int v) { *(PS_AS1 int*)p = v; }
+PS_GM uint8_t gload(const uint8_t* p) { return *(const PS_AS1 uint8_t*)p; }
+PS_GM void gstore(uint8_t* p, uint8_t v) { *(PS_AS1 uint8_t*)p = v; }
 PS_GM void gstore(unsigned* p, unsigned v) { *(PS_AS1 unsigned*)p = v; }
 
 #else

@@ -48,6 +48,7 @@ struct BuildTree {
     TreeMeta* meta;
     int32_t* posL;  // scratch [n]
     int32_t* posR;  // scratch [n]
+    uint8_t* cls;   // scratch [n]: class of a record against the current cut (chunked levels)
     unsigned* bbox_ord;  // [6] ordered-uint min[3], max[3]
     int32_t n;
 };
@@ -987,75 +988,132 @@ __global__ __launch_bounds__(kMidThreads) void build_mid_kernel(const BuildTree*
 // ---- chunked levels: the first kHugeLevels levels of nodes above kHuge points ------------------------------------
 // One workgroup per node cannot pull more than one CU's bandwidth, which made the top three levels of a 180 000-point
 // tree cost ~0.5 ms.  Here every pass of such a node is spread over the chip in 2 048-record chunks, one small
-// kernel per pass (kernel boundaries are the global sync): min/max -> counts -> {flag counts -> ranks -> swaps} x 2
-// -> emit.  Exactly the same arithmetic and the same closed-form Hoare sweeps as build_level_kernel.
+// kernel per pass (kernel boundaries are the global sync).  A dependent launch costs ~5 us whatever it does, so the
+// passes of a level are folded down to five:
+//   A  classify: the split (from the node's extents, which its PARENT's last pass accumulated; the root's are the cloud's
+//      bounding box), one class byte per record (< cut, == cut, > cut), the per-chunk "< cut" count, the node's totals
+//   B  sweep-0 ranks: misplaced counts of the earlier chunks follow from the per-chunk counts (only the chunk lim1 falls
+//      into needs its class bytes); flags come from the class bytes, not the records; one extra workgroup records the
+//      level's nodes, routes their children and plans the next level
+//   C  sweep-0 swaps of records AND class bytes; a record that arrives right of lim1 adds its sweep-1 flag to its chunk's count
+//   D  sweep-1 ranks (flags from the class bytes)
+//   E  sweep-1 swaps + the extents of the two children, accumulated into the children's tasks
+// Exactly the same arithmetic and the same closed-form Hoare sweeps as build_level_kernel.
 constexpr int kHuge = kMid;       // everything smaller goes to build_mid_kernel
 constexpr int kHugeLevels = 8;    // at most; the host launches ceil(log2(n_max / kMid)) of them (HugeState::levels)
 constexpr int kChunk = 2048;
 
 struct HugeTask {
     BuildTask k;
+    float4* pts;            // the node's first record / class byte / rank-list entries (tree arrays + k.l)
+    uint8_t* cls;
+    int32_t* posL;
+    int32_t* posR;
     int chunk0, nchunks;
-    unsigned mn[3], mx[3];  // ordered-uint accumulators
+    unsigned mn[3], mx[3];  // ordered-uint accumulators (filled by the parent's pass E / from the bounding box)
     int lt, le;
     unsigned maxlt, mingt;  // ordered-uint
+    int kid[2];             // slots of the children among the next level's chunked tasks, -1 = not chunked
+    int m0, m1;             // swap pairs of sweeps 0 / 1 (passes B / D, by the workgroup of the node's last chunk)
+};
+
+// what a workgroup needs to start on its chunk: ONE 32-byte read instead of a chain through the level, task and tree tables
+struct alignas(32) ChunkDesc {
+    float4* pts;   // first record of the chunk
+    uint8_t* cls;  // its class bytes
+    int32_t task, first, count, pad;  // records [first, first+count) relative to the node's first record; task < 0 = no chunk
 };
 
 struct HugeState {
     HugeTask* tasks[2];
     int32_t* ntasks;       // [kHugeLevels + 1]
     int32_t* nchunks;      // [kHugeLevels + 1] total chunks of the level
-    int32_t* c_mL;         // [max_chunks] misplaced-left count of a chunk (current sweep)
+    int32_t* c_lt;         // [max_chunks] records < cut of a chunk (pass A)
+    int32_t* c_mL;         // [max_chunks] misplaced-left count of a chunk, sweep 1 (passes B + C)
     int32_t* c_mR;
-    int32_t* c_task[2];    // [max_chunks] task of a chunk, by level parity (written by the plan: one load instead of a search)
+    ChunkDesc* desc[2];    // [max_chunks] by level parity (written by the plan)
     int32_t cap_tasks, cap_chunks;
+    int32_t grid_chunks;   // chunk workgroups the host launches per pass
     int32_t levels;        // chunked levels launched by the host
 };
 
-__device__ __forceinline__ void route_task(const BuildQueues& Q, const HugeState& H, const BuildTask& t, int next_level)
+// returns the slot among the next level's chunked tasks, or -1 when the task went to the other queues
+__device__ __forceinline__ int route_task(const BuildQueues& Q, const HugeState& H, const BuildTree& tr, const BuildTask& t, int next_level)
 {
     if (t.r - t.l > kHuge && next_level < H.levels) {
         const int slot = atomicAdd(&H.ntasks[next_level], 1);
-        if (slot < H.cap_tasks)
-            H.tasks[next_level & 1][slot].k = t;
-        else
-            Q.flags[1] = 1;
-    } else
-        push_task(Q, t, next_level);
+        if (slot < H.cap_tasks) {
+            HugeTask& h = H.tasks[next_level & 1][slot];
+            h.k = t;
+            h.pts = tr.pts + t.l;
+            h.cls = tr.cls + t.l;
+            h.posL = tr.posL + t.l;
+            h.posR = tr.posR + t.l;
+            for (int a = 0; a < 3; ++a) { h.mn[a] = 0xffffffffu; h.mx[a] = 0u; }
+            return slot;
+        }
+        Q.flags[1] = 1;
+        return -1;
+    }
+    push_task(Q, t, next_level);
+    return -1;
 }
 
-// Plan of a level's chunk ranges + accumulator reset, by one workgroup: thread i takes task i, chunk0 is the prefix sum
-// of the chunk counts (tasks are few: a serial prefix per thread over an LDS copy).
+// Plan of a level, by one workgroup: thread i takes task i (chunk0 = prefix sum of the chunk counts over an LDS copy, accumulator
+// reset), then thread c writes the descriptor of chunk c (its task by binary search over the LDS prefix).
 __device__ void huge_plan_block(const HugeState& H, int level)
 {
-    __shared__ int s_nc[256];
+    __shared__ int s_nc[256], s_c0[257];
     const int n = min(H.ntasks[level], H.cap_tasks);
+    HugeTask* tasks = H.tasks[level & 1];
+    ChunkDesc* desc = H.desc[level & 1];
     int carry = 0;
     for (int base = 0; base < n; base += 256) {
-        const int i = base + threadIdx.x;
+        const int i = base + threadIdx.x, nb = min(256, n - base);
         int nc = 0;
         if (i < n) {
-            const BuildTask& k = H.tasks[level & 1][i].k;
+            const BuildTask& k = tasks[i].k;
             nc = (k.r - k.l + kChunk - 1) / kChunk;
         }
+        __syncthreads();  // the previous round's readers of s_c0 / s_nc are done
         s_nc[threadIdx.x] = nc;
         __syncthreads();
         int c0 = carry, tot = carry;
-        for (int j = 0; j < min(256, n - base); ++j) {
+        for (int j = 0; j < nb; ++j) {
             if (j < (int)threadIdx.x) c0 += s_nc[j];
             tot += s_nc[j];
         }
+        s_c0[threadIdx.x] = c0;
+        if (threadIdx.x == 0) s_c0[256] = tot;
         if (i < n) {
-            HugeTask& t = H.tasks[level & 1][i];
+            HugeTask& t = tasks[i];
             t.chunk0 = c0;
             t.nchunks = nc;
-            for (int j = 0; j < nc && c0 + j < H.cap_chunks; ++j) H.c_task[level & 1][c0 + j] = i;
-            for (int a = 0; a < 3; ++a) { t.mn[a] = 0xffffffffu; t.mx[a] = 0u; }
             t.lt = 0; t.le = 0; t.maxlt = 0u; t.mingt = 0xffffffffu;
+            t.kid[0] = -1; t.kid[1] = -1;
+            t.m0 = 0; t.m1 = 0;
+        }
+        __syncthreads();
+        for (int c = carry + (int)threadIdx.x; c < min(tot, H.cap_chunks); c += 256) {
+            int lo = 0, hi = nb - 1;  // last task of the round whose chunk0 <= c
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_c0[mid] <= c) lo = mid; else hi = mid - 1;
+            }
+            // (tasks without chunks cannot exist: a chunked task has > kHuge records)
+            const HugeTask& t = tasks[base + lo];
+            ChunkDesc d;
+            d.first = (c - s_c0[lo]) * kChunk;
+            d.count = min(kChunk, t.k.r - t.k.l - d.first);
+            d.pts = t.pts + d.first;
+            d.cls = t.cls + d.first;
+            d.task = base + lo;
+            d.pad = 0;
+            desc[c] = d;
         }
         carry = tot;
-        __syncthreads();
     }
+    for (int c = min(carry, H.cap_chunks) + (int)threadIdx.x; c < H.grid_chunks; c += 256) desc[c].task = -1;
     if (threadIdx.x == 0) H.nchunks[level] = min(carry, H.cap_chunks);
 }
 
@@ -1076,29 +1134,24 @@ __device__ __forceinline__ void huge_root_block(const BuildTree* __restrict__ tr
         BuildTask k;
         k.tree = i; k.l = 0; k.r = t.n; k.parent = -1; k.side = 0; k.level = 0;
         for (int a = 0; a < 3; ++a) { k.lo[a] = m.lo[a]; k.hi[a] = m.hi[a]; }
-        route_task(Q, H, k, 0);
+        const int slot = route_task(Q, H, t, k, 0);
+        if (slot >= 0)  // the extents of a root's records ARE its bounding box (same reduction: init_points_kernel)
+            for (int a = 0; a < 3; ++a) { H.tasks[0][slot].mn[a] = t.bbox_ord[a]; H.tasks[0][slot].mx[a] = t.bbox_ord[3 + a]; }
     }
     __threadfence();
     __syncthreads();
     huge_plan_block(H, 0);
 }
 
-struct ChunkRef {
-    int task, first, count;  // records [first, first+count) relative to the node's first record
-};
-__device__ __forceinline__ ChunkRef find_chunk(const HugeState& H, int level, int c)
+__device__ __forceinline__ ChunkDesc load_desc(const HugeState& H, int level, int c)
 {
-    ChunkRef r;
-    r.task = -1;
-    r.first = 0;
-    r.count = 0;
-    if (c >= H.nchunks[level]) return r;
-    const int i = H.c_task[level & 1][c];
-    const HugeTask& t = H.tasks[level & 1][i];
-    r.task = i;
-    r.first = (c - t.chunk0) * kChunk;
-    r.count = min(kChunk, t.k.r - t.k.l - r.first);
-    return r;
+    const int4* q = reinterpret_cast<const int4*>(H.desc[level & 1] + c);
+    const int4 u = gload(q), v = gload(q + 1);
+    ChunkDesc d;
+    d.pts = reinterpret_cast<float4*>(((unsigned long long)(unsigned)u.y << 32) | (unsigned)u.x);
+    d.cls = reinterpret_cast<uint8_t*>(((unsigned long long)(unsigned)u.w << 32) | (unsigned)u.z);
+    d.task = v.x; d.first = v.y; d.count = v.z; d.pad = v.w;
+    return d;
 }
 
 __device__ __forceinline__ SplitChoice huge_split(const HugeTask& t)
@@ -1108,60 +1161,42 @@ __device__ __forceinline__ SplitChoice huge_split(const HugeTask& t)
     return choose_split(t.k.lo, t.k.hi, mn, mx);
 }
 
-__device__ __forceinline__ void huge_minmax_chunk(const BuildTree* __restrict__ trees, const HugeState& H, int level, int chunk)
+// sum of one int2 per thread over the workgroup (256 threads), result in every thread; s_red = 8 ints of LDS
+__device__ __forceinline__ int2 block_sum2(int x, int y, int* s_red)
 {
-    __shared__ float s_mn[4][3], s_mx[4][3];
-    const ChunkRef cr = find_chunk(H, level, chunk);
-    if (cr.task < 0) return;
-    HugeTask& t = H.tasks[level & 1][cr.task];
-    const GArr<const float4> a{trees[t.k.tree].pts + t.k.l + cr.first};
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-    for (int e = 0; e < kChunk / 256; ++e) {
-        const int i = e * 256 + threadIdx.x;
-        if (i < cr.count) {
-            const float4 p = a[i];
-            mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
-            mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
-            mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        {
-            mn[c] = wave_min(mn[c]);
-            mx[c] = wave_max(mx[c]);
-        }
-        if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6][c] = mn[c]; s_mx[threadIdx.x >> 6][c] = mx[c]; }
-    }
+    x = wave_sum(x);
+    y = wave_sum(y);
+    __syncthreads();  // s_red free
+    if ((threadIdx.x & 63) == 0) { s_red[2 * (threadIdx.x >> 6)] = x; s_red[2 * (threadIdx.x >> 6) + 1] = y; }
     __syncthreads();
-    if (threadIdx.x < 3) {
-        const int c = threadIdx.x;
-        atomicMin(&t.mn[c], f2ord(fminf(fminf(s_mn[0][c], s_mn[1][c]), fminf(s_mn[2][c], s_mn[3][c]))));
-        atomicMax(&t.mx[c], f2ord(fmaxf(fmaxf(s_mx[0][c], s_mx[1][c]), fmaxf(s_mx[2][c], s_mx[3][c]))));
-    }
+    return make_int2(s_red[0] + s_red[2] + s_red[4] + s_red[6], s_red[1] + s_red[3] + s_red[5] + s_red[7]);
 }
 
-__device__ __forceinline__ void huge_count_chunk(const BuildTree* __restrict__ trees, const HugeState& H, int level, int chunk)
+// pass A
+__device__ __forceinline__ void huge_classify_chunk(const HugeState& H, int level, int chunk)
 {
     __shared__ int s_i[4][2];
     __shared__ float s_f[4][2];
-    const ChunkRef cr = find_chunk(H, level, chunk);
-    if (cr.task < 0) return;
-    HugeTask& t = H.tasks[level & 1][cr.task];
+    const ChunkDesc d = load_desc(H, level, chunk);
+    if (d.task < 0) return;
+    float4 p[kChunk / 256];
+#pragma unroll
+    for (int e = 0; e < kChunk / 256; ++e) p[e] = gload(d.pts + min(e * 256 + (int)threadIdx.x, d.count - 1));  // all in flight
+    HugeTask& t = H.tasks[level & 1][d.task];
     const SplitChoice sc = huge_split(t);
-    const GArr<const float4> a{trees[t.k.tree].pts + t.k.l + cr.first};
     int lt = 0, le = 0;
     float maxlt = -INFINITY, mingt = INFINITY;
 #pragma unroll
     for (int e = 0; e < kChunk / 256; ++e) {
         const int i = e * 256 + threadIdx.x;
-        if (i < cr.count) {
-            const float v = comp(a[i], sc.ax);
-            lt += v < sc.cut;
-            le += v <= sc.cut;
-            if (v < sc.cut) maxlt = fmaxf(maxlt, v);
+        if (i < d.count) {
+            const float v = comp(p[e], sc.ax);
+            const bool is_lt = v < sc.cut, is_le = v <= sc.cut;
+            lt += is_lt;
+            le += is_le;
+            if (is_lt) maxlt = fmaxf(maxlt, v);
             if (v > sc.cut) mingt = fminf(mingt, v);
+            gstore(d.cls + i, (uint8_t)(is_lt ? 0 : (is_le ? 1 : 2)));
         }
     }
     {
@@ -1176,7 +1211,9 @@ __device__ __forceinline__ void huge_count_chunk(const BuildTree* __restrict__ t
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&t.lt, s_i[0][0] + s_i[1][0] + s_i[2][0] + s_i[3][0]);
+        const int clt = s_i[0][0] + s_i[1][0] + s_i[2][0] + s_i[3][0];
+        H.c_lt[chunk] = clt;
+        atomicAdd(&t.lt, clt);
         atomicAdd(&t.le, s_i[0][1] + s_i[1][1] + s_i[2][1] + s_i[3][1]);
         const float ml = fmaxf(fmaxf(s_f[0][0], s_f[1][0]), fmaxf(s_f[2][0], s_f[3][0]));
         const float mg = fminf(fminf(s_f[0][1], s_f[1][1]), fminf(s_f[2][1], s_f[3][1]));
@@ -1185,118 +1222,285 @@ __device__ __forceinline__ void huge_count_chunk(const BuildTree* __restrict__ t
     }
 }
 
-// flags of one chunk for sweep S as E ballots per wave (wave w owns records [w*512, w*512+512) of the chunk, striped)
-template <int S>
-__device__ __forceinline__ void chunk_flags(const GArr<const float4>& a, const ChunkRef& cr, const SplitChoice& sc, int lim1, int lim2, int wave, int lane,
-                                            unsigned long long (&bL)[8], unsigned long long (&bR)[8])
+// Sweep-0 misplaced counts (left, right) of the node's chunks [0, c_to) (indices within the node), summed over the
+// workgroup.  A chunk wholly left of lim1 misplaces its records that are not "< cut", one wholly right of it those that are;
+// the one chunk lim1 falls into is counted from its class bytes.
+__device__ __forceinline__ int2 sweep0_counts(const HugeState& H, const HugeTask& t, int n, int lim1, int chunk0, int c_to, int* s_red)
 {
-    const int from = S == 0 ? 0 : lim1, bound = S == 0 ? lim1 : lim2;
+    int mL = 0, mR = 0;
+    for (int c = (int)threadIdx.x; c < c_to; c += 256) {
+        const int f = c * kChunk, e = min(n, f + kChunk);
+        const int clt = H.c_lt[chunk0 + c];
+        if (e <= lim1) mL += (e - f) - clt;
+        else if (f >= lim1) mR += clt;
+    }
+    const int cs = lim1 / kChunk;  // the chunk lim1 falls into, if it cuts one
+    if (lim1 % kChunk != 0 && lim1 < n && cs < c_to) {
+        int cl[kChunk / 256];
+#pragma unroll
+        for (int j = 0; j < kChunk / 256; ++j) cl[j] = gload(t.cls + min(cs * kChunk + j * 256 + (int)threadIdx.x, n - 1));
+#pragma unroll
+        for (int j = 0; j < kChunk / 256; ++j) {
+            const int p = cs * kChunk + j * 256 + (int)threadIdx.x;
+            mL += (p < lim1 && cl[j] != 0);
+            mR += (p >= lim1 && p < n && cl[j] == 0);
+        }
+    }
+    return block_sum2(mL, mR, s_red);
+}
+
+// class bytes of one chunk, wave w owning records [w*512, w*512+512) of the chunk, striped (-1 past the end)
+__device__ __forceinline__ void chunk_classes(const ChunkDesc& d, int wave, int lane, int (&cl)[8])
+{
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int i = wave * 512 + e * 64 + lane;  // within the chunk
-        const int p = cr.first + i;                // within the node
-        bool isL = false, isR = false;
-        if (i < cr.count && p >= from) {
-            const float v = comp(a[i], sc.ax);
-            const bool keep_left = S == 0 ? (v < sc.cut) : (v <= sc.cut);
-            isL = p < bound && !keep_left;
-            isR = p >= bound && keep_left;
+        const int i = wave * 512 + e * 64 + lane;
+        cl[e] = gload(d.cls + min(i, d.count - 1));
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cl[e] = wave * 512 + e * 64 + lane < d.count ? cl[e] : -1;
+}
+// flags of sweep S as 8 ballots per wave
+template <int S>
+__device__ __forceinline__ void chunk_flags(const int (&cl)[8], const ChunkDesc& d, int lim1, int lim2, int wave, int lane,
+                                            unsigned long long (&bL)[8], unsigned long long (&bR)[8])
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int p = d.first + wave * 512 + e * 64 + lane;  // within the node
+        bool isL, isR;
+        if (S == 0) {
+            isL = cl[e] > 0 && p < lim1;
+            isR = cl[e] == 0 && p >= lim1;
+        } else {
+            isL = cl[e] == 2 && p >= lim1 && p < lim2;
+            isR = cl[e] == 1 && p >= lim2;
         }
         bL[e] = __ballot(isL);
         bR[e] = __ballot(isR);
     }
 }
 
+// passes B (S = 0) and D (S = 1)
 template <int S>
-__device__ __forceinline__ void huge_sweepcount_chunk(const BuildTree* __restrict__ trees, const HugeState& H, int level, int chunk)
+__device__ __forceinline__ void huge_scatter_chunk(const HugeState& H, int level, int chunk)
 {
+    __shared__ int s_red[8];
     __shared__ int s_c[4][2];
-    const ChunkRef cr = find_chunk(H, level, chunk);
-    if (cr.task < 0) return;
-    const HugeTask& t = H.tasks[level & 1][cr.task];
-    const SplitChoice sc = huge_split(t);
-    const GArr<const float4> a{trees[t.k.tree].pts + t.k.l + cr.first};
+    const ChunkDesc d = load_desc(H, level, chunk);
+    if (d.task < 0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned long long bL[8], bR[8];
-    chunk_flags<S>(a, cr, sc, t.lt, t.le, wave, lane, bL, bR);
-    int wL = 0, wR = 0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { wL += __popcll(bL[e]); wR += __popcll(bR[e]); }
-    if (lane == 0) { s_c[wave][0] = wL; s_c[wave][1] = wR; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        H.c_mL[chunk] = s_c[0][0] + s_c[1][0] + s_c[2][0] + s_c[3][0];
-        H.c_mR[chunk] = s_c[0][1] + s_c[1][1] + s_c[2][1] + s_c[3][1];
-    }
-}
-
-template <int S>
-__device__ __forceinline__ void huge_scatter_chunk(const BuildTree* __restrict__ trees, const HugeState& H, int level, int chunk)
-{
-    __shared__ int s_c[4][2];
-    __shared__ int s_off[2];
-    const ChunkRef cr = find_chunk(H, level, chunk);
-    if (cr.task < 0) return;
-    const HugeTask& t = H.tasks[level & 1][cr.task];
-    const BuildTree tr = trees[t.k.tree];
-    const SplitChoice sc = huge_split(t);
-    const GArr<const float4> a{tr.pts + t.k.l + cr.first};
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int cl[8];
+    chunk_classes(d, wave, lane, cl);  // (in flight under the prefix below)
+    HugeTask& t = H.tasks[level & 1][d.task];
+    const int lim1 = t.lt, lim2 = t.le, chunk0 = t.chunk0, nchunks = t.nchunks;
+    int32_t* const posL = t.posL;
+    int32_t* const posR = t.posR;
     // ranks before this chunk = misplaced counts of the node's earlier chunks
-    int pl = 0, pr = 0;
-    for (int c = t.chunk0 + threadIdx.x; c < chunk; c += 256) { pl += H.c_mL[c]; pr += H.c_mR[c]; }
-    pl = wave_sum(pl);
-    pr = wave_sum(pr);
-    if (lane == 0) { s_c[wave][0] = pl; s_c[wave][1] = pr; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        s_off[0] = s_c[0][0] + s_c[1][0] + s_c[2][0] + s_c[3][0];
-        s_off[1] = s_c[0][1] + s_c[1][1] + s_c[2][1] + s_c[3][1];
+    int2 off;
+    if (S == 0)
+        off = sweep0_counts(H, t, t.k.r - t.k.l, lim1, chunk0, chunk - chunk0, s_red);
+    else {
+        int pl = 0, pr = 0;
+        for (int c = chunk0 + threadIdx.x; c < chunk; c += 256) { pl += H.c_mL[c]; pr += H.c_mR[c]; }
+        off = block_sum2(pl, pr, s_red);
     }
     unsigned long long bL[8], bR[8];
-    chunk_flags<S>(a, cr, sc, t.lt, t.le, wave, lane, bL, bR);
+    chunk_flags<S>(cl, d, lim1, lim2, wave, lane, bL, bR);
     int wL = 0, wR = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { wL += __popcll(bL[e]); wR += __popcll(bR[e]); }
-    __syncthreads();  // s_off written, s_c free again
     if (lane == 0) { s_c[wave][0] = wL; s_c[wave][1] = wR; }
     __syncthreads();
-    int rL = s_off[0], rR = s_off[1];
+    int rL = off.x, rR = off.y;
+    if (threadIdx.x == 0 && chunk == chunk0 + nchunks - 1) {
+        const int m = off.x + s_c[0][0] + s_c[1][0] + s_c[2][0] + s_c[3][0];
+        if (S == 0) t.m0 = m; else t.m1 = m;
+    }
     for (int w = 0; w < wave; ++w) { rL += s_c[w][0]; rR += s_c[w][1]; }
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int p = cr.first + wave * 512 + e * 64 + lane;
-        if ((bL[e] >> lane) & 1ull) gstore(tr.posL + t.k.l + rL + __popcll(bL[e] & lt_mask), p);
-        if ((bR[e] >> lane) & 1ull) gstore(tr.posR + t.k.l + rR + __popcll(bR[e] & lt_mask), p);
+        const int p = d.first + wave * 512 + e * 64 + lane;
+        if ((bL[e] >> lane) & 1ull) gstore(posL + rL + __popcll(bL[e] & lt_mask), p);
+        if ((bR[e] >> lane) & 1ull) gstore(posR + rR + __popcll(bR[e] & lt_mask), p);
         rL += __popcll(bL[e]);
         rR += __popcll(bR[e]);
     }
+    if (S == 0) {
+        // sweep-1 flags of the records sweep 0 leaves in place (right of lim1 and not "< cut"); pass C adds the arrivals
+        unsigned long long b1L[8], b1R[8];
+        chunk_flags<1>(cl, d, lim1, lim2, wave, lane, b1L, b1R);
+        int v1L = 0, v1R = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v1L += __popcll(b1L[e]); v1R += __popcll(b1R[e]); }
+        __syncthreads();  // s_c read by everyone
+        if (lane == 0) { s_c[wave][0] = v1L; s_c[wave][1] = v1R; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            H.c_mL[chunk] = s_c[0][0] + s_c[1][0] + s_c[2][0] + s_c[3][0];
+            H.c_mR[chunk] = s_c[0][1] + s_c[1][1] + s_c[2][1] + s_c[3][1];
+        }
+    }
 }
 
-__device__ __forceinline__ void huge_swap_chunk(const BuildTree* __restrict__ trees, const HugeState& H, int level, int chunk)
+// The m swap pairs of a sweep are dealt out evenly over the node's chunks (their workgroups exist anyway): pairs [lo, hi) for
+// chunk c of nchunks, in multiples of 64.
+__device__ __forceinline__ void pair_share(int m, int c, int nchunks, int* lo, int* hi)
 {
-    __shared__ int s_c[4];
-    __shared__ int s_m;
-    const ChunkRef cr = find_chunk(H, level, chunk);
-    if (cr.task < 0) return;
-    const HugeTask& t = H.tasks[level & 1][cr.task];
-    const BuildTree tr = trees[t.k.tree];
-    const GArr<float4> a{tr.pts + t.k.l};
-    int m = 0;
-    for (int c = t.chunk0 + threadIdx.x; c < t.chunk0 + t.nchunks; c += 256) m += H.c_mL[c];
-    m = wave_sum(m);
-    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = m;
+    const int per = (((m + nchunks - 1) / nchunks) + 63) & ~63;
+    *lo = min(m, c * per);
+    *hi = min(m, (c + 1) * per);
+}
+constexpr int kPairBatch = 2;  // pairs per thread in flight together
+
+// pass C: sweep-0 swaps
+__device__ __forceinline__ void huge_swap0_chunk(const HugeState& H, int level, int chunk)
+{
+    const ChunkDesc d = load_desc(H, level, chunk);
+    if (d.task < 0) return;
+    const HugeTask& t = H.tasks[level & 1][d.task];
+    float4* const a = t.pts;
+    uint8_t* const cls = t.cls;
+    const int lim2 = t.le, chunk0 = t.chunk0;
+    const int m = t.m0;  // (the class bytes change under this pass: the count was taken in pass B)
+    int lo, hi;
+    pair_share(m, chunk - chunk0, t.nchunks, &lo, &hi);
+    for (int base = lo + (int)threadIdx.x; base < hi; base += 256 * kPairBatch) {
+        int pl[kPairBatch], pr[kPairBatch], cx[kPairBatch];
+        float4 x[kPairBatch], y[kPairBatch];
+#pragma unroll
+        for (int u = 0; u < kPairBatch; ++u) {
+            const int i = min(base + u * 256, hi - 1);
+            pl[u] = gload(t.posL + i);
+            pr[u] = gload(t.posR + m - 1 - i);
+        }
+#pragma unroll
+        for (int u = 0; u < kPairBatch; ++u) {
+            x[u] = gload(a + pl[u]);
+            y[u] = gload(a + pr[u]);
+            cx[u] = gload(cls + pl[u]);  // 1 or 2; the record at pr was "< cut"
+        }
+#pragma unroll
+        for (int u = 0; u < kPairBatch; ++u) {
+            int key = -1;
+            if (base + u * 256 < hi) {
+                gstore(a + pl[u], y[u]);
+                gstore(a + pr[u], x[u]);
+                gstore(cls + pl[u], (uint8_t)0);
+                gstore(cls + pr[u], (uint8_t)cx[u]);
+                // the record now at pr (right of lim1) may be misplaced for sweep 1
+                if (pr[u] < lim2) {
+                    if (cx[u] == 2) key = 2 * (pr[u] / kChunk);
+                } else if (cx[u] == 1)
+                    key = 2 * (pr[u] / kChunk) + 1;
+            }
+            // one atomic per (wave, chunk, side): consecutive pairs land close together
+            unsigned long long todo = __ballot(key >= 0);
+            while (todo) {
+                const int lead = __builtin_ctzll(todo);
+                const int k0 = __shfl(key, lead);
+                const unsigned long long same = __ballot(key == k0);
+                if ((int)(threadIdx.x & 63) == lead) atomicAdd(((k0 & 1) ? H.c_mR : H.c_mL) + chunk0 + (k0 >> 1), __popcll(same));
+                todo &= ~same;
+            }
+        }
+    }
+}
+
+// pass E: sweep-1 swaps + the extents of the two children
+__device__ __forceinline__ void huge_swap1_chunk(const HugeState& H, int level, int chunk)
+{
+    __shared__ float s_ext[4][12];
+    const ChunkDesc d = load_desc(H, level, chunk);
+    if (d.task < 0) return;
+    // the chunk's records and class bytes (neither is needed when no child is chunked, but the reads are cheap and start the chain early)
+    float4 q[kChunk / 256];
+    int cl[kChunk / 256];
+#pragma unroll
+    for (int e = 0; e < kChunk / 256; ++e) {
+        const int i = min(e * 256 + (int)threadIdx.x, d.count - 1);
+        q[e] = gload(d.pts + i);
+        cl[e] = gload(d.cls + i);
+    }
+    const HugeTask& t = H.tasks[level & 1][d.task];
+    float4* const a = t.pts;
+    const int n = t.k.r - t.k.l, lim1 = t.lt, lim2 = t.le, half = n / 2;
+    const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
+    const int kid0 = t.kid[0], kid1 = t.kid[1];
+    const bool want = kid0 >= 0 || kid1 >= 0;
+    const int m = t.m1;
+    float lo[2][3], hi[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lo[s][c] = INFINITY; hi[s][c] = -INFINITY; }
+    auto acc = [&](const float4& p, bool right) {
+        const float v[3] = {p.x, p.y, p.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lo[0][c] = fminf(lo[0][c], right ? INFINITY : v[c]);  hi[0][c] = fmaxf(hi[0][c], right ? -INFINITY : v[c]);
+            lo[1][c] = fminf(lo[1][c], right ? v[c] : INFINITY);  hi[1][c] = fmaxf(hi[1][c], right ? v[c] : -INFINITY);
+        }
+    };
+    // the records of this chunk that stay where they are (class bytes are not written in this pass; a record that moves is
+    // accounted for by the thread that moves it)
+#pragma unroll
+    for (int e = 0; e < kChunk / 256; ++e) {
+        const int i = e * 256 + (int)threadIdx.x, p = d.first + i;
+        const bool moves = p >= lim1 && (p < lim2 ? cl[e] == 2 : cl[e] == 1);
+        if (i < d.count && !moves) acc(q[e], p >= idx);
+    }
+    // this chunk's share of the m swap pairs: x (> cut) goes right of lim2, y (== cut) into [lim1, lim2)
+    int plo, phi;
+    pair_share(m, chunk - t.chunk0, t.nchunks, &plo, &phi);
+    for (int base = plo + (int)threadIdx.x; base < phi; base += 256 * kPairBatch) {
+        int pl[kPairBatch], pr[kPairBatch];
+        float4 x[kPairBatch], y[kPairBatch];
+#pragma unroll
+        for (int u = 0; u < kPairBatch; ++u) {
+            const int i = min(base + u * 256, phi - 1);
+            pl[u] = gload(t.posL + i);
+            pr[u] = gload(t.posR + m - 1 - i);
+        }
+#pragma unroll
+        for (int u = 0; u < kPairBatch; ++u) {
+            x[u] = gload(a + pl[u]);
+            y[u] = gload(a + pr[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kPairBatch; ++u)
+            if (base + u * 256 < phi) {
+                gstore(a + pl[u], y[u]);
+                gstore(a + pr[u], x[u]);
+                acc(x[u], pr[u] >= idx);
+                acc(y[u], pl[u] >= idx);
+            }
+    }
+    if (!want) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float l = wave_min(lo[s][c]), h = wave_max(hi[s][c]);
+            if (lane == 0) { s_ext[wave][s * 6 + c] = l; s_ext[wave][s * 6 + 3 + c] = h; }
+        }
     __syncthreads();
-    if (threadIdx.x == 0) s_m = s_c[0] + s_c[1] + s_c[2] + s_c[3];
-    __syncthreads();
-    m = s_m;
-    // this chunk's share of the m swap pairs
-    for (int i = cr.first + threadIdx.x; i < min(m, cr.first + kChunk); i += 256) {
-        const int pl = gload(tr.posL + t.k.l + i), pr = gload(tr.posR + t.k.l + m - 1 - i);
-        const float4 x = a[pl], y = a[pr];
-        a.set(pl, y);
-        a.set(pr, x);
+    if (threadIdx.x < 12) {
+        const int j = threadIdx.x, s = j / 6, c = j % 3;
+        const bool is_hi = (j % 6) >= 3;
+        const int kid = s == 0 ? kid0 : kid1;
+        if (kid >= 0) {
+            HugeTask& k = H.tasks[(level + 1) & 1][kid];
+            if (is_hi) {
+                const float h = fmaxf(fmaxf(s_ext[0][j], s_ext[1][j]), fmaxf(s_ext[2][j], s_ext[3][j]));
+                if (h > -INFINITY) atomicMax(&k.mx[c], f2ord(h));
+            } else {
+                const float l = fminf(fminf(s_ext[0][j], s_ext[1][j]), fminf(s_ext[2][j], s_ext[3][j]));
+                if (l < INFINITY) atomicMin(&k.mn[c], f2ord(l));
+            }
+        }
     }
 }
 
@@ -1306,15 +1510,17 @@ __device__ __forceinline__ void huge_emit_block(const BuildTree* __restrict__ tr
 {
     const int n = min(H.ntasks[level], H.cap_tasks);
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const HugeTask& t = H.tasks[level & 1][i];
+        HugeTask& t = H.tasks[level & 1][i];
         const BuildTree tr = trees[t.k.tree];
         const SplitChoice sc = huge_split(t);
         BuildTask kids[2];
         int id;
         emit_inner(Q, tr, t.k, sc.ax, sc.cut, t.lt, t.le, ord2f(t.maxlt), ord2f(t.mingt), kids, &id);
         link_to_parent(tr, t.k, id);
-        route_task(Q, H, kids[0], level + 1);
-        route_task(Q, H, kids[1], level + 1);
+        const int k0 = route_task(Q, H, tr, kids[0], level + 1);
+        const int k1 = route_task(Q, H, tr, kids[1], level + 1);
+        t.kid[0] = k0;
+        t.kid[1] = k1;
     }
     __threadfence();
     __syncthreads();
@@ -1329,24 +1535,22 @@ __global__ __launch_bounds__(256) void huge_root_kernel(const BuildTree* __restr
 {
     huge_root_block(trees, n_trees, Q, H);
 }
-// PHASE 2 carries one extra workgroup (the last one) that records the level's nodes, routes their children and plans the
-// next level while the others count: everything it needs (extents, counts) is final after PHASE 1, and what it writes (node
-// records, queues, the next level's task / chunk tables) is read by nobody before the next level's first pass.
+// PHASE 1 (pass B) carries one extra workgroup (the last one) that records the level's nodes, routes their children and plans
+// the next level while the others rank: everything it needs (extents, counts) is final after pass A, and what it writes (node
+// records, queues, the next level's task / chunk tables, kid slots) is read by nobody before pass E.
 template <int PHASE>
 __global__ __launch_bounds__(256) void huge_phase_kernel(const BuildTree* __restrict__ trees, BuildQueues Q, HugeState H, int level)
 {
-    if (PHASE == 2 && blockIdx.x == gridDim.x - 1) {
+    if (PHASE == 1 && blockIdx.x == gridDim.x - 1) {
         huge_emit_block(trees, Q, H, level);
         return;
     }
     const int c = blockIdx.x;
-    if (PHASE == 0) huge_minmax_chunk(trees, H, level, c);
-    if (PHASE == 1) huge_count_chunk(trees, H, level, c);
-    if (PHASE == 2) huge_sweepcount_chunk<0>(trees, H, level, c);
-    if (PHASE == 3) huge_scatter_chunk<0>(trees, H, level, c);
-    if (PHASE == 4) huge_swap_chunk(trees, H, level, c);
-    if (PHASE == 5) huge_sweepcount_chunk<1>(trees, H, level, c);
-    if (PHASE == 6) huge_scatter_chunk<1>(trees, H, level, c);
+    if (PHASE == 0) huge_classify_chunk(H, level, c);
+    if (PHASE == 1) huge_scatter_chunk<0>(H, level, c);
+    if (PHASE == 2) huge_swap0_chunk(H, level, c);
+    if (PHASE == 3) huge_scatter_chunk<1>(H, level, c);
+    if (PHASE == 4) huge_swap1_chunk(H, level, c);
 }
 
 // Last launch of a build: clears the "unfinished" word (kept in the flag layout; the straggler kernel leaves nothing unfinished).
@@ -1396,7 +1600,9 @@ void TreeSetPlan::carve(Arena& a)
         const size_t cap_tasks = tot / kHuge + T + 8, cap_chunks = tot / kChunk + cap_tasks + 8;
         add(sizeof(HugeTask) * cap_tasks * 2);
         add(sizeof(int32_t) * 2 * (kHugeLevels + 2));
-        add(sizeof(int32_t) * 4 * cap_chunks);
+        add(sizeof(int32_t) * 3 * cap_chunks);
+        add(sizeof(ChunkDesc) * 2 * cap_chunks);
+        add(tot + 16 * T + 16);
     }
     scratch_bytes = bytes;
     d_scratch = a.take<char>(bytes);
@@ -1420,12 +1626,14 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     const size_t cap_tasks = tot / kHuge + T + 8, cap_chunks = tot / kChunk + cap_tasks + 8;
     HugeTask* d_huge = reinterpret_cast<HugeTask*>(take(sizeof(HugeTask) * cap_tasks * 2));
     int32_t* d_hcnt = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 2 * (kHugeLevels + 2)));
-    int32_t* d_cm = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 4 * cap_chunks));
+    int32_t* d_cm = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 3 * cap_chunks));
+    ChunkDesc* d_desc = reinterpret_cast<ChunkDesc*>(take(sizeof(ChunkDesc) * 2 * cap_chunks));
+    uint8_t* d_cls = reinterpret_cast<uint8_t*>(take(tot + 16 * T + 16));
 
     // host staging lives in the plan (the caller keeps the plan alive until its final stream synchronisation)
     plan.host_blob.resize(sizeof(BuildTree) * T);
     BuildTree* h_trees = reinterpret_cast<BuildTree*>(plan.host_blob.data());
-    size_t pos_off = 0;
+    size_t pos_off = 0, cls_off = 0;
     int32_t max_n = 0;
     for (size_t i = 0; i < T; ++i) {
         BuildTree& t = h_trees[i];
@@ -1437,6 +1645,8 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
         t.posR = d_pos + pos_off + (size_t)plan.n[i] + 1;
         pos_off += 2 * ((size_t)plan.n[i] + 1);
         t.bbox_ord = d_bbox + 8 * i;
+        t.cls = d_cls + cls_off;
+        cls_off += ((size_t)plan.n[i] + 15) & ~size_t(15);
         t.n = plan.n[i];
         max_n = std::max(max_n, t.n);
     }
@@ -1455,8 +1665,9 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     H.nchunks = d_hcnt + (kHugeLevels + 2);
     H.c_mL = d_cm;
     H.c_mR = d_cm + cap_chunks;
-    H.c_task[0] = d_cm + 2 * cap_chunks;
-    H.c_task[1] = d_cm + 3 * cap_chunks;
+    H.c_lt = d_cm + 2 * cap_chunks;
+    H.desc[0] = d_desc;
+    H.desc[1] = d_desc + cap_chunks;
     H.cap_tasks = (int32_t)cap_tasks;
     H.cap_chunks = (int32_t)cap_chunks;
 
@@ -1483,23 +1694,21 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     const unsigned n_chunks_max = (unsigned)std::min<size_t>(cap_chunks, tot / kChunk + cap_tasks);
     {
         const dim3 gc(std::max(1u, n_chunks_max)), bc(256);
+        H.grid_chunks = (int32_t)gc.x;
         hipLaunchKernelGGL(huge_root_kernel, dim3(1), dim3(256), 0, st, d_trees, (int)T, Q, H);
         for (int level = 0; level < huge_levels; ++level) {
             // nodes above kHuge points: every pass spread over the chip (see "chunked levels" above)
             hipLaunchKernelGGL(huge_phase_kernel<0>, gc, bc, 0, st, d_trees, Q, H, level);
-            hipLaunchKernelGGL(huge_phase_kernel<1>, gc, bc, 0, st, d_trees, Q, H, level);
-            hipLaunchKernelGGL(huge_phase_kernel<2>, dim3(gc.x + 1), bc, 0, st, d_trees, Q, H, level);  // + the emit workgroup
+            hipLaunchKernelGGL(huge_phase_kernel<1>, dim3(gc.x + 1), bc, 0, st, d_trees, Q, H, level);  // + the emit workgroup
+            hipLaunchKernelGGL(huge_phase_kernel<2>, gc, bc, 0, st, d_trees, Q, H, level);
             hipLaunchKernelGGL(huge_phase_kernel<3>, gc, bc, 0, st, d_trees, Q, H, level);
-            hipLaunchKernelGGL(huge_phase_kernel<4>, gc, bc, 0, st, d_trees, Q, H, level);
-            hipLaunchKernelGGL(huge_phase_kernel<5>, gc, bc, 0, st, d_trees, Q, H, level);
-            hipLaunchKernelGGL(huge_phase_kernel<6>, gc, bc, 0, st, d_trees, Q, H, level);
             hipLaunchKernelGGL(huge_phase_kernel<4>, gc, bc, 0, st, d_trees, Q, H, level);
         }
     }
     // (the level queues are indexed by the level a task was pushed FOR: chunked level L pushes for L + 1, the roots for 0)
     hipLaunchKernelGGL(build_level_kernel, dim3(grid_big), dim3(kBigThreads), 0, st, d_trees, Q, huge_levels);
     PS_TRY(launch_mid_and_subtrees(c, d_trees, Q, tot, T, small_cap));
-    plan.launches = 6 + 8 * huge_levels;
+    plan.launches = 6 + 5 * huge_levels;
     return PS_OK;
 }
 

@@ -121,7 +121,7 @@ def test_full_size_properties():
         assert np.array_equal(bf, mine), r
 
 
-@pytest.mark.parametrize("case", ["lattice", "uniform", "duplicates", "tiny"])
+@pytest.mark.parametrize("case", ["lattice", "uniform", "duplicates", "tiny", "planes_on_cut", "aligned_halves", "outliers", "full_size"])
 def test_device_tree_equals_host_tree(lib, dbg, case):
     """White box: the device builder (level-synchronous, closed-form Hoare sweeps) produces the same permutation,
     splits, child order, root box and depth as the host restatement of nanoflann's recursive builder."""
@@ -135,6 +135,21 @@ def test_device_tree_equals_host_tree(lib, dbg, case):
     elif case == "duplicates":
         p = np.repeat(rng.random((300, 3), dtype=np.float32), 40, axis=0)
         rng.shuffle(p)
+    elif case == "planes_on_cut":
+        # integer lattice 0..64 x 0..32 x 0..32: the bounding-box midpoints (32, 16, ...) are lattice planes, so every chunked
+        # level has ~1 000 records EQUAL to the cut (the second Hoare sweep and the lim1 < idx < lim2 rule do real work)
+        p = np.stack(np.meshgrid(np.arange(65), np.arange(33), np.arange(33), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+        rng.shuffle(p)
+    elif case == "aligned_halves":
+        # 32 x 32 x 64 lattice: the first splits put exactly 32 768 / 16 384 records left of the cut -- lim1 on a chunk boundary
+        p = np.stack(np.meshgrid(np.arange(32), np.arange(32), np.arange(64), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+        rng.shuffle(p)
+    elif case == "outliers":
+        # five far outliers: the big child's box midpoint lies outside its records, the cut is clamped to their extent
+        p = np.concatenate([rng.random((30000, 3), dtype=np.float32), 100 + rng.random((5, 3), dtype=np.float32)])
+        rng.shuffle(p)
+    elif case == "full_size":
+        p = brats_cloud(180000, 4)
     else:
         p = rng.random((9, 3), dtype=np.float32)
     n = len(p)
