@@ -10,11 +10,10 @@
 //   4. head flags + exclusive scan -> cell number of every sorted element, M = number of cells
 //   5. one thread per cell walks its run in order: point sum * float(1.0/count), feature sum / float(count),
 //      majority label (ties -> smallest label; the reference's tie order is unspecified, :100-101)
-// Rows come out in ascending key order.  HBM-bound integer/byte work; the sort is rocPRIM's device radix sort
-// (a device-library primitive, like the reference's use of std::unordered_map), everything else is hand-written.
+// Rows come out in ascending key order.  HBM-bound integer/byte work; sort and scan are sortscan.hip's (eight key bits per
+// pass, only the passes the largest cell key needs).
 #include "common.h"
-
-#include <rocprim/rocprim.hpp>
+#include "sortscan.h"
 
 namespace ps {
 
@@ -147,19 +146,13 @@ extern "C" int ps_grid_subsample(ps_context* c, const float* points, int64_t n, 
     hipStream_t st = c->stream;
 
     // workspace layout
-    size_t sort_tmp = 0, scan_tmp = 0;
-    {
-        unsigned long long* k = nullptr;
-        unsigned* v = nullptr;
-        PS_HIP(rocprim::radix_sort_pairs(nullptr, sort_tmp, k, k, v, v, (size_t)n, 0, 64, st));
-        PS_HIP(rocprim::exclusive_scan(nullptr, scan_tmp, v, v, 0u, (size_t)n, rocprim::plus<unsigned>(), st));
-    }
+    const size_t sort_words = sort_workspace_words((size_t)n), scan_words = scan_workspace_words((size_t)n);
     Arena& A = c->knn_arena;  // shares the KNN workspace (the two ops never overlap on one context)
     float *d_pts = nullptr, *d_feat = nullptr, *o_pts = nullptr, *o_feat = nullptr;
     int32_t *d_cls = nullptr, *o_cls = nullptr;
     unsigned long long *k0 = nullptr, *k1 = nullptr;
     unsigned *v0 = nullptr, *v1 = nullptr, *flag = nullptr, *cell = nullptr, *start = nullptr, *mm = nullptr;
-    char *tmp1 = nullptr, *tmp2 = nullptr;
+    unsigned *tmp1 = nullptr, *tmp2 = nullptr;
     for (int pass = 0; pass < 2; ++pass) {
         A.begin(pass == 0);
         d_pts = A.take<float>(3 * (size_t)n);
@@ -173,8 +166,8 @@ extern "C" int ps_grid_subsample(ps_context* c, const float* points, int64_t n, 
         cell = A.take<unsigned>(n);
         start = A.take<unsigned>(n + 1);
         mm = A.take<unsigned>(8);
-        tmp1 = A.take<char>(sort_tmp + 256);
-        tmp2 = A.take<char>(scan_tmp + 256);
+        tmp1 = A.take<unsigned>(sort_words);
+        tmp2 = A.take<unsigned>(scan_words);
         o_pts = A.take<float>(3 * (size_t)n);
         o_feat = A.take<float>((size_t)n * fdim + 1);
         o_cls = A.take<int32_t>((size_t)n * ldim + 1);
@@ -207,11 +200,25 @@ extern "C" int ps_grid_subsample(ps_context* c, const float* points, int64_t n, 
         g.NX = (unsigned long long)floorf(ex) + 1;
         g.NY = (unsigned long long)floorf(ey) + 1;
     }
+    int key_bits = 64;  // the largest key any point can get: (NX - 1) + NX (NY - 1) + NX NY iZmax
+    {
+        volatile float ez = (mx[2] - g.org[2]) / sampleDl;
+        const long double cells = (long double)g.NX * (long double)g.NY * ((long double)floorf(ez) + 1.0L);
+        if (cells < 18446744073709551615.0L) {
+            unsigned long long top = (unsigned long long)cells;  // keys are < cells
+            key_bits = 1;
+            while (key_bits < 64 && (top >> key_bits) != 0) ++key_bits;
+        }
+    }
     const dim3 grid(ceil_div(n, 256)), blk(256);
     hipLaunchKernelGGL(cell_key_kernel, grid, blk, 0, st, d_pts, (size_t)n, g, k0, v0);
-    PS_HIP(rocprim::radix_sort_pairs(tmp1, sort_tmp, k0, k1, v0, v1, (size_t)n, 0, 64, st));
+    if (radix_sort_pairs_u64(st, k0, k1, v0, v1, (size_t)n, key_bits, tmp1) == 0) {
+        std::swap(k0, k1);
+        std::swap(v0, v1);
+    }
     hipLaunchKernelGGL(head_flag_kernel, grid, blk, 0, st, k1, (size_t)n, flag);
-    PS_HIP(rocprim::exclusive_scan(tmp2, scan_tmp, flag, cell, 0u, (size_t)n, rocprim::plus<unsigned>(), st));
+    exclusive_scan_u32(st, flag, cell, (size_t)n, tmp2);
+    PS_HIP(hipGetLastError());
     hipLaunchKernelGGL(seg_start_kernel, grid, blk, 0, st, flag, cell, (size_t)n, start);
     unsigned last_cell = 0, last_flag = 0;
     PS_HIP(hipMemcpyAsync(&last_cell, cell + (n - 1), 4, hipMemcpyDeviceToHost, st));

@@ -7,12 +7,12 @@
 //                                           normalised modalities as float32, the label (4 -> 3 is the caller's business),
 //                                           and the integer voxel index (`xyz_origin`)
 // Device form: two reduction passes per modality (NumPy's std is two-pass: mean first, then mean |x - mean|^2), a flag pass,
-// rocPRIM's exclusive scan for the compaction offsets, one scatter.  Summation order differs from NumPy's pairwise sum, so
+// an exclusive scan (sortscan.hip) for the compaction offsets, one scatter.  Summation order differs from NumPy's pairwise sum, so
 // the normalised values agree to float64 rounding (and are identical after the cast to float32 except at rounding ties);
 // the point set, its order and the coordinates are exact.  HBM-bound streaming work; offline in the reference.
 #include "common.h"
 
-#include <rocprim/rocprim.hpp>
+#include "sortscan.h"
 
 namespace ps {
 
@@ -104,17 +104,13 @@ extern "C" int ps_volume_to_cloud(ps_context* c, const float* volumes, const int
     PS_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const size_t nvox = (size_t)X * Y * Z;
-    size_t scan_tmp = 0;
-    {
-        unsigned* v = nullptr;
-        PS_HIP(rocprim::exclusive_scan(nullptr, scan_tmp, v, v, 0u, nvox, rocprim::plus<unsigned>(), st));
-    }
+    const size_t scan_words = scan_workspace_words(nvox + 1);
     Arena& A = c->knn_arena;  // shares the KNN / grid workspace (these ops never overlap on one context)
     float *d_vol = nullptr, *d_xyz = nullptr, *d_col = nullptr;
     int32_t *d_seg = nullptr, *d_lab = nullptr, *d_org = nullptr;
     unsigned *flag = nullptr, *pos = nullptr;
     VolStats* stats = nullptr;
-    char* tmp = nullptr;
+    unsigned* tmp = nullptr;
     const bool fill = xyz != nullptr;
     for (int pass = 0; pass < 2; ++pass) {
         A.begin(pass == 0);
@@ -123,7 +119,7 @@ extern "C" int ps_volume_to_cloud(ps_context* c, const float* volumes, const int
         flag = A.take<unsigned>(nvox + 1);
         pos = A.take<unsigned>(nvox + 1);
         stats = A.take<VolStats>(1);
-        tmp = A.take<char>(scan_tmp + 256);
+        tmp = A.take<unsigned>(scan_words);
         d_xyz = A.take<float>(fill ? 3 * nvox : 1);
         d_col = A.take<float>(fill ? 4 * nvox : 1);
         d_lab = A.take<int32_t>(fill ? nvox : 1);
@@ -139,7 +135,8 @@ extern "C" int ps_volume_to_cloud(ps_context* c, const float* volumes, const int
     hipLaunchKernelGGL(vol_dev_kernel, grid, dim3(256), 0, st, d_vol, nvox, stats);
     hipLaunchKernelGGL(vol_flag_kernel, dim3(grid.x), dim3(256), 0, st, d_vol, nvox, stats, flag);
     PS_HIP(hipMemsetAsync(flag + nvox, 0, sizeof(unsigned), st));
-    PS_HIP(rocprim::exclusive_scan(tmp, scan_tmp, flag, pos, 0u, nvox + 1, rocprim::plus<unsigned>(), st));
+    exclusive_scan_u32(st, flag, pos, nvox + 1, tmp);
+    PS_HIP(hipGetLastError());
     unsigned n_pts = 0;
     VolStats h_stats;
     PS_HIP(hipMemcpyAsync(&n_pts, pos + nvox, sizeof(unsigned), hipMemcpyDeviceToHost, st));

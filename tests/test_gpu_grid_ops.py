@@ -45,6 +45,21 @@ def test_grid_large_cloud_vs_oracle(oracle):
     assert len(got[0]) == len(want[0])
 
 
+@pytest.mark.parametrize("n", [63, 2049, 100003])
+@pytest.mark.parametrize("dl", [0.3, 0.01, 0.0011])
+def test_grid_sort_passes_and_ragged_tiles(oracle, n, dl):
+    """The cell keys need 6 .. 30 bits over these grid sizes = 1 .. 4 radix passes (the sorted pairs end in either buffer), and the
+    sizes leave a ragged last tile / a single partial wave; rows equal the oracle's after the canonical sort, labels included."""
+    from point_unet_amd.helper_tool import DataProcessing as DP
+    rng = np.random.default_rng(n)
+    p = (rng.random((n, 3), dtype=np.float32) * np.array([1.0, 0.7, 1.3], np.float32) - 0.25).astype(np.float32)
+    f = rng.standard_normal((n, 2)).astype(np.float32)
+    l = rng.integers(0, 4, (n, 1)).astype(np.int32)
+    got = _canon(oracle, DP.grid_sub_sampling(p, f, l, dl), True, True)
+    want = oracle.canonical_rows(*oracle.grid_subsample(p, f, l, dl))
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
 def test_grid_single_point_and_single_voxel(oracle):
     from point_unet_amd.helper_tool import DataProcessing as DP
     one = np.array([[0.3, -0.2, 0.9]], np.float32)
