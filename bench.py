@@ -382,6 +382,8 @@ def main():
     ap.add_argument("--local-bn", action="store_true", help="train mode, N > 1: per-GPU BatchNorm statistics instead of statistics shared by all ranks")
     ap.add_argument("--clouds", type=int, default=8, help="distinct resident clouds every rank rotates through (one per step)")
     ap.add_argument("--no-sub-results", action="store_true", help="skip the PCIe-inclusive sub-result of the default line")
+    ap.add_argument("--att-fp32-mfma", action="store_true",
+                    help="forward: attentive pooling at d_out = 64 / 128 on the fp32 MFMA instead of bf16 MFMA over exact three-way splits (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true", help="do not record hipEvents around the stages (A/B of their cost)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
@@ -487,6 +489,9 @@ def main():
             pipe.synchronize()
             torch.cuda.synchronize()
 
+    if args.att_fp32_mfma:
+        for cx in contexts:
+            cx.set_att_bf16x3(False)
     pcie_step = None
     if pipe is not None and (args.include_pcie or not args.no_sub_results):
         h_in = [(torch.from_numpy(x).pin_memory(), torch.from_numpy(f.astype(np.float16) if half else f).pin_memory()) for x, f in zip(xyz_all, feats_all)]

@@ -74,6 +74,11 @@ int ps_set_deferred_checks(ps_context* ctx, int on);
  * (SURVEY 8d, config 3).  Activations, gradients, BatchNorm, softmax, loss and Adam stay fp32.  Default off (fp32 MFMA).
  * The fused inference path (ps_randla_forward) is never affected. */
 int ps_set_train_gemm_bf16(ps_context* ctx, int on);
+/* Matrix instruction of the fused attentive-pooling kernels of ps_randla_forward at d_out = 64 and 128 (att_pooling,
+ * PointSegment/RandLANet.py:388-401, with LocSE and the neighbour gather fused in).  on != 0 (default): v_mfma_f32_32x32x16_bf16
+ * over exact three-way bfloat16 splits of the fp32 operands with fp32 accumulation (csrc/attpool32b.hip) -- fp32-level error, 2.7 x
+ * less matrix-pipe time; on == 0: the fp32 MFMA (csrc/attpool32.hip).  Both meet the same parity bar. */
+int ps_set_att_bf16x3(ps_context* ctx, int on);
 const char* ps_last_error(void);
 /* "pointseg-hip <version> gfx950" */
 const char* ps_version(void);

@@ -12,7 +12,14 @@ struct Att32Weights {
     const float* w2 = nullptr;   // LFA mlp2 (h -> h)
     const float* wb1 = nullptr;  // att_pooling_1 Wfc[h:, :] (h -> d)
     const float* wb2 = nullptr;  // att_pooling_2 Wfc[h:, :]
+    // the same four matrices as three-plane bfloat16 images (attpool32b.hip: pack_b3 / pack_b3_locse); null when not packed
+    const float* w1b = nullptr;
+    const float* w2b = nullptr;
+    const float* wb1b = nullptr;
+    const float* wb2b = nullptr;
 };
+void pack_b3(const float* W, int cin, int cout, uint16_t* out);   // [cin, cout], cin % 32 == 0, cout % 32 == 0 -> cin*cout*3 uint16
+void pack_b3_locse(const float* W1, int cout, uint16_t* out);     // [10, cout] -> (cout/32)*3*64*8 uint16
 void pack_p32(const float* W, int cin, int cout, float* out);   // [cin, cout] row-major, cin % 8 == 0, cout % 32 == 0 -> cin*cout floats
 void pack_p32_locse(const float* W1, int cout, float* out);     // [10, cout] -> (cout/32)*5*64 floats
 
@@ -34,6 +41,8 @@ struct AttStage {
 
 bool att_pool32_fits(const AttStage& s);
 int att_pool32_stage(ps_context* c, const AttStage& s);
+bool att_pool32b_fits(const AttStage& s);
+int att_pool32b_stage(ps_context* c, const AttStage& s);
 
 int att_pool_stage(ps_context* c, const AttStage& s);
 

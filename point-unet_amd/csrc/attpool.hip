@@ -544,6 +544,7 @@ static int dispatch_d(ps_context* c, int d, const AttArgs& a)
 
 int att_pool_stage(ps_context* c, const AttStage& s)
 {
+    if (c->att_bf16x3 && att_pool32b_fits(s)) return att_pool32b_stage(c, s);
     if (att_pool32_fits(s)) return att_pool32_stage(c, s);
     AttArgs a;
     a.xyz = s.xyz; a.idx = s.idx; a.order = s.order; a.fg = s.fg;

@@ -269,6 +269,12 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
             pack_p32(scaled(W(si + 2) + (size_t)h * d, (size_t)h * d), h, d, emit_raw(&e.p32.wb1, (size_t)h * d));
             pack_p32(W(si + 4), h, h, emit_raw(&e.p32.w2, (size_t)h * h));
             pack_p32(scaled(W(si + 5) + (size_t)h * d, (size_t)h * d), h, d, emit_raw(&e.p32.wb2, (size_t)h * d));
+            if (d == 64 || d == 128 || d == 256 || d == 512) {  // three-plane bfloat16 images (attpool32b.hip); 6 bytes per weight
+                pack_b3_locse(W(si + 1), h, reinterpret_cast<uint16_t*>(emit_raw(&e.p32.w1b, (size_t)(h / 32) * 3 * 64 * 4)));
+                pack_b3(scaled(W(si + 2) + (size_t)h * d, (size_t)h * d), h, d, reinterpret_cast<uint16_t*>(emit_raw(&e.p32.wb1b, (size_t)h * d * 3 / 2)));
+                pack_b3(W(si + 4), h, h, reinterpret_cast<uint16_t*>(emit_raw(&e.p32.w2b, (size_t)h * h * 3 / 2)));
+                pack_b3(scaled(W(si + 5) + (size_t)h * d, (size_t)h * d), h, d, reinterpret_cast<uint16_t*>(emit_raw(&e.p32.wb2b, (size_t)h * d * 3 / 2)));
+            }
         }
         emit(e.mlp1, W(si), Bv(si), d_in, h, 1); ++si;
         emit(e.lfa1, W(si), Bv(si), 10, h, 1); ++si;

@@ -37,6 +37,10 @@ class Context:
         """ps_pyramid_build without host synchronisation; status validated by synchronize()."""
         _lib.check(_lib.lib().ps_set_deferred_checks(self._h, 1 if on else 0))
 
+    def set_att_bf16x3(self, on=True):
+        """Attentive pooling at d_out = 64 / 128 on bf16 MFMA over exact three-way splits (default) or on the fp32 MFMA."""
+        _lib.check(_lib.lib().ps_set_att_bf16x3(self._h, 1 if on else 0))
+
     def synchronize(self):
         _lib.check(_lib.lib().ps_synchronize(self._h))
 
