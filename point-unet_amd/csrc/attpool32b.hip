@@ -388,6 +388,12 @@ __global__ __launch_bounds__(WAVES * 64) void att32s_kernel(Att32bArgs a)
     gstage(0, t_first);
     gstage(1, t_first);
     gstage(2, t_first);
+    static_assert(NB_H == 1, "att32s: one transposed block per wave");
+    const Planes W1 = load_planes(a.w1, wave, lane);  // this wave's LocSE block: resident for the whole kernel
+    const f32x16 seed1 = seed(a.b1, wave);
+    constexpr int PD = NQ < 4 ? NQ : 4;                // score-weight chunks in flight per block
+    constexpr int PD2 = STAGE == 2 ? (NQ < 8 ? NQ : 8) : 1;  // mlp2-weight chunks in flight
+    const int cbA = wave, cbB = wave + WAVES;
     for (int t0 = t_first; t0 < t_end; t0 += t_step) {
         int pp[PPT];
 #pragma unroll
@@ -401,14 +407,21 @@ __global__ __launch_bounds__(WAVES * 64) void att32s_kernel(Att32bArgs a)
         const Planes E = split8(ev);
         if (hl == 0 && wave == 0) NB[c32] = nbr;
         gstage(0, t0 + t_step);
-
-        // ---- LFA mlp1 (transposed), this wave's blocks ----
+        // the first weight chunks of the next product do not depend on anything: they travel under LocSE and its barrier
+        Planes ring[PD2], rA[PD], rB[PD];
+        if constexpr (STAGE == 2) {
 #pragma unroll
-        for (int i = 0; i < NB_H; ++i) {
-            const int cb = wave + i * WAVES;
-            const f32x16 acc = mfma6(load_planes(a.w1, cb, lane), E, seed(a.b1, cb));
-            emit_block(acc, cb, PA, STAGE == 1);
+            for (int q = 0; q < PD2; ++q) ring[q] = load_planes(a.w2, wave * NQ + q, lane);
+        } else {
+#pragma unroll
+            for (int q = 0; q < PD; ++q) {
+                rA[q] = load_planes(a.wb, cbA * NQ + q, lane);
+                rB[q] = load_planes(a.wb, cbB * NQ + q, lane);
+            }
         }
+
+        // ---- LFA mlp1 (transposed), this wave's block ----
+        emit_block(mfma6(W1, E, seed1), wave, PA, STAGE == 1);
         __syncthreads();
         gstage(1, t0 + t_step);
         // neighbour-row offsets and the gathers of this wave's two score blocks (they travel under the products below)
@@ -423,57 +436,65 @@ __global__ __launch_bounds__(WAVES * 64) void att32s_kernel(Att32bArgs a)
             }
         }
         const char* fgb = reinterpret_cast<const char*>(a.fg);
-        f32x2 gq[2][8], v[2][8];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rel = i * WAVES * 32 * 4;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) gq[i][r >> 1][r & 1] = *reinterpret_cast<const float*>(fgb + off[r] + (rel + H * 4));
-            if ((wave + i * WAVES) * 32 < H) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[i][r >> 1][r & 1] = *reinterpret_cast<const float*>(fgb + off[r] + rel);
-            }
-        }
         if constexpr (STAGE == 2) {
-            // ---- LFA mlp2 (transposed): weights (A) stream from L2 one chunk ahead, f_xyz1's planes (B) come from LDS ----
+            // ---- LFA mlp2 (transposed): weights (A) stream from L2 PD2 chunks ahead, f_xyz1's planes (B) come from LDS ----
+            const int cb = wave;
+            f32x16 acc = seed(a.b2, cb);
+#pragma unroll 1
+            for (int q0 = 0; q0 + PD2 < NQ; q0 += PD2) {
 #pragma unroll
-            for (int i = 0; i < NB_H; ++i) {
-                const int cb = wave + i * WAVES;
-                f32x16 acc = seed(a.b2, cb);
-                Planes wn = load_planes(a.w2, cb * NQ, lane);
-#pragma unroll 4
-                for (int q = 0; q < NQ; ++q) {
-                    const Planes wc = wn;
-                    if (q + 1 < NQ) wn = load_planes(a.w2, cb * NQ + q + 1, lane);
-                    acc = mfma6(wc, load_planes(PA, q, lane), acc);
+                for (int j = 0; j < PD2; ++j) {
+                    acc = mfma6(ring[j], load_planes(PA, q0 + j, lane), acc);
+                    ring[j] = load_planes(a.w2, cb * NQ + q0 + j + PD2, lane);  // refilled in place, behind its last reader
                 }
-                emit_block(acc, cb, PB, true);
             }
+#pragma unroll
+            for (int j = 0; j < PD2; ++j) acc = mfma6(ring[j], load_planes(PA, NQ - PD2 + j, lane), acc);
+#pragma unroll
+            for (int q = 0; q < PD; ++q) {  // the score product's first chunks, under the split + barrier
+                rA[q] = load_planes(a.wb, cbA * NQ + q, lane);
+                rB[q] = load_planes(a.wb, cbB * NQ + q, lane);
+            }
+            emit_block(acc, cb, PB, true);
             __syncthreads();
         }
         gstage(2, t0 + t_step);
 
         // ---- scores of this wave's two column blocks, softmax over the K rows of a point, weighted sum ----
-        const int cbA = wave, cbB = wave + WAVES;
         f32x16 accA, accB;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
+        f32x2 gq[2][8], v[2][8];
         {
-            Planes nA = load_planes(a.wb, cbA * NQ, lane), nB = load_planes(a.wb, cbB * NQ, lane);
-#pragma unroll 4
-            for (int q = 0; q < NQ; ++q) {
-                const Planes wA = nA, wB = nB;
-                if (q + 1 < NQ) {
-                    nA = load_planes(a.wb, cbA * NQ + q + 1, lane);
-                    nB = load_planes(a.wb, cbB * NQ + q + 1, lane);
+#pragma unroll 1
+            for (int q0 = 0; q0 + PD < NQ; q0 += PD) {
+#pragma unroll
+                for (int j = 0; j < PD; ++j) {
+                    const Planes x = load_planes(PB, q0 + j, lane);
+                    accA = mfma6(x, rA[j], accA);
+                    accB = mfma6(x, rB[j], accB);
+                    rA[j] = load_planes(a.wb, cbA * NQ + q0 + j + PD, lane);  // refilled in place, behind its last reader
+                    rB[j] = load_planes(a.wb, cbB * NQ + q0 + j + PD, lane);
                 }
-                const Planes x = load_planes(PB, q, lane);
-                accA = mfma6(x, wA, accA);
-                accB = mfma6(x, wB, accB);
+            }
+            // last pass: nothing is refilled any more; the G rows of both blocks travel under its products
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gq[i][r >> 1][r & 1] = *reinterpret_cast<const float*>(fgb + off[r] + (i * WAVES * 32 * 4 + H * 4));
+#pragma unroll
+            for (int j = 0; j < PD; ++j) {
+                const Planes x = load_planes(PB, NQ - PD + j, lane);
+                accA = mfma6(x, rA[j], accA);
+                accB = mfma6(x, rB[j], accB);
             }
         }
+        // value rows of the first block (columns < H: gathered neighbour features); the second block (f_xyz columns, LDS) goes first
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int r = 0; r < 16; ++r) v[0][r >> 1][r & 1] = *reinterpret_cast<const float*>(fgb + off[r]);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = 1 - ii;
             const int cb = wave + i * WAVES;
             const f32x16& acc = i == 0 ? accA : accB;
             f32x2 (&vv)[8] = v[i];
