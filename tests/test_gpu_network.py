@@ -55,6 +55,25 @@ def test_all_five_widths_small_cloud(oracle):
     assert err <= TOL, (err, report)
 
 
+def test_split_bf16_attention_is_as_accurate_as_the_fp32_mfma(oracle):
+    """Attentive pooling at d_out >= 64 runs on bf16 MFMA over exact three-way bfloat16 splits of the fp32 operands by default
+    (csrc/attpool32b.hip); ps_set_att_bf16x3(ctx, 0) selects the fp32 MFMA.  Both must meet the bar against the float64 oracle, and
+    the split form must not be the less accurate one by more than a rounding's worth (measured: 4.1e-6 against 3.7e-6)."""
+    from point_unet_amd import runtime
+    cfg, xyz, feats = netcase.small_deep(6000)
+    ctx = runtime.default_context(0)
+    errs = {}
+    try:
+        for on in (True, False):
+            ctx.set_att_bf16x3(on)
+            errs[on], mag, _ = _run_case(oracle, cfg, xyz, feats, taps=False)
+    finally:
+        ctx.set_att_bf16x3(True)
+    print("max|logit| %.3f  err split-bf16 %.3e  err fp32 MFMA %.3e" % (mag, errs[True], errs[False]))
+    assert errs[True] <= TOL and errs[False] <= TOL
+    assert errs[True] <= 2 * errs[False] + 2e-6 * max(1.0, mag), errs
+
+
 def test_batch_of_two_clouds(oracle):
     cfg, xyz, feats = netcase.small_deep(4000, seed=7, B=2)
     err, mag, report = _run_case(oracle, cfg, xyz, feats, taps=False)
