@@ -594,11 +594,19 @@ def main():
             cst = costs.get(name, dict(flops=0, bytes=0))
             gbs = cst["bytes"] / (per_step * 1e-3) / 1e9 if per_step > 0 else 0.0
             tfs = cst["flops"] / (per_step * 1e-3) / 1e12 if per_step > 0 else 0.0
-            f_h, f_m = gbs / HBM_PEAK_GBS, tfs / F32_MFMA_PEAK_TF
+            # attentive pooling at d_out >= 64 runs its products as SIX bf16 MFMAs per fp32 product (exact three-way splits,
+            # csrc/attpool32b.hip): the matrix-pipe ceiling of those stages, in fp32 FLOPs, is the dense bf16 peak / 6
+            split = (not args.att_fp32_mfma) and "_att" in name and name.startswith("enc") and cfg.d_out[int(name[3])] >= 64
+            mfma_peak = BF16_MFMA_PEAK_TF / 6 if split else F32_MFMA_PEAK_TF
+            f_h, f_m = gbs / HBM_PEAK_GBS, tfs / mfma_peak
             bound = "mfma" if f_m > f_h else "hbm"
-            stages.append(dict(name=name, ms_per_step=round(per_step, 4), launches_per_step=launches / args.steps, bound=bound,
-                               achieved=round(tfs if bound == "mfma" else gbs, 3), unit="TFLOP/s" if bound == "mfma" else "GB/s",
-                               frac=round(max(f_h, f_m), 5)))
+            row = dict(name=name, ms_per_step=round(per_step, 4), launches_per_step=launches / args.steps, bound=bound,
+                       achieved=round(tfs if bound == "mfma" else gbs, 3), unit="TFLOP/s" if bound == "mfma" else "GB/s",
+                       frac=round(max(f_h, f_m), 5))
+            if split and bound == "mfma":
+                row["peak"] = round(mfma_peak, 1)
+                row["peak_note"] = "bf16 MFMA dense peak / 6 piece products"
+            stages.append(row)
         stages.sort(key=lambda s: -s["ms_per_step"])
         dom = next((s for s in stages if s["name"] == dominant), None)
         roofline = None
@@ -638,6 +646,9 @@ def main():
         roofline_network = dict(bound="mfma", achieved=round(net_tfs, 3), peak=F32_MFMA_PEAK_TF, unit="TFLOP/s",
                                 frac=round(net_tfs / F32_MFMA_PEAK_TF, 5), ms_per_step=round(net_ms, 4),
                                 algorithmic_flops_per_step=total_cost["flops"], measured="serial profile pass, all network stages")
+        if not args.att_fp32_mfma:
+            roofline_network["note"] = ("quoted against the fp32 MFMA peak; the attention products at d_out >= 64 execute as six bf16 MFMAs per "
+                                        "fp32 product (ceiling 2500 / 6 = 417 TFLOP/s in fp32 FLOPs), everything else on the fp32 MFMA")
         out = {
             "metric": "points_per_sec_forward",
             "value": whole_job_value(world, B, n0, args.steps, elapsed),
@@ -659,7 +670,9 @@ def main():
                        "pipeline": "serial, one stream" if args.no_pipeline else
                        "%d clouds in flight, one HIP stream each (pyramid + forward per cloud on its stream)" % args.lanes,
                        "inputs": "pinned host memory, copied per step (PCIe-inclusive)" if args.include_pcie else "resident in HBM",
-                       "distinct_clouds": n_clouds},
+                       "distinct_clouds": n_clouds,
+                       "attention_mfma": "fp32 MFMA" if args.att_fp32_mfma else
+                       "bf16 MFMA over exact three-way bfloat16 splits of the fp32 operands, fp32 accumulate (fp32-level error: csrc/attpool32b.hip)"},
             "roofline": roofline,
             "roofline_network": roofline_network,
             "serial_ms_per_cloud": serial_ms,
