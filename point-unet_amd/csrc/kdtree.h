@@ -89,6 +89,20 @@ PS_HD float sq_dist(float qx, float qy, float qz, float px, float py, float pz)
 template <int K>
 PS_HD void topk_insert(float (&dist)[K], int (&idx)[K], float d, int p)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the list is ascending, so the new value of slot j is the MEDIAN of (dist[j-1], dist[j], d): dist[j] when d is not below it,
+    // d when it falls between the two, dist[j-1] when both move up -- one v_med3_f32 instead of a compare and two selects; the
+    // indices follow the same two predicates
+#pragma unroll
+    for (int j = K - 1; j >= 1; --j) {
+        const bool mine = dist[j] > d, prev = dist[j - 1] > d;
+        const int ni = prev ? idx[j - 1] : p;
+        idx[j] = mine ? ni : idx[j];
+        dist[j] = __builtin_amdgcn_fmed3f(dist[j - 1], dist[j], d);
+    }
+    idx[0] = dist[0] > d ? p : idx[0];
+    dist[0] = fminf(dist[0], d);
+#else
 #pragma unroll
     for (int j = K - 1; j >= 0; --j) {
         const bool mine = dist[j] > d;                             // slot j moves or takes the newcomer
@@ -98,6 +112,7 @@ PS_HD void topk_insert(float (&dist)[K], int (&idx)[K], float d, int p)
         dist[j] = mine ? nd : dist[j];
         idx[j] = mine ? ni : idx[j];
     }
+#endif
 }
 
 // Deferred far children of one query: (node id, lower bound m, per-axis offsets d0..d2).  PrivateStack keeps them in
@@ -174,7 +189,8 @@ PS_HD bool knn_search_one(const TreeView& t, float qx, float qy, float qz, float
             // leaf instead of one per point
             float4 pv[kLeafMax];
 #pragma unroll
-            for (int j = 0; j < kLeafMax; ++j) pv[j] = gload(t.pts + (lf_x + j < lf_y ? lf_x + j : lf_y - 1));
+            for (int j = 0; j < kLeafMax; ++j) pv[j] = gload(t.pts + lf_x + j);  // one address, ten immediate offsets: the record
+            // array is padded by kLeafMax entries (TreeSetPlan::carve), slots past the leaf's end are read and ignored below
 #pragma unroll
             for (int j = 0; j < kLeafMax; ++j) {
                 // A slot past the leaf's end gets d = FLT_MAX, which never beats the current worst.  The insertion then runs

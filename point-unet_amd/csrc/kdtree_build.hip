@@ -1581,7 +1581,7 @@ void TreeSetPlan::carve(Arena& a)
     const size_t tot = total_points();
     for (size_t i = 0; i < T; ++i) {
         d_nodes[i] = a.take<int4>(2 * (size_t)(n[i] > 0 ? n[i] : 1));
-        d_pts[i] = a.take<float4>((size_t)(n[i] > 0 ? n[i] : 1));
+        d_pts[i] = a.take<float4>((size_t)(n[i] > 0 ? n[i] : 1) + kLeafMax);  // (+ kLeafMax: the search reads whole leaf slots, kdtree.h)
     }
     d_meta = a.take<TreeMeta>(T);
     d_jobs = a.take<char>(128 * (T + (size_t)extra_jobs));
