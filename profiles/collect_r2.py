@@ -10,7 +10,7 @@ src = os.path.join(os.path.dirname(here), "gpurun_out")
 pairs = {"prof_pipe/pipe_kernel_stats.csv": "r2_bench_kernel_stats.csv", "prof_serial/serial_kernel_stats.csv": "r2_serial_kernel_stats.csv",
          "prof_train_b8/train_b8_kernel_stats.csv": "r2_train_b8_kernel_stats.csv",
          "r2_pmc_per_kernel.json": "r2_pmc_per_kernel.json", "r2_pmc_traffic.json": "r2_pmc_traffic.json", "r2_sq_counters.txt": "r2_sq_counters.txt"}
-for n in ("", "_driver_form", "_serial", "_config5", "_train_b8", "_train_b8_bf16", "_train_b1", "_2ranks_one_gpu_gloo"):
+for n in ("", "_driver_form", "_serial", "_att_fp32_mfma", "_config5", "_train_b8", "_train_b8_bf16", "_train_b1", "_2ranks_one_gpu_gloo"):
     pairs["r2_bench_line%s.json" % n] = "r2_bench_line%s.json" % n
 for s, d in pairs.items():
     cand = glob.glob(os.path.join(src, "**", os.path.basename(s)), recursive=True) if not os.path.exists(os.path.join(src, s)) else [os.path.join(src, s)]

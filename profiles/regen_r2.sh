@@ -17,6 +17,7 @@ python3 profiles/summarize_sq.py gpurun_out/pmc_sq > gpurun_out/r2_sq_counters.t
 python3 bench.py --steps 200 --warmup 20 2>/dev/null | tail -1 > gpurun_out/r2_bench_line.json
 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/r2_bench_line_driver_form.json
 python3 bench.py --steps 30 --warmup 3 --no-pipeline --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r2_bench_line_serial.json
+python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --att-fp32-mfma 2>/dev/null | tail -1 > gpurun_out/r2_bench_line_att_fp32_mfma.json
 python3 bench.py --workload config5 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r2_bench_line_config5.json
 python3 bench.py --mode train --batch 8 --steps 3 --warmup 1 2>/dev/null | tail -1 > gpurun_out/r2_bench_line_train_b8.json
 python3 bench.py --mode train --batch 8 --bf16-mlp --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r2_bench_line_train_b8_bf16.json
