@@ -284,6 +284,15 @@ int ps_op_att_pool_train_fwd(ps_context* ctx, const float* fset, int64_t ld, con
                              float* agg);
 int ps_op_att_pool_train_bwd(ps_context* ctx, const float* fset, int64_t ld, const float* wfc, const float* dagg, int64_t R,
                              int64_t K, int64_t d, float* dfset, int64_t lddf, float* dwfc);
+/* The same with gather_neighbour and the concat folded in (RandLANet.py:326-333: fset = concat(gather_neighbour(f, neigh_idx), f_xyz)):
+ * fset[b, n, k, :] = [ fl[b, idx[b,n,k], :] | fr[b, n, k, :] ] is never materialised.  fl [B*n_src, d/2] (row stride ldl), idx [B, n_q, K]
+ * cloud-local, fr [B*n_q*K, d/2] (row stride ldr).  The backward writes dfr (row stride lddr, overwritten), ADDS the gathered half's
+ * gradient into dfl (row stride lddl; float atomics, like ps_op_scatter_add_rows) and writes dwfc (overwritten, deterministic). */
+int ps_op_att_pool_train_fwd_split(ps_context* ctx, const float* fl, int64_t ldl, const int32_t* idx, int64_t B, int64_t n_src,
+                                   int64_t n_q, const float* fr, int64_t ldr, const float* wfc, int64_t K, int64_t d, float* agg);
+int ps_op_att_pool_train_bwd_split(ps_context* ctx, const float* fl, int64_t ldl, const int32_t* idx, int64_t B, int64_t n_src,
+                                   int64_t n_q, const float* fr, int64_t ldr, const float* wfc, const float* dagg, int64_t K, int64_t d,
+                                   float* dfl, int64_t lddl, float* dfr, int64_t lddr, float* dwfc);
 /* backward of random_sample (max over K); ties share the gradient evenly like tf.reduce_max; dfeature accumulates */
 int ps_op_random_sample_bwd(ps_context* ctx, const float* dout, const float* out, const float* feature,
                             const int32_t* pool_idx, int64_t B, int64_t N, int64_t M, int64_t K, int64_t d,

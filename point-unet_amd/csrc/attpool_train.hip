@@ -41,6 +41,14 @@ struct AttTrainArgs {
     float* dw_part;     // [gridDim.x, D*D] (backward)
     int64_t R;
     int ld, lddf, bf16;
+    // split-source form (gather_neighbour + concat folded in, RandLANet.py:326-333): F = [fl[idx] | f]; `f` / `df` then hold only the
+    // right half ([R*K, D/2] rows); the left half's gradient is added into dfl with float atomics (a scatter-add like
+    // ps_op_scatter_add_rows)
+    const float* fl;     // [B*n_src, D/2] rows (ldl), nullptr = F is materialised in f
+    const int32_t* idx;  // [R, K] cloud-local source rows
+    float* dfl;          // [B*n_src, D/2] rows (lddl), accumulated into (backward)
+    int64_t n_src, n_q;  // rows per cloud of fl / points per cloud
+    int ldl, lddl;
 };
 
 template <int D>
@@ -85,6 +93,32 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ f, int ld, i
     }
 }
 
+// split-source tile: columns [0, D/2) from fl[cloud base + idx[p, row]], columns [D/2, D) from row p*KN + row of f
+template <int D, int KN>
+__device__ __forceinline__ void load_tile_split(const AttTrainArgs& a, int64_t p, float* A, float* Ab, int lane)
+{
+    constexpr int PA = AttTrainGeom<D>::PA, Q = D / 4, QH = Q / 2, TOT = KN * Q;
+    const int64_t base = (p / a.n_q) * a.n_src;
+#pragma unroll
+    for (int e0 = 0; e0 < TOT; e0 += 64) {
+        const int e = e0 + lane;
+        if (TOT % 64 == 0 || e < TOT) {
+            const int row = e / Q, q = e - row * Q;
+            float4 v;
+            if (q < QH)
+                v = *reinterpret_cast<const float4*>(a.fl + (size_t)(base + a.idx[p * KN + row]) * a.ldl + 4 * q);
+            else
+                v = *reinterpret_cast<const float4*>(a.f + (size_t)(p * KN + row) * a.ld + 4 * (q - QH));
+            float* dst = A + row * PA + 4 * q;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            if (Ab) {
+                float* db = Ab + row * PA + 4 * q;
+                db[0] = round_bf16(v.x); db[1] = round_bf16(v.y); db[2] = round_bf16(v.z); db[3] = round_bf16(v.w);
+            }
+        }
+    }
+}
+
 // scores of column tile ct: C[k][c] = sum_j X[k][j] W[j][16 ct + c]   (X = tile with pitch PA, W in LDS with pitch PW)
 template <int D>
 __device__ __forceinline__ f32x4 score_tile(const float* X, const float* W, int ct, int lane)
@@ -111,7 +145,8 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_fwd_kernel(AttTrainArgs 
     stage_weights<D, WAVES * 64>(a.w, W, nullptr, a.bf16 != 0);
     __syncthreads();
     for (int64_t p = (int64_t)blockIdx.x * WAVES + wave; p < a.R; p += (int64_t)gridDim.x * WAVES) {
-        load_tile<D, KN>(a.f, a.ld, p, A, Ab, lane);
+        if (a.fl) load_tile_split<D, KN>(a, p, A, Ab, lane);
+        else load_tile<D, KN>(a.f, a.ld, p, A, Ab, lane);
         wave_lds_sync();
         const float* X = a.bf16 ? Ab : A;
 #pragma unroll
@@ -157,7 +192,8 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
         for (int tj = 0; tj < NT; ++tj) dw[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int64_t p = (int64_t)blockIdx.x * WAVES + wave; p < a.R; p += (int64_t)gridDim.x * WAVES) {
-        load_tile<D, KN>(a.f, a.ld, p, A, Ab, lane);
+        if (a.fl) load_tile_split<D, KN>(a, p, A, Ab, lane);
+        else load_tile<D, KN>(a.f, a.ld, p, A, Ab, lane);
         wave_lds_sync();
         const float* X = a.bf16 ? Ab : A;
         f32x4 dfd[NT];  // direct term p * g of every column tile (seeds the second product)
@@ -196,8 +232,23 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
             f32x4 acc = dfd[tj];
 #pragma unroll
             for (int s = 0; s < D / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[4 * s], wb[4 * s * PW], acc, 0, 0, 0);
+            if (!a.fl) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a.df[(size_t)(p * KN + 4 * g + r) * a.lddf + tj * 16 + c16] = acc[r];
+                for (int r = 0; r < 4; ++r) a.df[(size_t)(p * KN + 4 * g + r) * a.lddf + tj * 16 + c16] = acc[r];
+            } else {
+                const int col = tj * 16 + c16;
+                if (col >= D / 2) {  // f_xyz half: plain rows
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a.df[(size_t)(p * KN + 4 * g + r) * a.lddf + col - D / 2] = acc[r];
+                } else {             // gathered half: scatter-add onto the source rows
+                    const int4 nb = *reinterpret_cast<const int4*>(a.idx + p * KN + 4 * g);
+                    const int64_t base = (p / a.n_q) * a.n_src;
+                    atomicAdd(a.dfl + (size_t)(base + nb.x) * a.lddl + col, acc[0]);
+                    atomicAdd(a.dfl + (size_t)(base + nb.y) * a.lddl + col, acc[1]);
+                    atomicAdd(a.dfl + (size_t)(base + nb.z) * a.lddl + col, acc[2]);
+                    atomicAdd(a.dfl + (size_t)(base + nb.w) * a.lddl + col, acc[3]);
+                }
+            }
         }
         // ---- dWfc += F^T . dS  (contraction over the K = 16 rows: four MFMA steps per tile pair) ----
 #pragma unroll
@@ -309,6 +360,51 @@ extern "C" int ps_op_att_pool_train_bwd(ps_context* c, const float* fset, int64_
     Stage st(c, "train_att_fused_bwd", 2);
     AttTrainArgs a = {};
     a.f = fset; a.w = wfc; a.dagg = dagg; a.df = dfset; a.R = R; a.ld = (int)ld; a.lddf = (int)lddf; a.bf16 = c->train_bf16 ? 1 : 0;
+    switch (d) {
+        case 16: return launch_att_train<16>(c, a, true, dwfc);
+        case 32: return launch_att_train<32>(c, a, true, dwfc);
+        default: return launch_att_train<64>(c, a, true, dwfc);
+    }
+}
+
+/* split-source form: F = [fl[idx] | fr] is never materialised (see include/pointseg.h) */
+extern "C" int ps_op_att_pool_train_fwd_split(ps_context* c, const float* fl, int64_t ldl, const int32_t* idx, int64_t B, int64_t n_src, int64_t n_q,
+                                              const float* fr, int64_t ldr, const float* wfc, int64_t K, int64_t d, float* agg)
+{
+    PS_CHECK(c && fl && idx && fr && wfc && agg, "ps_op_att_pool_train_fwd_split: NULL argument");
+    PS_CHECK(att_train_ok(K, d, ldr, fr) && ldl % 4 == 0 && (reinterpret_cast<uintptr_t>(fl) & 15) == 0 && B >= 0 && n_src > 0 && n_q >= 0,
+             "ps_op_att_pool_train_fwd_split: K = 16, d in {16, 32, 64}, rows 16-byte aligned (got K %lld, d %lld)", (long long)K, (long long)d);
+    const int64_t R = B * n_q;
+    if (R <= 0) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "train_att_fused_fwd", 1);
+    AttTrainArgs a = {};
+    a.f = fr; a.ld = (int)ldr; a.fl = fl; a.ldl = (int)ldl; a.idx = idx; a.n_src = n_src; a.n_q = n_q;
+    a.w = wfc; a.agg = agg; a.R = R; a.bf16 = c->train_bf16 ? 1 : 0;
+    switch (d) {
+        case 16: return launch_att_train<16>(c, a, false, nullptr);
+        case 32: return launch_att_train<32>(c, a, false, nullptr);
+        default: return launch_att_train<64>(c, a, false, nullptr);
+    }
+}
+
+extern "C" int ps_op_att_pool_train_bwd_split(ps_context* c, const float* fl, int64_t ldl, const int32_t* idx, int64_t B, int64_t n_src, int64_t n_q,
+                                              const float* fr, int64_t ldr, const float* wfc, const float* dagg, int64_t K, int64_t d, float* dfl,
+                                              int64_t lddl, float* dfr, int64_t lddr, float* dwfc)
+{
+    PS_CHECK(c && fl && idx && fr && wfc && dagg && dfl && dfr && dwfc, "ps_op_att_pool_train_bwd_split: NULL argument");
+    PS_CHECK(att_train_ok(K, d, ldr, fr) && ldl % 4 == 0 && (reinterpret_cast<uintptr_t>(fl) & 15) == 0 && lddl >= d / 2 && lddr >= d / 2 && n_src > 0,
+             "ps_op_att_pool_train_bwd_split: K = 16, d in {16, 32, 64}, rows 16-byte aligned");
+    PS_HIP(hipSetDevice(c->device));
+    const int64_t R = B * n_q;
+    if (R <= 0) {
+        PS_HIP(hipMemsetAsync(dwfc, 0, sizeof(float) * d * d, c->stream));
+        return PS_OK;
+    }
+    Stage st(c, "train_att_fused_bwd", 2);
+    AttTrainArgs a = {};
+    a.f = fr; a.ld = (int)ldr; a.fl = fl; a.ldl = (int)ldl; a.idx = idx; a.n_src = n_src; a.n_q = n_q;
+    a.w = wfc; a.dagg = dagg; a.df = dfr; a.lddf = (int)lddr; a.dfl = dfl; a.lddl = (int)lddl; a.R = R; a.bf16 = c->train_bf16 ? 1 : 0;
     switch (d) {
         case 16: return launch_att_train<16>(c, a, true, dwfc);
         case 32: return launch_att_train<32>(c, a, true, dwfc);

@@ -253,6 +253,30 @@ class Tape:
         self.ops.append((agg, bw))
         return agg
 
+    def attpool_split(self, f_src, idx, f_xyz, W, gW, B):
+        """attpool over fset = [gather(f_src, idx) | f_xyz] without the gather, the concat buffer or the scatter-add of its gradient
+        (ps_op_att_pool_train_*_split).  f_src [B*N, h], idx [B, M, K], f_xyz [B*M*K, h] (rows may be strided), W [2h, 2h]."""
+        N, h = f_src.shape[0] // B, f_src.shape[1]
+        M, K = idx.shape[1], idx.shape[2]
+        d = 2 * h
+        fs, fx = _rowmajor(f_src), _rowmajor(f_xyz)
+        agg = torch.empty((B * M, d), dtype=torch.float32, device=f_src.device)
+        _lib.check(self.L.ps_op_att_pool_train_fwd_split(self.h, _p(fs), fs.stride(0), _p(idx), B, N, M, _p(fx), fx.stride(0), _p(W), K, d, _p(agg)))
+
+        def bw(dy):
+            dfx = torch.empty((B * M * K, h), dtype=torch.float32, device=f_src.device)
+            dsrc = self.accum_buffer(f_src)  # the gathered half's gradient is added in place (float atomics)
+            tmp = gW if gW.is_contiguous() else torch.empty((d, d), dtype=torch.float32, device=f_src.device)
+            _lib.check(self.L.ps_op_att_pool_train_bwd_split(self.h, _p(fs), fs.stride(0), _p(idx), B, N, M, _p(fx), fx.stride(0), _p(W),
+                                                             _p(dy.contiguous()), K, d, _p(dsrc), dsrc.stride(0), _p(dfx), h, _p(tmp)))
+            if tmp is not gW:
+                gW.copy_(tmp)
+            self.accum(f_xyz, dfx)
+
+        agg.requires_grad_flag = True
+        self.ops.append((agg, bw))
+        return agg
+
     def maxpool(self, x, pool_idx, B):
         N, d = x.shape[0] // B, x.shape[1]
         M, K = pool_idx.shape[1], pool_idx.shape[2]
@@ -392,6 +416,10 @@ class Trainer:
                          self.buffers[s + "/moving_variance"], act, out=out)
         return y
 
+    def _att_split(self, t, f_src, idx, f_xyz, name, B):
+        agg = t.attpool_split(f_src, idx, f_xyz, self.P[name + "fc/kernel"], self.G[name + "fc/kernel"], B)
+        return self._conv(t, agg, name + "mlp")
+
     def _att(self, t, fcat, name, K):
         W, gW = self.P[name + "fc/kernel"], self.G[name + "fc/kernel"]
         if self.fused_att and t.L.ps_op_att_pool_train_supported(K, fcat.shape[1]):
@@ -424,14 +452,22 @@ class Trainer:
             # tf.concat([f_neighbours, f_xyz]) (RandLANet.py:328,332): both producers write their column block of the concat
             # buffer directly (no concat copy forward, no split copies backward)
             hc = f_pc.shape[1]
-            cat1 = torch.empty((B * N * K, 2 * hc), dtype=torch.float32, device=x.device)
-            f_xyz = self._conv(t, rel, n + "LFAmlp1", out=cat1[:, hc:])
-            f_nb = t.gather(f_pc, idx, B, out=cat1[:, :hc])
-            f_agg = self._att(t, t.concat_views(cat1, f_nb, f_xyz), n + "LFAatt_pooling_1", K)
-            cat2 = torch.empty((B * N * K, 2 * hc), dtype=torch.float32, device=x.device)
-            f_xyz2 = self._conv(t, f_xyz, n + "LFAmlp2", out=cat2[:, hc:])
-            f_nb2 = t.gather(f_agg, idx, B, out=cat2[:, :hc])
-            f_agg2 = self._att(t, t.concat_views(cat2, f_nb2, f_xyz2), n + "LFAatt_pooling_2", K)
+            if self.fused_att and lib.ps_op_att_pool_train_supported(K, 2 * hc):
+                # gather_neighbour + concat + att_pooling's core as one kernel per direction: neither the gathered rows nor the concat
+                # buffer nor the gathered half of its gradient exist (the backward scatter-adds into f_pc's gradient itself)
+                f_xyz = self._conv(t, rel, n + "LFAmlp1")
+                f_agg = self._att_split(t, f_pc, idx, f_xyz, n + "LFAatt_pooling_1", B)
+                f_xyz2 = self._conv(t, f_xyz, n + "LFAmlp2")
+                f_agg2 = self._att_split(t, f_agg, idx, f_xyz2, n + "LFAatt_pooling_2", B)
+            else:
+                cat1 = torch.empty((B * N * K, 2 * hc), dtype=torch.float32, device=x.device)
+                f_xyz = self._conv(t, rel, n + "LFAmlp1", out=cat1[:, hc:])
+                f_nb = t.gather(f_pc, idx, B, out=cat1[:, :hc])
+                f_agg = self._att(t, t.concat_views(cat1, f_nb, f_xyz), n + "LFAatt_pooling_1", K)
+                cat2 = torch.empty((B * N * K, 2 * hc), dtype=torch.float32, device=x.device)
+                f_xyz2 = self._conv(t, f_xyz, n + "LFAmlp2", out=cat2[:, hc:])
+                f_nb2 = t.gather(f_agg, idx, B, out=cat2[:, :hc])
+                f_agg2 = self._att(t, t.concat_views(cat2, f_nb2, f_xyz2), n + "LFAatt_pooling_2", K)
             a = self._conv(t, f_agg2, n + "mlp2", act=False)
             b = self._conv(t, feature, n + "shortcut", act=False)
             f_enc = t.add_lrelu(a, b)

@@ -449,6 +449,47 @@ def test_fused_attentive_pooling_forward_backward(mode):
     torch.cuda.synchronize()
 
 
+def test_split_source_attentive_pooling_equals_gather_concat_attpool():
+    """ps_op_att_pool_train_*_split (gather_neighbour + concat folded into the fused attention) against the materialised form through
+    the SAME fused kernels: agg, the f_xyz half of the gradient and dWfc bit-identical (same arithmetic, fixed summation order); the
+    gathered half, scatter-added with float atomics, equal to ps_op_scatter_add_rows of the materialised gradient within the atomics'
+    summation-order noise (2e-6 of its max); it is ADDED to what the buffer held.  Two clouds, d = 16 / 32 / 64."""
+    import ctypes
+    import torch
+    from point_unet_amd import _lib, runtime
+    L, ctx = _lib.lib(), runtime.default_context(0)
+    h = ctx.handle
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(5)
+    B, N, M, K = 2, 700, 650, 16
+    for d in (16, 32, 64):
+        hh = d // 2
+        fsrc = torch.randn(B * N, hh, generator=g).cuda()
+        idx = torch.randint(0, N, (B, M, K), generator=g, dtype=torch.int32).cuda()
+        fx = torch.randn(B * M * K, hh, generator=g).cuda()
+        W = (torch.randn(d, d, generator=g) / d ** 0.5).cuda()
+        dagg = torch.randn(B * M, d, generator=g).cuda()
+        # materialised reference
+        cat = torch.empty(B * M * K, d).cuda()
+        _lib.check(L.ps_op_gather_neighbour_ex(h, p(fsrc), p(idx), B, N, M, K, hh, p(cat), d))
+        cat[:, hh:] = fx
+        agg0, dcat, dW0 = torch.empty(B * M, d).cuda(), torch.empty(B * M * K, d).cuda(), torch.empty(d, d).cuda()
+        _lib.check(L.ps_op_att_pool_train_fwd(h, p(cat), d, p(W), B * M, K, d, p(agg0)))
+        _lib.check(L.ps_op_att_pool_train_bwd(h, p(cat), d, p(W), p(dagg), B * M, K, d, p(dcat), d, p(dW0)))
+        dsrc0 = torch.ones(B * N, hh).cuda()
+        _lib.check(L.ps_op_scatter_add_rows_ex(h, p(dcat), d, p(idx), B, N, M * K, hh, p(dsrc0)))
+        # split-source form
+        agg1, dfx, dW1 = torch.empty(B * M, d).cuda(), torch.empty(B * M * K, hh).cuda(), torch.empty(d, d).cuda()
+        dsrc1 = torch.ones(B * N, hh).cuda()
+        _lib.check(L.ps_op_att_pool_train_fwd_split(h, p(fsrc), hh, p(idx), B, N, M, p(fx), hh, p(W), K, d, p(agg1)))
+        _lib.check(L.ps_op_att_pool_train_bwd_split(h, p(fsrc), hh, p(idx), B, N, M, p(fx), hh, p(W), p(dagg), K, d, p(dsrc1), hh, p(dfx), hh, p(dW1)))
+        assert torch.equal(agg0, agg1), d
+        assert torch.equal(dcat[:, hh:], dfx), d
+        assert torch.equal(dW0, dW1), d
+        assert (dsrc0 - dsrc1).abs().max() <= 2e-6 * dsrc0.abs().max(), d
+    torch.cuda.synchronize()
+
+
 def test_row_strided_variants_match_the_dense_ops():
     """ps_op_*_ex on column blocks of a wider tensor (the training step's concat buffers) give what the dense entry points give
     on contiguous copies; conv1x1_ex with accumulate adds in the epilogue."""
