@@ -293,6 +293,24 @@ int ps_op_att_pool_train_fwd_split(ps_context* ctx, const float* fl, int64_t ldl
 int ps_op_att_pool_train_bwd_split(ps_context* ctx, const float* fl, int64_t ldl, const int32_t* idx, int64_t B, int64_t n_src,
                                    int64_t n_q, const float* fr, int64_t ldr, const float* wfc, const float* dagg, int64_t K, int64_t d,
                                    float* dfl, int64_t lddl, float* dfr, int64_t lddr, float* dwfc);
+/* The LocSE branch of the training step, f_xyz = LeakyReLU(BN_train(relative_pos_encoding(xyz, idx) . w + b))   (RandLANet.py:323-325,
+ * 377-386; helper_tf_util.conv2d :115-170), without the [B*N*K, 10] encoding, the product or their gradients in memory: everything is
+ * recomputed from xyz [B*N,3] and idx [B,N,K] (csrc/locse_train.hip).  w [10,h], b [h]; h in {8,16,32,64} (ps_op_locse_train_supported).
+ *   _sums : sums[0:h] = sum_rows y, sums[h:2h] = sum_rows y^2, y = enc10 . w + b, accumulated and returned in float64 (the variance is a
+ *           difference of nearly equal numbers when a channel's mean is large against its spread; the caller forms mean / variance; SyncBN:
+ *           all-reduce first)
+ *   _apply: out[r, :] = LeakyReLU((y - mean) scale + beta), scale = gamma invstd; row stride ldo
+ *   _bwd  : one pass over dz (row stride lddz): sums = S1[h] | S2[h] | XS[h] | A[10,h] | G[10,h] | E[16] with xh = (y - mean) invstd,
+ *           g = dz lrelu', S1 = sum g, S2 = sum g xh, XS = sum xh, A = enc10^T g, G = enc10^T xh, E = sum enc10 (23 h + 16 floats); then
+ *           dgamma = S2, dbeta = S1, dw = gamma invstd (A - E x S1/M - G . S2/M), M = rows of all ranks.  Deterministic (fixed-order sums). */
+int ps_op_locse_train_supported(int64_t K, int64_t h);
+int ps_op_locse_train_sums(ps_context* ctx, const float* xyz, const int32_t* idx, int64_t B, int64_t N, int64_t K, const float* w,
+                           const float* b, int64_t h, double* sums);
+int ps_op_locse_train_apply(ps_context* ctx, const float* xyz, const int32_t* idx, int64_t B, int64_t N, int64_t K, const float* w,
+                            const float* b, int64_t h, const float* mean, const float* scale, const float* beta, float* out, int64_t ldo);
+int ps_op_locse_train_bwd(ps_context* ctx, const float* xyz, const int32_t* idx, int64_t B, int64_t N, int64_t K, const float* w,
+                          const float* b, int64_t h, const float* scale, const float* beta, const float* mean, const float* invstd,
+                          const float* dz, int64_t lddz, float* sums);
 /* backward of random_sample (max over K); ties share the gradient evenly like tf.reduce_max; dfeature accumulates */
 int ps_op_random_sample_bwd(ps_context* ctx, const float* dout, const float* out, const float* feature,
                             const int32_t* pool_idx, int64_t B, int64_t N, int64_t M, int64_t K, int64_t d,

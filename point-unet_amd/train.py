@@ -164,6 +164,54 @@ class Tape:
         self.ops.append((y, bw))
         return y
 
+    def locse_bn_act(self, xyz, idx, B, W, b, gW, gb, gamma, beta, ggamma, gbeta, mov_mean, mov_var, out=None):
+        """f_xyz = LeakyReLU(BN_train(relative_pos_encoding(xyz, idx) . W + b)) -> [B*N*K, h] (out: optional column block), with
+        nothing but that output in memory: statistics, output and every gradient are recomputed from xyz [B*N,3] and idx [B,N,K]
+        (ps_op_locse_train_*).  The [10,h]-sized finishing arithmetic of the weight gradient is done here."""
+        N, K = idx.shape[1], idx.shape[2]
+        h = W.shape[1]
+        R = B * N * K
+        dev = xyz.device
+        sync = self.sync
+        R_total = R if sync is None else R * sync.get_world_size()
+        sums = torch.empty(2 * h, dtype=torch.float64, device=dev)  # float64: the variance is a difference of nearly equal sums
+        _lib.check(self.L.ps_op_locse_train_sums(self.h, _p(xyz), _p(idx), B, N, K, _p(W), _p(b), h, _p(sums)))
+        if sync is not None:
+            sync.all_reduce(sums)
+        mean64 = sums[:h] / R_total
+        var = (sums[h:] / R_total - mean64 * mean64).clamp_min_(0.0).float()  # population variance (tf.nn.moments)
+        mean = mean64.float()
+        invstd = torch.rsqrt(var + BN_EPS)
+        scale = (gamma.reshape(-1) * invstd).contiguous()
+        shift = beta.reshape(-1).contiguous()
+        y = torch.empty((R, h), dtype=torch.float32, device=dev) if out is None else out
+        _lib.check(self.L.ps_op_locse_train_apply(self.h, _p(xyz), _p(idx), B, N, K, _p(W), _p(b), h, _p(mean), _p(scale), _p(shift), _p(y), y.stride(0)))
+        mov_mean.mul_(BN_MOMENTUM).add_(mean, alpha=1 - BN_MOMENTUM)
+        mov_var.mul_(BN_MOMENTUM).add_(var, alpha=1 - BN_MOMENTUM)
+        mean, invstd = mean.contiguous(), invstd.contiguous()
+
+        def bw(dz):
+            dzc = _rowmajor(dz)
+            acc = torch.empty(23 * h + 16, dtype=torch.float32, device=dev)
+            _lib.check(self.L.ps_op_locse_train_bwd(self.h, _p(xyz), _p(idx), B, N, K, _p(W), _p(b), h, _p(scale), _p(shift), _p(mean), _p(invstd),
+                                                    _p(dzc), dzc.stride(0), _p(acc)))
+            S1, S2, XS = acc[:h], acc[h:2 * h], acc[2 * h:3 * h]
+            A, G, E = acc[3 * h:13 * h].view(10, h), acc[13 * h:23 * h].view(10, h), acc[23 * h:23 * h + 10]
+            ggamma.copy_(S2.view_as(ggamma))  # this rank's dgamma / dbeta (averaged with every other gradient later)
+            gbeta.copy_(S1.view_as(gbeta))
+            tot = torch.stack([S1, S2])
+            if sync is not None:
+                sync.all_reduce(tot)
+            m1, m2 = tot[0] / R_total, tot[1] / R_total
+            k = gamma.reshape(-1) * invstd
+            # dy = k (g - m1 - xh m2)  =>  enc10^T dy and sum dy from the sums of the one pass
+            gW.copy_((k[None, :] * (A - E[:, None] * m1[None, :] - G * m2[None, :])).view_as(gW))
+            gb.copy_((k * (S1 - R * m1 - XS * m2)).view_as(gb))
+
+        y.requires_grad_flag = True
+        self.ops.append((y, bw))
+        return y
+
     def gather(self, x, idx, B, out=None):
         """x [B*N, d], idx [B, M, K] -> [B*M*K, d]; out: optional column block of a wider tensor that receives the rows"""
         N, d = x.shape[0] // B, x.shape[1]
@@ -326,7 +374,7 @@ class Trainer:
     """Parameters (flat fp32 buffer + named views), Adam state and the train step."""
 
     def __init__(self, config, params=None, device=0, seed=0, learning_rate=None, class_weights=None, keep_prob=0.5, ctx=None, sync_bn=False,
-                 mlp_dtype="fp32", ignored_label_inds=None, fused_att=True):
+                 mlp_dtype="fp32", ignored_label_inds=None, fused_att=True, fused_locse=True):
         """sync_bn: with a `dist` passed to train_step, BatchNorm uses the statistics of all ranks' rows, which makes "W GPUs x
         one cloud" numerically the same step as "one GPU x W clouds" (SURVEY 8e); off = per-GPU statistics.
         mlp_dtype: "fp32" (default) or "bf16" -- BASELINE configs[2]'s "bf16 MLPs": the shared-MLP GEMMs (forward, input gradient,
@@ -335,6 +383,9 @@ class Trainer:
             raise ValueError("mlp_dtype must be 'fp32' or 'bf16'")
         self.mlp_bf16 = mlp_dtype == "bf16"
         self.fused_att = bool(fused_att)  # False: the op-by-op attentive pooling everywhere (A/B switch of bench.py --no-fused-att)
+        # LocSE branch (relative_pos_encoding -> conv 10->h -> BatchNorm -> LeakyReLU) recomputed from coordinates and indices instead of
+        # materialised (csrc/locse_train.hip).  Not in the bf16-MLP mode: its weight gradient is defined on rounded operands of the GEMM
+        self.fused_locse = bool(fused_locse) and not self.mlp_bf16
         self.sync_bn = bool(sync_bn)
         self.cfg = config
         self.device = torch.device("cuda", device)
@@ -446,22 +497,33 @@ class Trainer:
             N = idx.shape[1]
             feature = f
             f_pc = self._conv(t, feature, n + "mlp1")
-            rel = torch.empty((B * N * K, 10), dtype=torch.float32, device=x.device)
-            _lib.check(lib.ps_op_relative_pos_encoding(h, _p(pyr.xyz[i]), _p(idx), B, N, K, _p(rel)))
-            rel.requires_grad_flag = False
+            hloc = self.P[n + "LFAmlp1/weights"].shape[1]
+            locse_fused = self.fused_locse and lib.ps_op_locse_train_supported(K, hloc)
+            if not locse_fused:
+                rel = torch.empty((B * N * K, 10), dtype=torch.float32, device=x.device)
+                _lib.check(lib.ps_op_relative_pos_encoding(h, _p(pyr.xyz[i]), _p(idx), B, N, K, _p(rel)))
+                rel.requires_grad_flag = False
+
+            def locse(out=None):
+                if not locse_fused:
+                    return self._conv(t, rel, n + "LFAmlp1", out=out)
+                s, sb = n + "LFAmlp1", n + "LFAmlp1/batch_normalization"
+                return t.locse_bn_act(pyr.xyz[i], idx, B, self.P[s + "/weights"], self.P[s + "/biases"], self.G[s + "/weights"], self.G[s + "/biases"],
+                                      self.P[sb + "/gamma"], self.P[sb + "/beta"], self.G[sb + "/gamma"], self.G[sb + "/beta"],
+                                      self.buffers[sb + "/moving_mean"], self.buffers[sb + "/moving_variance"], out=out)
             # tf.concat([f_neighbours, f_xyz]) (RandLANet.py:328,332): both producers write their column block of the concat
             # buffer directly (no concat copy forward, no split copies backward)
             hc = f_pc.shape[1]
             if self.fused_att and lib.ps_op_att_pool_train_supported(K, 2 * hc):
                 # gather_neighbour + concat + att_pooling's core as one kernel per direction: neither the gathered rows nor the concat
                 # buffer nor the gathered half of its gradient exist (the backward scatter-adds into f_pc's gradient itself)
-                f_xyz = self._conv(t, rel, n + "LFAmlp1")
+                f_xyz = locse()
                 f_agg = self._att_split(t, f_pc, idx, f_xyz, n + "LFAatt_pooling_1", B)
                 f_xyz2 = self._conv(t, f_xyz, n + "LFAmlp2")
                 f_agg2 = self._att_split(t, f_agg, idx, f_xyz2, n + "LFAatt_pooling_2", B)
             else:
                 cat1 = torch.empty((B * N * K, 2 * hc), dtype=torch.float32, device=x.device)
-                f_xyz = self._conv(t, rel, n + "LFAmlp1", out=cat1[:, hc:])
+                f_xyz = locse(out=cat1[:, hc:])
                 f_nb = t.gather(f_pc, idx, B, out=cat1[:, :hc])
                 f_agg = self._att(t, t.concat_views(cat1, f_nb, f_xyz), n + "LFAatt_pooling_1", K)
                 cat2 = torch.empty((B * N * K, 2 * hc), dtype=torch.float32, device=x.device)
