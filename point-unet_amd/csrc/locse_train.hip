@@ -25,7 +25,8 @@ struct LocseArgs {
     const float* xyz;    // [B*N, 3]
     const int32_t* idx;  // [B*N, K] cloud-local
     int64_t rows;        // B*N*K
-    int n_cloud, K;
+    int n_cloud, K, kshift;  // kshift = log2 K when K is a power of two, else -1
+    float inv_n;             // 1 / n_cloud
     const float* w;      // [10, H]
     const float* b;      // [H]
     const float* scale;  // [H] gamma * invstd            (apply / backward)
@@ -38,12 +39,18 @@ struct LocseArgs {
     int ldo, lddz;
 };
 
-__device__ __forceinline__ void locse_enc(const LocseArgs& a, int64_t t, float (&e)[10])
+// (row counts are < 2^31 and point counts < 2^24 here -- checked on the host --, so the two divisions of the row index are a shift /
+//  a float reciprocal with one correction instead of 64-bit integer divisions, which cost more than the rest of the row)
+__device__ __forceinline__ void locse_enc(const LocseArgs& a, int64_t t64, float (&e)[10])
 {
-    const int64_t p = t / a.K;
-    const int64_t q = (p / a.n_cloud) * a.n_cloud + a.idx[t];
-    const float cx = a.xyz[3 * p], cy = a.xyz[3 * p + 1], cz = a.xyz[3 * p + 2];
-    const float nx = a.xyz[3 * q], ny = a.xyz[3 * q + 1], nz = a.xyz[3 * q + 2];
+    const unsigned t = (unsigned)t64;
+    const unsigned p = a.kshift >= 0 ? t >> a.kshift : t / (unsigned)a.K;
+    unsigned cb = (unsigned)((float)p * a.inv_n);
+    cb -= (cb * (unsigned)a.n_cloud > p);                    // the estimate is off by at most one
+    cb += ((cb + 1u) * (unsigned)a.n_cloud <= p);
+    const unsigned q = cb * (unsigned)a.n_cloud + (unsigned)a.idx[t];
+    const float cx = a.xyz[3u * p], cy = a.xyz[3u * p + 1], cz = a.xyz[3u * p + 2];
+    const float nx = a.xyz[3u * q], ny = a.xyz[3u * q + 1], nz = a.xyz[3u * q + 2];
     const float rx = cx - nx, ry = cy - ny, rz = cz - nz;
     e[0] = __fsqrt_rn(rx * rx + ry * ry + rz * rz);  // (same expression as ps_op_relative_pos_encoding)
     e[1] = rx; e[2] = ry; e[3] = rz;
@@ -307,8 +314,14 @@ static int locse_launch(ps_context* c, LocseArgs a, int what, float* result)
     return PS_OK;
 }
 
-static int locse_dispatch(ps_context* c, int64_t h, const LocseArgs& a, int what, float* result)
+static int locse_dispatch(ps_context* c, int64_t h, LocseArgs a, int what, float* result)
 {
+    PS_CHECK(a.rows < (1ll << 31) && a.rows / a.K < (1ll << 24), "ps_op_locse_train: %lld rows exceed the 32-bit row / 24-bit point index range",
+             (long long)a.rows);
+    a.kshift = -1;
+    for (int sft = 0; sft < 31; ++sft)
+        if ((1 << sft) == a.K) a.kshift = sft;
+    a.inv_n = 1.0f / (float)a.n_cloud;
     switch (h) {
         case 8: return locse_launch<8>(c, a, what, result);
         case 16: return locse_launch<16>(c, a, what, result);
