@@ -74,6 +74,11 @@ int ps_set_deferred_checks(ps_context* ctx, int on);
  * (SURVEY 8d, config 3).  Activations, gradients, BatchNorm, softmax, loss and Adam stay fp32.  Default off (fp32 MFMA).
  * The fused inference path (ps_randla_forward) is never affected. */
 int ps_set_train_gemm_bf16(ps_context* ctx, int on);
+/* on != 0 (default): ps_op_conv1x1[_ex] runs its large, matrix-pipe-bound fp32 shapes (>= 4096 rows, cin >= 256 and a multiple of 32,
+ * cout a multiple of 128: att_pooling's score products at d_out >= 256 and their input gradients) on v_mfma_f32_32x32x16_bf16 over exact
+ * three-way bfloat16 splits of both operands with fp32 accumulation (csrc/gemm_b3.hip) -- fp32-level error at 2.7 x less matrix-pipe
+ * time; on == 0: the fp32 MFMA for every shape.  Ignored while ps_set_train_gemm_bf16 is on. */
+int ps_set_train_gemm_b3(ps_context* ctx, int on);
 /* Matrix instruction of the fused attentive-pooling kernels of ps_randla_forward at d_out = 64 and 128 (att_pooling,
  * PointSegment/RandLANet.py:388-401, with LocSE and the neighbour gather fused in).  on != 0 (default): v_mfma_f32_32x32x16_bf16
  * over exact three-way bfloat16 splits of the fp32 operands with fp32 accumulation (csrc/attpool32b.hip) -- fp32-level error, 2.7 x

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "ps_version": (ctypes.c_char_p, []),
     "ps_set_train_gemm_bf16": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "ps_set_att_bf16x3": (ctypes.c_int, [c_vp, ctypes.c_int]),
+    "ps_set_train_gemm_b3": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "ps_timing_begin": (ctypes.c_int, [c_vp]),
     "ps_timing_select": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
     "ps_timing_end": (ctypes.c_int, [c_vp, ctypes.POINTER(PsTimingRow), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),

@@ -87,6 +87,7 @@ struct ps_context {
     ps::DevBuf ops_ring[4];  // packed weights of ps_op_conv1x1 (a ring: consecutive calls never repack into the buffer the previous GEMM is still reading)
     int ops_ring_pos = 0;
     bool att_bf16x3 = true;   // ps_set_att_bf16x3: attentive pooling at d = 64 / 128 on bf16 MFMA over three-way splits (attpool32b.hip)
+    bool train_b3 = true;     // ps_set_train_gemm_b3: large fp32 op-level GEMMs on bf16 MFMA over exact three-way splits (gemm_b3.hip)
     bool train_bf16 = false;  // ps_set_train_gemm_bf16: the op-level GEMMs round their operands to bf16 (fp32 accumulate)
     // per-device kernel attributes already raised by this context (dynamic LDS above the default limit)
     bool mid_lds_attr = false;

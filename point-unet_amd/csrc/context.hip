@@ -208,6 +208,13 @@ int ps_set_train_gemm_bf16(ps_context* c, int on)
     return PS_OK;
 }
 
+int ps_set_train_gemm_b3(ps_context* c, int on)
+{
+    PS_CHECK(c != nullptr, "ps_set_train_gemm_b3: ctx is NULL");
+    c->train_b3 = on != 0;
+    return PS_OK;
+}
+
 int ps_set_att_bf16x3(ps_context* c, int on)
 {
     PS_CHECK(c != nullptr, "ps_set_att_bf16x3: ctx is NULL");

@@ -1,0 +1,192 @@
+// gemm_b3.hip -- Y[R, N] (+)= act(X[R, K] . W[K, N] + b) for the large fp32 products of the training step on
+// v_mfma_f32_32x32x16_bf16 over exact three-way bfloat16 splits of both operands (see attpool32b.hip: six piece products per fp32
+// product, fp32 accumulation, fp32-level error).
+//
+// The products in question are att_pooling's score GEMMs at the levels whose attention is not fused (RandLANet.py:394-395,
+// [B*N*K, d] x [d, d], d = 128 / 256 / 512: 47 GFLOP each at batch 8) and their input-gradient twins: 45-55 % of the fp32 MFMA peak in
+// rowgemm.hip, i.e. bound by the matrix pipe, which runs fp32 at 1/16 of the bf16 rate.
+//   * a workgroup owns 128 rows x 128 columns, a wave 32 rows x 128 columns (four accumulator tiles): an activation is read from HBM
+//     once per column panel, by exactly one wave -- straight from global memory, 32 bytes per lane and 16-K chunk, split in registers;
+//   * the weight planes (packed per call by gemm_b3_pack_kernel: the weights change every step) go through LDS, 24 KB per 32-K step,
+//     double buffered, shared by the four waves;
+//   * per wave and step: 48 MFMAs (1 536 cycles) against ~90 VALU (the splits), 24 ds_read_b128, 10 global accesses.
+// Row counts need not be multiples of 128 (clamped loads, predicated stores); K % 32 == 0, N % 128 == 0.
+#include "common.h"
+#include "mfma_tile.h"
+
+namespace ps {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+struct GemmB3Args {
+    const float* x; int ldx;
+    const uint4* wp;    // planes: [K/16][N/32][3][64] uint4
+    const float* bias;  // [N] or nullptr
+    float* y; int ldy;
+    int R, K, N, leaky, accum;
+};
+
+__device__ __forceinline__ void b3_split_pair(float x, float y, unsigned& q1, unsigned& q2, unsigned& q3)
+{
+    const unsigned xu = __float_as_uint(x), yu = __float_as_uint(y);
+    const float xr = x - __uint_as_float(xu & 0xffff0000u), yr = y - __uint_as_float(yu & 0xffff0000u);  // exact
+    const unsigned xru = __float_as_uint(xr), yru = __float_as_uint(yr);
+    const float x3 = xr - __uint_as_float(xru & 0xffff0000u), y3 = yr - __uint_as_float(yru & 0xffff0000u);  // exact, 8 bits
+    q1 = __builtin_amdgcn_perm(yu, xu, 0x07060302u);
+    q2 = __builtin_amdgcn_perm(yru, xru, 0x07060302u);
+    q3 = __builtin_amdgcn_perm(__float_as_uint(y3), __float_as_uint(x3), 0x07060302u);
+}
+struct B3Planes {
+    uint4 p[3];
+};
+__device__ __forceinline__ B3Planes b3_split8(const float4& lo, const float4& hi)
+{
+    B3Planes r;
+    b3_split_pair(lo.x, lo.y, r.p[0].x, r.p[1].x, r.p[2].x);
+    b3_split_pair(lo.z, lo.w, r.p[0].y, r.p[1].y, r.p[2].y);
+    b3_split_pair(hi.x, hi.y, r.p[0].z, r.p[1].z, r.p[2].z);
+    b3_split_pair(hi.z, hi.w, r.p[0].w, r.p[1].w, r.p[2].w);
+    return r;
+}
+__device__ __forceinline__ f32x16 b3_mfma(const uint4& a, const uint4& b, f32x16 acc)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 b3_mfma6(const B3Planes& a, const B3Planes& b, f32x16 acc)
+{
+    acc = b3_mfma(a.p[2], b.p[0], acc);
+    acc = b3_mfma(a.p[0], b.p[2], acc);
+    acc = b3_mfma(a.p[1], b.p[1], acc);
+    acc = b3_mfma(a.p[1], b.p[0], acc);
+    acc = b3_mfma(a.p[0], b.p[1], acc);
+    acc = b3_mfma(a.p[0], b.p[0], acc);
+    return acc;
+}
+
+// W[K, N] (row-major, ldw) -> planes [K/16][N/32][3][64] x 8 bfloat16: lane l of (chunk q, column tile cb) holds
+// W[16 q + 8 (l >> 5) + j][32 cb + (l & 31)], j = 0..7.  One thread per (q, cb, lane).
+__global__ __launch_bounds__(256) void gemm_b3_pack_kernel(const float* __restrict__ w, int ldw, int K, int N, uint4* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int ncb = N / 32;
+    if (i >= (K / 16) * ncb * 64) return;
+    const int lane = i & 63, cb = (i >> 6) % ncb, q = (i >> 6) / ncb;
+    const float* src = w + (size_t)(16 * q + 8 * (lane >> 5)) * ldw + 32 * cb + (lane & 31);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * ldw];
+    const B3Planes p = b3_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+    uint4* dst = out + ((size_t)(q * ncb + cb) * 3) * 64 + lane;
+    dst[0] = p.p[0]; dst[64] = p.p[1]; dst[128] = p.p[2];
+}
+
+__global__ __launch_bounds__(256) void gemm_b3_kernel(GemmB3Args a)
+{
+    // LDS: two buffers of one 32-K step of the workgroup's column panel: [2 chunks][4 column tiles][3 planes][64 lanes] uint4 = 24 KB each
+    __shared__ uint4 Bs[2][2 * 4 * 3 * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hl = lane >> 5, c32 = lane & 31;
+    const int ncb = a.N / 32, panels = a.N / 128;
+    const int panel = blockIdx.x % panels;
+    const int64_t r0 = (int64_t)(blockIdx.x / panels) * 128 + wave * 32;
+    const int steps = a.K / 32;
+    const int row = (int)min<int64_t>(r0 + c32, a.R - 1);  // clamped: rows past the end are computed and not stored
+    const float* xr = a.x + (size_t)row * a.ldx + 8 * hl;
+
+    // a step's B sub-tile in the global image: chunk q = 2 s + u, column tiles 4 panel .. 4 panel + 3 (contiguous: 4 * 3 * 64 uint4)
+    auto bsrc = [&](int s, int i) {  // i in [0, 1536): (u, rest)
+        const int u = i / 768, rest = i - u * 768;
+        return a.wp + ((size_t)((2 * s + u) * ncb + 4 * panel) * 3) * 64 + rest;
+    };
+    uint4 breg[6];
+    float4 areg[4];
+    auto load_b = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) breg[j] = *bsrc(s, j * 256 + threadIdx.x);
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) Bs[buf][j * 256 + threadIdx.x] = breg[j];
+    };
+    auto load_a = [&](int s) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            areg[2 * u] = *reinterpret_cast<const float4*>(xr + 32 * s + 16 * u);
+            areg[2 * u + 1] = *reinterpret_cast<const float4*>(xr + 32 * s + 16 * u + 4);
+        }
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    load_b(0);
+    load_a(0);
+    store_b(0);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const int buf = s & 1;
+        const float4 a0 = areg[0], a1 = areg[1], a2 = areg[2], a3 = areg[3];
+        if (s + 1 < steps) {  // the next step's operands travel under this step's products (two steps ahead was measured slower)
+            load_b(s + 1);
+            load_a(s + 1);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const B3Planes ap = u == 0 ? b3_split8(a0, a1) : b3_split8(a2, a3);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                B3Planes bp;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bp.p[pl] = Bs[buf][((u * 4 + t) * 3 + pl) * 64 + lane];
+                acc[t] = b3_mfma6(ap, bp, acc[t]);
+            }
+        }
+        if (s + 1 < steps) store_b(buf ^ 1);  // (the other buffer: its last readers passed the barrier at the end of step s - 1)
+        __syncthreads();
+    }
+    // accumulator register r of tile t = row (r & 3) + 8 (r >> 2) + 4 hl of the wave's 32, column 128 panel + 32 t + c32
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = 128 * panel + 32 * t + c32;
+        const float bb = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+            if (rr < a.R) {
+                float* dst = a.y + (size_t)rr * a.ldy + col;
+                float v = acc[t][r] + bb;
+                if (a.leaky) v = leaky02(v);
+                if (a.accum) v += *dst;  // (y += act(x . W + b): the op's accumulate epilogue, as rowgemm.hip)
+                *dst = v;
+            }
+        }
+    }
+}
+
+bool gemm_b3_fits(int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx)
+{
+    // K >= 256: measured against rowgemm.hip at batch 8 -- [360k, 256] x [256, 256]: 0.51 vs 0.67 ms, [90k, 512] x [512, 512]: 0.44 vs 0.56 ms;
+    // [1.44M, 128] x [128, 128] (HBM bound: 1.5 GB of rows against 47 GFLOP) is SLOWER here (0.63 vs 0.51 ms: the per-lane 4-byte epilogue)
+    return R >= 4096 && K >= 256 && K % 32 == 0 && N % 128 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && R < (1ll << 31);
+}
+
+size_t gemm_b3_plane_bytes(int64_t K, int64_t N) { return (size_t)K * N * 6; }
+
+int gemm_b3(ps_context* c, const float* x, int64_t ldx, const float* w, const float* bias, int64_t R, int64_t K, int64_t N, int leaky, int accumulate,
+            float* y, int64_t ldy, void* planes)
+{
+    hipLaunchKernelGGL(gemm_b3_pack_kernel, dim3(ceil_div((K / 16) * (N / 32) * 64, 256)), dim3(256), 0, c->stream, w, (int)N, (int)K, (int)N,
+                       static_cast<uint4*>(planes));
+    GemmB3Args a;
+    a.x = x; a.ldx = (int)ldx; a.wp = static_cast<const uint4*>(planes); a.bias = bias; a.y = y; a.ldy = (int)ldy;
+    a.R = (int)R; a.K = (int)K; a.N = (int)N; a.leaky = leaky; a.accum = accumulate ? 1 : 0;
+    const int64_t blocks = ((R + 127) / 128) * (N / 128);
+    hipLaunchKernelGGL(gemm_b3_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+}  // namespace ps

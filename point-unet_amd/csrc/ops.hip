@@ -229,6 +229,14 @@ extern "C" int ps_op_conv1x1_ex(ps_context* c, const float* x, int64_t ldx, cons
     PS_CHECK(R >= 0 && cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout, "ps_op_conv1x1: bad shape");
     if (!R) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
+    if (c->train_b3 && !c->train_bf16 && gemm_b3_fits(R, cin, cout, x, ldx)) {
+        // matrix-pipe bound shapes (att_pooling's score products at d >= 128): bf16 MFMA over exact splits, fp32-level error
+        ps::DevBuf& pw = c->ops_ring[c->ops_ring_pos];
+        c->ops_ring_pos = (c->ops_ring_pos + 1) & 3;
+        PS_TRY(pw.reserve(gemm_b3_plane_bytes(cin, cout)));
+        Stage st(c, "op_conv1x1", 2);
+        return gemm_b3(c, x, ldx, w, b, R, cin, cout, leaky, accumulate, y, ldy, pw.as<void>());
+    }
     PackedLinear L;
     L.cin = (int)cin; L.cout = (int)cout; L.leaky = leaky; L.accum = accumulate ? 1 : 0;
     L.ks = (L.cin + 3) / 4;

@@ -538,6 +538,43 @@ def test_fused_locse_branch_against_float64_autograd():
         assert errs["dW"] <= 2e-5 and errs["dgamma"] <= 2e-5 and errs["dbeta"] <= 2e-5 and errs["db"] <= 2e-5, (h, errs)
 
 
+def test_large_fp32_gemms_on_split_bf16_mfma():
+    """ps_op_conv1x1_ex at the matrix-pipe-bound shapes of the training step (>= 4096 rows, cin >= 256, cout % 128 == 0) runs on bf16 MFMA
+    over exact three-way splits (csrc/gemm_b3.hip).  Against a float64 product: error no larger than the fp32-MFMA path's on the same
+    inputs (+ 1e-6 of the output scale) -- measured 3e-7 both; ragged row count, strided input / output, bias + LeakyReLU, accumulate."""
+    import ctypes
+    import torch
+    from point_unet_amd import _lib, runtime
+    L, ctx = _lib.lib(), runtime.default_context(0)
+    h = ctx.handle
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(21)
+    try:
+        for R, K, N, leaky, acc in [(4096, 256, 128, 0, 0), (5001, 256, 256, 1, 0), (4500, 256, 256, 0, 1), (4097, 512, 512, 0, 0), (9000, 320, 256, 1, 1)]:
+            xw = torch.randn(R, K + 8, generator=g).cuda()
+            x = xw[:, 4:K + 4]
+            W = (torch.randn(K, N, generator=g) / K ** 0.5).cuda()
+            b = torch.randn(N, generator=g).cuda()
+            y0 = torch.randn(R, N + 4, generator=g).cuda()
+            ref = x.double() @ W.double() + b.double()
+            if leaky:
+                ref = torch.where(ref >= 0, ref, 0.2 * ref)
+            if acc:  # y += act(x . W + b)
+                ref = ref + y0[:, :N].double()
+            errs = {}
+            for on in (1, 0):
+                _lib.check(L.ps_set_train_gemm_b3(h, on))
+                y = y0.clone()
+                _lib.check(L.ps_op_conv1x1_ex(h, p(x), K + 8, p(W), p(b), R, K, N, leaky, acc, p(y), N + 4))
+                errs[on] = ((y[:, :N].double() - ref).abs().max() / ref.abs().max()).item()
+                assert torch.equal(y[:, N:], y0[:, N:])
+            print(R, K, N, errs)
+            assert errs[1] <= errs[0] + 1e-6 and errs[1] <= 2e-6, (R, K, N, errs)
+    finally:
+        _lib.check(L.ps_set_train_gemm_b3(h, 1))
+    torch.cuda.synchronize()
+
+
 def test_row_strided_variants_match_the_dense_ops():
     """ps_op_*_ex on column blocks of a wider tensor (the training step's concat buffers) give what the dense entry points give
     on contiguous copies; conv1x1_ex with accumulate adds in the epilogue."""
