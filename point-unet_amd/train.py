@@ -85,18 +85,26 @@ class Tape:
         self.grads = {}
 
     # ---- ops -------------------------------------------------------------------------------------------------------
-    def linear(self, x, W, b, gW, gb, transposed=False):
-        """y = x . W (+ b).  W is [cin,cout], or [cout,cin] when transposed (conv2d_transpose kernels)."""
+    def linear(self, x, W, b, gW, gb, transposed=False, into=None):
+        """y = x . W (+ b).  W is [cin,cout], or [cout,cin] when transposed (conv2d_transpose kernels).
+        into: an existing [R, cout] tensor of the tape that the product is ADDED to (the GEMM's accumulate epilogue); the result is that
+        same tensor, and its gradient is handed on unchanged to the op that produced it."""
         Wm = W.t().contiguous() if transposed else W
         x_in = x  # the tensor the tape knows (gradients are keyed by identity)
         x = _rowmajor(x)
         R, cin = x.shape
         ldx = x.stride(0)
         cout = Wm.shape[1]
-        y = torch.empty((R, cout), dtype=torch.float32, device=x.device)
-        _lib.check(self.L.ps_op_conv1x1_ex(self.h, _p(x), ldx, _p(Wm), _p(b), R, cin, cout, 0, 0, _p(y), cout))
+        if into is None:
+            y = torch.empty((R, cout), dtype=torch.float32, device=x.device)
+            _lib.check(self.L.ps_op_conv1x1_ex(self.h, _p(x), ldx, _p(Wm), _p(b), R, cin, cout, 0, 0, _p(y), cout))
+        else:
+            y = into
+            _lib.check(self.L.ps_op_conv1x1_ex(self.h, _p(x), ldx, _p(Wm), _p(b), R, cin, cout, 0, 1, _p(y), y.stride(0)))
 
         def bw(dy):
+            if into is not None:
+                self.grads[id(into)] = dy  # d(into + x.W)/d(into) = 1: the producer of `into` (earlier on the tape) gets the same gradient
             dy = _rowmajor(dy)
             lddy = dy.stride(0)
             pgb = _p(gb) if gb is not None else None
@@ -471,6 +479,16 @@ class Trainer:
         agg = t.attpool_split(f_src, idx, f_xyz, self.P[name + "fc/kernel"], self.G[name + "fc/kernel"], B)
         return self._conv(t, agg, name + "mlp")
 
+    def _att_pre(self, t, f_src, idx, fcat, f_xyz, name, K, B):
+        """att_pooling with the score product in the pre-product form of the inference kernels: fset . Wfc = (f . Wfc[:h])[idx] + f_xyz . Wfc[h:]
+        -- the [N*K]-row GEMMs (forward, input gradient, weight gradient) shrink to half their K, the other half runs on N rows.  Used where
+        those GEMMs are bound by the matrix pipe (d >= 256); fset (the values of the weighted sum) is still the concat buffer."""
+        W, gW = self.P[name + "fc/kernel"], self.G[name + "fc/kernel"]
+        h = f_src.shape[1]
+        s = t.gather(t.linear(f_src, W[:h], None, gW[:h], None), idx, B)
+        s = t.linear(f_xyz, W[h:], None, gW[h:], None, into=s)
+        return self._conv(t, t.softpool(fcat, s, K), name + "mlp")
+
     def _att(self, t, fcat, name, K):
         W, gW = self.P[name + "fc/kernel"], self.G[name + "fc/kernel"]
         if self.fused_att and t.L.ps_op_att_pool_train_supported(K, fcat.shape[1]):
@@ -524,12 +542,15 @@ class Trainer:
             else:
                 cat1 = torch.empty((B * N * K, 2 * hc), dtype=torch.float32, device=x.device)
                 f_xyz = locse(out=cat1[:, hc:])
+                pre = (not self.mlp_bf16) and 2 * hc >= 256  # (d = 128: measured slower, 58.1 vs 57.0 ms -- HBM bound there; bf16 mode: its yardstick rounds the operands of the ONE d x d product)
                 f_nb = t.gather(f_pc, idx, B, out=cat1[:, :hc])
-                f_agg = self._att(t, t.concat_views(cat1, f_nb, f_xyz), n + "LFAatt_pooling_1", K)
+                fcat1 = t.concat_views(cat1, f_nb, f_xyz)
+                f_agg = self._att_pre(t, f_pc, idx, fcat1, f_xyz, n + "LFAatt_pooling_1", K, B) if pre else self._att(t, fcat1, n + "LFAatt_pooling_1", K)
                 cat2 = torch.empty((B * N * K, 2 * hc), dtype=torch.float32, device=x.device)
                 f_xyz2 = self._conv(t, f_xyz, n + "LFAmlp2", out=cat2[:, hc:])
                 f_nb2 = t.gather(f_agg, idx, B, out=cat2[:, :hc])
-                f_agg2 = self._att(t, t.concat_views(cat2, f_nb2, f_xyz2), n + "LFAatt_pooling_2", K)
+                fcat2 = t.concat_views(cat2, f_nb2, f_xyz2)
+                f_agg2 = self._att_pre(t, f_agg, idx, fcat2, f_xyz2, n + "LFAatt_pooling_2", K, B) if pre else self._att(t, fcat2, n + "LFAatt_pooling_2", K)
             a = self._conv(t, f_agg2, n + "mlp2", act=False)
             b = self._conv(t, feature, n + "shortcut", act=False)
             f_enc = t.add_lrelu(a, b)
