@@ -5,11 +5,12 @@
 // The products in question are att_pooling's score GEMMs at the levels whose attention is not fused (RandLANet.py:394-395,
 // [B*N*K, d] x [d, d], d = 128 / 256 / 512: 47 GFLOP each at batch 8) and their input-gradient twins: 45-55 % of the fp32 MFMA peak in
 // rowgemm.hip, i.e. bound by the matrix pipe, which runs fp32 at 1/16 of the bf16 rate.
-//   * a workgroup owns 128 rows x 128 columns, a wave 32 rows x 128 columns (four accumulator tiles): an activation is read from HBM
+//   * a workgroup owns 256 rows x 128 columns, a wave 64 rows x 128 columns (2 x 4 accumulator tiles: a weight fragment read from LDS
+//     feeds two row tiles -- one row tile per wave was bound by the LDS reads): an activation is read from HBM
 //     once per column panel, by exactly one wave -- straight from global memory, 32 bytes per lane and 16-K chunk, split in registers;
 //   * the weight planes (packed per call by gemm_b3_pack_kernel: the weights change every step) go through LDS, 24 KB per 32-K step,
 //     double buffered, shared by the four waves;
-//   * per wave and step: 48 MFMAs (1 536 cycles) against ~90 VALU (the splits), 24 ds_read_b128, 10 global accesses.
+//   * per wave and step: 96 MFMAs (3 072 cycles) against ~180 VALU (the splits), 24 ds_read_b128, 14 global accesses.
 // Row counts need not be multiples of 128 (clamped loads, predicated stores); K % 32 == 0, N % 128 == 0.
 #include "common.h"
 #include "mfma_tile.h"
@@ -81,26 +82,35 @@ __global__ __launch_bounds__(256) void gemm_b3_pack_kernel(const float* __restri
     dst[0] = p.p[0]; dst[64] = p.p[1]; dst[128] = p.p[2];
 }
 
+// RT = 32-row tiles per wave: a weight fragment read from LDS feeds RT x 6 MFMAs (RT = 1 was LDS-bandwidth bound: 24 KB of fragments
+// per wave and step against 1 536 cycles of products, twelve waves per CU)
+constexpr int kB3RT = 2;
+
+template <bool ACC>
 __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmB3Args a)
 {
+    constexpr int RT = kB3RT;
     // LDS: two buffers of one 32-K step of the workgroup's column panel: [2 chunks][4 column tiles][3 planes][64 lanes] uint4 = 24 KB each
     __shared__ uint4 Bs[2][2 * 4 * 3 * 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hl = lane >> 5, c32 = lane & 31;
     const int ncb = a.N / 32, panels = a.N / 128;
     const int panel = blockIdx.x % panels;
-    const int64_t r0 = (int64_t)(blockIdx.x / panels) * 128 + wave * 32;
+    const int64_t r0 = (int64_t)(blockIdx.x / panels) * (128 * RT) + wave * (32 * RT);
     const int steps = a.K / 32;
-    const int row = (int)min<int64_t>(r0 + c32, a.R - 1);  // clamped: rows past the end are computed and not stored
-    const float* xr = a.x + (size_t)row * a.ldx + 8 * hl;
-
+    const float* xr[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int row = (int)min<int64_t>(r0 + 32 * i + c32, a.R - 1);  // clamped: rows past the end are computed and not stored
+        xr[i] = a.x + (size_t)row * a.ldx + 8 * hl;
+    }
     // a step's B sub-tile in the global image: chunk q = 2 s + u, column tiles 4 panel .. 4 panel + 3 (contiguous: 4 * 3 * 64 uint4)
     auto bsrc = [&](int s, int i) {  // i in [0, 1536): (u, rest)
         const int u = i / 768, rest = i - u * 768;
         return a.wp + ((size_t)((2 * s + u) * ncb + 4 * panel) * 3) * 64 + rest;
     };
     uint4 breg[6];
-    float4 areg[4];
+    float4 areg[RT][4];
     auto load_b = [&](int s) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) breg[j] = *bsrc(s, j * 256 + threadIdx.x);
@@ -111,16 +121,20 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmB3Args a)
     };
     auto load_a = [&](int s) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            areg[2 * u] = *reinterpret_cast<const float4*>(xr + 32 * s + 16 * u);
-            areg[2 * u + 1] = *reinterpret_cast<const float4*>(xr + 32 * s + 16 * u + 4);
-        }
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                areg[i][2 * u] = *reinterpret_cast<const float4*>(xr[i] + 32 * s + 16 * u);
+                areg[i][2 * u + 1] = *reinterpret_cast<const float4*>(xr[i] + 32 * s + 16 * u + 4);
+            }
     };
-    f32x16 acc[4];
+    f32x16 acc[RT][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 
     load_b(0);
     load_a(0);
@@ -128,48 +142,67 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmB3Args a)
     __syncthreads();
     for (int s = 0; s < steps; ++s) {
         const int buf = s & 1;
-        const float4 a0 = areg[0], a1 = areg[1], a2 = areg[2], a3 = areg[3];
-        if (s + 1 < steps) {  // the next step's operands travel under this step's products (two steps ahead was measured slower)
+        B3Planes ap[RT][2];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            ap[i][0] = b3_split8(areg[i][0], areg[i][1]);
+            ap[i][1] = b3_split8(areg[i][2], areg[i][3]);
+        }
+        if (s + 1 < steps) {  // the next step's operands travel under this step's products
             load_b(s + 1);
             load_a(s + 1);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const B3Planes ap = u == 0 ? b3_split8(a0, a1) : b3_split8(a2, a3);
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 B3Planes bp;
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) bp.p[pl] = Bs[buf][((u * 4 + t) * 3 + pl) * 64 + lane];
-                acc[t] = b3_mfma6(ap, bp, acc[t]);
+#pragma unroll
+                for (int i = 0; i < RT; ++i) acc[i][t] = b3_mfma6(ap[i][u], bp, acc[i][t]);
             }
-        }
         if (s + 1 < steps) store_b(buf ^ 1);  // (the other buffer: its last readers passed the barrier at the end of step s - 1)
         __syncthreads();
     }
-    // accumulator register r of tile t = row (r & 3) + 8 (r >> 2) + 4 hl of the wave's 32, column 128 panel + 32 t + c32
+    // accumulator register r of tile (i, t) = row 32 i + (r & 3) + 8 (r >> 2) + 4 hl of the wave's rows, column 128 panel + 32 t + c32
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int col = 128 * panel + 32 * t + c32;
-        const float bb = a.bias ? a.bias[col] : 0.f;
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-            if (rr < a.R) {
-                float* dst = a.y + (size_t)rr * a.ldy + col;
-                float v = acc[t][r] + bb;
-                if (a.leaky) v = leaky02(v);
-                if (a.accum) v += *dst;  // (y += act(x . W + b): the op's accumulate epilogue, as rowgemm.hip)
-                *dst = v;
+        for (int t = 0; t < 4; ++t) {
+            const int col = 128 * panel + 32 * t + c32;
+            const float bb = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float old[8];
+                if constexpr (ACC) {  // eight reads of the tile in flight before the first store (stores to y would otherwise fence them)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int r = 8 * half + q;
+                        const int64_t rr = min<int64_t>(r0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hl, a.R - 1);
+                        old[q] = a.y[(size_t)rr * a.ldy + col];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = 8 * half + q;
+                    const int64_t rr = r0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                    if (rr < a.R) {
+                        float v = acc[i][t][r] + bb;
+                        if (a.leaky) v = leaky02(v);
+                        if constexpr (ACC) v += old[q];  // (y += act(x . W + b): the op's accumulate epilogue, as rowgemm.hip)
+                        a.y[(size_t)rr * a.ldy + col] = v;
+                    }
+                }
             }
         }
-    }
 }
 
 bool gemm_b3_fits(int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx)
 {
-    // K >= 256: measured against rowgemm.hip at batch 8 -- [360k, 256] x [256, 256]: 0.51 vs 0.67 ms, [90k, 512] x [512, 512]: 0.44 vs 0.56 ms;
-    // [1.44M, 128] x [128, 128] (HBM bound: 1.5 GB of rows against 47 GFLOP) is SLOWER here (0.63 vs 0.51 ms: the per-lane 4-byte epilogue)
+    // K >= 256: measured against rowgemm.hip (profiles/tools/gemm_b3_ab.py; plain / accumulate epilogue) -- [360k, 256] x [256, 256]: 0.46 / 0.50 vs
+    // 0.67 / 0.83 ms, [90k, 512] x [512, 512]: 0.43 / 0.44 vs 0.56 / 0.67 ms, [90k, 256] x [256, 512]: 0.24 / 0.27 vs 0.31 / 0.40 ms;
+    // K = 128 ([1.44M, 128] x [128, 128], HBM bound: 1.5 GB of rows against 47 GFLOP) ties or loses (0.63 / 0.70 vs 0.60 / 0.66 ms)
     return R >= 4096 && K >= 256 && K % 32 == 0 && N % 128 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && R < (1ll << 31);
 }
 
@@ -183,8 +216,10 @@ int gemm_b3(ps_context* c, const float* x, int64_t ldx, const float* w, const fl
     GemmB3Args a;
     a.x = x; a.ldx = (int)ldx; a.wp = static_cast<const uint4*>(planes); a.bias = bias; a.y = y; a.ldy = (int)ldy;
     a.R = (int)R; a.K = (int)K; a.N = (int)N; a.leaky = leaky; a.accum = accumulate ? 1 : 0;
-    const int64_t blocks = ((R + 127) / 128) * (N / 128);
-    hipLaunchKernelGGL(gemm_b3_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
+    const int64_t rows_wg = 128 * kB3RT;
+    const int64_t blocks = ((R + rows_wg - 1) / rows_wg) * (N / 128);
+    if (a.accum) hipLaunchKernelGGL(gemm_b3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL(gemm_b3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
