@@ -40,9 +40,27 @@ def run(kind):
     t0 = time.perf_counter()
     for i in range(steps):
         one(i)
+    t_sub = time.perf_counter() - t0  # host time to enqueue everything (the GPU may still be far behind)
     pipe.synchronize(); torch.cuda.synchronize()
+    run.submit_ms = t_sub / steps * 1e3
     return (time.perf_counter() - t0) / steps * 1e3
 
 
 for kind in ("both", "pyramid", "network", "both"):
-    print("%-8s lanes %d: %.4f ms/step" % (kind, lanes, run(kind)), flush=True)
+    ms = run(kind)
+    print("%-8s lanes %d: %.4f ms/step (host enqueue %.4f ms/step)" % (kind, lanes, ms, run.submit_ms), flush=True)
+
+# pure host cost of the two calls: the GPU is idle when each one is issued (synchronised before), the call itself is timed
+ln = pipe.lanes[0]
+tb = tn = 0.0
+for i in range(50):
+    x, f = clouds[i % 8]
+    with torch.cuda.stream(ln.stream):
+        torch.cuda.synchronize(); pipe.synchronize()
+        t0 = time.perf_counter(); build_pyramid(x, cfg, ctx=ln.ctx, out=ln.pyramid); t1 = time.perf_counter()
+        torch.cuda.synchronize(); pipe.synchronize()
+        t2 = time.perf_counter(); ln.net.inference({"pyramid": ln.pyramid, "features": f}); t3 = time.perf_counter()
+    if i >= 10:
+        tb += t1 - t0; tn += t3 - t2
+pipe.synchronize()
+print("host cost per call with an idle GPU: build_pyramid %.3f ms, inference %.3f ms" % (tb / 40 * 1e3, tn / 40 * 1e3))
