@@ -70,8 +70,8 @@ def algorithmic_costs(cfg, n0, B):
     n = level_sizes(n0, cfg.sub_sampling_ratio[:L])
     c = {}
     nq = sum(n[:L])
-    c["knn_search_k"] = dict(flops=0, bytes=B * (nq * 12 + nq * K * 4))
-    c["knn_search_1nn"] = dict(flops=0, bytes=B * (nq * 12 + nq * 4))
+    # one launch: the K-NN self queries and the 1-NN up-sampling queries of every level (12 B query + 4 K B of indices out each)
+    c["knn_search"] = dict(flops=0, bytes=B * (nq * 12 + nq * K * 4) + B * (nq * 12 + nq * 4))
     c["kdtree_build"] = dict(flops=0, bytes=B * (sum(n) * 12 + sum(n) * 16 + 2 * sum(n) * 16))
     c["pyramid_slices"] = dict(flops=0, bytes=B * 2 * (sum(n[:L]) * 12 + sum(n[1:]) * K * 4))
     c["fc0"] = dict(flops=2 * B * n0 * cfg.in_channels * 8, bytes=B * n0 * (cfg.in_channels + 8) * 4)

@@ -82,10 +82,8 @@ struct WindowStack {
 };
 
 template <int K>
-__global__ __launch_bounds__(256) void knn_kernel(const KnnJob* __restrict__ jobs)
+__device__ __forceinline__ void knn_body(const KnnJob& job, float* win)
 {
-    __shared__ float win[kWin * 5 * 256];
-    const KnnJob& job = jobs[blockIdx.y];
     // XCD-aware order: workgroups go to the 8 XCDs round-robin, and queries are in leaf order, so workgroup b takes the
     // (b / 8)-th block of the (b % 8)-th eighth of the queries -- every XCD's L2 then serves one contiguous eighth of the tree's
     // leaves (plus the shared top levels) instead of all of it.
@@ -195,6 +193,24 @@ __global__ __launch_bounds__(256) void knn_kernel(const KnnJob* __restrict__ job
     }
 }
 
+template <int K>
+__global__ __launch_bounds__(256) void knn_kernel(const KnnJob* __restrict__ jobs)
+{
+    __shared__ float win[kWin * 5 * 256];
+    knn_body<K>(jobs[blockIdx.y], win);
+}
+
+// The pyramid's two searches in ONE launch: jobs [0, n_first) are the K-NN self queries, the rest the 1-NN up-sampling queries.  The
+// K-NN search ends with a long tail (its duration is its slowest wave's; the chip holds all of its waves at once), and a second launch
+// cannot start under it: here the 1-NN workgroups are dispatched as the K-NN ones retire.
+template <int K>
+__global__ __launch_bounds__(256) void knn_pair_kernel(const KnnJob* __restrict__ jobs, int n_first)
+{
+    __shared__ float win[kWin * 5 * 256];
+    if ((int)blockIdx.y < n_first) knn_body<K>(jobs[blockIdx.y], win);
+    else knn_body<1>(jobs[blockIdx.y], win);
+}
+
 __global__ void widen_kernel(const int32_t* __restrict__ in, int64_t* __restrict__ out, size_t count)
 {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -216,6 +232,28 @@ static int launch_knn(ps_context* c, const KnnJob* d_jobs, int n_jobs, int max_n
 #undef PS_KCASE
         default:
             set_error("ps_knn: K=%d is not a compiled size (1..16, 20, 24, 32, 48, 64)", K);
+            return PS_EINVAL;
+    }
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+static int launch_knn_pair(ps_context* c, const KnnJob* d_jobs, int n_first, int n_jobs, int max_nq, int K)
+{
+    if (K == 1) return launch_knn(c, d_jobs, n_jobs, max_nq, 1);
+    dim3 grid((ceil_div(max_nq, 256) + 7) & ~7, n_jobs);
+    if (grid.x == 0 || n_jobs == 0) return PS_OK;
+    switch (K) {
+#define PS_KCASE(k)                                                                            \
+    case k:                                                                                    \
+        hipLaunchKernelGGL(knn_pair_kernel<k>, grid, dim3(256), 0, c->stream, d_jobs, n_first); \
+        break;
+        PS_KCASE(2) PS_KCASE(3) PS_KCASE(4) PS_KCASE(5) PS_KCASE(6) PS_KCASE(7) PS_KCASE(8)
+        PS_KCASE(9) PS_KCASE(10) PS_KCASE(11) PS_KCASE(12) PS_KCASE(13) PS_KCASE(14) PS_KCASE(15) PS_KCASE(16)
+        PS_KCASE(20) PS_KCASE(24) PS_KCASE(32) PS_KCASE(48) PS_KCASE(64)
+#undef PS_KCASE
+        default:
+            set_error("ps_pyramid_build: K=%d is not a compiled size (1..16, 20, 24, 32, 48, 64)", K);
             return PS_EINVAL;
     }
     PS_HIP(hipGetLastError());
@@ -451,12 +489,8 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
     int32_t flag[3] = {0, 0, 0};
     {
         {
-            Stage st(c, "knn_search_k", 1);
-            PS_TRY(launch_knn(c, dj, (int)n_self, max_nq, K));
-        }
-        {
-            Stage st(c, "knn_search_1nn", 1);
-            PS_TRY(launch_knn(c, dj + n_self, (int)(jobs.size() - n_self), max_nq, 1));
+            Stage st(c, "knn_search", 1);  // K-NN self queries and 1-NN up-sampling queries of every level, one launch
+            PS_TRY(launch_knn_pair(c, dj, (int)n_self, (int)jobs.size(), max_nq, (int)K));
         }
         {
             Stage st(c, "pyramid_slices", 1);

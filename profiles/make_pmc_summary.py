@@ -35,7 +35,7 @@ for k in sorted(f, key=lambda k: -(f[k] + w.get(k, 0))):
                      raw_FETCH_SIZE_KiB=f[k], raw_WRITE_SIZE_KiB=w.get(k, 0.0)))
 here = os.path.dirname(os.path.abspath(__file__))
 json.dump(rows, open(os.path.join(here, "%s_pmc_per_kernel.json" % tag), "w"), indent=1)
-stage_of = {"knn_search_k": "ps::knn_kernel<16>", "knn_search_1nn": "ps::knn_kernel<1>"}
+stage_of = {"knn_search": "ps::knn_pair_kernel<16>"}
 out = {}
 for stage, frag in stage_of.items():
     for r in rows:
