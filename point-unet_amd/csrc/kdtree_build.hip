@@ -5,8 +5,8 @@
 //
 // The recursion is replaced by task queues over three tiers of node size (kernel boundaries are the only global sync):
 //   init kernels     points -> (x,y,z,index) records; root bounding boxes by block reduction + ordered-uint atomics
-//   chunked levels   nodes above kMid points: every pass of a level (min/max, counts, two Hoare sweeps as
-//                    count -> rank -> swap, emit) is one small kernel over 2 048-record chunks spread over the chip
+//   chunked levels   nodes above kMid points: every pass of a level (classify + counts, then rank -> swap for each of the two Hoare
+//                    sweeps; five in all, see "chunked levels" below) is one small kernel over 2 048-record chunks spread over the chip
 //   mid kernel       nodes of kSmall+1 .. kMid points: ONE workgroup loads the node into LDS and advances level by level
 //                    over all of its live segments at once, with __syncthreads() only
 //   flat kernel      nodes of <= kSmall points: one workgroup, one thread per point position; every round advances all live
@@ -19,7 +19,7 @@
 // children's tight extents on the split axis, which the parent can compute at split time as max{v < cut-side} /
 // min{v > cut-side} (the children's bounding boxes are never needed otherwise).
 //
-// Bound: launch latency for the chunked levels (~60 us per level), LDS / barrier latency below; HBM traffic is a few
+// Bound: launch latency for the chunked levels (~28 us per level: five dependent launches), instruction issue below; HBM traffic is a few
 // passes over 16 B per point per chunked level plus one read and one write per LDS tier.
 #include "kdtree_build.h"
 #include "wave_ops.h"
