@@ -21,6 +21,9 @@ int ps_debug_kdtree_device(ps_context* ctx, const float* support, int64_t n, int
                            float* pts, int32_t* root_depth, float* bbox);
 /* MFMA B-fragment packing of a row-major W[cin,cout] (csrc/rowgemm.h). */
 int ps_debug_pack_weights(const float* W, int cin, int cout, int ntb, float* out);
+/* Three-plane bfloat16 image of a row-major W[cin,cout] for the split-bf16 attention kernels (csrc/attpool32b.hip: pack_b3):
+ * out = uint16 [cout/32][cin/16][3 planes][64 lanes][8]. */
+int ps_debug_pack_b3(const float* W, int cin, int cout, uint16_t* out);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
 #include "kdtree_build.h"
 #include "kdtree_host.h"
 #include "rowgemm.h"
+#include "attpool.h"
 
 #include <cfloat>
 
@@ -70,6 +71,13 @@ extern "C" int ps_debug_pack_weights(const float* W, int cin, int cout, int ntb,
 {
     PS_CHECK(W && out && (ntb == 1 || ntb == 2 || ntb == 4), "ps_debug_pack_weights: bad argument");
     pack_weights(W, cin, cout, ntb, out);
+    return PS_OK;
+}
+
+extern "C" int ps_debug_pack_b3(const float* W, int cin, int cout, uint16_t* out)
+{
+    PS_CHECK(W && out && cin > 0 && cin % 32 == 0 && cout > 0 && cout % 32 == 0, "ps_debug_pack_b3: bad argument");
+    pack_b3(W, cin, cout, out);
     return PS_OK;
 }
 

@@ -32,7 +32,7 @@ def test_version_and_error_strings(lib):
 
 def test_debug_doors_live_in_their_own_library(lib, dbg):
     """The ps_debug_* test doors are not in the product library (and not in its header): csrc/debug_hooks.h / libpointseg_debug.so."""
-    for name in ("ps_debug_knn_host", "ps_debug_kdtree_host", "ps_debug_kdtree_device", "ps_debug_pack_weights"):
+    for name in ("ps_debug_knn_host", "ps_debug_kdtree_host", "ps_debug_kdtree_device", "ps_debug_pack_weights", "ps_debug_pack_b3"):
         assert not hasattr(lib, name) and hasattr(dbg, name)
     assert "ps_debug" not in open(os.path.join(ROOT, "include", "pointseg.h")).read()
     assert dbg.ps_debug_knn_host(None, None, 1, 1, 1, 16, None) != 0 and b"NULL" in lib.ps_last_error()

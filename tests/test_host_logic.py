@@ -87,6 +87,33 @@ def test_weight_packing_is_the_mfma_b_fragment_order(dbg, lib):
                         assert out[c, s, l, j] == Wp[s * 4 + (l >> 4), (c * ntb + j) * 16 + (l & 15)]
 
 
+def test_split_bf16_planes_add_up_exactly_and_follow_the_accumulator_order(dbg, lib):
+    """pack_b3 (csrc/attpool32b.hip): every fp32 weight is stored as three bfloat16 pieces whose sum IS the weight (8 + 8 + 8
+    significant bits, exact subtractions), in the K order of an operand that comes out of a transposed product's accumulators: chunk q,
+    lane half g, element j <-> channel 32 (q >> 1) + (r & 3) + 8 (r >> 2) + 4 g with r = 8 (q & 1) + j."""
+    rng = np.random.default_rng(4)
+    for cin, cout in [(32, 32), (64, 128), (128, 64)]:
+        W = (rng.standard_normal((cin, cout)) * np.exp(rng.uniform(-20, 20, (cin, cout)))).astype(np.float32)
+        W[0, 0], W[1, 1] = 0.0, -1.0
+        nq, cbs = cin // 16, cout // 32
+        out = np.zeros(cbs * nq * 3 * 64 * 8, np.uint16)
+        assert dbg.ps_debug_pack_b3(W.ctypes.data, cin, cout, out.ctypes.data) == 0
+        planes = (out.astype(np.uint32) << 16).view(np.float32).reshape(cbs, nq, 3, 64, 8)
+        seen = np.zeros((cin, cout), np.int32)
+        for cb in range(cbs):
+            for q in range(nq):
+                for l in range(64):
+                    for j in range(8):
+                        r = 8 * (q & 1) + j
+                        k = 32 * (q >> 1) + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+                        col = 32 * cb + (l & 31)
+                        p1, p2, p3 = (np.float64(planes[cb, q, pl, l, j]) for pl in range(3))
+                        assert p1 + p2 + p3 == np.float64(W[k, col]), (cin, cout, k, col)
+                        assert abs(p2) <= abs(p1) * 2.0 ** -7 + 1e-45 and abs(p3) <= abs(p1) * 2.0 ** -15 + 1e-45
+                        seen[k, col] += 1
+        assert np.all(seen == 1)
+
+
 def _replay_device_plan(cfg, blob, xyz, nbr, pool, up, feats):
     """NumPy float64 replay of csrc/randla.hip's launch plan from the folded blob: same layer order, the
     G = f.Wfc[:h] pre-product, [mlp2;shortcut] as one GEMM over the concatenated K axis."""
