@@ -281,15 +281,17 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
 // LDS tile (they serve both as the A operand and as the values of the weighted sum).  The pre-product formulation above
 // gathers 3 x as many bytes per neighbour ([f | G] rows); at levels 0-2 that gather traffic, not the MFMA pipe, was
 // the limit (rocprofv3 FETCH_SIZE 617 / 242 / 89 MB per launch against 92 / 92 / 46 MB of feature rows).
-template <int D, int STAGE, int KN, int WAVES>
+// PTS points per wave iteration (two at K = 16: the per-iteration scalar / address / wait overhead -- a quarter of the ~200 wave
+// instructions per point of this issue-bound kernel -- is paid once per pair); row tile rt belongs to point rt / (KN / 16).
+template <int D, int STAGE, int KN, int WAVES, int PTS>
 __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
 {
-    constexpr int H = D / 2, RT = KN / 16, PA = D + 2, PT = H + 2;
+    constexpr int H = D / 2, RPP = KN / 16, RT = PTS * RPP, ROWS = PTS * KN, PA = D + 2, PT = H + 2;
     constexpr int NTB_H = ntb_for(H), NTB_D = ntb_for(D);
     constexpr int NT_H = (H + 15) / 16, NT_D = D / 16;
     constexpr int CB_H = (NT_H + NTB_H - 1) / NTB_H, CB_D = (NT_D + NTB_D - 1) / NTB_D;
     constexpr int KS_H = (H + 3) / 4, KS_D = D / 4;
-    constexpr int PER_WAVE = KN * PA + (STAGE == 2 ? KN * PT : 0);
+    constexpr int PER_WAVE = ROWS * PA + (STAGE == 2 ? ROWS * PT : 0);
     using bfH = typename BFrag<NTB_H>::type;
     using bfD = typename BFrag<NTB_D>::type;
 
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, c16 = lane & 15;
     float* A = smem + wave * PER_WAVE;
-    float* T1 = A + KN * PA;
+    float* T1 = A + ROWS * PA;
 
     // Every B fragment and bias this wave will ever need, loaded ONCE: at d <= 32 the three weight matrices are a few dozen
     // registers, and re-reading them per point put an exposed L2 round trip in front of every MFMA group.
@@ -331,17 +333,27 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
     // (the kernel is VALU-issue bound -- one VALU instruction per SIMD every four cycles, ~180 of them per point, half of them index
     //  arithmetic --: no integer division for a single cloud, 32-bit element offsets from uniform bases)
     const bool one_cloud = a.n_total == a.n_cloud;
-    PointWalk walk(a.n_total, WAVES, wave);
-    for (int t = walk.t; t < walk.end; t += walk.stride) {
-        const unsigned p = one_cloud ? (a.order ? (unsigned)a.order[t] : (unsigned)t) : (unsigned)walk_point(a, t);
-        const unsigned base = one_cloud ? 0u : (p / (unsigned)a.n_cloud) * (unsigned)a.n_cloud;
-        const float* cp = a.xyz + 3u * p;
-        const float cx = cp[0], cy = cp[1], cz = cp[2];
+    // PTS consecutive points (of a contiguous eighth of the leaf order per XCD, as PointWalk) per wave iteration
+    const int per_xcd = ((((a.n_total + 7) >> 3) + PTS - 1) / PTS) * PTS;
+    const int w_end = min(a.n_total, (int)((blockIdx.x & 7) + 1) * per_xcd), w_slots = gridDim.x >> 3;
+    for (int t = (int)(blockIdx.x & 7) * per_xcd + ((int)(blockIdx.x >> 3) * WAVES + wave) * PTS; t < w_end; t += w_slots * WAVES * PTS) {
+        unsigned p[PTS], base[PTS];
+        float ctr[PTS][3];
+#pragma unroll
+        for (int i = 0; i < PTS; ++i) {
+            const int ti = min(t + i, w_end - 1);  // (a pair's second point past the end: recomputes the first, stores nothing)
+            p[i] = one_cloud ? (a.order ? (unsigned)a.order[ti] : (unsigned)ti) : (unsigned)walk_point(a, ti);
+            base[i] = one_cloud ? 0u : (p[i] / (unsigned)a.n_cloud) * (unsigned)a.n_cloud;
+            const float* cp = a.xyz + 3u * p[i];
+            ctr[i][0] = cp[0]; ctr[i][1] = cp[1]; ctr[i][2] = cp[2];
+        }
         int nb[RT];
         float a0[RT], a1[RT], a2[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            nb[rt] = (int)(base + (unsigned)a.idx[p * (unsigned)KN + (unsigned)(rt * 16 + c16)]);
+            const int pi = rt / RPP;
+            const float cx = ctr[pi][0], cy = ctr[pi][1], cz = ctr[pi][2];
+            nb[rt] = (int)(base[pi] + (unsigned)a.idx[p[pi] * (unsigned)KN + (unsigned)((rt % RPP) * 16 + c16)]);
             const float* np = a.xyz + 3u * (unsigned)nb[rt];
             const float nx = np[0], ny = np[1], nz = np[2];
             const float rx = cx - nx, ry = cy - ny, rz = cz - nz;
@@ -352,7 +364,8 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
         }
         // ---- neighbour features -> A[:, 0:H)  (16-byte loads, one row = H*4 contiguous bytes) ----
         {
-            constexpr int Q = H / 4, TOT = KN * Q;
+            constexpr int Q = H / 4, TOT = ROWS * Q;
+            static_assert(RT <= 2, "att_direct: one or two row tiles per iteration");
 #pragma unroll
             for (int e0 = 0; e0 < TOT; e0 += 64) {
                 const int e = e0 + lane;
@@ -451,24 +464,27 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
 #pragma unroll
             for (int j = 0; j < NTB_D; ++j) {
                 const int col = (cb * NTB_D + j) * 16 + c16;
-                float m = acc[0][j][0];
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
+                for (int pi = 0; pi < PTS; ++pi) {
+                    float m = acc[pi * RPP][j][0];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[rt][j][r]);
-                m = xor_max_lds(m);
-                float ssum = 0.f, num = 0.f;
+                    for (int rt = pi * RPP; rt < (pi + 1) * RPP; ++rt)
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
+                        for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[rt][j][r]);
+                    m = xor_max_lds(m);
+                    float ssum = 0.f, num = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(acc[rt][j][r] - m);  // the Wfc image carries log2(e) (randla.hip)
-                        ssum += e;
-                        num = __builtin_fmaf(e, A[(rt * 16 + g * 4 + r) * PA + col], num);
-                    }
-                ssum = xor_sum_lds(ssum);
-                num = xor_sum_lds(num);
-                if (g == 0) a.agg[p * (unsigned)D + (unsigned)col] = num * __builtin_amdgcn_rcpf(ssum);
+                    for (int rt = pi * RPP; rt < (pi + 1) * RPP; ++rt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = __builtin_amdgcn_exp2f(acc[rt][j][r] - m);  // the Wfc image carries log2(e) (randla.hip)
+                            ssum += e;
+                            num = __builtin_fmaf(e, A[(rt * 16 + g * 4 + r) * PA + col], num);
+                        }
+                    ssum = xor_sum_lds(ssum);
+                    num = xor_sum_lds(num);
+                    if (g == 0 && t + pi < w_end) a.agg[p[pi] * (unsigned)D + (unsigned)col] = num * __builtin_amdgcn_rcpf(ssum);
+                }
             }
         }
         wave_lds_sync();  // the tiles are overwritten by the next point
@@ -479,13 +495,14 @@ template <int D, int STAGE, int KN>
 static int launch_att_direct(ps_context* c, const AttArgs& a)
 {
     constexpr int H = D / 2;
-    constexpr size_t per_wave = ((size_t)KN * (D + 2) + (STAGE == 2 ? (size_t)KN * (H + 2) : 0)) * sizeof(float);
+    constexpr int PTS = KN == 16 ? 2 : 1;
+    constexpr size_t per_wave = ((size_t)PTS * KN * (D + 2) + (STAGE == 2 ? (size_t)PTS * KN * (H + 2) : 0)) * sizeof(float);
     constexpr int WAVES = per_wave * 4 <= 160 * 1024 ? 4 : (per_wave * 2 <= 160 * 1024 ? 2 : 1);
     static_assert(per_wave * WAVES <= 160 * 1024, "attention tile does not fit the LDS");
     const size_t smem = per_wave * WAVES;
-    auto kern = att_direct_kernel<D, STAGE, KN, WAVES>;
+    auto kern = att_direct_kernel<D, STAGE, KN, WAVES, PTS>;
     if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    const int blocks = (std::min(ceil_div(a.n_total, WAVES), 256 * 8) + 7) & ~7;  // a multiple of 8 (PointWalk)
+    const int blocks = (std::min(ceil_div(a.n_total, WAVES * PTS), 256 * 8) + 7) & ~7;  // a multiple of 8 (one eighth of the points per XCD)
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
     PS_HIP(hipGetLastError());
     return PS_OK;
