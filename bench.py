@@ -579,6 +579,20 @@ def main():
             sub["include_pcie"] = {"ms_per_step": 1e3 * t_pcie / args.steps, "points_per_s": B * n0 * args.steps / t_pcie, "steps": args.steps,
                                    "what": "every step also copies its cloud (xyz + features) from pinned host memory and its logits back, on the "
                                            "lane's stream (this rank only; the service rate -- never the headline value)"}
+        if not args.no_sub_results and not args.att_fp32_mfma and not args.include_pcie:
+            # the same timed region with attentive pooling on the fp32 MFMA (the default runs it on bf16 MFMA over exact three-way splits
+            # of the fp32 operands: same accuracy, see csrc/attpool32b.hip) -- the A/B number next to the headline, this rank only
+            for cx in contexts:
+                cx.set_att_bf16x3(False)
+            for _ in range(max(4, args.warmup // 2)):
+                step()
+            sync()
+            t_f32, _ = timed_region(step, args.steps, sync, None)
+            for cx in contexts:
+                cx.set_att_bf16x3(True)
+            sub["att_fp32_mfma"] = {"ms_per_step": 1e3 * t_f32 / args.steps, "points_per_s": B * n0 * args.steps / t_f32, "steps": args.steps,
+                                    "what": "attentive pooling at d_out >= 64 on the fp32 MFMA instead of bf16 MFMA over exact three-way splits "
+                                            "(ps_set_att_bf16x3(ctx, 0)); both forms measure 4e-6 on the logits against the float64 restatement"}
 
     if rank == 0:
         costs = algorithmic_costs(cfg, n0, B)
@@ -679,6 +693,7 @@ def main():
             "serial_ms_per_cloud": serial_ms,
             "serial": sub.get("serial"),
             "include_pcie": sub.get("include_pcie"),
+            "att_fp32_mfma": sub.get("att_fp32_mfma"),
             "device_ms_per_step": round(dev_ms, 4),
             "split": split,
             "algorithmic": {"gflop_per_step": total_cost["flops"] / 1e9, "gbyte_per_step": total_cost["bytes"] / 1e9},
