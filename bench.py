@@ -288,7 +288,7 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
     ctx = runtime.default_context(local_rank)
     params = weights.init_params(cfg, seed=2)
     tr = Trainer(cfg, params=params, device=local_rank, ctx=ctx, keep_prob=0.5, sync_bn=world > 1 and not args.local_bn,
-                 mlp_dtype="bf16" if args.bf16_mlp else "fp32", fused_att=not args.no_fused_att, fused_locse=not args.no_fused_locse)
+                 mlp_dtype="bf16" if args.bf16_mlp else "fp32", fused_att=not args.no_fused_att, fused_locse=not args.no_fused_locse, fused_convbn=args.fused_convbn)
     d_xyz, d_feats, d_lab = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
     pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
     seen = ranks_seen(dist, "cuda" if args.dist_backend == "nccl" else "cpu") if dist is not None else 1
@@ -379,6 +379,7 @@ def main():
                          "PCIe-inclusive rate DESIGN.md quotes next to the headline (which keeps inputs resident in HBM)")
     ap.add_argument("--bf16-mlp", action="store_true", help="train mode: shared-MLP GEMMs on bf16 operands with fp32 accumulate (BASELINE configs[2])")
     ap.add_argument("--no-fused-att", action="store_true", help="train mode: the op-by-op attentive pooling at every level (A/B of csrc/attpool_train.hip)")
+    ap.add_argument("--fused-convbn", action="store_true", help="train mode: LFA mlp2 in the recompute form (csrc/smallconv_train.hip; measured slower, off by default)")
     ap.add_argument("--no-fused-locse", action="store_true", help="train mode: the op-by-op LocSE branch (A/B of csrc/locse_train.hip)")
     ap.add_argument("--local-bn", action="store_true", help="train mode, N > 1: per-GPU BatchNorm statistics instead of statistics shared by all ranks")
     ap.add_argument("--clouds", type=int, default=8, help="distinct resident clouds every rank rotates through (one per step)")

@@ -316,6 +316,26 @@ int ps_op_locse_train_apply(ps_context* ctx, const float* xyz, const int32_t* id
 int ps_op_locse_train_bwd(ps_context* ctx, const float* xyz, const int32_t* idx, int64_t B, int64_t N, int64_t K, const float* w,
                           const float* b, int64_t h, const float* scale, const float* beta, const float* mean, const float* invstd,
                           const float* dz, int64_t lddz, float* sums);
+/* conv2d(C -> C, bias) + batch_normalization(training=True) + LeakyReLU on [R, C] rows without the pre-BatchNorm product or its gradient in
+ * memory (LFA mlp2 of building_block, RandLANet.py:331; csrc/smallconv_train.hip): y = x . w + b is recomputed from 16-row tiles of x on
+ * the fp32 MFMA wherever it is needed.  w [C,C], C in {8,16,32,64} (ps_op_conv_bn_train_supported); CP = max(C, 16).
+ *   _sums     : sums = sum y [CP] | sum y^2 [CP] | sum x [CP] in float64 (the caller forms mean / variance; SyncBN: all-reduce first)
+ *   _apply    : out[r, :] = LeakyReLU((y - mean) scale + beta), scale = gamma invstd
+ *   _bwd_sums : one pass over dz: S1 [CP] | S2 [CP] | XS [CP] | A [CP,CP] | G [CP,CP] with xh = (y - mean) invstd, g = dz lrelu',
+ *               S1 = sum g, S2 = sum g xh, XS = sum xh, A = x^T g, G = x^T xh; then dgamma = S2, dbeta = S1,
+ *               dw = gamma invstd (A - (sum x) x S1/M - G . S2/M), M = rows of all ranks
+ *   _bwd_apply: dx (+)= (gamma invstd (g - m1 - xh m2)) . w^T with m1 = S1/M, m2 = S2/M
+ * Deterministic (per-workgroup partials merged in a fixed order). */
+int ps_op_conv_bn_train_supported(int64_t C);
+int ps_op_conv_bn_train_sums(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t C, double* sums);
+int ps_op_conv_bn_train_apply(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t C,
+                              const float* mean, const float* scale, const float* beta, float* out, int64_t ldo);
+int ps_op_conv_bn_train_bwd_sums(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t C,
+                                 const float* mean, const float* invstd, const float* scale, const float* beta, const float* dz,
+                                 int64_t lddz, float* sums);
+int ps_op_conv_bn_train_bwd_apply(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t C,
+                                  const float* mean, const float* invstd, const float* scale, const float* beta, const float* m1,
+                                  const float* m2, const float* dz, int64_t lddz, int accumulate, float* dx, int64_t lddx);
 /* backward of random_sample (max over K); ties share the gradient evenly like tf.reduce_max; dfeature accumulates */
 int ps_op_random_sample_bwd(ps_context* ctx, const float* dout, const float* out, const float* feature,
                             const int32_t* pool_idx, int64_t B, int64_t N, int64_t M, int64_t K, int64_t d,

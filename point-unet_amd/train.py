@@ -220,6 +220,69 @@ class Tape:
         self.ops.append((y, bw))
         return y
 
+    def conv_bn_act(self, x, W, b, gW, gb, gamma, beta, ggamma, gbeta, mov_mean, mov_var, out=None):
+        """z = LeakyReLU(BN_train(x . W + b)) for W [C, C] on [R, C] rows without storing x . W or its gradient (ps_op_conv_bn_train_*):
+        the product is recomputed from x in the statistics pass, the apply pass and the two backward passes.  The [C, C]-sized
+        finishing arithmetic of the weight gradient is done here."""
+        x_in = x
+        x = _rowmajor(x)
+        R, C = x.shape
+        CP = max(C, 16)
+        dev = x.device
+        sync = self.sync
+        R_total = R if sync is None else R * sync.get_world_size()
+        sums = torch.empty(3 * CP, dtype=torch.float64, device=dev)
+        _lib.check(self.L.ps_op_conv_bn_train_sums(self.h, _p(x), x.stride(0), _p(W), _p(b), R, C, _p(sums)))
+        if sync is not None:
+            sync.all_reduce(sums)
+        mean64 = sums[:C] / R_total
+        var = (sums[CP:CP + C] / R_total - mean64 * mean64).clamp_min_(0.0).float()
+        mean = mean64.float().contiguous()
+        sumx = sums[2 * CP:2 * CP + C].float()  # (of all ranks under SyncBN; only its local part is needed: see bw)
+        invstd = torch.rsqrt(var + BN_EPS).contiguous()
+        scale = (gamma.reshape(-1) * invstd).contiguous()
+        shift = beta.reshape(-1).contiguous()
+        y = torch.empty((R, C), dtype=torch.float32, device=dev) if out is None else out
+        _lib.check(self.L.ps_op_conv_bn_train_apply(self.h, _p(x), x.stride(0), _p(W), _p(b), R, C, _p(mean), _p(scale), _p(shift), _p(y), y.stride(0)))
+        mov_mean.mul_(BN_MOMENTUM).add_(mean, alpha=1 - BN_MOMENTUM)
+        mov_var.mul_(BN_MOMENTUM).add_(var, alpha=1 - BN_MOMENTUM)
+        if sync is not None:  # this rank's own sum of x for its own weight gradient
+            local = torch.empty(3 * CP, dtype=torch.float64, device=dev)
+            _lib.check(self.L.ps_op_conv_bn_train_sums(self.h, _p(x), x.stride(0), _p(W), _p(b), R, C, _p(local)))
+            sumx = local[2 * CP:2 * CP + C].float()
+
+        def bw(dz):
+            dzc = _rowmajor(dz)
+            acc = torch.empty(3 * CP + 2 * CP * CP, dtype=torch.float32, device=dev)
+            _lib.check(self.L.ps_op_conv_bn_train_bwd_sums(self.h, _p(x), x.stride(0), _p(W), _p(b), R, C, _p(mean), _p(invstd), _p(scale), _p(shift),
+                                                           _p(dzc), dzc.stride(0), _p(acc)))
+            S1, S2, XS = acc[:C], acc[CP:CP + C], acc[2 * CP:2 * CP + C]
+            A = acc[3 * CP:3 * CP + CP * CP].view(CP, CP)[:C, :C]
+            G = acc[3 * CP + CP * CP:].view(CP, CP)[:C, :C]
+            ggamma.copy_(S2.view_as(ggamma))
+            gbeta.copy_(S1.view_as(gbeta))
+            tot = torch.stack([S1, S2])
+            if sync is not None:
+                sync.all_reduce(tot)
+            m1, m2 = (tot[0] / R_total).contiguous(), (tot[1] / R_total).contiguous()
+            k = gamma.reshape(-1) * invstd
+            gW.copy_((k[None, :] * (A - sumx[:, None] * m1[None, :] - G * m2[None, :])).view_as(gW))
+            gb.copy_((k * (S1 - R * m1 - XS * m2)).view_as(gb))
+            if getattr(x_in, "requires_grad_flag", False):
+                have = self.grads.get(id(x_in))
+                if have is not None and have.dim() == 2 and have.stride(1) == 1:
+                    _lib.check(self.L.ps_op_conv_bn_train_bwd_apply(self.h, _p(x), x.stride(0), _p(W), _p(b), R, C, _p(mean), _p(invstd), _p(scale),
+                                                                    _p(shift), _p(m1), _p(m2), _p(dzc), dzc.stride(0), 1, _p(have), have.stride(0)))
+                else:
+                    dx = torch.empty((R, C), dtype=torch.float32, device=dev)
+                    _lib.check(self.L.ps_op_conv_bn_train_bwd_apply(self.h, _p(x), x.stride(0), _p(W), _p(b), R, C, _p(mean), _p(invstd), _p(scale),
+                                                                    _p(shift), _p(m1), _p(m2), _p(dzc), dzc.stride(0), 0, _p(dx), C))
+                    self.accum(x_in, dx)
+
+        y.requires_grad_flag = True
+        self.ops.append((y, bw))
+        return y
+
     def gather(self, x, idx, B, out=None):
         """x [B*N, d], idx [B, M, K] -> [B*M*K, d]; out: optional column block of a wider tensor that receives the rows"""
         N, d = x.shape[0] // B, x.shape[1]
@@ -382,7 +445,7 @@ class Trainer:
     """Parameters (flat fp32 buffer + named views), Adam state and the train step."""
 
     def __init__(self, config, params=None, device=0, seed=0, learning_rate=None, class_weights=None, keep_prob=0.5, ctx=None, sync_bn=False,
-                 mlp_dtype="fp32", ignored_label_inds=None, fused_att=True, fused_locse=True):
+                 mlp_dtype="fp32", ignored_label_inds=None, fused_att=True, fused_locse=True, fused_convbn=False):
         """sync_bn: with a `dist` passed to train_step, BatchNorm uses the statistics of all ranks' rows, which makes "W GPUs x
         one cloud" numerically the same step as "one GPU x W clouds" (SURVEY 8e); off = per-GPU statistics.
         mlp_dtype: "fp32" (default) or "bf16" -- BASELINE configs[2]'s "bf16 MLPs": the shared-MLP GEMMs (forward, input gradient,
@@ -394,6 +457,11 @@ class Trainer:
         # LocSE branch (relative_pos_encoding -> conv 10->h -> BatchNorm -> LeakyReLU) recomputed from coordinates and indices instead of
         # materialised (csrc/locse_train.hip).  Not in the bf16-MLP mode: its weight gradient is defined on rounded operands of the GEMM
         self.fused_locse = bool(fused_locse) and not self.mlp_bf16
+        # LFA mlp2 (conv c->c + BatchNorm + LeakyReLU on [N*K] rows) with the pre-BatchNorm product recomputed instead of stored
+        # (csrc/smallconv_train.hip); same restriction.  OFF by default: 8 passes instead of 14, but its 16-row MFMA tile kernels are
+        # issue bound and measured SLOWER than the streaming kernels they replace (batch 8: +0.7 / +0.2 / +1.0 ms with c = 8 / 32 / 64
+        # alone, 58.8 vs 56.9 ms with all three) -- correct (tests/test_gpu_train.py) and kept as the starting point for wider tiles
+        self.fused_convbn = bool(fused_convbn) and not self.mlp_bf16
         self.sync_bn = bool(sync_bn)
         self.cfg = config
         self.device = torch.device("cuda", device)
@@ -475,6 +543,17 @@ class Trainer:
                          self.buffers[s + "/moving_variance"], act, out=out)
         return y
 
+    def _conv_bn_square(self, t, x, scope, out=None):
+        """conv (c -> c) + BatchNorm + LeakyReLU: the recompute form where it is compiled (c in 8 / 16 / 32 / 64), else the three ops"""
+        W = self.P[scope + "/weights"]
+        if not (self.fused_convbn and W.shape[0] == W.shape[1] and t.L.ps_op_conv_bn_train_supported(W.shape[0])
+                and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0):
+            return self._conv(t, x, scope, out=out)
+        s = scope + "/batch_normalization"
+        return t.conv_bn_act(x, W, self.P[scope + "/biases"], self.G[scope + "/weights"], self.G[scope + "/biases"], self.P[s + "/gamma"],
+                             self.P[s + "/beta"], self.G[s + "/gamma"], self.G[s + "/beta"], self.buffers[s + "/moving_mean"],
+                             self.buffers[s + "/moving_variance"], out=out)
+
     def _att_split(self, t, f_src, idx, f_xyz, name, B):
         agg = t.attpool_split(f_src, idx, f_xyz, self.P[name + "fc/kernel"], self.G[name + "fc/kernel"], B)
         return self._conv(t, agg, name + "mlp")
@@ -537,7 +616,7 @@ class Trainer:
                 # buffer nor the gathered half of its gradient exist (the backward scatter-adds into f_pc's gradient itself)
                 f_xyz = locse()
                 f_agg = self._att_split(t, f_pc, idx, f_xyz, n + "LFAatt_pooling_1", B)
-                f_xyz2 = self._conv(t, f_xyz, n + "LFAmlp2")
+                f_xyz2 = self._conv_bn_square(t, f_xyz, n + "LFAmlp2")
                 f_agg2 = self._att_split(t, f_agg, idx, f_xyz2, n + "LFAatt_pooling_2", B)
             else:
                 cat1 = torch.empty((B * N * K, 2 * hc), dtype=torch.float32, device=x.device)
@@ -547,7 +626,7 @@ class Trainer:
                 fcat1 = t.concat_views(cat1, f_nb, f_xyz)
                 f_agg = self._att_pre(t, f_pc, idx, fcat1, f_xyz, n + "LFAatt_pooling_1", K, B) if pre else self._att(t, fcat1, n + "LFAatt_pooling_1", K)
                 cat2 = torch.empty((B * N * K, 2 * hc), dtype=torch.float32, device=x.device)
-                f_xyz2 = self._conv(t, f_xyz, n + "LFAmlp2", out=cat2[:, hc:])
+                f_xyz2 = self._conv_bn_square(t, f_xyz, n + "LFAmlp2", out=cat2[:, hc:])
                 f_nb2 = t.gather(f_agg, idx, B, out=cat2[:, :hc])
                 fcat2 = t.concat_views(cat2, f_nb2, f_xyz2)
                 f_agg2 = self._att_pre(t, f_agg, idx, fcat2, f_xyz2, n + "LFAatt_pooling_2", K, B) if pre else self._att(t, fcat2, n + "LFAatt_pooling_2", K)

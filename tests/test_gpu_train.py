@@ -575,6 +575,54 @@ def test_large_fp32_gemms_on_split_bf16_mfma():
     torch.cuda.synchronize()
 
 
+def test_fused_square_conv_bn_branch_against_float64_autograd():
+    """ps_op_conv_bn_train_* (conv c->c + BatchNorm(train) + LeakyReLU with the pre-BatchNorm product recomputed, csrc/smallconv_train.hip)
+    through Tape.conv_bn_act against torch float64 autograd: output, batch statistics, dx, dW, db, dgamma, dbeta.  c = 8 / 16 / 32 / 64,
+    ragged row count, strided input and output, input gradient written fresh and accumulated into an existing one."""
+    import torch
+    from point_unet_amd import runtime
+    from point_unet_amd.train import Tape, BN_EPS
+    ctx = runtime.default_context(0)
+    g = torch.Generator().manual_seed(9)
+    for C, R in ((8, 10007), (16, 4099), (32, 5003), (64, 3001)):
+        wide_in = torch.randn(R, C + 8, generator=g).cuda()
+        x = wide_in[:, 4:C + 4]
+        x.requires_grad_flag = True
+        W = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+        b = (0.1 * torch.randn(C, generator=g)).cuda()
+        gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+        gW, gb, gg, gbt = torch.zeros_like(W), torch.zeros_like(b), torch.zeros_like(gamma), torch.zeros_like(beta)
+        mm, mv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+        dz = torch.randn(R, C, generator=g).cuda()
+        Xd = x.double().clone().requires_grad_(True)
+        Wd, bd, gd, btd = [v.double().clone().requires_grad_(True) for v in (W, b, gamma, beta)]
+        yy = Xd @ Wd + bd
+        mean, var = yy.mean(0), yy.var(0, unbiased=False)
+        z = torch.nn.functional.leaky_relu((yy - mean) / torch.sqrt(var + BN_EPS) * gd + btd, 0.2)
+        (z * dz.double()).sum().backward()
+        for prior in (False, True):
+            t = Tape(ctx, None)
+            wide_out = torch.zeros(R, 2 * C).cuda()
+            y = t.conv_bn_act(x, W, b, gW, gb, gamma, beta, gg, gbt, mm.clone(), mv.clone(), out=wide_out[:, C:])
+            extra = torch.randn(R, C, generator=g).cuda()
+            if prior:
+                t.grads[id(x)] = extra.clone()
+            t.grads[id(y)] = dz
+            for tt, bw in reversed(t.ops):
+                gr = t.grads.pop(id(tt), None)
+                if gr is not None:
+                    bw(gr)
+            dx = t.grads[id(x)]
+            torch.cuda.synchronize()
+            want_dx = Xd.grad + (extra.double() if prior else 0)
+            rel = lambda a, r: (a.double() - r).abs().max().item() / r.abs().max().item()  # noqa: E731
+            errs = dict(out=rel(wide_out[:, C:], z), dx=rel(dx, want_dx), dW=rel(gW, Wd.grad), dgamma=rel(gg, gd.grad), dbeta=rel(gbt, btd.grad),
+                        db=(gb.double() - bd.grad).abs().max().item() / Wd.grad.abs().max().item())
+            print(C, prior, errs)
+            assert errs["out"] <= 2e-6 and errs["dx"] <= 2e-5 and errs["dW"] <= 2e-5 and errs["dgamma"] <= 2e-5 and errs["dbeta"] <= 2e-5 and errs["db"] <= 2e-5, (C, errs)
+            assert torch.all(wide_out[:, :C] == 0)
+
+
 def test_row_strided_variants_match_the_dense_ops():
     """ps_op_*_ex on column blocks of a wider tensor (the training step's concat buffers) give what the dense entry points give
     on contiguous copies; conv1x1_ex with accumulate adds in the epilogue."""
