@@ -391,8 +391,8 @@ __global__ __launch_bounds__(WAVES * 64) void att32s_kernel(Att32bArgs a)
     static_assert(NB_H == 1, "att32s: one transposed block per wave");
     const Planes W1 = load_planes(a.w1, wave, lane);  // this wave's LocSE block: resident for the whole kernel
     const f32x16 seed1 = seed(a.b1, wave);
-    constexpr int PD = NQ < 4 ? NQ : 4;                // score-weight chunks in flight per block
-    constexpr int PD2 = STAGE == 2 ? (NQ < 8 ? NQ : 8) : 1;  // mlp2-weight chunks in flight
+    constexpr int PD = D >= 512 ? 4 : 2;                // score-weight chunks in flight per block (measured: 2 at d = 256, 4 at d = 512)
+    constexpr int PD2 = STAGE == 2 ? (D >= 512 ? 4 : 8) : 1;  // mlp2-weight chunks in flight (measured: all 8 at d = 256, 4 at d = 512)
     const int cbA = wave, cbB = wave + WAVES;
     for (int t0 = t_first; t0 < t_end; t0 += t_step) {
         int pp[PPT];
