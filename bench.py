@@ -287,7 +287,7 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
     labels = rng.integers(0, cfg.num_classes, (B, n0)).astype(np.int32)
     ctx = runtime.default_context(local_rank)
     params = weights.init_params(cfg, seed=2)
-    tr = Trainer(cfg, params=params, device=local_rank, ctx=ctx, keep_prob=0.5, sync_bn=world > 1 and not args.local_bn,
+    tr = Trainer(cfg, params=params, device=local_rank, ctx=ctx, keep_prob=0.5, sync_bn=dist is not None and not args.local_bn,
                  mlp_dtype="bf16" if args.bf16_mlp else "fp32", fused_att=not args.no_fused_att, fused_locse=not args.no_fused_locse, fused_convbn=args.fused_convbn)
     d_xyz, d_feats, d_lab = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
     pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)

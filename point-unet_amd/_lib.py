@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpointseg_hip.so")
 PS_MAX_LAYERS = 8
 c_f32p = ctypes.POINTER(ctypes.c_float)
 c_i32p = ctypes.POINTER(ctypes.c_int32)
-ctypes.c_int64p = ctypes.POINTER(ctypes.c_int64)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
 c_vp = ctypes.c_void_p
 
 
@@ -64,7 +64,7 @@ PROTOTYPES = {
     "ps_pyramid_build": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, c_i32p, ctypes.c_int32,
                                         ctypes.POINTER(PsPyramid)]),
     "ps_grid_subsample": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, ctypes.c_int64, c_vp, ctypes.c_int64, ctypes.c_float,
-                                         ctypes.c_int64p, c_vp, c_vp, c_vp]),
+                                         c_i64p, c_vp, c_vp, c_vp]),
     "ps_randla_create": (ctypes.c_int, [c_vp, ctypes.POINTER(PsRandlaConfig), ctypes.POINTER(c_vp)]),
     "ps_randla_destroy": (ctypes.c_int, [c_vp]),
     "ps_randla_weight_count": (ctypes.c_int64, [c_vp]),

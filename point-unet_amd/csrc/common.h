@@ -100,6 +100,8 @@ struct ps_context {
     uint64_t builds = 0;          // ps_pyramid_build calls on this context so far (error messages name the failing one)
     uint64_t flag_serial[8] = {}; // which build each pending slot belongs to
     int flag_slot = 0;
+    int sticky_rc = 0;            // a failed deferred check found while reusing its slot: reported by the next ps_synchronize
+    std::string sticky_msg;
     hipEvent_t flag_ev[8] = {};   // recorded behind the copy into each slot: reusing a slot waits for THAT copy, not for the stream
     std::vector<char> host_ring[8];  // host staging kept alive behind asynchronous uploads
     int ring_pos = 0;

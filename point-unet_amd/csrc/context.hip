@@ -74,6 +74,12 @@ int ps_context::check_deferred()
         const int r = check_flag_slot(s);
         if (r != PS_OK) rc = r;
     }
+    if (sticky_rc != PS_OK) {  // the oldest failure wins: it was found first (ps_pyramid_build, slot reuse)
+        ps::set_error("%s", sticky_msg.c_str());
+        rc = sticky_rc;
+        sticky_rc = PS_OK;
+        sticky_msg.clear();
+    }
     return rc;
 }
 

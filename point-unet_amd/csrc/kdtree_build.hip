@@ -267,13 +267,14 @@ struct BlockRed {
 
 // Stragglers: a node that is still above kMid points after the chunked levels (lopsided bounding-box-midpoint splits: very
 // unbalanced clouds, dense clusters).  One workgroup takes the node and finishes EVERYTHING above kMid points below it depth
-// first: after a split it keeps one big child and parks the other on a stack in LDS; children of <= kMid points go to the
+// first: after a split it keeps its SMALLER big child and parks the larger one on a stack in LDS; children of <= kMid points go to the
 // mid / small queues of the kernels that follow.  One launch therefore completes the top of every tree however unbalanced the
 // cloud is -- there is no "unfinished build" state for the host to detect and repair, which is what makes ps_pyramid_build
 // safe to run without host synchronisation (deferred checks): the searches and the network that are enqueued right behind
-// it always see complete trees and write every index.  Stack entries are disjoint ranges of more than kMid points inside
-// the node, so kStragglerStack of them cover a 2^25-point tree with room to spare.
-constexpr int kStragglerStack = 96;
+// it always see complete trees and write every index.  Continuing with the smaller child halves the node in hand at
+// every push, so at most log2(n / kMid) <= 12 entries are ever parked for a 2^25-point tree; 32 leave room to spare (overflow
+// still sets flags[1]).
+constexpr int kStragglerStack = 32;
 
 __device__ __forceinline__ void push_small_task(const BuildQueues& Q, const BuildTask& t)
 {
@@ -451,17 +452,27 @@ __global__ __launch_bounds__(kBigThreads) void build_level_kernel(const BuildTre
         link_to_parent(t, k, id);
         int sp = s_sp;
         bool have = false;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (kids[s].r - kids[s].l <= kMid)
-                push_small_task(Q, kids[s]);
-            else if (!have) {
-                s_cur = kids[s];  // carry on with this child
-                have = true;
-            } else if (sp < kStragglerStack)
-                s_stack[sp++] = kids[s];
+        const int n0 = kids[0].r - kids[0].l, n1 = kids[1].r - kids[1].l;
+        if (n0 > kMid && n1 > kMid) {
+            // both children are still big: carry on with the SMALLER one and park the larger -- every parked node is then at least
+            // as large as everything handled before it is popped, so the stack never holds more than log2(n / kMid) entries
+            const int small = n0 <= n1 ? 0 : 1;
+            s_cur = kids[small];
+            have = true;
+            if (sp < kStragglerStack)
+                s_stack[sp++] = kids[small ^ 1];
             else
                 Q.flags[1] = 1;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (kids[s].r - kids[s].l <= kMid)
+                    push_small_task(Q, kids[s]);
+                else {
+                    s_cur = kids[s];  // carry on with the one big child
+                    have = true;
+                }
+            }
         }
         if (!have) {
             if (sp > 0)

@@ -515,9 +515,15 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
             if (!ev) PS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             if (c->pending_mask & (1u << c->flag_slot)) {
                 // the slot still holds the status words of the build eight calls ago: wait for THAT copy (long done), not for
-                // the stream -- a stream synchronisation here would serialise the host with the GPU every eighth cloud
+                // the stream -- a stream synchronisation here would serialise the host with the GPU every eighth cloud.  A failure
+                // it reports is remembered in the context and raised by ps_synchronize: this build's slot, serial and event must
+                // line up with the caller's submission count whatever the old build did
                 PS_HIP(hipEventSynchronize(ev));
-                PS_TRY(c->check_flag_slot(c->flag_slot));
+                const int stale_rc = c->check_flag_slot(c->flag_slot);
+                if (stale_rc != PS_OK && c->sticky_rc == PS_OK) {  // kept for ps_synchronize (the caller's submit loop never sees it)
+                    c->sticky_rc = stale_rc;
+                    c->sticky_msg = ps_last_error();
+                }
             }
             PS_HIP(hipMemcpyAsync(c->h_flags + 4 * c->flag_slot, plan.d_flags, 12, hipMemcpyDeviceToHost, c->stream));
             PS_HIP(hipEventRecord(ev, c->stream));

@@ -135,6 +135,56 @@ def test_full_size_config2_properties(oracle):
     assert np.abs(got - enc0).max() <= TOL
 
 
+def test_full_size_config5_properties(oracle):
+    """BASELINE configs[4] at its full size: 262 144-point cloud, K = 32, 4 input channels (xyz + one CT value, runPancreas.py:118,125),
+    2 classes, features handed over as float16, int32 indices.  Like configs[1] above the float64 oracle cannot run the whole cloud,
+    so: (1) the pyramid the forward ran on equals the oracle's, index for index (all five levels); (2) the float16 hand-over equals
+    the fp32 path fed the same rounded values, bit for bit; (3) the head re-evaluated on the host from the tapped last decoder
+    activation; (4) fc0 and the whole level-0 dilated_res_block (K = 32 neighbour sets of all 262 144 points) against the oracle."""
+    import torch
+    from conftest import brats_cloud
+    from oracle import randla_oracle as ro
+    from point_unet_amd import weights
+    from point_unet_amd.helper_tool import ConfigBraTS
+    from point_unet_amd.RandLANet import Network
+    from point_unet_amd.pyramid import build_pyramid
+
+    class cfg(ConfigBraTS):
+        k_n, num_classes, in_channels = 32, 2, 4
+
+    n0 = 262144
+    xyz = brats_cloud(n0, 0)[None]
+    f16 = np.concatenate([xyz, np.random.default_rng(1).standard_normal((1, n0, 1)).astype(np.float32)], -1).astype(np.float16)
+    params = weights.init_params(cfg, seed=2, randomize_bn=True)
+    net = Network(cfg, params=params)
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    logits = net.inference({"pyramid": pyr, "features": torch.from_numpy(f16).cuda()}).cpu().numpy()
+    assert logits.shape == (1, n0, 2) and np.isfinite(logits).all()
+    import os
+    th = max(1, min(os.cpu_count() or 1, 32))
+    pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: oracle.knn_batch(s, q, k, threads=th, qpar=True), xyz, cfg.k_n, cfg.sub_sampling_ratio)
+    for i in range(cfg.num_layers):
+        assert pyr.neigh_idx[i].dtype == torch.int32
+        assert np.array_equal(pyr.neigh_idx[i].cpu().numpy(), nbr[i]), i
+        assert np.array_equal(pyr.sub_idx[i].cpu().numpy(), pool[i]), i
+        assert np.array_equal(pyr.interp_idx[i].cpu().numpy(), up[i]), i
+    dec4 = net.tap(44, (1, n0, 32)).astype(np.float64)
+    fc0 = net.tap(0, (1, n0, 8)).astype(np.float64)
+    got0 = net.tap(10, (1, n0, 32))
+    same = net.inference({"pyramid": pyr, "features": torch.from_numpy(f16.astype(np.float32)).cuda()}).cpu().numpy()
+    assert np.array_equal(logits, same)
+    f = ro.conv2d(dec4, params, "fc1", np.float64)
+    f = ro.conv2d(f, params, "fc2", np.float64)
+    want = ro.conv2d(f, params, "fc", np.float64, bn=False, act=False)
+    assert np.abs(logits - want).max() <= TOL
+    want_fc0 = f16.astype(np.float64) @ params["fc0/kernel"].astype(np.float64) + params["fc0/bias"].astype(np.float64)
+    want_fc0 = ro.leaky_relu(ro.batch_norm_eval(want_fc0, params, "batch_normalization", np.dtype(np.float64)))
+    assert np.abs(fc0 - want_fc0).max() <= TOL
+    enc0 = ro.dilated_res_block(fc0, xyz.astype(np.float64), nbr[0], params, "Encoder_layer_0", np.float64)
+    assert np.abs(got0 - enc0).max() <= TOL
+    net.close()
+
+
 def test_pipeline_matches_serial():
     """ForwardPipeline (consecutive clouds on consecutive lanes, one HIP stream + context each, three in flight) returns,
     for every cloud of a sequence, bit-identical logits to the serial one-stream path."""
