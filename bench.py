@@ -70,8 +70,9 @@ def algorithmic_costs(cfg, n0, B):
     n = level_sizes(n0, cfg.sub_sampling_ratio[:L])
     c = {}
     nq = sum(n[:L])
-    # one launch: the K-NN self queries and the 1-NN up-sampling queries of every level (12 B query + 4 K B of indices out each)
-    c["knn_search"] = dict(flops=0, bytes=B * (nq * 12 + nq * K * 4) + B * (nq * 12 + nq * 4))
+    # one launch: the K-NN self queries and the 1-NN up-sampling queries of every level.  SURVEY 8(d): read xyz sum N_i * 12 + write
+    # sum N_i * K * 4 (neigh_idx) + write sum N_i * 4 (interp_idx) = 19.2 MB for the 180 000-point cloud (the query point is counted once)
+    c["knn_search"] = dict(flops=0, bytes=B * nq * (12 + K * 4 + 4))
     c["kdtree_build"] = dict(flops=0, bytes=B * (sum(n) * 12 + sum(n) * 16 + 2 * sum(n) * 16))
     c["pyramid_slices"] = dict(flops=0, bytes=B * 2 * (sum(n[:L]) * 12 + sum(n[1:]) * K * 4))
     c["fc0"] = dict(flops=2 * B * n0 * cfg.in_channels * 8, bytes=B * n0 * (cfg.in_channels + 8) * 4)
@@ -81,15 +82,19 @@ def algorithmic_costs(cfg, n0, B):
         h = d // 2
         N, N1 = B * n[i], B * n[i + 1]
         locse = K * 10 * h
+        # "bytes" = SURVEY 8(d)'s gather-counted figure (a gathered row counts once per use); "unique" = every distinct row once (what HBM
+        # has to deliver at least: the repeats are L2 / MALL hits) -- the HBM fraction of a stage is priced on the unique bytes
+        att_unique = N * (12 + K * 4 + 12 + h * 4 + d * 4)
         c["enc%d_att1" % i] = dict(flops=2 * N * (locse + K * d * d),
-                                   bytes=N * (12 + K * 4 + K * 12 + K * h * 4 + d * 4))
+                                   bytes=N * (12 + K * 4 + K * 12 + K * h * 4 + d * 4), unique=att_unique)
         # (the kernel re-derives LocSE + LFA-mlp1 in stage 2 instead of storing [N,K,h]; the reference computes it once,
         #  so it is counted once)
         c["enc%d_att2" % i] = dict(flops=2 * N * (K * h * h + K * d * d),
-                                   bytes=N * (12 + K * 4 + K * 12 + K * h * 4 + d * 4))
+                                   bytes=N * (12 + K * 4 + K * 12 + K * h * 4 + d * 4), unique=att_unique)
         c["enc%d_dense" % i] = dict(flops=2 * N * (d_in * h + d * h + d * d + 2 * d * d + 2 * d_in * d),
                                     bytes=N * 4 * (2 * d_in + h + d + h + d + d + 2 * d))
-        c["enc%d_pool" % i] = dict(flops=0, bytes=N1 * (K * 4 + K * 2 * d * 4 + 2 * d * 4))
+        c["enc%d_pool" % i] = dict(flops=0, bytes=N1 * (K * 4 + K * 2 * d * 4 + 2 * d * 4),
+                                   unique=N1 * K * 4 + min(N1 * K, N) * 2 * d * 4 + N1 * 2 * d * 4)
         d_in = 2 * d
     c["decoder_0"] = dict(flops=2 * B * n[L] * d_in * d_in, bytes=B * n[L] * 2 * d_in * 4 + d_in * d_in * 4)
     chans = [2 * cfg.d_out[0]] + [2 * d for d in cfg.d_out[:L]]
@@ -273,6 +278,115 @@ def cpu_baseline_train(cfg, params, points, seed=0):
                 knn_seconds=t1 - t0, step_seconds=t2 - t1)
 
 
+def train_roofline(cfg, n0, B, ms, bf16):
+    """Whole-step roofline of the training step: forward + input-gradient + weight-gradient GEMMs = 3 x the forward's algorithmic FLOPs
+    (SURVEY 8d figure x 3); bytes: the backward reads every activation once more and writes its gradient (x 3).  Against the dtype's
+    MFMA peak and HBM."""
+    fwd = algorithmic_costs(cfg, n0, B)
+    net = [v for k, v in fwd.items() if not k.startswith(("knn", "kdtree", "pyramid"))]
+    step_flops, step_bytes = 3 * sum(v["flops"] for v in net), 3 * sum(v["bytes"] for v in net)
+    peak = BF16_MFMA_PEAK_TF if bf16 else F32_MFMA_PEAK_TF
+    tfs, gbs = step_flops / (ms * 1e-3) / 1e12, step_bytes / (ms * 1e-3) / 1e9
+    mf = tfs / peak > gbs / HBM_PEAK_GBS
+    return {"bound": "mfma" if mf else "hbm", "kernel": "whole training step", "achieved": round(tfs if mf else gbs, 3), "peak": peak if mf else HBM_PEAK_GBS,
+            "unit": "TFLOP/s" if mf else "GB/s", "frac": round(max(tfs / peak, gbs / HBM_PEAK_GBS), 5), "traffic": None,
+            "algorithmic_flops_per_step": step_flops, "algorithmic_bytes_per_step": step_bytes,
+            "mfma_frac": round(tfs / peak, 5), "hbm_frac": round(gbs / HBM_PEAK_GBS, 5)}
+
+
+def sub_train_b8(cfg, xyz_list, local_rank, bf16, steps=2, warmup=1):
+    """BASELINE configs[2] inside the default line: batch 8 x 180 000-point clouds, pyramid + forward + backward + Adam through
+    ps_randla_train_step, `steps` timed steps after `warmup` (the first step also grows the activation pool)."""
+    import torch
+    from point_unet_amd import runtime, weights
+    from point_unet_amd.pyramid import alloc_pyramid, build_pyramid
+    from point_unet_amd.train import Trainer
+    B = len(xyz_list)
+    xyz = np.concatenate(xyz_list, 0)
+    n0 = xyz.shape[1]
+    rng = np.random.default_rng(7)
+    feats = np.concatenate([xyz, rng.standard_normal((B, n0, cfg.in_channels - 3)).astype(np.float32)], -1)
+    labels = rng.integers(0, cfg.num_classes, (B, n0)).astype(np.int32)
+    ctx = runtime.default_context(local_rank)
+    ctx.use_torch_stream()
+    ctx.set_deferred_checks(False)
+    tr = Trainer(cfg, params=weights.init_params(cfg, seed=2), device=local_rank, ctx=ctx, keep_prob=0.5, mlp_dtype="bf16" if bf16 else "fp32")
+    d_xyz, d_feats, d_lab = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
+    pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
+
+    def step():
+        build_pyramid(d_xyz, cfg, ctx=ctx, out=pyr)
+        return tr.train_step(pyr, d_feats, d_lab)
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    elapsed, loss = timed_region(step, steps, sync, None)
+    ms = 1e3 * elapsed / steps
+    out = {"ms_per_step": ms, "points_per_s": B * n0 * steps / elapsed, "steps": steps, "warmup": warmup, "batch": B, "points": n0,
+           "dtype": "bf16" if bf16 else "f32", "loss": float(loss), "pool_peak_gb": tr.pool_peak_bytes() / 2 ** 30,
+           "roofline": train_roofline(cfg, n0, B, ms, bf16),
+           "what": "BASELINE configs[2]: one training step (pyramid + train-mode forward + weighted CE + backward + Adam) = ONE ps_pyramid_build + ONE "
+                   "ps_randla_train_step call, batch %d x %d points, %s" % (B, n0, "bf16 MLP GEMMs (fp32 accumulate), rest fp32" if bf16 else "fp32")}
+    tr.close()
+    del tr, pyr, d_xyz, d_feats, d_lab
+    torch.cuda.empty_cache()
+    return out
+
+
+def sub_config5(local_rank, lanes, reuse, steps=40, warmup=8, n_clouds=4):
+    """BASELINE configs[4] inside the default line: 262 144-point cloud, K = 32, 4 input channels, 2 classes, fp16 feature hand-over,
+    int32 indices; pyramid + forward, `lanes` clouds in flight and one cloud in flight."""
+    import torch
+    from point_unet_amd import weights
+    from point_unet_amd.helper_tool import ConfigBraTS
+    from point_unet_amd.pipeline import ForwardPipeline
+
+    class cfg5(ConfigBraTS):
+        k_n, num_classes, in_channels = 32, 2, 4
+
+    n0 = 262144
+    clouds = []
+    for i in range(n_clouds):
+        x = brats_cloud(n0, 5000 + 17 * i)[None]
+        f = np.concatenate([x, np.random.default_rng(31 * i).standard_normal((1, n0, 1)).astype(np.float32)], -1).astype(np.float16)
+        clouds.append((torch.from_numpy(x).cuda(), torch.from_numpy(f).cuda()))
+    # on the headline pipeline's own streams and contexts: four MORE streams in the process cost this configuration 20 % pipelined and
+    # 60 % serial (ForwardPipeline.__init__, profiles/tools/exp_second_pipeline.py)
+    pipe = ForwardPipeline(cfg5, params=weights.init_params(cfg5, seed=2, randomize_bn=True), device=local_rank, lanes=lanes, reuse=reuse)
+    pipe.prime(*clouds[0])
+    k = [0]
+
+    def step(overlap=True):
+        x, f = clouds[k[0] % n_clouds]
+        k[0] += 1
+        return pipe.submit(x, f, overlap=overlap)
+
+    def sync():
+        pipe.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    elapsed, logits = timed_region(step, steps, sync, None)
+    assert bool(torch.isfinite(logits).all())
+    n_serial = max(4, steps // 4)
+    t_serial, _ = timed_region(lambda: step(overlap=False), n_serial, sync, None)
+    costs = algorithmic_costs(cfg5, n0, 1)
+    net_flops = sum(v["flops"] for kk, v in costs.items() if not kk.startswith(("knn", "kdtree", "pyramid")))
+    out = {"ms_per_step": 1e3 * elapsed / steps, "points_per_s": n0 * steps / elapsed, "steps": steps, "warmup": warmup,
+           "serial_ms_per_cloud": 1e3 * t_serial / n_serial, "points": n0, "k_n": 32, "lanes": lanes, "dtype": "f32 (fp16 feature input, int32 indices)",
+           "algorithmic_gflop_per_step": net_flops / 1e9, "achieved_tflops_serial": net_flops / (t_serial / n_serial) / 1e12,
+           "what": "BASELINE configs[4]: 262 144-point cloud, K=32, 4 input channels, 2 classes, features handed over as fp16, pyramid + forward"}
+    pipe.close()
+    del pipe, clouds
+    torch.cuda.empty_cache()
+    return out
+
+
 def bench_train(args, cfg, rank, local_rank, world, dist):
     """BASELINE configs[2] (--batch 8, 1 GPU) / configs[3] (--gpus 8 --batch 1): one training step = index pyramid +
     training-mode forward + class-weighted CE + backward + (all-reduce of the flat gradient buffer) + Adam."""
@@ -288,7 +402,8 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
     ctx = runtime.default_context(local_rank)
     params = weights.init_params(cfg, seed=2)
     tr = Trainer(cfg, params=params, device=local_rank, ctx=ctx, keep_prob=0.5, sync_bn=dist is not None and not args.local_bn,
-                 mlp_dtype="bf16" if args.bf16_mlp else "fp32", fused_att=not args.no_fused_att, fused_locse=not args.no_fused_locse, fused_convbn=args.fused_convbn)
+                 mlp_dtype="bf16" if args.bf16_mlp else "fp32", fused_att=not args.no_fused_att, fused_locse=not args.no_fused_locse, fused_convbn=args.fused_convbn,
+                 engine=args.train_engine)
     d_xyz, d_feats, d_lab = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
     pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
     seen = ranks_seen(dist, "cuda" if args.dist_backend == "nccl" else "cpu") if dist is not None else 1
@@ -316,23 +431,11 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
     assert bool(torch.isfinite(loss).all())
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
-        fwd = algorithmic_costs(cfg, n0, B)
-        net_flops = sum(v["flops"] for k, v in fwd.items() if not k.startswith(("knn", "kdtree", "pyramid")))
-        net_bytes = sum(v["bytes"] for k, v in fwd.items() if not k.startswith(("knn", "kdtree", "pyramid")))
-        # forward + input-gradient + weight-gradient GEMMs: 3 x the forward FLOPs (SURVEY 8d figure x 3); bytes: forward + backward read
-        # every activation once more and write its gradient (x 3)
-        step_flops, step_bytes = 3 * net_flops, 3 * net_bytes
-        peak = BF16_MFMA_PEAK_TF if args.bf16_mlp else F32_MFMA_PEAK_TF
-        tfs, gbs = step_flops / (ms * 1e-3) / 1e12, step_bytes / (ms * 1e-3) / 1e9
         stages = sorted(({"name": nm, "ms_per_step": round(t / prof_steps, 4), "launches_per_step": ln / prof_steps} for nm, t, ln in prof_rows),
                         key=lambda r: -r["ms_per_step"])
-        dom = stages[0] if stages else None
-        roofline = {"bound": "mfma" if tfs / peak > gbs / HBM_PEAK_GBS else "hbm", "kernel": "whole training step",
-                    "achieved": round(tfs if tfs / peak > gbs / HBM_PEAK_GBS else gbs, 3), "peak": peak if tfs / peak > gbs / HBM_PEAK_GBS else HBM_PEAK_GBS,
-                    "unit": "TFLOP/s" if tfs / peak > gbs / HBM_PEAK_GBS else "GB/s", "frac": round(max(tfs / peak, gbs / HBM_PEAK_GBS), 5), "traffic": None,
-                    "algorithmic_flops_per_step": step_flops, "algorithmic_bytes_per_step": step_bytes,
-                    "mfma_frac": round(tfs / peak, 5), "hbm_frac": round(gbs / HBM_PEAK_GBS, 5),
-                    "dominant_stage": dom, "measured": "timed region (whole step); stages: hipEvent pairs over %d extra steps" % prof_steps}
+        roofline = train_roofline(cfg, n0, B, ms, args.bf16_mlp)
+        roofline["dominant_stage"] = stages[0] if stages else None
+        roofline["measured"] = "timed region (whole step); stages: hipEvent pairs over %d extra steps" % prof_steps
         out = {
             "metric": "points_per_sec_train_step", "value": whole_job_value(world, B, n0, args.steps, elapsed), "unit": "points/s",
             "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -344,8 +447,9 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
                                        2 if world == 1 else 3, n0, B, "bf16 MLP GEMMs (fp32 accumulate), rest fp32" if args.bf16_mlp else "fp32",
                                        (", gradient all-reduce over RCCL, BatchNorm statistics %s" % ("per GPU" if args.local_bn else "shared by all ranks")) if world > 1 else ""),
                        "points": n0, "batch_per_gpu": B, "parameters": tr.num_params()},
-            "roofline": roofline, "stages": stages,
-            "loss": float(loss), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "roofline": roofline, "stages": stages, "launches_per_step": sum(r["launches_per_step"] for r in stages) if stages else None,
+            "engine": tr.engine, "loss": float(loss), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "pool_peak_gb": tr.pool_peak_bytes() / 2 ** 30 if tr.engine == "native" else None,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_train(cfg, params, min(n0, 45000))
@@ -381,6 +485,9 @@ def main():
     ap.add_argument("--no-fused-att", action="store_true", help="train mode: the op-by-op attentive pooling at every level (A/B of csrc/attpool_train.hip)")
     ap.add_argument("--fused-convbn", action="store_true", help="train mode: LFA mlp2 in the recompute form (csrc/smallconv_train.hip; measured slower, off by default)")
     ap.add_argument("--no-fused-locse", action="store_true", help="train mode: the op-by-op LocSE branch (A/B of csrc/locse_train.hip)")
+    ap.add_argument("--train-engine", choices=["native", "python"], default="native",
+                    help="train mode: native = ps_randla_train_step, the whole step behind one C-ABI call (csrc/trainer.hip); python = the host-side "
+                         "tape over the same op-level kernels (A/B)")
     ap.add_argument("--local-bn", action="store_true", help="train mode, N > 1: per-GPU BatchNorm statistics instead of statistics shared by all ranks")
     ap.add_argument("--clouds", type=int, default=8, help="distinct resident clouds every rank rotates through (one per step)")
     ap.add_argument("--no-sub-results", action="store_true", help="skip the PCIe-inclusive sub-result of the default line")
@@ -576,6 +683,12 @@ def main():
         sub["serial"] = {"ms_per_cloud": serial_ms, "points_per_s": B * n0 / (serial_ms * 1e-3), "steps": dom_steps,
                          "what": "one cloud in flight: every step waits for the previous cloud (per-cloud latency of pyramid + forward on this rank)"}
         if not args.no_sub_results and not args.include_pcie:
+            # untimed warm-up of the service path itself: the first transfers through freshly pinned host buffers and fresh device slots
+            # are slow (page registration with the DMA engines), and at the driver's --steps 20 they WERE the number (r2: 1.66 ms
+            # against 1.02 once warm, profiles/tools/exp_pcie.py)
+            for _ in range(max(2 * args.lanes, args.warmup)):
+                pcie_step()
+            sync()
             t_pcie, _ = timed_region(pcie_step, args.steps, sync, None)
             sub["include_pcie"] = {"ms_per_step": 1e3 * t_pcie / args.steps, "points_per_s": B * n0 * args.steps / t_pcie, "steps": args.steps,
                                    "what": "every step also copies its cloud (xyz + features) from pinned host memory and its logits back, on the "
@@ -608,7 +721,8 @@ def main():
             per_step = ms / prof_steps
             launches = launches * args.steps / prof_steps
             cst = costs.get(name, dict(flops=0, bytes=0))
-            gbs = cst["bytes"] / (per_step * 1e-3) / 1e9 if per_step > 0 else 0.0
+            gathered = cst["bytes"] / (per_step * 1e-3) / 1e9 if per_step > 0 else 0.0   # gather-counted
+            gbs = cst.get("unique", cst["bytes"]) / (per_step * 1e-3) / 1e9 if per_step > 0 else 0.0  # every distinct byte once
             tfs = cst["flops"] / (per_step * 1e-3) / 1e12 if per_step > 0 else 0.0
             # attentive pooling at d_out >= 64 runs its products as SIX bf16 MFMAs per fp32 product (exact three-way splits,
             # csrc/attpool32b.hip): the matrix-pipe ceiling of those stages, in fp32 FLOPs, is the dense bf16 peak / 6
@@ -622,6 +736,11 @@ def main():
             if split and bound == "mfma":
                 row["peak"] = round(mfma_peak, 1)
                 row["peak_note"] = "bf16 MFMA dense peak / 6 piece products"
+            row["pipe"] = "bf16x3" if split else "f32"
+            row["flops"] = cst["flops"]
+            if "unique" in cst:
+                row["hbm_frac_unique_bytes"] = round(f_h, 5)
+                row["gather_counted_gbs"] = round(gathered, 1)  # mostly L2 / MALL hits: NOT an HBM rate, never used for frac
             stages.append(row)
         stages.sort(key=lambda s: -s["ms_per_step"])
         dom = next((s for s in stages if s["name"] == dominant), None)
@@ -630,14 +749,14 @@ def main():
             # the dominant stage re-measured LIVE inside the timed region (its own event pair only)
             t_ms, n_launch = live[dominant]
             cst = costs.get(dominant, dict(flops=0, bytes=0))
-            gbs = cst["bytes"] / (t_ms * 1e-3) / 1e9
+            gbs = cst.get("unique", cst["bytes"]) / (t_ms * 1e-3) / 1e9
             tfs = cst["flops"] / (t_ms * 1e-3) / 1e12
             mf = tfs / F32_MFMA_PEAK_TF > gbs / HBM_PEAK_GBS
             roofline = dict(kernel=dominant, bound="mfma" if mf else "hbm", achieved=round(tfs if mf else gbs, 3),
                             peak=F32_MFMA_PEAK_TF if mf else HBM_PEAK_GBS, unit="TFLOP/s" if mf else "GB/s",
                             frac=round(max(tfs / F32_MFMA_PEAK_TF, gbs / HBM_PEAK_GBS), 5), traffic=None,
                             ms_per_step=round(t_ms, 4), launches_per_step=n_launch, avg_launch_ms=round(t_ms / max(n_launch, 1), 5),
-                            algorithmic_bytes_per_step=cst["bytes"], algorithmic_flops_per_step=cst["flops"], measured=dom_where)
+                            algorithmic_bytes_per_step=cst.get("unique", cst["bytes"]), algorithmic_flops_per_step=cst["flops"], measured=dom_where)
             # HBM bytes per launch cannot be counted from inside this process: they come from separate rocprofv3 --pmc passes of this
             # same command (profiles/run_pmc.sh; FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), committed with the commit they
             # were taken at.  The number is labelled with that source; null when no such file exists for this round.
@@ -662,9 +781,24 @@ def main():
         roofline_network = dict(bound="mfma", achieved=round(net_tfs, 3), peak=F32_MFMA_PEAK_TF, unit="TFLOP/s",
                                 frac=round(net_tfs / F32_MFMA_PEAK_TF, 5), ms_per_step=round(net_ms, 4),
                                 algorithmic_flops_per_step=total_cost["flops"], measured="serial profile pass, all network stages")
+        # ... and split by the matrix pipe the stages actually run on: a utilisation figure only means something per pipe
+        by_pipe = {}
+        for srow in stages:
+            if srow["name"].startswith(("kdtree", "knn", "pyramid")):
+                continue
+            acc = by_pipe.setdefault(srow["pipe"], [0.0, 0.0])
+            acc[0] += srow["flops"]
+            acc[1] += srow["ms_per_step"]
+        roofline_network["by_pipe"] = {
+            pipe: dict(algorithmic_flops_per_step=fl, ms_per_step=round(ms_p, 4), achieved=round(fl / (ms_p * 1e-3) / 1e12, 3) if ms_p > 0 else 0.0,
+                       unit="TFLOP/s", peak=round(BF16_MFMA_PEAK_TF / 6, 1) if pipe == "bf16x3" else F32_MFMA_PEAK_TF,
+                       frac=round(fl / (ms_p * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TF / 6 if pipe == "bf16x3" else F32_MFMA_PEAK_TF), 5) if ms_p > 0 else 0.0,
+                       what=("attentive pooling at d_out >= 64: six bf16 MFMAs per fp32 product over exact splits (ceiling = dense bf16 peak / 6, in fp32 FLOPs)"
+                             if pipe == "bf16x3" else "everything else: fp32 MFMA / HBM-bound stages"))
+            for pipe, (fl, ms_p) in by_pipe.items()}
         if not args.att_fp32_mfma:
-            roofline_network["note"] = ("quoted against the fp32 MFMA peak; the attention products at d_out >= 64 execute as six bf16 MFMAs per "
-                                        "fp32 product (ceiling 2500 / 6 = 417 TFLOP/s in fp32 FLOPs), everything else on the fp32 MFMA")
+            roofline_network["note"] = ("the single figure above is quoted against the fp32 MFMA peak although ten stages run on the bf16 pipe: it is a "
+                                        "rate in reference-formulation FLOPs, not the utilisation of one pipe -- see by_pipe")
         out = {
             "metric": "points_per_sec_forward",
             "value": whole_job_value(world, B, n0, args.steps, elapsed),
@@ -700,6 +834,14 @@ def main():
             "algorithmic": {"gflop_per_step": total_cost["flops"] / 1e9, "gbyte_per_step": total_cost["bytes"] / 1e9},
             "stages": stages,
         }
+        if world == 1 and not args.no_sub_results and args.workload == "config2" and B == 1 and pipe is not None and not args.include_pcie:
+            # the other single-GPU BASELINE configurations, timed in the same run (a few seconds each, after the headline's timed region):
+            # configs[2] = the batch-8 training step (fp32 and "bf16 MLPs"), configs[4] = the 262 144-point / K = 32 forward
+            t_sub = time.perf_counter()
+            out["config5"] = sub_config5(local_rank, args.lanes, pipe)
+            pipe = None
+            out["train_b8"] = {"f32": sub_train_b8(cfg, xyz_all[:8], local_rank, False), "bf16": sub_train_b8(cfg, xyz_all[:8], local_rank, True)} if len(xyz_all) >= 8 else None
+            out["sub_results_seconds"] = round(time.perf_counter() - t_sub, 2)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, xyz[:1], feats[:1], params)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -356,6 +356,61 @@ int ps_op_adam(ps_context* ctx, float* p, const float* g, float* m, float* v, in
 /* tf.nn.dropout: y = x * mask, mask = (u < keep_prob) / keep_prob from a counter-based hash of (element, seed) */
 int ps_op_dropout(ps_context* ctx, const float* x, int64_t n, uint32_t seed, float keep_prob, float* y, float* mask);
 
+/* ---- the training step behind one call ----------------------------------------------------------------------------------
+ * Replaces Network.__init__'s loss / optimizer and Network.train's sess.run([train_op, extra_update_ops, ...])
+ * (PointSegment/RandLANet.py:62-90, 162-169, 267-274) over the graph of Network.inference in training mode (:110-152, 314-401;
+ * tf.layers.batch_normalization(training=True), helper_tf_util.py:167,246; tf.nn.dropout before the last layer, :553-574).
+ * csrc/trainer.hip holds the tape in C++: no Python, no torch in the loop.
+ *
+ * Memory: parameters, gradients, Adam moments and BatchNorm moving statistics are CALLER-OWNED flat fp32 device buffers
+ * (ps_trainer_bind) of ps_trainer_param_count() (first four) and ps_trainer_buffer_count() floats; ps_trainer_layout enumerates
+ * the named tensors inside them (the reference's variable names without the "layers/" scope, in graph order: for every layer
+ * kernel / weights [cin,cout] ([cout,cin] for the transposed convolutions of the decoder), bias, BatchNorm gamma, beta; buffers:
+ * moving_mean, moving_variance per BatchNorm).  Activations and gradients of a step live in a pool the trainer owns (grows to the
+ * high-water mark during the first step, then reused; ps_trainer_pool_peak_bytes).
+ *
+ * Collectives: the library links no communication library.  A data-parallel host passes an all-reduce callback
+ * (RCCL: `ncclAllReduce(buf, buf, count, dtype ? ncclDouble : ncclFloat, ncclSum, comm, (hipStream_t)hip_stream)`); the step
+ * calls it once for the flat gradient buffer (then divides by world_size) and, with sync_bn != 0, twice per BatchNorm layer for
+ * the [sum | sum of squares] / [sum g | sum g*xhat] vectors, so that "N GPUs x 1 cloud" is the same optimisation step as "1 GPU x N clouds". */
+typedef struct ps_trainer ps_trainer;
+typedef struct {
+    float learning_rate;            /* cfg.learning_rate (helper_tool.py:33); Adam beta1 0.9, beta2 0.999, eps 1e-8 (TF defaults) */
+    float keep_prob;                /* dropout in front of the last layer, RandLANet.py:148 (0.5) */
+    int32_t mlp_bf16;               /* BASELINE configs[2] "bf16 MLPs": the shared-MLP GEMMs round their operands to bf16 (fp32 accumulate) */
+    int32_t fused_att;              /* attentive pooling (+ gather / concat / scatter-add) as one kernel per direction where compiled (d <= 64) */
+    int32_t fused_locse;            /* the LocSE branch recomputed from coordinates and indices instead of materialised (fp32 mode only) */
+    int32_t num_ignored;            /* cfg.ignored_label_inds (RandLANet.py:68-81): labels dropped from the loss, <= 8 */
+    int32_t ignored_label_inds[8];
+} ps_train_options;
+/* In-place sum over the ranks of `count` elements at device pointer `buf` (dtype 0: float32, 1: float64), ordered on `hip_stream`
+ * (the context's stream).  Returns 0 on success. */
+typedef int (*ps_allreduce_fn)(void* user, void* buf, int64_t count, int dtype, void* hip_stream);
+
+int ps_trainer_create(ps_context* ctx, const ps_randla_config* cfg, const ps_train_options* opt, ps_trainer** out);
+int ps_trainer_destroy(ps_trainer* t);
+int64_t ps_trainer_param_count(const ps_trainer* t);   /* trainable floats: 4 992 852 for the BraTS model */
+int64_t ps_trainer_buffer_count(const ps_trainer* t);  /* BatchNorm moving statistics */
+int ps_trainer_layout_rows(const ps_trainer* t);
+/* row-th named tensor: its offset (floats) and shape inside the parameter buffer (is_buffer 0) or the statistics buffer (1) */
+int ps_trainer_layout(const ps_trainer* t, int row, char* name, int name_cap, int64_t* offset, int64_t* rows, int64_t* cols,
+                      int* is_buffer);
+/* device pointers; adam_m / adam_v may be NULL for a host that only calls ps_randla_backward */
+int ps_trainer_bind(ps_trainer* t, float* params, float* grads, float* adam_m, float* adam_v, float* bn_buffers);
+int ps_trainer_set_collective(ps_trainer* t, ps_allreduce_fn fn, void* user, int world_size, int rank, int sync_bn);
+int ps_trainer_set_options(ps_trainer* t, const ps_train_options* opt);  /* everything but the ignored labels */
+int ps_trainer_set_step(ps_trainer* t, int64_t step);                    /* optimisation steps taken so far (checkpoint resume) */
+int64_t ps_trainer_get_step(const ps_trainer* t);
+int64_t ps_trainer_pool_peak_bytes(const ps_trainer* t);                 /* activation + gradient footprint of the last step */
+/* Training-mode forward + class-weighted cross-entropy + backward: fills the bound gradient buffer (this rank's gradients, no
+ * collective), updates the BatchNorm moving statistics, writes the loss (device float) and optionally the logits
+ * f32[B*N0, classes] (NULL: not wanted).  features f32[B,N0,in_channels], labels i32[B,N0], class_weights f32[classes]; device pointers. */
+int ps_randla_backward(ps_trainer* t, const ps_pyramid* pyr, const float* features, const int32_t* labels,
+                       const float* class_weights, float* loss, float* logits);
+/* The whole optimisation step: ps_randla_backward + mean of the gradients over the ranks (if a collective is set) + Adam. */
+int ps_randla_train_step(ps_trainer* t, const ps_pyramid* pyr, const float* features, const int32_t* labels,
+                         const float* class_weights, float* loss, float* logits);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,22 @@ class PsRandlaConfig(ctypes.Structure):
     ]
 
 
+class PsTrainOptions(ctypes.Structure):
+    _fields_ = [
+        ("learning_rate", ctypes.c_float),
+        ("keep_prob", ctypes.c_float),
+        ("mlp_bf16", ctypes.c_int32),
+        ("fused_att", ctypes.c_int32),
+        ("fused_locse", ctypes.c_int32),
+        ("num_ignored", ctypes.c_int32),
+        ("ignored_label_inds", ctypes.c_int32 * 8),
+    ]
+
+
+# int (*ps_allreduce_fn)(void* user, void* buf, int64_t count, int dtype, void* hip_stream)
+PS_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p)
+
+
 class PsTimingRow(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 48), ("ms", ctypes.c_double), ("launches", ctypes.c_int64)]
 
@@ -129,6 +145,21 @@ PROTOTYPES = {
     "ps_op_bn_train_bwd_sums_ex": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64] + [c_vp] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int] + [c_vp] * 2),
     "ps_op_bn_train_bwd_apply_ex": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64] + [c_vp] * 7 + [ctypes.c_int64] * 3 + [ctypes.c_int, c_vp]),
     "ps_op_scatter_add_rows_ex": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp] + [ctypes.c_int64] * 4 + [c_vp]),
+    # the training step behind one call (csrc/trainer.hip)
+    "ps_trainer_create": (ctypes.c_int, [c_vp, ctypes.POINTER(PsRandlaConfig), ctypes.POINTER(PsTrainOptions), ctypes.POINTER(c_vp)]),
+    "ps_trainer_destroy": (ctypes.c_int, [c_vp]),
+    "ps_trainer_param_count": (ctypes.c_int64, [c_vp]),
+    "ps_trainer_buffer_count": (ctypes.c_int64, [c_vp]),
+    "ps_trainer_layout_rows": (ctypes.c_int, [c_vp]),
+    "ps_trainer_layout": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, c_i64p, c_i64p, c_i64p, ctypes.POINTER(ctypes.c_int)]),
+    "ps_trainer_bind": (ctypes.c_int, [c_vp] * 6),
+    "ps_trainer_set_collective": (ctypes.c_int, [c_vp, PS_ALLREDUCE_FN, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "ps_trainer_set_options": (ctypes.c_int, [c_vp, ctypes.POINTER(PsTrainOptions)]),
+    "ps_trainer_set_step": (ctypes.c_int, [c_vp, ctypes.c_int64]),
+    "ps_trainer_get_step": (ctypes.c_int64, [c_vp]),
+    "ps_trainer_pool_peak_bytes": (ctypes.c_int64, [c_vp]),
+    "ps_randla_backward": (ctypes.c_int, [c_vp, ctypes.POINTER(PsPyramid), c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ps_randla_train_step": (ctypes.c_int, [c_vp, ctypes.POINTER(PsPyramid), c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 
 _lib = None

@@ -1,0 +1,1135 @@
+// trainer.hip -- the training step of the PointSegment RandLA-Net behind ONE C-ABI call (ps_randla_train_step / ps_randla_backward).
+//
+// What it replaces in the reference (TensorFlow autodiff over the graph of Network.inference):
+//     loss + optimizer                         PointSegment/RandLANet.py:62-90, 267-274
+//     sess.run([train_op, extra_update_ops..]) PointSegment/RandLANet.py:162-169
+//     tf.layers.batch_normalization(training)  PointSegment/helper_tf_util.py:167,246; RandLANet.py:115
+//     the graph itself                         PointSegment/RandLANet.py:110-152, 314-401
+//
+// Structure: a tape in C++.  The forward pass (Trainer::forward, a line-by-line counterpart of Network.inference in training mode)
+// calls the op-level kernels of this library (ops.hip, ops_train.hip, attpool_train.hip, locse_train.hip, gemm_b3.hip ...) and records,
+// per op, a closure that computes the input gradients from the output gradient; backward() replays the closures in reverse.  No
+// Python, no torch: device memory for activations and gradients comes from a pool owned by the trainer (blocks are reference counted
+// and go back to the pool the moment the last user drops them, so the step's footprint is that of the live tensors), parameters /
+// gradients / Adam moments / BatchNorm moving statistics are CALLER-OWNED flat device buffers (ps_trainer_bind) in the layout
+// ps_trainer_layout reports, BatchNorm moving statistics are updated by the kernels that finish the batch statistics, and collectives
+// (gradient mean, BatchNorm statistics shared by the ranks) go through a callback the host supplies (ps_trainer_set_collective: the
+// library does not link a communication library; RCCL sits behind torch.distributed in bench.py, behind ncclAllReduce in a C++ host).
+#include "common.h"
+
+#include <cmath>
+#include <functional>
+#include <memory>
+#include <unordered_map>
+
+using namespace ps;
+
+namespace ps {
+
+static constexpr float kBnEps = 1e-6f;      // tf.layers.batch_normalization(x, -1, 0.99, 1e-6)  RandLANet.py:115, helper_tf_util.py:167
+static constexpr float kBnMomentum = 0.99f;
+
+struct TrainError {
+    int rc;
+};
+#define TK(expr)                                \
+    do {                                        \
+        int rc_ = (expr);                       \
+        if (rc_ != PS_OK) throw TrainError{rc_}; \
+    } while (0)
+#define TK_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            ps::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            throw TrainError{PS_EHIP};                                                                \
+        }                                                                                             \
+    } while (0)
+
+// ---- device memory pool -----------------------------------------------------------------------------------------------------------
+// First-fit over address-ordered free blocks with coalescing, in chunks obtained from hipMalloc.  Everything runs on ONE stream, so a
+// block can be handed out again the moment the host drops it: the kernels that still read it were enqueued before the kernels of its
+// next user.  Chunks are never returned; the first step grows the pool to its high-water mark (a handful of chunks), every later
+// step of the same shape repeats the same allocation sequence and finds the same places (steady state: no hipMalloc).
+struct Pool {
+    struct Chunk {
+        char* base;
+        size_t size;
+    };
+    std::vector<Chunk> chunks;
+    std::map<char*, size_t> free_;
+    std::unordered_map<char*, size_t> used;
+    size_t in_use = 0, peak = 0, total = 0;
+
+    void add_chunk(size_t bytes)
+    {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            ps::set_error("training pool: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            throw TrainError{PS_ENOMEM};
+        }
+        chunks.push_back({static_cast<char*>(p), bytes});
+        free_[static_cast<char*>(p)] = bytes;
+        total += bytes;
+    }
+    void* alloc(size_t bytes)
+    {
+        bytes = (bytes + 255) & ~size_t(255);
+        if (!bytes) bytes = 256;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            for (auto it = free_.begin(); it != free_.end(); ++it) {
+                if (it->second < bytes) continue;
+                char* p = it->first;
+                const size_t rest = it->second - bytes;
+                free_.erase(it);
+                if (rest) free_[p + bytes] = rest;
+                used[p] = bytes;
+                in_use += bytes;
+                if (in_use > peak) peak = in_use;
+                return p;
+            }
+            // grow: at least the request, at least 1 GiB, at least half of what there is (few chunks even for a first, unsized step)
+            size_t want = std::max(bytes, std::max<size_t>(size_t(1) << 30, total / 2));
+            add_chunk(want);
+        }
+        ps::set_error("training pool: allocation of %zu bytes failed", bytes);
+        throw TrainError{PS_ENOMEM};
+    }
+    void release(void* q)
+    {
+        char* p = static_cast<char*>(q);
+        auto u = used.find(p);
+        if (u == used.end()) return;
+        size_t bytes = u->second;
+        used.erase(u);
+        in_use -= bytes;
+        auto nx = free_.lower_bound(p);
+        // merge with the following block (same chunk only: chunks are separate allocations and never adjacent by contract)
+        if (nx != free_.end() && p + bytes == nx->first && same_chunk(p, nx->first)) {
+            bytes += nx->second;
+            nx = free_.erase(nx);
+        }
+        if (nx != free_.begin()) {
+            auto pv = std::prev(nx);
+            if (pv->first + pv->second == p && same_chunk(pv->first, p)) {
+                pv->second += bytes;
+                return;
+            }
+        }
+        free_[p] = bytes;
+    }
+    bool same_chunk(const char* a, const char* b) const
+    {
+        for (const Chunk& c : chunks)
+            if (a >= c.base && a < c.base + c.size) return b >= c.base && b < c.base + c.size;
+        return false;
+    }
+    // in front of a step: everything is free again
+    void begin_step()
+    {
+        if (!used.empty()) {  // a step that failed half-way
+            used.clear();
+            in_use = 0;
+            free_.clear();
+            for (const Chunk& c : chunks) free_[c.base] = c.size;
+        }
+        // (several chunks stay several chunks: the allocation sequence of a step is deterministic, so first-fit places every tensor of
+        //  the next step exactly where it was -- merging them into one allocation cost a 20 GB hipFree + hipMalloc, ~1.4 s, in step 2)
+        peak = 0;
+    }
+    void destroy()
+    {
+        if (!chunks.empty()) (void)hipDeviceSynchronize();
+        for (const Chunk& c : chunks) (void)hipFree(c.base);
+        chunks.clear();
+        free_.clear();
+        used.clear();
+        in_use = total = 0;
+    }
+};
+
+struct Block {
+    Pool* pool;
+    void* p;
+    Block(Pool* pl, void* q) : pool(pl), p(q) {}
+    ~Block() { pool->release(p); }
+    Block(const Block&) = delete;
+    Block& operator=(const Block&) = delete;
+};
+
+// a 2-D fp32 device tensor (rows contiguous, row stride ld >= C); `own` keeps the pool block alive (null: caller-owned memory)
+struct Tn {
+    float* p = nullptr;
+    int64_t R = 0, C = 0, ld = 0;
+    int id = -1;
+    bool req = false;  // takes part in the backward pass
+    std::shared_ptr<Block> own;
+    bool contiguous() const { return ld == C; }
+    int64_t numel() const { return R * C; }
+    explicit operator bool() const { return p != nullptr; }
+};
+
+// ---- small kernels of the tape itself ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tr_transpose_kernel(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst)
+{
+    // dst[c, r] = src[r, c]; 32x32 tiles through LDS (weights only: at most 1.5 M elements)
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (by + j < rows && bx + tx < cols) tile[j][tx] = src[(size_t)(by + j) * cols + bx + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (bx + j < cols && by + tx < rows) dst[(size_t)(bx + j) * rows + by + tx] = tile[tx][j];
+}
+
+template <bool ADD>
+__global__ __launch_bounds__(256) void tr_copy2d_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst, int64_t ldd, int64_t n, int C)
+{
+    for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / C;
+        const int c = (int)(e - r * C);
+        const float v = src[r * lds + c];
+        if (ADD)
+            dst[r * ldd + c] += v;
+        else
+            dst[r * ldd + c] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void tr_scale_kernel(float* __restrict__ x, int64_t n, float s)
+{
+    for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) x[e] *= s;
+}
+
+// moving statistics (the reference's extra_update_ops, RandLANet.py:90,163): moving = momentum * moving + (1 - momentum) * batch
+__global__ void tr_ema2_kernel(float* __restrict__ mov_mean, float* __restrict__ mov_var, const float* __restrict__ mean, const float* __restrict__ var, int C,
+                               float momentum)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    mov_mean[c] = mov_mean[c] * momentum + mean[c] * (1.f - momentum);
+    mov_var[c] = mov_var[c] * momentum + var[c] * (1.f - momentum);
+}
+
+// labels -> training labels (RandLANet.py:77-81: a 0 inserted at every ignored index of range(C); ignored entries become -1 here)
+__global__ __launch_bounds__(256) void tr_label_map_kernel(const int32_t* __restrict__ lab, const int32_t* __restrict__ map, int nmap, int64_t n,
+                                                           int32_t* __restrict__ out)
+{
+    for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int v = lab[e];
+        out[e] = (v >= 0 && v < nmap) ? map[v] : -1;
+    }
+}
+
+// LocSE branch, forward finish: float64 sums of y and y^2 over all rows (of all ranks) -> mean, variance, invstd, scale = gamma invstd,
+// and the moving-statistics update.  out = mean[h] | var[h] | invstd[h] | scale[h]
+__global__ void tr_locse_stats_kernel(const double* __restrict__ sums, double rows, const float* __restrict__ gamma, int h, float eps, float* __restrict__ out,
+                                      float* __restrict__ mov_mean, float* __restrict__ mov_var, float momentum)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= h) return;
+    const double m = sums[c] / rows;
+    double v = sums[h + c] / rows - m * m;  // population variance (tf.nn.moments)
+    if (v < 0.0) v = 0.0;
+    const float mean = (float)m, var = (float)v;
+    const float invstd = rsqrtf(var + eps);
+    out[c] = mean;
+    out[h + c] = var;
+    out[2 * h + c] = invstd;
+    out[3 * h + c] = gamma[c] * invstd;
+    mov_mean[c] = mov_mean[c] * momentum + mean * (1.f - momentum);
+    mov_var[c] = mov_var[c] * momentum + var * (1.f - momentum);
+}
+
+// LocSE branch, backward finish.  acc = S1[h] | S2[h] | XS[h] | A[10,h] | G[10,h] | E[16] (ps_op_locse_train_bwd); tot = S1 | S2 summed over
+// the ranks.  dgamma = S2, dbeta = S1 (this rank's); dw = k (A - E x m1 - G . m2), db = k (S1 - R m1 - XS m2), k = gamma invstd,
+// m = tot / rows of all ranks
+__global__ void tr_locse_local_kernel(const float* __restrict__ acc, int h, float* __restrict__ ggamma, float* __restrict__ gbeta, float* __restrict__ tot)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= h) return;
+    gbeta[c] = acc[c];
+    ggamma[c] = acc[h + c];
+    tot[c] = acc[c];
+    tot[h + c] = acc[h + c];
+}
+__global__ void tr_locse_wgrad_kernel(const float* __restrict__ acc, const float* __restrict__ tot, const float* __restrict__ gamma,
+                                      const float* __restrict__ invstd, int h, float rows_local, float inv_rows_total, float* __restrict__ gW,
+                                      float* __restrict__ gb)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= h) return;
+    const float m1 = tot[c] * inv_rows_total, m2 = tot[h + c] * inv_rows_total;
+    const float k = gamma[c] * invstd[c];
+    const float* A = acc + 3 * h;
+    const float* G = acc + 13 * h;
+    const float* E = acc + 23 * h;
+    for (int j = 0; j < 10; ++j) gW[j * h + c] = k * (A[j * h + c] - E[j] * m1 - G[j * h + c] * m2);
+    gb[c] = k * (acc[c] - rows_local * m1 - acc[2 * h + c] * m2);
+}
+
+__global__ void tr_pair_copy_kernel(const float* __restrict__ a, const float* __restrict__ b, int C, float* __restrict__ out)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    out[c] = a[c];
+    out[C + c] = b[c];
+}
+
+static inline unsigned tr_grid(int64_t n)
+{
+    const int64_t b = (n + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+// ---- parameter layout (point-unet_amd/weights.py: layer_dims) -------------------------------------------------------------------------
+enum LayerKind { kDense, kDenseNoBias, kConv, kConvNoBn, kDeconv };
+
+struct LayerP {
+    std::string scope;
+    LayerKind kind;
+    int cin, cout;
+    int64_t w = -1, b = -1, gamma = -1, beta = -1;  // offsets into the flat parameter / gradient buffers
+    int64_t mov_mean = -1, mov_var = -1;            // offsets into the flat BatchNorm-statistics buffer
+};
+
+struct LayoutRow {
+    std::string name;
+    int64_t offset, rows, cols;
+    int is_buffer;
+};
+
+}  // namespace ps
+
+struct ps_trainer {
+    ps_context* c = nullptr;
+    ps_randla_config cfg{};
+    ps_train_options opt{};
+    std::vector<LayerP> layers;
+    std::unordered_map<std::string, int> by_scope;
+    std::vector<LayoutRow> rows;
+    int64_t n_params = 0, n_buffers = 0;
+    float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr, *buffers = nullptr;
+    ps_allreduce_fn coll = nullptr;
+    void* coll_user = nullptr;
+    int world = 1, rank = 0;
+    bool sync_bn = false;
+    int64_t step = 0;
+    Pool pool;
+    DevBuf label_map;  // int32 [num_classes + ignored]
+    int n_label_map = 0;
+    int next_id = 0;
+
+    // ---- tape state of the step in flight
+    struct Op {
+        int out_id;
+        std::function<void(const Tn&)> bw;
+    };
+    std::vector<Op> ops;
+    std::unordered_map<int, Tn> grad_of;
+
+    hipStream_t stream() const { return c->stream; }
+
+    // ---- tensors
+    Tn alloc(int64_t R, int64_t C, bool req = true)
+    {
+        Tn t;
+        t.R = R; t.C = C; t.ld = C;
+        t.id = next_id++;
+        t.req = req;
+        void* p = pool.alloc(sizeof(float) * (size_t)std::max<int64_t>(R * C, 1));
+        t.own = std::make_shared<Block>(&pool, p);
+        t.p = static_cast<float*>(p);
+        return t;
+    }
+    Tn zeros(int64_t R, int64_t C)
+    {
+        Tn t = alloc(R, C);
+        TK_HIP(hipMemsetAsync(t.p, 0, sizeof(float) * (size_t)(R * C), stream()));
+        return t;
+    }
+    Tn cols(const Tn& t, int64_t c0, int64_t nc, bool fresh_id = true)
+    {
+        Tn v = t;
+        v.p = t.p + c0;
+        v.C = nc;
+        if (fresh_id) v.id = next_id++;
+        return v;
+    }
+    Tn rows_of(const Tn& t, int64_t r0, int64_t nr)  // (row blocks of a parameter matrix: contiguous)
+    {
+        Tn v = t;
+        v.p = t.p + r0 * t.ld;
+        v.R = nr;
+        v.id = next_id++;
+        return v;
+    }
+    Tn external(float* p, int64_t R, int64_t C, bool req)
+    {
+        Tn t;
+        t.p = p; t.R = R; t.C = C; t.ld = C; t.id = next_id++; t.req = req;
+        return t;
+    }
+    void copy2d(const Tn& src, const Tn& dst, bool add)
+    {
+        const int64_t n = src.R * src.C;
+        if (!n) return;
+        Stage st(c, "train_copies", 1);
+        if (add)
+            hipLaunchKernelGGL(tr_copy2d_kernel<true>, dim3(tr_grid(n)), dim3(256), 0, stream(), src.p, src.ld, dst.p, dst.ld, n, (int)src.C);
+        else
+            hipLaunchKernelGGL(tr_copy2d_kernel<false>, dim3(tr_grid(n)), dim3(256), 0, stream(), src.p, src.ld, dst.p, dst.ld, n, (int)src.C);
+        TK_HIP(hipGetLastError());
+    }
+    Tn contig(const Tn& t)
+    {
+        if (t.contiguous()) return t;
+        Tn o = alloc(t.R, t.C, t.req);
+        copy2d(t, o, false);
+        return o;
+    }
+    Tn transpose(const Tn& w)  // [r, c] contiguous -> fresh [c, r]
+    {
+        Tn o = alloc(w.C, w.R, false);
+        Stage st(c, "train_copies", 1);
+        hipLaunchKernelGGL(tr_transpose_kernel, dim3(ceil_div(w.C, 32), ceil_div(w.R, 32)), dim3(256), 0, stream(), w.p, (int)w.R, (int)w.C, o.p);
+        TK_HIP(hipGetLastError());
+        return o;
+    }
+    void transpose_into(const Tn& src, float* dst)
+    {
+        Stage st(c, "train_copies", 1);
+        hipLaunchKernelGGL(tr_transpose_kernel, dim3(ceil_div(src.C, 32), ceil_div(src.R, 32)), dim3(256), 0, stream(), src.p, (int)src.R, (int)src.C, dst);
+        TK_HIP(hipGetLastError());
+    }
+    void allreduce(void* buf, int64_t count, int dtype)
+    {
+        if (!coll || world <= 1) return;
+        const int rc = coll(coll_user, buf, count, dtype, (void*)stream());
+        if (rc != 0) {
+            ps::set_error("the host's all-reduce callback failed with code %d", rc);
+            throw TrainError{PS_ESTATE};
+        }
+    }
+
+    // ---- gradient bookkeeping (keys = tensor ids, like the identity keys of a Python tape)
+    void accum(const Tn& t, const Tn& g)
+    {
+        auto it = grad_of.find(t.id);
+        if (it == grad_of.end()) {
+            grad_of[t.id] = g;
+            return;
+        }
+        Tn& have = it->second;
+        if (have.contiguous() && g.contiguous())
+            TK(ps_op_axpy(c, 1.0f, g.p, g.numel(), have.p));
+        else
+            copy2d(g, have, true);
+    }
+    // the gradient buffer of t for ops that ADD into their output (scatter-add, max-pool backward): the one already recorded, or a
+    // fresh zero tensor that becomes it
+    Tn accum_buffer(const Tn& t)
+    {
+        auto it = grad_of.find(t.id);
+        if (it != grad_of.end()) return it->second;
+        Tn z = zeros(t.R, t.C);
+        grad_of[t.id] = z;
+        return z;
+    }
+    void record(const Tn& out, std::function<void(const Tn&)> bw) { ops.push_back({out.id, std::move(bw)}); }
+    void backward(const Tn& out, const Tn& dout)
+    {
+        grad_of[out.id] = dout;
+        for (size_t i = ops.size(); i-- > 0;) {
+            auto it = grad_of.find(ops[i].out_id);
+            if (it == grad_of.end()) {
+                ops[i].bw = nullptr;
+                continue;
+            }
+            Tn g = it->second;
+            grad_of.erase(it);
+            ops[i].bw(g);
+            ops[i].bw = nullptr;  // drops the activations only this op held
+        }
+        ops.clear();
+        grad_of.clear();
+    }
+
+    // ---- parameters
+    const LayerP& layer(const std::string& scope) const
+    {
+        auto it = by_scope.find(scope);
+        if (it == by_scope.end()) {
+            ps::set_error("trainer: no layer named %s", scope.c_str());
+            throw TrainError{PS_EINVAL};
+        }
+        return layers[it->second];
+    }
+    Tn P(int64_t off, int64_t R, int64_t C) { return external(params + off, R, C, false); }
+    Tn G(int64_t off, int64_t R, int64_t C) { return external(grads + off, R, C, false); }
+
+    // ---- ops (each: forward kernels now, a closure for the backward pass) -----------------------------------------------------------
+    // y = x . W (+ b).  W is [cin, cout], or [cout, cin] when transposed (conv2d_transpose kernels, helper_tf_util.py:208-212).
+    // into: an existing [R, cout] tensor of the tape that the product is ADDED to (the GEMM's accumulate epilogue); the result is that
+    // same tensor and its gradient is handed on unchanged to the op that produced it.
+    Tn linear(const Tn& x, const Tn& W, const float* b, const Tn& gW, float* gb, bool transposed = false, const Tn* into = nullptr)
+    {
+        const Tn Wm = transposed ? transpose(W) : W;  // [cin, cout]
+        const int64_t R = x.R, cin = x.C, cout = Wm.C;
+        Tn y;
+        if (!into) {
+            y = alloc(R, cout);
+            TK(ps_op_conv1x1_ex(c, x.p, x.ld, Wm.p, b, R, cin, cout, 0, 0, y.p, y.ld));
+        } else {
+            y = *into;
+            TK(ps_op_conv1x1_ex(c, x.p, x.ld, Wm.p, b, R, cin, cout, 0, 1, y.p, y.ld));
+        }
+        const bool had_into = into != nullptr;
+        const Tn into_t = had_into ? *into : Tn();
+        record(y, [=](const Tn& dy) {
+            if (had_into) grad_of[into_t.id] = dy;  // d(into + x.W)/d(into) = 1: the producer of `into` (earlier on the tape) gets the same gradient
+            if (transposed) {
+                Tn dW = alloc(cin, cout, false);
+                TK(ps_op_linear_wgrad_ex(c, x.p, x.ld, dy.p, dy.ld, R, cin, cout, dW.p, gb));
+                transpose_into(dW, gW.p);
+            } else {
+                TK(ps_op_linear_wgrad_ex(c, x.p, x.ld, dy.p, dy.ld, R, cin, cout, gW.p, gb));  // straight into the flat gradient buffer
+            }
+            if (x.req) {
+                const Tn Wt = transposed ? W : transpose(Wm);  // [cout, cin]
+                auto it = grad_of.find(x.id);
+                if (it != grad_of.end()) {
+                    // x already has a gradient from another consumer: add this one in the GEMM epilogue
+                    Tn& have = it->second;
+                    TK(ps_op_conv1x1_ex(c, dy.p, dy.ld, Wt.p, nullptr, R, cout, cin, 0, 1, have.p, have.ld));
+                } else {
+                    Tn dx = alloc(R, cin);
+                    TK(ps_op_conv1x1_ex(c, dy.p, dy.ld, Wt.p, nullptr, R, cout, cin, 0, 0, dx.p, dx.ld));
+                    accum(x, dx);
+                }
+            }
+        });
+        return y;
+    }
+
+    // y = act(BN_train(x)); out: optional [R, C] column block of a wider tensor (rows contiguous) that receives y
+    Tn bn_act(const Tn& x_in, const LayerP& lp, bool leaky, const Tn* out = nullptr)
+    {
+        const Tn x = contig(x_in);
+        const int64_t R = x.R, C = x.C;
+        Tn y = out ? *out : alloc(R, C);
+        y.req = true;
+        Tn stats = alloc(5, C, false);  // mean, invstd, var, [sum x | sum x^2]
+        float *mean = stats.p, *invstd = stats.p + C, *var = stats.p + 2 * C, *sums = stats.p + 3 * C;
+        const float *gamma = params + lp.gamma, *beta = params + lp.beta;
+        const bool sync = sync_bn && coll && world > 1;
+        const int64_t R_total = sync ? R * world : R;
+        if (!sync) {
+            TK(ps_op_bn_train_fwd_ex(c, x.p, gamma, beta, R, C, kBnEps, leaky ? 1 : 0, y.p, y.ld, mean, invstd, var, sums));
+        } else {
+            // statistics over the rows of ALL ranks: two small all-reduces per layer (2*C floats forward, 2*C backward)
+            TK(ps_op_bn_train_sums(c, x.p, R, C, sums));
+            allreduce(sums, 2 * C, 0);
+            TK(ps_op_bn_train_apply_ex(c, x.p, gamma, beta, sums, R, R_total, C, kBnEps, leaky ? 1 : 0, y.p, y.ld, mean, invstd, var));
+        }
+        {
+            Stage st(c, "train_bn_fwd", 1);
+            hipLaunchKernelGGL(tr_ema2_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream(), buffers + lp.mov_mean, buffers + lp.mov_var, mean, var, (int)C,
+                               kBnMomentum);
+            TK_HIP(hipGetLastError());
+        }
+        float *ggamma = grads + lp.gamma, *gbeta = grads + lp.beta;
+        const Tn xin = x_in;
+        record(y, [=](const Tn& dy) {
+            Tn dx = alloc(R, C);
+            if (!sync) {
+                TK(ps_op_bn_train_bwd_ex(c, dy.p, dy.ld, x.p, gamma, beta, mean, invstd, R, C, leaky ? 1 : 0, dx.p, ggamma, gbeta));
+            } else {
+                // local sums are this rank's dgamma / dbeta (averaged with every other gradient later); dx needs the global ones
+                TK(ps_op_bn_train_bwd_sums_ex(c, dy.p, dy.ld, x.p, gamma, beta, mean, invstd, R, C, leaky ? 1 : 0, ggamma, gbeta));
+                Tn tot = alloc(2, C, false);
+                hipLaunchKernelGGL(tr_pair_copy_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream(), gbeta, ggamma, (int)C, tot.p);
+                TK_HIP(hipGetLastError());
+                allreduce(tot.p, 2 * C, 0);
+                TK(ps_op_bn_train_bwd_apply_ex(c, dy.p, dy.ld, x.p, gamma, beta, mean, invstd, tot.p, tot.p + C, R, R_total, C, leaky ? 1 : 0, dx.p));
+            }
+            (void)stats;  // (mean / invstd live in it)
+            accum(xin, dx);
+        });
+        return y;
+    }
+
+    // f_xyz = LeakyReLU(BN_train(relative_pos_encoding(xyz, idx) . W + b)) -> [B*N*K, h] (out: optional column block), with nothing but
+    // that output in memory: statistics, output and every gradient are recomputed from xyz [B*N,3] and idx [B,N,K] (locse_train.hip)
+    Tn locse_bn_act(const float* xyz, const int32_t* idx, int64_t B, int64_t N, int64_t K, const LayerP& lp, const Tn* out = nullptr)
+    {
+        const int64_t h = lp.cout, R = B * N * K;
+        const bool sync = sync_bn && coll && world > 1;
+        const int64_t R_total = sync ? R * world : R;
+        const float *W = params + lp.w, *b = params + lp.b, *gamma = params + lp.gamma, *beta = params + lp.beta;
+        Tn sums = alloc(1, 4 * h, false);  // 2h doubles: the variance is a difference of nearly equal sums
+        double* s64 = reinterpret_cast<double*>(sums.p);
+        TK(ps_op_locse_train_sums(c, xyz, idx, B, N, K, W, b, h, s64));
+        if (sync) allreduce(s64, 2 * h, 1);
+        Tn st4 = alloc(4, h, false);  // mean | var | invstd | scale
+        float *mean = st4.p, *invstd = st4.p + 2 * h, *scale = st4.p + 3 * h;
+        {
+            Stage st(c, "train_locse_fwd", 1);
+            hipLaunchKernelGGL(tr_locse_stats_kernel, dim3(ceil_div(h, 64)), dim3(64), 0, stream(), s64, (double)R_total, gamma, (int)h, kBnEps, st4.p,
+                               buffers + lp.mov_mean, buffers + lp.mov_var, kBnMomentum);
+            TK_HIP(hipGetLastError());
+        }
+        Tn y = out ? *out : alloc(R, h);
+        y.req = true;
+        TK(ps_op_locse_train_apply(c, xyz, idx, B, N, K, W, b, h, mean, scale, beta, y.p, y.ld));
+        float *gW = grads + lp.w, *gb = grads + lp.b, *ggamma = grads + lp.gamma, *gbeta = grads + lp.beta;
+        record(y, [=](const Tn& dz) {
+            Tn acc = alloc(1, 23 * h + 16, false);
+            TK(ps_op_locse_train_bwd(c, xyz, idx, B, N, K, W, b, h, scale, beta, mean, invstd, dz.p, dz.ld, acc.p));
+            Tn tot = alloc(2, h, false);
+            Stage st(c, "train_locse_bwd", 2);
+            hipLaunchKernelGGL(tr_locse_local_kernel, dim3(ceil_div(h, 64)), dim3(64), 0, stream(), acc.p, (int)h, ggamma, gbeta, tot.p);
+            TK_HIP(hipGetLastError());
+            if (sync) allreduce(tot.p, 2 * h, 0);
+            hipLaunchKernelGGL(tr_locse_wgrad_kernel, dim3(ceil_div(h, 64)), dim3(64), 0, stream(), acc.p, tot.p, gamma, invstd, (int)h, (float)R,
+                               1.0f / (float)R_total, gW, gb);
+            TK_HIP(hipGetLastError());
+            (void)st4;
+        });
+        return y;
+    }
+
+    // x [B*N, d], idx [B, M, K] -> [B*M*K, d]; out: optional column block of a wider tensor that receives the rows
+    Tn gather(const Tn& x_in, const int32_t* idx, int64_t B, int64_t M, int64_t K, const Tn* out = nullptr)
+    {
+        const Tn x = contig(x_in);
+        const int64_t N = x.R / B, d = x.C;
+        Tn o = out ? *out : alloc(B * M * K, d);
+        o.req = true;
+        TK(ps_op_gather_neighbour_ex(c, x.p, idx, B, N, M, K, d, o.p, o.ld));
+        const Tn xin = x_in;
+        record(o, [=](const Tn& dy) {
+            Tn buf = accum_buffer(xin);
+            if (!buf.contiguous()) {
+                ps::set_error("trainer: scatter-add into a strided gradient");
+                throw TrainError{PS_ESTATE};
+            }
+            TK(ps_op_scatter_add_rows_ex(c, dy.p, dy.ld, idx, B, N, M * K, d, buf.p));
+        });
+        return o;
+    }
+
+    // buf [R, ca+cb] whose left / right column blocks a and b were written in place by their producers: the concat costs nothing, and
+    // its backward hands the column blocks of the gradient on as views
+    Tn concat_views(const Tn& buf, const Tn& a, const Tn& b)
+    {
+        Tn o = buf;
+        o.req = true;
+        const int64_t ca = a.C, cb = b.C;
+        record(o, [=](const Tn& dy) {
+            if (a.req) accum(a, cols(dy, 0, ca));
+            if (b.req) accum(b, cols(dy, ca, cb));
+        });
+        return o;
+    }
+
+    Tn softpool(const Tn& fset, const Tn& scores, int64_t K)
+    {
+        const int64_t RK = fset.R, d = fset.C, R = RK / K;
+        const Tn fs = contig(fset), sc = contig(scores);
+        Tn probs = alloc(RK, d, false), agg = alloc(R, d);
+        TK(ps_op_softmax_pool_fwd(c, fs.p, sc.p, R, K, d, probs.p, agg.p));
+        record(agg, [=](const Tn& dy_in) {
+            const Tn dy = contig(dy_in);
+            Tn dfset = alloc(RK, d), dscores = alloc(RK, d);
+            TK(ps_op_softmax_pool_bwd(c, dy.p, fs.p, probs.p, R, K, d, dfset.p, dscores.p));
+            accum(fset, dfset);
+            accum(scores, dscores);
+        });
+        return agg;
+    }
+
+    // att_pooling's score product + softmax over K + weighted sum as ONE kernel per direction (attpool_train.hip)
+    Tn attpool(const Tn& fset, const Tn& W, const Tn& gW, int64_t K)
+    {
+        const int64_t RK = fset.R, d = fset.C, R = RK / K;
+        Tn agg = alloc(R, d);
+        TK(ps_op_att_pool_train_fwd(c, fset.p, fset.ld, W.p, R, K, d, agg.p));
+        record(agg, [=](const Tn& dy_in) {
+            const Tn dy = contig(dy_in);
+            Tn dfset = alloc(RK, d);
+            TK(ps_op_att_pool_train_bwd(c, fset.p, fset.ld, W.p, dy.p, R, K, d, dfset.p, d, gW.p));
+            accum(fset, dfset);
+        });
+        return agg;
+    }
+
+    // attpool over fset = [gather(f_src, idx) | f_xyz] without the gather, the concat buffer or the scatter-add of its gradient
+    Tn attpool_split(const Tn& f_src_in, const int32_t* idx, int64_t B, int64_t M, int64_t K, const Tn& f_xyz, const Tn& W, const Tn& gW)
+    {
+        const Tn f_src = f_src_in;
+        const int64_t N = f_src.R / B, h = f_src.C, d = 2 * h;
+        Tn agg = alloc(B * M, d);
+        TK(ps_op_att_pool_train_fwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, K, d, agg.p));
+        record(agg, [=](const Tn& dy_in) {
+            const Tn dy = contig(dy_in);
+            Tn dfx = alloc(B * M * K, h);
+            Tn dsrc = accum_buffer(f_src);  // the gathered half's gradient is added in place
+            TK(ps_op_att_pool_train_bwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, dy.p, K, d, dsrc.p, dsrc.ld, dfx.p, h, gW.p));
+            accum(f_xyz, dfx);
+        });
+        return agg;
+    }
+
+    Tn maxpool(const Tn& x_in, const int32_t* pool_idx, int64_t B, int64_t M, int64_t K)
+    {
+        const Tn x = contig(x_in);
+        const int64_t N = x.R / B, d = x.C;
+        Tn out = alloc(B * M, d);
+        TK(ps_op_random_sample(c, x.p, pool_idx, B, N, M, K, d, out.p));
+        const Tn xin = x_in;
+        record(out, [=](const Tn& dy_in) {
+            const Tn dy = contig(dy_in);
+            Tn buf = accum_buffer(xin);
+            TK(ps_op_random_sample_bwd(c, dy.p, out.p, x.p, pool_idx, B, N, M, K, d, buf.p));
+        });
+        return out;
+    }
+
+    Tn add_lrelu(const Tn& a, const Tn& b)
+    {
+        Tn y = alloc(a.R, a.C);
+        TK(ps_op_add_lrelu(c, a.p, b.p, a.numel(), y.p));
+        record(y, [=](const Tn& dy_in) {
+            const Tn dy = contig(dy_in);
+            Tn ds = alloc(a.R, a.C);
+            TK(ps_op_add_lrelu_bwd(c, dy.p, y.p, a.numel(), ds.p));
+            // the same values are the gradient of both summands: two tensors only where one of them already has a gradient to add to
+            Tn ds2 = alloc(a.R, a.C);
+            TK_HIP(hipMemcpyAsync(ds2.p, ds.p, sizeof(float) * (size_t)a.numel(), hipMemcpyDeviceToDevice, stream()));
+            accum(a, ds);
+            accum(b, ds2);
+        });
+        return y;
+    }
+
+    Tn dropout(const Tn& x, float keep_prob, uint32_t seed)
+    {
+        if (keep_prob >= 1.0f) return x;
+        Tn y = alloc(x.R, x.C), mask = alloc(x.R, x.C, false);
+        TK(ps_op_dropout(c, x.p, x.numel(), seed, keep_prob, y.p, mask.p));
+        record(y, [=](const Tn& dy_in) {
+            const Tn dy = contig(dy_in);
+            Tn dx = alloc(x.R, x.C);
+            TK(ps_op_mul(c, dy.p, mask.p, x.numel(), dx.p));
+            accum(x, dx);
+        });
+        return y;
+    }
+
+    // ---- graph pieces (RandLANet.py call sites) -----------------------------------------------------------------------------------------
+    Tn Wt(const LayerP& lp) { return lp.kind == kDeconv ? P(lp.w, lp.cout, lp.cin) : P(lp.w, lp.cin, lp.cout); }
+    Tn gWt(const LayerP& lp) { return lp.kind == kDeconv ? G(lp.w, lp.cout, lp.cin) : G(lp.w, lp.cin, lp.cout); }
+
+    // helper_tf_util.conv2d / conv2d_transpose (:115-250): 1x1 conv + bias [+ BatchNorm(training) [+ LeakyReLU(0.2)]]
+    Tn conv(const Tn& x, const std::string& scope, bool bn = true, bool act = true, const Tn* out = nullptr)
+    {
+        const LayerP& lp = layer(scope);
+        Tn y = linear(x, Wt(lp), lp.b >= 0 ? params + lp.b : nullptr, gWt(lp), lp.b >= 0 ? grads + lp.b : nullptr, lp.kind == kDeconv);
+        if (bn) y = bn_act(y, lp, act, out);
+        return y;
+    }
+    Tn att_split(const Tn& f_src, const int32_t* idx, int64_t B, int64_t M, int64_t K, const Tn& f_xyz, const std::string& name)
+    {
+        const LayerP& fc = layer(name + "fc");
+        Tn agg = attpool_split(f_src, idx, B, M, K, f_xyz, P(fc.w, fc.cin, fc.cout), G(fc.w, fc.cin, fc.cout));
+        return conv(agg, name + "mlp");
+    }
+    // att_pooling with the score product in the pre-product form of the inference kernels: fset . Wfc = (f . Wfc[:h])[idx] + f_xyz . Wfc[h:]
+    Tn att_pre(const Tn& f_src, const int32_t* idx, int64_t B, int64_t M, int64_t K, const Tn& fcat, const Tn& f_xyz, const std::string& name)
+    {
+        const LayerP& fc = layer(name + "fc");
+        const Tn W = P(fc.w, fc.cin, fc.cout), gW = G(fc.w, fc.cin, fc.cout);
+        const int64_t h = f_src.C;
+        Tn s = gather(linear(f_src, rows_of(W, 0, h), nullptr, rows_of(gW, 0, h), nullptr), idx, B, M, K);
+        s = linear(f_xyz, rows_of(W, h, W.R - h), nullptr, rows_of(gW, h, W.R - h), nullptr, false, &s);
+        return conv(softpool(fcat, s, K), name + "mlp");
+    }
+    Tn att(const Tn& fcat, const std::string& name, int64_t K)
+    {
+        const LayerP& fc = layer(name + "fc");
+        const Tn W = P(fc.w, fc.cin, fc.cout), gW = G(fc.w, fc.cin, fc.cout);
+        Tn agg;
+        if (opt.fused_att && ps_op_att_pool_train_supported(K, fcat.C)) {
+            agg = attpool(fcat, W, gW, K);  // levels whose [N*K, d] tensors are large: one kernel per direction
+        } else {
+            Tn s = linear(fcat, W, nullptr, gW, nullptr);
+            agg = softpool(fcat, s, K);
+        }
+        return conv(agg, name + "mlp");
+    }
+
+    // Network.inference in training mode (RandLANet.py:110-152); features [B*N0, Cin] -> logits [B*N0, classes]
+    Tn forward(const ps_pyramid* pyr, const float* features)
+    {
+        const int L = cfg.num_layers;
+        const int64_t B = pyr->B, K = cfg.k_n;
+        Tn x = external(const_cast<float*>(features), B * pyr->n[0], cfg.in_channels, false);
+        const LayerP& fc0 = layer("fc0");
+        Tn f = linear(x, P(fc0.w, fc0.cin, fc0.cout), params + fc0.b, G(fc0.w, fc0.cin, fc0.cout), grads + fc0.b);
+        f = bn_act(f, fc0, true);
+        std::vector<Tn> enc;
+        for (int i = 0; i < L; ++i) {
+            const std::string n = "Encoder_layer_" + std::to_string(i);
+            const int32_t* idx = pyr->neigh_idx[i];
+            const int64_t N = pyr->n[i];
+            const Tn feature = f;
+            Tn f_pc = conv(feature, n + "mlp1");
+            const LayerP& lfa1 = layer(n + "LFAmlp1");
+            const int64_t hloc = lfa1.cout;
+            const bool locse_fused = opt.fused_locse && !opt.mlp_bf16 && ps_op_locse_train_supported(K, hloc);
+            Tn rel;
+            if (!locse_fused) {
+                rel = alloc(B * N * K, 10, false);
+                TK(ps_op_relative_pos_encoding(c, pyr->xyz[i], idx, B, N, K, rel.p));
+            }
+            auto locse = [&](const Tn* out) -> Tn {
+                if (!locse_fused) return conv(rel, n + "LFAmlp1", true, true, out);
+                return locse_bn_act(pyr->xyz[i], idx, B, N, K, lfa1, out);
+            };
+            // tf.concat([f_neighbours, f_xyz]) (RandLANet.py:328,332): both producers write their column block of the concat buffer
+            // directly (no concat copy forward, no split copies backward)
+            const int64_t hc = f_pc.C;
+            Tn f_agg2;
+            if (opt.fused_att && ps_op_att_pool_train_supported(K, 2 * hc)) {
+                // gather_neighbour + concat + att_pooling's core as one kernel per direction
+                Tn f_xyz = locse(nullptr);
+                Tn f_agg = att_split(f_pc, idx, B, N, K, f_xyz, n + "LFAatt_pooling_1");
+                Tn f_xyz2 = conv(f_xyz, n + "LFAmlp2");
+                f_agg2 = att_split(f_agg, idx, B, N, K, f_xyz2, n + "LFAatt_pooling_2");
+            } else {
+                // (d = 128: the pre-product form measured slower, HBM bound there; bf16 mode: its yardstick rounds the operands of the ONE d x d product)
+                const bool pre = !opt.mlp_bf16 && 2 * hc >= 256;
+                Tn cat1 = alloc(B * N * K, 2 * hc);
+                Tn right1 = cols(cat1, hc, hc);
+                Tn f_xyz = locse(&right1);
+                Tn left1 = cols(cat1, 0, hc);
+                Tn f_nb = gather(f_pc, idx, B, N, K, &left1);
+                Tn fcat1 = concat_views(cat1, f_nb, f_xyz);
+                Tn f_agg = pre ? att_pre(f_pc, idx, B, N, K, fcat1, f_xyz, n + "LFAatt_pooling_1") : att(fcat1, n + "LFAatt_pooling_1", K);
+                Tn cat2 = alloc(B * N * K, 2 * hc);
+                Tn right2 = cols(cat2, hc, hc);
+                Tn f_xyz2 = conv(f_xyz, n + "LFAmlp2", true, true, &right2);
+                Tn left2 = cols(cat2, 0, hc);
+                Tn f_nb2 = gather(f_agg, idx, B, N, K, &left2);
+                Tn fcat2 = concat_views(cat2, f_nb2, f_xyz2);
+                f_agg2 = pre ? att_pre(f_agg, idx, B, N, K, fcat2, f_xyz2, n + "LFAatt_pooling_2") : att(fcat2, n + "LFAatt_pooling_2", K);
+            }
+            Tn a = conv(f_agg2, n + "mlp2", true, false);
+            Tn b = conv(feature, n + "shortcut", true, false);
+            Tn f_enc = add_lrelu(a, b);
+            f = maxpool(f_enc, pyr->sub_idx[i], B, pyr->n[i + 1], K);
+            if (i == 0) enc.push_back(f_enc);
+            enc.push_back(f);
+        }
+        f = conv(enc.back(), "decoder_0");
+        for (int j = 0; j < L; ++j) {
+            // nearest_interpolation + tf.concat([skip, up]) (RandLANet.py:134-143): the gather writes the right column block of the concat
+            // buffer, the skip rows are copied into the left one
+            const Tn& skip = enc[enc.size() - 2 - j];
+            const int lvl = L - 1 - j;
+            const int64_t M = pyr->n[lvl];
+            Tn cat = alloc(B * M, skip.C + f.C);
+            Tn right = cols(cat, skip.C, f.C);
+            Tn up = gather(f, pyr->interp_idx[lvl], B, M, 1, &right);
+            Tn left = cols(cat, 0, skip.C, false);  // (same id as nothing recorded: the copy below has its own backward)
+            left.id = next_id++;
+            copy2d(skip, left, false);
+            left.req = true;
+            {
+                const Tn sk = skip;
+                record(left, [=](const Tn& dy) { accum(sk, contig(dy)); });  // (consumers such as the max-pool backward ADD into a dense buffer)
+            }
+            Tn both = concat_views(cat, left, up);
+            f = conv(both, "Decoder_layer_" + std::to_string(j));
+        }
+        f = conv(f, "fc1");
+        f = conv(f, "fc2");
+        // every rank draws its own mask (N GPUs x 1 cloud behaves like 1 GPU x N clouds, where the clouds sit at different element offsets)
+        f = dropout(f, opt.keep_prob, (uint32_t)(0x9e3779b9u * (uint32_t)(step + 1) + 0x85ebca6bu * (uint32_t)rank));
+        return conv(f, "fc", false, false);
+    }
+};
+
+namespace ps {
+
+static void build_layout(ps_trainer* t)
+{
+    const ps_randla_config& cfg = t->cfg;
+    const int L = cfg.num_layers;
+    auto add = [&](const std::string& scope, LayerKind kind, int cin, int cout) {
+        LayerP lp;
+        lp.scope = scope; lp.kind = kind; lp.cin = cin; lp.cout = cout;
+        t->by_scope[scope] = (int)t->layers.size();
+        t->layers.push_back(lp);
+    };
+    add("fc0", kDense, cfg.in_channels, 8);
+    int d_in = 8;
+    for (int i = 0; i < L; ++i) {
+        const int d = cfg.d_out[i], h = d / 2;
+        const std::string n = "Encoder_layer_" + std::to_string(i);
+        add(n + "mlp1", kConv, d_in, h);
+        add(n + "LFAmlp1", kConv, 10, h);
+        add(n + "LFAatt_pooling_1fc", kDenseNoBias, d, d);
+        add(n + "LFAatt_pooling_1mlp", kConv, d, h);
+        add(n + "LFAmlp2", kConv, h, h);
+        add(n + "LFAatt_pooling_2fc", kDenseNoBias, d, d);
+        add(n + "LFAatt_pooling_2mlp", kConv, d, d);
+        add(n + "mlp2", kConv, d, 2 * d);
+        add(n + "shortcut", kConv, d_in, 2 * d);
+        d_in = 2 * d;
+    }
+    add("decoder_0", kConv, d_in, d_in);
+    std::vector<int> chans;  // f_encoder_list channel widths (RandLANet.py:119-127)
+    chans.push_back(2 * cfg.d_out[0]);
+    for (int i = 0; i < L; ++i) chans.push_back(2 * cfg.d_out[i]);
+    int up = d_in;
+    for (int j = 0; j < L; ++j) {
+        const int skip = chans[chans.size() - 2 - j];
+        add("Decoder_layer_" + std::to_string(j), kDeconv, skip + up, skip);
+        up = skip;
+    }
+    add("fc1", kConv, up, 64);
+    add("fc2", kConv, 64, 32);
+    add("fc", kConvNoBn, 32, cfg.num_classes);
+
+    int64_t off = 0, boff = 0;
+    for (LayerP& lp : t->layers) {
+        const bool dense = lp.kind == kDense || lp.kind == kDenseNoBias;
+        const std::string wname = lp.scope + (dense ? "/kernel" : "/weights"), bname = lp.scope + (dense ? "/bias" : "/biases");
+        const std::string bn = lp.kind == kDense ? std::string("batch_normalization") : lp.scope + "/batch_normalization";  // fc0's BN is un-scoped
+        lp.w = off;
+        const int64_t wr = lp.kind == kDeconv ? lp.cout : lp.cin, wc = lp.kind == kDeconv ? lp.cin : lp.cout;
+        t->rows.push_back({wname, off, wr, wc, 0});
+        off += (int64_t)lp.cin * lp.cout;
+        if (lp.kind != kDenseNoBias) {
+            lp.b = off;
+            t->rows.push_back({bname, off, 1, lp.cout, 0});
+            off += lp.cout;
+        }
+        if (lp.kind == kDense || lp.kind == kConv || lp.kind == kDeconv) {
+            lp.gamma = off;
+            t->rows.push_back({bn + "/gamma", off, 1, lp.cout, 0});
+            off += lp.cout;
+            lp.beta = off;
+            t->rows.push_back({bn + "/beta", off, 1, lp.cout, 0});
+            off += lp.cout;
+            lp.mov_mean = boff;
+            t->rows.push_back({bn + "/moving_mean", boff, 1, lp.cout, 1});
+            boff += lp.cout;
+            lp.mov_var = boff;
+            t->rows.push_back({bn + "/moving_variance", boff, 1, lp.cout, 1});
+            boff += lp.cout;
+        }
+    }
+    t->n_params = off;
+    t->n_buffers = boff;
+}
+
+static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features, const int32_t* labels, const float* class_weights, float* loss,
+                    float* logits_out, bool optimise)
+{
+    ps_context* c = t->c;
+    PS_CHECK(t->params && t->grads && t->buffers, "trainer: ps_trainer_bind has not been called");
+    PS_CHECK(!optimise || (t->adam_m && t->adam_v), "ps_randla_train_step: the Adam moment buffers are not bound");
+    PS_CHECK(pyr && features && labels && class_weights && loss, "trainer: NULL argument");
+    PS_CHECK(pyr->num_layers == t->cfg.num_layers && pyr->K == t->cfg.k_n, "trainer: the pyramid does not match the network (layers / K)");
+    PS_HIP(hipSetDevice(c->device));
+    const bool bf16 = t->opt.mlp_bf16 != 0;
+    const bool was_bf16 = c->train_bf16;
+    int rc = PS_OK;
+    try {
+        t->pool.begin_step();
+        t->next_id = 0;
+        t->ops.clear();
+        t->grad_of.clear();
+        c->train_bf16 = bf16;
+        Tn logits = t->forward(pyr, features);
+        const int64_t R = logits.R, C = logits.C;
+        const int32_t* lab = labels;
+        Tn mapped;
+        if (t->n_label_map) {
+            mapped = t->alloc(1, R, false);
+            hipLaunchKernelGGL(tr_label_map_kernel, dim3(tr_grid(R)), dim3(256), 0, c->stream, labels, t->label_map.as<int32_t>(), t->n_label_map, R,
+                               reinterpret_cast<int32_t*>(mapped.p));
+            TK_HIP(hipGetLastError());
+            lab = reinterpret_cast<const int32_t*>(mapped.p);
+        }
+        Tn dlogits = t->alloc(R, C);
+        TK_HIP(hipMemsetAsync(loss, 0, sizeof(float), c->stream));
+        TK(ps_op_weighted_ce(c, logits.p, lab, class_weights, R, C, loss, dlogits.p));
+        if (logits_out) TK_HIP(hipMemcpyAsync(logits_out, logits.p, sizeof(float) * (size_t)(R * C), hipMemcpyDeviceToDevice, c->stream));
+        t->backward(logits, dlogits);
+    } catch (const TrainError& e) {
+        rc = e.rc;
+    } catch (const std::bad_alloc&) {
+        ps::set_error("trainer: out of host memory");
+        rc = PS_ENOMEM;
+    }
+    c->train_bf16 = was_bf16;  // the context may be shared with inference-side op calls: never leave the mode on
+    t->ops.clear();
+    t->grad_of.clear();
+    if (rc != PS_OK) return rc;
+    if (!optimise) return PS_OK;
+    try {
+        if (t->coll && t->world > 1) {
+            // gradient synchronisation of config 4: ONE all-reduce of the flat fp32 gradient buffer, then the mean over the ranks
+            t->allreduce(t->grads, t->n_params, 0);
+            Stage st(c, "train_adam", 1);
+            hipLaunchKernelGGL(tr_scale_kernel, dim3(tr_grid(t->n_params)), dim3(256), 0, c->stream, t->grads, t->n_params, 1.0f / (float)t->world);
+            TK_HIP(hipGetLastError());
+        }
+    } catch (const TrainError& e) {
+        return e.rc;
+    }
+    t->step += 1;
+    return ps_op_adam(c, t->params, t->grads, t->adam_m, t->adam_v, t->n_params, t->opt.learning_rate, 0.9f, 0.999f, 1e-8f, t->step);
+}
+
+}  // namespace ps
+
+extern "C" {
+
+int ps_trainer_create(ps_context* c, const ps_randla_config* cfg, const ps_train_options* opt, ps_trainer** out)
+{
+    PS_CHECK(c && cfg && opt && out, "ps_trainer_create: NULL argument");
+    PS_CHECK(cfg->num_layers >= 1 && cfg->num_layers <= PS_MAX_LAYERS && cfg->k_n >= 1 && cfg->num_classes >= 1 && cfg->in_channels >= 1,
+             "ps_trainer_create: bad configuration");
+    PS_CHECK(opt->keep_prob > 0.f && opt->keep_prob <= 1.f && opt->learning_rate > 0.f, "ps_trainer_create: keep_prob must be in (0, 1], learning_rate > 0");
+    PS_CHECK(opt->num_ignored >= 0 && opt->num_ignored <= 8, "ps_trainer_create: at most 8 ignored labels");
+    for (int i = 0; i < cfg->num_layers; ++i) PS_CHECK(cfg->d_out[i] >= 2 && cfg->d_out[i] % 2 == 0, "ps_trainer_create: d_out must be even");
+    ps_trainer* t = new ps_trainer();
+    t->c = c;
+    t->cfg = *cfg;
+    t->opt = *opt;
+    build_layout(t);
+    if (opt->num_ignored > 0) {
+        // RandLANet.py:77-81: reducing_list = range(C) with a 0 inserted at every ignored index (ascending); ignored entries become -1 here
+        std::vector<int32_t> red;
+        for (int i = 0; i < cfg->num_classes; ++i) red.push_back(i);
+        std::vector<int> ign(opt->ignored_label_inds, opt->ignored_label_inds + opt->num_ignored);
+        std::sort(ign.begin(), ign.end());
+        for (int v : ign) {
+            if (v < 0 || v > (int)red.size()) {
+                delete t;
+                ps::set_error("ps_trainer_create: ignored label %d out of range", v);
+                return PS_EINVAL;
+            }
+            red.insert(red.begin() + v, -1);
+        }
+        t->n_label_map = (int)red.size();
+        int rc = t->label_map.reserve(sizeof(int32_t) * red.size());
+        if (rc != PS_OK) {
+            delete t;
+            return rc;
+        }
+        hipError_t e = hipMemcpy(t->label_map.p, red.data(), sizeof(int32_t) * red.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            delete t;
+            ps::set_error("ps_trainer_create: label map upload failed: %s", hipGetErrorString(e));
+            return PS_EHIP;
+        }
+    }
+    *out = t;
+    return PS_OK;
+}
+
+int ps_trainer_destroy(ps_trainer* t)
+{
+    if (!t) return PS_OK;
+    t->ops.clear();
+    t->grad_of.clear();
+    t->pool.destroy();
+    t->label_map.release();
+    delete t;
+    return PS_OK;
+}
+
+int64_t ps_trainer_param_count(const ps_trainer* t) { return t ? t->n_params : -1; }
+int64_t ps_trainer_buffer_count(const ps_trainer* t) { return t ? t->n_buffers : -1; }
+int ps_trainer_layout_rows(const ps_trainer* t) { return t ? (int)t->rows.size() : -1; }
+
+int ps_trainer_layout(const ps_trainer* t, int row, char* name, int name_cap, int64_t* offset, int64_t* rows, int64_t* cols, int* is_buffer)
+{
+    PS_CHECK(t && row >= 0 && row < (int)t->rows.size(), "ps_trainer_layout: row out of range");
+    const LayoutRow& r = t->rows[row];
+    if (name && name_cap > 0) {
+        std::strncpy(name, r.name.c_str(), (size_t)name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (offset) *offset = r.offset;
+    if (rows) *rows = r.rows;
+    if (cols) *cols = r.cols;
+    if (is_buffer) *is_buffer = r.is_buffer;
+    return PS_OK;
+}
+
+int ps_trainer_bind(ps_trainer* t, float* params, float* grads, float* adam_m, float* adam_v, float* bn_buffers)
+{
+    PS_CHECK(t && params && grads && bn_buffers, "ps_trainer_bind: params, grads and bn_buffers are required");
+    t->params = params;
+    t->grads = grads;
+    t->adam_m = adam_m;
+    t->adam_v = adam_v;
+    t->buffers = bn_buffers;
+    return PS_OK;
+}
+
+int ps_trainer_set_collective(ps_trainer* t, ps_allreduce_fn fn, void* user, int world_size, int rank, int sync_bn)
+{
+    PS_CHECK(t && world_size >= 1 && rank >= 0 && rank < world_size, "ps_trainer_set_collective: bad world size / rank");
+    PS_CHECK(fn || world_size == 1, "ps_trainer_set_collective: a world of %d ranks needs an all-reduce callback", world_size);
+    t->coll = fn;
+    t->coll_user = user;
+    t->world = world_size;
+    t->rank = rank;
+    t->sync_bn = sync_bn != 0;
+    return PS_OK;
+}
+
+int ps_trainer_set_step(ps_trainer* t, int64_t step)
+{
+    PS_CHECK(t && step >= 0, "ps_trainer_set_step: bad argument");
+    t->step = step;
+    return PS_OK;
+}
+
+int64_t ps_trainer_get_step(const ps_trainer* t) { return t ? t->step : -1; }
+
+int ps_trainer_set_options(ps_trainer* t, const ps_train_options* opt)
+{
+    PS_CHECK(t && opt, "ps_trainer_set_options: NULL argument");
+    PS_CHECK(opt->keep_prob > 0.f && opt->keep_prob <= 1.f && opt->learning_rate > 0.f, "ps_trainer_set_options: keep_prob must be in (0, 1], learning_rate > 0");
+    PS_CHECK(opt->num_ignored == t->opt.num_ignored, "ps_trainer_set_options: the ignored labels are fixed at creation");
+    t->opt = *opt;
+    return PS_OK;
+}
+
+int64_t ps_trainer_pool_peak_bytes(const ps_trainer* t) { return t ? (int64_t)t->pool.peak : -1; }
+
+int ps_randla_backward(ps_trainer* t, const ps_pyramid* pyr, const float* features, const int32_t* labels, const float* class_weights, float* loss,
+                       float* logits)
+{
+    PS_CHECK(t, "ps_randla_backward: trainer is NULL");
+    return run_step(t, pyr, features, labels, class_weights, loss, logits, false);
+}
+
+int ps_randla_train_step(ps_trainer* t, const ps_pyramid* pyr, const float* features, const int32_t* labels, const float* class_weights, float* loss,
+                         float* logits)
+{
+    PS_CHECK(t, "ps_randla_train_step: trainer is NULL");
+    return run_step(t, pyr, features, labels, class_weights, loss, logits, true);
+}
+
+}  // extern "C"

@@ -25,9 +25,9 @@ from .RandLANet import Network
 
 
 class _Lane:
-    def __init__(self, config, params, device, seed):
-        self.stream = torch.cuda.Stream(torch.device("cuda", device))
-        self.ctx = runtime.Context(device)
+    def __init__(self, config, params, device, seed, stream=None, ctx=None):
+        self.stream = stream if stream is not None else torch.cuda.Stream(torch.device("cuda", device))
+        self.ctx = ctx if ctx is not None else runtime.Context(device)
         self.ctx.set_stream(self.stream)
         self.ctx.set_deferred_checks(True)  # tree-build status words are validated at synchronize()
         self.net = Network(config, params=params, device=device, seed=seed, ctx=self.ctx)
@@ -37,13 +37,31 @@ class _Lane:
 
 
 class ForwardPipeline:
-    def __init__(self, config, params=None, device=0, seed=0, lanes=4):
+    def __init__(self, config, params=None, device=0, seed=0, lanes=4, reuse=None):
+        """reuse: a ForwardPipeline that is done (another network / configuration): its lanes' HIP streams and contexts (workspaces) are
+        taken over instead of creating new ones and it must not be used afterwards.  Every extra stream a process has touched costs:
+        measured with this very class, a second pipeline on four NEW streams runs 2.33 ms pipelined / 4.3 ms serial per 262 144-point
+        cloud against 1.93 / 2.63 ms for the same pipeline alone in a process (profiles/tools/exp_second_pipeline.py: four idle streams
+        taken from torch's pool beforehand are enough; GPU_MAX_HW_QUEUES=10 does the same to the FIRST pipeline) -- dependent kernels
+        on streams spread over more hardware queues are scheduled later."""
         self.cfg = config
         self.device = torch.device("cuda", device)
         if params is None:
             from . import weights
             params = weights.init_params(config, seed=seed)
-        self.lanes = [_Lane(config, params, device, seed) for _ in range(int(lanes))]
+        if reuse is not None:
+            reuse.synchronize()
+            old = reuse.lanes
+            reuse.lanes = []
+            for ln in old:
+                ln.net.close()
+            self.lanes = [_Lane(config, params, device, seed, stream=ln.stream, ctx=ln.ctx) for ln in old[:int(lanes)]]
+            for ln in old[int(lanes):]:
+                ln.ctx.close()
+            while len(self.lanes) < int(lanes):
+                self.lanes.append(_Lane(config, params, device, seed))
+        else:
+            self.lanes = [_Lane(config, params, device, seed) for _ in range(int(lanes))]
         self._shape = None
         self._i = 0
         self.last_done = None

@@ -5,10 +5,15 @@ dropout), class-weighted cross-entropy, backward, Adam -- the device counterpart
     Network.train's sess.run([train_op, extra_update_ops, ...])   PointSegment/RandLANet.py:162-169
     tf.layers.batch_normalization(..., training=True)             helper_tf_util.py:167,246; RandLANet.py:115
 
-The reference relies on TF autodiff; here the host records a tape of op-level HIP kernels (csrc/ops_train.hip,
-csrc/ops.hip, csrc/rowgemm.hip through the C ABI) and replays it backwards.  This is the straightforward, unfused
-formulation ([B,N,K,C] tensors are materialised like the reference does); PyTorch only provides device buffers,
-concatenation/slicing copies and -- for config 4 -- the RCCL all-reduce of the flat gradient buffer.
+The reference relies on TF autodiff.  Here the whole step is ONE call through the C ABI, `ps_randla_train_step`
+(csrc/trainer.hip: the tape, the activation pool and the BatchNorm moving-statistics updates live in C++; include/pointseg.h).
+`Trainer` below is the host-side holder: it owns the flat parameter / gradient / Adam / statistics buffers as torch tensors
+(named views in the reference's variable names), binds them to the native trainer, and supplies the collective -- torch.distributed's
+all-reduce (RCCL on the GPU box) wrapped as the C callback the library asks for.
+
+`Trainer(engine="python")` keeps the earlier host-side tape (class Tape below: the same op-level kernels recorded and replayed
+from Python) as the A/B reference of the native engine and as the home of experimental pieces that are not part of the native
+step (fused_convbn).
 
 Multi-GPU: one cloud per GPU, gradients averaged with ONE all-reduce of the flat fp32 buffer
 (4 992 852 floats for BraTS).  BatchNorm statistics are per-GPU by default (the reference itself never runs batch > 1);
@@ -445,13 +450,20 @@ class Trainer:
     """Parameters (flat fp32 buffer + named views), Adam state and the train step."""
 
     def __init__(self, config, params=None, device=0, seed=0, learning_rate=None, class_weights=None, keep_prob=0.5, ctx=None, sync_bn=False,
-                 mlp_dtype="fp32", ignored_label_inds=None, fused_att=True, fused_locse=True, fused_convbn=False):
+                 mlp_dtype="fp32", ignored_label_inds=None, fused_att=True, fused_locse=True, fused_convbn=False, engine="native"):
         """sync_bn: with a `dist` passed to train_step, BatchNorm uses the statistics of all ranks' rows, which makes "W GPUs x
         one cloud" numerically the same step as "one GPU x W clouds" (SURVEY 8e); off = per-GPU statistics.
         mlp_dtype: "fp32" (default) or "bf16" -- BASELINE configs[2]'s "bf16 MLPs": the shared-MLP GEMMs (forward, input gradient,
-        weight gradient) round their operands to bf16 and accumulate in fp32 (ps_set_train_gemm_bf16); everything else stays fp32."""
+        weight gradient) round their operands to bf16 and accumulate in fp32 (ps_set_train_gemm_bf16); everything else stays fp32.
+        engine: "native" (default) = ps_randla_train_step, the tape in C++ (csrc/trainer.hip); "python" = the host-side tape of this
+        file (A/B reference; the only engine with fused_convbn)."""
         if mlp_dtype not in ("fp32", "bf16"):
             raise ValueError("mlp_dtype must be 'fp32' or 'bf16'")
+        if engine not in ("native", "python"):
+            raise ValueError("engine must be 'native' or 'python'")
+        if fused_convbn and engine == "native":
+            engine = "python"  # (measured slower than the streaming kernels it replaces: kept out of the native step)
+        self.engine = engine
         self.mlp_bf16 = mlp_dtype == "bf16"
         self.fused_att = bool(fused_att)  # False: the op-by-op attentive pooling everywhere (A/B switch of bench.py --no-fused-att)
         # LocSE branch (relative_pos_encoding -> conv 10->h -> BatchNorm -> LeakyReLU) recomputed from coordinates and indices instead of
@@ -469,38 +481,42 @@ class Trainer:
         self.keep_prob = keep_prob
         params = params if params is not None else weights.init_params(config, seed=seed)
         self.lr = float(learning_rate if learning_rate is not None else getattr(config, "learning_rate", 1e-4))
-        train_names, buf_names = [], []
-        for scope, kind, cin, cout in weights.layer_dims(config):
-            if kind in ("dense", "dense_nobias"):
-                train_names.append(scope + "/kernel")
-                if kind == "dense":
-                    train_names += [scope + "/bias", "batch_normalization/gamma", "batch_normalization/beta"]
-                    buf_names += ["batch_normalization/moving_mean", "batch_normalization/moving_variance"]
-            else:
-                train_names += [scope + "/weights", scope + "/biases"]
-                if kind != "conv_nobn":
-                    bn = scope + "/batch_normalization"
-                    train_names += [bn + "/gamma", bn + "/beta"]
-                    buf_names += [bn + "/moving_mean", bn + "/moving_variance"]
-        self.names = train_names
-        sizes = [int(np.prod(params[n].shape)) for n in train_names]
-        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=self.device)
+        ign = ignored_label_inds if ignored_label_inds is not None else getattr(config, "ignored_label_inds", [])
+        self.ignored_label_inds = sorted(int(v) for v in ign)
+        # the native trainer defines the layout of the flat buffers (csrc/trainer.hip: build_layout == weights.layer_dims order)
+        lib = _lib.lib()
+        rc = _lib.PsRandlaConfig()
+        rc.num_layers, rc.k_n, rc.num_classes, rc.in_channels = config.num_layers, config.k_n, config.num_classes, config.in_channels
+        for i in range(config.num_layers):
+            rc.d_out[i] = config.d_out[i]
+        self._h = ctypes.c_void_p()
+        _lib.check(lib.ps_trainer_create(self.ctx.handle, ctypes.byref(rc), ctypes.byref(self._options()), ctypes.byref(self._h)))
+        n_par, n_buf = lib.ps_trainer_param_count(self._h), lib.ps_trainer_buffer_count(self._h)
+        self.flat = torch.empty(n_par, dtype=torch.float32, device=self.device)
         self.grad = torch.zeros_like(self.flat)
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
-        self.P, self.G = {}, {}
-        off = 0
-        for n, sz in zip(train_names, sizes):
+        self.flat_buffers = torch.empty(n_buf, dtype=torch.float32, device=self.device)
+        self.P, self.G, self.buffers, self.names = {}, {}, {}, []
+        name = ctypes.create_string_buffer(256)
+        off, nr, nc, isb = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        for row in range(lib.ps_trainer_layout_rows(self._h)):
+            _lib.check(lib.ps_trainer_layout(self._h, row, name, 256, ctypes.byref(off), ctypes.byref(nr), ctypes.byref(nc), ctypes.byref(isb)))
+            n = name.value.decode()
             shape = tuple(params[n].shape)
-            self.P[n] = self.flat[off:off + sz].view(shape)
-            self.G[n] = self.grad[off:off + sz].view(shape)
-            self.P[n].copy_(torch.from_numpy(np.ascontiguousarray(params[n])))
-            off += sz
-        self.buffers = {n: torch.from_numpy(np.ascontiguousarray(params[n])).to(self.device) for n in buf_names}
+            assert int(np.prod(shape)) == nr.value * nc.value, (n, shape, nr.value, nc.value)
+            src = torch.from_numpy(np.ascontiguousarray(params[n]))
+            if isb.value:
+                self.buffers[n] = self.flat_buffers[off.value:off.value + src.numel()].view(shape)
+                self.buffers[n].copy_(src)
+            else:
+                self.names.append(n)
+                self.P[n] = self.flat[off.value:off.value + src.numel()].view(shape)
+                self.G[n] = self.grad[off.value:off.value + src.numel()].view(shape)
+                self.P[n].copy_(src)
+        _lib.check(lib.ps_trainer_bind(self._h, _p(self.flat), _p(self.grad), _p(self.m), _p(self.v), _p(self.flat_buffers)))
         cw = class_weights if class_weights is not None else np.ones(config.num_classes, np.float32)
         self.class_weights = torch.from_numpy(np.asarray(cw, np.float32).reshape(-1)).to(self.device)
-        ign = ignored_label_inds if ignored_label_inds is not None else getattr(config, "ignored_label_inds", [])
-        self.ignored_label_inds = sorted(int(v) for v in ign)
         self.label_map = None
         if self.ignored_label_inds:
             # RandLANet.py:77-81: reducing_list = range(C) with a 0 inserted at every ignored index; ignored entries become -1 here
@@ -510,29 +526,57 @@ class Trainer:
             self.label_map = torch.tensor(red, dtype=torch.int32, device=self.device)
         self.step = 0
         self._rank = 0
+        self._coll = None  # (callback object, dist) kept alive while the native trainer may call it
+        self._warned_export = False
+
+    def _options(self):
+        o = _lib.PsTrainOptions()
+        o.learning_rate, o.keep_prob = self.lr, self.keep_prob
+        o.mlp_bf16, o.fused_att, o.fused_locse = int(self.mlp_bf16), int(self.fused_att), int(self.fused_locse)
+        o.num_ignored = len(self.ignored_label_inds)
+        for i, v in enumerate(self.ignored_label_inds):
+            o.ignored_label_inds[i] = v
+        return o
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.lib().ps_trainer_destroy(h)
+
+    def __del__(self):
+        try:
+            if getattr(self.ctx, "handle", None):
+                self.close()
+        except Exception:
+            pass
 
     def num_params(self):
         return self.flat.numel()
 
     def sync_buffers(self, dist):
         """BatchNorm moving statistics averaged over the ranks (they differ between GPUs when sync_bn is off: every rank has
-        seen its own clouds).  Call before export_params() / checkpointing in a multi-GPU run."""
+        seen its own clouds).  COLLECTIVE: every rank must call it (it all-reduces) -- call it on all ranks, then let rank 0 write
+        the checkpoint."""
         if dist is None or not self.buffers:
             return
-        names = sorted(self.buffers)
-        flat = torch.cat([self.buffers[n].reshape(-1) for n in names])
-        allreduce_mean_(flat, dist)
-        off = 0
-        for n in names:
-            k = self.buffers[n].numel()
-            self.buffers[n].copy_(flat[off:off + k].view_as(self.buffers[n]))
-            off += k
+        allreduce_mean_(self.flat_buffers, dist)
 
     def export_params(self, dist=None):
+        """Parameter dict in the reference's variable names.  With `dist` this is a COLLECTIVE call (sync_buffers): the pattern
+        `if rank == 0: save(trainer.export_params(dist))` deadlocks the other ranks -- call export_params(dist) on every rank and
+        save on one.  Without `dist` in a multi-GPU run with per-GPU BatchNorm statistics the export holds THIS rank's moving
+        statistics only (the reference has a single set): a warning says so once."""
+        if dist is None and self._world > 1 and not self.sync_bn and not self._warned_export:
+            import warnings
+            warnings.warn("Trainer.export_params() without `dist` in a %d-rank run with per-GPU BatchNorm statistics: the exported moving "
+                          "statistics are rank-local; call export_params(dist) (or sync_buffers(dist)) on ALL ranks first" % self._world)
+            self._warned_export = True
         self.sync_buffers(dist)
         out = {n: self.P[n].detach().cpu().numpy().copy() for n in self.names}
         out.update({n: b.cpu().numpy().copy() for n, b in self.buffers.items()})
         return out
+
+    _world = 1
 
     # ---- graph pieces ------------------------------------------------------------------------------------------------
     def _conv(self, t, x, scope, bn=True, act=True, transposed=False, out=None):
@@ -658,9 +702,80 @@ class Trainer:
         with torch.cuda.stream(own):  # a context with its own stream (a pipeline lane): torch's helper ops follow it
             return self._train_step(pyr, features, labels, dist)
 
+    def _collective(self, dist):
+        """torch.distributed's all-reduce as the C callback of ps_trainer_set_collective.  The library hands over a raw device pointer
+        on the context's stream (= torch's current stream here); it is wrapped without a copy through __cuda_array_interface__."""
+        if self._coll is not None and self._coll[1] is dist:
+            return self._coll[0]
+        device = self.device
+
+        class _Raw:
+            def __init__(self, ptr, count, f64):
+                self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8" if f64 else "<f4", "data": (int(ptr), False), "version": 2}
+
+        def cb(user, buf, count, dtype, stream):
+            try:
+                t = torch.as_tensor(_Raw(buf, count, dtype == 1), device=device)
+                dist.all_reduce(t)
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                import sys
+                print("all-reduce callback failed: %r" % (e,), file=sys.stderr)
+                return 1
+
+        fn = _lib.PS_ALLREDUCE_FN(cb)
+        self._coll = (fn, dist)
+        return fn
+
     def _train_step(self, pyr, features, labels, dist):
+        if self.engine == "python":
+            return self._train_step_python(pyr, features, labels, dist)
+        lib = _lib.lib()
+        self._rank = dist.get_rank() if dist is not None else 0
+        self._world = dist.get_world_size() if dist is not None else 1
+        if dist is not None:
+            _lib.check(lib.ps_trainer_set_collective(self._h, self._collective(dist), None, self._world, self._rank, 1 if self.sync_bn else 0))
+        else:
+            _lib.check(lib.ps_trainer_set_collective(self._h, _lib.PS_ALLREDUCE_FN(), None, 1, 0, 0))  # NULL callback: single rank
+        _lib.check(lib.ps_trainer_set_options(self._h, ctypes.byref(self._options())))
+        _lib.check(lib.ps_trainer_set_step(self._h, self.step))
+        B, n0 = features.shape[0], features.shape[1]
+        feats = features.reshape(-1, features.shape[-1]).contiguous()
+        if feats.dtype != torch.float32:
+            feats = feats.float()
+        lab = labels.reshape(-1).to(torch.int32).contiguous()
+        loss = torch.zeros(1, dtype=torch.float32, device=feats.device)
+        logits = torch.empty((B * n0, self.cfg.num_classes), dtype=torch.float32, device=feats.device)
+        _lib.check(lib.ps_randla_train_step(self._h, ctypes.byref(pyr.struct), _p(feats), _p(lab), _p(self.class_weights), _p(loss), _p(logits)))
+        self.step = int(lib.ps_trainer_get_step(self._h))
+        self.last_logits = logits
+        return loss
+
+    def backward_only(self, pyr, features, labels):
+        """ps_randla_backward: training-mode forward + loss + backward, gradients left in self.grad / self.G (this rank's, no collective,
+        no optimiser step) -- for hosts that run their own gradient synchronisation or optimiser."""
+        lib = _lib.lib()
+        _lib.check(lib.ps_trainer_set_options(self._h, ctypes.byref(self._options())))
+        _lib.check(lib.ps_trainer_set_step(self._h, self.step))
+        B, n0 = features.shape[0], features.shape[1]
+        feats = features.reshape(-1, features.shape[-1]).contiguous().float()
+        lab = labels.reshape(-1).to(torch.int32).contiguous()
+        loss = torch.zeros(1, dtype=torch.float32, device=feats.device)
+        logits = torch.empty((B * n0, self.cfg.num_classes), dtype=torch.float32, device=feats.device)
+        own = getattr(self.ctx, "_stream", None)
+        if own is None:
+            self.ctx.use_torch_stream()
+        _lib.check(lib.ps_randla_backward(self._h, ctypes.byref(pyr.struct), _p(feats), _p(lab), _p(self.class_weights), _p(loss), _p(logits)))
+        self.last_logits = logits
+        return loss
+
+    def pool_peak_bytes(self):
+        return int(_lib.lib().ps_trainer_pool_peak_bytes(self._h))
+
+    def _train_step_python(self, pyr, features, labels, dist):
         lib, h = _lib.lib(), self.ctx.handle
         self._rank = dist.get_rank() if dist is not None else 0
+        self._world = dist.get_world_size() if dist is not None else 1
         t = Tape(self.ctx, sync=dist if (self.sync_bn and dist is not None) else None)
         if self.mlp_bf16:
             _lib.check(lib.ps_set_train_gemm_bf16(h, 1))

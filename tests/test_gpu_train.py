@@ -776,3 +776,77 @@ def test_streaming_gemm_for_millions_of_rows():
         assert (y.double() - refb).abs().max() <= 2e-5 * refb.abs().max(), (R, cin, cout)
         del buf, x, y, ref, refb, want
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_native_step_equals_the_python_tape(mode):
+    """ps_randla_train_step (csrc/trainer.hip: tape, activation pool and moving-statistics updates in C++, ONE C-ABI call per step)
+    against Trainer(engine="python") (the host-side tape of point-unet_amd/train.py recording the same op-level kernels): same
+    parameters, same clouds, dropout ON (the mask is a counter hash of (element, step, rank): identical in both), two consecutive
+    steps.  Same kernels in the same order; what differs is the [h]-sized finishing arithmetic of the LocSE BatchNorm (torch float ops
+    there, one small kernel here: last-bit differences in mean / invstd) and the float atomics of the gradient sums, so the bars are:
+    loss 2e-6 relative, logits 2e-5 of their magnitude, moving statistics 1e-5; gradients relative L2 5e-3 -- the bar of the fp32 step
+    against float64 autograd: at 6 000 points the deepest BatchNorms see 23 rows and a last-bit change of an activation next to a
+    leaky-ReLU kink moves the gradient by 1e-3 (measured between the engines: 2.7e-3) -- and parameters after Adam relative L2 1e-3
+    (Adam moves a noise-level entry by up to 2 lr when its gradient's sign flips: max |diff| <= 2.1 lr)."""
+    import torch
+    from point_unet_amd import weights
+    from point_unet_amd.pyramid import build_pyramid
+    from point_unet_amd.train import Trainer
+    cfg, xyz, feats = netcase.small_deep(6000, seed=21, B=2)
+    params = weights.init_params(cfg, seed=5, randomize_bn=True)
+    rng = np.random.default_rng(3)
+    labels = rng.integers(0, cfg.num_classes, xyz.shape[:2]).astype(np.int32)
+    cw = np.linspace(1.0, 2.0, cfg.num_classes).astype(np.float32)
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    d_feats, d_lab = torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
+    runs = {}
+    for engine in ("native", "python"):
+        tr = Trainer(cfg, params=params, learning_rate=1e-3, class_weights=cw, keep_prob=0.5, mlp_dtype=mode, engine=engine)
+        assert tr.engine == engine and tr.num_params() == weights.num_params(cfg)
+        out = []
+        for _ in range(2):
+            loss = tr.train_step(pyr, d_feats, d_lab)
+            torch.cuda.synchronize()
+            out.append(dict(loss=float(loss), logits=tr.last_logits.cpu().numpy().copy(), grad=tr.grad.cpu().numpy().copy(),
+                            flat=tr.flat.cpu().numpy().copy(), buffers={k: v.cpu().numpy().copy() for k, v in tr.buffers.items()}))
+        assert tr.step == 2
+        runs[engine] = out
+        if engine == "native":
+            assert tr.pool_peak_bytes() > 0
+        tr.close() if hasattr(tr, "close") else None
+    for a, b in zip(runs["native"], runs["python"]):
+        assert abs(a["loss"] - b["loss"]) <= 2e-6 * abs(b["loss"]), (a["loss"], b["loss"])
+        assert np.abs(a["logits"].reshape(b["logits"].shape) - b["logits"]).max() <= 2e-5 * np.abs(b["logits"]).max()
+        for k in b["buffers"]:
+            assert np.abs(a["buffers"][k] - b["buffers"][k]).max() <= 1e-5 * max(1.0, np.abs(b["buffers"][k]).max()), k
+        assert np.linalg.norm(a["grad"] - b["grad"]) <= 5e-3 * np.linalg.norm(b["grad"])
+        assert np.abs(a["flat"] - b["flat"]).max() <= 2.1e-3
+        assert np.linalg.norm(a["flat"] - b["flat"]) <= 1e-3 * np.linalg.norm(b["flat"])
+
+
+def test_backward_only_leaves_the_parameters_alone():
+    """ps_randla_backward = the step without the collective and without Adam: gradients as train_step computes them, parameters and
+    Adam moments untouched, moving statistics updated."""
+    import torch
+    from point_unet_amd import weights
+    from point_unet_amd.pyramid import build_pyramid
+    from point_unet_amd.train import Trainer
+    cfg, xyz, feats = netcase.small_deep(3000, seed=4, B=1)
+    params = weights.init_params(cfg, seed=6, randomize_bn=True)
+    labels = np.random.default_rng(0).integers(0, cfg.num_classes, xyz.shape[:2]).astype(np.int32)
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    d_feats, d_lab = torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
+    a = Trainer(cfg, params=params, learning_rate=1e-3, keep_prob=1.0)
+    b = Trainer(cfg, params=params, learning_rate=1e-3, keep_prob=1.0)
+    before = a.flat.clone()
+    la = a.backward_only(pyr, d_feats, d_lab)
+    lb = b.train_step(pyr, d_feats, d_lab)
+    torch.cuda.synchronize()
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb))
+    assert torch.equal(a.flat, before) and float(a.m.abs().max()) == 0.0 and a.step == 0
+    assert not torch.equal(b.flat, before)
+    assert np.linalg.norm((a.grad - b.grad).cpu().numpy()) <= 1e-4 * np.linalg.norm(b.grad.cpu().numpy())
+    assert torch.allclose(a.flat_buffers, b.flat_buffers, rtol=1e-6, atol=1e-7)
+    mm = a.buffers["Encoder_layer_0mlp1/batch_normalization/moving_mean"].cpu().numpy()
+    assert not np.array_equal(mm, params["Encoder_layer_0mlp1/batch_normalization/moving_mean"])
