@@ -429,6 +429,13 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
         prof_rows = ctx.timing_end()
     elapsed, loss = timed_region(step, args.steps, sync, dist)
     assert bool(torch.isfinite(loss).all())
+    sections = None
+    if tr.engine == "native" and not args.no_stage_timing:  # per-level device time of one more step (outside the timed region)
+        tr.set_profile(True)
+        step()
+        sync()
+        sections = [{"name": nm, "ms": round(t, 4)} for nm, t in tr.profile()]
+        tr.set_profile(False)
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         stages = sorted(({"name": nm, "ms_per_step": round(t / prof_steps, 4), "launches_per_step": ln / prof_steps} for nm, t, ln in prof_rows),
@@ -447,7 +454,7 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
                                        2 if world == 1 else 3, n0, B, "bf16 MLP GEMMs (fp32 accumulate), rest fp32" if args.bf16_mlp else "fp32",
                                        (", gradient all-reduce over RCCL, BatchNorm statistics %s" % ("per GPU" if args.local_bn else "shared by all ranks")) if world > 1 else ""),
                        "points": n0, "batch_per_gpu": B, "parameters": tr.num_params()},
-            "roofline": roofline, "stages": stages, "launches_per_step": sum(r["launches_per_step"] for r in stages) if stages else None,
+            "roofline": roofline, "sections": sections, "stages": stages, "launches_per_step": sum(r["launches_per_step"] for r in stages) if stages else None,
             "engine": tr.engine, "loss": float(loss), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
             "pool_peak_gb": tr.pool_peak_bytes() / 2 ** 30 if tr.engine == "native" else None,
         }

@@ -377,9 +377,10 @@ typedef struct ps_trainer ps_trainer;
 typedef struct {
     float learning_rate;            /* cfg.learning_rate (helper_tool.py:33); Adam beta1 0.9, beta2 0.999, eps 1e-8 (TF defaults) */
     float keep_prob;                /* dropout in front of the last layer, RandLANet.py:148 (0.5) */
-    int32_t mlp_bf16;               /* BASELINE configs[2] "bf16 MLPs": the shared-MLP GEMMs round their operands to bf16 (fp32 accumulate) */
+    int32_t mlp_bf16;               /* BASELINE configs[2] "bf16 MLPs": the shared-MLP GEMMs round their operands to bf16 (fp32 accumulate);
+                                     * the LocSE convolution 10 -> h (position encoding, K = 10) stays fp32 */
     int32_t fused_att;              /* attentive pooling (+ gather / concat / scatter-add) as one kernel per direction where compiled (d <= 64) */
-    int32_t fused_locse;            /* the LocSE branch recomputed from coordinates and indices instead of materialised (fp32 mode only) */
+    int32_t fused_locse;            /* the LocSE branch recomputed from coordinates and indices instead of materialised */
     int32_t num_ignored;            /* cfg.ignored_label_inds (RandLANet.py:68-81): labels dropped from the loss, <= 8 */
     int32_t ignored_label_inds[8];
 } ps_train_options;
@@ -402,6 +403,11 @@ int ps_trainer_set_options(ps_trainer* t, const ps_train_options* opt);  /* ever
 int ps_trainer_set_step(ps_trainer* t, int64_t step);                    /* optimisation steps taken so far (checkpoint resume) */
 int64_t ps_trainer_get_step(const ps_trainer* t);
 int64_t ps_trainer_pool_peak_bytes(const ps_trainer* t);                 /* activation + gradient footprint of the last step */
+/* on != 0: every step records hipEvents at its section boundaries (fc0, each encoder level, decoder, head; forward and backward
+ * separately; loss, gradient all-reduce, Adam) and synchronises at its end; ps_trainer_profile returns the last step's rows
+ * (name, device ms; `launches` unused).  Off by default. */
+int ps_trainer_set_profile(ps_trainer* t, int on);
+int ps_trainer_profile(const ps_trainer* t, ps_timing_row* rows, int cap, int* n_rows);
 /* Training-mode forward + class-weighted cross-entropy + backward: fills the bound gradient buffer (this rank's gradients, no
  * collective), updates the BatchNorm moving statistics, writes the loss (device float) and optionally the logits
  * f32[B*N0, classes] (NULL: not wanted).  features f32[B,N0,in_channels], labels i32[B,N0], class_weights f32[classes]; device pointers. */

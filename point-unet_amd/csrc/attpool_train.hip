@@ -283,6 +283,226 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
     }
 }
 
+// ---- bf16 mode on the bf16 matrix pipe ---------------------------------------------------------------------------------------------------
+// Trainer(mlp_dtype="bf16") rounds the operands of the three products to bfloat16; the kernels above then multiply the rounded values on
+// the fp32 MFMA (same results as a bf16 MFMA with fp32 accumulation, but at the fp32 rate: 1/16 of the bf16 pipe).  The kernels below keep
+// the rounded operands AS bfloat16 in LDS -- both weight orientations, the tile of F and the tile of dS -- and run the products on
+// v_mfma_f32_16x16x16_bf16: lane (i, g) supplies k = 4g .. 4g+3, i.e. ONE 8-byte LDS read per operand and sixteen k per instruction
+// (D/16 instructions per 16 x 16 output tile instead of D/4); the output layout is that of the fp32 16x16x4 tile, so the softmax, the
+// direct term, the stores and the per-workgroup dWfc reduction are unchanged.  LDS pitches are 32 bytes (mod 128): the 64 lanes' 8-byte
+// reads spread over the banks four to a word, the minimum.
+typedef short bf16x4s __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bf16_bits(float x)
+{
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (finite inputs)
+    return u >> 16;
+}
+
+template <int D>
+struct AttBf16Geom {
+    static constexpr int PB = D == 16 ? 16 : (D == 32 ? 48 : 80);  // bfloat16 elements per tile / weight row: 32, 96, 160 bytes
+    static constexpr int PA = D + 2;                                // fp32 value tile (the weighted sum uses the unrounded F)
+    static constexpr int NT = D / 16;
+};
+
+// W (row-major [D, D]) -> Wb[i][j] = bf16(W[i][j]) and WTb[j][i] = bf16(W[i][j]); either may be null
+template <int D, int THREADS>
+__device__ __forceinline__ void stage_weights_bf16(const float* __restrict__ w, unsigned short* Wb, unsigned short* WTb)
+{
+    constexpr int PB = AttBf16Geom<D>::PB;
+    for (int i = threadIdx.x; i < D * D; i += THREADS) {
+        const int r = i / D, c = i - r * D;
+        const unsigned short v = (unsigned short)bf16_bits(w[i]);
+        if (Wb) Wb[r * PB + c] = v;
+        if (WTb) WTb[c * PB + r] = v;
+    }
+}
+
+// the K x D tile of point p -> A (fp32, pitch PA) and Xb (bfloat16, pitch PB); plain or split-source rows
+template <int D, int KN>
+__device__ __forceinline__ void load_tile_bf16(const AttTrainArgs& a, int64_t p, float* A, unsigned short* Xb, int lane)
+{
+    constexpr int PA = AttBf16Geom<D>::PA, PB = AttBf16Geom<D>::PB, Q = D / 4, QH = Q / 2, TOT = KN * Q;
+    const int64_t base = a.fl ? (p / a.n_q) * a.n_src : 0;
+#pragma unroll
+    for (int e0 = 0; e0 < TOT; e0 += 64) {
+        const int e = e0 + lane;
+        if (TOT % 64 == 0 || e < TOT) {
+            const int row = e / Q, q = e - row * Q;
+            float4 v;
+            if (!a.fl)
+                v = *reinterpret_cast<const float4*>(a.f + (size_t)(p * KN + row) * a.ld + 4 * q);
+            else if (q < QH)
+                v = *reinterpret_cast<const float4*>(a.fl + (size_t)(base + a.idx[p * KN + row]) * a.ldl + 4 * q);
+            else
+                v = *reinterpret_cast<const float4*>(a.f + (size_t)(p * KN + row) * a.ld + 4 * (q - QH));
+            float* dst = A + row * PA + 4 * q;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            uint2 pk;
+            pk.x = bf16_bits(v.x) | (bf16_bits(v.y) << 16);
+            pk.y = bf16_bits(v.z) | (bf16_bits(v.w) << 16);
+            *reinterpret_cast<uint2*>(Xb + row * PB + 4 * q) = pk;
+        }
+    }
+}
+
+// C[k][c] = sum_j X[k][j] B[j][16 ct + c] with X rows and the B columns both stored k-contiguous: Xb[row][j], Bt[col][j]
+template <int D>
+__device__ __forceinline__ f32x4 tile_mma_bf16(const unsigned short* Xb, const unsigned short* Bt, int ct, int lane, f32x4 acc)
+{
+    constexpr int PB = AttBf16Geom<D>::PB;
+    const bf16x4s* xa = reinterpret_cast<const bf16x4s*>(Xb + (lane & 15) * PB + 4 * (lane >> 4));
+    const bf16x4s* wb = reinterpret_cast<const bf16x4s*>(Bt + (ct * 16 + (lane & 15)) * PB + 4 * (lane >> 4));
+#pragma unroll
+    for (int kk = 0; kk < D / 16; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xa[4 * kk], wb[4 * kk], acc, 0, 0, 0);
+    return acc;
+}
+
+template <int D, int KN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void att_train_fwd_bf16_kernel(AttTrainArgs a)
+{
+    static_assert(KN == 16, "one 16-row tile per point");
+    constexpr int PB = AttBf16Geom<D>::PB, PA = AttBf16Geom<D>::PA, NT = D / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* WTb = reinterpret_cast<unsigned short*>(smem);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    constexpr int W_FLOATS = D * PB / 2, TILE_FLOATS = KN * PA + KN * PB / 2;
+    float* A = smem + W_FLOATS + wave * TILE_FLOATS;
+    unsigned short* Xb = reinterpret_cast<unsigned short*>(A + KN * PA);
+    stage_weights_bf16<D, WAVES * 64>(a.w, nullptr, WTb);
+    __syncthreads();
+    for (int64_t p = (int64_t)blockIdx.x * WAVES + wave; p < a.R; p += (int64_t)gridDim.x * WAVES) {
+        load_tile_bf16<D, KN>(a, p, A, Xb, lane);
+        wave_lds_sync();
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            const f32x4 s = tile_mma_bf16<D>(Xb, WTb, ct, lane, f32x4{0.f, 0.f, 0.f, 0.f});
+            float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+            m = xor_max(m);
+            float ssum = 0.f, num = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[r] - m);
+                ssum += e;
+                num = __builtin_fmaf(e, A[(4 * g + r) * PA + ct * 16 + c16], num);
+            }
+            ssum = xor_sum(ssum);
+            num = xor_sum(num);
+            if (g == 0) a.agg[(size_t)p * D + ct * 16 + c16] = num / ssum;
+        }
+        wave_lds_sync();
+    }
+}
+
+template <int D, int KN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrainArgs a)
+{
+    static_assert(KN == 16, "one 16-row tile per point");
+    constexpr int PB = AttBf16Geom<D>::PB, PA = AttBf16Geom<D>::PA, NT = D / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int W_FLOATS = D * PB / 2, TILE_FLOATS = KN * PA + 2 * (KN * PB / 2);
+    unsigned short* Wb = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* WTb = reinterpret_cast<unsigned short*>(smem + W_FLOATS);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    float* A = smem + 2 * W_FLOATS + wave * TILE_FLOATS;
+    unsigned short* Xb = reinterpret_cast<unsigned short*>(A + KN * PA);
+    unsigned short* Tb = Xb + KN * PB;  // dS, rounded: it only ever feeds the two products
+    stage_weights_bf16<D, WAVES * 64>(a.w, Wb, WTb);
+    __syncthreads();
+
+    f32x4 dw[NT][NT];  // this wave's share of dWfc: tile (ti, tj) = rows 16 ti.., columns 16 tj..
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) dw[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t p = (int64_t)blockIdx.x * WAVES + wave; p < a.R; p += (int64_t)gridDim.x * WAVES) {
+        load_tile_bf16<D, KN>(a, p, A, Xb, lane);
+        wave_lds_sync();
+        f32x4 dfd[NT];  // direct term p * g of every column tile (seeds the second product)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            const f32x4 s = tile_mma_bf16<D>(Xb, WTb, ct, lane, f32x4{0.f, 0.f, 0.f, 0.f});
+            float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+            m = xor_max(m);
+            float e[4], fv[4], ssum = 0.f, num = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[r] = __expf(s[r] - m);
+                fv[r] = A[(4 * g + r) * PA + ct * 16 + c16];
+                ssum += e[r];
+                num = __builtin_fmaf(e[r], fv[r], num);
+            }
+            ssum = xor_sum(ssum);
+            num = xor_sum(num);
+            const float inv = 1.f / ssum, agg = num * inv;
+            const float gch = a.dagg[(size_t)p * D + ct * 16 + c16];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = e[r] * inv;
+                dfd[ct][r] = pr * gch;
+                Tb[(4 * g + r) * PB + ct * 16 + c16] = (unsigned short)bf16_bits(pr * gch * (fv[r] - agg));
+            }
+        }
+        wave_lds_sync();
+        // ---- dF = p . g + dS . Wfc^T  -> global:  out[row][i] = sum_j dS[row][j] W[i][j]  (B columns = rows of W: Wb) ----
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+            const f32x4 acc = tile_mma_bf16<D>(Tb, Wb, tj, lane, dfd[tj]);
+            if (!a.fl) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a.df[(size_t)(p * KN + 4 * g + r) * a.lddf + tj * 16 + c16] = acc[r];
+            } else {
+                const int col = tj * 16 + c16;
+                if (col >= D / 2) {  // f_xyz half: plain rows
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a.df[(size_t)(p * KN + 4 * g + r) * a.lddf + col - D / 2] = acc[r];
+                } else {             // gathered half: scatter-add onto the source rows
+                    const int4 nb = *reinterpret_cast<const int4*>(a.idx + p * KN + 4 * g);
+                    const int64_t base = (p / a.n_q) * a.n_src;
+                    atomicAdd(a.dfl + (size_t)(base + nb.x) * a.lddl + col, acc[0]);
+                    atomicAdd(a.dfl + (size_t)(base + nb.y) * a.lddl + col, acc[1]);
+                    atomicAdd(a.dfl + (size_t)(base + nb.z) * a.lddl + col, acc[2]);
+                    atomicAdd(a.dfl + (size_t)(base + nb.w) * a.lddl + col, acc[3]);
+                }
+            }
+        }
+        // ---- dWfc += F^T . dS: ONE 16-row contraction per tile pair (lane (i, g) supplies rows 4g .. 4g+3 of column i) ----
+        {
+            bf16x4s fa[NT], db[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const unsigned short* xp = Xb + (4 * g) * PB + t * 16 + c16;
+                const unsigned short* tp = Tb + (4 * g) * PB + t * 16 + c16;
+                fa[t] = bf16x4s{(short)xp[0], (short)xp[PB], (short)xp[2 * PB], (short)xp[3 * PB]};
+                db[t] = bf16x4s{(short)tp[0], (short)tp[PB], (short)tp[2 * PB], (short)tp[3 * PB]};
+            }
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) dw[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fa[ti], db[tj], dw[ti][tj], 0, 0, 0);
+        }
+        wave_lds_sync();
+    }
+    // ---- the workgroup's dWfc partial: waves add up through LDS (fixed order), one plain store per element ----
+    __syncthreads();
+    float* red = smem;  // weights and tiles are dead: the whole buffer holds the WAVES partials (sized for it on the host)
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(size_t)wave * D * D + (ti * 16 + 4 * g + r) * D + tj * 16 + c16] = dw[ti][tj][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < D * D; i += WAVES * 64) {
+        float sum = 0.f;
+        for (int w = 0; w < WAVES; ++w) sum += red[(size_t)w * D * D + i];
+        a.dw_part[(size_t)blockIdx.x * D * D + i] = sum;
+    }
+}
+
 __global__ __launch_bounds__(256) void att_train_dw_reduce_kernel(const float* __restrict__ part, int n_part, int dd, float* __restrict__ dw)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -297,7 +517,29 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
 {
     constexpr int KN = 16, WAVES = 8;
     constexpr int PW = AttTrainGeom<D>::PW, PA = AttTrainGeom<D>::PA;
-    const size_t tiles = (size_t)WAVES * (a.bf16 ? (backward ? 3 : 2) : (backward ? 2 : 1)) * KN * PA;
+    if (a.bf16) {  // the bf16-MLP mode: operands kept as bfloat16 in LDS, products on the bf16 matrix pipe
+        constexpr int PB = AttBf16Geom<D>::PB;
+        size_t smem = sizeof(float) * ((backward ? 2 : 1) * (size_t)(D * PB / 2) + (size_t)WAVES * (KN * PA + (backward ? 2 : 1) * (KN * PB / 2)));
+        if (backward) smem = std::max(smem, sizeof(float) * (size_t)WAVES * D * D);
+        PS_CHECK(smem <= 160 * 1024, "att_pool_train: %zu bytes of LDS needed", smem);
+        const int per_cu = std::max(1, std::min(4, (int)(160 * 1024 / smem)));
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + WAVES - 1) / WAVES, 256 * per_cu));
+        if (!backward) {
+            auto kern = att_train_fwd_bf16_kernel<D, KN, WAVES>;
+            if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
+        } else {
+            PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * D * D + 256));
+            a.dw_part = c->red_ws.as<float>();
+            auto kern = att_train_bwd_bf16_kernel<D, KN, WAVES>;
+            if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
+            hipLaunchKernelGGL(att_train_dw_reduce_kernel, dim3(ceil_div(D * D, 256)), dim3(256), 0, c->stream, a.dw_part, blocks, D * D, dW);
+        }
+        PS_HIP(hipGetLastError());
+        return PS_OK;
+    }
+    const size_t tiles = (size_t)WAVES * (backward ? 2 : 1) * KN * PA;
     size_t smem = sizeof(float) * ((backward ? 2 : 1) * (size_t)D * PW + tiles);
     if (backward) smem = std::max(smem, sizeof(float) * (size_t)WAVES * D * D);
     PS_CHECK(smem <= 160 * 1024, "att_pool_train: %zu bytes of LDS needed", smem);

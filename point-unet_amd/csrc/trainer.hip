@@ -321,9 +321,51 @@ struct ps_trainer {
     int n_label_map = 0;
     int next_id = 0;
 
+    // ---- per-section device time of a step (ps_trainer_profile): hipEvents at the section boundaries of the forward pass, and in the
+    // backward pass wherever the section of the op in hand changes
+    bool profile = false;
+    int section = 0;
+    std::vector<std::string> section_names;
+    std::vector<std::pair<std::string, hipEvent_t>> marks;
+    std::vector<std::pair<std::string, double>> profile_rows;
+    int begin_section(const std::string& name)
+    {
+        section_names.push_back(name);
+        section = (int)section_names.size() - 1;
+        mark("fwd " + name);
+        return section;
+    }
+    void mark(const std::string& name)
+    {
+        if (!profile) return;
+        hipEvent_t e;
+        TK_HIP(hipEventCreate(&e));
+        TK_HIP(hipEventRecord(e, stream()));
+        marks.emplace_back(name, e);
+    }
+    void finish_profile()
+    {
+        if (!profile) return;
+        mark("end");
+        (void)hipStreamSynchronize(stream());
+        std::map<std::string, double> acc;
+        std::vector<std::string> order;
+        for (size_t i = 0; i + 1 < marks.size(); ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, marks[i].second, marks[i + 1].second);
+            if (!acc.count(marks[i].first)) order.push_back(marks[i].first);
+            acc[marks[i].first] += ms;
+        }
+        for (auto& m : marks) (void)hipEventDestroy(m.second);
+        marks.clear();
+        profile_rows.clear();
+        for (const std::string& n : order) profile_rows.emplace_back(n, acc[n]);
+    }
+
     // ---- tape state of the step in flight
     struct Op {
         int out_id;
+        int section;
         std::function<void(const Tn&)> bw;
     };
     std::vector<Op> ops;
@@ -437,11 +479,16 @@ struct ps_trainer {
         grad_of[t.id] = z;
         return z;
     }
-    void record(const Tn& out, std::function<void(const Tn&)> bw) { ops.push_back({out.id, std::move(bw)}); }
+    void record(const Tn& out, std::function<void(const Tn&)> bw) { ops.push_back({out.id, section, std::move(bw)}); }
     void backward(const Tn& out, const Tn& dout)
     {
         grad_of[out.id] = dout;
+        int cur = -1;
         for (size_t i = ops.size(); i-- > 0;) {
+            if (profile && ops[i].section != cur) {
+                cur = ops[i].section;
+                mark("bwd " + section_names[cur]);
+            }
             auto it = grad_of.find(ops[i].out_id);
             if (it == grad_of.end()) {
                 ops[i].bw = nullptr;
@@ -473,8 +520,17 @@ struct ps_trainer {
     // y = x . W (+ b).  W is [cin, cout], or [cout, cin] when transposed (conv2d_transpose kernels, helper_tf_util.py:208-212).
     // into: an existing [R, cout] tensor of the tape that the product is ADDED to (the GEMM's accumulate epilogue); the result is that
     // same tensor and its gradient is handed on unchanged to the op that produced it.
-    Tn linear(const Tn& x, const Tn& W, const float* b, const Tn& gW, float* gb, bool transposed = false, const Tn* into = nullptr)
+    // fp32_only: this layer is not one of the "bf16 MLPs" (the LocSE convolution 10 -> h: part of the position encoding, K = 10 is no
+    // matrix-pipe shape, and its fused form computes in fp32): its three GEMMs keep fp32 operands in the bf16 mode too.
+    Tn linear(const Tn& x, const Tn& W, const float* b, const Tn& gW, float* gb, bool transposed = false, const Tn* into = nullptr, bool fp32_only = false)
     {
+        struct Fp32Scope {  // switches the context's bf16-GEMM mode off for the lifetime of the object
+            ps_context* c;
+            bool was;
+            Fp32Scope(ps_context* ctx, bool on) : c(ctx), was(ctx->train_bf16) { if (on) c->train_bf16 = false; }
+            ~Fp32Scope() { c->train_bf16 = was; }
+        };
+        Fp32Scope fwd_scope(c, fp32_only);
         const Tn Wm = transposed ? transpose(W) : W;  // [cin, cout]
         const int64_t R = x.R, cin = x.C, cout = Wm.C;
         Tn y;
@@ -488,6 +544,7 @@ struct ps_trainer {
         const bool had_into = into != nullptr;
         const Tn into_t = had_into ? *into : Tn();
         record(y, [=](const Tn& dy) {
+            Fp32Scope bwd_scope(c, fp32_only);
             if (had_into) grad_of[into_t.id] = dy;  // d(into + x.W)/d(into) = 1: the producer of `into` (earlier on the tape) gets the same gradient
             if (transposed) {
                 Tn dW = alloc(cin, cout, false);
@@ -733,10 +790,10 @@ struct ps_trainer {
     Tn gWt(const LayerP& lp) { return lp.kind == kDeconv ? G(lp.w, lp.cout, lp.cin) : G(lp.w, lp.cin, lp.cout); }
 
     // helper_tf_util.conv2d / conv2d_transpose (:115-250): 1x1 conv + bias [+ BatchNorm(training) [+ LeakyReLU(0.2)]]
-    Tn conv(const Tn& x, const std::string& scope, bool bn = true, bool act = true, const Tn* out = nullptr)
+    Tn conv(const Tn& x, const std::string& scope, bool bn = true, bool act = true, const Tn* out = nullptr, bool fp32_only = false)
     {
         const LayerP& lp = layer(scope);
-        Tn y = linear(x, Wt(lp), lp.b >= 0 ? params + lp.b : nullptr, gWt(lp), lp.b >= 0 ? grads + lp.b : nullptr, lp.kind == kDeconv);
+        Tn y = linear(x, Wt(lp), lp.b >= 0 ? params + lp.b : nullptr, gWt(lp), lp.b >= 0 ? grads + lp.b : nullptr, lp.kind == kDeconv, nullptr, fp32_only);
         if (bn) y = bn_act(y, lp, act, out);
         return y;
     }
@@ -776,26 +833,28 @@ struct ps_trainer {
         const int L = cfg.num_layers;
         const int64_t B = pyr->B, K = cfg.k_n;
         Tn x = external(const_cast<float*>(features), B * pyr->n[0], cfg.in_channels, false);
+        begin_section("fc0");
         const LayerP& fc0 = layer("fc0");
         Tn f = linear(x, P(fc0.w, fc0.cin, fc0.cout), params + fc0.b, G(fc0.w, fc0.cin, fc0.cout), grads + fc0.b);
         f = bn_act(f, fc0, true);
         std::vector<Tn> enc;
         for (int i = 0; i < L; ++i) {
             const std::string n = "Encoder_layer_" + std::to_string(i);
+            begin_section("enc" + std::to_string(i));
             const int32_t* idx = pyr->neigh_idx[i];
             const int64_t N = pyr->n[i];
             const Tn feature = f;
             Tn f_pc = conv(feature, n + "mlp1");
             const LayerP& lfa1 = layer(n + "LFAmlp1");
             const int64_t hloc = lfa1.cout;
-            const bool locse_fused = opt.fused_locse && !opt.mlp_bf16 && ps_op_locse_train_supported(K, hloc);
+            const bool locse_fused = opt.fused_locse && ps_op_locse_train_supported(K, hloc);
             Tn rel;
             if (!locse_fused) {
                 rel = alloc(B * N * K, 10, false);
                 TK(ps_op_relative_pos_encoding(c, pyr->xyz[i], idx, B, N, K, rel.p));
             }
             auto locse = [&](const Tn* out) -> Tn {
-                if (!locse_fused) return conv(rel, n + "LFAmlp1", true, true, out);
+                if (!locse_fused) return conv(rel, n + "LFAmlp1", true, true, out, true);
                 return locse_bn_act(pyr->xyz[i], idx, B, N, K, lfa1, out);
             };
             // tf.concat([f_neighbours, f_xyz]) (RandLANet.py:328,332): both producers write their column block of the concat buffer
@@ -833,6 +892,7 @@ struct ps_trainer {
             if (i == 0) enc.push_back(f_enc);
             enc.push_back(f);
         }
+        begin_section("decoder");
         f = conv(enc.back(), "decoder_0");
         for (int j = 0; j < L; ++j) {
             // nearest_interpolation + tf.concat([skip, up]) (RandLANet.py:134-143): the gather writes the right column block of the concat
@@ -854,6 +914,7 @@ struct ps_trainer {
             Tn both = concat_views(cat, left, up);
             f = conv(both, "Decoder_layer_" + std::to_string(j));
         }
+        begin_section("head");
         f = conv(f, "fc1");
         f = conv(f, "fc2");
         // every rank draws its own mask (N GPUs x 1 cloud behaves like 1 GPU x N clouds, where the clouds sit at different element offsets)
@@ -954,6 +1015,8 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
         t->next_id = 0;
         t->ops.clear();
         t->grad_of.clear();
+        t->section_names.clear();
+        t->section = 0;
         c->train_bf16 = bf16;
         Tn logits = t->forward(pyr, features);
         const int64_t R = logits.R, C = logits.C;
@@ -966,6 +1029,7 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
             TK_HIP(hipGetLastError());
             lab = reinterpret_cast<const int32_t*>(mapped.p);
         }
+        t->mark("loss");
         Tn dlogits = t->alloc(R, C);
         TK_HIP(hipMemsetAsync(loss, 0, sizeof(float), c->stream));
         TK(ps_op_weighted_ce(c, logits.p, lab, class_weights, R, C, loss, dlogits.p));
@@ -981,7 +1045,19 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
     t->ops.clear();
     t->grad_of.clear();
     if (rc != PS_OK) return rc;
-    if (!optimise) return PS_OK;
+    if (!optimise) {
+        try {
+            t->finish_profile();
+        } catch (const TrainError& e) {
+            return e.rc;
+        }
+        return PS_OK;
+    }
+    try {
+        t->mark("grad all-reduce");
+    } catch (const TrainError& e) {
+        return e.rc;
+    }
     try {
         if (t->coll && t->world > 1) {
             // gradient synchronisation of config 4: ONE all-reduce of the flat fp32 gradient buffer, then the mean over the ranks
@@ -994,7 +1070,18 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
         return e.rc;
     }
     t->step += 1;
-    return ps_op_adam(c, t->params, t->grads, t->adam_m, t->adam_v, t->n_params, t->opt.learning_rate, 0.9f, 0.999f, 1e-8f, t->step);
+    try {
+        t->mark("adam");
+    } catch (const TrainError& e) {
+        return e.rc;
+    }
+    const int arc = ps_op_adam(c, t->params, t->grads, t->adam_m, t->adam_v, t->n_params, t->opt.learning_rate, 0.9f, 0.999f, 1e-8f, t->step);
+    try {
+        t->finish_profile();
+    } catch (const TrainError& e) {
+        return e.rc;
+    }
+    return arc;
 }
 
 }  // namespace ps
@@ -1117,6 +1204,29 @@ int ps_trainer_set_options(ps_trainer* t, const ps_train_options* opt)
 }
 
 int64_t ps_trainer_pool_peak_bytes(const ps_trainer* t) { return t ? (int64_t)t->pool.peak : -1; }
+
+int ps_trainer_set_profile(ps_trainer* t, int on)
+{
+    PS_CHECK(t, "ps_trainer_set_profile: trainer is NULL");
+    t->profile = on != 0;
+    return PS_OK;
+}
+
+int ps_trainer_profile(const ps_trainer* t, ps_timing_row* rows, int cap, int* n_rows)
+{
+    PS_CHECK(t && rows && n_rows && cap >= 0, "ps_trainer_profile: bad argument");
+    int n = 0;
+    for (const auto& r : t->profile_rows) {
+        if (n >= cap) break;
+        std::strncpy(rows[n].name, r.first.c_str(), sizeof(rows[n].name) - 1);
+        rows[n].name[sizeof(rows[n].name) - 1] = 0;
+        rows[n].ms = r.second;
+        rows[n].launches = 0;
+        ++n;
+    }
+    *n_rows = n;
+    return PS_OK;
+}
 
 int ps_randla_backward(ps_trainer* t, const ps_pyramid* pyr, const float* features, const int32_t* labels, const float* class_weights, float* loss,
                        float* logits)

@@ -52,8 +52,10 @@ def allreduce_mean_(flat, dist):
 class Tape:
     """Records (output, backward closure) pairs; gradients are keyed by tensor identity and accumulated on the device."""
 
-    def __init__(self, ctx, sync=None):
-        """sync: an initialised torch.distributed module for BatchNorm statistics shared by all ranks (None: per-GPU)."""
+    def __init__(self, ctx, sync=None, bf16=False):
+        """sync: an initialised torch.distributed module for BatchNorm statistics shared by all ranks (None: per-GPU).
+        bf16: the step runs in the bf16-MLP mode (ps_set_train_gemm_bf16 is on around it)."""
+        self.bf16 = bool(bf16)
         self.ctx = ctx
         self.L = _lib.lib()
         self.h = ctx.handle
@@ -90,10 +92,28 @@ class Tape:
         self.grads = {}
 
     # ---- ops -------------------------------------------------------------------------------------------------------
-    def linear(self, x, W, b, gW, gb, transposed=False, into=None):
+    def linear(self, x, W, b, gW, gb, transposed=False, into=None, fp32_only=False):
         """y = x . W (+ b).  W is [cin,cout], or [cout,cin] when transposed (conv2d_transpose kernels).
         into: an existing [R, cout] tensor of the tape that the product is ADDED to (the GEMM's accumulate epilogue); the result is that
         same tensor, and its gradient is handed on unchanged to the op that produced it."""
+        if fp32_only and self.bf16:
+            # not one of the "bf16 MLPs" (the LocSE convolution 10 -> h): forward now, backward later, both with fp32 operands
+            _lib.check(self.L.ps_set_train_gemm_bf16(self.h, 0))
+            try:
+                y = self.linear(x, W, b, gW, gb, transposed, into)
+            finally:
+                _lib.check(self.L.ps_set_train_gemm_bf16(self.h, 1))
+            t, inner = self.ops[-1]
+
+            def bw32(dy):
+                _lib.check(self.L.ps_set_train_gemm_bf16(self.h, 0))
+                try:
+                    inner(dy)
+                finally:
+                    _lib.check(self.L.ps_set_train_gemm_bf16(self.h, 1))
+
+            self.ops[-1] = (t, bw32)
+            return y
         Wm = W.t().contiguous() if transposed else W
         x_in = x  # the tensor the tape knows (gradients are keyed by identity)
         x = _rowmajor(x)
@@ -467,8 +487,9 @@ class Trainer:
         self.mlp_bf16 = mlp_dtype == "bf16"
         self.fused_att = bool(fused_att)  # False: the op-by-op attentive pooling everywhere (A/B switch of bench.py --no-fused-att)
         # LocSE branch (relative_pos_encoding -> conv 10->h -> BatchNorm -> LeakyReLU) recomputed from coordinates and indices instead of
-        # materialised (csrc/locse_train.hip).  Not in the bf16-MLP mode: its weight gradient is defined on rounded operands of the GEMM
-        self.fused_locse = bool(fused_locse) and not self.mlp_bf16
+        # materialised (csrc/locse_train.hip).  Also in the bf16-MLP mode: the 10 -> h convolution of the position encoding is not one of
+        # the "bf16 MLPs" (K = 10 is no matrix-pipe shape): it keeps fp32 operands, fused or not
+        self.fused_locse = bool(fused_locse)
         # LFA mlp2 (conv c->c + BatchNorm + LeakyReLU on [N*K] rows) with the pre-BatchNorm product recomputed instead of stored
         # (csrc/smallconv_train.hip); same restriction.  OFF by default: 8 passes instead of 14, but its 16-row MFMA tile kernels are
         # issue bound and measured SLOWER than the streaming kernels they replace (batch 8: +0.7 / +0.2 / +1.0 ms with c = 8 / 32 / 64
@@ -579,8 +600,9 @@ class Trainer:
     _world = 1
 
     # ---- graph pieces ------------------------------------------------------------------------------------------------
-    def _conv(self, t, x, scope, bn=True, act=True, transposed=False, out=None):
-        y = t.linear(x, self.P[scope + "/weights"], self.P[scope + "/biases"], self.G[scope + "/weights"], self.G[scope + "/biases"], transposed)
+    def _conv(self, t, x, scope, bn=True, act=True, transposed=False, out=None, fp32_only=False):
+        y = t.linear(x, self.P[scope + "/weights"], self.P[scope + "/biases"], self.G[scope + "/weights"], self.G[scope + "/biases"], transposed,
+                     fp32_only=fp32_only)
         if bn:
             s = scope + "/batch_normalization"
             y = t.bn_act(y, self.P[s + "/gamma"], self.P[s + "/beta"], self.G[s + "/gamma"], self.G[s + "/beta"], self.buffers[s + "/moving_mean"],
@@ -647,7 +669,7 @@ class Trainer:
 
             def locse(out=None):
                 if not locse_fused:
-                    return self._conv(t, rel, n + "LFAmlp1", out=out)
+                    return self._conv(t, rel, n + "LFAmlp1", out=out, fp32_only=True)
                 s, sb = n + "LFAmlp1", n + "LFAmlp1/batch_normalization"
                 return t.locse_bn_act(pyr.xyz[i], idx, B, self.P[s + "/weights"], self.P[s + "/biases"], self.G[s + "/weights"], self.G[s + "/biases"],
                                       self.P[sb + "/gamma"], self.P[sb + "/beta"], self.G[sb + "/gamma"], self.G[sb + "/beta"],
@@ -769,6 +791,16 @@ class Trainer:
         self.last_logits = logits
         return loss
 
+    def set_profile(self, on=True):
+        """Per-section device time of every following step (ps_trainer_set_profile); read with profile()."""
+        _lib.check(_lib.lib().ps_trainer_set_profile(self._h, 1 if on else 0))
+
+    def profile(self):
+        rows = (_lib.PsTimingRow * 64)()
+        n = ctypes.c_int(0)
+        _lib.check(_lib.lib().ps_trainer_profile(self._h, rows, 64, ctypes.byref(n)))
+        return [(rows[i].name.decode(), rows[i].ms) for i in range(n.value)]
+
     def pool_peak_bytes(self):
         return int(_lib.lib().ps_trainer_pool_peak_bytes(self._h))
 
@@ -776,7 +808,7 @@ class Trainer:
         lib, h = _lib.lib(), self.ctx.handle
         self._rank = dist.get_rank() if dist is not None else 0
         self._world = dist.get_world_size() if dist is not None else 1
-        t = Tape(self.ctx, sync=dist if (self.sync_bn and dist is not None) else None)
+        t = Tape(self.ctx, sync=dist if (self.sync_bn and dist is not None) else None, bf16=self.mlp_bf16)
         if self.mlp_bf16:
             _lib.check(lib.ps_set_train_gemm_bf16(h, 1))
         try:

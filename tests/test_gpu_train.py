@@ -128,7 +128,10 @@ def test_one_training_step_matches_autograd(oracle):
 def _bf16_rule(kind, cin, cout):
     """Which GEMMs of Trainer(mlp_dtype="bf16") run on bf16-rounded operands (csrc/ops.hip: ps_op_conv1x1_ex takes the bf16 kernel
     when its K axis is a multiple of 16 -- for the input-gradient GEMM dy . W^T that axis is cout --; the weight-gradient kernel
-    rounds every shape)."""
+    rounds every shape).  The LocSE convolution (cin = 10: relative_pos_encoding -> conv 10 -> h, RandLANet.py:324-325) is not one of
+    the "bf16 MLPs": fp32 operands in all three GEMMs (its fused form, csrc/locse_train.hip, computes in fp32)."""
+    if cin == 10:
+        return False
     return True if kind == "wgrad" else ((cin if kind == "fwd" else cout) % 16 == 0)
 
 
@@ -815,11 +818,14 @@ def test_native_step_equals_the_python_tape(mode):
         if engine == "native":
             assert tr.pool_peak_bytes() > 0
         tr.close() if hasattr(tr, "close") else None
-    for a, b in zip(runs["native"], runs["python"]):
-        assert abs(a["loss"] - b["loss"]) <= 2e-6 * abs(b["loss"]), (a["loss"], b["loss"])
-        assert np.abs(a["logits"].reshape(b["logits"].shape) - b["logits"]).max() <= 2e-5 * np.abs(b["logits"]).max()
+    for i, (a, b) in enumerate(zip(runs["native"], runs["python"])):
+        # step 1 starts from identical parameters; step 2 from parameters that already differ by the first step's gradient noise
+        # through Adam (lr 1e-3): its forward quantities agree to ~1e-5 only
+        t_loss, t_logit, t_buf = (2e-6, 2e-5, 1e-5) if i == 0 else (1e-4, 2e-3, 1e-3)
+        assert abs(a["loss"] - b["loss"]) <= t_loss * abs(b["loss"]), (i, a["loss"], b["loss"])
+        assert np.abs(a["logits"].reshape(b["logits"].shape) - b["logits"]).max() <= t_logit * np.abs(b["logits"]).max()
         for k in b["buffers"]:
-            assert np.abs(a["buffers"][k] - b["buffers"][k]).max() <= 1e-5 * max(1.0, np.abs(b["buffers"][k]).max()), k
+            assert np.abs(a["buffers"][k] - b["buffers"][k]).max() <= t_buf * max(1.0, np.abs(b["buffers"][k]).max()), k
         assert np.linalg.norm(a["grad"] - b["grad"]) <= 5e-3 * np.linalg.norm(b["grad"])
         assert np.abs(a["flat"] - b["flat"]).max() <= 2.1e-3
         assert np.linalg.norm(a["flat"] - b["flat"]) <= 1e-3 * np.linalg.norm(b["flat"])
