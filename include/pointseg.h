@@ -260,6 +260,11 @@ int ps_op_linear_wgrad_ex(ps_context* ctx, const float* x, int64_t ldx, const fl
 int ps_op_bn_train_fwd_ex(ps_context* ctx, const float* x, const float* gamma, const float* beta, int64_t R, int64_t C,
                           float eps, int leaky, float* y, int64_t ldy, float* mean, float* invstd, float* var,
                           float* scratch2C);
+/* ps_op_bn_train_fwd_ex plus the moving-statistics update of the reference's extra_update_ops (RandLANet.py:90,163; momentum 0.99):
+ * moving = momentum * moving + (1 - momentum) * batch, done by the kernel that finishes the batch statistics (three launches in all). */
+int ps_op_bn_train_fwd_mov(ps_context* ctx, const float* x, const float* gamma, const float* beta, int64_t R, int64_t C,
+                           float eps, int leaky, float* y, int64_t ldy, float* mean, float* invstd, float* var,
+                           float* scratch2C, float* moving_mean, float* moving_var, float momentum);
 int ps_op_bn_train_bwd_ex(ps_context* ctx, const float* dy, int64_t lddy, const float* x, const float* gamma,
                           const float* beta, const float* mean, const float* invstd, int64_t R, int64_t C, int leaky,
                           float* dx, float* dgamma, float* dbeta);

@@ -140,6 +140,8 @@ PROTOTYPES = {
     "ps_op_linear_wgrad_ex": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, ctypes.c_int64] + [ctypes.c_int64] * 3 + [c_vp, c_vp]),
     "ps_op_bn_train_fwd_ex": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int, c_vp, ctypes.c_int64]
                               + [c_vp] * 4),
+    "ps_op_bn_train_fwd_mov": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int, c_vp, ctypes.c_int64]
+                               + [c_vp] * 6 + [ctypes.c_float]),
     "ps_op_bn_train_bwd_ex": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64] + [c_vp] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int] + [c_vp] * 3),
     "ps_op_bn_train_apply_ex": (ctypes.c_int, [c_vp] * 5 + [ctypes.c_int64] * 3 + [ctypes.c_float, ctypes.c_int, c_vp, ctypes.c_int64] + [c_vp] * 3),
     "ps_op_bn_train_bwd_sums_ex": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64] + [c_vp] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int] + [c_vp] * 2),

@@ -84,6 +84,7 @@ struct ps_context {
     ps::DevBuf stage_in;     // host<->device staging for device_ptrs == 0 calls
     ps::DevBuf stage_out;
     ps::DevBuf red_ws;       // per-block partial sums of the per-channel reductions (ops_train.hip)
+    ps::DevBuf wgrad_ws;     // per-slab partials of ps_op_linear_wgrad[_ex] (ops_train.hip)
     ps::DevBuf ops_ring[4];  // packed weights of ps_op_conv1x1 (a ring: consecutive calls never repack into the buffer the previous GEMM is still reading)
     int ops_ring_pos = 0;
     bool att_bf16x3 = true;   // ps_set_att_bf16x3: attentive pooling at d = 64 / 128 on bf16 MFMA over three-way splits (attpool32b.hip)
@@ -145,4 +146,16 @@ struct Stage {
 };
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// weight-gradient partials (ops_train.hip): the GEMM writes one [rows, cols] partial per row slab, wgrad_finish adds them up in slab
+// order for a whole table of jobs in one launch (the native training step finishes every gradient of a step with it)
+struct WgradJob {
+    const float* part;  // [slabs][rows][cols]
+    float* dst;         // [rows][cols], or [cols][rows] when transposed
+    int slabs, rows, cols, transposed;
+};
+int64_t wgrad_partial_slabs(int64_t R, int64_t cin, int64_t cout);
+int wgrad_partial(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout, float* part,
+                  float* dbpart);
+int wgrad_finish(ps_context* c, const WgradJob* d_jobs, int n_jobs, int64_t max_elems);
 }  // namespace ps

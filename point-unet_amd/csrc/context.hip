@@ -179,6 +179,7 @@ int ps_destroy(ps_context* c)
     c->stage_in.release();
     c->stage_out.release();
     c->red_ws.release();
+    c->wgrad_ws.release();
     for (auto& b : c->ops_ring) b.release();
     if (c->h_flags) (void)hipHostFree(c->h_flags);
     for (auto& e : c->flag_ev)

@@ -118,8 +118,44 @@ __global__ __launch_bounds__(64) void colreduce_finish_kernel(const float* __res
     }
 }
 
+// BatchNorm statistics finished in the reduction's own second stage: [sum | sum of squares] -> mean, population variance, invstd and
+// (optionally) the moving-statistics update  moving = momentum * moving + (1 - momentum) * batch  (the reference's extra_update_ops,
+// RandLANet.py:90,163) -- one launch instead of three
+struct BnFinish {
+    float* mean; float* invstd; float* var; float* mov_mean; float* mov_var;
+    float rows, eps, momentum;
+};
+__global__ __launch_bounds__(64) void colreduce_finish_bn_kernel(const float* __restrict__ part0, const float* __restrict__ part1, int blocks, int C,
+                                                                 float* __restrict__ out0, float* __restrict__ out1, BnFinish bn)
+{
+    const int c = blockIdx.x;
+    float t0 = 0.f, t1 = 0.f;
+    for (int b = threadIdx.x; b < blocks; b += 64) {
+        t0 += part0[(size_t)b * C + c];
+        t1 += part1[(size_t)b * C + c];
+    }
+    for (int o = 32; o; o >>= 1) {
+        t0 += __shfl_down(t0, o);
+        t1 += __shfl_down(t1, o);
+    }
+    if (threadIdx.x == 0) {
+        out0[c] = t0;
+        out1[c] = t1;
+        const float m = t0 / bn.rows;
+        float v = t1 / bn.rows - m * m;  // population variance (tf.nn.moments)
+        v = v < 0.f ? 0.f : v;
+        bn.mean[c] = m;
+        bn.var[c] = v;
+        bn.invstd[c] = rsqrtf(v + bn.eps);
+        if (bn.mov_mean) {
+            bn.mov_mean[c] = bn.mov_mean[c] * bn.momentum + m * (1.f - bn.momentum);
+            bn.mov_var[c] = bn.mov_var[c] * bn.momentum + v * (1.f - bn.momentum);
+        }
+    }
+}
+
 template <class F>
-static int colreduce2(ps_context* c, F f, int64_t R, int C, float* out0, float* out1)
+static int colreduce2(ps_context* c, F f, int64_t R, int C, float* out0, float* out1, const BnFinish* bn = nullptr)
 {
     if (R <= 0) {
         PS_HIP(hipMemsetAsync(out0, 0, sizeof(float) * C, c->stream));
@@ -136,7 +172,10 @@ static int colreduce2(ps_context* c, F f, int64_t R, int C, float* out0, float* 
     float* p1 = out1 ? p0 + (size_t)nb * C : nullptr;
     const int vec = (C & 3) == 0 && (1024 % C) == 0 && f.aligned16();
     hipLaunchKernelGGL(colreduce2_kernel<F>, dim3((unsigned)nb), dim3(256), 0, c->stream, f, R, C, rpb, vec, p0, p1);
-    hipLaunchKernelGGL(colreduce_finish_kernel, dim3((unsigned)C), dim3(64), 0, c->stream, p0, p1, nb, C, out0, out1);
+    if (bn)
+        hipLaunchKernelGGL(colreduce_finish_bn_kernel, dim3((unsigned)C), dim3(64), 0, c->stream, p0, p1, nb, C, out0, out1, *bn);
+    else
+        hipLaunchKernelGGL(colreduce_finish_kernel, dim3((unsigned)C), dim3(64), 0, c->stream, p0, p1, nb, C, out0, out1);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -361,6 +400,11 @@ template <int TI, int TJ, int WK, bool VEC, bool BF16>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy, int64_t R, int cin,
                                                     int cout, int64_t rows_per_block, float* __restrict__ dW, float* __restrict__ db)
 {
+    // dW / db point at this launch's PARTIALS: slab b (= blockIdx.x) owns dW[b][cin][cout] and db[b][cout] and every element of them is
+    // written exactly once, by the one workgroup whose tile holds it -- plain stores, no atomics; wgrad_reduce_kernel adds the slabs
+    // up in slab order afterwards (deterministic, and nothing has to be zeroed first)
+    dW += (size_t)blockIdx.x * cin * cout;
+    if (db != nullptr) db += (size_t)blockIdx.x * cout;
     constexpr int WI = 4 / WK;
     constexpr int CI = TI * WI * 16, CJ = TJ * 16;
     constexpr int SX = BF16 ? CI + 4 : wg_stride(CI), SD = BF16 ? CJ + 4 : wg_stride(CJ);
@@ -432,16 +476,43 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x,
                 for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
+    if constexpr (WK > 1) {
+        // the WK wave groups hold partial sums of the SAME tiles (they split the k-steps): groups 1 .. WK-1 hand theirs to group 0
+        // through LDS, one after the other (fixed order)
+        static_assert(CH * SD >= WI * TI * TJ * 256, "the dY staging buffer doubles as the wave-group reduction buffer");
+        for (int k = 1; k < WK; ++k) {
+            __syncthreads();
+            if (wk == k) {
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+                for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j)
+                    for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                // C layout: row = (lane>>4)*4 + q, col = lane&15
-                const int ci = c0 + (wi * TI + i) * 16 + k4 * 4 + q, n = n0 + j * 16 + i16;
-                if (ci < cin && n < cout) atomicAdd(&dW[(size_t)ci * cout + n], acc[i][j][q]);
+                        for (int q = 0; q < 4; ++q) ds[((wi * TI + i) * TJ + j) * 256 + q * 64 + lane] = acc[i][j][q];
             }
+            __syncthreads();
+            if (wk == 0) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[i][j][q] += ds[((wi * TI + i) * TJ + j) * 256 + q * 64 + lane];
+            }
+        }
+    }
+    if (wk == 0) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // C layout: row = (lane>>4)*4 + q, col = lane&15
+                    const int ci = c0 + (wi * TI + i) * 16 + k4 * 4 + q, n = n0 + j * 16 + i16;
+                    if (ci < cin && n < cout) dW[(size_t)ci * cout + n] = acc[i][j][q];
+                }
+    }
     if (db != nullptr && blockIdx.y == 0) {
         // threads sharing a column merge through LDS (the dY block is dead by now); one atomic per column and workgroup
         __syncthreads();
@@ -456,24 +527,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x,
             } else {
                 for (int m = 0; m < 256 / Q; ++m) t += ds[threadIdx.x + Q * m];
             }
-            atomicAdd(&db[n0 + threadIdx.x], t);
+            db[n0 + threadIdx.x] = t;
         }
     }
+}
+
+// rows per slab and number of slabs of a weight-gradient launch (the partials are [slabs][cin][cout])
+template <int TI, int TJ, int WK>
+static void wgrad_slabs(int64_t R, int cin, int cout, int64_t& rpb, int64_t& nb)
+{
+    constexpr int CI = TI * (4 / WK) * 16, CJ = TJ * 16;
+    constexpr int kWgChunk = wg_chunk(CI + CJ) > 16 * WK ? wg_chunk(CI + CJ) : 16 * WK;  // >= either flavour's chunk
+    const int ty = (cin + CI - 1) / CI, tz = (cout + CJ - 1) / CJ;
+    // ~3 workgroups per CU; fewer, longer slabs when the dW block is large (every slab is a [cin, cout] partial the reduction reads back)
+    int64_t slabs = 768 / ((int64_t)ty * tz);
+    slabs = slabs < 1 ? 1 : slabs;
+    rpb = (R + slabs - 1) / slabs;
+    rpb = ((rpb + kWgChunk - 1) / kWgChunk) * kWgChunk;
+    rpb = rpb < 4 * kWgChunk ? 4 * kWgChunk : rpb;
+    nb = (R + rpb - 1) / rpb;
 }
 
 template <int TI, int TJ, int WK>
 static void launch_wgrad(ps_context* c, const float* x, int ldx, const float* dy, int lddy, int64_t R, int cin, int cout, float* dW, float* db)
 {
     constexpr int CI = TI * (4 / WK) * 16, CJ = TJ * 16;
-    constexpr int kWgChunk = wg_chunk(CI + CJ) > 16 * WK ? wg_chunk(CI + CJ) : 16 * WK;  // >= either flavour's chunk
     const int ty = (cin + CI - 1) / CI, tz = (cout + CJ - 1) / CJ;
-    // ~3 workgroups per CU; fewer, longer slabs when the dW block is large (every workgroup ends with CI*CJ float atomics)
-    int64_t slabs = 768 / ((int64_t)ty * tz);
-    slabs = slabs < 1 ? 1 : slabs;
-    int64_t rpb = (R + slabs - 1) / slabs;
-    rpb = ((rpb + kWgChunk - 1) / kWgChunk) * kWgChunk;
-    rpb = rpb < 4 * kWgChunk ? 4 * kWgChunk : rpb;
-    const int64_t nb = (R + rpb - 1) / rpb;
+    int64_t rpb, nb;
+    wgrad_slabs<TI, TJ, WK>(R, cin, cout, rpb, nb);
     // float4 staging needs every row start and block origin on a 16-byte boundary (CI, CJ are multiples of 16 already)
     const bool vec = ((cin | cout | ldx | lddy) & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
     const dim3 grid((unsigned)nb, ty, tz);
@@ -727,6 +808,87 @@ int ps_op_linear_wgrad(ps_context* c, const float* x, const float* dy, int64_t R
     return ps_op_linear_wgrad_ex(c, x, cin, dy, cout, R, cin, cout, dW, db);
 }
 
+}  // extern "C"
+
+namespace ps {
+// per-wave tile block TI x TJ and the number of wave groups splitting the k-steps (WK) for a [cin, cout] gradient; see wgrad_kernel
+#define PS_WGRAD_DISPATCH(ti, tj, DO)     \
+    do {                                   \
+        if ((tj) >= 8) {                   \
+            if ((ti) >= 8) DO(2, 8, 1);    \
+            else if ((ti) >= 3) DO(1, 8, 1); \
+            else if ((ti) == 2) DO(1, 8, 2); \
+            else DO(1, 8, 4);              \
+        } else if ((tj) >= 3) {            \
+            if ((ti) >= 3) DO(1, 4, 1);    \
+            else if ((ti) == 2) DO(1, 4, 2); \
+            else DO(1, 4, 4);              \
+        } else if ((tj) == 2) {            \
+            if ((ti) >= 3) DO(1, 2, 1);    \
+            else if ((ti) == 2) DO(1, 2, 2); \
+            else DO(1, 2, 4);              \
+        } else {                           \
+            if ((ti) >= 3) DO(1, 1, 1);    \
+            else if ((ti) == 2) DO(1, 1, 2); \
+            else DO(1, 1, 4);              \
+        }                                  \
+    } while (0)
+
+int64_t wgrad_partial_slabs(int64_t R, int64_t cin, int64_t cout)
+{
+    if (R <= 0) return 0;
+    const int ti = (int)((cin + 15) / 16), tj = (int)((cout + 15) / 16);
+    int64_t rpb = 0, nb = 0;
+#define PS_WG(TI, TJ, WK) wgrad_slabs<TI, TJ, WK>(R, (int)cin, (int)cout, rpb, nb)
+    PS_WGRAD_DISPATCH(ti, tj, PS_WG);
+#undef PS_WG
+    return nb;
+}
+
+// part [slabs][cin][cout], dbpart [slabs][cout] (may be null): written completely, nothing needs zeroing
+int wgrad_partial(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout, float* part,
+                  float* dbpart)
+{
+    if (R <= 0) return PS_OK;
+    const int ti = (int)((cin + 15) / 16), tj = (int)((cout + 15) / 16);
+    const int ci = (int)cin, co = (int)cout;
+#define PS_WG(TI, TJ, WK) launch_wgrad<TI, TJ, WK>(c, x, (int)ldx, dy, (int)lddy, R, ci, co, part, dbpart)
+    PS_WGRAD_DISPATCH(ti, tj, PS_WG);
+#undef PS_WG
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+// dst = sum over the slabs, in slab order (fixed order: deterministic).  blockIdx.y walks a table of jobs, so every weight and bias
+// gradient of a training step is finished by ONE launch; transposed: dst is [cols][rows] (the conv2d_transpose kernels, stored [out, in])
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradJob* __restrict__ jobs)
+{
+    const WgradJob j = jobs[blockIdx.y];
+    const int64_t n = (int64_t)j.rows * j.cols;
+    for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        float sum = 0.f;
+        for (int b = 0; b < j.slabs; ++b) sum += j.part[(size_t)b * n + e];
+        if (j.transposed) {
+            const int64_t r = e / j.cols, cc = e - r * j.cols;
+            j.dst[cc * j.rows + r] = sum;
+        } else {
+            j.dst[e] = sum;
+        }
+    }
+}
+
+int wgrad_finish(ps_context* c, const WgradJob* d_jobs, int n_jobs, int64_t max_elems)
+{
+    if (n_jobs <= 0) return PS_OK;
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((max_elems + 255) / 256, 64));
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, (unsigned)n_jobs), dim3(256), 0, c->stream, d_jobs);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+}  // namespace ps
+
+extern "C" {
+
 int ps_op_linear_wgrad_ex(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout, float* dW,
                           float* db)
 {
@@ -734,35 +896,24 @@ int ps_op_linear_wgrad_ex(ps_context* c, const float* x, int64_t ldx, const floa
     PS_CHECK(ldx >= cin && lddy >= cout, "ps_op_linear_wgrad: row stride below the channel count");
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_wgrad", 2);
-    PS_HIP(hipMemsetAsync(dW, 0, sizeof(float) * cin * cout, c->stream));
-    if (db) PS_HIP(hipMemsetAsync(db, 0, sizeof(float) * cout, c->stream));
-    if (R > 0) {
-        const int ti = (int)((cin + 15) / 16), tj = (int)((cout + 15) / 16);
-        const int ci = (int)cin, co = (int)cout;
-        // per-wave tile block TI x TJ and the number of wave groups splitting the k-steps (WK); see wgrad_kernel
-#define PS_WG(TI, TJ, WK) launch_wgrad<TI, TJ, WK>(c, x, (int)ldx, dy, (int)lddy, R, ci, co, dW, db)
-        if (tj >= 8) {
-            if (ti >= 8) PS_WG(2, 8, 1);
-            else if (ti >= 3) PS_WG(1, 8, 1);
-            else if (ti == 2) PS_WG(1, 8, 2);
-            else PS_WG(1, 8, 4);
-        } else if (tj >= 3) {
-            if (ti >= 3) PS_WG(1, 4, 1);
-            else if (ti == 2) PS_WG(1, 4, 2);
-            else PS_WG(1, 4, 4);
-        } else if (tj == 2) {
-            if (ti >= 3) PS_WG(1, 2, 1);
-            else if (ti == 2) PS_WG(1, 2, 2);
-            else PS_WG(1, 2, 4);
-        } else {
-            if (ti >= 3) PS_WG(1, 1, 1);
-            else if (ti == 2) PS_WG(1, 1, 2);
-            else PS_WG(1, 1, 4);
-        }
-#undef PS_WG
-        PS_HIP(hipGetLastError());
+    if (R <= 0) {
+        PS_HIP(hipMemsetAsync(dW, 0, sizeof(float) * cin * cout, c->stream));
+        if (db) PS_HIP(hipMemsetAsync(db, 0, sizeof(float) * cout, c->stream));
+        return PS_OK;
     }
-    return PS_OK;
+    // per-slab partials (plain stores) + one reduction in slab order: deterministic, no float atomics, nothing zeroed first
+    const int64_t nb = wgrad_partial_slabs(R, cin, cout);
+    const size_t wfl = (size_t)nb * cin * cout, bfl = db ? (size_t)nb * cout : 0;
+    PS_TRY(c->wgrad_ws.reserve(sizeof(float) * (wfl + bfl) + 2 * sizeof(WgradJob) + 256));
+    float* part = c->wgrad_ws.as<float>();
+    float* dbpart = db ? part + wfl : nullptr;
+    PS_TRY(wgrad_partial(c, x, ldx, dy, lddy, R, cin, cout, part, dbpart));
+    WgradJob jobs[2];
+    jobs[0] = WgradJob{part, dW, (int)nb, (int)cin, (int)cout, 0};
+    jobs[1] = WgradJob{dbpart, db, (int)nb, 1, (int)cout, 0};
+    WgradJob* dj = reinterpret_cast<WgradJob*>(c->wgrad_ws.as<char>() + ((sizeof(float) * (wfl + bfl) + 255) & ~size_t(255)));
+    PS_TRY(c->upload_async(dj, jobs, sizeof(WgradJob) * (db ? 2 : 1)));
+    return wgrad_finish(c, dj, db ? 2 : 1, cin * cout);
 }
 
 int ps_op_bn_train_fwd(ps_context* c, const float* x, const float* gamma, const float* beta, int64_t R, int64_t C, float eps, int leaky, float* y,
@@ -780,6 +931,25 @@ int ps_op_bn_train_fwd_ex(ps_context* c, const float* x, const float* gamma, con
     Stage st(c, "train_bn_fwd", 3);
     PS_TRY(colreduce2(c, SumSq{x}, R, (int)C, scratch2C, scratch2C + C));
     hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, c->stream, scratch2C, scratch2C + C, R, (int)C, eps, mean, invstd, var);
+    if (bn_vec_ok(C, x, y, x, ldy))
+        hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(ew_grid(R * C / 4)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y,
+                           ldy);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(ew_grid(R * C)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y,
+                           ldy);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+int ps_op_bn_train_fwd_mov(ps_context* c, const float* x, const float* gamma, const float* beta, int64_t R, int64_t C, float eps, int leaky, float* y,
+                           int64_t ldy, float* mean, float* invstd, float* var, float* scratch2C, float* moving_mean, float* moving_var, float momentum)
+{
+    PS_CHECK(c && x && gamma && beta && y && mean && invstd && var && scratch2C && moving_mean && moving_var, "ps_op_bn_train_fwd_mov: NULL argument");
+    PS_CHECK(R >= 1 && C >= 1 && ldy >= C, "ps_op_bn_train_fwd_mov: empty tensor");
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "train_bn_fwd", 3);
+    const BnFinish bn = {mean, invstd, var, moving_mean, moving_var, (float)R, eps, momentum};
+    PS_TRY(colreduce2(c, SumSq{x}, R, (int)C, scratch2C, scratch2C + C, &bn));
     if (bn_vec_ok(C, x, y, x, ldy))
         hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(ew_grid(R * C / 4)), dim3(256), 0, c->stream, x, gamma, beta, mean, invstd, R * C, (int)C, leaky, y,
                            ldy);

@@ -370,6 +370,20 @@ struct ps_trainer {
     };
     std::vector<Op> ops;
     std::unordered_map<int, Tn> grad_of;
+    std::vector<WgradJob> wjobs;  // weight / bias gradient partials waiting for the step's one reduction launch
+    std::vector<Tn> wkeep;
+    void finish_wgrads()
+    {
+        if (wjobs.empty()) return;
+        Stage st(c, "train_wgrad", 1);
+        Tn table = alloc(1, (int64_t)((sizeof(WgradJob) * wjobs.size() + 3) / 4), false);
+        TK(c->upload_async(table.p, wjobs.data(), sizeof(WgradJob) * wjobs.size()));
+        int64_t most = 1;
+        for (const WgradJob& j : wjobs) most = std::max<int64_t>(most, (int64_t)j.rows * j.cols);
+        TK(wgrad_finish(c, reinterpret_cast<const WgradJob*>(table.p), (int)wjobs.size(), most));
+        wjobs.clear();
+        wkeep.clear();
+    }
 
     hipStream_t stream() const { return c->stream; }
 
@@ -501,6 +515,7 @@ struct ps_trainer {
         }
         ops.clear();
         grad_of.clear();
+        finish_wgrads();
     }
 
     // ---- parameters
@@ -546,12 +561,20 @@ struct ps_trainer {
         record(y, [=](const Tn& dy) {
             Fp32Scope bwd_scope(c, fp32_only);
             if (had_into) grad_of[into_t.id] = dy;  // d(into + x.W)/d(into) = 1: the producer of `into` (earlier on the tape) gets the same gradient
-            if (transposed) {
-                Tn dW = alloc(cin, cout, false);
-                TK(ps_op_linear_wgrad_ex(c, x.p, x.ld, dy.p, dy.ld, R, cin, cout, dW.p, gb));
-                transpose_into(dW, gW.p);
-            } else {
-                TK(ps_op_linear_wgrad_ex(c, x.p, x.ld, dy.p, dy.ld, R, cin, cout, gW.p, gb));  // straight into the flat gradient buffer
+            {
+                // weight / bias gradient: per-slab partials now (plain stores), summed in slab order by the ONE wgrad_finish launch at the
+                // end of the backward pass -- deterministic, no memsets, and the [out, in] layout of the transposed kernels is just a flag
+                Stage st(c, "train_wgrad", 1);
+                const int64_t nb = wgrad_partial_slabs(R, cin, cout);
+                Tn part = alloc(nb, cin * cout, false);
+                Tn dbp = gb ? alloc(nb, cout, false) : Tn();
+                TK(wgrad_partial(c, x.p, x.ld, dy.p, dy.ld, R, cin, cout, part.p, gb ? dbp.p : nullptr));
+                wjobs.push_back(WgradJob{part.p, gW.p, (int)nb, (int)cin, (int)cout, transposed ? 1 : 0});
+                wkeep.push_back(part);
+                if (gb) {
+                    wjobs.push_back(WgradJob{dbp.p, gb, (int)nb, 1, (int)cout, 0});
+                    wkeep.push_back(dbp);
+                }
             }
             if (x.req) {
                 const Tn Wt = transposed ? W : transpose(Wm);  // [cout, cin]
@@ -583,14 +606,16 @@ struct ps_trainer {
         const bool sync = sync_bn && coll && world > 1;
         const int64_t R_total = sync ? R * world : R;
         if (!sync) {
-            TK(ps_op_bn_train_fwd_ex(c, x.p, gamma, beta, R, C, kBnEps, leaky ? 1 : 0, y.p, y.ld, mean, invstd, var, sums));
+            // statistics, moving-statistics update and the apply pass: three launches
+            TK(ps_op_bn_train_fwd_mov(c, x.p, gamma, beta, R, C, kBnEps, leaky ? 1 : 0, y.p, y.ld, mean, invstd, var, sums, buffers + lp.mov_mean,
+                                      buffers + lp.mov_var, kBnMomentum));
         } else {
             // statistics over the rows of ALL ranks: two small all-reduces per layer (2*C floats forward, 2*C backward)
             TK(ps_op_bn_train_sums(c, x.p, R, C, sums));
             allreduce(sums, 2 * C, 0);
             TK(ps_op_bn_train_apply_ex(c, x.p, gamma, beta, sums, R, R_total, C, kBnEps, leaky ? 1 : 0, y.p, y.ld, mean, invstd, var));
         }
-        {
+        if (sync) {
             Stage st(c, "train_bn_fwd", 1);
             hipLaunchKernelGGL(tr_ema2_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream(), buffers + lp.mov_mean, buffers + lp.mov_var, mean, var, (int)C,
                                kBnMomentum);
@@ -1044,6 +1069,8 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
     c->train_bf16 = was_bf16;  // the context may be shared with inference-side op calls: never leave the mode on
     t->ops.clear();
     t->grad_of.clear();
+    t->wjobs.clear();
+    t->wkeep.clear();
     if (rc != PS_OK) return rc;
     if (!optimise) {
         try {
@@ -1137,6 +1164,7 @@ int ps_trainer_destroy(ps_trainer* t)
     if (!t) return PS_OK;
     t->ops.clear();
     t->grad_of.clear();
+    t->wkeep.clear();
     t->pool.destroy();
     t->label_map.release();
     delete t;

@@ -820,8 +820,8 @@ def test_native_step_equals_the_python_tape(mode):
         tr.close() if hasattr(tr, "close") else None
     for i, (a, b) in enumerate(zip(runs["native"], runs["python"])):
         # step 1 starts from identical parameters; step 2 from parameters that already differ by the first step's gradient noise
-        # through Adam (lr 1e-3): its forward quantities agree to ~1e-5 only
-        t_loss, t_logit, t_buf = (2e-6, 2e-5, 1e-5) if i == 0 else (1e-4, 2e-3, 1e-3)
+        # through Adam (lr 1e-3 moves a noise-level gradient entry by up to 2e-3 when its sign flips): its forward quantities agree to a few 1e-3
+        t_loss, t_logit, t_buf = (2e-6, 2e-5, 1e-5) if i == 0 else (1e-3, 1e-2, 5e-3)
         assert abs(a["loss"] - b["loss"]) <= t_loss * abs(b["loss"]), (i, a["loss"], b["loss"])
         assert np.abs(a["logits"].reshape(b["logits"].shape) - b["logits"]).max() <= t_logit * np.abs(b["logits"]).max()
         for k in b["buffers"]:
