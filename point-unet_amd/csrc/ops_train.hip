@@ -863,16 +863,39 @@ int wgrad_partial(ps_context* c, const float* x, int64_t ldx, const float* dy, i
 // gradient of a training step is finished by ONE launch; transposed: dst is [cols][rows] (the conv2d_transpose kernels, stored [out, in])
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradJob* __restrict__ jobs)
 {
+    // 64 elements per workgroup pass, the slabs dealt over 4 thread groups x 4 accumulators (slab b goes to group b % 4, accumulator
+    // (b / 4) % 4): sixteen independent load chains per element instead of one `slabs`-long chain (768 slabs for a small matrix), and
+    // still one fixed summation order
+    __shared__ float red[4][64];
     const WgradJob j = jobs[blockIdx.y];
     const int64_t n = (int64_t)j.rows * j.cols;
-    for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-        float sum = 0.f;
-        for (int b = 0; b < j.slabs; ++b) sum += j.part[(size_t)b * n + e];
-        if (j.transposed) {
-            const int64_t r = e / j.cols, cc = e - r * j.cols;
-            j.dst[cc * j.rows + r] = sum;
-        } else {
-            j.dst[e] = sum;
+    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < n; e0 += (int64_t)gridDim.x * 64) {
+        const int64_t e = e0 + el;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (e < n) {
+            int b = grp;
+            for (; b + 12 < j.slabs; b += 16) {
+                a0 += j.part[(size_t)b * n + e];
+                a1 += j.part[(size_t)(b + 4) * n + e];
+                a2 += j.part[(size_t)(b + 8) * n + e];
+                a3 += j.part[(size_t)(b + 12) * n + e];
+            }
+            if (b < j.slabs) a0 += j.part[(size_t)b * n + e];
+            if (b + 4 < j.slabs) a1 += j.part[(size_t)(b + 4) * n + e];
+            if (b + 8 < j.slabs) a2 += j.part[(size_t)(b + 8) * n + e];
+        }
+        __syncthreads();
+        red[grp][el] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (grp == 0 && e < n) {
+            const float sum = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+            if (j.transposed) {
+                const int64_t r = e / j.cols, cc = e - r * j.cols;
+                j.dst[cc * j.rows + r] = sum;
+            } else {
+                j.dst[e] = sum;
+            }
         }
     }
 }
@@ -880,7 +903,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradJob* __res
 int wgrad_finish(ps_context* c, const WgradJob* d_jobs, int n_jobs, int64_t max_elems)
 {
     if (n_jobs <= 0) return PS_OK;
-    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((max_elems + 255) / 256, 64));
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((max_elems + 63) / 64, 256));
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, (unsigned)n_jobs), dim3(256), 0, c->stream, d_jobs);
     PS_HIP(hipGetLastError());
     return PS_OK;
