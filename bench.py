@@ -693,7 +693,7 @@ def main():
             # untimed warm-up of the service path itself: the first transfers through freshly pinned host buffers and fresh device slots
             # are slow (page registration with the DMA engines), and at the driver's --steps 20 they WERE the number (r2: 1.66 ms
             # against 1.02 once warm, profiles/tools/exp_pcie.py)
-            for _ in range(max(2 * args.lanes, args.warmup)):
+            for _ in range(max(3 * n_clouds, 2 * args.lanes, args.warmup)):  # (every pinned host buffer has gone through the DMA engines)
                 pcie_step()
             sync()
             t_pcie, _ = timed_region(pcie_step, args.steps, sync, None)

@@ -203,7 +203,10 @@ bool gemm_b3_fits(int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx)
     // K >= 256: measured against rowgemm.hip (profiles/tools/gemm_b3_ab.py; plain / accumulate epilogue) -- [360k, 256] x [256, 256]: 0.46 / 0.50 vs
     // 0.67 / 0.83 ms, [90k, 512] x [512, 512]: 0.43 / 0.44 vs 0.56 / 0.67 ms, [90k, 256] x [256, 512]: 0.24 / 0.27 vs 0.31 / 0.40 ms;
     // K = 128 ([1.44M, 128] x [128, 128], HBM bound: 1.5 GB of rows against 47 GFLOP) ties or loses (0.63 / 0.70 vs 0.60 / 0.66 ms)
-    return R >= 4096 && K >= 256 && K % 32 == 0 && N % 128 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && R < (1ll << 31);
+    // R >= 16384: a workgroup owns 256 rows x 128 columns, so the few-row GEMMs of the deep levels leave most CUs without one (round 3,
+    // profiles/tools/gemm_shapes_ab.py: [5624, 1536] x [1536, 512] 0.276 ms here against 0.125 on the split-K fp32 kernel, [5624, 512] x
+    // [512, 256] 0.078 against 0.024, [5624, 1024] x [1024, 512] 0.139 against 0.085; [22496, 256] x [256, 512] 0.077 against 0.087)
+    return R >= 16384 && K >= 256 && K % 32 == 0 && N % 128 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && R < (1ll << 31);
 }
 
 size_t gemm_b3_plane_bytes(int64_t K, int64_t N) { return (size_t)K * N * 6; }
