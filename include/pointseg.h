@@ -74,7 +74,7 @@ int ps_set_deferred_checks(ps_context* ctx, int on);
  * (SURVEY 8d, config 3).  Activations, gradients, BatchNorm, softmax, loss and Adam stay fp32.  Default off (fp32 MFMA).
  * The fused inference path (ps_randla_forward) is never affected. */
 int ps_set_train_gemm_bf16(ps_context* ctx, int on);
-/* on != 0 (default): ps_op_conv1x1[_ex] runs its large, matrix-pipe-bound fp32 shapes (>= 16384 rows, cin >= 256 and a multiple of 32,
+/* on != 0 (default): ps_op_conv1x1[_ex] runs its large, matrix-pipe-bound fp32 shapes (>= 16384 rows, cin >= 128 and a multiple of 32,
  * cout a multiple of 128: att_pooling's score products at d_out >= 256 and their input gradients) on v_mfma_f32_32x32x16_bf16 over exact
  * three-way bfloat16 splits of both operands with fp32 accumulation (csrc/gemm_b3.hip) -- fp32-level error at 2.7 x less matrix-pipe
  * time; on == 0: the fp32 MFMA for every shape.  Ignored while ps_set_train_gemm_bf16 is on. */

@@ -109,24 +109,35 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmB3Args a)
         const int u = i / 768, rest = i - u * 768;
         return a.wp + ((size_t)((2 * s + u) * ncb + 4 * panel) * 3) * 64 + rest;
     };
-    uint4 breg[6];
+    // (six named registers, not an array behind a lambda: the array form stayed an alloca -- 112 bytes of private segment -- and every
+    //  prefetched weight plane went global -> scratch -> LDS with an s_waitcnt in front of each scratch store)
+    uint4 breg0, breg1, breg2, breg3, breg4, breg5;
     float4 areg[RT][4];
-    auto load_b = [&](int s) {
+#define PS_B3_LOAD_B(s_)                              \
+    do {                                              \
+        breg0 = *bsrc((s_), 0 * 256 + threadIdx.x);   \
+        breg1 = *bsrc((s_), 1 * 256 + threadIdx.x);   \
+        breg2 = *bsrc((s_), 2 * 256 + threadIdx.x);   \
+        breg3 = *bsrc((s_), 3 * 256 + threadIdx.x);   \
+        breg4 = *bsrc((s_), 4 * 256 + threadIdx.x);   \
+        breg5 = *bsrc((s_), 5 * 256 + threadIdx.x);   \
+    } while (0)
+#define PS_B3_STORE_B(buf_)                           \
+    do {                                              \
+        Bs[(buf_)][0 * 256 + threadIdx.x] = breg0;    \
+        Bs[(buf_)][1 * 256 + threadIdx.x] = breg1;    \
+        Bs[(buf_)][2 * 256 + threadIdx.x] = breg2;    \
+        Bs[(buf_)][3 * 256 + threadIdx.x] = breg3;    \
+        Bs[(buf_)][4 * 256 + threadIdx.x] = breg4;    \
+        Bs[(buf_)][5 * 256 + threadIdx.x] = breg5;    \
+    } while (0)
+    // one 16-K half (u) of a step's activations: 2 x 16 bytes per row tile and lane
+    auto load_a_half = [&](int s, int u) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) breg[j] = *bsrc(s, j * 256 + threadIdx.x);
-    };
-    auto store_b = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) Bs[buf][j * 256 + threadIdx.x] = breg[j];
-    };
-    auto load_a = [&](int s) {
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                areg[i][2 * u] = *reinterpret_cast<const float4*>(xr[i] + 32 * s + 16 * u);
-                areg[i][2 * u + 1] = *reinterpret_cast<const float4*>(xr[i] + 32 * s + 16 * u + 4);
-            }
+        for (int i = 0; i < RT; ++i) {
+            areg[i][2 * u] = *reinterpret_cast<const float4*>(xr[i] + 32 * s + 16 * u);
+            areg[i][2 * u + 1] = *reinterpret_cast<const float4*>(xr[i] + 32 * s + 16 * u + 4);
+        }
     };
     f32x16 acc[RT][4];
 #pragma unroll
@@ -136,35 +147,44 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmB3Args a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 
-    load_b(0);
-    load_a(0);
-    store_b(0);
+    PS_B3_LOAD_B(0);
+    load_a_half(0, 0);
+    load_a_half(0, 1);
+    PS_B3_STORE_B(0);
     __syncthreads();
+    // Register budget (256 VGPRs, two waves per SIMD): 128 accumulators + 32 (activations in flight) + 24 (weight planes in flight) + 24
+    // (one half's split planes) + 12 (a weight fragment): each half is split right before its products, its registers take the next
+    // step's loads as soon as they are dead, and the weight planes are fetched under the second half.  (Round 2's form kept the
+    // prefetched planes in scratch -- see breg above -- and the matrix pipe idled 74 % of the time: rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES,
+    // [360k, 256] x [256, 128] 0.248 ms.)
     for (int s = 0; s < steps; ++s) {
         const int buf = s & 1;
-        B3Planes ap[RT][2];
+        const bool more = s + 1 < steps;
 #pragma unroll
-        for (int i = 0; i < RT; ++i) {
-            ap[i][0] = b3_split8(areg[i][0], areg[i][1]);
-            ap[i][1] = b3_split8(areg[i][2], areg[i][3]);
-        }
-        if (s + 1 < steps) {  // the next step's operands travel under this step's products
-            load_b(s + 1);
-            load_a(s + 1);
-        }
+        for (int u = 0; u < 2; ++u) {
+            B3Planes ap[RT];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+            for (int i = 0; i < RT; ++i) ap[i] = b3_split8(areg[i][2 * u], areg[i][2 * u + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {  // the next step's operands travel under this step's products
+                load_a_half(s + 1, u);
+                if (u == 1) PS_B3_LOAD_B(s + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 B3Planes bp;
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) bp.p[pl] = Bs[buf][((u * 4 + t) * 3 + pl) * 64 + lane];
 #pragma unroll
-                for (int i = 0; i < RT; ++i) acc[i][t] = b3_mfma6(ap[i][u], bp, acc[i][t]);
+                for (int i = 0; i < RT; ++i) acc[i][t] = b3_mfma6(ap[i], bp, acc[i][t]);
             }
-        if (s + 1 < steps) store_b(buf ^ 1);  // (the other buffer: its last readers passed the barrier at the end of step s - 1)
+        }
+        if (more) PS_B3_STORE_B(buf ^ 1);  // (the other buffer: its last readers passed the barrier at the end of step s - 1)
         __syncthreads();
     }
+#undef PS_B3_LOAD_B
+#undef PS_B3_STORE_B
     // accumulator register r of tile (i, t) = row 32 i + (r & 3) + 8 (r >> 2) + 4 hl of the wave's rows, column 128 panel + 32 t + c32
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -200,13 +220,13 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmB3Args a)
 
 bool gemm_b3_fits(int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx)
 {
-    // K >= 256: measured against rowgemm.hip (profiles/tools/gemm_b3_ab.py; plain / accumulate epilogue) -- [360k, 256] x [256, 256]: 0.46 / 0.50 vs
-    // 0.67 / 0.83 ms, [90k, 512] x [512, 512]: 0.43 / 0.44 vs 0.56 / 0.67 ms, [90k, 256] x [256, 512]: 0.24 / 0.27 vs 0.31 / 0.40 ms;
-    // K = 128 ([1.44M, 128] x [128, 128], HBM bound: 1.5 GB of rows against 47 GFLOP) ties or loses (0.63 / 0.70 vs 0.60 / 0.66 ms)
-    // R >= 16384: a workgroup owns 256 rows x 128 columns, so the few-row GEMMs of the deep levels leave most CUs without one (round 3,
-    // profiles/tools/gemm_shapes_ab.py: [5624, 1536] x [1536, 512] 0.276 ms here against 0.125 on the split-K fp32 kernel, [5624, 512] x
-    // [512, 256] 0.078 against 0.024, [5624, 1024] x [1024, 512] 0.139 against 0.085; [22496, 256] x [256, 512] 0.077 against 0.087)
-    return R >= 16384 && K >= 256 && K % 32 == 0 && N % 128 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && R < (1ll << 31);
+    // Measured against rowgemm.hip (profiles/tools/gemm_shapes_ab.py, round 3, after the prefetched weight planes left scratch memory):
+    //   [360k, 256] x [256, 128] 0.177 vs 0.340 ms, [90k, 512] x [512, 256] 0.148 vs 0.279, [90k, 256] x [256, 512] 0.164 vs 0.298,
+    //   [22k, 256] x [256, 512] 0.056 vs 0.085; K = 128: [1.44M, 128] x [128, 128] 0.457 vs 0.530 (1.5 GB of rows: HBM bound),
+    //   [360k, 128] x [128, 256] 0.219 vs 0.289.
+    // R >= 16384: a workgroup owns 256 rows x 128 columns, so the few-row GEMMs of the deep levels leave most CUs without one ([5624, 1536]
+    // x [1536, 512] 0.276 ms here against 0.125 on the split-K fp32 kernel, [5624, 512] x [512, 256] 0.078 against 0.024)
+    return R >= 16384 && K >= 128 && K % 32 == 0 && N % 128 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && R < (1ll << 31);
 }
 
 size_t gemm_b3_plane_bytes(int64_t K, int64_t N) { return (size_t)K * N * 6; }
