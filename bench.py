@@ -403,7 +403,7 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
     params = weights.init_params(cfg, seed=2)
     tr = Trainer(cfg, params=params, device=local_rank, ctx=ctx, keep_prob=0.5, sync_bn=dist is not None and not args.local_bn,
                  mlp_dtype="bf16" if args.bf16_mlp else "fp32", fused_att=not args.no_fused_att, fused_locse=not args.no_fused_locse, fused_convbn=args.fused_convbn,
-                 engine=args.train_engine)
+                 engine=args.train_engine, deterministic=not args.atomic_scatter)
     d_xyz, d_feats, d_lab = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
     pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
     seen = ranks_seen(dist, "cuda" if args.dist_backend == "nccl" else "cpu") if dist is not None else 1
@@ -495,6 +495,9 @@ def main():
     ap.add_argument("--train-engine", choices=["native", "python"], default="native",
                     help="train mode: native = ps_randla_train_step, the whole step behind one C-ABI call (csrc/trainer.hip); python = the host-side "
                          "tape over the same op-level kernels (A/B)")
+    ap.add_argument("--atomic-scatter", action="store_true",
+                    help="train mode: the scatter-adds of the backward pass with float atomics (run-to-run differences in the last bits) instead of "
+                         "fixed-order gather-reductions over inverse indices (A/B of csrc/invidx.hip)")
     ap.add_argument("--local-bn", action="store_true", help="train mode, N > 1: per-GPU BatchNorm statistics instead of statistics shared by all ranks")
     ap.add_argument("--clouds", type=int, default=8, help="distinct resident clouds every rank rotates through (one per step)")
     ap.add_argument("--no-sub-results", action="store_true", help="skip the PCIe-inclusive sub-result of the default line")

@@ -341,6 +341,31 @@ int ps_op_conv_bn_train_bwd_sums(ps_context* ctx, const float* x, int64_t ldx, c
 int ps_op_conv_bn_train_bwd_apply(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t C,
                                   const float* mean, const float* invstd, const float* scale, const float* beta, const float* m1,
                                   const float* m2, const float* dz, int64_t lddz, int accumulate, float* dx, int64_t lddx);
+/* ---- deterministic scatter-adds (csrc/invidx.hip).  The backward of tf.batch_gather (gather_neighbour, nearest_interpolation,
+ * random_sample: RandLANet.py:345-386) adds gradient rows onto the rows they were gathered from; with float atomics the order of the
+ * additions changes from run to run.  ps_op_inverse_index inverts a gather table idx i32[B, rows_per_cloud] (values in [0, N)):
+ * offsets i32[B*N + 1], src i32[B*rows_per_cloud] = the flat rows r that read source row j = b*N + idx[r], ASCENDING, for
+ * j's segment offsets[j] .. offsets[j+1]; workspace: ps_op_inverse_index_workspace(B*N, B*rows_per_cloud) int32 words, 8-byte aligned
+ * (tables of a million rows and more go through a stable radix sort of (destination, row) pairs, smaller ones through count / scan / fill).  ps_op_gather_reduce_rows then
+ * forms dst[j, :] (+)= sum over the segment, in that order, of rows[src, :] -- every backward scatter as a gather-reduction, no atomics. */
+int64_t ps_op_inverse_index_workspace(int64_t n_dst, int64_t rows);
+int ps_op_inverse_index(ps_context* ctx, const int32_t* idx, int64_t B, int64_t N, int64_t rows_per_cloud, int32_t* offsets,
+                        int32_t* src, int32_t* workspace);
+int ps_op_gather_reduce_rows(ps_context* ctx, const float* rows, int64_t ldr, const int32_t* offsets, const int32_t* src,
+                             int64_t n_dst, int64_t d, float* dst, int64_t ldd, int accumulate);
+/* ps_op_random_sample_bwd through an inverse index.  pool_idx i32[B, M, K] must be the first M rows per cloud of a table
+ * i32[B, N', K] with N' >= M (the pyramid's sub_idx = neigh_idx[:, :M], runBraTS.py:150) and offsets / src the inverse index of THAT
+ * table (rows_per_cloud = N'*K, here N' = N): the pooling rows are a prefix of every segment, no second index is built.
+ * share_ws: B*M*d floats */
+int ps_op_random_sample_bwd_inv(ps_context* ctx, const float* dout, const float* out, const float* feature,
+                                const int32_t* pool_idx, const int32_t* offsets, const int32_t* src, int64_t B, int64_t N,
+                                int64_t M, int64_t K, int64_t d, float* share_ws, float* dfeature);
+/* ps_op_att_pool_train_bwd_split with the gathered half's gradient written as plain rows dfl_rows f32[B*n_q*K, d/2] (row stride
+ * ld_rows) instead of scatter-added: follow it with ps_op_gather_reduce_rows over the inverse index of idx. */
+int ps_op_att_pool_train_bwd_split_rows(ps_context* ctx, const float* fl, int64_t ldl, const int32_t* idx, int64_t B,
+                                        int64_t n_src, int64_t n_q, const float* fr, int64_t ldr, const float* wfc,
+                                        const float* dagg, int64_t K, int64_t d, float* dfl_rows, int64_t ld_rows, float* dfr,
+                                        int64_t lddr, float* dwfc);
 /* backward of random_sample (max over K); ties share the gradient evenly like tf.reduce_max; dfeature accumulates */
 int ps_op_random_sample_bwd(ps_context* ctx, const float* dout, const float* out, const float* feature,
                             const int32_t* pool_idx, int64_t B, int64_t N, int64_t M, int64_t K, int64_t d,
@@ -388,6 +413,8 @@ typedef struct {
     int32_t fused_locse;            /* the LocSE branch recomputed from coordinates and indices instead of materialised */
     int32_t num_ignored;            /* cfg.ignored_label_inds (RandLANet.py:68-81): labels dropped from the loss, <= 8 */
     int32_t ignored_label_inds[8];
+    int32_t deterministic;          /* every scatter-add of the backward pass as a fixed-order gather-reduction over an inverse index built
+                                     * once per level and step (csrc/invidx.hip): two runs of a step give bit-identical gradients */
 } ps_train_options;
 /* In-place sum over the ranks of `count` elements at device pointer `buf` (dtype 0: float32, 1: float64), ordered on `hip_stream`
  * (the context's stream).  Returns 0 on success. */

@@ -49,6 +49,8 @@ struct AttTrainArgs {
     float* dfl;          // [B*n_src, D/2] rows (lddl), accumulated into (backward)
     int64_t n_src, n_q;  // rows per cloud of fl / points per cloud
     int ldl, lddl;
+    float* dfl_rows;     // non-null: the gathered half's gradient goes HERE as plain rows [R*K, D/2] (ld_rows) instead of being scatter-added into
+    int ld_rows;         // dfl with float atomics; ps_op_gather_reduce_rows then adds the rows up in a fixed order (deterministic step)
 };
 
 template <int D>
@@ -240,6 +242,9 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
                 if (col >= D / 2) {  // f_xyz half: plain rows
 #pragma unroll
                     for (int r = 0; r < 4; ++r) a.df[(size_t)(p * KN + 4 * g + r) * a.lddf + col - D / 2] = acc[r];
+                } else if (a.dfl_rows) {  // gathered half as plain rows: summed per source row by a gather-reduction afterwards
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a.dfl_rows[(size_t)(p * KN + 4 * g + r) * a.ld_rows + col] = acc[r];
                 } else {             // gathered half: scatter-add onto the source rows
                     const int4 nb = *reinterpret_cast<const int4*>(a.idx + p * KN + 4 * g);
                     const int64_t base = (p / a.n_q) * a.n_src;
@@ -459,6 +464,9 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
                 if (col >= D / 2) {  // f_xyz half: plain rows
 #pragma unroll
                     for (int r = 0; r < 4; ++r) a.df[(size_t)(p * KN + 4 * g + r) * a.lddf + col - D / 2] = acc[r];
+                } else if (a.dfl_rows) {  // gathered half as plain rows: summed per source row by a gather-reduction afterwards
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a.dfl_rows[(size_t)(p * KN + 4 * g + r) * a.ld_rows + col] = acc[r];
                 } else {             // gathered half: scatter-add onto the source rows
                     const int4 nb = *reinterpret_cast<const int4*>(a.idx + p * KN + 4 * g);
                     const int64_t base = (p / a.n_q) * a.n_src;
@@ -630,9 +638,29 @@ extern "C" int ps_op_att_pool_train_fwd_split(ps_context* c, const float* fl, in
     }
 }
 
+static int att_bwd_split_impl(ps_context* c, const float* fl, int64_t ldl, const int32_t* idx, int64_t B, int64_t n_src, int64_t n_q, const float* fr,
+                              int64_t ldr, const float* wfc, const float* dagg, int64_t K, int64_t d, float* dfl, int64_t lddl, float* dfr, int64_t lddr,
+                              float* dwfc, float* dfl_rows, int64_t ld_rows);
+
 extern "C" int ps_op_att_pool_train_bwd_split(ps_context* c, const float* fl, int64_t ldl, const int32_t* idx, int64_t B, int64_t n_src, int64_t n_q,
                                               const float* fr, int64_t ldr, const float* wfc, const float* dagg, int64_t K, int64_t d, float* dfl,
                                               int64_t lddl, float* dfr, int64_t lddr, float* dwfc)
+{
+    PS_CHECK(dfl, "ps_op_att_pool_train_bwd_split: NULL argument");
+    return att_bwd_split_impl(c, fl, ldl, idx, B, n_src, n_q, fr, ldr, wfc, dagg, K, d, dfl, lddl, dfr, lddr, dwfc, nullptr, 0);
+}
+
+extern "C" int ps_op_att_pool_train_bwd_split_rows(ps_context* c, const float* fl, int64_t ldl, const int32_t* idx, int64_t B, int64_t n_src, int64_t n_q,
+                                                   const float* fr, int64_t ldr, const float* wfc, const float* dagg, int64_t K, int64_t d,
+                                                   float* dfl_rows, int64_t ld_rows, float* dfr, int64_t lddr, float* dwfc)
+{
+    PS_CHECK(dfl_rows && ld_rows >= d / 2, "ps_op_att_pool_train_bwd_split_rows: dfl_rows is NULL or its row stride below d/2");
+    return att_bwd_split_impl(c, fl, ldl, idx, B, n_src, n_q, fr, ldr, wfc, dagg, K, d, dfl_rows, ld_rows, dfr, lddr, dwfc, dfl_rows, ld_rows);
+}
+
+static int att_bwd_split_impl(ps_context* c, const float* fl, int64_t ldl, const int32_t* idx, int64_t B, int64_t n_src, int64_t n_q, const float* fr,
+                              int64_t ldr, const float* wfc, const float* dagg, int64_t K, int64_t d, float* dfl, int64_t lddl, float* dfr, int64_t lddr,
+                              float* dwfc, float* dfl_rows, int64_t ld_rows)
 {
     PS_CHECK(c && fl && idx && fr && wfc && dagg && dfl && dfr && dwfc, "ps_op_att_pool_train_bwd_split: NULL argument");
     PS_CHECK(att_train_ok(K, d, ldr, fr) && ldl % 4 == 0 && (reinterpret_cast<uintptr_t>(fl) & 15) == 0 && lddl >= d / 2 && lddr >= d / 2 && n_src > 0,
@@ -647,6 +675,7 @@ extern "C" int ps_op_att_pool_train_bwd_split(ps_context* c, const float* fl, in
     AttTrainArgs a = {};
     a.f = fr; a.ld = (int)ldr; a.fl = fl; a.ldl = (int)ldl; a.idx = idx; a.n_src = n_src; a.n_q = n_q;
     a.w = wfc; a.dagg = dagg; a.df = dfr; a.lddf = (int)lddr; a.dfl = dfl; a.lddl = (int)lddl; a.R = R; a.bf16 = c->train_bf16 ? 1 : 0;
+    a.dfl_rows = dfl_rows; a.ld_rows = (int)ld_rows;
     switch (d) {
         case 16: return launch_att_train<16>(c, a, true, dwfc);
         case 32: return launch_att_train<32>(c, a, true, dwfc);

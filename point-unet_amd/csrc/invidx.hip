@@ -1,0 +1,243 @@
+// invidx.hip -- inverse index of a gather table and the gather-reductions built on it: the DETERMINISTIC backward of
+// gather_neighbour / nearest_interpolation / random_sample (tf.batch_gather and tf.reduce_max in PointSegment/RandLANet.py:345-386).
+//
+// The backward of `out[r, :] = pc[b(r) * N + idx[r], :]` is a scatter-add, dpc[b * N + idx[r], :] += dout[r, :].  With float atomics
+// the order of the additions -- and with it the last bits of every gradient -- changes from run to run.  Here the table is inverted once
+// per pyramid level and step: offsets[j] .. offsets[j + 1] delimit the rows r that read source row j, in ASCENDING r (count with integer
+// atomics, exclusive scan, fill, then a per-segment sort that removes the fill order), and every backward becomes a gather-reduction
+// over that segment in that fixed order -- one coalesced read of every gradient row, one write per source row, no atomics.  Segments are
+// short (a point sits in about K neighbour lists), wide rows (d >= 64 floats at levels 2-4) make the gather itself efficient.
+#include "common.h"
+#include "sortscan.h"
+
+namespace ps {
+
+__global__ __launch_bounds__(256) void inv_count_kernel(const int32_t* __restrict__ idx, int64_t rows, int rows_per_cloud, int n_cloud,
+                                                        unsigned* __restrict__ cnt)
+{
+    for (int64_t r = blockIdx.x * (int64_t)256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256)
+        atomicAdd(&cnt[(r / rows_per_cloud) * n_cloud + idx[r]], 1u);  // (integer atomics: the counts do not depend on the order)
+}
+
+__global__ __launch_bounds__(256) void inv_fill_kernel(const int32_t* __restrict__ idx, int64_t rows, int rows_per_cloud, int n_cloud,
+                                                       const unsigned* __restrict__ offsets, unsigned* __restrict__ cursor, int32_t* __restrict__ src)
+{
+    for (int64_t r = blockIdx.x * (int64_t)256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+        const int64_t j = (r / rows_per_cloud) * n_cloud + idx[r];
+        const unsigned slot = atomicAdd(&cursor[j], 1u);
+        src[offsets[j] + slot] = (int32_t)r;
+    }
+}
+
+// one thread per segment: ascending order (the fill order is whatever the atomics made it).  Segments of up to 32 entries are sorted in
+// registers, longer ones (duplicate points, degenerate clouds) by insertion in place.
+__global__ __launch_bounds__(256) void inv_sort_kernel(const unsigned* __restrict__ offsets, int64_t n_dst, int32_t* __restrict__ src)
+{
+    const int64_t j = blockIdx.x * (int64_t)256 + threadIdx.x;
+    if (j >= n_dst) return;
+    const unsigned lo = offsets[j], hi = offsets[j + 1];
+    const int n = (int)(hi - lo);
+    if (n < 2) return;
+    int32_t* s = src + lo;
+    for (int i = 1; i < n; ++i) {
+        const int32_t v = s[i];
+        int k = i - 1;
+        while (k >= 0 && s[k] > v) {
+            s[k + 1] = s[k];
+            --k;
+        }
+        s[k + 1] = v;
+    }
+}
+
+// ---- the same inverse index by a stable radix sort of (destination, row) pairs: for the multi-million-row tables of the shallow levels the
+// two random-access atomics per row above cost 3 ms for 23 M rows; three 8-bit passes of the sort stream the pairs instead ----
+__global__ __launch_bounds__(256) void inv_keys_kernel(const int32_t* __restrict__ idx, int64_t rows, int rows_per_cloud, int n_cloud,
+                                                       unsigned* __restrict__ keys, unsigned* __restrict__ vals)
+{
+    for (int64_t r = blockIdx.x * (int64_t)256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+        keys[r] = (unsigned)((r / rows_per_cloud) * n_cloud + idx[r]);
+        vals[r] = (unsigned)r;
+    }
+}
+// sorted keys -> offsets: position i opens the segments of every destination in (keys[i-1], keys[i]]; the last position closes the rest
+__global__ __launch_bounds__(256) void inv_offsets_kernel(const unsigned* __restrict__ keys, int64_t rows, int64_t n_dst, unsigned* __restrict__ offsets)
+{
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < rows; i += (int64_t)gridDim.x * 256) {
+        const long long key = (long long)keys[i], prev = i > 0 ? (long long)keys[i - 1] : -1;
+        for (long long q = prev + 1; q <= key; ++q) offsets[q] = (unsigned)i;
+        if (i == rows - 1)
+            for (long long q = key + 1; q <= n_dst; ++q) offsets[q] = (unsigned)rows;
+    }
+}
+
+// dst[j, :] (+)= sum over the segment of j of rows[src, :], in segment order.  One lane group of d/4 (VEC) or d lanes per destination row.
+template <bool VEC>
+__global__ __launch_bounds__(256) void gather_reduce_kernel(const float* __restrict__ rows, int64_t ldr, const unsigned* __restrict__ offsets,
+                                                            const int32_t* __restrict__ src, int64_t n_dst, int d, float* __restrict__ dst, int64_t ldd,
+                                                            int accumulate)
+{
+    const int per = VEC ? d / 4 : d;
+    const int64_t total = n_dst * per;
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t j = t / per;
+        const int q = (int)(t - j * per);
+        const unsigned lo = offsets[j], hi = offsets[j + 1];
+        if (VEC) {
+            float4 acc = accumulate ? *reinterpret_cast<const float4*>(dst + j * ldd + 4 * q) : float4{0.f, 0.f, 0.f, 0.f};
+            for (unsigned s = lo; s < hi; ++s) {
+                const float4 v = *reinterpret_cast<const float4*>(rows + (int64_t)src[s] * ldr + 4 * q);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            *reinterpret_cast<float4*>(dst + j * ldd + 4 * q) = acc;
+        } else {
+            float acc = accumulate ? dst[j * ldd + q] : 0.f;
+            for (unsigned s = lo; s < hi; ++s) acc += rows[(int64_t)src[s] * ldr + q];
+            dst[j * ldd + q] = acc;
+        }
+    }
+}
+
+// random_sample backward, step 1: share[m, c] = dout[m, c] / (number of the K gathered rows that attain the maximum) -- ties share the
+// gradient evenly like tf.reduce_max's
+__global__ __launch_bounds__(256) void maxpool_share_kernel(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ feat,
+                                                            const int32_t* __restrict__ idx, size_t rows, int m_cloud, int n_cloud, int K, int d,
+                                                            float* __restrict__ share)
+{
+    const size_t t = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (t >= rows * d) return;
+    const size_t row = t / d;
+    const int ch = (int)(t - row * d);
+    const size_t base = (row / m_cloud) * n_cloud;
+    const int32_t* ix = idx + row * K;
+    const float mx = out[t];
+    int ties = 0;
+    for (int k = 0; k < K; ++k) ties += feat[(base + ix[k]) * d + ch] == mx;
+    share[t] = dout[t] / (float)ties;
+}
+// step 2: dfeat[j, c] += sum over the (m, k) that gathered row j, in ascending order, of share[m, c] where feat[j, c] attains out[m, c].
+// The inverse index is that of the level's NEIGHBOUR table [B, N, K]: the pooling table is its first M rows per cloud (sub_idx =
+// neigh_idx[:, :M], runBraTS.py:150), a segment lists its rows in ascending order and all of them belong to the cloud of j -- so the
+// pooling rows of a segment are a PREFIX of it and no second index is needed.
+__global__ __launch_bounds__(256) void maxpool_bwd_inv_kernel(const float* __restrict__ share, const float* __restrict__ out, const float* __restrict__ feat,
+                                                              const unsigned* __restrict__ offsets, const int32_t* __restrict__ src, int64_t n_dst, int n_cloud,
+                                                              int m_cloud, int K, int d, float* __restrict__ dfeat)
+{
+    const int64_t total = n_dst * d;
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t j = t / d;
+        const int ch = (int)(t - j * d);
+        const unsigned lo = offsets[j], hi = offsets[j + 1];
+        if (lo == hi) continue;
+        const int64_t b = j / n_cloud;
+        const float f = feat[t];
+        float acc = 0.f;
+        for (unsigned s = lo; s < hi; ++s) {
+            const int64_t n = src[s] / K - b * n_cloud;  // src holds flat (point * K + k) positions of the neighbour table
+            if (n >= m_cloud) break;                      // (ascending: the rest of the segment is not part of the pooling table)
+            const int64_t m = b * m_cloud + n;
+            if (out[m * d + ch] == f) acc += share[m * d + ch];
+        }
+        dfeat[t] += acc;
+    }
+}
+
+static inline unsigned iv_grid(int64_t n)
+{
+    const int64_t b = (n + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+}  // namespace ps
+
+using namespace ps;
+
+extern "C" {
+
+static constexpr int64_t kInvSortRows = 1 << 20;  // tables of at least this many rows are inverted by the radix sort
+
+int64_t ps_op_inverse_index_workspace(int64_t n_dst, int64_t rows)
+{
+    if (n_dst < 0 || rows < 0) return -1;
+    if (rows >= kInvSortRows) return (int64_t)(2 * rows + rows + sort_workspace_words((size_t)rows) + 64);  // two key arrays, one value array
+    return (int64_t)(n_dst + 1 + scan_workspace_words((size_t)n_dst + 1) + 64);
+}
+
+int ps_op_inverse_index(ps_context* c, const int32_t* idx, int64_t B, int64_t N, int64_t rows_per_cloud, int32_t* offsets, int32_t* src, int32_t* workspace)
+{
+    PS_CHECK(c && idx && offsets && src && workspace, "ps_op_inverse_index: NULL argument");
+    PS_CHECK(B >= 1 && N >= 1 && rows_per_cloud >= 0 && B * N < (1ll << 31) && B * rows_per_cloud < (1ll << 31), "ps_op_inverse_index: bad sizes");
+    PS_HIP(hipSetDevice(c->device));
+    const int64_t n_dst = B * N, rows = B * rows_per_cloud;
+    unsigned* off = reinterpret_cast<unsigned*>(offsets);
+    if (rows >= kInvSortRows) {
+        Stage st(c, "train_inverse_index", 12);
+        PS_CHECK((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "ps_op_inverse_index: workspace must be 8-byte aligned");
+        unsigned* k0 = reinterpret_cast<unsigned*>(workspace);
+        unsigned* k1 = k0 + rows;
+        unsigned* vtmp = k1 + rows;
+        unsigned* sort_ws = vtmp + rows;
+        int bits = 1;
+        while ((1ll << bits) < n_dst) ++bits;
+        const int passes = (bits + 7) / 8;
+        // the sorted values must end in `src`: an odd number of passes ends in the second pair of arrays
+        unsigned* v0 = (passes & 1) ? vtmp : reinterpret_cast<unsigned*>(src);
+        unsigned* v1 = (passes & 1) ? reinterpret_cast<unsigned*>(src) : vtmp;
+        hipLaunchKernelGGL(inv_keys_kernel, dim3(iv_grid(rows)), dim3(256), 0, c->stream, idx, rows, (int)rows_per_cloud, (int)N, k0, v0);
+        const int cur = radix_sort_pairs_u32(c->stream, k0, k1, v0, v1, (size_t)rows, bits, sort_ws);
+        hipLaunchKernelGGL(inv_offsets_kernel, dim3(iv_grid(rows)), dim3(256), 0, c->stream, cur ? k1 : k0, rows, n_dst, off);
+        PS_HIP(hipGetLastError());
+        return PS_OK;
+    }
+    Stage st(c, "train_inverse_index", 5);
+    unsigned* cursor = reinterpret_cast<unsigned*>(workspace);
+    unsigned* scan_ws = cursor + n_dst + 1;
+    PS_HIP(hipMemsetAsync(off, 0, sizeof(unsigned) * (size_t)(n_dst + 1), c->stream));
+    PS_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned) * (size_t)(n_dst + 1), c->stream));
+    if (rows > 0) hipLaunchKernelGGL(inv_count_kernel, dim3(iv_grid(rows)), dim3(256), 0, c->stream, idx, rows, (int)rows_per_cloud, (int)N, off);
+    exclusive_scan_u32(c->stream, off, off, (size_t)n_dst + 1, scan_ws);
+    if (rows > 0) {
+        hipLaunchKernelGGL(inv_fill_kernel, dim3(iv_grid(rows)), dim3(256), 0, c->stream, idx, rows, (int)rows_per_cloud, (int)N, off, cursor, src);
+        hipLaunchKernelGGL(inv_sort_kernel, dim3(ceil_div(n_dst, 256)), dim3(256), 0, c->stream, off, n_dst, src);
+    }
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+int ps_op_gather_reduce_rows(ps_context* c, const float* rows, int64_t ldr, const int32_t* offsets, const int32_t* src, int64_t n_dst, int64_t d, float* dst,
+                             int64_t ldd, int accumulate)
+{
+    PS_CHECK(c && rows && offsets && src && dst, "ps_op_gather_reduce_rows: NULL argument");
+    PS_CHECK(n_dst >= 0 && d >= 1 && ldr >= d && ldd >= d, "ps_op_gather_reduce_rows: bad shape");
+    if (!n_dst) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "train_scatter_add", 1);
+    const bool vec = (d % 4) == 0 && (ldr % 4) == 0 && (ldd % 4) == 0 && ((reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    const unsigned* off = reinterpret_cast<const unsigned*>(offsets);
+    if (vec)
+        hipLaunchKernelGGL(gather_reduce_kernel<true>, dim3(iv_grid(n_dst * (d / 4))), dim3(256), 0, c->stream, rows, ldr, off, src, n_dst, (int)d, dst, ldd,
+                           accumulate);
+    else
+        hipLaunchKernelGGL(gather_reduce_kernel<false>, dim3(iv_grid(n_dst * d)), dim3(256), 0, c->stream, rows, ldr, off, src, n_dst, (int)d, dst, ldd,
+                           accumulate);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+int ps_op_random_sample_bwd_inv(ps_context* c, const float* dout, const float* out, const float* feature, const int32_t* pool_idx, const int32_t* offsets,
+                                const int32_t* src, int64_t B, int64_t N, int64_t M, int64_t K, int64_t d, float* share_ws, float* dfeature)
+{
+    PS_CHECK(c && dout && out && feature && pool_idx && offsets && src && share_ws && dfeature, "ps_op_random_sample_bwd_inv: NULL argument");
+    const size_t rows = (size_t)B * M;
+    if (!rows) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "train_maxpool_bwd", 2);
+    hipLaunchKernelGGL(maxpool_share_kernel, dim3(ceil_div(rows * d, 256)), dim3(256), 0, c->stream, dout, out, feature, pool_idx, rows, (int)M, (int)N, (int)K,
+                       (int)d, share_ws);
+    hipLaunchKernelGGL(maxpool_bwd_inv_kernel, dim3(iv_grid(B * N * d)), dim3(256), 0, c->stream, share_ws, out, feature,
+                       reinterpret_cast<const unsigned*>(offsets), src, B * N, (int)N, (int)M, (int)K, (int)d, dfeature);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+}  // extern "C"

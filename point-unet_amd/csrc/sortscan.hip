@@ -73,7 +73,8 @@ size_t pad64(size_t n) { return (n + 63) & ~size_t(63); }
 
 // digit counts of one tile -> table[digit * ntiles + tile] (digit-major: its exclusive scan is, for every (digit, tile), the
 // number of keys with a smaller digit plus those with the same digit in earlier tiles = where the tile's run of that digit starts)
-__global__ __launch_bounds__(256) void radix_hist_kernel(const unsigned long long* __restrict__ keys, size_t n, int shift, unsigned* __restrict__ table,
+template <class KeyT>
+__global__ __launch_bounds__(256) void radix_hist_kernel(const KeyT* __restrict__ keys, size_t n, int shift, unsigned* __restrict__ table,
                                                          unsigned ntiles)
 {
     __shared__ unsigned h[256];
@@ -92,19 +93,20 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const unsigned long lon
 // Stable scatter of one tile.  Wave w owns elements [512 w, 512 w + 512) of the tile and walks them in order, 64 at a time:
 // a key's position = start of (digit, tile) + the same-digit keys of the earlier waves + those this wave has already placed +
 // its rank among the same-digit lanes below it (match mask from eight ballots).
-__global__ __launch_bounds__(256) void radix_scatter_kernel(const unsigned long long* __restrict__ kin, const unsigned* __restrict__ vin,
-                                                            unsigned long long* __restrict__ kout, unsigned* __restrict__ vout, size_t n, int shift,
+template <class KeyT>
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const KeyT* __restrict__ kin, const unsigned* __restrict__ vin,
+                                                            KeyT* __restrict__ kout, unsigned* __restrict__ vout, size_t n, int shift,
                                                             const unsigned* __restrict__ start /* scanned table */, unsigned ntiles)
 {
     __shared__ unsigned s_cnt[4][256], s_off[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t w0 = blockIdx.x * (size_t)kTile + (size_t)wave * 512;
-    unsigned long long k[8];
+    KeyT k[8];
     unsigned v[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const size_t i = w0 + s * 64 + lane;
-        k[s] = i < n ? kin[i] : 0ull;
+        k[s] = i < n ? kin[i] : KeyT(0);
         v[s] = i < n ? vin[i] : 0u;
     }
 #pragma unroll
@@ -172,23 +174,35 @@ size_t sort_workspace_words(size_t n)
     return table + scan_workspace_words(table);
 }
 
-int radix_sort_pairs_u64(hipStream_t st, unsigned long long* k0, unsigned long long* k1, unsigned* v0, unsigned* v1, size_t n, int bits, unsigned* work)
+template <class KeyT>
+static int radix_sort_pairs(hipStream_t st, KeyT* k0, KeyT* k1, unsigned* v0, unsigned* v1, size_t n, int bits, unsigned* work)
 {
     if (n == 0) return 0;
     const size_t nt = tiles_of(n), table_n = 256 * nt;
     unsigned* table = work;
     unsigned* scan_work = work + pad64(table_n);
-    unsigned long long* k[2] = {k0, k1};
+    KeyT* k[2] = {k0, k1};
     unsigned* v[2] = {v0, v1};
     const int passes = bits <= 8 ? 1 : (bits + 7) / 8;
     int cur = 0;
     for (int p = 0; p < passes; ++p) {
-        hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)nt), dim3(256), 0, st, k[cur], n, 8 * p, table, (unsigned)nt);
+        hipLaunchKernelGGL(radix_hist_kernel<KeyT>, dim3((unsigned)nt), dim3(256), 0, st, k[cur], n, 8 * p, table, (unsigned)nt);
         exclusive_scan_u32(st, table, table, table_n, scan_work);
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nt), dim3(256), 0, st, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], n, 8 * p, table, (unsigned)nt);
+        hipLaunchKernelGGL(radix_scatter_kernel<KeyT>, dim3((unsigned)nt), dim3(256), 0, st, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], n, 8 * p, table,
+                           (unsigned)nt);
         cur ^= 1;
     }
     return cur;
+}
+
+int radix_sort_pairs_u64(hipStream_t st, unsigned long long* k0, unsigned long long* k1, unsigned* v0, unsigned* v1, size_t n, int bits, unsigned* work)
+{
+    return radix_sort_pairs<unsigned long long>(st, k0, k1, v0, v1, n, bits, work);
+}
+
+int radix_sort_pairs_u32(hipStream_t st, unsigned* k0, unsigned* k1, unsigned* v0, unsigned* v1, size_t n, int bits, unsigned* work)
+{
+    return radix_sort_pairs<unsigned>(st, k0, k1, v0, v1, n, bits, work);
 }
 
 }  // namespace ps

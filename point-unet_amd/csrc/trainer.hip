@@ -19,6 +19,7 @@
 
 #include <cmath>
 #include <functional>
+#include <map>
 #include <memory>
 #include <unordered_map>
 
@@ -370,6 +371,25 @@ struct ps_trainer {
     };
     std::vector<Op> ops;
     std::unordered_map<int, Tn> grad_of;
+    // inverse indices of the step's gather tables (deterministic mode): built at their first use in the backward pass, kept to its end
+    struct Inv {
+        Tn offsets, src;
+        int64_t n_dst;
+    };
+    std::map<const int32_t*, Inv> inv_cache;
+    const Inv& inverse(const int32_t* idx, int64_t B, int64_t N, int64_t rows_per_cloud)
+    {
+        auto it = inv_cache.find(idx);
+        if (it != inv_cache.end()) return it->second;
+        Inv v;
+        v.n_dst = B * N;
+        v.offsets = alloc(1, v.n_dst + 1, false);
+        v.src = alloc(1, std::max<int64_t>(B * rows_per_cloud, 1), false);
+        Tn ws = alloc(1, ps_op_inverse_index_workspace(v.n_dst, B * rows_per_cloud), false);
+        TK(ps_op_inverse_index(c, idx, B, N, rows_per_cloud, reinterpret_cast<int32_t*>(v.offsets.p), reinterpret_cast<int32_t*>(v.src.p),
+                               reinterpret_cast<int32_t*>(ws.p)));
+        return inv_cache.emplace(idx, v).first->second;
+    }
     std::vector<WgradJob> wjobs;  // weight / bias gradient partials waiting for the step's one reduction launch
     std::vector<Tn> wkeep;
     void finish_wgrads()
@@ -515,6 +535,7 @@ struct ps_trainer {
         }
         ops.clear();
         grad_of.clear();
+        inv_cache.clear();
         finish_wgrads();
     }
 
@@ -697,7 +718,13 @@ struct ps_trainer {
                 ps::set_error("trainer: scatter-add into a strided gradient");
                 throw TrainError{PS_ESTATE};
             }
-            TK(ps_op_scatter_add_rows_ex(c, dy.p, dy.ld, idx, B, N, M * K, d, buf.p));
+            if (opt.deterministic) {
+                const Inv& iv = inverse(idx, B, N, M * K);
+                TK(ps_op_gather_reduce_rows(c, dy.p, dy.ld, reinterpret_cast<const int32_t*>(iv.offsets.p), reinterpret_cast<const int32_t*>(iv.src.p), B * N, d,
+                                            buf.p, buf.ld, 1));
+            } else {
+                TK(ps_op_scatter_add_rows_ex(c, dy.p, dy.ld, idx, B, N, M * K, d, buf.p));
+            }
         });
         return o;
     }
@@ -758,13 +785,23 @@ struct ps_trainer {
             const Tn dy = contig(dy_in);
             Tn dfx = alloc(B * M * K, h);
             Tn dsrc = accum_buffer(f_src);  // the gathered half's gradient is added in place
-            TK(ps_op_att_pool_train_bwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, dy.p, K, d, dsrc.p, dsrc.ld, dfx.p, h, gW.p));
+            if (opt.deterministic) {
+                // ... as plain rows first, then summed per source row in ascending row order (no float atomics)
+                Tn rows = alloc(B * M * K, h, false);
+                TK(ps_op_att_pool_train_bwd_split_rows(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, dy.p, K, d, rows.p, h, dfx.p, h, gW.p));
+                const Inv& iv = inverse(idx, B, N, M * K);
+                TK(ps_op_gather_reduce_rows(c, rows.p, h, reinterpret_cast<const int32_t*>(iv.offsets.p), reinterpret_cast<const int32_t*>(iv.src.p), B * N, h,
+                                            dsrc.p, dsrc.ld, 1));
+            } else {
+                TK(ps_op_att_pool_train_bwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, dy.p, K, d, dsrc.p, dsrc.ld, dfx.p, h, gW.p));
+            }
             accum(f_xyz, dfx);
         });
         return agg;
     }
 
-    Tn maxpool(const Tn& x_in, const int32_t* pool_idx, int64_t B, int64_t M, int64_t K)
+    // neigh: the level's neighbour table [B, N, K] whose first M rows per cloud ARE pool_idx (ps_pyramid: sub_idx = neigh_idx[:, :M])
+    Tn maxpool(const Tn& x_in, const int32_t* pool_idx, const int32_t* neigh, int64_t B, int64_t M, int64_t K)
     {
         const Tn x = contig(x_in);
         const int64_t N = x.R / B, d = x.C;
@@ -774,7 +811,14 @@ struct ps_trainer {
         record(out, [=](const Tn& dy_in) {
             const Tn dy = contig(dy_in);
             Tn buf = accum_buffer(xin);
-            TK(ps_op_random_sample_bwd(c, dy.p, out.p, x.p, pool_idx, B, N, M, K, d, buf.p));
+            if (opt.deterministic && buf.contiguous()) {
+                const Inv& iv = inverse(neigh, B, N, N * K);  // (shared with the level's gathers: the pooling rows are a prefix of every segment)
+                Tn share = alloc(B * M, d, false);
+                TK(ps_op_random_sample_bwd_inv(c, dy.p, out.p, x.p, pool_idx, reinterpret_cast<const int32_t*>(iv.offsets.p),
+                                               reinterpret_cast<const int32_t*>(iv.src.p), B, N, M, K, d, share.p, buf.p));
+            } else {
+                TK(ps_op_random_sample_bwd(c, dy.p, out.p, x.p, pool_idx, B, N, M, K, d, buf.p));
+            }
         });
         return out;
     }
@@ -913,7 +957,7 @@ struct ps_trainer {
             Tn a = conv(f_agg2, n + "mlp2", true, false);
             Tn b = conv(feature, n + "shortcut", true, false);
             Tn f_enc = add_lrelu(a, b);
-            f = maxpool(f_enc, pyr->sub_idx[i], B, pyr->n[i + 1], K);
+            f = maxpool(f_enc, pyr->sub_idx[i], idx, B, pyr->n[i + 1], K);
             if (i == 0) enc.push_back(f_enc);
             enc.push_back(f);
         }
@@ -1071,6 +1115,7 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
     t->grad_of.clear();
     t->wjobs.clear();
     t->wkeep.clear();
+    t->inv_cache.clear();
     if (rc != PS_OK) return rc;
     if (!optimise) {
         try {
@@ -1165,6 +1210,7 @@ int ps_trainer_destroy(ps_trainer* t)
     t->ops.clear();
     t->grad_of.clear();
     t->wkeep.clear();
+    t->inv_cache.clear();
     t->pool.destroy();
     t->label_map.release();
     delete t;

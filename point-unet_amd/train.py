@@ -470,13 +470,15 @@ class Trainer:
     """Parameters (flat fp32 buffer + named views), Adam state and the train step."""
 
     def __init__(self, config, params=None, device=0, seed=0, learning_rate=None, class_weights=None, keep_prob=0.5, ctx=None, sync_bn=False,
-                 mlp_dtype="fp32", ignored_label_inds=None, fused_att=True, fused_locse=True, fused_convbn=False, engine="native"):
+                 mlp_dtype="fp32", ignored_label_inds=None, fused_att=True, fused_locse=True, fused_convbn=False, engine="native", deterministic=True):
         """sync_bn: with a `dist` passed to train_step, BatchNorm uses the statistics of all ranks' rows, which makes "W GPUs x
         one cloud" numerically the same step as "one GPU x W clouds" (SURVEY 8e); off = per-GPU statistics.
         mlp_dtype: "fp32" (default) or "bf16" -- BASELINE configs[2]'s "bf16 MLPs": the shared-MLP GEMMs (forward, input gradient,
         weight gradient) round their operands to bf16 and accumulate in fp32 (ps_set_train_gemm_bf16); everything else stays fp32.
         engine: "native" (default) = ps_randla_train_step, the tape in C++ (csrc/trainer.hip); "python" = the host-side tape of this
-        file (A/B reference; the only engine with fused_convbn)."""
+        file (A/B reference; the only engine with fused_convbn).
+        deterministic (native engine): the scatter-adds of the backward pass run as fixed-order gather-reductions over inverse indices
+        (csrc/invidx.hip) instead of float atomics -- two runs of a step produce bit-identical gradients."""
         if mlp_dtype not in ("fp32", "bf16"):
             raise ValueError("mlp_dtype must be 'fp32' or 'bf16'")
         if engine not in ("native", "python"):
@@ -484,6 +486,7 @@ class Trainer:
         if fused_convbn and engine == "native":
             engine = "python"  # (measured slower than the streaming kernels it replaces: kept out of the native step)
         self.engine = engine
+        self.deterministic = bool(deterministic)
         self.mlp_bf16 = mlp_dtype == "bf16"
         self.fused_att = bool(fused_att)  # False: the op-by-op attentive pooling everywhere (A/B switch of bench.py --no-fused-att)
         # LocSE branch (relative_pos_encoding -> conv 10->h -> BatchNorm -> LeakyReLU) recomputed from coordinates and indices instead of
@@ -554,6 +557,7 @@ class Trainer:
         o = _lib.PsTrainOptions()
         o.learning_rate, o.keep_prob = self.lr, self.keep_prob
         o.mlp_bf16, o.fused_att, o.fused_locse = int(self.mlp_bf16), int(self.fused_att), int(self.fused_locse)
+        o.deterministic = int(self.deterministic)
         o.num_ignored = len(self.ignored_label_inds)
         for i, v in enumerate(self.ignored_label_inds):
             o.ignored_label_inds[i] = v

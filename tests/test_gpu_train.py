@@ -253,8 +253,17 @@ def test_full_size_config3_step_properties(mode):
     assert bool(torch.isfinite(grad).all()) and float(grad.norm()) > 0
     rel = float((runs[1][2].double() - grad.double()).norm() / grad.double().norm())
     print("config3 %s: loss %.5f, grad norm %.4e, run-to-run rel L2 %.2e, max |step| %.3e" % (mode, loss, float(grad.norm()), rel, step))
-    assert rel <= (1e-5 if mode == "fp32" else 2e-3)
+    # the default step is DETERMINISTIC: weight / bias gradients and BatchNorm sums are fixed-order partial sums, every scatter-add of the
+    # backward pass a gather-reduction over an inverse index in ascending row order (csrc/invidx.hip) -- two runs, bit-identical gradients
+    assert torch.equal(runs[1][2], grad), rel
     assert 0 < step <= 1e-4 * (1 + 1e-3)
+    # ... and the float-atomics form of the scatter-adds (Trainer(deterministic=False)) computes the same gradients to summation order
+    tr = Trainer(cfg, params=params, learning_rate=1e-4, class_weights=cw, keep_prob=1.0, mlp_dtype=mode, deterministic=False)
+    loss_a = tr.train_step(pyr, d_f, d_l)
+    torch.cuda.synchronize()
+    rel_a = float((tr.grad.double() - grad.double()).norm() / grad.double().norm())
+    print("atomic scatter-adds against the deterministic ones: rel L2 %.2e" % rel_a)
+    assert float(loss_a) == loss and rel_a <= (1e-5 if mode == "fp32" else 2e-3)
 
 
 def test_ignored_labels_leave_the_loss_and_its_mean(oracle):
@@ -837,9 +846,12 @@ def test_native_step_equals_the_python_tape(mode):
             assert np.abs(a["logits"].reshape(b["logits"].shape) - b["logits"]).max() <= 0.1 * np.abs(b["logits"]).max()
             cos = float((a["grad"] * b["grad"]).sum() / (np.linalg.norm(a["grad"]) * np.linalg.norm(b["grad"])))
             assert cos >= 0.9, cos
-        else:
+        elif mode == "fp32":
             assert abs(a["loss"] - b["loss"]) <= 1e-2 * abs(b["loss"]), (a["loss"], b["loss"])
             assert np.abs(a["logits"].reshape(b["logits"].shape) - b["logits"]).max() <= 5e-2 * np.abs(b["logits"]).max()
+            assert np.abs(a["flat"] - b["flat"]).max() <= 4.2e-3
+        else:  # (bf16 mode, second step: two trajectories of a chaotic model -- only "still the same run")
+            assert np.isfinite(a["loss"]) and abs(a["loss"] - b["loss"]) <= 5e-2 * abs(b["loss"]), (a["loss"], b["loss"])
             assert np.abs(a["flat"] - b["flat"]).max() <= 4.2e-3
 
 
@@ -868,3 +880,63 @@ def test_backward_only_leaves_the_parameters_alone():
     assert torch.allclose(a.flat_buffers, b.flat_buffers, rtol=1e-6, atol=1e-7)
     mm = a.buffers["Encoder_layer_0mlp1/batch_normalization/moving_mean"].cpu().numpy()
     assert not np.array_equal(mm, params["Encoder_layer_0mlp1/batch_normalization/moving_mean"])
+
+
+def test_inverse_index_and_gather_reduction(oracle):
+    """ps_op_inverse_index / ps_op_gather_reduce_rows / ps_op_random_sample_bwd_inv / ps_op_att_pool_train_bwd_split_rows (csrc/invidx.hip): the
+    inverse of a gather table lists, per source row, the gathering rows in ASCENDING order; the gather-reduction over it equals the
+    scatter-add (to summation order) and repeats bit for bit; duplicated indices inside one K-list (n < K clouds are padded with 0),
+    rows nobody gathers, batches, strided gradient rows."""
+    import ctypes
+    import torch
+    from point_unet_amd import _lib, runtime
+    L, ctx = _lib.lib(), runtime.default_context(0)
+    h = ctx.handle
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(5)
+    for B, N, M, K, d in [(2, 700, 700, 16, 8), (1, 300, 1200, 1, 64), (3, 500, 125, 16, 32), (1, 40, 40, 16, 5), (2, 40000, 40000, 16, 4)]:  # (the last: the radix-sort form)
+        idx = torch.randint(0, N, (B, M, K), generator=g).int()
+        idx[:, : M // 7, K // 2:] = 0                       # zero padding / duplicates inside a list
+        idx[idx == N - 1] = 0                                # a source row nobody gathers
+        d_idx = idx.cuda()
+        n_dst, rpc = B * N, M * K
+        off = torch.empty(n_dst + 1, dtype=torch.int32, device="cuda")
+        src = torch.empty(B * rpc, dtype=torch.int32, device="cuda")
+        ws = torch.empty(int(L.ps_op_inverse_index_workspace(n_dst, B * rpc)), dtype=torch.int32, device="cuda")
+        _lib.check(L.ps_op_inverse_index(h, p(d_idx), B, N, rpc, p(off), p(src), p(ws)))
+        off_h, src_h = off.cpu().numpy(), src.cpu().numpy()
+        flat = (idx.reshape(B, -1).numpy().astype(np.int64) + (np.arange(B) * N)[:, None]).reshape(-1)
+        assert off_h[0] == 0 and off_h[-1] == B * rpc
+        assert np.array_equal(np.diff(off_h), np.bincount(flat, minlength=n_dst))
+        order = np.argsort(flat, kind="stable")              # ascending row inside every segment
+        assert np.array_equal(src_h, order.astype(np.int32))
+        # gather-reduction == scatter-add (float64 reference), strided rows, accumulate on and off
+        wide = torch.randn(B * rpc, d + 4, generator=g).cuda()
+        rows = wide[:, 2:d + 2]
+        ref = torch.zeros(n_dst, d, dtype=torch.float64)
+        ref.index_add_(0, torch.from_numpy(flat), rows.cpu().double())
+        for acc in (0, 1):
+            base = torch.randn(n_dst, d, generator=g).cuda()
+            out = base.clone()
+            _lib.check(L.ps_op_gather_reduce_rows(h, p(rows), d + 4, p(off), p(src), n_dst, d, p(out), d, acc))
+            want = ref + (base.cpu().double() if acc else 0)
+            assert (out.cpu().double() - want).abs().max() <= 1e-5 * max(1.0, want.abs().max())
+            again = base.clone()
+            _lib.check(L.ps_op_gather_reduce_rows(h, p(rows), d + 4, p(off), p(src), n_dst, d, p(again), d, acc))
+            assert torch.equal(out, again)
+        # random_sample backward through the inverse index of the table whose first M2 rows per cloud are the pooling table (the pyramid's
+        # sub_idx = neigh_idx[:, :M2]) == the atomics form on that prefix (ties included: quantised features)
+        if K > 1 and M == N:
+            M2 = max(1, M // 4)
+            pool = idx[:, :M2].contiguous().cuda()
+            feat = (torch.randint(0, 4, (B * N, d), generator=g).float() / 2).cuda()
+            out = torch.empty(B * M2, d, device="cuda")
+            _lib.check(L.ps_op_random_sample(h, p(feat), p(pool), B, N, M2, K, d, p(out)))
+            dout = torch.randn(B * M2, d, generator=g).cuda()
+            a = torch.zeros(B * N, d, device="cuda")
+            _lib.check(L.ps_op_random_sample_bwd(h, p(dout), p(out), p(feat), p(pool), B, N, M2, K, d, p(a)))
+            b = torch.zeros(B * N, d, device="cuda")
+            share = torch.empty(B * M2, d, device="cuda")
+            _lib.check(L.ps_op_random_sample_bwd_inv(h, p(dout), p(out), p(feat), p(pool), p(off), p(src), B, N, M2, K, d, p(share), p(b)))
+            assert (a - b).abs().max() <= 5e-5 * max(1.0, float(a.abs().max()))
+    torch.cuda.synchronize()
