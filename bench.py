@@ -294,7 +294,7 @@ def train_roofline(cfg, n0, B, ms, bf16):
             "mfma_frac": round(tfs / peak, 5), "hbm_frac": round(gbs / HBM_PEAK_GBS, 5)}
 
 
-def sub_train_b8(cfg, xyz_list, local_rank, bf16, steps=2, warmup=1):
+def sub_train_b8(cfg, xyz_list, local_rank, bf16, steps=2, warmup=1, deterministic=True):
     """BASELINE configs[2] inside the default line: batch 8 x 180 000-point clouds, pyramid + forward + backward + Adam through
     ps_randla_train_step, `steps` timed steps after `warmup` (the first step also grows the activation pool)."""
     import torch
@@ -310,7 +310,8 @@ def sub_train_b8(cfg, xyz_list, local_rank, bf16, steps=2, warmup=1):
     ctx = runtime.default_context(local_rank)
     ctx.use_torch_stream()
     ctx.set_deferred_checks(False)
-    tr = Trainer(cfg, params=weights.init_params(cfg, seed=2), device=local_rank, ctx=ctx, keep_prob=0.5, mlp_dtype="bf16" if bf16 else "fp32")
+    tr = Trainer(cfg, params=weights.init_params(cfg, seed=2), device=local_rank, ctx=ctx, keep_prob=0.5, mlp_dtype="bf16" if bf16 else "fp32",
+                 deterministic=deterministic)
     d_xyz, d_feats, d_lab = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
     pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
 
@@ -328,6 +329,7 @@ def sub_train_b8(cfg, xyz_list, local_rank, bf16, steps=2, warmup=1):
     ms = 1e3 * elapsed / steps
     out = {"ms_per_step": ms, "points_per_s": B * n0 * steps / elapsed, "steps": steps, "warmup": warmup, "batch": B, "points": n0,
            "dtype": "bf16" if bf16 else "f32", "loss": float(loss), "pool_peak_gb": tr.pool_peak_bytes() / 2 ** 30,
+           "gradients": "bit-reproducible (fixed-order reductions, csrc/invidx.hip)" if deterministic else "float-atomic scatter-adds (repeat to ~2e-6)",
            "roofline": train_roofline(cfg, n0, B, ms, bf16),
            "what": "BASELINE configs[2]: one training step (pyramid + train-mode forward + weighted CE + backward + Adam) = ONE ps_pyramid_build + ONE "
                    "ps_randla_train_step call, batch %d x %d points, %s" % (B, n0, "bf16 MLP GEMMs (fp32 accumulate), rest fp32" if bf16 else "fp32")}
@@ -850,7 +852,8 @@ def main():
             t_sub = time.perf_counter()
             out["config5"] = sub_config5(local_rank, args.lanes, pipe)
             pipe = None
-            out["train_b8"] = {"f32": sub_train_b8(cfg, xyz_all[:8], local_rank, False), "bf16": sub_train_b8(cfg, xyz_all[:8], local_rank, True)} if len(xyz_all) >= 8 else None
+            out["train_b8"] = {"f32": sub_train_b8(cfg, xyz_all[:8], local_rank, False), "bf16": sub_train_b8(cfg, xyz_all[:8], local_rank, True),
+                               "f32_atomic_scatter": sub_train_b8(cfg, xyz_all[:8], local_rank, False, deterministic=False)} if len(xyz_all) >= 8 else None
             out["sub_results_seconds"] = round(time.perf_counter() - t_sub, 2)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, xyz[:1], feats[:1], params)
