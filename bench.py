@@ -772,12 +772,12 @@ def main():
             # HBM bytes per launch cannot be counted from inside this process: they come from separate rocprofv3 --pmc passes of this
             # same command (profiles/run_pmc.sh; FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), committed with the commit they
             # were taken at.  The number is labelled with that source; null when no such file exists for this round.
-            pmc = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
-            if os.path.exists(pmc):
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", "r%d_pmc_traffic.json" % k) for k in (3, 2)) if os.path.exists(q)), "")
+            if pmc:
                 t = json.load(open(pmc))
                 roofline["traffic"] = t.get(dominant)
-                roofline["traffic_source"] = "profiles/r2_pmc_traffic.json: rocprofv3 --pmc passes of `%s` at commit %s (not measured in this run)" % (
-                    t.get("_command", "python bench.py"), t.get("_commit", "?"))
+                roofline["traffic_source"] = "profiles/%s: rocprofv3 --pmc passes of `%s` at commit %s (not measured in this run)" % (
+                    os.path.basename(pmc), t.get("_command", "python bench.py"), t.get("_commit", "?"))
                 roofline["traffic_top_kernels"] = t.get("_top_kernels")
         total_cost = {k: sum(v[k] for v in costs.values()) for k in ("flops", "bytes")}
         dev_ms = sum(s["ms_per_step"] for s in stages)

@@ -154,8 +154,14 @@ struct WgradJob {
     float* dst;         // [rows][cols], or [cols][rows] when transposed
     int slabs, rows, cols, transposed;
 };
-int64_t wgrad_partial_slabs(int64_t R, int64_t cin, int64_t cout);
+// (both take the operands: which kernel runs -- fp32 MFMA or, for 128-multiple shapes of many rows, split-bf16 MFMA (gemm_b3.hip) --
+//  depends on their alignment, and the two must agree on the number of slabs)
+int64_t wgrad_partial_slabs(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout);
 int wgrad_partial(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout, float* part,
                   float* dbpart);
+bool wgrad_b3_fits(int64_t R, int64_t cin, int64_t cout, const float* x, int64_t ldx, const float* dy, int64_t lddy);
+int64_t wgrad_b3_slabs(int64_t R, int64_t cin, int64_t cout);
+int wgrad_b3_partial(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout, float* part,
+                     float* dbpart);
 int wgrad_finish(ps_context* c, const WgradJob* d_jobs, int n_jobs, int64_t max_elems);
 }  // namespace ps

@@ -218,6 +218,156 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmB3Args a)
         }
 }
 
+// ---- weight gradient on the same split-bf16 products: dW[cin, cout] = X^T . dY with the ROW axis as K -------------------------------------
+// (RandLANet.py's shared MLPs under tf.gradients: the third of the training step's FLOPs that ops_train.hip's wgrad_kernel runs on the fp32
+// MFMA at 45-50 % of its peak.)  A workgroup owns a 128 x 128 block of dW (2 x 2 waves, each 64 x 64 = four 32x32 accumulator tiles) and a
+// slab of rows; its partial goes to part[slab] with plain stores and wgrad_finish adds the slabs up in slab order (deterministic, as the
+// fp32 kernel).  Both operands need "eight consecutive k (= rows) per lane": a loader thread fetches an 8-row x 4-column patch (eight
+// 16-byte loads, rows coalesced across the wave), so every one of its four columns IS one lane's k-group -- it splits the eight values
+// into the three bfloat16 planes once and writes them to LDS in MFMA operand order (ds_write_b128); the four waves then read ready
+// operands (ds_read_b128) -- nothing is split twice and no operand is read column-wise.  Waves 0-1 load X, waves 2-3 load dY (one
+// 16-row k-step each); the next chunk's patches are in flight under the 48 MFMAs of the current one.  The bias gradient (column sums of
+// dY) rides on the dY loaders.
+struct WgradB3Args {
+    const float* x; int ldx;
+    const float* dy; int lddy;
+    int64_t R, rows_per_slab;
+    int cin, cout;
+    float* part;    // [slabs][cin][cout]
+    float* dbpart;  // [slabs][cout] or nullptr
+};
+
+__global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradB3Args a)
+{
+    // [operand: 0 = X (A), 1 = dY (B)][k-step][plane][32-column tile][lane] : 48 KB
+    __shared__ uint4 Ops[2][2][3][4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hl = lane >> 5, c32 = lane & 31;
+    const int wi = wave & 1, wj = wave >> 1;  // this wave's 64 x 64 block: cin tiles 2 wi, 2 wi + 1; cout tiles 2 wj, 2 wj + 1
+    const int c0 = blockIdx.y * 128, n0 = blockIdx.z * 128;
+    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_slab;
+    const int64_t r1 = r0 + a.rows_per_slab < a.R ? r0 + a.rows_per_slab : a.R;
+    // loader role of this wave
+    const int op = wave >> 1, ks = wave & 1;
+    const float* src = (op == 0 ? a.x : a.dy) + (op == 0 ? c0 : n0) + 4 * c32;
+    const int ld = op == 0 ? a.ldx : a.lddy;
+    float4 pre[8];
+    auto load_patch = [&](int64_t rbase) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t row = rbase + 16 * ks + 8 * hl + j;
+            pre[j] = row < r1 ? *reinterpret_cast<const float4*>(src + (size_t)row * ld) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    load_patch(r0);
+    for (int64_t r = r0; r < r1; r += 32) {
+        __syncthreads();  // the previous chunk's operands have been read
+        {
+            // column 4 c32 + e of the patch = lane (c32' = (4 c32 + e) & 31, hl) of tile (4 c32 + e) >> 5: four consecutive lanes of one tile
+            const int t = (4 * c32) >> 5, l0 = ((4 * c32) & 31) + 32 * hl;
+            const float px[8] = {pre[0].x, pre[1].x, pre[2].x, pre[3].x, pre[4].x, pre[5].x, pre[6].x, pre[7].x};
+            const float py[8] = {pre[0].y, pre[1].y, pre[2].y, pre[3].y, pre[4].y, pre[5].y, pre[6].y, pre[7].y};
+            const float pz[8] = {pre[0].z, pre[1].z, pre[2].z, pre[3].z, pre[4].z, pre[5].z, pre[6].z, pre[7].z};
+            const float pw[8] = {pre[0].w, pre[1].w, pre[2].w, pre[3].w, pre[4].w, pre[5].w, pre[6].w, pre[7].w};
+            const float* cols[4] = {px, py, pz, pw};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float* v = cols[e];
+                const B3Planes p = b3_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) Ops[op][ks][pl][t][l0 + e] = p.p[pl];
+                bsum[e] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+        }
+        if (r + 32 < r1) load_patch(r + 32);  // the next chunk travels under this chunk's products
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            B3Planes av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    av[i].p[pl] = Ops[0][k][pl][2 * wi + i][lane];
+                    bv[i].p[pl] = Ops[1][k][pl][2 * wj + i][lane];
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = b3_mfma6(av[i], bv[j], acc[i][j]);
+        }
+    }
+    // accumulator register r of tile (i, j) = dW row 32 (2 wi + i) + (r & 3) + 8 (r >> 2) + 4 hl, column 32 (2 wj + j) + c32
+    float* out = a.part + (size_t)blockIdx.x * a.cin * a.cout;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = c0 + 32 * (2 * wi + i) + (r & 3) + 8 * (r >> 2) + 4 * hl, n = n0 + 32 * (2 * wj + j) + c32;
+                out[(size_t)ci * a.cout + n] = acc[i][j][r];
+            }
+    if (a.dbpart != nullptr && blockIdx.y == 0) {
+        // the dY loaders hold the column sums of their row groups: four partials per column, added in a fixed order
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(&Ops[0][0][0][0][0]);
+        if (op == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(2 * ks + hl) * 128 + 4 * c32 + e] = bsum[e];
+        }
+        __syncthreads();
+        if (threadIdx.x < 128)
+            a.dbpart[(size_t)blockIdx.x * a.cout + n0 + threadIdx.x] =
+                (red[threadIdx.x] + red[128 + threadIdx.x]) + (red[256 + threadIdx.x] + red[384 + threadIdx.x]);
+    }
+}
+
+bool wgrad_b3_fits(int64_t R, int64_t cin, int64_t cout, const float* x, int64_t ldx, const float* dy, int64_t lddy)
+{
+    return R >= 16384 && R < (1ll << 40) && cin % 128 == 0 && cout % 128 == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
+           ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+}
+
+static void wgrad_b3_plan(int64_t R, int64_t cin, int64_t cout, int64_t& rows_per_slab, int64_t& slabs)
+{
+    const int64_t blocks = (cin / 128) * (cout / 128);
+    int64_t want = 768 / blocks;  // ~3 workgroups per CU
+    want = want < 1 ? 1 : want;
+    rows_per_slab = (R + want - 1) / want;
+    rows_per_slab = ((rows_per_slab + 31) / 32) * 32;
+    rows_per_slab = rows_per_slab < 256 ? 256 : rows_per_slab;
+    slabs = (R + rows_per_slab - 1) / rows_per_slab;
+}
+
+int64_t wgrad_b3_slabs(int64_t R, int64_t cin, int64_t cout)
+{
+    int64_t rps, slabs;
+    wgrad_b3_plan(R, cin, cout, rps, slabs);
+    return slabs;
+}
+
+int wgrad_b3_partial(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout, float* part,
+                     float* dbpart)
+{
+    WgradB3Args a;
+    a.x = x; a.ldx = (int)ldx; a.dy = dy; a.lddy = (int)lddy; a.R = R; a.cin = (int)cin; a.cout = (int)cout; a.part = part; a.dbpart = dbpart;
+    int64_t slabs;
+    wgrad_b3_plan(R, cin, cout, a.rows_per_slab, slabs);
+    hipLaunchKernelGGL(wgrad_b3_kernel, dim3((unsigned)slabs, (unsigned)(cin / 128), (unsigned)(cout / 128)), dim3(256), 0, c->stream, a);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
 bool gemm_b3_fits(int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx)
 {
     // Measured against rowgemm.hip (profiles/tools/gemm_shapes_ab.py, round 3, after the prefetched weight planes left scratch memory):

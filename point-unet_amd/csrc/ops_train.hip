@@ -834,9 +834,15 @@ namespace ps {
         }                                  \
     } while (0)
 
-int64_t wgrad_partial_slabs(int64_t R, int64_t cin, int64_t cout)
+static bool wgrad_on_b3(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout)
+{
+    return c->train_b3 && !c->train_bf16 && wgrad_b3_fits(R, cin, cout, x, ldx, dy, lddy);
+}
+
+int64_t wgrad_partial_slabs(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout)
 {
     if (R <= 0) return 0;
+    if (wgrad_on_b3(c, x, ldx, dy, lddy, R, cin, cout)) return wgrad_b3_slabs(R, cin, cout);
     const int ti = (int)((cin + 15) / 16), tj = (int)((cout + 15) / 16);
     int64_t rpb = 0, nb = 0;
 #define PS_WG(TI, TJ, WK) wgrad_slabs<TI, TJ, WK>(R, (int)cin, (int)cout, rpb, nb)
@@ -850,6 +856,7 @@ int wgrad_partial(ps_context* c, const float* x, int64_t ldx, const float* dy, i
                   float* dbpart)
 {
     if (R <= 0) return PS_OK;
+    if (wgrad_on_b3(c, x, ldx, dy, lddy, R, cin, cout)) return wgrad_b3_partial(c, x, ldx, dy, lddy, R, cin, cout, part, dbpart);
     const int ti = (int)((cin + 15) / 16), tj = (int)((cout + 15) / 16);
     const int ci = (int)cin, co = (int)cout;
 #define PS_WG(TI, TJ, WK) launch_wgrad<TI, TJ, WK>(c, x, (int)ldx, dy, (int)lddy, R, ci, co, part, dbpart)
@@ -925,7 +932,7 @@ int ps_op_linear_wgrad_ex(ps_context* c, const float* x, int64_t ldx, const floa
         return PS_OK;
     }
     // per-slab partials (plain stores) + one reduction in slab order: deterministic, no float atomics, nothing zeroed first
-    const int64_t nb = wgrad_partial_slabs(R, cin, cout);
+    const int64_t nb = wgrad_partial_slabs(c, x, ldx, dy, lddy, R, cin, cout);
     const size_t wfl = (size_t)nb * cin * cout, bfl = db ? (size_t)nb * cout : 0;
     PS_TRY(c->wgrad_ws.reserve(sizeof(float) * (wfl + bfl) + 2 * sizeof(WgradJob) + 256));
     float* part = c->wgrad_ws.as<float>();

@@ -586,7 +586,7 @@ struct ps_trainer {
                 // weight / bias gradient: per-slab partials now (plain stores), summed in slab order by the ONE wgrad_finish launch at the
                 // end of the backward pass -- deterministic, no memsets, and the [out, in] layout of the transposed kernels is just a flag
                 Stage st(c, "train_wgrad", 1);
-                const int64_t nb = wgrad_partial_slabs(R, cin, cout);
+                const int64_t nb = wgrad_partial_slabs(c, x.p, x.ld, dy.p, dy.ld, R, cin, cout);
                 Tn part = alloc(nb, cin * cout, false);
                 Tn dbp = gb ? alloc(nb, cout, false) : Tn();
                 TK(wgrad_partial(c, x.p, x.ld, dy.p, dy.ld, R, cin, cout, part.p, gb ? dbp.p : nullptr));

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Regenerates every round-3 profile artifact in one gpurun call (run from the repo root on the GPU box):
+#   gpurun --timeout 2400 -- 'bash profiles/regen_r3.sh <commit>'
+# then, back in the container:  python profiles/collect_r3.py     (copies the summaries from gpurun_out/ into profiles/)
+# Passes: kernel-trace stats of the default (pipelined) and the serial bench and of the batch-8 training step, FETCH_SIZE / WRITE_SIZE /
+# SQ counter passes of the serial forward (each --pmc pass on its own, no trace domains), then the bench lines with the fresh PMC
+# traffic in place.
+set -u
+COMMIT=${1:-unknown}
+TOPN=6 bash profiles/run_kernel_stats.sh pipe --steps 200 --warmup 20 --no-sub-results
+TOPN=6 bash profiles/run_kernel_stats.sh serial --no-pipeline --steps 30 --warmup 3
+TOPN=6 bash profiles/run_kernel_stats.sh train_b8 --mode train --batch 8 --steps 2 --warmup 1
+TOPN=6 bash profiles/run_kernel_stats.sh train_b8_bf16 --mode train --batch 8 --bf16-mlp --steps 2 --warmup 1
+bash profiles/run_pmc.sh fetch FETCH_SIZE --steps 5 --warmup 1
+bash profiles/run_pmc.sh write WRITE_SIZE --steps 5 --warmup 1
+bash profiles/run_pmc.sh sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" --steps 3 --warmup 1
+python3 profiles/make_pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write r3 "$COMMIT" "python bench.py --no-pipeline --no-cpu-baseline --no-stage-timing --steps 5 --warmup 1" > gpurun_out/pmc_summary.txt
+cp profiles/r3_pmc_per_kernel.json profiles/r3_pmc_traffic.json gpurun_out/
+python3 profiles/summarize_sq.py gpurun_out/pmc_sq > gpurun_out/r3_sq_counters.txt
+python3 bench.py --steps 200 --warmup 20 2>/dev/null | tail -1 > gpurun_out/r3_bench_line.json
+python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/r3_bench_line_driver_form.json
+python3 bench.py --steps 30 --warmup 3 --no-pipeline --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r3_bench_line_serial.json
+python3 bench.py --workload config5 --steps 40 --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r3_bench_line_config5.json
+python3 bench.py --mode train --batch 8 --steps 3 --warmup 2 2>/dev/null | tail -1 > gpurun_out/r3_bench_line_train_b8.json
+python3 bench.py --mode train --batch 8 --bf16-mlp --steps 3 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r3_bench_line_train_b8_bf16.json
+python3 bench.py --mode train --batch 8 --atomic-scatter --steps 3 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r3_bench_line_train_b8_atomic_scatter.json
+python3 bench.py --mode train --batch 8 --train-engine python --steps 3 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r3_bench_line_train_b8_python_tape.json
+python3 bench.py --mode train --batch 1 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r3_bench_line_train_b1.json
+python3 bench.py --gpus 2 --share-gpu --dist-backend gloo --steps 20 --warmup 5 --no-cpu-baseline --no-sub-results 2>/dev/null | tail -1 > gpurun_out/r3_bench_line_2ranks_one_gpu_gloo.json
+ls -la gpurun_out | head -60

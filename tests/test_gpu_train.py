@@ -940,3 +940,42 @@ def test_inverse_index_and_gather_reduction(oracle):
             _lib.check(L.ps_op_random_sample_bwd_inv(h, p(dout), p(out), p(feat), p(pool), p(off), p(src), B, N, M2, K, d, p(share), p(b)))
             assert (a - b).abs().max() <= 5e-5 * max(1.0, float(a.abs().max()))
     torch.cuda.synchronize()
+
+
+def test_weight_gradients_on_split_bf16_mfma():
+    """ps_op_linear_wgrad_ex for many-row, 128-multiple shapes (>= 16384 rows, cin % 128 == 0, cout % 128 == 0) runs csrc/gemm_b3.hip's
+    wgrad_b3_kernel: X^T . dY on bf16 MFMA over exact three-way splits, the row axis as K, per-slab partials summed in slab order.  Against
+    a float64 product: error no larger than the fp32-MFMA kernel's on the same inputs (+ 1e-6 of the output scale); strided operands, ragged
+    row counts, the bias gradient; two calls give bit-identical results (no float atomics)."""
+    import ctypes
+    import torch
+    from point_unet_amd import _lib, runtime
+    L, ctx = _lib.lib(), runtime.default_context(0)
+    h = ctx.handle
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(33)
+    try:
+        for R, cin, cout in [(16384, 128, 128), (20001, 256, 128), (17003, 128, 384), (40000, 128, 128)]:
+            xw = torch.randn(R, cin + 8, generator=g).cuda()
+            dw = torch.randn(R, cout + 4, generator=g).cuda()
+            x, dy = xw[:, 4:cin + 4], dw[:, :cout]
+            ref_w = x.double().t() @ dy.double()
+            ref_b = dy.double().sum(0)
+            errs, outs = {}, {}
+            for on in (1, 0):
+                _lib.check(L.ps_set_train_gemm_b3(h, on))
+                gW = torch.full((cin, cout), 7.0, device="cuda")   # (overwritten, not accumulated into)
+                gb = torch.full((cout,), 7.0, device="cuda")
+                _lib.check(L.ps_op_linear_wgrad_ex(h, p(x), cin + 8, p(dy), cout + 4, R, cin, cout, p(gW), p(gb)))
+                errs[on] = (((gW.double() - ref_w).abs().max() / ref_w.abs().max()).item(), ((gb.double() - ref_b).abs().max() / ref_b.abs().max()).item())
+                outs[on] = (gW.clone(), gb.clone())
+            _lib.check(L.ps_set_train_gemm_b3(h, 1))
+            gW2, gb2 = torch.empty(cin, cout, device="cuda"), torch.empty(cout, device="cuda")
+            _lib.check(L.ps_op_linear_wgrad_ex(h, p(x), cin + 8, p(dy), cout + 4, R, cin, cout, p(gW2), p(gb2)))
+            print(R, cin, cout, errs)
+            assert torch.equal(gW2, outs[1][0]) and torch.equal(gb2, outs[1][1])
+            assert errs[1][0] <= errs[0][0] + 1e-6 and errs[1][0] <= 3e-6, (R, cin, cout, errs)
+            assert errs[1][1] <= 1e-5, errs
+    finally:
+        _lib.check(L.ps_set_train_gemm_b3(h, 1))
+    torch.cuda.synchronize()
