@@ -222,6 +222,70 @@ extern "C" int ps_op_nearest_interpolation(ps_context* c, const float* feature, 
     return PS_OK;
 }
 
+namespace ps {
+// ---- tiny convolutions over millions of rows (level 0 of the training step: the h -> h LocSE convolution on [B*N*K, 8] rows and its input
+// gradient): 64 multiply-adds per 64 bytes of row traffic.  The MFMA kernels stage such rows through LDS in 16-row tiles and ran at
+// 2.2 TB/s; here a THREAD owns a row -- 16-byte loads, the CIN x COUT weights broadcast from LDS, 16-byte stores -- and the pass runs
+// at the HBM rate.  bf16 mode: both operands rounded (RNE) before the fp32 multiply-add, like the MFMA flavours.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void tinyconv_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, const float* __restrict__ b,
+                                                       int64_t R, int leaky, int accum, int bf16, float* __restrict__ y, int64_t ldy)
+{
+    __shared__ __attribute__((aligned(16))) float W[CIN * COUT];
+    __shared__ float Bv[COUT];
+    auto rb = [&](float v) {
+        unsigned u = __float_as_uint(v);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return __uint_as_float(u & 0xffff0000u);
+    };
+    for (int i = threadIdx.x; i < CIN * COUT; i += 256) W[i] = bf16 ? rb(w[i]) : w[i];
+    if ((int)threadIdx.x < COUT) Bv[threadIdx.x] = b ? b[threadIdx.x] : 0.f;
+    __syncthreads();
+    for (int64_t r = blockIdx.x * (int64_t)256 + threadIdx.x; r < R; r += (int64_t)gridDim.x * 256) {
+        float xv[CIN];
+#pragma unroll
+        for (int q = 0; q < CIN / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + 4 * q);
+            xv[4 * q] = v.x; xv[4 * q + 1] = v.y; xv[4 * q + 2] = v.z; xv[4 * q + 3] = v.w;
+        }
+        if (bf16) {
+#pragma unroll
+            for (int k = 0; k < CIN; ++k) xv[k] = rb(xv[k]);
+        }
+        float acc[COUT];
+#pragma unroll
+        for (int n = 0; n < COUT; ++n) acc[n] = Bv[n];
+#pragma unroll
+        for (int k = 0; k < CIN; ++k)
+#pragma unroll
+            for (int q = 0; q < COUT / 4; ++q) {
+                const float4 wv = *reinterpret_cast<const float4*>(&W[k * COUT + 4 * q]);  // (same address in every lane: an LDS broadcast)
+                acc[4 * q] = __builtin_fmaf(xv[k], wv.x, acc[4 * q]);
+                acc[4 * q + 1] = __builtin_fmaf(xv[k], wv.y, acc[4 * q + 1]);
+                acc[4 * q + 2] = __builtin_fmaf(xv[k], wv.z, acc[4 * q + 2]);
+                acc[4 * q + 3] = __builtin_fmaf(xv[k], wv.w, acc[4 * q + 3]);
+            }
+#pragma unroll
+        for (int q = 0; q < COUT / 4; ++q) {
+            float4 o = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            if (leaky) { o.x = fmaxf(o.x, 0.2f * o.x); o.y = fmaxf(o.y, 0.2f * o.y); o.z = fmaxf(o.z, 0.2f * o.z); o.w = fmaxf(o.w, 0.2f * o.w); }
+            float4* dst = reinterpret_cast<float4*>(y + r * ldy + 4 * q);
+            if (accum) {
+                const float4 old = *dst;
+                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            *dst = o;
+        }
+    }
+}
+
+static bool tinyconv_fits(int64_t R, int64_t cin, int64_t cout, const float* x, int64_t ldx, const float* y, int64_t ldy)
+{
+    return R >= (1 << 20) && (cin == 8 || cin == 16) && (cout == 8 || cout == 16) && ldx % 4 == 0 && ldy % 4 == 0 &&
+           ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+}
+}  // namespace ps
+
 extern "C" int ps_op_conv1x1_ex(ps_context* c, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t cin, int64_t cout, int leaky,
                                 int accumulate, float* y, int64_t ldy)
 {
@@ -229,6 +293,20 @@ extern "C" int ps_op_conv1x1_ex(ps_context* c, const float* x, int64_t ldx, cons
     PS_CHECK(R >= 0 && cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout, "ps_op_conv1x1: bad shape");
     if (!R) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
+    if (tinyconv_fits(R, cin, cout, x, ldx, y, ldy)) {
+        Stage st(c, "op_conv1x1", 1);
+        const dim3 grid(2048);
+        // (the MFMA bf16 flavour only covers cin % 16 == 0: the rounding follows the same rule here)
+        const int bf = c->train_bf16 && cin % 16 == 0 ? 1 : 0;
+#define PS_TINY(CI, CO) hipLaunchKernelGGL((tinyconv_kernel<CI, CO>), grid, dim3(256), 0, c->stream, x, ldx, w, b, R, leaky, accumulate ? 1 : 0, bf, y, ldy)
+        if (cin == 8 && cout == 8) PS_TINY(8, 8);
+        else if (cin == 8) PS_TINY(8, 16);
+        else if (cout == 8) PS_TINY(16, 8);
+        else PS_TINY(16, 16);
+#undef PS_TINY
+        PS_HIP(hipGetLastError());
+        return PS_OK;
+    }
     if (c->train_b3 && !c->train_bf16 && gemm_b3_fits(R, cin, cout, x, ldx)) {
         // matrix-pipe bound shapes (att_pooling's score products at d >= 128): bf16 MFMA over exact splits, fp32-level error
         ps::DevBuf& pw = c->ops_ring[c->ops_ring_pos];
