@@ -22,6 +22,7 @@
 // two bfloat16 values is exact in fp32), accumulation in fp32: the same values as a bf16 MFMA with fp32 accumulate.
 #include "common.h"
 #include "mfma_tile.h"
+#include "reduce_partials.h"
 
 namespace ps {
 
@@ -511,15 +512,6 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
     }
 }
 
-__global__ __launch_bounds__(256) void att_train_dw_reduce_kernel(const float* __restrict__ part, int n_part, int dd, float* __restrict__ dw)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= dd) return;
-    float sum = 0.f;
-    for (int b = 0; b < n_part; ++b) sum += part[(size_t)b * dd + i];
-    dw[i] = sum;
-}
-
 template <int D>
 static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float* dW)
 {
@@ -542,7 +534,7 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
             auto kern = att_train_bwd_bf16_kernel<D, KN, WAVES>;
             if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
-            hipLaunchKernelGGL(att_train_dw_reduce_kernel, dim3(ceil_div(D * D, 256)), dim3(256), 0, c->stream, a.dw_part, blocks, D * D, dW);
+            hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(ceil_div(D * D, 16)), dim3(256), 0, c->stream, static_cast<const float*>(a.dw_part), blocks, D * D, dW);
         }
         PS_HIP(hipGetLastError());
         return PS_OK;
@@ -563,7 +555,7 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
         auto kern = att_train_bwd_kernel<D, KN, WAVES>;
         if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
-        hipLaunchKernelGGL(att_train_dw_reduce_kernel, dim3(ceil_div(D * D, 256)), dim3(256), 0, c->stream, a.dw_part, blocks, D * D, dW);
+        hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(ceil_div(D * D, 16)), dim3(256), 0, c->stream, static_cast<const float*>(a.dw_part), blocks, D * D, dW);
     }
     PS_HIP(hipGetLastError());
     return PS_OK;

@@ -17,6 +17,7 @@
 // fp32 VALU work (10 h FMAs per row against 16 + 4 h bytes): HBM / issue bound, no MFMA.  All sums are per-block partials merged in a
 // fixed order (deterministic).  h in {8, 16, 32, 64}.
 #include "common.h"
+#include "reduce_partials.h"
 #include "wave_ops.h"
 
 namespace ps {
@@ -160,15 +161,6 @@ __global__ __launch_bounds__(256) void locse_sums_kernel(LocseArgs a)
     for (int i = threadIdx.x; i < 2 * H; i += 256) dst[i] = ((red[i] + red[2 * H + i]) + red[4 * H + i]) + red[6 * H + i];
 }
 
-__global__ __launch_bounds__(256) void locse_finish64_kernel(const double* __restrict__ part, int blocks, int nv, double* __restrict__ out)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nv) return;
-    double s = 0.;
-    for (int b = 0; b < blocks; ++b) s += part[(size_t)b * nv + i];
-    out[i] = s;
-}
-
 // ---- forward: normalise + LeakyReLU -> rows ----------------------------------------------------------------------------------
 template <int H>
 __global__ __launch_bounds__(256) void locse_apply_kernel(LocseArgs a)
@@ -277,16 +269,6 @@ __global__ __launch_bounds__(256) void locse_bwd_kernel(LocseArgs a)
     for (int i = threadIdx.x; i < NV; i += 256) dst[i] = ((red[i] + red[NV + i]) + red[2 * NV + i]) + red[3 * NV + i];
 }
 
-// out[i] = sum_b part[b][i], one thread per value, blocks in order
-__global__ __launch_bounds__(256) void locse_finish_kernel(const float* __restrict__ part, int blocks, int nv, float* __restrict__ out)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nv) return;
-    float s = 0.f;
-    for (int b = 0; b < blocks; ++b) s += part[(size_t)b * nv + i];
-    out[i] = s;
-}
-
 static bool locse_ok(int64_t K, int64_t h) { return K >= 1 && (h == 8 || h == 16 || h == 32 || h == 64); }
 
 template <int H>
@@ -303,11 +285,12 @@ static int locse_launch(ps_context* c, LocseArgs a, int what, float* result)
         a.part = c->red_ws.as<float>();
         if (what == 0) {
             hipLaunchKernelGGL(locse_sums_kernel<H>, dim3(blocks), dim3(256), 0, c->stream, a);
-            hipLaunchKernelGGL(locse_finish64_kernel, dim3(ceil_div(nv, 256)), dim3(256), 0, c->stream, reinterpret_cast<const double*>(a.part), (int)blocks,
-                               nv, reinterpret_cast<double*>(result));
+            hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3(ceil_div(nv, 16)), dim3(256), 0, c->stream, reinterpret_cast<const double*>(a.part),
+                               (int)blocks, nv, reinterpret_cast<double*>(result));
         } else {
             hipLaunchKernelGGL(locse_bwd_kernel<H>, dim3(blocks), dim3(256), 0, c->stream, a);
-            hipLaunchKernelGGL(locse_finish_kernel, dim3(ceil_div(nv, 256)), dim3(256), 0, c->stream, a.part, (int)blocks, nv, result);
+            hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(ceil_div(nv, 16)), dim3(256), 0, c->stream, static_cast<const float*>(a.part), (int)blocks, nv,
+                               result);
         }
     }
     PS_HIP(hipGetLastError());

@@ -16,6 +16,7 @@
 //   (train.py; under SyncBN that is also where the sums of all ranks meet).
 // 8 passes instead of 14.  Sums are per-workgroup partials merged in a fixed order (deterministic).  c in {8, 16, 32, 64}.
 #include "common.h"
+#include "reduce_partials.h"
 #include "mfma_tile.h"
 
 namespace ps {
@@ -351,23 +352,6 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void sc_finish64_kernel(const double* __restrict__ part, int blocks, int nv, double* __restrict__ out)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nv) return;
-    double s = 0.;
-    for (int b = 0; b < blocks; ++b) s += part[(size_t)b * nv + i];
-    out[i] = s;
-}
-__global__ __launch_bounds__(256) void sc_finish_kernel(const float* __restrict__ part, int blocks, int nv, float* __restrict__ out)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nv) return;
-    float s = 0.f;
-    for (int b = 0; b < blocks; ++b) s += part[(size_t)b * nv + i];
-    out[i] = s;
-}
-
 static bool sc_ok(int64_t C) { return C == 8 || C == 16 || C == 32 || C == 64; }
 
 template <int C>
@@ -394,7 +378,7 @@ static int sc_launch(ps_context* c, ScArgs a, int what, void* result)
         PS_TRY(c->red_ws.reserve(sizeof(double) * (size_t)blocks * 3 * CP + 256));
         a.part = c->red_ws.as<void>();
         hipLaunchKernelGGL(sc_sums_kernel<C>, dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
-        hipLaunchKernelGGL(sc_finish64_kernel, dim3(ceil_div(3 * CP, 256)), dim3(256), 0, c->stream, static_cast<const double*>(a.part), blocks, 3 * CP,
+        hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3(ceil_div(3 * CP, 16)), dim3(256), 0, c->stream, static_cast<const double*>(a.part), blocks, 3 * CP,
                            static_cast<double*>(result));
     } else if (what == 1) {
         hipLaunchKernelGGL(sc_apply_kernel<C>, dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
@@ -402,7 +386,7 @@ static int sc_launch(ps_context* c, ScArgs a, int what, void* result)
         PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * NVB + 256));
         a.part = c->red_ws.as<void>();
         hipLaunchKernelGGL(sc_bwd_sums_kernel<C>, dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
-        hipLaunchKernelGGL(sc_finish_kernel, dim3(ceil_div(NVB, 256)), dim3(256), 0, c->stream, static_cast<const float*>(a.part), blocks, NVB,
+        hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(ceil_div(NVB, 16)), dim3(256), 0, c->stream, static_cast<const float*>(a.part), blocks, NVB,
                            static_cast<float*>(result));
     } else {
         hipLaunchKernelGGL(sc_bwd_apply_kernel<C>, dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
