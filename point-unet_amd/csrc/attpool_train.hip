@@ -52,6 +52,7 @@ struct AttTrainArgs {
     int ldl, lddl;
     float* dfl_rows;     // non-null: the gathered half's gradient goes HERE as plain rows [R*K, D/2] (ld_rows) instead of being scatter-added into
     int ld_rows;         // dfl with float atomics; ps_op_gather_reduce_rows then adds the rows up in a fixed order (deterministic step)
+    int df_accum;        // split form: df (the f_xyz half's gradient) is ADDED to what the rows already hold (a second gradient of the same tensor)
 };
 
 template <int D>
@@ -242,7 +243,10 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
                 const int col = tj * 16 + c16;
                 if (col >= D / 2) {  // f_xyz half: plain rows
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a.df[(size_t)(p * KN + 4 * g + r) * a.lddf + col - D / 2] = acc[r];
+                    for (int r = 0; r < 4; ++r) {
+                        float* q = a.df + (size_t)(p * KN + 4 * g + r) * a.lddf + col - D / 2;
+                        *q = a.df_accum ? *q + acc[r] : acc[r];
+                    }
                 } else if (a.dfl_rows) {  // gathered half as plain rows: summed per source row by a gather-reduction afterwards
 #pragma unroll
                     for (int r = 0; r < 4; ++r) a.dfl_rows[(size_t)(p * KN + 4 * g + r) * a.ld_rows + col] = acc[r];
@@ -464,7 +468,10 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
                 const int col = tj * 16 + c16;
                 if (col >= D / 2) {  // f_xyz half: plain rows
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a.df[(size_t)(p * KN + 4 * g + r) * a.lddf + col - D / 2] = acc[r];
+                    for (int r = 0; r < 4; ++r) {
+                        float* q = a.df + (size_t)(p * KN + 4 * g + r) * a.lddf + col - D / 2;
+                        *q = a.df_accum ? *q + acc[r] : acc[r];
+                    }
                 } else if (a.dfl_rows) {  // gathered half as plain rows: summed per source row by a gather-reduction afterwards
 #pragma unroll
                     for (int r = 0; r < 4; ++r) a.dfl_rows[(size_t)(p * KN + 4 * g + r) * a.ld_rows + col] = acc[r];
@@ -667,7 +674,7 @@ static int att_bwd_split_impl(ps_context* c, const float* fl, int64_t ldl, const
     AttTrainArgs a = {};
     a.f = fr; a.ld = (int)ldr; a.fl = fl; a.ldl = (int)ldl; a.idx = idx; a.n_src = n_src; a.n_q = n_q;
     a.w = wfc; a.dagg = dagg; a.df = dfr; a.lddf = (int)lddr; a.dfl = dfl; a.lddl = (int)lddl; a.R = R; a.bf16 = c->train_bf16 ? 1 : 0;
-    a.dfl_rows = dfl_rows; a.ld_rows = (int)ld_rows;
+    a.dfl_rows = dfl_rows; a.ld_rows = (int)ld_rows; a.df_accum = c->att_df_accum ? 1 : 0;
     switch (d) {
         case 16: return launch_att_train<16>(c, a, true, dwfc);
         case 32: return launch_att_train<32>(c, a, true, dwfc);

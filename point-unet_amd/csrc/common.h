@@ -89,6 +89,7 @@ struct ps_context {
     int ops_ring_pos = 0;
     bool att_bf16x3 = true;   // ps_set_att_bf16x3: attentive pooling at d = 64 / 128 on bf16 MFMA over three-way splits (attpool32b.hip)
     bool train_b3 = true;     // ps_set_train_gemm_b3: large fp32 op-level GEMMs on bf16 MFMA over exact three-way splits (gemm_b3.hip)
+    bool att_df_accum = false;  // (internal, set around a call by the native trainer) ps_op_att_pool_train_bwd_split*: dfr += instead of dfr =
     bool train_bf16 = false;  // ps_set_train_gemm_bf16: the op-level GEMMs round their operands to bf16 (fp32 accumulate)
     // per-device kernel attributes already raised by this context (dynamic LDS above the default limit)
     bool mid_lds_attr = false;
@@ -146,6 +147,9 @@ struct Stage {
 };
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// random_sample forward, vector form (randla.hip): out[b, m, :] = max over k of feat[b, idx[b, m, k], :], ch % 4 == 0; order: optional row walk
+int pool_max(ps_context* c, const float* feat, const int32_t* idx, const int32_t* order, float* out, int64_t B, int64_t n, int64_t m, int K, int ch);
 
 // weight-gradient partials (ops_train.hip): the GEMM writes one [rows, cols] partial per row slab, wgrad_finish adds them up in slab
 // order for a whole table of jobs in one launch (the native training step finishes every gradient of a step with it)

@@ -203,6 +203,9 @@ extern "C" int ps_op_random_sample(ps_context* c, const float* feature, const in
     if (!rows) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "op_random_sample", 1);
+    // (rows of whole float4s: the vector kernel of the fused forward -- all K gathers of a thread in flight together)
+    if (d % 4 == 0 && (reinterpret_cast<uintptr_t>(feature) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && B * std::max(N, M) < (1ll << 31))
+        return pool_max(c, feature, pool_idx, nullptr, out, B, N, M, (int)K, (int)d);
     hipLaunchKernelGGL(pool_max_scalar_kernel, dim3(ceil_div(rows * d, 256)), dim3(256), 0, c->stream, feature, pool_idx, out, rows, (int)M, (int)N,
                        (int)K, (int)d);
     PS_HIP(hipGetLastError());

@@ -783,19 +783,28 @@ struct ps_trainer {
         TK(ps_op_att_pool_train_fwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, K, d, agg.p));
         record(agg, [=](const Tn& dy_in) {
             const Tn dy = contig(dy_in);
-            Tn dfx = alloc(B * M * K, h);
+            // f_xyz usually has a gradient already (the h -> h convolution's input gradient ran first): the kernel adds into it instead of
+            // writing a second tensor that an axpy pass then folds in (4 passes over [N*K, h] -> 2)
+            auto have = grad_of.find(f_xyz.id);
+            const bool add_in_place = have != grad_of.end() && have->second.C == h && have->second.R == B * M * K;
+            Tn dfx = add_in_place ? have->second : alloc(B * M * K, h);
+            struct Flag {
+                ps_context* c;
+                Flag(ps_context* ctx, bool on) : c(ctx) { c->att_df_accum = on; }
+                ~Flag() { c->att_df_accum = false; }
+            } flag(c, add_in_place);
             Tn dsrc = accum_buffer(f_src);  // the gathered half's gradient is added in place
             if (opt.deterministic) {
                 // ... as plain rows first, then summed per source row in ascending row order (no float atomics)
                 Tn rows = alloc(B * M * K, h, false);
-                TK(ps_op_att_pool_train_bwd_split_rows(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, dy.p, K, d, rows.p, h, dfx.p, h, gW.p));
+                TK(ps_op_att_pool_train_bwd_split_rows(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, dy.p, K, d, rows.p, h, dfx.p, dfx.ld, gW.p));
                 const Inv& iv = inverse(idx, B, N, M * K);
                 TK(ps_op_gather_reduce_rows(c, rows.p, h, reinterpret_cast<const int32_t*>(iv.offsets.p), reinterpret_cast<const int32_t*>(iv.src.p), B * N, h,
                                             dsrc.p, dsrc.ld, 1));
             } else {
-                TK(ps_op_att_pool_train_bwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, dy.p, K, d, dsrc.p, dsrc.ld, dfx.p, h, gW.p));
+                TK(ps_op_att_pool_train_bwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, dy.p, K, d, dsrc.p, dsrc.ld, dfx.p, dfx.ld, gW.p));
             }
-            accum(f_xyz, dfx);
+            if (!add_in_place) accum(f_xyz, dfx);
         });
         return agg;
     }
@@ -831,11 +840,19 @@ struct ps_trainer {
             const Tn dy = contig(dy_in);
             Tn ds = alloc(a.R, a.C);
             TK(ps_op_add_lrelu_bwd(c, dy.p, y.p, a.numel(), ds.p));
-            // the same values are the gradient of both summands: two tensors only where one of them already has a gradient to add to
-            Tn ds2 = alloc(a.R, a.C);
-            TK_HIP(hipMemcpyAsync(ds2.p, ds.p, sizeof(float) * (size_t)a.numel(), hipMemcpyDeviceToDevice, stream()));
-            accum(a, ds);
-            accum(b, ds2);
+            // the same values are the gradient of both summands.  In this graph both (mlp2's and the shortcut's BatchNorm outputs) have no
+            // other consumer, so nothing is ever added into either gradient: they share ONE read-only tensor.  Only where a summand already
+            // holds a gradient (another graph) does the second one get its own copy.
+            if (grad_of.count(a.id) || grad_of.count(b.id)) {
+                Tn ds2 = alloc(a.R, a.C);
+                TK_HIP(hipMemcpyAsync(ds2.p, ds.p, sizeof(float) * (size_t)a.numel(), hipMemcpyDeviceToDevice, stream()));
+                accum(a, ds);
+                accum(b, ds2);
+            } else {
+                grad_of[a.id] = ds;
+                Tn alias = ds;
+                grad_of[b.id] = alias;
+            }
         });
         return y;
     }
