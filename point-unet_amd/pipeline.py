@@ -128,3 +128,67 @@ class ForwardPipeline:
         for ln in self.lanes:
             ln.net.close()
             ln.ctx.close()
+
+
+class PyramidPrefetcher:
+    """The training-side counterpart of ForwardPipeline: the index pyramid of the NEXT batch is built on its own HIP stream and context
+    while the current batch trains -- the reference's `tf.data` `.map(tf_map).prefetch()` (runBraTS.py:166-185), whose CPU workers
+    build pyramids underneath the GPU's training step.  `depth` pyramid slots (double buffered by default); stream-ordered with events,
+    the host never blocks:
+
+        pre.submit(xyz_next)            # enqueue batch k+1's pyramid on the prefetch stream
+        pyr, slot = pre.next()          # batch k's pyramid (submitted a step earlier); the caller's stream waits for its build
+        loss = trainer.train_step(pyr, features, labels)
+        pre.release(slot)               # the slot may be rebuilt once the work enqueued so far has run
+    """
+
+    def __init__(self, config, device=0, depth=2):
+        self.cfg = config
+        self.device = torch.device("cuda", device)
+        self.stream = torch.cuda.Stream(self.device)
+        self.ctx = runtime.Context(device)
+        self.ctx.set_stream(self.stream)
+        self.ctx.set_deferred_checks(True)  # status words validated at synchronize()
+        self.depth = int(depth)
+        self.slots = [None] * self.depth
+        self.ready = [None] * self.depth
+        self.free = [None] * self.depth
+        self._in = self._out = 0
+
+    def submit(self, xyz):
+        k = self._in % self.depth
+        assert self._in - self._out < self.depth, "PyramidPrefetcher: every slot holds a pyramid nobody has taken yet"
+        self._in += 1
+        B, n0 = xyz.shape[0], xyz.shape[1]
+        slot = self.slots[k]
+        if slot is None or slot.xyz[0].shape[:2] != (B, n0):
+            ratios = list(self.cfg.sub_sampling_ratio)[:self.cfg.num_layers]
+            slot = self.slots[k] = alloc_pyramid(B, n0, ratios, self.cfg.k_n, xyz.device)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))  # xyz was produced on the caller's stream
+        if self.free[k] is not None:
+            self.stream.wait_event(self.free[k])                        # the consumer of this slot's previous pyramid has run
+        with torch.cuda.stream(self.stream):
+            build_pyramid(xyz, self.cfg, ctx=self.ctx, out=slot)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        xyz.record_stream(self.stream)
+        self.ready[k] = ev
+
+    def next(self):
+        assert self._out < self._in, "PyramidPrefetcher.next() without a submitted pyramid"
+        k = self._out % self.depth
+        self._out += 1
+        torch.cuda.current_stream(self.device).wait_event(self.ready[k])
+        return self.slots[k], k
+
+    def release(self, k):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.free[k] = ev
+
+    def synchronize(self):
+        self.ctx.synchronize()
+
+    def close(self):
+        self.synchronize()
+        self.ctx.close()

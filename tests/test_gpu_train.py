@@ -982,3 +982,33 @@ def test_weight_gradients_on_split_bf16_mfma():
     finally:
         _lib.check(L.ps_set_train_gemm_b3(h, 1))
     torch.cuda.synchronize()
+
+
+def test_pyramid_prefetcher_feeds_the_same_pyramids():
+    """PyramidPrefetcher (the next batch's pyramid built on its own stream while the current batch trains): three steps through it give the
+    losses of three steps with the pyramid built in front of each step, bit for bit (deterministic step, same pyramids)."""
+    import torch
+    from point_unet_amd import weights
+    from point_unet_amd.pipeline import PyramidPrefetcher
+    from point_unet_amd.pyramid import build_pyramid
+    from point_unet_amd.train import Trainer
+    cfg, xyz, feats = netcase.small_deep(6000, seed=61, B=2)
+    clouds = [torch.from_numpy(netcase.small_deep(6000, seed=61 + 3 * i, B=2)[1]).cuda() for i in range(3)]
+    params = weights.init_params(cfg, seed=3, randomize_bn=True)
+    labels = torch.from_numpy(np.random.default_rng(1).integers(0, cfg.num_classes, xyz.shape[:2]).astype(np.int32)).cuda()
+    d_f = torch.from_numpy(feats).cuda()
+    a = Trainer(cfg, params=params, learning_rate=1e-3, keep_prob=1.0)
+    want = [float(a.train_step(build_pyramid(c, cfg), d_f, labels)) for c in clouds]
+    b = Trainer(cfg, params=params, learning_rate=1e-3, keep_prob=1.0)
+    pre = PyramidPrefetcher(cfg)
+    pre.submit(clouds[0])
+    got = []
+    for i in range(3):
+        if i + 1 < 3:
+            pre.submit(clouds[i + 1])
+        pyr, slot = pre.next()
+        got.append(b.train_step(pyr, d_f, labels))
+        pre.release(slot)
+    torch.cuda.synchronize()
+    pre.close()
+    assert [float(g) for g in got] == want
