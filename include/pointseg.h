@@ -356,10 +356,15 @@ int ps_op_gather_reduce_rows(ps_context* ctx, const float* rows, int64_t ldr, co
 /* ps_op_random_sample_bwd through an inverse index.  pool_idx i32[B, M, K] must be the first M rows per cloud of a table
  * i32[B, N', K] with N' >= M (the pyramid's sub_idx = neigh_idx[:, :M], runBraTS.py:150) and offsets / src the inverse index of THAT
  * table (rows_per_cloud = N'*K, here N' = N): the pooling rows are a prefix of every segment, no second index is built.
- * share_ws: B*M*d floats */
+ * ties: u8[B*M, d] from ps_op_random_sample_ties (how many of the K rows attain the maximum), or NULL: then they are recounted into
+ * share_ws (B*M*d floats) by an extra pass. */
 int ps_op_random_sample_bwd_inv(ps_context* ctx, const float* dout, const float* out, const float* feature,
                                 const int32_t* pool_idx, const int32_t* offsets, const int32_t* src, int64_t B, int64_t N,
-                                int64_t M, int64_t K, int64_t d, float* share_ws, float* dfeature);
+                                int64_t M, int64_t K, int64_t d, const uint8_t* ties, float* share_ws, float* dfeature);
+/* ps_op_random_sample that also writes ties u8[B*M, d] (d % 4 == 0, K <= 255): tf.reduce_max's gradient is shared evenly by the rows
+ * that attain the maximum, and the forward has all K of them in registers anyway */
+int ps_op_random_sample_ties(ps_context* ctx, const float* feature, const int32_t* pool_idx, int64_t B, int64_t N, int64_t M,
+                             int64_t K, int64_t d, float* out, uint8_t* ties);
 /* ps_op_att_pool_train_bwd_split with the gathered half's gradient written as plain rows dfl_rows f32[B*n_q*K, d/2] (row stride
  * ld_rows) instead of scatter-added: follow it with ps_op_gather_reduce_rows over the inverse index of idx. */
 int ps_op_att_pool_train_bwd_split_rows(ps_context* ctx, const float* fl, int64_t ldl, const int32_t* idx, int64_t B,

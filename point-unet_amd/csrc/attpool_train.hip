@@ -303,12 +303,14 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
 // reads spread over the banks four to a word, the minimum.
 typedef short bf16x4s __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned bf16_bits(float x)
+typedef __bf16 bf16x2h __attribute__((ext_vector_type(2)));
+typedef float f32x2h __attribute__((ext_vector_type(2)));
+// round to nearest even on v_cvt_pk_bf16_f32 (one instruction per PAIR; the bit-twiddling form was five per element in an issue-bound kernel)
+__device__ __forceinline__ unsigned bf16_pair(float a, float b)
 {
-    unsigned u = __float_as_uint(x);
-    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (finite inputs)
-    return u >> 16;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2h{a, b}, bf16x2h));
 }
+__device__ __forceinline__ unsigned bf16_bits(float x) { return bf16_pair(x, 0.f) & 0xffffu; }
 
 template <int D>
 struct AttBf16Geom {
@@ -351,8 +353,8 @@ __device__ __forceinline__ void load_tile_bf16(const AttTrainArgs& a, int64_t p,
             float* dst = A + row * PA + 4 * q;
             dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
             uint2 pk;
-            pk.x = bf16_bits(v.x) | (bf16_bits(v.y) << 16);
-            pk.y = bf16_bits(v.z) | (bf16_bits(v.w) << 16);
+            pk.x = bf16_pair(v.x, v.y);
+            pk.y = bf16_pair(v.z, v.w);
             *reinterpret_cast<uint2*>(Xb + row * PB + 4 * q) = pk;
         }
     }

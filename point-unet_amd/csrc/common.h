@@ -149,7 +149,8 @@ struct Stage {
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // random_sample forward, vector form (randla.hip): out[b, m, :] = max over k of feat[b, idx[b, m, k], :], ch % 4 == 0; order: optional row walk
-int pool_max(ps_context* c, const float* feat, const int32_t* idx, const int32_t* order, float* out, int64_t B, int64_t n, int64_t m, int K, int ch);
+int pool_max(ps_context* c, const float* feat, const int32_t* idx, const int32_t* order, float* out, int64_t B, int64_t n, int64_t m, int K, int ch,
+             unsigned char* ties = nullptr);
 
 // weight-gradient partials (ops_train.hip): the GEMM writes one [rows, cols] partial per row slab, wgrad_finish adds them up in slab
 // order for a whole table of jobs in one launch (the native training step finishes every gradient of a step with it)

@@ -119,10 +119,14 @@ __global__ __launch_bounds__(256) void maxpool_share_kernel(const float* __restr
 // The inverse index is that of the level's NEIGHBOUR table [B, N, K]: the pooling table is its first M rows per cloud (sub_idx =
 // neigh_idx[:, :M], runBraTS.py:150), a segment lists its rows in ascending order and all of them belong to the cloud of j -- so the
 // pooling rows of a segment are a PREFIX of it and no second index is needed.
-__global__ __launch_bounds__(256) void maxpool_bwd_inv_kernel(const float* __restrict__ share, const float* __restrict__ out, const float* __restrict__ feat,
+template <bool TIES>
+__global__ __launch_bounds__(256) void maxpool_bwd_inv_kernel(const float* __restrict__ share, const unsigned char* __restrict__ ties,
+                                                              const float* __restrict__ out, const float* __restrict__ feat,
                                                               const unsigned* __restrict__ offsets, const int32_t* __restrict__ src, int64_t n_dst, int n_cloud,
                                                               int m_cloud, int K, int d, float* __restrict__ dfeat)
 {
+    // TIES: `share` is dout itself and ties[m, c] (written by the forward, ps_op_random_sample_ties) the number of rows that attain the
+    // maximum -- no separate pass that re-gathers the K rows of every (m, c) to count them
     const int64_t total = n_dst * d;
     for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int64_t j = t / d;
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_inv_kernel(const float* __res
             const int64_t n = src[s] / K - b * n_cloud;  // src holds flat (point * K + k) positions of the neighbour table
             if (n >= m_cloud) break;                      // (ascending: the rest of the segment is not part of the pooling table)
             const int64_t m = b * m_cloud + n;
-            if (out[m * d + ch] == f) acc += share[m * d + ch];
+            if (out[m * d + ch] == f) acc += TIES ? share[m * d + ch] / (float)ties[m * d + ch] : share[m * d + ch];
         }
         dfeat[t] += acc;
     }
@@ -225,16 +229,23 @@ int ps_op_gather_reduce_rows(ps_context* c, const float* rows, int64_t ldr, cons
 }
 
 int ps_op_random_sample_bwd_inv(ps_context* c, const float* dout, const float* out, const float* feature, const int32_t* pool_idx, const int32_t* offsets,
-                                const int32_t* src, int64_t B, int64_t N, int64_t M, int64_t K, int64_t d, float* share_ws, float* dfeature)
+                                const int32_t* src, int64_t B, int64_t N, int64_t M, int64_t K, int64_t d, const uint8_t* ties, float* share_ws,
+                                float* dfeature)
 {
-    PS_CHECK(c && dout && out && feature && pool_idx && offsets && src && share_ws && dfeature, "ps_op_random_sample_bwd_inv: NULL argument");
+    PS_CHECK(c && dout && out && feature && pool_idx && offsets && src && (ties || share_ws) && dfeature, "ps_op_random_sample_bwd_inv: NULL argument");
     const size_t rows = (size_t)B * M;
     if (!rows) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
-    Stage st(c, "train_maxpool_bwd", 2);
+    Stage st(c, "train_maxpool_bwd", ties ? 1 : 2);
+    if (ties) {
+        hipLaunchKernelGGL(maxpool_bwd_inv_kernel<true>, dim3(iv_grid(B * N * d)), dim3(256), 0, c->stream, dout, ties, out, feature,
+                           reinterpret_cast<const unsigned*>(offsets), src, B * N, (int)N, (int)M, (int)K, (int)d, dfeature);
+        PS_HIP(hipGetLastError());
+        return PS_OK;
+    }
     hipLaunchKernelGGL(maxpool_share_kernel, dim3(ceil_div(rows * d, 256)), dim3(256), 0, c->stream, dout, out, feature, pool_idx, rows, (int)M, (int)N, (int)K,
                        (int)d, share_ws);
-    hipLaunchKernelGGL(maxpool_bwd_inv_kernel, dim3(iv_grid(B * N * d)), dim3(256), 0, c->stream, share_ws, out, feature,
+    hipLaunchKernelGGL(maxpool_bwd_inv_kernel<false>, dim3(iv_grid(B * N * d)), dim3(256), 0, c->stream, share_ws, nullptr, out, feature,
                        reinterpret_cast<const unsigned*>(offsets), src, B * N, (int)N, (int)M, (int)K, (int)d, dfeature);
     PS_HIP(hipGetLastError());
     return PS_OK;

@@ -212,6 +212,19 @@ extern "C" int ps_op_random_sample(ps_context* c, const float* feature, const in
     return PS_OK;
 }
 
+extern "C" int ps_op_random_sample_ties(ps_context* c, const float* feature, const int32_t* pool_idx, int64_t B, int64_t N, int64_t M, int64_t K, int64_t d,
+                                        float* out, uint8_t* ties)
+{
+    PS_CHECK(c && feature && pool_idx && out && ties, "ps_op_random_sample_ties: NULL argument");
+    PS_CHECK(d % 4 == 0 && K <= 255 && (reinterpret_cast<uintptr_t>(feature) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(ties) & 3) == 0 && B * std::max(N, M) < (1ll << 31),
+             "ps_op_random_sample_ties: d must be a multiple of 4, K <= 255, buffers 16-byte aligned");
+    if (!(B * M)) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "op_random_sample", 1);
+    return pool_max(c, feature, pool_idx, nullptr, out, B, N, M, (int)K, (int)d, ties);
+}
+
 extern "C" int ps_op_nearest_interpolation(ps_context* c, const float* feature, const int32_t* interp_idx, int64_t B, int64_t N, int64_t M, int64_t d,
                                            float* out)
 {

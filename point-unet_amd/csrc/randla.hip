@@ -24,7 +24,8 @@ namespace ps {
 // ---- random_sample: out[b,m,:] = max_k feature[b, pool_idx[b,m,k], :]  (RandLANet.py:345-360) ----------------
 template <int KN>
 __global__ __launch_bounds__(256) void pool_max_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx, const int32_t* __restrict__ order,
-                                                       float* __restrict__ out, int rows_out, int m_cloud, int n_cloud, int K, int c4 /* channels / 4 */)
+                                                       float* __restrict__ out, int rows_out, int m_cloud, int n_cloud, int K, int c4 /* channels / 4 */,
+                                                       unsigned char* __restrict__ ties /* optional [rows_out, 4 c4]: how many of the K rows attain the maximum */)
 {
     // one thread per (output row, float4 of channels).  Output rows are walked XCD by XCD in `order` (the kd-tree leaf order of
     // the output level, when the pyramid carries it): the K gathered rows of neighbouring outputs overlap and stay in that XCD's L2.
@@ -55,6 +56,14 @@ __global__ __launch_bounds__(256) void pool_max_kernel(const float* __restrict__
             for (int k = 1; k < KN; ++k) {
                 m.x = fmaxf(m.x, v[k].x); m.y = fmaxf(m.y, v[k].y); m.z = fmaxf(m.z, v[k].z); m.w = fmaxf(m.w, v[k].w);
             }
+            if (ties) {  // (training: tf.reduce_max's gradient is shared evenly by the rows that attain the maximum)
+                int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+                for (int k = 0; k < KN; ++k) {
+                    t0 += v[k].x == m.x; t1 += v[k].y == m.y; t2 += v[k].z == m.z; t3 += v[k].w == m.w;
+                }
+                reinterpret_cast<uchar4*>(ties)[(size_t)row * c4 + q] = make_uchar4((unsigned char)t0, (unsigned char)t1, (unsigned char)t2, (unsigned char)t3);
+            }
         } else {
             m = f4[(size_t)(base + ix[0]) * c4 + q];
             for (int k = 1; k < K; ++k) {
@@ -64,19 +73,28 @@ __global__ __launch_bounds__(256) void pool_max_kernel(const float* __restrict__
                 m.z = fmaxf(m.z, v.z);
                 m.w = fmaxf(m.w, v.w);
             }
+            if (ties) {
+                int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+                for (int k = 0; k < K; ++k) {
+                    const float4 v = f4[(size_t)(base + ix[k]) * c4 + q];
+                    t0 += v.x == m.x; t1 += v.y == m.y; t2 += v.z == m.z; t3 += v.w == m.w;
+                }
+                reinterpret_cast<uchar4*>(ties)[(size_t)row * c4 + q] = make_uchar4((unsigned char)t0, (unsigned char)t1, (unsigned char)t2, (unsigned char)t3);
+            }
         }
         reinterpret_cast<float4*>(out)[(size_t)row * c4 + q] = m;
     }
 }
 
-int pool_max(ps_context* c, const float* feat, const int32_t* idx, const int32_t* order, float* out, int64_t B, int64_t n, int64_t m, int K, int ch)
+int pool_max(ps_context* c, const float* feat, const int32_t* idx, const int32_t* order, float* out, int64_t B, int64_t n, int64_t m, int K, int ch,
+             unsigned char* ties)
 {
     PS_CHECK(ch % 4 == 0, "pool_max: channel count %d is not a multiple of 4", ch);
     const size_t tot = (size_t)B * m * (ch / 4);
     if (!tot) return PS_OK;
     const unsigned blocks = (unsigned)((std::min<size_t>(ceil_div(tot, 256), 256 * 16) + 7) & ~size_t(7));  // a multiple of 8 (XCD walk)
     const bool al = (reinterpret_cast<uintptr_t>(idx) & 15) == 0;
-#define PS_POOL(KN) hipLaunchKernelGGL(pool_max_kernel<KN>, dim3(blocks), dim3(256), 0, c->stream, feat, idx, order, out, (int)(B * m), (int)m, (int)n, K, ch / 4)
+#define PS_POOL(KN) hipLaunchKernelGGL(pool_max_kernel<KN>, dim3(blocks), dim3(256), 0, c->stream, feat, idx, order, out, (int)(B * m), (int)m, (int)n, K, ch / 4, ties)
     if (K == 16 && al) PS_POOL(16);
     else if (K == 32 && al) PS_POOL(32);
     else PS_POOL(0);

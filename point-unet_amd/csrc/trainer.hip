@@ -815,16 +815,23 @@ struct ps_trainer {
         const Tn x = contig(x_in);
         const int64_t N = x.R / B, d = x.C;
         Tn out = alloc(B * M, d);
-        TK(ps_op_random_sample(c, x.p, pool_idx, B, N, M, K, d, out.p));
+        Tn ties;  // deterministic mode: the forward leaves the tie counts for the backward (one byte per output)
+        if (opt.deterministic && d % 4 == 0 && K <= 255) {
+            ties = alloc(1, (B * M * d + 3) / 4, false);
+            TK(ps_op_random_sample_ties(c, x.p, pool_idx, B, N, M, K, d, out.p, reinterpret_cast<uint8_t*>(ties.p)));
+        } else {
+            TK(ps_op_random_sample(c, x.p, pool_idx, B, N, M, K, d, out.p));
+        }
         const Tn xin = x_in;
         record(out, [=](const Tn& dy_in) {
             const Tn dy = contig(dy_in);
             Tn buf = accum_buffer(xin);
             if (opt.deterministic && buf.contiguous()) {
                 const Inv& iv = inverse(neigh, B, N, N * K);  // (shared with the level's gathers: the pooling rows are a prefix of every segment)
-                Tn share = alloc(B * M, d, false);
+                Tn share = ties ? Tn() : alloc(B * M, d, false);
                 TK(ps_op_random_sample_bwd_inv(c, dy.p, out.p, x.p, pool_idx, reinterpret_cast<const int32_t*>(iv.offsets.p),
-                                               reinterpret_cast<const int32_t*>(iv.src.p), B, N, M, K, d, share.p, buf.p));
+                                               reinterpret_cast<const int32_t*>(iv.src.p), B, N, M, K, d,
+                                               ties ? reinterpret_cast<const uint8_t*>(ties.p) : nullptr, ties ? nullptr : share.p, buf.p));
             } else {
                 TK(ps_op_random_sample_bwd(c, dy.p, out.p, x.p, pool_idx, B, N, M, K, d, buf.p));
             }

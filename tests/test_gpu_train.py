@@ -940,8 +940,16 @@ def test_inverse_index_and_gather_reduction(oracle):
             _lib.check(L.ps_op_random_sample_bwd(h, p(dout), p(out), p(feat), p(pool), B, N, M2, K, d, p(a)))
             b = torch.zeros(B * N, d, device="cuda")
             share = torch.empty(B * M2, d, device="cuda")
-            _lib.check(L.ps_op_random_sample_bwd_inv(h, p(dout), p(out), p(feat), p(pool), p(off), p(src), B, N, M2, K, d, p(share), p(b)))
+            _lib.check(L.ps_op_random_sample_bwd_inv(h, p(dout), p(out), p(feat), p(pool), p(off), p(src), B, N, M2, K, d, None, p(share), p(b)))
             assert (a - b).abs().max() <= 5e-5 * max(1.0, float(a.abs().max()))
+            if d % 4 == 0:  # the forward that leaves the tie counts: same output, and the backward without the recount pass
+                out2 = torch.empty_like(out)
+                ties = torch.empty((B * M2, d), dtype=torch.uint8, device="cuda")
+                _lib.check(L.ps_op_random_sample_ties(h, p(feat), p(pool), B, N, M2, K, d, p(out2), p(ties)))
+                assert torch.equal(out2, out) and int(ties.min()) >= 1
+                b2 = torch.zeros(B * N, d, device="cuda")
+                _lib.check(L.ps_op_random_sample_bwd_inv(h, p(dout), p(out), p(feat), p(pool), p(off), p(src), B, N, M2, K, d, p(ties), None, p(b2)))
+                assert torch.equal(b2, b)
     torch.cuda.synchronize()
 
 
