@@ -103,11 +103,20 @@ __global__ __launch_bounds__(64) void colreduce_finish_kernel(const float* __res
                                                               float* __restrict__ out0, float* __restrict__ out1)
 {
     const int c = blockIdx.x;
-    float t0 = 0.f, t1 = 0.f;
-    for (int b = threadIdx.x; b < blocks; b += 64) {
-        t0 += part0[(size_t)b * C + c];
-        if (part1) t1 += part1[(size_t)b * C + c];
+    // (four independent load chains per lane and output: up to 2 048 partials were 32 dependent L2 round trips per lane)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    int b = threadIdx.x;
+    for (; b + 192 < blocks; b += 256) {
+        a0 += part0[(size_t)b * C + c]; a1 += part0[(size_t)(b + 64) * C + c]; a2 += part0[(size_t)(b + 128) * C + c]; a3 += part0[(size_t)(b + 192) * C + c];
+        if (part1) {
+            b0 += part1[(size_t)b * C + c]; b1 += part1[(size_t)(b + 64) * C + c]; b2 += part1[(size_t)(b + 128) * C + c]; b3 += part1[(size_t)(b + 192) * C + c];
+        }
     }
+    for (; b < blocks; b += 64) {
+        a0 += part0[(size_t)b * C + c];
+        if (part1) b0 += part1[(size_t)b * C + c];
+    }
+    float t0 = (a0 + a1) + (a2 + a3), t1 = (b0 + b1) + (b2 + b3);
     for (int o = 32; o; o >>= 1) {
         t0 += __shfl_down(t0, o);
         t1 += __shfl_down(t1, o);
@@ -129,11 +138,17 @@ __global__ __launch_bounds__(64) void colreduce_finish_bn_kernel(const float* __
                                                                  float* __restrict__ out0, float* __restrict__ out1, BnFinish bn)
 {
     const int c = blockIdx.x;
-    float t0 = 0.f, t1 = 0.f;
-    for (int b = threadIdx.x; b < blocks; b += 64) {
-        t0 += part0[(size_t)b * C + c];
-        t1 += part1[(size_t)b * C + c];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    int b = threadIdx.x;
+    for (; b + 192 < blocks; b += 256) {
+        a0 += part0[(size_t)b * C + c]; a1 += part0[(size_t)(b + 64) * C + c]; a2 += part0[(size_t)(b + 128) * C + c]; a3 += part0[(size_t)(b + 192) * C + c];
+        b0 += part1[(size_t)b * C + c]; b1 += part1[(size_t)(b + 64) * C + c]; b2 += part1[(size_t)(b + 128) * C + c]; b3 += part1[(size_t)(b + 192) * C + c];
     }
+    for (; b < blocks; b += 64) {
+        a0 += part0[(size_t)b * C + c];
+        b0 += part1[(size_t)b * C + c];
+    }
+    float t0 = (a0 + a1) + (a2 + a3), t1 = (b0 + b1) + (b2 + b3);
     for (int o = 32; o; o >>= 1) {
         t0 += __shfl_down(t0, o);
         t1 += __shfl_down(t1, o);
