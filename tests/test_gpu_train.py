@@ -1020,3 +1020,27 @@ def test_pyramid_prefetcher_feeds_the_same_pyramids():
     torch.cuda.synchronize()
     pre.close()
     assert [float(g) for g in got] == want
+
+
+def test_training_step_k32_two_classes(oracle):
+    """The Pancreas shape family (BASELINE configs[4]: K = 32, 4 input channels, 2 classes; runPancreas.py:118,125) through the native
+    training step: the fused attention / LocSE kernels are compiled for K = 16 only, so this runs the op-by-op forms at every level --
+    loss, logits and gradients against torch-CPU float64 autograd at the bars of test_one_training_step_matches_autograd."""
+    import torch
+    from oracle import randla_train_oracle as rto
+    cfg, xyz, feats = netcase.small_deep(3000, seed=6, B=2, k_n=32, classes=2, mods=1)
+    cfg.d_out = [16, 32, 64, 32, 16]
+    tr, pyr, params, labels, cw, (pts, nbr, pool, up) = _setup(cfg, xyz, feats)
+    loss = tr.train_step(pyr, torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda())
+    torch.cuda.synchronize()
+    want = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, step=1)
+    assert abs(float(loss) - want["loss"]) <= 1e-5 * max(1.0, abs(want["loss"])), (float(loss), want["loss"])
+    assert np.abs(tr.last_logits.cpu().numpy().reshape(want["logits"].shape) - want["logits"]).max() < 1e-4
+    gscale = max(np.abs(g).max() for g in want["grads"].values())
+    worst = []
+    for name in tr.names:
+        got = tr.G[name].cpu().numpy()
+        ref = want["grads"][name]
+        worst.append((float(np.abs(got - ref).max() / (2e-3 * np.abs(ref).max() + 2e-5 * gscale)), name))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 1.0, worst[:5]
