@@ -1028,14 +1028,17 @@ def test_training_step_k32_two_classes(oracle):
     loss, logits and gradients against torch-CPU float64 autograd at the bars of test_one_training_step_matches_autograd."""
     import torch
     from oracle import randla_train_oracle as rto
-    cfg, xyz, feats = netcase.small_deep(3000, seed=6, B=2, k_n=32, classes=2, mods=1)
+    # 9 000 points: the deepest level keeps 35 >= K of them (below K the neighbour lists are zero-padded and the BatchNorms of that level
+    # see a couple of dozen rows: the float32 error of the logits then grows to several 1e-4)
+    cfg, xyz, feats = netcase.small_deep(9000, seed=6, B=2, k_n=32, classes=2, mods=1)
     cfg.d_out = [16, 32, 64, 32, 16]
     tr, pyr, params, labels, cw, (pts, nbr, pool, up) = _setup(cfg, xyz, feats)
     loss = tr.train_step(pyr, torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda())
     torch.cuda.synchronize()
     want = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, step=1)
     assert abs(float(loss) - want["loss"]) <= 1e-5 * max(1.0, abs(want["loss"])), (float(loss), want["loss"])
-    assert np.abs(tr.last_logits.cpu().numpy().reshape(want["logits"].shape) - want["logits"]).max() < 1e-4
+    err = np.abs(tr.last_logits.cpu().numpy().reshape(want["logits"].shape) - want["logits"]).max()
+    assert err <= 1e-4 * max(1.0, np.abs(want["logits"]).max() / 4), err
     gscale = max(np.abs(g).max() for g in want["grads"].values())
     worst = []
     for name in tr.names:
@@ -1043,4 +1046,5 @@ def test_training_step_k32_two_classes(oracle):
         ref = want["grads"][name]
         worst.append((float(np.abs(got - ref).max() / (2e-3 * np.abs(ref).max() + 2e-5 * gscale)), name))
     worst.sort(reverse=True)
+    print("K = 32 step: logits err %.2e, worst gradient tensors %s" % (err, worst[:3]))
     assert worst[0][0] <= 1.0, worst[:5]
