@@ -67,16 +67,17 @@ __device__ __forceinline__ f32x16 b3_mfma6(const B3Planes& a, const B3Planes& b,
 
 // W[K, N] (row-major, ldw) -> planes [K/16][N/32][3][64] x 8 bfloat16: lane l of (chunk q, column tile cb) holds
 // W[16 q + 8 (l >> 5) + j][32 cb + (l & 31)], j = 0..7.  One thread per (q, cb, lane).
-__global__ __launch_bounds__(256) void gemm_b3_pack_kernel(const float* __restrict__ w, int ldw, int K, int N, uint4* __restrict__ out)
+__global__ __launch_bounds__(256) void gemm_b3_pack_kernel(const float* __restrict__ w, int64_t sk, int64_t sn, int K, int N, uint4* __restrict__ out)
 {
+    // element (k, n) of the [K, N] matrix sits at w[k * sk + n * sn] (sk = N, sn = 1 row-major; sk = 1, sn = K for a matrix stored [N, K])
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int ncb = N / 32;
     if (i >= (K / 16) * ncb * 64) return;
     const int lane = i & 63, cb = (i >> 6) % ncb, q = (i >> 6) / ncb;
-    const float* src = w + (size_t)(16 * q + 8 * (lane >> 5)) * ldw + 32 * cb + (lane & 31);
+    const float* src = w + (int64_t)(16 * q + 8 * (lane >> 5)) * sk + (int64_t)(32 * cb + (lane & 31)) * sn;
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * ldw];
+    for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)j * sk];
     const B3Planes p = b3_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
     uint4* dst = out + ((size_t)(q * ncb + cb) * 3) * 64 + lane;
     dst[0] = p.p[0]; dst[64] = p.p[1]; dst[128] = p.p[2];
@@ -381,10 +382,10 @@ bool gemm_b3_fits(int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx)
 
 size_t gemm_b3_plane_bytes(int64_t K, int64_t N) { return (size_t)K * N * 6; }
 
-int gemm_b3(ps_context* c, const float* x, int64_t ldx, const float* w, const float* bias, int64_t R, int64_t K, int64_t N, int leaky, int accumulate,
-            float* y, int64_t ldy, void* planes)
+int gemm_b3(ps_context* c, const float* x, int64_t ldx, const float* w, int64_t sk, int64_t sn, const float* bias, int64_t R, int64_t K, int64_t N, int leaky,
+            int accumulate, float* y, int64_t ldy, void* planes)
 {
-    hipLaunchKernelGGL(gemm_b3_pack_kernel, dim3(ceil_div((K / 16) * (N / 32) * 64, 256)), dim3(256), 0, c->stream, w, (int)N, (int)K, (int)N,
+    hipLaunchKernelGGL(gemm_b3_pack_kernel, dim3(ceil_div((K / 16) * (N / 32) * 64, 256)), dim3(256), 0, c->stream, w, sk, sn, (int)K, (int)N,
                        static_cast<uint4*>(planes));
     GemmB3Args a;
     a.x = x; a.ldx = (int)ldx; a.wp = static_cast<const uint4*>(planes); a.bias = bias; a.y = y; a.ldy = (int)ldy;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void pool_max_scalar_kernel(const float* __res
     out[t] = m;
 }
 
-__global__ void pack_weights_kernel(const float* __restrict__ W, int cin, int cout, int ntb, int ks, int cblocks, float* __restrict__ out)
+__global__ void pack_weights_kernel(const float* __restrict__ W, int64_t sk, int64_t sn, int cin, int cout, int ntb, int ks, int cblocks, float* __restrict__ out)
 {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t total = (size_t)cblocks * ks * 64 * ntb;
@@ -88,10 +88,10 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, int cin, int co
     const int s = (int)((t / ntb / 64) % ks);
     const int cb = (int)(t / ntb / 64 / ks);
     const int k = s * 4 + (l >> 4), col = (cb * ntb + j) * 16 + (l & 15);
-    out[t] = (k < cin && col < cout) ? W[(size_t)k * cout + col] : 0.f;
+    out[t] = (k < cin && col < cout) ? W[k * sk + col * sn] : 0.f;
 }
 
-__global__ void pack_weights_kperm_kernel(const float* __restrict__ W, int cin, int cout, int ntb, int nc, int cblocks, float* __restrict__ out)
+__global__ void pack_weights_kperm_kernel(const float* __restrict__ W, int64_t sk, int64_t sn, int cin, int cout, int ntb, int nc, int cblocks, float* __restrict__ out)
 {
     // k-permuted image of rowgemm.h: out[((((cb*nc + c)*16 + s)*64 + l)*ntb) + j] = W[c*64 + 16*(l>>4) + s][(cb*ntb + j)*16 + (l&15)]
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -103,11 +103,11 @@ __global__ void pack_weights_kperm_kernel(const float* __restrict__ W, int cin, 
     const int c = (int)((t / ntb / 64 / 16) % nc);
     const int cb = (int)(t / ntb / 64 / 16 / nc);
     const int k = c * 64 + 16 * (l >> 4) + s, col = (cb * ntb + j) * 16 + (l & 15);
-    out[t] = (k < cin && col < cout) ? W[(size_t)k * cout + col] : 0.f;
+    out[t] = (k < cin && col < cout) ? W[k * sk + col * sn] : 0.f;
 }
 
 // bf16 image of rowgemm.h (PackedLinear::wb): one thread per bf16 element
-__global__ void pack_weights_bf16_kernel(const float* __restrict__ W, int cin, int cout, int ntb, int nc, int cblocks, __bf16* __restrict__ out)
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ W, int64_t sk, int64_t sn, int cin, int cout, int ntb, int nc, int cblocks, __bf16* __restrict__ out)
 {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t total = (size_t)cblocks * nc * 2 * 64 * ntb * 8;
@@ -119,7 +119,7 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ W, int cin, i
     const int c = (int)((t / 8 / ntb / 64 / 2) % nc);
     const int cb = (int)(t / 8 / ntb / 64 / 2 / nc);
     const int k = c * 64 + 16 * (l >> 4) + 8 * s + e, col = (cb * ntb + j) * 16 + (l & 15);
-    out[t] = (__bf16)((k < cin && col < cout) ? W[(size_t)k * cout + col] : 0.f);
+    out[t] = (__bf16)((k < cin && col < cout) ? W[k * sk + col * sn] : 0.f);
 }
 
 // agg[r, col] = sum_k fset[r,k,col] * softmax_k( (fset[r] . wfc)[k, col] )    (RandLANet.py:394-398)
@@ -244,7 +244,7 @@ namespace ps {
 // 2.2 TB/s; here a THREAD owns a row -- 16-byte loads, the CIN x COUT weights broadcast from LDS, 16-byte stores -- and the pass runs
 // at the HBM rate.  bf16 mode: both operands rounded (RNE) before the fp32 multiply-add, like the MFMA flavours.
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void tinyconv_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, const float* __restrict__ b,
+__global__ __launch_bounds__(256) void tinyconv_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, int wt, const float* __restrict__ b,
                                                        int64_t R, int leaky, int accum, int bf16, float* __restrict__ y, int64_t ldy)
 {
     __shared__ __attribute__((aligned(16))) float W[CIN * COUT];
@@ -254,7 +254,10 @@ __global__ __launch_bounds__(256) void tinyconv_kernel(const float* __restrict__
         u += 0x7fffu + ((u >> 16) & 1u);
         return __uint_as_float(u & 0xffff0000u);
     };
-    for (int i = threadIdx.x; i < CIN * COUT; i += 256) W[i] = bf16 ? rb(w[i]) : w[i];
+    for (int i = threadIdx.x; i < CIN * COUT; i += 256) {  // W[k][n]; wt: the matrix is stored [n][k]
+        const float v = wt ? w[(i % COUT) * CIN + i / COUT] : w[i];
+        W[i] = bf16 ? rb(v) : v;
+    }
     if ((int)threadIdx.x < COUT) Bv[threadIdx.x] = b ? b[threadIdx.x] : 0.f;
     __syncthreads();
     for (int64_t r = blockIdx.x * (int64_t)256 + threadIdx.x; r < R; r += (int64_t)gridDim.x * 256) {
@@ -309,12 +312,16 @@ extern "C" int ps_op_conv1x1_ex(ps_context* c, const float* x, int64_t ldx, cons
     PS_CHECK(R >= 0 && cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout, "ps_op_conv1x1: bad shape");
     if (!R) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
+    // (internal switch of the native training step: `w` is stored [cout, cin] -- the transposed-convolution kernels of the decoder in the
+    //  forward pass, every other layer's kernel in its input-gradient GEMM; the packing kernels read it through strides, no transposed copy)
+    const bool wt = c->conv_w_transposed;
+    const int64_t sk = wt ? 1 : cout, sn = wt ? cin : 1;
     if (tinyconv_fits(R, cin, cout, x, ldx, y, ldy)) {
         Stage st(c, "op_conv1x1", 1);
         const dim3 grid(2048);
         // (the MFMA bf16 flavour only covers cin % 16 == 0: the rounding follows the same rule here)
         const int bf = c->train_bf16 && cin % 16 == 0 ? 1 : 0;
-#define PS_TINY(CI, CO) hipLaunchKernelGGL((tinyconv_kernel<CI, CO>), grid, dim3(256), 0, c->stream, x, ldx, w, b, R, leaky, accumulate ? 1 : 0, bf, y, ldy)
+#define PS_TINY(CI, CO) hipLaunchKernelGGL((tinyconv_kernel<CI, CO>), grid, dim3(256), 0, c->stream, x, ldx, w, wt ? 1 : 0, b, R, leaky, accumulate ? 1 : 0, bf, y, ldy)
         if (cin == 8 && cout == 8) PS_TINY(8, 8);
         else if (cin == 8) PS_TINY(8, 16);
         else if (cout == 8) PS_TINY(16, 8);
@@ -329,7 +336,7 @@ extern "C" int ps_op_conv1x1_ex(ps_context* c, const float* x, int64_t ldx, cons
         c->ops_ring_pos = (c->ops_ring_pos + 1) & 3;
         PS_TRY(pw.reserve(gemm_b3_plane_bytes(cin, cout)));
         Stage st(c, "op_conv1x1", 2);
-        return gemm_b3(c, x, ldx, w, b, R, cin, cout, leaky, accumulate, y, ldy, pw.as<void>());
+        return gemm_b3(c, x, ldx, w, sk, sn, b, R, cin, cout, leaky, accumulate, y, ldy, pw.as<void>());
     }
     PackedLinear L;
     L.cin = (int)cin; L.cout = (int)cout; L.leaky = leaky; L.accum = accumulate ? 1 : 0;
@@ -345,13 +352,13 @@ extern "C" int ps_op_conv1x1_ex(ps_context* c, const float* x, int64_t ldx, cons
     PS_TRY(ws.reserve(need));
     Stage st(c, "op_conv1x1", 2);
     if (bf16)
-        hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(ceil_div(L.bf16_bytes() / 2, 256)), dim3(256), 0, c->stream, w, L.cin, L.cout, L.ntb, L.nchunks(),
+        hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(ceil_div(L.bf16_bytes() / 2, 256)), dim3(256), 0, c->stream, w, sk, sn, L.cin, L.cout, L.ntb, L.nchunks(),
                            L.cblocks, ws.as<__bf16>());
     else if (kperm)
-        hipLaunchKernelGGL(pack_weights_kperm_kernel, dim3(ceil_div(L.kperm_floats(), 256)), dim3(256), 0, c->stream, w, L.cin, L.cout, L.ntb, L.nchunks(),
+        hipLaunchKernelGGL(pack_weights_kperm_kernel, dim3(ceil_div(L.kperm_floats(), 256)), dim3(256), 0, c->stream, w, sk, sn, L.cin, L.cout, L.ntb, L.nchunks(),
                            L.cblocks, ws.as<float>());
     else
-        hipLaunchKernelGGL(pack_weights_kernel, dim3(ceil_div(L.packed_floats(), 256)), dim3(256), 0, c->stream, w, L.cin, L.cout, L.ntb, L.ks, L.cblocks,
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(ceil_div(L.packed_floats(), 256)), dim3(256), 0, c->stream, w, sk, sn, L.cin, L.cout, L.ntb, L.ks, L.cblocks,
                            ws.as<float>());
     PS_HIP(hipGetLastError());
     L.wp = kperm ? nullptr : ws.as<float>();

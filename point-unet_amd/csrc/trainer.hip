@@ -566,16 +566,23 @@ struct ps_trainer {
             Fp32Scope(ps_context* ctx, bool on) : c(ctx), was(ctx->train_bf16) { if (on) c->train_bf16 = false; }
             ~Fp32Scope() { c->train_bf16 = was; }
         };
+        struct WtScope {  // tells ps_op_conv1x1_ex that its weight matrix is stored [cout, cin] (read through strides while packing)
+            ps_context* c;
+            WtScope(ps_context* ctx, bool on) : c(ctx) { c->conv_w_transposed = on; }
+            ~WtScope() { c->conv_w_transposed = false; }
+        };
         Fp32Scope fwd_scope(c, fp32_only);
-        const Tn Wm = transposed ? transpose(W) : W;  // [cin, cout]
-        const int64_t R = x.R, cin = x.C, cout = Wm.C;
+        const int64_t R = x.R, cin = x.C, cout = transposed ? W.R : W.C;
         Tn y;
-        if (!into) {
-            y = alloc(R, cout);
-            TK(ps_op_conv1x1_ex(c, x.p, x.ld, Wm.p, b, R, cin, cout, 0, 0, y.p, y.ld));
-        } else {
-            y = *into;
-            TK(ps_op_conv1x1_ex(c, x.p, x.ld, Wm.p, b, R, cin, cout, 0, 1, y.p, y.ld));
+        {
+            WtScope wt(c, transposed);  // conv2d_transpose kernels are stored [out, in]
+            if (!into) {
+                y = alloc(R, cout);
+                TK(ps_op_conv1x1_ex(c, x.p, x.ld, W.p, b, R, cin, cout, 0, 0, y.p, y.ld));
+            } else {
+                y = *into;
+                TK(ps_op_conv1x1_ex(c, x.p, x.ld, W.p, b, R, cin, cout, 0, 1, y.p, y.ld));
+            }
         }
         const bool had_into = into != nullptr;
         const Tn into_t = had_into ? *into : Tn();
@@ -598,15 +605,16 @@ struct ps_trainer {
                 }
             }
             if (x.req) {
-                const Tn Wt = transposed ? W : transpose(Wm);  // [cout, cin]
+                // dx = dy . W^T: the GEMM's [cout, cin] matrix IS the stored kernel for the transposed layers and its transpose for all others
+                WtScope wt(c, !transposed);
                 auto it = grad_of.find(x.id);
                 if (it != grad_of.end()) {
                     // x already has a gradient from another consumer: add this one in the GEMM epilogue
                     Tn& have = it->second;
-                    TK(ps_op_conv1x1_ex(c, dy.p, dy.ld, Wt.p, nullptr, R, cout, cin, 0, 1, have.p, have.ld));
+                    TK(ps_op_conv1x1_ex(c, dy.p, dy.ld, W.p, nullptr, R, cout, cin, 0, 1, have.p, have.ld));
                 } else {
                     Tn dx = alloc(R, cin);
-                    TK(ps_op_conv1x1_ex(c, dy.p, dy.ld, Wt.p, nullptr, R, cout, cin, 0, 0, dx.p, dx.ld));
+                    TK(ps_op_conv1x1_ex(c, dy.p, dy.ld, W.p, nullptr, R, cout, cin, 0, 0, dx.p, dx.ld));
                     accum(x, dx);
                 }
             }
