@@ -371,6 +371,7 @@ struct ps_trainer {
     };
     std::vector<Op> ops;
     std::unordered_map<int, Tn> grad_of;
+    std::unordered_map<int, std::vector<std::function<void()>>> deferred;  // input-gradient GEMMs waiting for another consumer's plain store
     // inverse indices of the step's gather tables (deterministic mode): built at their first use in the backward pass, kept to its end
     struct Inv {
         Tn offsets, src;
@@ -514,6 +515,16 @@ struct ps_trainer {
         return z;
     }
     void record(const Tn& out, std::function<void(const Tn&)> bw) { ops.push_back({out.id, section, std::move(bw)}); }
+    // runs the input-gradient products that were parked on tensor `id` (linear(..., defer_dgrad)): called once the consumer they waited
+    // for has stored its own gradient, and in any case before the producer of `id` runs its backward
+    void run_deferred(int id)
+    {
+        auto it = deferred.find(id);
+        if (it == deferred.end()) return;
+        std::vector<std::function<void()>> fs = std::move(it->second);
+        deferred.erase(it);
+        for (auto& f : fs) f();
+    }
     void backward(const Tn& out, const Tn& dout)
     {
         grad_of[out.id] = dout;
@@ -523,6 +534,7 @@ struct ps_trainer {
                 cur = ops[i].section;
                 mark("bwd " + section_names[cur]);
             }
+            run_deferred(ops[i].out_id);
             auto it = grad_of.find(ops[i].out_id);
             if (it == grad_of.end()) {
                 ops[i].bw = nullptr;
@@ -535,6 +547,7 @@ struct ps_trainer {
         }
         ops.clear();
         grad_of.clear();
+        deferred.clear();
         inv_cache.clear();
         finish_wgrads();
     }
@@ -558,7 +571,11 @@ struct ps_trainer {
     // same tensor and its gradient is handed on unchanged to the op that produced it.
     // fp32_only: this layer is not one of the "bf16 MLPs" (the LocSE convolution 10 -> h: part of the position encoding, K = 10 is no
     // matrix-pipe shape, and its fused form computes in fp32): its three GEMMs keep fp32 operands in the bf16 mode too.
-    Tn linear(const Tn& x, const Tn& W, const float* b, const Tn& gW, float* gb, bool transposed = false, const Tn* into = nullptr, bool fp32_only = false)
+    // defer_dgrad: x has a later-running consumer whose backward STORES its gradient of x (the fused attention kernels); this layer's
+    // input-gradient GEMM then waits for that store and adds into it in its epilogue (a streaming read-modify-write) instead of making the
+    // attention kernel read-modify-write a tensor this GEMM wrote first
+    Tn linear(const Tn& x, const Tn& W, const float* b, const Tn& gW, float* gb, bool transposed = false, const Tn* into = nullptr, bool fp32_only = false,
+              bool defer_dgrad = false)
     {
         struct Fp32Scope {  // switches the context's bf16-GEMM mode off for the lifetime of the object
             ps_context* c;
@@ -606,17 +623,24 @@ struct ps_trainer {
             }
             if (x.req) {
                 // dx = dy . W^T: the GEMM's [cout, cin] matrix IS the stored kernel for the transposed layers and its transpose for all others
-                WtScope wt(c, !transposed);
-                auto it = grad_of.find(x.id);
-                if (it != grad_of.end()) {
-                    // x already has a gradient from another consumer: add this one in the GEMM epilogue
-                    Tn& have = it->second;
-                    TK(ps_op_conv1x1_ex(c, dy.p, dy.ld, W.p, nullptr, R, cout, cin, 0, 1, have.p, have.ld));
-                } else {
-                    Tn dx = alloc(R, cin);
-                    TK(ps_op_conv1x1_ex(c, dy.p, dy.ld, W.p, nullptr, R, cout, cin, 0, 0, dx.p, dx.ld));
-                    accum(x, dx);
-                }
+                auto dgrad = [=]() {
+                    Fp32Scope scope(c, fp32_only);
+                    WtScope wt(c, !transposed);
+                    auto it = grad_of.find(x.id);
+                    if (it != grad_of.end()) {
+                        // x already has a gradient from another consumer: add this one in the GEMM epilogue
+                        Tn& have = it->second;
+                        TK(ps_op_conv1x1_ex(c, dy.p, dy.ld, W.p, nullptr, R, cout, cin, 0, 1, have.p, have.ld));
+                    } else {
+                        Tn dx = alloc(R, cin);
+                        TK(ps_op_conv1x1_ex(c, dy.p, dy.ld, W.p, nullptr, R, cout, cin, 0, 0, dx.p, dx.ld));
+                        accum(x, dx);
+                    }
+                };
+                if (defer_dgrad && !grad_of.count(x.id))
+                    deferred[x.id].push_back(dgrad);
+                else
+                    dgrad();
             }
         });
         return y;
@@ -813,6 +837,7 @@ struct ps_trainer {
                 TK(ps_op_att_pool_train_bwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, dy.p, K, d, dsrc.p, dsrc.ld, dfx.p, dfx.ld, gW.p));
             }
             if (!add_in_place) accum(f_xyz, dfx);
+            run_deferred(f_xyz.id);
         });
         return agg;
     }
@@ -891,10 +916,11 @@ struct ps_trainer {
     Tn gWt(const LayerP& lp) { return lp.kind == kDeconv ? G(lp.w, lp.cout, lp.cin) : G(lp.w, lp.cin, lp.cout); }
 
     // helper_tf_util.conv2d / conv2d_transpose (:115-250): 1x1 conv + bias [+ BatchNorm(training) [+ LeakyReLU(0.2)]]
-    Tn conv(const Tn& x, const std::string& scope, bool bn = true, bool act = true, const Tn* out = nullptr, bool fp32_only = false)
+    Tn conv(const Tn& x, const std::string& scope, bool bn = true, bool act = true, const Tn* out = nullptr, bool fp32_only = false, bool defer_dgrad = false)
     {
         const LayerP& lp = layer(scope);
-        Tn y = linear(x, Wt(lp), lp.b >= 0 ? params + lp.b : nullptr, gWt(lp), lp.b >= 0 ? grads + lp.b : nullptr, lp.kind == kDeconv, nullptr, fp32_only);
+        Tn y = linear(x, Wt(lp), lp.b >= 0 ? params + lp.b : nullptr, gWt(lp), lp.b >= 0 ? grads + lp.b : nullptr, lp.kind == kDeconv, nullptr, fp32_only,
+                      defer_dgrad);
         if (bn) y = bn_act(y, lp, act, out);
         return y;
     }
@@ -966,7 +992,7 @@ struct ps_trainer {
                 // gather_neighbour + concat + att_pooling's core as one kernel per direction
                 Tn f_xyz = locse(nullptr);
                 Tn f_agg = att_split(f_pc, idx, B, N, K, f_xyz, n + "LFAatt_pooling_1");
-                Tn f_xyz2 = conv(f_xyz, n + "LFAmlp2");
+                Tn f_xyz2 = conv(f_xyz, n + "LFAmlp2", true, true, nullptr, false, /*defer_dgrad: pooling 1's backward stores first*/ true);
                 f_agg2 = att_split(f_agg, idx, B, N, K, f_xyz2, n + "LFAatt_pooling_2");
             } else {
                 // (d = 128: the pre-product form measured slower, HBM bound there; bf16 mode: its yardstick rounds the operands of the ONE d x d product)
