@@ -53,6 +53,7 @@ struct AttTrainArgs {
     float* dfl_rows;     // non-null: the gathered half's gradient goes HERE as plain rows [R*K, D/2] (ld_rows) instead of being scatter-added into
     int ld_rows;         // dfl with float atomics; ps_op_gather_reduce_rows then adds the rows up in a fixed order (deterministic step)
     int df_accum;        // split form: df (the f_xyz half's gradient) is ADDED to what the rows already hold (a second gradient of the same tensor)
+    int vec_store;       // backward: the row outputs (df, dfl_rows) are 16-byte aligned with pitches % 4 == 0 -> staged through LDS, float4 stores
 };
 
 template <int D>
@@ -119,6 +120,38 @@ __device__ __forceinline__ void load_tile_split(const AttTrainArgs& a, int64_t p
                 float* db = Ab + row * PA + 4 * q;
                 db[0] = round_bf16(v.x); db[1] = round_bf16(v.y); db[2] = round_bf16(v.z); db[3] = round_bf16(v.w);
             }
+        }
+    }
+}
+
+// the K x D tile of dF staged in LDS (pitch PA, 8-byte aligned rows) -> global as 16-byte stores: whole rows of df (plain form), or the
+// gathered half -> dfl_rows and the f_xyz half -> df (split form).  A point's rows are contiguous in each destination, so the wave writes
+// one or two dense spans instead of 4-byte columns of sixteen lanes.
+template <int D, int KN, int PA>
+__device__ __forceinline__ void store_tile_rows(const AttTrainArgs& a, int64_t p, const float* S, int lane)
+{
+    constexpr int Q = D / 4, QH = Q / 2, TOT = KN * Q;
+#pragma unroll
+    for (int e0 = 0; e0 < TOT; e0 += 64) {
+        const int e = e0 + lane;
+        if (TOT % 64 == 0 || e < TOT) {
+            const int row = e / Q, q = e - row * Q;
+            const float2 lo = *reinterpret_cast<const float2*>(S + row * PA + 4 * q);
+            const float2 hi = *reinterpret_cast<const float2*>(S + row * PA + 4 * q + 2);
+            float4 v = make_float4(lo.x, lo.y, hi.x, hi.y);
+            float4* dst;
+            if (!a.fl) {
+                dst = reinterpret_cast<float4*>(a.df + (size_t)(p * KN + row) * a.lddf + 4 * q);
+            } else if (q < QH) {
+                dst = reinterpret_cast<float4*>(a.dfl_rows + (size_t)(p * KN + row) * a.ld_rows + 4 * q);
+            } else {
+                dst = reinterpret_cast<float4*>(a.df + (size_t)(p * KN + row) * a.lddf + 4 * (q - QH));
+                if (a.df_accum) {
+                    const float4 o = *dst;
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+            }
+            *dst = v;
         }
     }
 }
@@ -228,6 +261,21 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
             }
         }
         wave_lds_sync();
+        // ---- dWfc += F^T . dS  (contraction over the K = 16 rows: four MFMA steps per tile pair) ----
+#pragma unroll
+        for (int s = 0; s < KN / 4; ++s) {
+            float fa[NT], db[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                fa[t] = X[(4 * s + g) * PA + t * 16 + c16];  // A operand: F^T[i = 16 t + c16][k = 4 s + g]
+                db[t] = T[(4 * s + g) * PA + t * 16 + c16];  // B operand: dS[k][j = 16 t + c16]
+            }
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) dw[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ti], db[tj], dw[ti][tj], 0, 0, 0);
+        }
+        if (a.vec_store) wave_lds_sync();  // the value tile is dead from here on: it stages dF for the 16-byte stores
         // ---- dF = p . g + dS . Wfc^T  -> global ----
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) {
@@ -236,7 +284,10 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
             f32x4 acc = dfd[tj];
 #pragma unroll
             for (int s = 0; s < D / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[4 * s], wb[4 * s * PW], acc, 0, 0, 0);
-            if (!a.fl) {
+            if (a.vec_store) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[(4 * g + r) * PA + tj * 16 + c16] = acc[r];
+            } else if (!a.fl) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a.df[(size_t)(p * KN + 4 * g + r) * a.lddf + tj * 16 + c16] = acc[r];
             } else {
@@ -260,19 +311,9 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
                 }
             }
         }
-        // ---- dWfc += F^T . dS  (contraction over the K = 16 rows: four MFMA steps per tile pair) ----
-#pragma unroll
-        for (int s = 0; s < KN / 4; ++s) {
-            float fa[NT], db[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                fa[t] = X[(4 * s + g) * PA + t * 16 + c16];  // A operand: F^T[i = 16 t + c16][k = 4 s + g]
-                db[t] = T[(4 * s + g) * PA + t * 16 + c16];  // B operand: dS[k][j = 16 t + c16]
-            }
-#pragma unroll
-            for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-                for (int tj = 0; tj < NT; ++tj) dw[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ti], db[tj], dw[ti][tj], 0, 0, 0);
+        if (a.vec_store) {
+            wave_lds_sync();
+            store_tile_rows<D, KN, PA>(a, p, A, lane);
         }
         wave_lds_sync();
     }
@@ -463,7 +504,10 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) {
             const f32x4 acc = tile_mma_bf16<D>(Tb, Wb, tj, lane, dfd[tj]);
-            if (!a.fl) {
+            if (a.vec_store) {  // (the fp32 value tile is dead after the softmax loop: it stages dF for the 16-byte stores)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[(4 * g + r) * PA + tj * 16 + c16] = acc[r];
+            } else if (!a.fl) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a.df[(size_t)(p * KN + 4 * g + r) * a.lddf + tj * 16 + c16] = acc[r];
             } else {
@@ -502,6 +546,10 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
 #pragma unroll
                 for (int tj = 0; tj < NT; ++tj) dw[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fa[ti], db[tj], dw[ti][tj], 0, 0, 0);
         }
+        if (a.vec_store) {
+            wave_lds_sync();
+            store_tile_rows<D, KN, PA>(a, p, A, lane);
+        }
         wave_lds_sync();
     }
     // ---- the workgroup's dWfc partial: waves add up through LDS (fixed order), one plain store per element ----
@@ -526,6 +574,11 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
 {
     constexpr int KN = 16, WAVES = 8;
     constexpr int PW = AttTrainGeom<D>::PW, PA = AttTrainGeom<D>::PA;
+    if (backward) {
+        auto al = [](const void* q, int ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0; };
+        const bool rows_out = !a.fl || a.dfl_rows;  // (the atomic scatter form keeps its per-element path)
+        a.vec_store = rows_out && al(a.df, a.lddf) && (!a.fl || al(a.dfl_rows, a.ld_rows)) ? 1 : 0;
+    }
     if (a.bf16) {  // the bf16-MLP mode: operands kept as bfloat16 in LDS, products on the bf16 matrix pipe
         constexpr int PB = AttBf16Geom<D>::PB;
         size_t smem = sizeof(float) * ((backward ? 2 : 1) * (size_t)(D * PB / 2) + (size_t)WAVES * (KN * PA + (backward ? 2 : 1) * (KN * PB / 2)));
