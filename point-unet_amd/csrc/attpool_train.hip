@@ -77,84 +77,118 @@ __device__ __forceinline__ void stage_weights(const float* __restrict__ w, float
     }
 }
 
-// the K x D tile of point p -> LDS (pitch PA), 16-byte loads; `Ab` receives the bf16-rounded copy when non-null
+// Walks a wave's points (p, p + stride, ...) keeping the cloud of p without a 64-bit division per point (split form: cloud base of fl).
+struct PointWalk {
+    int p, stride, cloud, rem, n_q;
+    __device__ __forceinline__ PointWalk(int first, int stride_, int n_q_) : p(first), stride(stride_), n_q(n_q_ > 0 ? n_q_ : 0x7fffffff)
+    {
+        cloud = first / n_q;
+        rem = first - cloud * n_q;
+    }
+    __device__ __forceinline__ PointWalk next() const
+    {
+        PointWalk w = *this;
+        w.p += stride;
+        w.rem += stride;
+        while (w.rem >= n_q) {
+            w.rem -= n_q;
+            ++w.cloud;
+        }
+        return w;
+    }
+};
+
+// The K x D tile of one point as registers: lane e of pass i holds float4 q of row (64 i + e) / (D/4).  fetch = global -> registers
+// (issued one point AHEAD: a wave works on one point at a time, and at two to eight waves per SIMD nothing else covers the latency of
+// these loads), commit = registers -> LDS.  Split form: columns [0, D/2) from fl[cloud base + idx[p, row]], [D/2, D) from row p*KN + row of f.
 template <int D, int KN>
-__device__ __forceinline__ void load_tile(const float* __restrict__ f, int ld, int64_t p, float* A, float* Ab, int lane)
-{
-    constexpr int PA = AttTrainGeom<D>::PA, Q = D / 4, TOT = KN * Q;
+struct TileRegs {
+    static constexpr int Q = D / 4, QH = Q / 2, TOT = KN * Q, NV = (TOT + 63) / 64;
+    float4 v[NV];
+    __device__ __forceinline__ void fetch(const AttTrainArgs& a, const PointWalk& w, int lane)
+    {
+        const int64_t p = w.p;
+        const int64_t base = (int64_t)w.cloud * a.n_src;
 #pragma unroll
-    for (int e0 = 0; e0 < TOT; e0 += 64) {
-        const int e = e0 + lane;
-        if (TOT % 64 == 0 || e < TOT) {
-            const int row = e / Q, q = e - row * Q;
-            const float4 v = *reinterpret_cast<const float4*>(f + (size_t)(p * KN + row) * ld + 4 * q);
-            float* dst = A + row * PA + 4 * q;
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-            if (Ab) {
-                float* db = Ab + row * PA + 4 * q;
-                db[0] = round_bf16(v.x); db[1] = round_bf16(v.y); db[2] = round_bf16(v.z); db[3] = round_bf16(v.w);
+        for (int i = 0; i < NV; ++i) {
+            const int e = 64 * i + lane;
+            if (TOT % 64 == 0 || e < TOT) {
+                const int row = e / Q, q = e - row * Q;
+                if (!a.fl)
+                    v[i] = *reinterpret_cast<const float4*>(a.f + (size_t)(p * KN + row) * a.ld + 4 * q);
+                else if (q < QH)
+                    v[i] = *reinterpret_cast<const float4*>(a.fl + (size_t)(base + a.idx[p * KN + row]) * a.ldl + 4 * q);
+                else
+                    v[i] = *reinterpret_cast<const float4*>(a.f + (size_t)(p * KN + row) * a.ld + 4 * (q - QH));
             }
         }
     }
-}
-
-// split-source tile: columns [0, D/2) from fl[cloud base + idx[p, row]], columns [D/2, D) from row p*KN + row of f
-template <int D, int KN>
-__device__ __forceinline__ void load_tile_split(const AttTrainArgs& a, int64_t p, float* A, float* Ab, int lane)
-{
-    constexpr int PA = AttTrainGeom<D>::PA, Q = D / 4, QH = Q / 2, TOT = KN * Q;
-    const int64_t base = (p / a.n_q) * a.n_src;
+    // fp32 tile (pitch PA); `Ab` receives the bf16-rounded copy when non-null
+    template <int PA>
+    __device__ __forceinline__ void commit(float* A, float* Ab, int lane) const
+    {
 #pragma unroll
-    for (int e0 = 0; e0 < TOT; e0 += 64) {
-        const int e = e0 + lane;
-        if (TOT % 64 == 0 || e < TOT) {
-            const int row = e / Q, q = e - row * Q;
-            float4 v;
-            if (q < QH)
-                v = *reinterpret_cast<const float4*>(a.fl + (size_t)(base + a.idx[p * KN + row]) * a.ldl + 4 * q);
-            else
-                v = *reinterpret_cast<const float4*>(a.f + (size_t)(p * KN + row) * a.ld + 4 * (q - QH));
-            float* dst = A + row * PA + 4 * q;
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-            if (Ab) {
-                float* db = Ab + row * PA + 4 * q;
-                db[0] = round_bf16(v.x); db[1] = round_bf16(v.y); db[2] = round_bf16(v.z); db[3] = round_bf16(v.w);
-            }
-        }
-    }
-}
-
-// the K x D tile of dF staged in LDS (pitch PA, 8-byte aligned rows) -> global as 16-byte stores: whole rows of df (plain form), or the
-// gathered half -> dfl_rows and the f_xyz half -> df (split form).  A point's rows are contiguous in each destination, so the wave writes
-// one or two dense spans instead of 4-byte columns of sixteen lanes.
-template <int D, int KN, int PA>
-__device__ __forceinline__ void store_tile_rows(const AttTrainArgs& a, int64_t p, const float* S, int lane)
-{
-    constexpr int Q = D / 4, QH = Q / 2, TOT = KN * Q;
-#pragma unroll
-    for (int e0 = 0; e0 < TOT; e0 += 64) {
-        const int e = e0 + lane;
-        if (TOT % 64 == 0 || e < TOT) {
-            const int row = e / Q, q = e - row * Q;
-            const float2 lo = *reinterpret_cast<const float2*>(S + row * PA + 4 * q);
-            const float2 hi = *reinterpret_cast<const float2*>(S + row * PA + 4 * q + 2);
-            float4 v = make_float4(lo.x, lo.y, hi.x, hi.y);
-            float4* dst;
-            if (!a.fl) {
-                dst = reinterpret_cast<float4*>(a.df + (size_t)(p * KN + row) * a.lddf + 4 * q);
-            } else if (q < QH) {
-                dst = reinterpret_cast<float4*>(a.dfl_rows + (size_t)(p * KN + row) * a.ld_rows + 4 * q);
-            } else {
-                dst = reinterpret_cast<float4*>(a.df + (size_t)(p * KN + row) * a.lddf + 4 * (q - QH));
-                if (a.df_accum) {
-                    const float4 o = *dst;
-                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        for (int i = 0; i < NV; ++i) {
+            const int e = 64 * i + lane;
+            if (TOT % 64 == 0 || e < TOT) {
+                const int row = e / Q, q = e - row * Q;
+                float* dst = A + row * PA + 4 * q;
+                dst[0] = v[i].x; dst[1] = v[i].y; dst[2] = v[i].z; dst[3] = v[i].w;
+                if (Ab) {
+                    float* db = Ab + row * PA + 4 * q;
+                    db[0] = round_bf16(v[i].x); db[1] = round_bf16(v[i].y); db[2] = round_bf16(v[i].z); db[3] = round_bf16(v[i].w);
                 }
             }
-            *dst = v;
         }
     }
-}
+};
+
+// The K x D tile of dF staged in LDS (pitch PA, 8-byte aligned rows) -> global as 16-byte stores: whole rows of df (plain form), or the
+// gathered half -> dfl_rows and the f_xyz half -> df (split form).  A point's rows are contiguous in each destination, so the wave writes
+// one or two dense spans instead of 4-byte columns of sixteen lanes.  take() reads the staged tile into registers (the LDS tile is then
+// free for the next point), put() issues the stores.
+template <int D, int KN, int PA>
+struct RowStore {
+    static constexpr int Q = D / 4, QH = Q / 2, TOT = KN * Q, NV = (TOT + 63) / 64;
+    float4 v[NV];
+    __device__ __forceinline__ void take(const float* S, int lane)
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = 64 * i + lane;
+            if (TOT % 64 == 0 || e < TOT) {
+                const int row = e / Q, q = e - row * Q;
+                const float2 lo = *reinterpret_cast<const float2*>(S + row * PA + 4 * q);
+                const float2 hi = *reinterpret_cast<const float2*>(S + row * PA + 4 * q + 2);
+                v[i] = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+    }
+    __device__ __forceinline__ void put(const AttTrainArgs& a, int64_t p, int lane) const
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = 64 * i + lane;
+            if (TOT % 64 == 0 || e < TOT) {
+                const int row = e / Q, q = e - row * Q;
+                float4 o = v[i];
+                float4* dst;
+                if (!a.fl) {
+                    dst = reinterpret_cast<float4*>(a.df + (size_t)(p * KN + row) * a.lddf + 4 * q);
+                } else if (q < QH) {
+                    dst = reinterpret_cast<float4*>(a.dfl_rows + (size_t)(p * KN + row) * a.ld_rows + 4 * q);
+                } else {
+                    dst = reinterpret_cast<float4*>(a.df + (size_t)(p * KN + row) * a.lddf + 4 * (q - QH));
+                    if (a.df_accum) {
+                        const float4 h = *dst;
+                        o.x += h.x; o.y += h.y; o.z += h.z; o.w += h.w;
+                    }
+                }
+                *dst = o;
+            }
+        }
+    }
+};
 
 // scores of column tile ct: C[k][c] = sum_j X[k][j] W[j][16 ct + c]   (X = tile with pitch PA, W in LDS with pitch PW)
 template <int D>
@@ -181,10 +215,15 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_fwd_kernel(AttTrainArgs 
     float* Ab = a.bf16 ? A + KN * PA : nullptr;
     stage_weights<D, WAVES * 64>(a.w, W, nullptr, a.bf16 != 0);
     __syncthreads();
-    for (int64_t p = (int64_t)blockIdx.x * WAVES + wave; p < a.R; p += (int64_t)gridDim.x * WAVES) {
-        if (a.fl) load_tile_split<D, KN>(a, p, A, Ab, lane);
-        else load_tile<D, KN>(a.f, a.ld, p, A, Ab, lane);
+    PointWalk w((int)(blockIdx.x * WAVES + wave), (int)(gridDim.x * WAVES), (int)a.n_q);
+    TileRegs<D, KN> regs;
+    if (w.p < a.R) regs.fetch(a, w, lane);
+    for (; w.p < a.R; w = w.next()) {
+        const int64_t p = w.p;
+        regs.template commit<PA>(A, Ab, lane);
         wave_lds_sync();
+        const PointWalk wn = w.next();
+        if (wn.p < a.R) regs.fetch(a, wn, lane);  // the next point's tile travels while this one is worked on
         const float* X = a.bf16 ? Ab : A;
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
@@ -228,10 +267,29 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) dw[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int64_t p = (int64_t)blockIdx.x * WAVES + wave; p < a.R; p += (int64_t)gridDim.x * WAVES) {
-        if (a.fl) load_tile_split<D, KN>(a, p, A, Ab, lane);
-        else load_tile<D, KN>(a.f, a.ld, p, A, Ab, lane);
-        wave_lds_sync();
+    // per point: [tile and dagg of the NEXT point requested] -> scores / softmax / dS -> the two products, dF staged in the value tile ->
+    // staged rows to registers -> next tile committed -> stores issued.  Loads and stores so have a whole point's work to complete in.
+    PointWalk w((int)(blockIdx.x * WAVES + wave), (int)(gridDim.x * WAVES), (int)a.n_q);
+    TileRegs<D, KN> regs;
+    float gnext[NT];
+    if (w.p < a.R) {
+        regs.fetch(a, w, lane);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) gnext[ct] = a.dagg[(size_t)w.p * D + ct * 16 + c16];
+        regs.template commit<PA>(A, Ab, lane);
+    }
+    wave_lds_sync();
+    for (; w.p < a.R; w = w.next()) {
+        const int64_t p = w.p;
+        const PointWalk wn = w.next();
+        float gcur[NT];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) gcur[ct] = gnext[ct];
+        if (wn.p < a.R) {
+            regs.fetch(a, wn, lane);
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) gnext[ct] = a.dagg[(size_t)wn.p * D + ct * 16 + c16];
+        }
         const float* X = a.bf16 ? Ab : A;
         f32x4 dfd[NT];  // direct term p * g of every column tile (seeds the second product)
 #pragma unroll
@@ -250,7 +308,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
             ssum = xor_sum(ssum);
             num = xor_sum(num);
             const float inv = 1.f / ssum, agg = num * inv;
-            const float gch = a.dagg[(size_t)p * D + ct * 16 + c16];
+            const float gch = gcur[ct];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pr = e[r] * inv;
@@ -311,10 +369,14 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
                 }
             }
         }
+        wave_lds_sync();
+        RowStore<D, KN, PA> out;
         if (a.vec_store) {
+            out.take(A, lane);
             wave_lds_sync();
-            store_tile_rows<D, KN, PA>(a, p, A, lane);
         }
+        if (wn.p < a.R) regs.template commit<PA>(A, Ab, lane);
+        if (a.vec_store) out.put(a, p, lane);
         wave_lds_sync();
     }
     // ---- the workgroup's dWfc partial: waves add up through LDS (fixed order), one plain store per element ----
@@ -373,24 +435,17 @@ __device__ __forceinline__ void stage_weights_bf16(const float* __restrict__ w, 
     }
 }
 
-// the K x D tile of point p -> A (fp32, pitch PA) and Xb (bfloat16, pitch PB); plain or split-source rows
+// a fetched tile -> A (fp32, pitch PA) and Xb (bfloat16, pitch PB)
 template <int D, int KN>
-__device__ __forceinline__ void load_tile_bf16(const AttTrainArgs& a, int64_t p, float* A, unsigned short* Xb, int lane)
+__device__ __forceinline__ void commit_tile_bf16(const TileRegs<D, KN>& t, float* A, unsigned short* Xb, int lane)
 {
-    constexpr int PA = AttBf16Geom<D>::PA, PB = AttBf16Geom<D>::PB, Q = D / 4, QH = Q / 2, TOT = KN * Q;
-    const int64_t base = a.fl ? (p / a.n_q) * a.n_src : 0;
+    constexpr int PA = AttBf16Geom<D>::PA, PB = AttBf16Geom<D>::PB, Q = D / 4, TOT = KN * Q;
 #pragma unroll
-    for (int e0 = 0; e0 < TOT; e0 += 64) {
-        const int e = e0 + lane;
+    for (int i = 0; i < TileRegs<D, KN>::NV; ++i) {
+        const int e = 64 * i + lane;
         if (TOT % 64 == 0 || e < TOT) {
             const int row = e / Q, q = e - row * Q;
-            float4 v;
-            if (!a.fl)
-                v = *reinterpret_cast<const float4*>(a.f + (size_t)(p * KN + row) * a.ld + 4 * q);
-            else if (q < QH)
-                v = *reinterpret_cast<const float4*>(a.fl + (size_t)(base + a.idx[p * KN + row]) * a.ldl + 4 * q);
-            else
-                v = *reinterpret_cast<const float4*>(a.f + (size_t)(p * KN + row) * a.ld + 4 * (q - QH));
+            const float4 v = t.v[i];
             float* dst = A + row * PA + 4 * q;
             dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
             uint2 pk;
@@ -426,9 +481,15 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_fwd_bf16_kernel(AttTrain
     unsigned short* Xb = reinterpret_cast<unsigned short*>(A + KN * PA);
     stage_weights_bf16<D, WAVES * 64>(a.w, nullptr, WTb);
     __syncthreads();
-    for (int64_t p = (int64_t)blockIdx.x * WAVES + wave; p < a.R; p += (int64_t)gridDim.x * WAVES) {
-        load_tile_bf16<D, KN>(a, p, A, Xb, lane);
+    PointWalk w((int)(blockIdx.x * WAVES + wave), (int)(gridDim.x * WAVES), (int)a.n_q);
+    TileRegs<D, KN> regs;
+    if (w.p < a.R) regs.fetch(a, w, lane);
+    for (; w.p < a.R; w = w.next()) {
+        const int64_t p = w.p;
+        commit_tile_bf16<D, KN>(regs, A, Xb, lane);
         wave_lds_sync();
+        const PointWalk wn = w.next();
+        if (wn.p < a.R) regs.fetch(a, wn, lane);  // the next point's tile travels while this one is worked on
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
             const f32x4 s = tile_mma_bf16<D>(Xb, WTb, ct, lane, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -471,9 +532,29 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) dw[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int64_t p = (int64_t)blockIdx.x * WAVES + wave; p < a.R; p += (int64_t)gridDim.x * WAVES) {
-        load_tile_bf16<D, KN>(a, p, A, Xb, lane);
-        wave_lds_sync();
+    // per point: [tile and dagg of the NEXT point requested] -> scores / softmax / dS -> the two products, dF staged in the value tile ->
+    // staged rows to registers -> next tile committed -> stores issued.  Loads and stores so have a whole point's work to complete in.
+    PointWalk w((int)(blockIdx.x * WAVES + wave), (int)(gridDim.x * WAVES), (int)a.n_q);
+    TileRegs<D, KN> regs;
+    float gnext[NT];
+    if (w.p < a.R) {
+        regs.fetch(a, w, lane);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) gnext[ct] = a.dagg[(size_t)w.p * D + ct * 16 + c16];
+        commit_tile_bf16<D, KN>(regs, A, Xb, lane);
+    }
+    wave_lds_sync();
+    for (; w.p < a.R; w = w.next()) {
+        const int64_t p = w.p;
+        const PointWalk wn = w.next();
+        float gcur[NT];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) gcur[ct] = gnext[ct];
+        if (wn.p < a.R) {
+            regs.fetch(a, wn, lane);
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) gnext[ct] = a.dagg[(size_t)wn.p * D + ct * 16 + c16];
+        }
         f32x4 dfd[NT];  // direct term p * g of every column tile (seeds the second product)
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
@@ -491,7 +572,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
             ssum = xor_sum(ssum);
             num = xor_sum(num);
             const float inv = 1.f / ssum, agg = num * inv;
-            const float gch = a.dagg[(size_t)p * D + ct * 16 + c16];
+            const float gch = gcur[ct];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pr = e[r] * inv;
@@ -546,10 +627,14 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
 #pragma unroll
                 for (int tj = 0; tj < NT; ++tj) dw[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fa[ti], db[tj], dw[ti][tj], 0, 0, 0);
         }
+        wave_lds_sync();
+        RowStore<D, KN, PA> out;
         if (a.vec_store) {
+            out.take(A, lane);
             wave_lds_sync();
-            store_tile_rows<D, KN, PA>(a, p, A, lane);
         }
+        if (wn.p < a.R) commit_tile_bf16<D, KN>(regs, A, Xb, lane);
+        if (a.vec_store) out.put(a, p, lane);
         wave_lds_sync();
     }
     // ---- the workgroup's dWfc partial: waves add up through LDS (fixed order), one plain store per element ----
