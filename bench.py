@@ -404,7 +404,7 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
     ctx = runtime.default_context(local_rank)
     params = weights.init_params(cfg, seed=2)
     tr = Trainer(cfg, params=params, device=local_rank, ctx=ctx, keep_prob=0.5, sync_bn=dist is not None and not args.local_bn,
-                 mlp_dtype="bf16" if args.bf16_mlp else "fp32", fused_att=not args.no_fused_att, fused_locse=not args.no_fused_locse, fused_convbn=args.fused_convbn,
+                 mlp_dtype="bf16" if args.bf16_mlp else "fp32", fused_att=not args.no_fused_att, fused_locse=not args.no_fused_locse, fused_convbn=True if args.fused_convbn else (False if args.no_fused_convbn else None),
                  engine=args.train_engine, deterministic=not args.atomic_scatter)
     d_xyz, d_feats, d_lab = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
     pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
@@ -511,7 +511,8 @@ def main():
                          "PCIe-inclusive rate DESIGN.md quotes next to the headline (which keeps inputs resident in HBM)")
     ap.add_argument("--bf16-mlp", action="store_true", help="train mode: shared-MLP GEMMs on bf16 operands with fp32 accumulate (BASELINE configs[2])")
     ap.add_argument("--no-fused-att", action="store_true", help="train mode: the op-by-op attentive pooling at every level (A/B of csrc/attpool_train.hip)")
-    ap.add_argument("--fused-convbn", action="store_true", help="train mode: LFA mlp2 in the recompute form (csrc/smallconv_train.hip; measured slower, off by default)")
+    ap.add_argument("--fused-convbn", action="store_true", help="train mode: LFA mlp2 in the recompute form (csrc/smallconv_train.hip, convbn_rows.hip); the native engine's default")
+    ap.add_argument("--no-fused-convbn", action="store_true", help="train mode: LFA mlp2 op by op (A/B switch)")
     ap.add_argument("--no-fused-locse", action="store_true", help="train mode: the op-by-op LocSE branch (A/B of csrc/locse_train.hip)")
     ap.add_argument("--train-engine", choices=["native", "python"], default="native",
                     help="train mode: native = ps_randla_train_step, the whole step behind one C-ABI call (csrc/trainer.hip); python = the host-side "

@@ -341,6 +341,18 @@ int ps_op_conv_bn_train_bwd_sums(ps_context* ctx, const float* x, int64_t ldx, c
 int ps_op_conv_bn_train_bwd_apply(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t C,
                                   const float* mean, const float* invstd, const float* scale, const float* beta, const float* m1,
                                   const float* m2, const float* dz, int64_t lddz, int accumulate, float* dx, int64_t lddx);
+/* The two backward passes in the form the C++ training step uses: the weight gradient comes out of the apply pass as dW = x^T dy, db = sum dy
+ * (dy = gamma invstd (g - S1/M - xh S2/M), the gradient of the pre-BatchNorm product, which never reaches memory), so the sums pass only
+ * carries S1 and S2.  C = 8 runs one THREAD per row (csrc/convbn_rows.hip: 32-byte rows in registers, every pass at the HBM rate).
+ *   _bwd_sums2   : s12 = S1 [C] | S2 [C] (| C floats of scratch: the buffer holds 3 C floats); dgamma = S2, dbeta = S1; SyncBN: all-reduce 2 C
+ *   _bwd_apply_w : dx (+)= dy . w^T, dw [C, C] and db [C] overwritten; s12 = the sums of all ranks, inv_rows = 1 / rows of all ranks */
+int ps_op_conv_bn_train_bwd_sums2(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t C,
+                                  const float* mean, const float* invstd, const float* scale, const float* beta, const float* dz,
+                                  int64_t lddz, float* s12);
+int ps_op_conv_bn_train_bwd_apply_w(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t C,
+                                    const float* mean, const float* invstd, const float* scale, const float* beta, const float* s12,
+                                    float inv_rows, const float* dz, int64_t lddz, int accumulate, float* dx, int64_t lddx, float* dw,
+                                    float* db);
 /* ---- deterministic scatter-adds (csrc/invidx.hip).  The backward of tf.batch_gather (gather_neighbour, nearest_interpolation,
  * random_sample: RandLANet.py:345-386) adds gradient rows onto the rows they were gathered from; with float atomics the order of the
  * additions changes from run to run.  ps_op_inverse_index inverts a gather table idx i32[B, rows_per_cloud] (values in [0, N)):
@@ -420,6 +432,9 @@ typedef struct {
     int32_t ignored_label_inds[8];
     int32_t deterministic;          /* every scatter-add of the backward pass as a fixed-order gather-reduction over an inverse index built
                                      * once per level and step (csrc/invidx.hip): two runs of a step give bit-identical gradients */
+    int32_t fused_convbn;           /* LFA mlp2 (conv h -> h + BatchNorm + LeakyReLU on the [N*K, h] rows, RandLANet.py:331) with the pre-BatchNorm
+                                     * product recomputed instead of stored (h <= 64; in the bf16-MLP mode only h = 8, whose product has no
+                                     * matrix-pipe shape and stays fp32 there) */
 } ps_train_options;
 /* In-place sum over the ranks of `count` elements at device pointer `buf` (dtype 0: float32, 1: float64), ordered on `hip_stream`
  * (the context's stream).  Returns 0 on success. */

@@ -50,6 +50,7 @@ class PsTrainOptions(ctypes.Structure):
         ("num_ignored", ctypes.c_int32),
         ("ignored_label_inds", ctypes.c_int32 * 8),
         ("deterministic", ctypes.c_int32),
+        ("fused_convbn", ctypes.c_int32),
     ]
 
 
@@ -118,6 +119,10 @@ PROTOTYPES = {
                                                     ctypes.c_int64, c_vp]),
     "ps_op_conv_bn_train_bwd_apply": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                                      c_vp, c_vp, ctypes.c_int64, ctypes.c_int, c_vp, ctypes.c_int64]),
+    "ps_op_conv_bn_train_bwd_sums2": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                     ctypes.c_int64, c_vp]),
+    "ps_op_conv_bn_train_bwd_apply_w": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                       ctypes.c_float, c_vp, ctypes.c_int64, ctypes.c_int, c_vp, ctypes.c_int64, c_vp, c_vp]),
     "ps_op_locse_train_supported": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64]),
     "ps_op_locse_train_sums": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, c_vp]),
     "ps_op_locse_train_apply": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, c_vp, c_vp,

@@ -27,11 +27,13 @@ struct ScArgs {
     const float* b;      // [C]
     const float* mean; const float* invstd; const float* scale; const float* beta;  // [C]; scale = gamma invstd
     const float* m1; const float* m2;  // [C] S1 / M, S2 / M (backward apply)
+    float mscale;        // m1 / m2 hold the raw sums S1 / S2 of all ranks: multiplied by this (1 / rows of all ranks); 1 when they are means
     const float* dz;     // [R, C] (lddz)
     float* out;          // apply: z rows (ldo);  backward apply: dx rows (ldo)
     void* part;          // per-workgroup partial sums
     int64_t R;
     int ldx, lddz, ldo, accum;
+    int vec;             // dz / out rows are 16-byte aligned with pitches % 4 == 0: tiles travel as float4 through LDS
 };
 
 template <int C>
@@ -55,27 +57,71 @@ __device__ __forceinline__ void sc_stage_w(const float* __restrict__ w, float* W
     }
 }
 
-// 16 rows of x starting at row r0 -> LDS tile (pitch PA); rows past R and padding columns are zero
+// 16 rows of a [R, C] tensor starting at row r0 as registers (lane e of pass i: float4 q of row (64 i + e) / (C/4); rows past R are zero).
+// fetch = global -> registers, issued one tile AHEAD of its use (a wave works on one tile at a time: nothing else covers the latency),
+// commit = registers -> LDS tile (pitch PA; padding columns zeroed), take = LDS tile -> registers (8-byte aligned rows), put = 16-byte stores.
 template <int C>
-__device__ __forceinline__ void sc_load_tile(const float* __restrict__ x, int ldx, int64_t r0, int64_t R, float* A, int lane)
-{
+struct ScTile {
     using G = ScGeom<C>;
-    constexpr int Q = C / 4, TOT = 16 * Q;
+    static constexpr int Q = C / 4, TOT = 16 * Q, NV = (TOT + 63) / 64;
+    float4 v[NV];
+    __device__ __forceinline__ void fetch(const float* __restrict__ x, int ldx, int64_t r0, int64_t R, int lane)
+    {
 #pragma unroll
-    for (int e0 = 0; e0 < TOT; e0 += 64) {
-        const int e = e0 + lane;
-        if (TOT % 64 == 0 || e < TOT) {
-            const int row = e / Q, q = e - row * Q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r0 + row < R) v = *reinterpret_cast<const float4*>(x + (size_t)(r0 + row) * ldx + 4 * q);
-            float* dst = A + row * G::PA + 4 * q;
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        for (int i = 0; i < NV; ++i) {
+            const int e = 64 * i + lane;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (TOT % 64 == 0 || e < TOT) {
+                const int row = e / Q, q = e - row * Q;
+                if (r0 + row < R) v[i] = *reinterpret_cast<const float4*>(x + (size_t)(r0 + row) * ldx + 4 * q);
+            }
         }
     }
-    if constexpr (C < 16) {  // padding columns (read as A operands of the x^T products)
-        for (int e = lane; e < 16 * (16 - C); e += 64) A[(e / (16 - C)) * G::PA + C + e % (16 - C)] = 0.f;
+    __device__ __forceinline__ void commit(float* A, int lane) const
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = 64 * i + lane;
+            if (TOT % 64 == 0 || e < TOT) {
+                const int row = e / Q, q = e - row * Q;
+                float* dst = A + row * G::PA + 4 * q;
+                dst[0] = v[i].x; dst[1] = v[i].y; dst[2] = v[i].z; dst[3] = v[i].w;
+            }
+        }
+        if constexpr (C < 16) {  // padding columns (read as A operands of the x^T products)
+            for (int e = lane; e < 16 * (16 - C); e += 64) A[(e / (16 - C)) * G::PA + C + e % (16 - C)] = 0.f;
+        }
     }
-}
+    __device__ __forceinline__ void take(const float* S, int lane)
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = 64 * i + lane;
+            if (TOT % 64 == 0 || e < TOT) {
+                const int row = e / Q, q = e - row * Q;
+                const float2 lo = *reinterpret_cast<const float2*>(S + row * G::PA + 4 * q);
+                const float2 hi = *reinterpret_cast<const float2*>(S + row * G::PA + 4 * q + 2);
+                v[i] = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+    }
+    __device__ __forceinline__ void add(const ScTile& o)
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { v[i].x += o.v[i].x; v[i].y += o.v[i].y; v[i].z += o.v[i].z; v[i].w += o.v[i].w; }
+    }
+    __device__ __forceinline__ void put(float* __restrict__ out, int ldo, int64_t r0, int64_t R, int lane) const
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = 64 * i + lane;
+            if (TOT % 64 == 0 || e < TOT) {
+                const int row = e / Q, q = e - row * Q;
+                if (r0 + row < R) *reinterpret_cast<float4*>(out + (size_t)(r0 + row) * ldo + 4 * q) = v[i];
+            }
+        }
+    }
+};
 
 // column tile ct of y = X . W: lane (c16, g) gets rows 4 g + r (r = 0..3) of column 16 ct + c16
 template <int C>
@@ -121,11 +167,15 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_sums_kernel(ScArgs a)
     double sy[NT], sq[NT], sx[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) { sy[t] = 0.; sq[t] = 0.; sx[t] = 0.; }
-    const int64_t tiles = (a.R + 15) / 16;
-    for (int64_t tl = (int64_t)blockIdx.x * kScWaves + wave; tl < tiles; tl += (int64_t)gridDim.x * kScWaves) {
+    const int64_t tiles = (a.R + 15) / 16, tstride = (int64_t)gridDim.x * kScWaves;
+    int64_t tl = (int64_t)blockIdx.x * kScWaves + wave;
+    ScTile<C> xr;
+    if (tl < tiles) xr.fetch(a.x, a.ldx, tl * 16, a.R, lane);
+    for (; tl < tiles; tl += tstride) {
         const int64_t r0 = tl * 16;
-        sc_load_tile<C>(a.x, a.ldx, r0, a.R, A, lane);
+        xr.commit(A, lane);
         wave_lds_sync();
+        if (tl + tstride < tiles) xr.fetch(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
             const f32x4 y = sc_y_tile<C>(A, W, ct, lane);
@@ -178,21 +228,50 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_apply_kernel(ScArgs a)
     sc_stage_w<C, kScWaves * 64>(a.w, W, nullptr);
     __syncthreads();
     const ScCols<NT> bias(a.b, c16, C), mu(a.mean, c16, C), sc(a.scale, c16, C), be(a.beta, c16, C);
-    const int64_t tiles = (a.R + 15) / 16;
-    for (int64_t tl = (int64_t)blockIdx.x * kScWaves + wave; tl < tiles; tl += (int64_t)gridDim.x * kScWaves) {
+    const int64_t tiles = (a.R + 15) / 16, tstride = (int64_t)gridDim.x * kScWaves;
+    int64_t tl = (int64_t)blockIdx.x * kScWaves + wave;
+    ScTile<C> xr;
+    if (tl < tiles) {
+        xr.fetch(a.x, a.ldx, tl * 16, a.R, lane);
+        xr.commit(A, lane);
+    }
+    wave_lds_sync();
+    for (; tl < tiles; tl += tstride) {
         const int64_t r0 = tl * 16;
-        sc_load_tile<C>(a.x, a.ldx, r0, a.R, A, lane);
-        wave_lds_sync();
+        const bool more = tl + tstride < tiles;
+        if (more) xr.fetch(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
+        f32x4 z[NT];
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
             const f32x4 y = sc_y_tile<C>(A, W, ct, lane);
-            const int col = ct * 16 + c16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float z = __builtin_fmaf((y[r] + bias.v[ct]) - mu.v[ct], sc.v[ct], be.v[ct]);
-                z = z < 0.f ? 0.2f * z : z;
-                if (col < C && r0 + 4 * g + r < a.R) a.out[(size_t)(r0 + 4 * g + r) * a.ldo + col] = z;
+                const float t = __builtin_fmaf((y[r] + bias.v[ct]) - mu.v[ct], sc.v[ct], be.v[ct]);
+                z[ct][r] = t < 0.f ? 0.2f * t : t;
             }
+        }
+        if (a.vec) {  // z staged in the (now dead) x tile, 16-byte stores
+            wave_lds_sync();
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[(4 * g + r) * G::PA + ct * 16 + c16] = z[ct][r];
+            wave_lds_sync();
+            ScTile<C> o;
+            o.take(A, lane);
+            wave_lds_sync();
+            if (more) xr.commit(A, lane);
+            o.put(a.out, a.ldo, r0, a.R, lane);
+        } else {
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                const int col = ct * 16 + c16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col < C && r0 + 4 * g + r < a.R) a.out[(size_t)(r0 + 4 * g + r) * a.ldo + col] = z[ct][r];
+            }
+            wave_lds_sync();
+            if (more) xr.commit(A, lane);
         }
         wave_lds_sync();
     }
@@ -200,11 +279,12 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_apply_kernel(ScArgs a)
 
 // ---- backward: sums --------------------------------------------------------------------------------------------------------------
 // partial layout per workgroup (floats): S1[CP] | S2[CP] | XS[CP] | A[CP][CP] | G[CP][CP]
-template <int C>
+// FULL = false: only S1 | S2 | XS (the weight gradient then comes out of sc_bwd_apply_kernel<C, true> as x^T dy)
+template <int C, bool FULL>
 __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_sums_kernel(ScArgs a)
 {
     using G = ScGeom<C>;
-    constexpr int NT = G::NT, CP = G::CP, NV = 3 * CP + 2 * CP * CP;
+    constexpr int NT = G::NT, CP = G::CP, NV = FULL ? 3 * CP + 2 * CP * CP : 3 * CP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
@@ -222,11 +302,24 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_sums_kernel(ScArgs a)
 #pragma unroll
         for (int u = 0; u < NT; ++u) { aw[t][u] = f32x4{0.f, 0.f, 0.f, 0.f}; gw[t][u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
-    const int64_t tiles = (a.R + 15) / 16;
-    for (int64_t tl = (int64_t)blockIdx.x * kScWaves + wave; tl < tiles; tl += (int64_t)gridDim.x * kScWaves) {
+    // vec: the dz tile travels like the x tile (16-byte loads one tile ahead, through LDS tile T1) instead of as 4-byte loads in the
+    // accumulator layout
+    const int64_t tiles = (a.R + 15) / 16, tstride = (int64_t)gridDim.x * kScWaves;
+    int64_t tl = (int64_t)blockIdx.x * kScWaves + wave;
+    ScTile<C> xr, zr;
+    if (tl < tiles) {
+        xr.fetch(a.x, a.ldx, tl * 16, a.R, lane);
+        if (a.vec) zr.fetch(a.dz, a.lddz, tl * 16, a.R, lane);
+    }
+    for (; tl < tiles; tl += tstride) {
         const int64_t r0 = tl * 16;
-        sc_load_tile<C>(a.x, a.ldx, r0, a.R, A, lane);
+        xr.commit(A, lane);
+        if (a.vec) zr.commit(T1, lane);
         wave_lds_sync();
+        if (tl + tstride < tiles) {
+            xr.fetch(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
+            if (a.vec) zr.fetch(a.dz, a.lddz, (tl + tstride) * 16, a.R, lane);
+        }
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
             const f32x4 y = sc_y_tile<C>(A, W, ct, lane);
@@ -236,19 +329,21 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_sums_kernel(ScArgs a)
                 const bool live = col < C && r0 + 4 * g + r < a.R;
                 const float yc = (y[r] + bias.v[ct]) - mu.v[ct];
                 const float xh = live ? yc * is.v[ct] : 0.f;
-                float gv = live ? a.dz[(size_t)(r0 + 4 * g + r) * a.lddz + col] : 0.f;
+                float gv = !live ? 0.f : a.vec ? T1[(4 * g + r) * G::PA + col] : a.dz[(size_t)(r0 + 4 * g + r) * a.lddz + col];
                 if (__builtin_fmaf(yc, sc.v[ct], be.v[ct]) < 0.f) gv *= 0.2f;
                 s1[ct] += gv;
                 s2[ct] = __builtin_fmaf(gv, xh, s2[ct]);
                 xs[ct] += xh;
-                T1[(4 * g + r) * G::PA + col] = gv;
-                T2[(4 * g + r) * G::PA + col] = xh;
+                if (FULL) {
+                    T1[(4 * g + r) * G::PA + col] = gv;
+                    T2[(4 * g + r) * G::PA + col] = xh;
+                }
             }
         }
         wave_lds_sync();
         // A += x^T g, G += x^T xh: contraction over the tile's 16 rows (four MFMA steps per tile pair)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; FULL && s < 4; ++s) {
             float fa[NT], f1[NT], f2[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -280,7 +375,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_sums_kernel(ScArgs a)
         const float v1 = gsum(s1[t]), v2 = gsum(s2[t]), v3 = gsum(xs[t]);
         if (g == 0) { r[t * 16 + c16] = v1; r[CP + t * 16 + c16] = v2; r[2 * CP + t * 16 + c16] = v3; }
 #pragma unroll
-        for (int u = 0; u < NT; ++u)
+        for (int u = 0; FULL && u < NT; ++u)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 r[3 * CP + (t * 16 + 4 * g + q) * CP + u * 16 + c16] = aw[t][u][q];
@@ -297,7 +392,8 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_sums_kernel(ScArgs a)
 }
 
 // ---- backward: input gradient ----------------------------------------------------------------------------------------------------
-template <int C>
+// WG = true: also the weight / bias gradient dW = x^T dy, db = sum dy as per-workgroup partials (dW[CP][CP] | db[CP]) in a.part
+template <int C, bool WG>
 __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
 {
     using G = ScGeom<C>;
@@ -310,13 +406,41 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
     float* T1 = A + 16 * G::PA;
     sc_stage_w<C, kScWaves * 64>(a.w, W, WT);
     __syncthreads();
-    const ScCols<NT> bias(a.b, c16, C), mu(a.mean, c16, C), is(a.invstd, c16, C), sc(a.scale, c16, C), be(a.beta, c16, C), m1(a.m1, c16, C),
-        m2(a.m2, c16, C);
-    const int64_t tiles = (a.R + 15) / 16;
-    for (int64_t tl = (int64_t)blockIdx.x * kScWaves + wave; tl < tiles; tl += (int64_t)gridDim.x * kScWaves) {
+    const ScCols<NT> bias(a.b, c16, C), mu(a.mean, c16, C), is(a.invstd, c16, C), sc(a.scale, c16, C), be(a.beta, c16, C);
+    ScCols<NT> m1(a.m1, c16, C), m2(a.m2, c16, C);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { m1.v[t] *= a.mscale; m2.v[t] *= a.mscale; }
+    f32x4 dw[NT][NT];
+    float dbs[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        dbs[t] = 0.f;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) dw[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // vec: x, dz and (accumulate) the old dx rows of the NEXT tile are requested before this tile's work starts; the dz tile sits in T1 and is
+    // replaced in place by dy; dx is staged in the x tile once the weight-gradient product has read it, and leaves as 16-byte stores
+    const int64_t tiles = (a.R + 15) / 16, tstride = (int64_t)gridDim.x * kScWaves;
+    int64_t tl = (int64_t)blockIdx.x * kScWaves + wave;
+    const bool vec = a.vec != 0, acc_old = vec && a.accum;
+    ScTile<C> xr, zr, old_next;
+    if (tl < tiles) {
+        xr.fetch(a.x, a.ldx, tl * 16, a.R, lane);
+        if (vec) zr.fetch(a.dz, a.lddz, tl * 16, a.R, lane);
+        if (acc_old) old_next.fetch(a.out, a.ldo, tl * 16, a.R, lane);
+        xr.commit(A, lane);
+        if (vec) zr.commit(T1, lane);
+    }
+    wave_lds_sync();
+    for (; tl < tiles; tl += tstride) {
         const int64_t r0 = tl * 16;
-        sc_load_tile<C>(a.x, a.ldx, r0, a.R, A, lane);
-        wave_lds_sync();
+        const bool more = tl + tstride < tiles;
+        ScTile<C> old_cur = old_next;
+        if (more) {
+            xr.fetch(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
+            if (vec) zr.fetch(a.dz, a.lddz, (tl + tstride) * 16, a.R, lane);
+            if (acc_old) old_next.fetch(a.out, a.ldo, (tl + tstride) * 16, a.R, lane);
+        }
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
             const f32x4 y = sc_y_tile<C>(A, W, ct, lane);
@@ -326,12 +450,30 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
                 const bool live = col < C && r0 + 4 * g + r < a.R;
                 const float yc = (y[r] + bias.v[ct]) - mu.v[ct];
                 const float xh = yc * is.v[ct];
-                float gv = live ? a.dz[(size_t)(r0 + 4 * g + r) * a.lddz + col] : 0.f;
+                float gv = !live ? 0.f : vec ? T1[(4 * g + r) * G::PA + col] : a.dz[(size_t)(r0 + 4 * g + r) * a.lddz + col];
                 if (__builtin_fmaf(yc, sc.v[ct], be.v[ct]) < 0.f) gv *= 0.2f;
-                T1[(4 * g + r) * G::PA + col] = live ? sc.v[ct] * (gv - m1.v[ct] - xh * m2.v[ct]) : 0.f;
+                const float dyv = live ? sc.v[ct] * (gv - m1.v[ct] - xh * m2.v[ct]) : 0.f;
+                T1[(4 * g + r) * G::PA + col] = dyv;
+                if (WG) dbs[ct] += dyv;
             }
         }
         wave_lds_sync();
+        if (WG) {  // dW += x^T dy: contraction over the tile's 16 rows
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float fa[NT], fb[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    fa[t] = A[(4 * s + g) * G::PA + t * 16 + c16];
+                    fb[t] = T1[(4 * s + g) * G::PA + t * 16 + c16];
+                }
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj) dw[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ti], fb[tj], dw[ti][tj], 0, 0, 0);
+            }
+        }
+        if (vec) wave_lds_sync();  // the x tile is dead from here on: it stages dx
         // dx = dy . W^T
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) {
@@ -341,38 +483,85 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
 #pragma unroll
             for (int s = 0; s < CP / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[4 * s], wb[4 * s * G::PW], acc, 0, 0, 0);
             const int col = tj * 16 + c16;
+            if (vec) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (col < C && r0 + 4 * g + r < a.R) {
-                    float* dst = a.out + (size_t)(r0 + 4 * g + r) * a.ldo + col;
-                    *dst = a.accum ? *dst + acc[r] : acc[r];
-                }
+                for (int r = 0; r < 4; ++r) A[(4 * g + r) * G::PA + col] = acc[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col < C && r0 + 4 * g + r < a.R) {
+                        float* dst = a.out + (size_t)(r0 + 4 * g + r) * a.ldo + col;
+                        *dst = a.accum ? *dst + acc[r] : acc[r];
+                    }
+            }
         }
         wave_lds_sync();
+        ScTile<C> o;
+        if (vec) {
+            o.take(A, lane);
+            if (acc_old) o.add(old_cur);
+            wave_lds_sync();
+        }
+        if (more) {
+            xr.commit(A, lane);
+            if (vec) zr.commit(T1, lane);
+        }
+        if (vec) o.put(a.out, a.ldo, r0, a.R, lane);
+        wave_lds_sync();
+    }
+    if (WG) {  // the workgroup's partial: waves add up through LDS in order (weights and tiles are dead)
+        constexpr int NV = CP * CP + CP;
+        __syncthreads();
+        float* red = smem;
+        float* r = red + (size_t)wave * NV;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float v = dbs[t];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0) r[CP * CP + t * 16 + c16] = v;
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r[(t * 16 + 4 * g + q) * CP + u * 16 + c16] = dw[t][u][q];
+        }
+        __syncthreads();
+        float* dst = static_cast<float*>(a.part) + (size_t)blockIdx.x * NV;
+        for (int i = threadIdx.x; i < NV; i += kScWaves * 64) {
+            float s = 0.f;
+            for (int w = 0; w < kScWaves; ++w) s += red[(size_t)w * NV + i];
+            dst[i] = s;
+        }
     }
 }
 
 static bool sc_ok(int64_t C) { return C == 8 || C == 16 || C == 32 || C == 64; }
 
+// what: 0 forward sums, 1 forward apply, 2 backward sums (S1 | S2 | XS | A | G), 3 backward apply, 4 backward sums (S1 | S2 | XS only),
+//       5 backward apply + weight / bias gradient (result = dW, result2 = db)
 template <int C>
-static int sc_launch(ps_context* c, ScArgs a, int what, void* result)
+static int sc_launch(ps_context* c, ScArgs a, int what, void* result, void* result2 = nullptr)
 {
     using G = ScGeom<C>;
-    constexpr int CP = G::CP, NVB = 3 * CP + 2 * CP * CP;
+    constexpr int CP = G::CP, NVB = 3 * CP + 2 * CP * CP, NVW = CP * CP + CP;
     const size_t wts = sizeof(float) * CP * G::PW, tile = sizeof(float) * 16 * G::PA;
     size_t smem = 0;
     if (what == 0) smem = wts + kScWaves * tile + sizeof(double) * kScWaves * 3 * CP;
     if (what == 1) smem = wts + kScWaves * tile;
     if (what == 2) smem = std::max(wts + kScWaves * 3 * tile, sizeof(float) * (size_t)kScWaves * NVB);
+    if (what == 4) smem = std::max(wts + kScWaves * 3 * tile, sizeof(float) * (size_t)kScWaves * 3 * CP);
     if (what == 3) smem = 2 * wts + kScWaves * 2 * tile;
+    if (what == 5) smem = std::max(2 * wts + kScWaves * 2 * tile, sizeof(float) * (size_t)kScWaves * NVW);
     PS_CHECK(smem <= 160 * 1024, "smallconv_train: %zu bytes of LDS needed", smem);
     const int64_t tiles = (a.R + 15) / 16;
     const int per_cu = std::max(1, std::min(4, (int)(160 * 1024 / smem)));
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((tiles + kScWaves - 1) / kScWaves, 256 * per_cu));
     const void* kern = what == 0 ? reinterpret_cast<const void*>(sc_sums_kernel<C>)
                      : what == 1 ? reinterpret_cast<const void*>(sc_apply_kernel<C>)
-                     : what == 2 ? reinterpret_cast<const void*>(sc_bwd_sums_kernel<C>)
-                                 : reinterpret_cast<const void*>(sc_bwd_apply_kernel<C>);
+                     : what == 2 ? reinterpret_cast<const void*>(sc_bwd_sums_kernel<C, true>)
+                     : what == 3 ? reinterpret_cast<const void*>(sc_bwd_apply_kernel<C, false>)
+                     : what == 4 ? reinterpret_cast<const void*>(sc_bwd_sums_kernel<C, false>)
+                                 : reinterpret_cast<const void*>(sc_bwd_apply_kernel<C, true>);
     if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     if (what == 0) {
         PS_TRY(c->red_ws.reserve(sizeof(double) * (size_t)blocks * 3 * CP + 256));
@@ -382,28 +571,49 @@ static int sc_launch(ps_context* c, ScArgs a, int what, void* result)
                            static_cast<double*>(result));
     } else if (what == 1) {
         hipLaunchKernelGGL(sc_apply_kernel<C>, dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
-    } else if (what == 2) {
-        PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * NVB + 256));
+    } else if (what == 2 || what == 4) {
+        const int nv = what == 2 ? NVB : 3 * CP;
+        PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * nv + 256));
         a.part = c->red_ws.as<void>();
-        hipLaunchKernelGGL(sc_bwd_sums_kernel<C>, dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
-        hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(ceil_div(NVB, 16)), dim3(256), 0, c->stream, static_cast<const float*>(a.part), blocks, NVB,
+        if (what == 2) hipLaunchKernelGGL((sc_bwd_sums_kernel<C, true>), dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
+        else hipLaunchKernelGGL((sc_bwd_sums_kernel<C, false>), dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
+        hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(ceil_div(nv, 16)), dim3(256), 0, c->stream, static_cast<const float*>(a.part), blocks, nv,
                            static_cast<float*>(result));
+    } else if (what == 3) {
+        hipLaunchKernelGGL((sc_bwd_apply_kernel<C, false>), dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
     } else {
-        hipLaunchKernelGGL(sc_bwd_apply_kernel<C>, dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
+        PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * NVW + 256));
+        a.part = c->red_ws.as<void>();
+        hipLaunchKernelGGL((sc_bwd_apply_kernel<C, true>), dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
+        hipLaunchKernelGGL(reduce_partials2_kernel<float>, dim3(ceil_div(NVW, 16)), dim3(256), 0, c->stream, static_cast<const float*>(a.part), blocks, NVW,
+                           CP * CP, static_cast<float*>(result), static_cast<float*>(result2));
     }
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
 
-static int sc_dispatch(ps_context* c, int64_t C, const ScArgs& a, int what, void* result)
+static int sc_dispatch(ps_context* c, int64_t C, const ScArgs& a_in, int what, void* result, void* result2 = nullptr)
 {
+    ScArgs a = a_in;
+    auto al = [](const void* q, int ld) { return !q || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0); };
+    a.vec = al(a.dz, a.lddz) && al(a.out, a.ldo) ? 1 : 0;
     switch (C) {
-        case 8: return sc_launch<8>(c, a, what, result);
-        case 16: return sc_launch<16>(c, a, what, result);
-        case 32: return sc_launch<32>(c, a, what, result);
-        default: return sc_launch<64>(c, a, what, result);
+        case 8: return sc_launch<8>(c, a, what, result, result2);
+        case 16: return sc_launch<16>(c, a, what, result, result2);
+        case 32: return sc_launch<32>(c, a, what, result, result2);
+        default: return sc_launch<64>(c, a, what, result, result2);
     }
 }
+
+// one thread per row at C = 8 (convbn_rows.hip)
+int convbn_rows_sums(ps_context* c, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, double* sums);
+int convbn_rows_apply(ps_context* c, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, const float* mean, const float* scale,
+                      const float* beta, float* out, int64_t ldo);
+int convbn_rows_bwd_sums(ps_context* c, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, const float* mean, const float* invstd,
+                         const float* scale, const float* beta, const float* dz, int64_t lddz, float* s12);
+int convbn_rows_bwd_apply(ps_context* c, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, const float* mean, const float* invstd,
+                          const float* scale, const float* beta, const float* s12, float inv_rows, const float* dz, int64_t lddz, int accumulate, float* dx,
+                          int64_t lddx, float* dw, float* db);
 
 static bool sc_rows_ok(const float* p, int64_t ld, int64_t C) { return p && ld >= C && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -423,6 +633,7 @@ extern "C" int ps_op_conv_bn_train_sums(ps_context* c, const float* x, int64_t l
         return PS_OK;
     }
     Stage st(c, "train_convbn_fwd", 2);
+    if (C == 8) return convbn_rows_sums(c, x, ldx, w, b, R, sums);
     ScArgs a = {};
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R;
     return sc_dispatch(c, C, a, 0, sums);
@@ -436,6 +647,7 @@ extern "C" int ps_op_conv_bn_train_apply(ps_context* c, const float* x, int64_t 
     if (R <= 0) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_convbn_fwd", 1);
+    if (C == 8 && ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) return convbn_rows_apply(c, x, ldx, w, b, R, mean, scale, beta, out, ldo);
     ScArgs a = {};
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.scale = scale; a.beta = beta; a.out = out; a.ldo = (int)ldo;
     return sc_dispatch(c, C, a, 1, nullptr);
@@ -470,6 +682,47 @@ extern "C" int ps_op_conv_bn_train_bwd_apply(ps_context* c, const float* x, int6
     Stage st(c, "train_convbn_bwd", 1);
     ScArgs a = {};
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.invstd = invstd; a.scale = scale; a.beta = beta; a.m1 = m1; a.m2 = m2;
-    a.dz = dz; a.lddz = (int)lddz; a.out = dx; a.ldo = (int)lddx; a.accum = accumulate ? 1 : 0;
+    a.dz = dz; a.lddz = (int)lddz; a.out = dx; a.ldo = (int)lddx; a.accum = accumulate ? 1 : 0; a.mscale = 1.f;
     return sc_dispatch(c, C, a, 3, nullptr);
+}
+
+extern "C" int ps_op_conv_bn_train_bwd_sums2(ps_context* c, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t C,
+                                             const float* mean, const float* invstd, const float* scale, const float* beta, const float* dz, int64_t lddz,
+                                             float* s12)
+{
+    PS_CHECK(c && w && b && mean && invstd && scale && beta && dz && s12 && sc_ok(C) && sc_rows_ok(x, ldx, C) && lddz >= C,
+             "ps_op_conv_bn_train_bwd_sums2: C in {8, 16, 32, 64}, rows 16-byte aligned");
+    PS_HIP(hipSetDevice(c->device));
+    if (R <= 0) {
+        PS_HIP(hipMemsetAsync(s12, 0, sizeof(float) * 3 * C, c->stream));
+        return PS_OK;
+    }
+    Stage st(c, "train_convbn_bwd", 2);
+    if (C == 8 && sc_rows_ok(dz, lddz, C)) return convbn_rows_bwd_sums(c, x, ldx, w, b, R, mean, invstd, scale, beta, dz, lddz, s12);
+    PS_CHECK(C >= 16, "ps_op_conv_bn_train_bwd_sums2: C = 8 needs 16-byte aligned dz rows");
+    ScArgs a = {};
+    a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.invstd = invstd; a.scale = scale; a.beta = beta; a.dz = dz; a.lddz = (int)lddz;
+    return sc_dispatch(c, C, a, 4, s12);
+}
+
+extern "C" int ps_op_conv_bn_train_bwd_apply_w(ps_context* c, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t C,
+                                               const float* mean, const float* invstd, const float* scale, const float* beta, const float* s12,
+                                               float inv_rows, const float* dz, int64_t lddz, int accumulate, float* dx, int64_t lddx, float* dw, float* db)
+{
+    PS_CHECK(c && w && b && mean && invstd && scale && beta && s12 && dz && dx && dw && db && sc_ok(C) && sc_rows_ok(x, ldx, C) && lddz >= C && lddx >= C,
+             "ps_op_conv_bn_train_bwd_apply_w: C in {8, 16, 32, 64}, rows 16-byte aligned");
+    PS_HIP(hipSetDevice(c->device));
+    if (R <= 0) {
+        PS_HIP(hipMemsetAsync(dw, 0, sizeof(float) * C * C, c->stream));
+        PS_HIP(hipMemsetAsync(db, 0, sizeof(float) * C, c->stream));
+        return PS_OK;
+    }
+    Stage st(c, "train_convbn_bwd", 2);
+    if (C == 8 && sc_rows_ok(dz, lddz, C) && sc_rows_ok(dx, lddx, C))
+        return convbn_rows_bwd_apply(c, x, ldx, w, b, R, mean, invstd, scale, beta, s12, inv_rows, dz, lddz, accumulate, dx, lddx, dw, db);
+    PS_CHECK(C >= 16, "ps_op_conv_bn_train_bwd_apply_w: C = 8 needs 16-byte aligned dz / dx rows");
+    ScArgs a = {};
+    a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.invstd = invstd; a.scale = scale; a.beta = beta; a.m1 = s12; a.m2 = s12 + C;
+    a.mscale = inv_rows; a.dz = dz; a.lddz = (int)lddz; a.out = dx; a.ldo = (int)lddx; a.accum = accumulate ? 1 : 0;
+    return sc_dispatch(c, C, a, 5, dw, db);
 }

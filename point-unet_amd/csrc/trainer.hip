@@ -226,12 +226,12 @@ __global__ __launch_bounds__(256) void tr_label_map_kernel(const int32_t* __rest
 // LocSE branch, forward finish: float64 sums of y and y^2 over all rows (of all ranks) -> mean, variance, invstd, scale = gamma invstd,
 // and the moving-statistics update.  out = mean[h] | var[h] | invstd[h] | scale[h]
 __global__ void tr_locse_stats_kernel(const double* __restrict__ sums, double rows, const float* __restrict__ gamma, int h, float eps, float* __restrict__ out,
-                                      float* __restrict__ mov_mean, float* __restrict__ mov_var, float momentum)
+                                      float* __restrict__ mov_mean, float* __restrict__ mov_var, float momentum, int sq_off)
 {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= h) return;
     const double m = sums[c] / rows;
-    double v = sums[h + c] / rows - m * m;  // population variance (tf.nn.moments)
+    double v = sums[sq_off + c] / rows - m * m;  // population variance (tf.nn.moments)
     if (v < 0.0) v = 0.0;
     const float mean = (float)m, var = (float)v;
     const float invstd = rsqrtf(var + eps);
@@ -712,7 +712,7 @@ struct ps_trainer {
         {
             Stage st(c, "train_locse_fwd", 1);
             hipLaunchKernelGGL(tr_locse_stats_kernel, dim3(ceil_div(h, 64)), dim3(64), 0, stream(), s64, (double)R_total, gamma, (int)h, kBnEps, st4.p,
-                               buffers + lp.mov_mean, buffers + lp.mov_var, kBnMomentum);
+                               buffers + lp.mov_mean, buffers + lp.mov_var, kBnMomentum, (int)h);
             TK_HIP(hipGetLastError());
         }
         Tn y = out ? *out : alloc(R, h);
@@ -733,6 +733,75 @@ struct ps_trainer {
             (void)st4;
         });
         return y;
+    }
+
+    // LFA mlp2 on the [N*K, h] rows (conv h -> h + BatchNorm + LeakyReLU, RandLANet.py:331) with the pre-BatchNorm product recomputed from x
+    // wherever it is needed instead of stored (smallconv_train.hip; h = 8: convbn_rows.hip): 3 + 6 passes over [rows, h] tensors instead of
+    // 5 + 10.  defer_dgrad as in linear(): the input-gradient pass waits for the other consumer's plain store and adds into it.
+    bool convbn_fused_ok(const Tn& x, const LayerP& lp) const
+    {
+        if (!opt.fused_convbn || lp.cin != lp.cout || !ps_op_conv_bn_train_supported(lp.cout) || lp.kind == kDeconv || lp.b < 0) return false;
+        if (opt.mlp_bf16 && lp.cout != 8) return false;  // (wider layers round their operands to bf16 there: a different function)
+        return x.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x.p) & 15) == 0;  // (a column block of a concat buffer is fine)
+    }
+    Tn conv_bn_fused(const Tn& x, const LayerP& lp, bool defer_dgrad, const Tn* out = nullptr)
+    {
+        const int64_t R = x.R, h = lp.cout, CP = h < 16 ? 16 : h;
+        const bool sync = sync_bn && coll && world > 1;
+        const int64_t R_total = sync ? R * world : R;
+        const float *W = params + lp.w, *b = params + lp.b, *gamma = params + lp.gamma, *beta = params + lp.beta;
+        Tn sums = alloc(1, 6 * CP, false);  // 3 CP doubles: sum y | sum y^2 | sum x
+        double* s64 = reinterpret_cast<double*>(sums.p);
+        TK(ps_op_conv_bn_train_sums(c, x.p, x.ld, W, b, R, h, s64));
+        if (sync) allreduce(s64, 2 * CP, 1);
+        Tn st4 = alloc(4, h, false);  // mean | var | invstd | scale
+        float *mean = st4.p, *invstd = st4.p + 2 * h, *scale = st4.p + 3 * h;
+        {
+            Stage st(c, "train_convbn_fwd", 1);
+            hipLaunchKernelGGL(tr_locse_stats_kernel, dim3(ceil_div(h, 64)), dim3(64), 0, stream(), s64, (double)R_total, gamma, (int)h, kBnEps, st4.p,
+                               buffers + lp.mov_mean, buffers + lp.mov_var, kBnMomentum, (int)CP);
+            TK_HIP(hipGetLastError());
+        }
+        Tn z = out ? *out : alloc(R, h);
+        z.req = true;
+        TK(ps_op_conv_bn_train_apply(c, x.p, x.ld, W, b, R, h, mean, scale, beta, z.p, z.ld));
+        float *gW = grads + lp.w, *gb = grads + lp.b, *ggamma = grads + lp.gamma, *gbeta = grads + lp.beta;
+        record(z, [=](const Tn& dz_in) {
+            const bool dz_ok = dz_in.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(dz_in.p) & 15) == 0;
+            const Tn dz = dz_ok ? dz_in : contig(dz_in);
+            Tn acc = alloc(1, 3 * h, false);
+            TK(ps_op_conv_bn_train_bwd_sums2(c, x.p, x.ld, W, b, R, h, mean, invstd, scale, beta, dz.p, dz.ld, acc.p));
+            Tn tot = alloc(2, h, false);
+            {
+                Stage st(c, "train_convbn_bwd", 1);
+                hipLaunchKernelGGL(tr_locse_local_kernel, dim3(ceil_div(h, 64)), dim3(64), 0, stream(), acc.p, (int)h, ggamma, gbeta, tot.p);
+                TK_HIP(hipGetLastError());
+            }
+            if (sync) allreduce(tot.p, 2 * h, 0);
+            auto apply = [=]() {
+                auto it = grad_of.find(x.id);
+                const bool add = it != grad_of.end();
+                Tn dx = add ? it->second : alloc(R, h);
+                if (add && !(dx.ld % 4 == 0 && dx.R == R && dx.C == h)) {
+                    ps::set_error("trainer: conv_bn_fused: unexpected gradient layout");
+                    throw TrainError{PS_ESTATE};
+                }
+                TK(ps_op_conv_bn_train_bwd_apply_w(c, x.p, x.ld, W, b, R, h, mean, invstd, scale, beta, tot.p, 1.0f / (float)R_total, dz.p, dz.ld, add ? 1 : 0,
+                                                   dx.p, dx.ld, gW, gb));
+                if (!add) accum(x, dx);
+                (void)st4;
+            };
+            if (!x.req) {
+                ps::set_error("trainer: conv_bn_fused on an input without gradient");
+                throw TrainError{PS_ESTATE};
+            }
+            if (defer_dgrad && !grad_of.count(x.id))
+                deferred[x.id].push_back(apply);
+            else
+                apply();
+        });
+        z.req = true;
+        return z;
     }
 
     // x [B*N, d], idx [B, M, K] -> [B*M*K, d]; out: optional column block of a wider tensor that receives the rows
@@ -992,7 +1061,9 @@ struct ps_trainer {
                 // gather_neighbour + concat + att_pooling's core as one kernel per direction
                 Tn f_xyz = locse(nullptr);
                 Tn f_agg = att_split(f_pc, idx, B, N, K, f_xyz, n + "LFAatt_pooling_1");
-                Tn f_xyz2 = conv(f_xyz, n + "LFAmlp2", true, true, nullptr, false, /*defer_dgrad: pooling 1's backward stores first*/ true);
+                const LayerP& l2 = layer(n + "LFAmlp2");
+                Tn f_xyz2 = convbn_fused_ok(f_xyz, l2) ? conv_bn_fused(f_xyz, l2, true)
+                                                       : conv(f_xyz, n + "LFAmlp2", true, true, nullptr, false, /*defer_dgrad: pooling 1's backward stores first*/ true);
                 f_agg2 = att_split(f_agg, idx, B, N, K, f_xyz2, n + "LFAatt_pooling_2");
             } else {
                 // (d = 128: the pre-product form measured slower, HBM bound there; bf16 mode: its yardstick rounds the operands of the ONE d x d product)
@@ -1006,7 +1077,9 @@ struct ps_trainer {
                 Tn f_agg = pre ? att_pre(f_pc, idx, B, N, K, fcat1, f_xyz, n + "LFAatt_pooling_1") : att(fcat1, n + "LFAatt_pooling_1", K);
                 Tn cat2 = alloc(B * N * K, 2 * hc);
                 Tn right2 = cols(cat2, hc, hc);
-                Tn f_xyz2 = conv(f_xyz, n + "LFAmlp2", true, true, &right2);
+                // (defer_dgrad: f_xyz's other gradient, a column block of pooling 1's dF, arrives later; the convolution adds into it in place)
+                const LayerP& l2 = layer(n + "LFAmlp2");
+                Tn f_xyz2 = convbn_fused_ok(f_xyz, l2) ? conv_bn_fused(f_xyz, l2, true, &right2) : conv(f_xyz, n + "LFAmlp2", true, true, &right2, false, true);
                 Tn left2 = cols(cat2, 0, hc);
                 Tn f_nb2 = gather(f_agg, idx, B, N, K, &left2);
                 Tn fcat2 = concat_views(cat2, f_nb2, f_xyz2);

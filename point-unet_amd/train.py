@@ -470,22 +470,22 @@ class Trainer:
     """Parameters (flat fp32 buffer + named views), Adam state and the train step."""
 
     def __init__(self, config, params=None, device=0, seed=0, learning_rate=None, class_weights=None, keep_prob=0.5, ctx=None, sync_bn=False,
-                 mlp_dtype="fp32", ignored_label_inds=None, fused_att=True, fused_locse=True, fused_convbn=False, engine="native", deterministic=True):
+                 mlp_dtype="fp32", ignored_label_inds=None, fused_att=True, fused_locse=True, fused_convbn=None, engine="native", deterministic=True):
         """sync_bn: with a `dist` passed to train_step, BatchNorm uses the statistics of all ranks' rows, which makes "W GPUs x
         one cloud" numerically the same step as "one GPU x W clouds" (SURVEY 8e); off = per-GPU statistics.
         mlp_dtype: "fp32" (default) or "bf16" -- BASELINE configs[2]'s "bf16 MLPs": the shared-MLP GEMMs (forward, input gradient,
         weight gradient) round their operands to bf16 and accumulate in fp32 (ps_set_train_gemm_bf16); everything else stays fp32.
         engine: "native" (default) = ps_randla_train_step, the tape in C++ (csrc/trainer.hip); "python" = the host-side tape of this
-        file (A/B reference; the only engine with fused_convbn).
+        file (A/B reference).
         deterministic (native engine): the scatter-adds of the backward pass run as fixed-order gather-reductions over inverse indices
         (csrc/invidx.hip) instead of float atomics -- two runs of a step produce bit-identical gradients."""
         if mlp_dtype not in ("fp32", "bf16"):
             raise ValueError("mlp_dtype must be 'fp32' or 'bf16'")
         if engine not in ("native", "python"):
             raise ValueError("engine must be 'native' or 'python'")
-        if fused_convbn and engine == "native":
-            engine = "python"  # (measured slower than the streaming kernels it replaces: kept out of the native step)
         self.engine = engine
+        if fused_convbn is None:  # on in the native step (measured 47.9 -> 46.3 ms at batch 8), off in the Python tape (its older passes lose)
+            fused_convbn = engine == "native"
         self.deterministic = bool(deterministic)
         self.mlp_bf16 = mlp_dtype == "bf16"
         self.fused_att = bool(fused_att)  # False: the op-by-op attentive pooling everywhere (A/B switch of bench.py --no-fused-att)
@@ -498,6 +498,9 @@ class Trainer:
         # issue bound and measured SLOWER than the streaming kernels they replace (batch 8: +0.7 / +0.2 / +1.0 ms with c = 8 / 32 / 64
         # alone, 58.8 vs 56.9 ms with all three) -- correct (tests/test_gpu_train.py) and kept as the starting point for wider tiles
         self.fused_convbn = bool(fused_convbn) and not self.mlp_bf16
+        # native engine (ps_train_options.fused_convbn): c = 8 on one-thread-per-row kernels (csrc/convbn_rows.hip, also in the bf16-MLP mode:
+        # an 8 x 8 product has no matrix-pipe shape and stays fp32 there), wider layers on the tile kernels in fp32 mode
+        self._fused_convbn_native = bool(fused_convbn)
         self.sync_bn = bool(sync_bn)
         self.cfg = config
         self.device = torch.device("cuda", device)
@@ -558,6 +561,7 @@ class Trainer:
         o.learning_rate, o.keep_prob = self.lr, self.keep_prob
         o.mlp_bf16, o.fused_att, o.fused_locse = int(self.mlp_bf16), int(self.fused_att), int(self.fused_locse)
         o.deterministic = int(self.deterministic)
+        o.fused_convbn = int(self._fused_convbn_native)
         o.num_ignored = len(self.ignored_label_inds)
         for i, v in enumerate(self.ignored_label_inds):
             o.ignored_label_inds[i] = v

@@ -67,6 +67,7 @@ int main(int argc, char** argv)
     opt.fused_att = 1;
     opt.fused_locse = 1;
     opt.deterministic = 1;
+    opt.fused_convbn = 1;
     ps_trainer* tr = nullptr;
     CK(ps_trainer_create(ctx, &cfg, &opt, &tr));
     if (ps_trainer_param_count(tr) != (int64_t)params.size() || ps_trainer_buffer_count(tr) != (int64_t)buffers.size()) {

@@ -1047,4 +1047,111 @@ def test_training_step_k32_two_classes(oracle):
         worst.append((float(np.abs(got - ref).max() / (2e-3 * np.abs(ref).max() + 2e-5 * gscale)), name))
     worst.sort(reverse=True)
     print("K = 32 step: logits err %.2e, worst gradient tensors %s" % (err, worst[:3]))
-    assert worst[0][0] <= 1.0, worst[:5]
+    assert worst[0][0] <= 1.0, worst[:5]@pytest.mark.gpu
+def test_square_conv_bn_passes_of_the_native_step_against_float64_autograd():
+    """The form of the conv c->c + BatchNorm(train) + LeakyReLU recompute passes that csrc/trainer.hip drives (ps_op_conv_bn_train_sums /
+    _apply / _bwd_sums2 / _bwd_apply_w: the weight and bias gradients come out of the apply pass as x^T dy and sum dy; c = 8 on the
+    one-thread-per-row kernels of csrc/convbn_rows.hip, wider layers on the 16-row tiles) against torch float64 autograd: output, S1 / S2
+    (= dbeta / dgamma), dx written fresh and added to an existing gradient, dW, db.  Ragged row counts; c = 8 also at a row count that
+    makes every thread loop (> 2048 x 256 rows), and run twice for bit-identical results."""
+    import ctypes
+    import torch
+    from point_unet_amd import runtime, _lib
+    from point_unet_amd.train import BN_EPS
+    ctx = runtime.default_context(0)
+    L = _lib.lib()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(19)
+    for C, R in ((8, 10007), (8, 600011), (16, 4099), (32, 5003), (64, 3001)):
+        CP = max(C, 16)
+        x = torch.randn(R, C, generator=g).cuda()
+        W = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+        b = (0.1 * torch.randn(C, generator=g)).cuda()
+        gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+        dz = torch.randn(R, C, generator=g).cuda()
+        Xd = x.double().clone().requires_grad_(True)
+        Wd, bd, gd, btd = [v.double().clone().requires_grad_(True) for v in (W, b, gamma, beta)]
+        yy = Xd @ Wd + bd
+        mean_d, var_d = yy.mean(0), yy.var(0, unbiased=False)
+        z_d = torch.nn.functional.leaky_relu((yy - mean_d) / torch.sqrt(var_d + BN_EPS) * gd + btd, 0.2)
+        (z_d * dz.double()).sum().backward()
+        sums = torch.zeros(3 * CP, dtype=torch.float64).cuda()
+        assert L.ps_op_conv_bn_train_sums(ctx.handle, vp(x), C, vp(W), vp(b), R, C, vp(sums)) == 0
+        mean64 = sums[:C] / R
+        var64 = (sums[CP:CP + C] / R - mean64 * mean64).clamp_min(0)
+        assert (mean64 - mean_d.detach()).abs().max().item() <= 1e-6 and (var64 - var_d.detach()).abs().max().item() <= 1e-6 * var_d.max().item() + 1e-7
+        assert (sums[2 * CP:2 * CP + C] - x.double().sum(0)).abs().max().item() <= 1e-6 * R ** 0.5 + 1e-4
+        mean, var = mean64.float(), var64.float()
+        invstd = torch.rsqrt(var + BN_EPS)
+        scale = gamma * invstd
+        z = torch.empty(R, C).cuda()
+        assert L.ps_op_conv_bn_train_apply(ctx.handle, vp(x), C, vp(W), vp(b), R, C, vp(mean), vp(scale), vp(beta), vp(z), C) == 0
+        rel = lambda a, r: (a.double() - r).abs().max().item() / r.abs().max().item()  # noqa: E731
+        assert rel(z, z_d.detach()) <= 2e-6
+        s12 = torch.zeros(3 * C).cuda()
+        assert L.ps_op_conv_bn_train_bwd_sums2(ctx.handle, vp(x), C, vp(W), vp(b), R, C, vp(mean), vp(invstd), vp(scale), vp(beta), vp(dz), C, vp(s12)) == 0
+        assert rel(s12[:C], btd.grad) <= 2e-5 and rel(s12[C:2 * C], gd.grad) <= 2e-5
+        first = None
+        for prior in (False, True, True):
+            extra = torch.randn(R, C, generator=torch.Generator().manual_seed(5)).cuda()
+            dx = extra.clone() if prior else torch.full((R, C), float("nan")).cuda()
+            dw, db = torch.full((C, C), float("nan")).cuda(), torch.full((C,), float("nan")).cuda()
+            assert L.ps_op_conv_bn_train_bwd_apply_w(ctx.handle, vp(x), C, vp(W), vp(b), R, C, vp(mean), vp(invstd), vp(scale), vp(beta), vp(s12),
+                                                     ctypes.c_float(1.0 / R), vp(dz), C, 1 if prior else 0, vp(dx), C, vp(dw), vp(db)) == 0
+            torch.cuda.synchronize()
+            want_dx = Xd.grad + (extra.double() if prior else 0)
+            errs = dict(dx=rel(dx, want_dx), dW=rel(dw, Wd.grad), db=(db.double() - bd.grad).abs().max().item() / Wd.grad.abs().max().item())
+            print(C, R, prior, errs)
+            assert errs["dx"] <= 2e-5 and errs["dW"] <= 2e-5 and errs["db"] <= 2e-5, (C, R, errs)
+            if prior:
+                if first is None:
+                    first = (dx.clone(), dw.clone(), db.clone())
+                else:
+                    assert torch.equal(first[0], dx) and torch.equal(first[1], dw) and torch.equal(first[2], db)
+
+
+@pytest.mark.gpu
+def test_native_step_with_recomputed_square_convolutions():
+    """Trainer(fused_convbn=True) (ps_train_options.fused_convbn: LFA mlp2 of every level with h <= 64 in the recompute form) against the
+    op-by-op native step: same parameters and clouds, one step.  fp32: loss 2e-6, logits 2e-5 of their magnitude, moving statistics 1e-5,
+    gradients 5e-3 relative L2 (the bar between the two engines; the recompute form sums in a different order).  bf16-MLP mode: only the
+    h = 8 layer changes (its product has no matrix-pipe shape and is fp32 in both forms) -- held to the bf16 bars of the engine test.
+    Also: two runs of the fused step give bit-identical gradients."""
+    import torch
+    from point_unet_amd import weights
+    from point_unet_amd.pyramid import build_pyramid
+    from point_unet_amd.train import Trainer
+    cfg, xyz, feats = netcase.small_deep(6000, seed=23, B=2)
+    params = weights.init_params(cfg, seed=6, randomize_bn=True)
+    rng = np.random.default_rng(4)
+    labels = rng.integers(0, cfg.num_classes, xyz.shape[:2]).astype(np.int32)
+    cw = np.linspace(1.0, 2.0, cfg.num_classes).astype(np.float32)
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    d_feats, d_lab = torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
+    for mode in ("fp32", "bf16"):
+        runs = []
+        for fused in (True, True, False):
+            tr = Trainer(cfg, params=params, learning_rate=1e-3, class_weights=cw, keep_prob=0.5, mlp_dtype=mode, fused_convbn=fused)
+            assert tr.engine == "native"
+            loss = tr.train_step(pyr, d_feats, d_lab)
+            torch.cuda.synchronize()
+            runs.append(dict(loss=float(loss), logits=tr.last_logits.cpu().numpy().copy(), grad=tr.grad.cpu().numpy().copy(),
+                             buffers={k: v.cpu().numpy().copy() for k, v in tr.buffers.items()}))
+            tr.close()
+        a, a2, b = runs
+        assert a["loss"] == a2["loss"] and np.array_equal(a["grad"], a2["grad"]) and np.array_equal(a["logits"], a2["logits"])
+        assert not np.array_equal(a["grad"], b["grad"])  # (the switch does switch something)
+        if mode == "fp32":
+            assert abs(a["loss"] - b["loss"]) <= 2e-6 * abs(b["loss"]), (a["loss"], b["loss"])
+            assert np.abs(a["logits"] - b["logits"]).max() <= 2e-5 * np.abs(b["logits"]).max()
+            for k in b["buffers"]:
+                assert np.abs(a["buffers"][k] - b["buffers"][k]).max() <= 1e-5 * max(1.0, np.abs(b["buffers"][k]).max()), k
+            assert np.linalg.norm(a["grad"] - b["grad"]) <= 5e-3 * np.linalg.norm(b["grad"])
+        else:
+            assert abs(a["loss"] - b["loss"]) <= 1e-2 * abs(b["loss"]), (a["loss"], b["loss"])
+            assert np.abs(a["logits"] - b["logits"]).max() <= 0.1 * np.abs(b["logits"]).max()
+            cos = float((a["grad"] * b["grad"]).sum() / (np.linalg.norm(a["grad"]) * np.linalg.norm(b["grad"])))
+            assert cos >= 0.9, cos
+
+
+
