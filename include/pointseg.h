@@ -279,11 +279,15 @@ int ps_op_bn_train_bwd_apply_ex(ps_context* ctx, const float* dy, int64_t lddy, 
                                 const float* sum_gx, int64_t R, int64_t R_total, int64_t C, int leaky, float* dx);
 int ps_op_scatter_add_rows_ex(ps_context* ctx, const float* drows, int64_t ldd, const int32_t* idx, int64_t B,
                               int64_t N, int64_t rows_per_cloud, int64_t d, float* dpc);
-/* att_pooling core: probs = softmax over K of scores, agg = sum_K fset * probs   (RandLANet.py:396-398) */
+/* att_pooling core: probs = softmax over K of scores, agg = sum_K fset * probs   (RandLANet.py:396-398).  probs may be NULL (not
+ * kept); ps_op_softmax_pool_bwd_scores then forms the softmax again from the scores (same arithmetic as the forward; dscores may alias
+ * scores): one [R*K, d] tensor less written and kept per pooling. */
 int ps_op_softmax_pool_fwd(ps_context* ctx, const float* fset, const float* scores, int64_t R, int64_t K, int64_t d,
                            float* probs, float* agg);
 int ps_op_softmax_pool_bwd(ps_context* ctx, const float* dagg, const float* fset, const float* probs, int64_t R,
                            int64_t K, int64_t d, float* dfset, float* dscores);
+int ps_op_softmax_pool_bwd_scores(ps_context* ctx, const float* dagg, const float* fset, const float* scores, int64_t R,
+                                  int64_t K, int64_t d, float* dfset, float* dscores);
 /* att_pooling's score product + softmax + weighted sum FUSED per point for the training step (csrc/attpool_train.hip):
  * agg[n,c] = sum_k softmax_k(fset . wfc)[n,k,c] * fset[n,k,c]   (RandLANet.py:394-398, wfc = the dense kernel [d,d], no bias).
  * fset rows have stride ld (a column block of a wider buffer is fine).  Neither the scores nor the probabilities are written; the

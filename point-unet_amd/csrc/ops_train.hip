@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void softpool_fwd_kernel(const float* __restri
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
             const float p = sv[k] / den;
-            probs[r * K * d + (size_t)k * d + c] = p;
+            if (probs) probs[r * K * d + (size_t)k * d + c] = p;
             a += fv[k] * p;
         }
         agg[t] = a;
@@ -633,15 +633,17 @@ __global__ __launch_bounds__(256) void softpool_fwd_kernel(const float* __restri
     float a = 0.f;
     for (int k = 0; k < K; ++k) {
         const float p = expf(s[(size_t)k * d] - m) / den;
-        probs[r * K * d + (size_t)k * d + c] = p;
+        if (probs) probs[r * K * d + (size_t)k * d + c] = p;
         a += f[(size_t)k * d] * p;
     }
     agg[t] = a;
 }
 
-template <int KK>
-__global__ __launch_bounds__(256) void softpool_bwd_kernel(const float* __restrict__ dagg, const float* __restrict__ fset, const float* __restrict__ probs,
-                                                           int64_t R, int K, int d, float* __restrict__ dfset, float* __restrict__ dscores)
+// RECOMP: `probs` holds the SCORES (the forward kept no probabilities): the softmax is formed again, with the forward's arithmetic.  dscores
+// may then alias the scores (a thread reads the K values of its (row, channel) before it writes them).
+template <int KK, bool RECOMP>
+__global__ __launch_bounds__(256) void softpool_bwd_kernel(const float* dagg, const float* fset, const float* probs, int64_t R, int K, int d, float* dfset,
+                                                           float* dscores)
 {
     const int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;
     if (t >= R * d) return;
@@ -654,6 +656,16 @@ __global__ __launch_bounds__(256) void softpool_bwd_kernel(const float* __restri
         float pv[KK > 0 ? KK : 1], fv[KK > 0 ? KK : 1];
 #pragma unroll
         for (int k = 0; k < KK; ++k) { pv[k] = probs[base + (size_t)k * d]; fv[k] = fset[base + (size_t)k * d]; }
+        if (RECOMP) {
+            float m = pv[0];
+#pragma unroll
+            for (int k = 1; k < KK; ++k) m = fmaxf(m, pv[k]);
+            float den = 0.f;
+#pragma unroll
+            for (int k = 0; k < KK; ++k) { pv[k] = expf(pv[k] - m); den += pv[k]; }
+#pragma unroll
+            for (int k = 0; k < KK; ++k) pv[k] = pv[k] / den;
+        }
 #pragma unroll
         for (int k = 0; k < KK; ++k) dot += pv[k] * g * fv[k];
 #pragma unroll
@@ -663,9 +675,17 @@ __global__ __launch_bounds__(256) void softpool_bwd_kernel(const float* __restri
         }
         return;
     }
-    for (int k = 0; k < K; ++k) dot += probs[base + (size_t)k * d] * g * fset[base + (size_t)k * d];
+    float m = 0.f, den = 1.f;
+    if (RECOMP) {
+        m = probs[base];
+        for (int k = 1; k < K; ++k) m = fmaxf(m, probs[base + (size_t)k * d]);
+        den = 0.f;
+        for (int k = 0; k < K; ++k) den += expf(probs[base + (size_t)k * d] - m);
+    }
+    auto prob = [&](int k) { return RECOMP ? expf(probs[base + (size_t)k * d] - m) / den : probs[base + (size_t)k * d]; };
+    for (int k = 0; k < K; ++k) dot += prob(k) * g * fset[base + (size_t)k * d];
     for (int k = 0; k < K; ++k) {
-        const float p = probs[base + (size_t)k * d], f = fset[base + (size_t)k * d];
+        const float p = prob(k), f = fset[base + (size_t)k * d];
         dfset[base + (size_t)k * d] = g * p;
         dscores[base + (size_t)k * d] = p * (g * f - dot);
     }
@@ -1131,7 +1151,7 @@ int ps_op_scatter_add_rows_ex(ps_context* c, const float* drows, int64_t ldd, co
 
 int ps_op_softmax_pool_fwd(ps_context* c, const float* fset, const float* scores, int64_t R, int64_t K, int64_t d, float* probs, float* agg)
 {
-    PS_CHECK(c && fset && scores && probs && agg, "ps_op_softmax_pool_fwd: NULL argument");
+    PS_CHECK(c && fset && scores && agg, "ps_op_softmax_pool_fwd: NULL argument");  // (probs may be NULL: not kept)
     if (!R) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_softpool_fwd", 1);
@@ -1151,9 +1171,24 @@ int ps_op_softmax_pool_bwd(ps_context* c, const float* dagg, const float* fset, 
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_softpool_bwd", 1);
     const dim3 grid(ceil_div(R * d, 256));
-    if (K == 16) hipLaunchKernelGGL(softpool_bwd_kernel<16>, grid, dim3(256), 0, c->stream, dagg, fset, probs, R, (int)K, (int)d, dfset, dscores);
-    else if (K == 32) hipLaunchKernelGGL(softpool_bwd_kernel<32>, grid, dim3(256), 0, c->stream, dagg, fset, probs, R, (int)K, (int)d, dfset, dscores);
-    else hipLaunchKernelGGL(softpool_bwd_kernel<0>, grid, dim3(256), 0, c->stream, dagg, fset, probs, R, (int)K, (int)d, dfset, dscores);
+    if (K == 16) hipLaunchKernelGGL((softpool_bwd_kernel<16, false>), grid, dim3(256), 0, c->stream, dagg, fset, probs, R, (int)K, (int)d, dfset, dscores);
+    else if (K == 32) hipLaunchKernelGGL((softpool_bwd_kernel<32, false>), grid, dim3(256), 0, c->stream, dagg, fset, probs, R, (int)K, (int)d, dfset, dscores);
+    else hipLaunchKernelGGL((softpool_bwd_kernel<0, false>), grid, dim3(256), 0, c->stream, dagg, fset, probs, R, (int)K, (int)d, dfset, dscores);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+int ps_op_softmax_pool_bwd_scores(ps_context* c, const float* dagg, const float* fset, const float* scores, int64_t R, int64_t K, int64_t d, float* dfset,
+                                  float* dscores)
+{
+    PS_CHECK(c && dagg && fset && scores && dfset && dscores, "ps_op_softmax_pool_bwd_scores: NULL argument");
+    if (!R) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "train_softpool_bwd", 1);
+    const dim3 grid(ceil_div(R * d, 256));
+    if (K == 16) hipLaunchKernelGGL((softpool_bwd_kernel<16, true>), grid, dim3(256), 0, c->stream, dagg, fset, scores, R, (int)K, (int)d, dfset, dscores);
+    else if (K == 32) hipLaunchKernelGGL((softpool_bwd_kernel<32, true>), grid, dim3(256), 0, c->stream, dagg, fset, scores, R, (int)K, (int)d, dfset, dscores);
+    else hipLaunchKernelGGL((softpool_bwd_kernel<0, true>), grid, dim3(256), 0, c->stream, dagg, fset, scores, R, (int)K, (int)d, dfset, dscores);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }

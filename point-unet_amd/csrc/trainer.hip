@@ -848,12 +848,13 @@ struct ps_trainer {
     {
         const int64_t RK = fset.R, d = fset.C, R = RK / K;
         const Tn fs = contig(fset), sc = contig(scores);
-        Tn probs = alloc(RK, d, false), agg = alloc(R, d);
-        TK(ps_op_softmax_pool_fwd(c, fs.p, sc.p, R, K, d, probs.p, agg.p));
+        // (the probabilities are not kept: the backward forms the softmax again from the scores, one [R*K, d] write + one live tensor less)
+        Tn agg = alloc(R, d);
+        TK(ps_op_softmax_pool_fwd(c, fs.p, sc.p, R, K, d, nullptr, agg.p));
         record(agg, [=](const Tn& dy_in) {
             const Tn dy = contig(dy_in);
             Tn dfset = alloc(RK, d), dscores = alloc(RK, d);
-            TK(ps_op_softmax_pool_bwd(c, dy.p, fs.p, probs.p, R, K, d, dfset.p, dscores.p));
+            TK(ps_op_softmax_pool_bwd_scores(c, dy.p, fs.p, sc.p, R, K, d, dfset.p, dscores.p));
             accum(fset, dfset);
             accum(scores, dscores);
         });

@@ -1154,4 +1154,35 @@ def test_native_step_with_recomputed_square_convolutions():
             assert cos >= 0.9, cos
 
 
+@pytest.mark.gpu
+def test_softmax_pool_backward_from_scores_equals_the_one_from_probabilities():
+    """ps_op_softmax_pool_bwd_scores (the native step keeps no probabilities: the backward forms softmax_K(scores) again) against
+    ps_op_softmax_pool_bwd fed the probabilities the forward wrote: same arithmetic, so bit-identical dfset / dscores; K = 16, 32 (register
+    forms) and 5 (loop form); the forward with probs = NULL returns the same agg; dscores written over the scores in place."""
+    import ctypes
+    import torch
+    from point_unet_amd import runtime, _lib
+    ctx = runtime.default_context(0)
+    L = _lib.lib()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(31)
+    for R, K, d in ((1003, 16, 128), (257, 32, 64), (300, 5, 24)):
+        fset = torch.randn(R * K, d, generator=g).cuda()
+        scores = (3 * torch.randn(R * K, d, generator=g)).cuda()
+        dagg = torch.randn(R, d, generator=g).cuda()
+        probs, agg, agg2 = torch.empty_like(fset), torch.empty(R, d).cuda(), torch.empty(R, d).cuda()
+        assert L.ps_op_softmax_pool_fwd(ctx.handle, vp(fset), vp(scores), R, K, d, vp(probs), vp(agg)) == 0
+        assert L.ps_op_softmax_pool_fwd(ctx.handle, vp(fset), vp(scores), R, K, d, None, vp(agg2)) == 0
+        want = (torch.softmax(scores.double().view(R, K, d), 1) * fset.double().view(R, K, d)).sum(1)
+        assert torch.equal(agg, agg2) and (agg.double() - want).abs().max().item() <= 1e-5
+        df1, ds1, df2, ds2 = (torch.empty_like(fset) for _ in range(4))
+        assert L.ps_op_softmax_pool_bwd(ctx.handle, vp(dagg), vp(fset), vp(probs), R, K, d, vp(df1), vp(ds1)) == 0
+        assert L.ps_op_softmax_pool_bwd_scores(ctx.handle, vp(dagg), vp(fset), vp(scores), R, K, d, vp(df2), vp(ds2)) == 0
+        assert torch.equal(df1, df2) and torch.equal(ds1, ds2)
+        inplace = scores.clone()
+        assert L.ps_op_softmax_pool_bwd_scores(ctx.handle, vp(dagg), vp(fset), vp(inplace), R, K, d, vp(df2), vp(inplace)) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(inplace, ds1)
+
+
 
