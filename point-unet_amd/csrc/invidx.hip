@@ -72,21 +72,37 @@ __global__ __launch_bounds__(256) void inv_offsets_kernel(const unsigned* __rest
 }
 
 // dst[j, :] (+)= sum over the segment of j of rows[src, :], in segment order.  One lane group of d/4 (VEC) or d lanes per destination row.
+// A lane walks its segment alone, so the loop is written four sources at a time: four independent index loads, then four independent row
+// loads, then the four additions in segment order (a one-source-per-iteration loop is a chain of dependent loads: 2 x 16 round trips per
+// destination row at a few waves per SIMD).
 template <bool VEC>
 __global__ __launch_bounds__(256) void gather_reduce_kernel(const float* __restrict__ rows, int64_t ldr, const unsigned* __restrict__ offsets,
                                                             const int32_t* __restrict__ src, int64_t n_dst, int d, float* __restrict__ dst, int64_t ldd,
                                                             int accumulate)
 {
-    const int per = VEC ? d / 4 : d;
+    const unsigned per = VEC ? d / 4 : d;
     const int64_t total = n_dst * per;
     for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-        const int64_t j = t / per;
+        const int64_t j = total < (1ll << 32) ? (int64_t)((unsigned)t / per) : t / per;
         const int q = (int)(t - j * per);
         const unsigned lo = offsets[j], hi = offsets[j + 1];
         if (VEC) {
+            const float* base = rows + 4 * q;
             float4 acc = accumulate ? *reinterpret_cast<const float4*>(dst + j * ldd + 4 * q) : float4{0.f, 0.f, 0.f, 0.f};
-            for (unsigned s = lo; s < hi; ++s) {
-                const float4 v = *reinterpret_cast<const float4*>(rows + (int64_t)src[s] * ldr + 4 * q);
+            unsigned s = lo;
+            for (; s + 4 <= hi; s += 4) {
+                const int32_t i0 = src[s], i1 = src[s + 1], i2 = src[s + 2], i3 = src[s + 3];
+                const float4 v0 = *reinterpret_cast<const float4*>(base + (int64_t)i0 * ldr);
+                const float4 v1 = *reinterpret_cast<const float4*>(base + (int64_t)i1 * ldr);
+                const float4 v2 = *reinterpret_cast<const float4*>(base + (int64_t)i2 * ldr);
+                const float4 v3 = *reinterpret_cast<const float4*>(base + (int64_t)i3 * ldr);
+                acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+                acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+                acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+                acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+            }
+            for (; s < hi; ++s) {
+                const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)src[s] * ldr);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
             *reinterpret_cast<float4*>(dst + j * ldd + 4 * q) = acc;
@@ -143,6 +159,46 @@ __global__ __launch_bounds__(256) void maxpool_bwd_inv_kernel(const float* __res
             if (out[m * d + ch] == f) acc += TIES ? share[m * d + ch] / (float)ties[m * d + ch] : share[m * d + ch];
         }
         dfeat[t] += acc;
+    }
+}
+
+// The same walk with four channels per lane (d % 4 == 0, 32-bit index arithmetic): the segment bookkeeping -- two divisions per lane in the
+// scalar form above -- is shared by four channels, rows travel as 16-byte loads and the tie counts as one 4-byte load.
+__global__ __launch_bounds__(256) void maxpool_bwd_inv4_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ ties,
+                                                               const float* __restrict__ out, const float* __restrict__ feat,
+                                                               const unsigned* __restrict__ offsets, const int32_t* __restrict__ src, unsigned n_dst,
+                                                               unsigned n_cloud, unsigned m_cloud, unsigned K, unsigned d4, float* __restrict__ dfeat)
+{
+    const unsigned total = n_dst * d4;
+    const float4* out4 = reinterpret_cast<const float4*>(out);
+    const float4* dout4 = reinterpret_cast<const float4*>(dout);
+    const uchar4* ties4 = reinterpret_cast<const uchar4*>(ties);
+    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+        const unsigned j = t / d4, q = t - j * d4;
+        const unsigned lo = offsets[j], hi = offsets[j + 1];
+        if (lo == hi) continue;
+        const unsigned b = j / n_cloud;
+        const unsigned first = b * n_cloud, mbase = b * m_cloud;
+        const float4 f = reinterpret_cast<const float4*>(feat)[t];
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (unsigned s = lo; s < hi; ++s) {
+            const unsigned n = (unsigned)src[s] / K - first;  // src holds flat (point * K + k) positions of the neighbour table
+            if (n >= m_cloud) break;                           // (ascending: the rest of the segment is not part of the pooling table)
+            const unsigned e = (mbase + n) * d4 + q;
+            const float4 o = out4[e];
+            if (o.x == f.x || o.y == f.y || o.z == f.z || o.w == f.w) {
+                const float4 g = dout4[e];
+                const uchar4 c = ties4[e];
+                if (o.x == f.x) acc.x += g.x / (float)c.x;
+                if (o.y == f.y) acc.y += g.y / (float)c.y;
+                if (o.z == f.z) acc.z += g.z / (float)c.z;
+                if (o.w == f.w) acc.w += g.w / (float)c.w;
+            }
+        }
+        float4* dst = reinterpret_cast<float4*>(dfeat) + t;
+        float4 h = *dst;
+        h.x += acc.x; h.y += acc.y; h.z += acc.z; h.w += acc.w;
+        *dst = h;
     }
 }
 
@@ -237,6 +293,14 @@ int ps_op_random_sample_bwd_inv(ps_context* c, const float* dout, const float* o
     if (!rows) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_maxpool_bwd", ties ? 1 : 2);
+    const bool al16 = ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(feature) |
+                        reinterpret_cast<uintptr_t>(dfeature)) & 15) == 0 && (reinterpret_cast<uintptr_t>(ties) & 3) == 0;
+    if (ties && d % 4 == 0 && al16 && B * N * d < (1ll << 32) && B * N * K < (1ll << 31)) {
+        hipLaunchKernelGGL(maxpool_bwd_inv4_kernel, dim3(iv_grid(B * N * (d / 4))), dim3(256), 0, c->stream, dout, ties, out, feature,
+                           reinterpret_cast<const unsigned*>(offsets), src, (unsigned)(B * N), (unsigned)N, (unsigned)M, (unsigned)K, (unsigned)(d / 4), dfeature);
+        PS_HIP(hipGetLastError());
+        return PS_OK;
+    }
     if (ties) {
         hipLaunchKernelGGL(maxpool_bwd_inv_kernel<true>, dim3(iv_grid(B * N * d)), dim3(256), 0, c->stream, dout, ties, out, feature,
                            reinterpret_cast<const unsigned*>(offsets), src, B * N, (int)N, (int)M, (int)K, (int)d, dfeature);
