@@ -742,6 +742,8 @@ struct ps_trainer {
     {
         if (!opt.fused_convbn || lp.cin != lp.cout || !ps_op_conv_bn_train_supported(lp.cout) || lp.kind == kDeconv || lp.b < 0) return false;
         if (opt.mlp_bf16 && lp.cout != 8) return false;  // (wider layers round their operands to bf16 there: a different function)
+        static const int max_c = [] { const char* e = getenv("PS_CONVBN_MAX_C"); return e ? atoi(e) : 64; }();  // (A/B knob of the experiments in DESIGN.md)
+        if (lp.cout > max_c) return false;
         return x.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x.p) & 15) == 0;  // (a column block of a concat buffer is fine)
     }
     Tn conv_bn_fused(const Tn& x, const LayerP& lp, bool defer_dgrad, const Tn* out = nullptr)
