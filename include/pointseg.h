@@ -334,7 +334,8 @@ int ps_op_locse_train_bwd(ps_context* ctx, const float* xyz, const int32_t* idx,
  *               S1 = sum g, S2 = sum g xh, XS = sum xh, A = x^T g, G = x^T xh; then dgamma = S2, dbeta = S1,
  *               dw = gamma invstd (A - (sum x) x S1/M - G . S2/M), M = rows of all ranks
  *   _bwd_apply: dx (+)= (gamma invstd (g - m1 - xh m2)) . w^T with m1 = S1/M, m2 = S2/M
- * Deterministic (per-workgroup partials merged in a fixed order). */
+ * Deterministic (per-workgroup partials merged in a fixed order).  With ps_set_train_gemm_bf16 on and C % 16 == 0 the operands of the
+ * products (x and w; dy and w^T; x and dy) are rounded to bfloat16 first, fp32 accumulation -- the rule of ps_op_conv1x1_ex. */
 int ps_op_conv_bn_train_supported(int64_t C);
 int ps_op_conv_bn_train_sums(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t C, double* sums);
 int ps_op_conv_bn_train_apply(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t C,
@@ -437,8 +438,8 @@ typedef struct {
     int32_t deterministic;          /* every scatter-add of the backward pass as a fixed-order gather-reduction over an inverse index built
                                      * once per level and step (csrc/invidx.hip): two runs of a step give bit-identical gradients */
     int32_t fused_convbn;           /* LFA mlp2 (conv h -> h + BatchNorm + LeakyReLU on the [N*K, h] rows, RandLANet.py:331) with the pre-BatchNorm
-                                     * product recomputed instead of stored (h <= 64; in the bf16-MLP mode only h = 8, whose product has no
-                                     * matrix-pipe shape and stays fp32 there) */
+                                     * product recomputed instead of stored (h <= 64; in the bf16-MLP mode the operands of its three products are
+                                     * rounded like the GEMMs it replaces -- h % 16 == 0 --, the 8-channel layer stays fp32 in both forms) */
 } ps_train_options;
 /* In-place sum over the ranks of `count` elements at device pointer `buf` (dtype 0: float32, 1: float64), ordered on `hip_stream`
  * (the context's stream).  Returns 0 on success. */

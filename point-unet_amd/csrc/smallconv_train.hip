@@ -34,6 +34,8 @@ struct ScArgs {
     int64_t R;
     int ldx, lddz, ldo, accum;
     int vec;             // dz / out rows are 16-byte aligned with pitches % 4 == 0: tiles travel as float4 through LDS
+    int bf16;            // bf16-MLP mode: the operands of the three products (x and w; dy and w^T; x and dy) are rounded to bfloat16 (RNE) first and
+                         // multiplied on the fp32 MFMA (exact products, fp32 accumulation: the values of a bf16 MFMA with fp32 accumulate)
 };
 
 template <int C>
@@ -44,14 +46,22 @@ struct ScGeom {
     static constexpr int PA = CP + 2;                                // tile pitch = 2 (mod 32): conflict-free A-fragment reads
 };
 
+__device__ __forceinline__ float sc_round_bf16(float x)
+{
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (finite inputs)
+    return __uint_as_float(u & 0xffff0000u);
+}
+
 // W (and optionally W^T) -> LDS, zero-padded to CP x CP
 template <int C, int THREADS>
-__device__ __forceinline__ void sc_stage_w(const float* __restrict__ w, float* W, float* WT)
+__device__ __forceinline__ void sc_stage_w(const float* __restrict__ w, float* W, float* WT, bool bf16 = false)
 {
     using G = ScGeom<C>;
     for (int i = threadIdx.x; i < G::CP * G::CP; i += THREADS) {
         const int r = i / G::CP, c = i - r * G::CP;
-        const float v = (r < C && c < C) ? w[r * C + c] : 0.f;
+        float v = (r < C && c < C) ? w[r * C + c] : 0.f;
+        if (bf16) v = sc_round_bf16(v);
         W[r * G::PW + c] = v;
         if (WT) WT[c * G::PW + r] = v;
     }
@@ -77,7 +87,7 @@ struct ScTile {
             }
         }
     }
-    __device__ __forceinline__ void commit(float* A, int lane) const
+    __device__ __forceinline__ void commit(float* A, int lane, bool bf16 = false) const
     {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -85,7 +95,11 @@ struct ScTile {
             if (TOT % 64 == 0 || e < TOT) {
                 const int row = e / Q, q = e - row * Q;
                 float* dst = A + row * G::PA + 4 * q;
-                dst[0] = v[i].x; dst[1] = v[i].y; dst[2] = v[i].z; dst[3] = v[i].w;
+                if (bf16) {
+                    dst[0] = sc_round_bf16(v[i].x); dst[1] = sc_round_bf16(v[i].y); dst[2] = sc_round_bf16(v[i].z); dst[3] = sc_round_bf16(v[i].w);
+                } else {
+                    dst[0] = v[i].x; dst[1] = v[i].y; dst[2] = v[i].z; dst[3] = v[i].w;
+                }
             }
         }
         if constexpr (C < 16) {  // padding columns (read as A operands of the x^T products)
@@ -161,7 +175,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_sums_kernel(ScArgs a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     float* A = smem + G::CP * G::PW + wave * 16 * G::PA;
     double* red = reinterpret_cast<double*>(smem + G::CP * G::PW + kScWaves * 16 * G::PA);  // [kScWaves][3 CP]
-    sc_stage_w<C, kScWaves * 64>(a.w, W, nullptr);
+    sc_stage_w<C, kScWaves * 64>(a.w, W, nullptr, a.bf16 != 0);
     __syncthreads();
     const ScCols<NT> bias(a.b, c16, C);
     double sy[NT], sq[NT], sx[NT];
@@ -173,7 +187,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_sums_kernel(ScArgs a)
     if (tl < tiles) xr.fetch(a.x, a.ldx, tl * 16, a.R, lane);
     for (; tl < tiles; tl += tstride) {
         const int64_t r0 = tl * 16;
-        xr.commit(A, lane);
+        xr.commit(A, lane, a.bf16 != 0);
         wave_lds_sync();
         if (tl + tstride < tiles) xr.fetch(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
 #pragma unroll
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_apply_kernel(ScArgs a)
     float* W = smem;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     float* A = smem + G::CP * G::PW + wave * 16 * G::PA;
-    sc_stage_w<C, kScWaves * 64>(a.w, W, nullptr);
+    sc_stage_w<C, kScWaves * 64>(a.w, W, nullptr, a.bf16 != 0);
     __syncthreads();
     const ScCols<NT> bias(a.b, c16, C), mu(a.mean, c16, C), sc(a.scale, c16, C), be(a.beta, c16, C);
     const int64_t tiles = (a.R + 15) / 16, tstride = (int64_t)gridDim.x * kScWaves;
@@ -233,7 +247,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_apply_kernel(ScArgs a)
     ScTile<C> xr;
     if (tl < tiles) {
         xr.fetch(a.x, a.ldx, tl * 16, a.R, lane);
-        xr.commit(A, lane);
+        xr.commit(A, lane, a.bf16 != 0);
     }
     wave_lds_sync();
     for (; tl < tiles; tl += tstride) {
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_apply_kernel(ScArgs a)
             ScTile<C> o;
             o.take(A, lane);
             wave_lds_sync();
-            if (more) xr.commit(A, lane);
+            if (more) xr.commit(A, lane, a.bf16 != 0);
             o.put(a.out, a.ldo, r0, a.R, lane);
         } else {
 #pragma unroll
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_apply_kernel(ScArgs a)
                     if (col < C && r0 + 4 * g + r < a.R) a.out[(size_t)(r0 + 4 * g + r) * a.ldo + col] = z[ct][r];
             }
             wave_lds_sync();
-            if (more) xr.commit(A, lane);
+            if (more) xr.commit(A, lane, a.bf16 != 0);
         }
         wave_lds_sync();
     }
@@ -291,7 +305,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_sums_kernel(ScArgs a)
     float* A = smem + CP * G::PW + wave * 3 * 16 * G::PA;  // x tile | g tile | xh tile
     float* T1 = A + 16 * G::PA;
     float* T2 = T1 + 16 * G::PA;
-    sc_stage_w<C, kScWaves * 64>(a.w, W, nullptr);
+    sc_stage_w<C, kScWaves * 64>(a.w, W, nullptr, a.bf16 != 0);
     __syncthreads();
     const ScCols<NT> bias(a.b, c16, C), mu(a.mean, c16, C), is(a.invstd, c16, C), sc(a.scale, c16, C), be(a.beta, c16, C);
     float s1[NT], s2[NT], xs[NT];
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_sums_kernel(ScArgs a)
     }
     for (; tl < tiles; tl += tstride) {
         const int64_t r0 = tl * 16;
-        xr.commit(A, lane);
+        xr.commit(A, lane, a.bf16 != 0);
         if (a.vec) zr.commit(T1, lane);
         wave_lds_sync();
         if (tl + tstride < tiles) {
@@ -404,7 +418,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     float* A = smem + 2 * CP * G::PW + wave * 2 * 16 * G::PA;  // x tile | dy tile
     float* T1 = A + 16 * G::PA;
-    sc_stage_w<C, kScWaves * 64>(a.w, W, WT);
+    sc_stage_w<C, kScWaves * 64>(a.w, W, WT, a.bf16 != 0);
     __syncthreads();
     const ScCols<NT> bias(a.b, c16, C), mu(a.mean, c16, C), is(a.invstd, c16, C), sc(a.scale, c16, C), be(a.beta, c16, C);
     ScCols<NT> m1(a.m1, c16, C), m2(a.m2, c16, C);
@@ -428,7 +442,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
         xr.fetch(a.x, a.ldx, tl * 16, a.R, lane);
         if (vec) zr.fetch(a.dz, a.lddz, tl * 16, a.R, lane);
         if (acc_old) old_next.fetch(a.out, a.ldo, tl * 16, a.R, lane);
-        xr.commit(A, lane);
+        xr.commit(A, lane, a.bf16 != 0);
         if (vec) zr.commit(T1, lane);
     }
     wave_lds_sync();
@@ -453,7 +467,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
                 float gv = !live ? 0.f : vec ? T1[(4 * g + r) * G::PA + col] : a.dz[(size_t)(r0 + 4 * g + r) * a.lddz + col];
                 if (__builtin_fmaf(yc, sc.v[ct], be.v[ct]) < 0.f) gv *= 0.2f;
                 const float dyv = live ? sc.v[ct] * (gv - m1.v[ct] - xh * m2.v[ct]) : 0.f;
-                T1[(4 * g + r) * G::PA + col] = dyv;
+                T1[(4 * g + r) * G::PA + col] = a.bf16 ? sc_round_bf16(dyv) : dyv;  // (operand of the two products; the bias gradient sums the unrounded value)
                 if (WG) dbs[ct] += dyv;
             }
         }
@@ -503,7 +517,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
             wave_lds_sync();
         }
         if (more) {
-            xr.commit(A, lane);
+            xr.commit(A, lane, a.bf16 != 0);
             if (vec) zr.commit(T1, lane);
         }
         if (vec) o.put(a.out, a.ldo, r0, a.R, lane);
@@ -597,6 +611,7 @@ static int sc_dispatch(ps_context* c, int64_t C, const ScArgs& a_in, int what, v
     ScArgs a = a_in;
     auto al = [](const void* q, int ld) { return !q || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0); };
     a.vec = al(a.dz, a.lddz) && al(a.out, a.ldo) ? 1 : 0;
+    a.bf16 = c->train_bf16 && C % 16 == 0 ? 1 : 0;  // (ps_set_train_gemm_bf16; the rule of ps_op_conv1x1_ex: an 8-channel product stays fp32)
     switch (C) {
         case 8: return sc_launch<8>(c, a, what, result, result2);
         case 16: return sc_launch<16>(c, a, what, result, result2);

@@ -741,7 +741,8 @@ struct ps_trainer {
     bool convbn_fused_ok(const Tn& x, const LayerP& lp) const
     {
         if (!opt.fused_convbn || lp.cin != lp.cout || !ps_op_conv_bn_train_supported(lp.cout) || lp.kind == kDeconv || lp.b < 0) return false;
-        if (opt.mlp_bf16 && lp.cout != 8) return false;  // (wider layers round their operands to bf16 there: a different function)
+        // (bf16-MLP mode: the tile kernels round the operands of their three products like the GEMMs they replace -- cin % 16 == 0 --, the
+        //  8-channel layer stays fp32 in both forms)
         static const int max_c = [] { const char* e = getenv("PS_CONVBN_MAX_C"); return e ? atoi(e) : 64; }();  // (A/B knob of the experiments in DESIGN.md)
         if (lp.cout > max_c) return false;
         return x.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x.p) & 15) == 0;  // (a column block of a concat buffer is fine)

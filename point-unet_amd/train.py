@@ -498,8 +498,8 @@ class Trainer:
         # issue bound and measured SLOWER than the streaming kernels they replace (batch 8: +0.7 / +0.2 / +1.0 ms with c = 8 / 32 / 64
         # alone, 58.8 vs 56.9 ms with all three) -- correct (tests/test_gpu_train.py) and kept as the starting point for wider tiles
         self.fused_convbn = bool(fused_convbn) and not self.mlp_bf16
-        # native engine (ps_train_options.fused_convbn): c = 8 on one-thread-per-row kernels (csrc/convbn_rows.hip, also in the bf16-MLP mode:
-        # an 8 x 8 product has no matrix-pipe shape and stays fp32 there), wider layers on the tile kernels in fp32 mode
+        # native engine (ps_train_options.fused_convbn): c = 8 on one-thread-per-row kernels (csrc/convbn_rows.hip; fp32 also in the bf16-MLP
+        # mode: an 8 x 8 product has no matrix-pipe shape), wider layers on the tile kernels, which round their operands in the bf16 mode
         self._fused_convbn_native = bool(fused_convbn)
         self.sync_bn = bool(sync_bn)
         self.cfg = config

@@ -1114,8 +1114,9 @@ def test_square_conv_bn_passes_of_the_native_step_against_float64_autograd():
 def test_native_step_with_recomputed_square_convolutions():
     """Trainer(fused_convbn=True) (ps_train_options.fused_convbn: LFA mlp2 of every level with h <= 64 in the recompute form) against the
     op-by-op native step: same parameters and clouds, one step.  fp32: loss 2e-6, logits 2e-5 of their magnitude, moving statistics 1e-5,
-    gradients 5e-3 relative L2 (the bar between the two engines; the recompute form sums in a different order).  bf16-MLP mode: only the
-    h = 8 layer changes (its product has no matrix-pipe shape and is fp32 in both forms) -- held to the bf16 bars of the engine test.
+    gradients 5e-3 relative L2 (the bar between the two engines; the recompute form sums in a different order).  bf16-MLP mode: the
+    tile kernels round the operands of their products like the GEMMs they replace (the h = 8 layer is fp32 in both forms) -- held to the
+    bf16 bars of the engine test.
     Also: two runs of the fused step give bit-identical gradients."""
     import torch
     from point_unet_amd import weights
