@@ -358,6 +358,27 @@ int ps_op_conv_bn_train_bwd_apply_w(ps_context* ctx, const float* x, int64_t ldx
                                     const float* mean, const float* invstd, const float* scale, const float* beta, const float* s12,
                                     float inv_rows, const float* dz, int64_t lddz, int accumulate, float* dx, int64_t lddx, float* dw,
                                     float* db);
+/* The same recompute scheme for the shared MLPs that WIDEN their rows (csrc/rectconv_train.hip): conv2d(cin -> cout, bias) +
+ * batch_normalization(training=True) [+ LeakyReLU when leaky != 0] on [R, cin] rows -- Encoder mlp2 / shortcut (RandLANet.py:312-321, no
+ * activation) and fc1 (:145).  (cin, cout) in {(8,32), (16,32), (32,64), (32,128), (64,128)} (ps_op_convbn_train_supported); rows 16-byte
+ * aligned, pitches % 4 == 0.  3 cin + 11 cout row passes op by op become 5 cin + 3 cout.
+ *   _sums      : sums = sum y [cout] | sum y^2 [cout] in float64 (SyncBN: all-reduce, then mean / variance)
+ *   _apply     : out[r, :] = act((y - mean) scale + beta), scale = gamma invstd
+ *   _bwd_sums  : s12 = S1 [cout] | S2 [cout] (dbeta | dgamma; SyncBN: all-reduce)
+ *   _bwd_apply : dx (+)= dy . w^T (dx may be NULL), dw [cin, cout] and db [cout] overwritten; s12 of all ranks, inv_rows = 1 / rows of all ranks
+ * Deterministic; bf16-MLP mode (ps_set_train_gemm_bf16, cin % 16 == 0): operands of the three products rounded to bfloat16 first. */
+int ps_op_convbn_train_supported(int64_t cin, int64_t cout);
+int ps_op_convbn_train_sums(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t cin,
+                            int64_t cout, double* sums);
+int ps_op_convbn_train_apply(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t cin,
+                             int64_t cout, const float* mean, const float* scale, const float* beta, int leaky, float* out, int64_t ldo);
+int ps_op_convbn_train_bwd_sums(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t cin,
+                                int64_t cout, const float* mean, const float* invstd, const float* scale, const float* beta, int leaky,
+                                const float* dz, int64_t lddz, float* s12);
+int ps_op_convbn_train_bwd_apply(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t cin,
+                                 int64_t cout, const float* mean, const float* invstd, const float* scale, const float* beta, int leaky,
+                                 const float* s12, float inv_rows, const float* dz, int64_t lddz, int accumulate, float* dx,
+                                 int64_t lddx, float* dw, float* db);
 /* ---- deterministic scatter-adds (csrc/invidx.hip).  The backward of tf.batch_gather (gather_neighbour, nearest_interpolation,
  * random_sample: RandLANet.py:345-386) adds gradient rows onto the rows they were gathered from; with float atomics the order of the
  * additions changes from run to run.  ps_op_inverse_index inverts a gather table idx i32[B, rows_per_cloud] (values in [0, N)):
@@ -437,7 +458,8 @@ typedef struct {
     int32_t ignored_label_inds[8];
     int32_t deterministic;          /* every scatter-add of the backward pass as a fixed-order gather-reduction over an inverse index built
                                      * once per level and step (csrc/invidx.hip): two runs of a step give bit-identical gradients */
-    int32_t fused_convbn;           /* LFA mlp2 (conv h -> h + BatchNorm + LeakyReLU on the [N*K, h] rows, RandLANet.py:331) with the pre-BatchNorm
+    int32_t fused_convbn;           /* LFA mlp2 (conv h -> h + BatchNorm + LeakyReLU on the [N*K, h] rows, RandLANet.py:331) and the widening shared
+                                     * MLPs (Encoder mlp2 / shortcut, fc1: ps_op_convbn_train_supported) with the pre-BatchNorm
                                      * product recomputed instead of stored (h <= 64; in the bf16-MLP mode the operands of its three products are
                                      * rounded like the GEMMs it replaces -- h % 16 == 0 --, the 8-channel layer stays fp32 in both forms) */
 } ps_train_options;

@@ -124,6 +124,15 @@ PROTOTYPES = {
                                                      ctypes.c_int64, c_vp]),
     "ps_op_conv_bn_train_bwd_apply_w": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                                        ctypes.c_float, c_vp, ctypes.c_int64, ctypes.c_int, c_vp, ctypes.c_int64, c_vp, c_vp]),
+    "ps_op_convbn_train_supported": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64]),
+    "ps_op_convbn_train_sums": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp]),
+    "ps_op_convbn_train_apply": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, c_vp,
+                                                ctypes.c_int, c_vp, ctypes.c_int64]),
+    "ps_op_convbn_train_bwd_sums": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, c_vp,
+                                                   c_vp, ctypes.c_int, c_vp, ctypes.c_int64, c_vp]),
+    "ps_op_convbn_train_bwd_apply": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, c_vp,
+                                                    c_vp, ctypes.c_int, c_vp, ctypes.c_float, c_vp, ctypes.c_int64, ctypes.c_int, c_vp, ctypes.c_int64, c_vp,
+                                                    c_vp]),
     "ps_op_locse_train_supported": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64]),
     "ps_op_locse_train_sums": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, c_vp]),
     "ps_op_locse_train_apply": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, c_vp, c_vp,

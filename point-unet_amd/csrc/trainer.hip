@@ -807,6 +807,63 @@ struct ps_trainer {
         return z;
     }
 
+    // The widening shared MLPs (Encoder mlp2 / shortcut, fc1) in the same recompute form (rectconv_train.hip): cin -> cout with cout > cin,
+    // 5 cin + 3 cout row passes instead of 3 cin + 11 cout.
+    bool convbn_rect_ok(const Tn& x, const LayerP& lp) const
+    {
+        if (!opt.fused_convbn || lp.kind == kDeconv || lp.b < 0 || lp.gamma < 0 || !ps_op_convbn_train_supported(lp.cin, lp.cout)) return false;
+        static const int max_w = [] { const char* e = getenv("PS_CONVBN_RECT_MAX"); return e ? atoi(e) : 1 << 30; }();  // (A/B knob: cin * cout)
+        if (lp.cin * lp.cout > max_w) return false;
+        return x.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x.p) & 15) == 0;
+    }
+    Tn conv_bn_rect(const Tn& x, const LayerP& lp, bool leaky)
+    {
+        const int64_t R = x.R, ci = lp.cin, co = lp.cout;
+        const bool sync = sync_bn && coll && world > 1;
+        const int64_t R_total = sync ? R * world : R;
+        const float *W = params + lp.w, *b = params + lp.b, *gamma = params + lp.gamma, *beta = params + lp.beta;
+        Tn sums = alloc(1, 4 * co, false);  // 2 cout doubles: sum y | sum y^2
+        double* s64 = reinterpret_cast<double*>(sums.p);
+        TK(ps_op_convbn_train_sums(c, x.p, x.ld, W, b, R, ci, co, s64));
+        if (sync) allreduce(s64, 2 * co, 1);
+        Tn st4 = alloc(4, co, false);  // mean | var | invstd | scale
+        float *mean = st4.p, *invstd = st4.p + 2 * co, *scale = st4.p + 3 * co;
+        {
+            Stage st(c, "train_convbn_fwd", 1);
+            hipLaunchKernelGGL(tr_locse_stats_kernel, dim3(ceil_div(co, 64)), dim3(64), 0, stream(), s64, (double)R_total, gamma, (int)co, kBnEps, st4.p,
+                               buffers + lp.mov_mean, buffers + lp.mov_var, kBnMomentum, (int)co);
+            TK_HIP(hipGetLastError());
+        }
+        Tn z = alloc(R, co);
+        TK(ps_op_convbn_train_apply(c, x.p, x.ld, W, b, R, ci, co, mean, scale, beta, leaky ? 1 : 0, z.p, z.ld));
+        float *gW = grads + lp.w, *gb = grads + lp.b, *ggamma = grads + lp.gamma, *gbeta = grads + lp.beta;
+        record(z, [=](const Tn& dz_in) {
+            const bool dz_ok = dz_in.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(dz_in.p) & 15) == 0;
+            const Tn dz = dz_ok ? dz_in : contig(dz_in);
+            Tn acc = alloc(1, 2 * co, false);
+            TK(ps_op_convbn_train_bwd_sums(c, x.p, x.ld, W, b, R, ci, co, mean, invstd, scale, beta, leaky ? 1 : 0, dz.p, dz.ld, acc.p));
+            Tn tot = alloc(2, co, false);
+            {
+                Stage st(c, "train_convbn_bwd", 1);
+                hipLaunchKernelGGL(tr_locse_local_kernel, dim3(ceil_div(co, 64)), dim3(64), 0, stream(), acc.p, (int)co, ggamma, gbeta, tot.p);
+                TK_HIP(hipGetLastError());
+            }
+            if (sync) allreduce(tot.p, 2 * co, 0);
+            Tn dx;
+            int add = 0;
+            if (x.req) {
+                auto it = grad_of.find(x.id);
+                add = it != grad_of.end() && it->second.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(it->second.p) & 15) == 0 ? 1 : 0;
+                dx = add ? it->second : alloc(R, ci);
+            }
+            TK(ps_op_convbn_train_bwd_apply(c, x.p, x.ld, W, b, R, ci, co, mean, invstd, scale, beta, leaky ? 1 : 0, tot.p, 1.0f / (float)R_total, dz.p, dz.ld, add,
+                                            x.req ? dx.p : nullptr, x.req ? dx.ld : 0, gW, gb));
+            if (x.req && !add) accum(x, dx);
+            (void)st4;
+        });
+        return z;
+    }
+
     // x [B*N, d], idx [B, M, K] -> [B*M*K, d]; out: optional column block of a wider tensor that receives the rows
     Tn gather(const Tn& x_in, const int32_t* idx, int64_t B, int64_t M, int64_t K, const Tn* out = nullptr)
     {
@@ -992,6 +1049,7 @@ struct ps_trainer {
     Tn conv(const Tn& x, const std::string& scope, bool bn = true, bool act = true, const Tn* out = nullptr, bool fp32_only = false, bool defer_dgrad = false)
     {
         const LayerP& lp = layer(scope);
+        if (bn && !out && !fp32_only && !defer_dgrad && convbn_rect_ok(x, lp)) return conv_bn_rect(x, lp, act);
         Tn y = linear(x, Wt(lp), lp.b >= 0 ? params + lp.b : nullptr, gWt(lp), lp.b >= 0 ? grads + lp.b : nullptr, lp.kind == kDeconv, nullptr, fp32_only,
                       defer_dgrad);
         if (bn) y = bn_act(y, lp, act, out);

@@ -1111,8 +1111,77 @@ def test_square_conv_bn_passes_of_the_native_step_against_float64_autograd():
 
 
 @pytest.mark.gpu
+def test_widening_conv_bn_passes_against_float64_autograd():
+    """ps_op_convbn_train_* (csrc/rectconv_train.hip: conv cin -> cout + BatchNorm(train) [+ LeakyReLU] with the pre-BatchNorm product recomputed;
+    Encoder mlp2 / shortcut and fc1 of the native step) against torch float64 autograd for every compiled (cin, cout): batch statistics,
+    output with and without the activation, S1 / S2 (= dbeta / dgamma), dx fresh / added to an existing gradient / not asked for, dW, db;
+    ragged row counts, strided x; the backward run twice for bit-identical results."""
+    import ctypes
+    import torch
+    from point_unet_amd import runtime, _lib
+    from point_unet_amd.train import BN_EPS
+    ctx = runtime.default_context(0)
+    L = _lib.lib()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    g = torch.Generator().manual_seed(23)
+    assert not L.ps_op_convbn_train_supported(32, 32) and not L.ps_op_convbn_train_supported(64, 32)
+    for (CI, CO), R, leaky in (((8, 32), 10007, 0), ((16, 32), 70001, 1), ((32, 64), 5003, 1), ((32, 128), 3001, 0), ((64, 128), 4099, 0), ((64, 128), 777, 1)):
+        assert L.ps_op_convbn_train_supported(CI, CO)
+        wide = torch.randn(R, CI + 8, generator=g).cuda()
+        x = wide[:, 4:CI + 4]
+        ldx = CI + 8
+        W = (torch.randn(CI, CO, generator=g) / CI ** 0.5).cuda()
+        b = (0.1 * torch.randn(CO, generator=g)).cuda()
+        gamma, beta = (1 + 0.2 * torch.randn(CO, generator=g)).cuda(), (0.1 * torch.randn(CO, generator=g)).cuda()
+        dz = torch.randn(R, CO, generator=g).cuda()
+        Xd = x.double().clone().requires_grad_(True)
+        Wd, bd, gd, btd = [v.double().clone().requires_grad_(True) for v in (W, b, gamma, beta)]
+        yy = Xd @ Wd + bd
+        mean_d, var_d = yy.mean(0), yy.var(0, unbiased=False)
+        z_d = (yy - mean_d) / torch.sqrt(var_d + BN_EPS) * gd + btd
+        if leaky:
+            z_d = torch.nn.functional.leaky_relu(z_d, 0.2)
+        (z_d * dz.double()).sum().backward()
+        sums = torch.zeros(2 * CO, dtype=torch.float64).cuda()
+        assert L.ps_op_convbn_train_sums(ctx.handle, vp(x), ldx, vp(W), vp(b), R, CI, CO, vp(sums)) == 0
+        mean64 = sums[:CO] / R
+        var64 = (sums[CO:] / R - mean64 * mean64).clamp_min(0)
+        assert (mean64 - mean_d.detach()).abs().max().item() <= 1e-6 and (var64 - var_d.detach()).abs().max().item() <= 1e-6 * var_d.max().item() + 1e-7
+        mean, var = mean64.float(), var64.float()
+        invstd = torch.rsqrt(var + BN_EPS)
+        scale = gamma * invstd
+        z = torch.empty(R, CO).cuda()
+        assert L.ps_op_convbn_train_apply(ctx.handle, vp(x), ldx, vp(W), vp(b), R, CI, CO, vp(mean), vp(scale), vp(beta), leaky, vp(z), CO) == 0
+        rel = lambda a, r: (a.double() - r).abs().max().item() / r.abs().max().item()  # noqa: E731
+        assert rel(z, z_d.detach()) <= 2e-6, (CI, CO, rel(z, z_d.detach()))
+        s12 = torch.zeros(2 * CO).cuda()
+        assert L.ps_op_convbn_train_bwd_sums(ctx.handle, vp(x), ldx, vp(W), vp(b), R, CI, CO, vp(mean), vp(invstd), vp(scale), vp(beta), leaky, vp(dz), CO,
+                                             vp(s12)) == 0
+        assert rel(s12[:CO], btd.grad) <= 2e-5 and rel(s12[CO:], gd.grad) <= 2e-5
+        first = None
+        for prior in (0, 1, 1, None):
+            extra = torch.randn(R, CI, generator=torch.Generator().manual_seed(5)).cuda()
+            dx = None if prior is None else (extra.clone() if prior else torch.full((R, CI), float("nan")).cuda())
+            dw, db = torch.full((CI, CO), float("nan")).cuda(), torch.full((CO,), float("nan")).cuda()
+            assert L.ps_op_convbn_train_bwd_apply(ctx.handle, vp(x), ldx, vp(W), vp(b), R, CI, CO, vp(mean), vp(invstd), vp(scale), vp(beta), leaky, vp(s12),
+                                                  ctypes.c_float(1.0 / R), vp(dz), CO, 1 if prior else 0, vp(dx), CI, vp(dw), vp(db)) == 0
+            torch.cuda.synchronize()
+            errs = dict(dW=rel(dw, Wd.grad), db=(db.double() - bd.grad).abs().max().item() / Wd.grad.abs().max().item())
+            if dx is not None:
+                errs["dx"] = rel(dx, Xd.grad + (extra.double() if prior else 0))
+            print(CI, CO, R, leaky, prior, errs)
+            assert max(errs.values()) <= 2e-5, (CI, CO, R, errs)
+            if prior == 1:
+                if first is None:
+                    first = (dx.clone(), dw.clone(), db.clone())
+                else:
+                    assert torch.equal(first[0], dx) and torch.equal(first[1], dw) and torch.equal(first[2], db)
+
+
+@pytest.mark.gpu
 def test_native_step_with_recomputed_square_convolutions():
-    """Trainer(fused_convbn=True) (ps_train_options.fused_convbn: LFA mlp2 of every level with h <= 64 in the recompute form) against the
+    """Trainer(fused_convbn=True) (ps_train_options.fused_convbn: LFA mlp2 of every level with h <= 64, and the widening shared MLPs -- Encoder
+    mlp2 / shortcut of levels 0-1, fc1 --, in the recompute form) against the
     op-by-op native step: same parameters and clouds, one step.  fp32: loss 2e-6, logits 2e-5 of their magnitude, moving statistics 1e-5,
     gradients 5e-3 relative L2 (the bar between the two engines; the recompute form sums in a different order).  bf16-MLP mode: the
     tile kernels round the operands of their products like the GEMMs they replace (the h = 8 layer is fp32 in both forms) -- held to the
