@@ -24,6 +24,9 @@
 #include "mfma_tile.h"
 #include "reduce_partials.h"
 
+#include <map>
+#include <mutex>
+
 namespace ps {
 
 __device__ __forceinline__ float round_bf16(float x)
@@ -654,6 +657,25 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
     }
 }
 
+// Workgroups per launch: every workgroup walks the points with the same stride, so a grid that is not a multiple of what the chip holds at
+// once ends with a round at partial occupancy (the d = 16 backward: 77 VGPRs allow three 8-wave workgroups per CU where the LDS footprint
+// alone allows four -- 1024 workgroups ran as 768 + 256, the second round as long as the first).  Ask the runtime what fits.
+static int att_resident_blocks(const void* kern, int threads, size_t smem, int lds_guess)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void*, size_t>, int> cache;  // (asked once per kernel and LDS size)
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({kern, smem});
+    if (it != cache.end()) return it->second;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, smem) != hipSuccess || occ < 1) {
+        (void)hipGetLastError();
+        occ = lds_guess;
+    }
+    cache[{kern, smem}] = occ;
+    return occ;
+}
+
 template <int D>
 static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float* dW)
 {
@@ -670,16 +692,19 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
         if (backward) smem = std::max(smem, sizeof(float) * (size_t)WAVES * D * D);
         PS_CHECK(smem <= 160 * 1024, "att_pool_train: %zu bytes of LDS needed", smem);
         const int per_cu = std::max(1, std::min(4, (int)(160 * 1024 / smem)));
-        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + WAVES - 1) / WAVES, 256 * per_cu));
         if (!backward) {
             auto kern = att_train_fwd_bf16_kernel<D, KN, WAVES>;
             if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            const int occ = std::min(per_cu, att_resident_blocks(reinterpret_cast<const void*>(kern), WAVES * 64, smem, per_cu));
+            const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + WAVES - 1) / WAVES, 256 * occ));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
         } else {
-            PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * D * D + 256));
-            a.dw_part = c->red_ws.as<float>();
             auto kern = att_train_bwd_bf16_kernel<D, KN, WAVES>;
             if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            const int occ = std::min(per_cu, att_resident_blocks(reinterpret_cast<const void*>(kern), WAVES * 64, smem, per_cu));
+            const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + WAVES - 1) / WAVES, 256 * occ));
+            PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * D * D + 256));
+            a.dw_part = c->red_ws.as<float>();
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
             hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(ceil_div(D * D, 16)), dim3(256), 0, c->stream, static_cast<const float*>(a.dw_part), blocks, D * D, dW);
         }
@@ -691,16 +716,19 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
     if (backward) smem = std::max(smem, sizeof(float) * (size_t)WAVES * D * D);
     PS_CHECK(smem <= 160 * 1024, "att_pool_train: %zu bytes of LDS needed", smem);
     const int per_cu = std::max(1, std::min(4, (int)(160 * 1024 / smem)));
-    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + WAVES - 1) / WAVES, 256 * per_cu));
     if (!backward) {
         auto kern = att_train_fwd_kernel<D, KN, WAVES>;
         if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const int occ = std::min(per_cu, att_resident_blocks(reinterpret_cast<const void*>(kern), WAVES * 64, smem, per_cu));
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + WAVES - 1) / WAVES, 256 * occ));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
     } else {
-        PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * D * D + 256));
-        a.dw_part = c->red_ws.as<float>();
         auto kern = att_train_bwd_kernel<D, KN, WAVES>;
         if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const int occ = std::min(per_cu, att_resident_blocks(reinterpret_cast<const void*>(kern), WAVES * 64, smem, per_cu));
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + WAVES - 1) / WAVES, 256 * occ));
+        PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * D * D + 256));
+        a.dw_part = c->red_ws.as<float>();
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
         hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(ceil_div(D * D, 16)), dim3(256), 0, c->stream, static_cast<const float*>(a.dw_part), blocks, D * D, dW);
     }
