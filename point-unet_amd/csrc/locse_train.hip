@@ -277,7 +277,16 @@ static int locse_launch(ps_context* c, LocseArgs a, int what, float* result)
     const int nv = what == 0 ? 2 * H : 23 * H + 16;
     const int64_t per_block = 4 * (64 / (H / 4));  // rows per workgroup and step
     if (what == 1) {
-        const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((a.rows + per_block - 1) / per_block, 256 * 8));
+        // (a multiple of what the chip holds at once: all workgroups walk the rows with the same stride, a partial last round costs a full one)
+        static const int occ = [] {
+            int o = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, reinterpret_cast<const void*>(locse_apply_kernel<H>), 256, 0) != hipSuccess || o < 1) {
+                (void)hipGetLastError();
+                o = 4;
+            }
+            return o;
+        }();
+        const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((a.rows + per_block - 1) / per_block, 256 * std::min(occ, 8)));
         hipLaunchKernelGGL(locse_apply_kernel<H>, dim3(blocks), dim3(256), 0, c->stream, a);
     } else {
         const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((a.rows + per_block - 1) / per_block, 256 * 4));
