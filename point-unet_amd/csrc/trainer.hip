@@ -1070,7 +1070,9 @@ struct ps_trainer {
         const Tn W = P(fc.w, fc.cin, fc.cout), gW = G(fc.w, fc.cin, fc.cout);
         const int64_t h = f_src.C;
         Tn s = gather(linear(f_src, rows_of(W, 0, h), nullptr, rows_of(gW, 0, h), nullptr), idx, B, M, K);
-        s = linear(f_xyz, rows_of(W, h, W.R - h), nullptr, rows_of(gW, h, W.R - h), nullptr, false, &s);
+        // (defer_dgrad: f_xyz's other gradient is a column block of this pooling's dF, handed on by the concat's backward AFTER this product's;
+        //  parked, the input-gradient GEMM adds into that view in its epilogue instead of a strided add pass folding the view into its output)
+        s = linear(f_xyz, rows_of(W, h, W.R - h), nullptr, rows_of(gW, h, W.R - h), nullptr, false, &s, false, true);
         return conv(softpool(fcat, s, K), name + "mlp");
     }
     Tn att(const Tn& fcat, const std::string& name, int64_t K)
