@@ -91,6 +91,7 @@ struct ps_context {
     bool train_b3 = true;     // ps_set_train_gemm_b3: large fp32 op-level GEMMs on bf16 MFMA over exact three-way splits (gemm_b3.hip)
     bool conv_w_transposed = false;  // (internal, set around a call by the native trainer) ps_op_conv1x1_ex: w is stored [cout, cin]
     bool att_df_accum = false;  // (internal, set around a call by the native trainer) ps_op_att_pool_train_bwd_split*: dfr += instead of dfr =
+    bool pool_bwd_overwrite = false;  // ps_op_random_sample_bwd_inv (tie-count form) STORES the gradient instead of adding into a zeroed buffer (trainer.hip)
     bool train_bf16 = false;  // ps_set_train_gemm_bf16: the op-level GEMMs round their operands to bf16 (fp32 accumulate)
     // per-device kernel attributes already raised by this context (dynamic LDS above the default limit)
     bool mid_lds_attr = false;

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_inv_kernel(const float* __res
 __global__ __launch_bounds__(256) void maxpool_bwd_inv4_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ ties,
                                                                const float* __restrict__ out, const float* __restrict__ feat,
                                                                const unsigned* __restrict__ offsets, const int32_t* __restrict__ src, unsigned n_dst,
-                                                               unsigned n_cloud, unsigned m_cloud, unsigned K, unsigned d4, float* __restrict__ dfeat)
+                                                               unsigned n_cloud, unsigned m_cloud, unsigned K, unsigned d4, float* __restrict__ dfeat,
+                                                               int overwrite)
 {
     const unsigned total = n_dst * d4;
     const float4* out4 = reinterpret_cast<const float4*>(out);
@@ -176,7 +177,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_inv4_kernel(const float* __re
     for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
         const unsigned j = t / d4, q = t - j * d4;
         const unsigned lo = offsets[j], hi = offsets[j + 1];
-        if (lo == hi) continue;
+        if (lo == hi) {
+            if (overwrite) reinterpret_cast<float4*>(dfeat)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
         const unsigned b = j / n_cloud;
         const unsigned first = b * n_cloud, mbase = b * m_cloud;
         const float4 f = reinterpret_cast<const float4*>(feat)[t];
@@ -196,9 +200,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_inv4_kernel(const float* __re
             }
         }
         float4* dst = reinterpret_cast<float4*>(dfeat) + t;
-        float4 h = *dst;
-        h.x += acc.x; h.y += acc.y; h.z += acc.z; h.w += acc.w;
-        *dst = h;
+        if (overwrite) {
+            *dst = acc;
+        } else {
+            float4 h = *dst;
+            h.x += acc.x; h.y += acc.y; h.z += acc.z; h.w += acc.w;
+            *dst = h;
+        }
     }
 }
 
@@ -297,10 +305,12 @@ int ps_op_random_sample_bwd_inv(ps_context* c, const float* dout, const float* o
                         reinterpret_cast<uintptr_t>(dfeature)) & 15) == 0 && (reinterpret_cast<uintptr_t>(ties) & 3) == 0;
     if (ties && d % 4 == 0 && al16 && B * N * d < (1ll << 32) && B * N * K < (1ll << 31)) {
         hipLaunchKernelGGL(maxpool_bwd_inv4_kernel, dim3(iv_grid(B * N * (d / 4))), dim3(256), 0, c->stream, dout, ties, out, feature,
-                           reinterpret_cast<const unsigned*>(offsets), src, (unsigned)(B * N), (unsigned)N, (unsigned)M, (unsigned)K, (unsigned)(d / 4), dfeature);
+                           reinterpret_cast<const unsigned*>(offsets), src, (unsigned)(B * N), (unsigned)N, (unsigned)M, (unsigned)K, (unsigned)(d / 4), dfeature,
+                           c->pool_bwd_overwrite ? 1 : 0);
         PS_HIP(hipGetLastError());
         return PS_OK;
     }
+    PS_CHECK(!c->pool_bwd_overwrite, "ps_op_random_sample_bwd_inv: the overwriting form needs tie counts, d % 4 == 0 and 16-byte aligned rows");
     if (ties) {
         hipLaunchKernelGGL(maxpool_bwd_inv_kernel<true>, dim3(iv_grid(B * N * d)), dim3(256), 0, c->stream, dout, ties, out, feature,
                            reinterpret_cast<const unsigned*>(offsets), src, B * N, (int)N, (int)M, (int)K, (int)d, dfeature);

@@ -874,6 +874,15 @@ struct ps_trainer {
         TK(ps_op_gather_neighbour_ex(c, x.p, idx, B, N, M, K, d, o.p, o.ld));
         const Tn xin = x_in;
         record(o, [=](const Tn& dy) {
+            if (opt.deterministic && !grad_of.count(xin.id)) {
+                // first gradient of x: the gather-reduction writes every row (empty segments as zeros): no zero-filled buffer to add into
+                Tn fresh = alloc(xin.R, xin.C);
+                const Inv& iv = inverse(idx, B, N, M * K);
+                TK(ps_op_gather_reduce_rows(c, dy.p, dy.ld, reinterpret_cast<const int32_t*>(iv.offsets.p), reinterpret_cast<const int32_t*>(iv.src.p), B * N, d,
+                                            fresh.p, fresh.ld, 0));
+                grad_of[xin.id] = fresh;
+                return;
+            }
             Tn buf = accum_buffer(xin);
             if (!buf.contiguous()) {
                 ps::set_error("trainer: scatter-add into a strided gradient");
@@ -955,14 +964,16 @@ struct ps_trainer {
                 Flag(ps_context* ctx, bool on) : c(ctx) { c->att_df_accum = on; }
                 ~Flag() { c->att_df_accum = false; }
             } flag(c, add_in_place);
-            Tn dsrc = accum_buffer(f_src);  // the gathered half's gradient is added in place
+            const bool fresh_src = opt.deterministic && !grad_of.count(f_src.id);  // (first gradient of f_src: written, not added into zeros)
+            Tn dsrc = fresh_src ? alloc(f_src.R, f_src.C) : accum_buffer(f_src);  // the gathered half's gradient is added in place
             if (opt.deterministic) {
                 // ... as plain rows first, then summed per source row in ascending row order (no float atomics)
                 Tn rows = alloc(B * M * K, h, false);
                 TK(ps_op_att_pool_train_bwd_split_rows(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, dy.p, K, d, rows.p, h, dfx.p, dfx.ld, gW.p));
                 const Inv& iv = inverse(idx, B, N, M * K);
                 TK(ps_op_gather_reduce_rows(c, rows.p, h, reinterpret_cast<const int32_t*>(iv.offsets.p), reinterpret_cast<const int32_t*>(iv.src.p), B * N, h,
-                                            dsrc.p, dsrc.ld, 1));
+                                            dsrc.p, dsrc.ld, fresh_src ? 0 : 1));
+                if (fresh_src) grad_of[f_src.id] = dsrc;
             } else {
                 TK(ps_op_att_pool_train_bwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, dy.p, K, d, dsrc.p, dsrc.ld, dfx.p, dfx.ld, gW.p));
             }
@@ -988,7 +999,16 @@ struct ps_trainer {
         const Tn xin = x_in;
         record(out, [=](const Tn& dy_in) {
             const Tn dy = contig(dy_in);
-            Tn buf = accum_buffer(xin);
+            // (first gradient of x, tie-count form: the kernel stores -- zeros where nothing was pooled from a row -- instead of adding into a
+            //  zero-filled buffer)
+            const bool fresh = opt.deterministic && ties && !grad_of.count(xin.id) && xin.contiguous() && (reinterpret_cast<uintptr_t>(dy.p) & 15) == 0;
+            Tn buf = fresh ? alloc(xin.R, xin.C) : accum_buffer(xin);
+            if (fresh) grad_of[xin.id] = buf;
+            struct Flag {
+                ps_context* c;
+                Flag(ps_context* ctx, bool on) : c(ctx) { c->pool_bwd_overwrite = on; }
+                ~Flag() { c->pool_bwd_overwrite = false; }
+            } flag(c, fresh);
             if (opt.deterministic && buf.contiguous()) {
                 const Inv& iv = inverse(neigh, B, N, N * K);  // (shared with the level's gathers: the pooling rows are a prefix of every segment)
                 Tn share = ties ? Tn() : alloc(B * M, d, false);
