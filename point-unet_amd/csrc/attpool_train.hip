@@ -261,7 +261,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_fwd_kernel(AttTrainArgs 
             }
             ssum = xor_sum(ssum);
             num = xor_sum(num);
-            if (g == 0) a.agg[(size_t)p * D + ct * 16 + c16] = num / ssum;
+            if (g == 0) a.agg[(size_t)p * D + ct * 16 + c16] = num * __builtin_amdgcn_rcpf(ssum);  // (v_rcp_f32, 1 ulp: the IEEE division is ten instructions in an issue-bound loop)
         }
         wave_lds_sync();
     }
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
             }
             ssum = xor_sum(ssum);
             num = xor_sum(num);
-            const float inv = 1.f / ssum, agg = num * inv;
+            const float inv = __builtin_amdgcn_rcpf(ssum), agg = num * inv;
             const float gch = gcur[ct];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_fwd_bf16_kernel(AttTrain
             }
             ssum = xor_sum(ssum);
             num = xor_sum(num);
-            if (g == 0) a.agg[(size_t)p * D + ct * 16 + c16] = num / ssum;
+            if (g == 0) a.agg[(size_t)p * D + ct * 16 + c16] = num * __builtin_amdgcn_rcpf(ssum);  // (v_rcp_f32, 1 ulp: the IEEE division is ten instructions in an issue-bound loop)
         }
         wave_lds_sync();
     }
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
             }
             ssum = xor_sum(ssum);
             num = xor_sum(num);
-            const float inv = 1.f / ssum, agg = num * inv;
+            const float inv = __builtin_amdgcn_rcpf(ssum), agg = num * inv;
             const float gch = gcur[ct];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
