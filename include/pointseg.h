@@ -294,6 +294,8 @@ int ps_op_softmax_pool_bwd_scores(ps_context* ctx, const float* dagg, const floa
  * backward recomputes them from fset and returns dfset (row stride lddf, overwritten) and dwfc [d,d] (overwritten; summed in a
  * fixed order: deterministic).  K = 16, d in {16, 32, 64} (ps_op_att_pool_train_supported); follows ps_set_train_gemm_bf16. */
 int ps_op_att_pool_train_supported(int64_t K, int64_t d);
+/* ... with the mode: d = 128 exists for the bf16-MLP mode only (both weight orientations as bfloat16 in LDS; ps_set_train_gemm_bf16 on) */
+int ps_op_att_pool_train_supported_ex(int64_t K, int64_t d, int bf16_mode);
 int ps_op_att_pool_train_fwd(ps_context* ctx, const float* fset, int64_t ld, const float* wfc, int64_t R, int64_t K, int64_t d,
                              float* agg);
 int ps_op_att_pool_train_bwd(ps_context* ctx, const float* fset, int64_t ld, const float* wfc, const float* dagg, int64_t R,

@@ -110,6 +110,7 @@ PROTOTYPES = {
     "ps_op_softmax_pool_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp, c_vp]),
     "ps_op_softmax_pool_bwd_scores": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp, c_vp]),
     "ps_op_att_pool_train_supported": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64]),
+    "ps_op_att_pool_train_supported_ex": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
     "ps_op_att_pool_train_fwd": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp] + [ctypes.c_int64] * 3 + [c_vp]),
     "ps_op_att_pool_train_bwd": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp, ctypes.c_int64, c_vp]),
     "ps_op_conv_bn_train_supported": (ctypes.c_int, [ctypes.c_int64]),

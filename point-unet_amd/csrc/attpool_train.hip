@@ -439,9 +439,12 @@ __device__ __forceinline__ unsigned bf16_pair(float a, float b)
 }
 __device__ __forceinline__ unsigned bf16_bits(float x) { return bf16_pair(x, 0.f) & 0xffffu; }
 
+// (dWfc partials per wave instead of per workgroup when the cross-wave reduction buffer would outgrow LDS)
+constexpr bool att_wave_partials(int D, int WAVES) { return (size_t)WAVES * D * D * sizeof(float) > 128 * 1024; }
+
 template <int D>
 struct AttBf16Geom {
-    static constexpr int PB = D == 16 ? 16 : (D == 32 ? 48 : 80);  // bfloat16 elements per tile / weight row: 32, 96, 160 bytes
+    static constexpr int PB = D == 16 ? 16 : (D == 32 ? 48 : (D == 64 ? 80 : 144));  // bfloat16 elements per tile / weight row: 32, 96, 160, 288 bytes
     static constexpr int PA = D + 2;                                // fp32 value tile (the weighted sum uses the unrounded F)
     static constexpr int NT = D / 16;
 };
@@ -661,6 +664,18 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
         if (a.vec_store) out.put(a, p, lane);
         wave_lds_sync();
     }
+    if constexpr (att_wave_partials(D, WAVES)) {
+        // d = 128: WAVES x D x D floats do not fit LDS -- every WAVE stores its own partial (the fixed-order reduction behind this kernel
+        // simply sees WAVES times as many rows)
+        float* dst = a.dw_part + ((size_t)blockIdx.x * WAVES + wave) * D * D;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(ti * 16 + 4 * g + r) * D + tj * 16 + c16] = dw[ti][tj][r];
+        return;
+    }
     // ---- the workgroup's dWfc partial: waves add up through LDS (fixed order), one plain store per element ----
     __syncthreads();
     float* red = smem;  // weights and tiles are dead: the whole buffer holds the WAVES partials (sized for it on the host)
@@ -702,6 +717,9 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
 {
     constexpr int KN = 16, WAVES = 8;
     constexpr int PW = AttTrainGeom<D>::PW, PA = AttTrainGeom<D>::PA;
+    // d = 128 exists on the bf16 matrix pipe only (both weight orientations as bfloat16: 74 KB; in fp32 they are 147 KB): four waves per
+    // workgroup in the backward (17.5 KB of tiles per wave, the 64 x 4 dWfc accumulators in AGPRs: one wave per SIMD), eight in the forward
+    constexpr int WAVES_F = 8, WAVES_B = D == 128 ? 4 : 8;
     if (backward) {
         auto al = [](const void* q, int ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0; };
         const bool rows_out = !a.fl || a.dfl_rows;  // (the atomic scatter form keeps its per-element path)
@@ -709,29 +727,35 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
     }
     if (a.bf16) {  // the bf16-MLP mode: operands kept as bfloat16 in LDS, products on the bf16 matrix pipe
         constexpr int PB = AttBf16Geom<D>::PB;
-        size_t smem = sizeof(float) * ((backward ? 2 : 1) * (size_t)(D * PB / 2) + (size_t)WAVES * (KN * PA + (backward ? 2 : 1) * (KN * PB / 2)));
-        if (backward) smem = std::max(smem, sizeof(float) * (size_t)WAVES * D * D);
+        const int waves = backward ? WAVES_B : WAVES_F;
+        size_t smem = sizeof(float) * ((backward ? 2 : 1) * (size_t)(D * PB / 2) + (size_t)waves * (KN * PA + (backward ? 2 : 1) * (KN * PB / 2)));
+        if (backward && !att_wave_partials(D, WAVES_B)) smem = std::max(smem, sizeof(float) * (size_t)WAVES_B * D * D);
         PS_CHECK(smem <= 160 * 1024, "att_pool_train: %zu bytes of LDS needed", smem);
         const int per_cu = std::max(1, std::min(4, (int)(160 * 1024 / smem)));
         if (!backward) {
-            auto kern = att_train_fwd_bf16_kernel<D, KN, WAVES>;
+            auto kern = att_train_fwd_bf16_kernel<D, KN, WAVES_F>;
             if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            const int occ = std::min(per_cu, att_resident_blocks(reinterpret_cast<const void*>(kern), WAVES * 64, smem, per_cu));
-            const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + WAVES - 1) / WAVES, 256 * occ));
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
+            const int occ = std::min(per_cu, att_resident_blocks(reinterpret_cast<const void*>(kern), WAVES_F * 64, smem, per_cu));
+            const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + WAVES_F - 1) / WAVES_F, 256 * occ));
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES_F * 64), smem, c->stream, a);
         } else {
-            auto kern = att_train_bwd_bf16_kernel<D, KN, WAVES>;
+            auto kern = att_train_bwd_bf16_kernel<D, KN, WAVES_B>;
             if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            const int occ = std::min(per_cu, att_resident_blocks(reinterpret_cast<const void*>(kern), WAVES * 64, smem, per_cu));
-            const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + WAVES - 1) / WAVES, 256 * occ));
-            PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * D * D + 256));
+            const int occ = std::min(per_cu, att_resident_blocks(reinterpret_cast<const void*>(kern), WAVES_B * 64, smem, per_cu));
+            const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + WAVES_B - 1) / WAVES_B, 256 * occ));
+            const int parts = att_wave_partials(D, WAVES_B) ? blocks * WAVES_B : blocks;
+            PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)parts * D * D + 256));
             a.dw_part = c->red_ws.as<float>();
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a);
-            hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(ceil_div(D * D, 16)), dim3(256), 0, c->stream, static_cast<const float*>(a.dw_part), blocks, D * D, dW);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES_B * 64), smem, c->stream, a);
+            hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(ceil_div(D * D, 16)), dim3(256), 0, c->stream, static_cast<const float*>(a.dw_part), parts, D * D, dW);
         }
         PS_HIP(hipGetLastError());
         return PS_OK;
     }
+    if constexpr (D == 128) {
+        set_error("att_pool_train: d = 128 is compiled for the bf16-MLP mode only (ps_set_train_gemm_bf16)");
+        return PS_EINVAL;
+    } else {
     const size_t tiles = (size_t)WAVES * (backward ? 2 : 1) * KN * PA;
     size_t smem = sizeof(float) * ((backward ? 2 : 1) * (size_t)D * PW + tiles);
     if (backward) smem = std::max(smem, sizeof(float) * (size_t)WAVES * D * D);
@@ -755,11 +779,12 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
     }
     PS_HIP(hipGetLastError());
     return PS_OK;
+    }
 }
 
 static bool att_train_ok(int64_t K, int64_t d, int64_t ld, const void* f)
 {
-    return K == 16 && (d == 16 || d == 32 || d == 64) && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(f) & 15) == 0;
+    return K == 16 && (d == 16 || d == 32 || d == 64 || d == 128) && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(f) & 15) == 0;
 }
 
 }  // namespace ps
@@ -767,6 +792,10 @@ static bool att_train_ok(int64_t K, int64_t d, int64_t ld, const void* f)
 using namespace ps;
 
 extern "C" int ps_op_att_pool_train_supported(int64_t K, int64_t d) { return K == 16 && (d == 16 || d == 32 || d == 64) ? 1 : 0; }
+extern "C" int ps_op_att_pool_train_supported_ex(int64_t K, int64_t d, int bf16_mode)
+{
+    return K == 16 && (d == 16 || d == 32 || d == 64 || (d == 128 && bf16_mode)) ? 1 : 0;
+}
 
 extern "C" int ps_op_att_pool_train_fwd(ps_context* c, const float* fset, int64_t ld, const float* wfc, int64_t R, int64_t K, int64_t d, float* agg)
 {
@@ -781,7 +810,8 @@ extern "C" int ps_op_att_pool_train_fwd(ps_context* c, const float* fset, int64_
     switch (d) {
         case 16: return launch_att_train<16>(c, a, false, nullptr);
         case 32: return launch_att_train<32>(c, a, false, nullptr);
-        default: return launch_att_train<64>(c, a, false, nullptr);
+        case 64: return launch_att_train<64>(c, a, false, nullptr);
+        default: return launch_att_train<128>(c, a, false, nullptr);
     }
 }
 
@@ -801,7 +831,8 @@ extern "C" int ps_op_att_pool_train_bwd(ps_context* c, const float* fset, int64_
     switch (d) {
         case 16: return launch_att_train<16>(c, a, true, dwfc);
         case 32: return launch_att_train<32>(c, a, true, dwfc);
-        default: return launch_att_train<64>(c, a, true, dwfc);
+        case 64: return launch_att_train<64>(c, a, true, dwfc);
+        default: return launch_att_train<128>(c, a, true, dwfc);
     }
 }
 
@@ -822,7 +853,8 @@ extern "C" int ps_op_att_pool_train_fwd_split(ps_context* c, const float* fl, in
     switch (d) {
         case 16: return launch_att_train<16>(c, a, false, nullptr);
         case 32: return launch_att_train<32>(c, a, false, nullptr);
-        default: return launch_att_train<64>(c, a, false, nullptr);
+        case 64: return launch_att_train<64>(c, a, false, nullptr);
+        default: return launch_att_train<128>(c, a, false, nullptr);
     }
 }
 
@@ -867,6 +899,7 @@ static int att_bwd_split_impl(ps_context* c, const float* fl, int64_t ldl, const
     switch (d) {
         case 16: return launch_att_train<16>(c, a, true, dwfc);
         case 32: return launch_att_train<32>(c, a, true, dwfc);
-        default: return launch_att_train<64>(c, a, true, dwfc);
+        case 64: return launch_att_train<64>(c, a, true, dwfc);
+        default: return launch_att_train<128>(c, a, true, dwfc);
     }
 }

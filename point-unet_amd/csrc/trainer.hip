@@ -1143,7 +1143,7 @@ struct ps_trainer {
             // directly (no concat copy forward, no split copies backward)
             const int64_t hc = f_pc.C;
             Tn f_agg2;
-            if (opt.fused_att && ps_op_att_pool_train_supported(K, 2 * hc)) {
+            if (opt.fused_att && ps_op_att_pool_train_supported_ex(K, 2 * hc, opt.mlp_bf16 ? 1 : 0)) {
                 // gather_neighbour + concat + att_pooling's core as one kernel per direction
                 Tn f_xyz = locse(nullptr);
                 Tn f_agg = att_split(f_pc, idx, B, N, K, f_xyz, n + "LFAatt_pooling_1");

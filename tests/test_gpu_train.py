@@ -415,7 +415,7 @@ def test_fused_attentive_pooling_forward_backward(mode):
     """ps_op_att_pool_train_fwd / _bwd (score product + softmax over K + weighted sum in one kernel per direction; the backward
     recomputes scores and probabilities) against torch float64 autograd of  agg = sum_K softmax_K(F.W) * F  -- for the bf16 mode with
     the operands of the three products rounded exactly as the kernel rounds them (F, W for the scores; dS, W^T for dF; F, dS for dW).
-    Strided input (a column block of a wider buffer), ragged point counts, d = 16 / 32 / 64.  Bars: agg 2e-6 (fp32) / 2e-5 (bf16) of its
+    Strided input (a column block of a wider buffer), ragged point counts, d = 16 / 32 / 64 (and 128 in the bf16 mode).  Bars: agg 2e-6 (fp32) / 2e-5 (bf16) of its
     max; dF and dW 2e-5 of their max in fp32; in the bf16 mode 2e-3 / 1e-3: dS is rounded to bfloat16 from its fp32 value in the
     kernel and from its float64 value here, and an element within fp32 noise of a rounding boundary lands on the neighbouring
     bfloat16 (a 4e-3 relative change of that one term).  The weight gradient is bit-identical from run to run (fixed summation order)."""
@@ -430,8 +430,11 @@ def test_fused_attentive_pooling_forward_backward(mode):
     K = 16
     try:
         _lib.check(L.ps_set_train_gemm_bf16(h, 1 if mode == "bf16" else 0))
-        for R, d, wide in [(1000, 16, 16), (4097, 16, 32), (777, 32, 32), (2049, 64, 64), (300, 64, 128)]:
-            assert L.ps_op_att_pool_train_supported(K, d) == 1
+        shapes = [(1000, 16, 16), (4097, 16, 32), (777, 32, 32), (2049, 64, 64), (300, 64, 128)]
+        if mode == "bf16":  # d = 128 (level 2) exists on the bf16 matrix pipe only: both weight orientations as bfloat16 in LDS
+            shapes += [(1500, 128, 128), (333, 128, 192)]
+        for R, d, wide in shapes:
+            assert L.ps_op_att_pool_train_supported_ex(K, d, 1 if mode == "bf16" else 0) == 1
             buf = torch.randn(R * K, wide, generator=g).cuda()
             F = buf[:, wide - d:]
             W = (torch.randn(d, d, generator=g) / d ** 0.5).cuda()
@@ -460,6 +463,7 @@ def test_fused_attentive_pooling_forward_backward(mode):
                 ((torch.softmax(Fa @ Wa, 1) * Fa).sum(1) * dagg.double()).sum().backward()
                 assert (dF_ref - Fa.grad).abs().max() < 1e-10 and (dW_ref - Wa.grad).abs().max() < 1e-9
         assert L.ps_op_att_pool_train_supported(K, 128) == 0 and L.ps_op_att_pool_train_supported(32, 16) == 0
+        assert L.ps_op_att_pool_train_supported_ex(K, 128, 0) == 0 and L.ps_op_att_pool_train_supported_ex(K, 128, 1) == 1
     finally:
         _lib.check(L.ps_set_train_gemm_bf16(h, 0))
     torch.cuda.synchronize()
