@@ -693,6 +693,194 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
     }
 }
 
+// ---- column-split backward (bf16 mode, d = 128): FOUR waves share one point ---------------------------------------------------------------
+// At d = 128 the kernel above holds 64 x 4 dWfc accumulators per wave (464 registers: one wave per SIMD) and 17.5 KB of tiles per wave next
+// to 74 KB of weights (four waves per CU): every point is one long serial chain -- fetch, scores, softmax, dS, two products, stores -- with
+// nothing to hide its latencies.  Here the four waves of a GROUP work on the same point and split the column tiles of every phase: a wave
+// computes the scores / softmax / dS of its D/64 column tiles (a 16 x 16 tile holds all K rows of its channels: the softmax stays inside
+// the wave), accumulates the matching columns of dWfc (64 x 4 / 4 accumulators), and -- once all of dS is in LDS -- its column tiles of
+// dF = p g + dS . Wfc^T.  The group shares ONE set of tiles, so a workgroup of GROUPS groups fits 4 GROUPS waves, each a quarter as long
+// per point.  Workgroup barriers separate the phases (all groups take the same number of iterations; a group past the end idles through
+// them).  Row outputs only (df / dfl_rows as 16-byte stores): the deterministic step's form.
+template <int D, int KN, int GROUPS>
+__global__ __launch_bounds__(GROUPS * 256) void att_train_bwd_bf16_cs_kernel(AttTrainArgs a)
+{
+    static_assert(KN == 16 && D % 64 == 0, "one 16-row tile per point, column tiles split over four waves");
+    constexpr int PB = AttBf16Geom<D>::PB, PA = AttBf16Geom<D>::PA, NT = D / 16, NTW = NT / 4;
+    constexpr int Q = D / 4, QH = Q / 2, TOT = KN * Q, NVG = TOT / 256;  // float4 per lane of the group's 256 lanes
+    static_assert(TOT % 256 == 0, "the tile divides over the group's lanes");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int W_FLOATS = D * PB / 2, TILE_FLOATS = KN * PA + 2 * (KN * PB / 2);
+    unsigned short* Wb = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* WTb = reinterpret_cast<unsigned short*>(smem + W_FLOATS);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int grp = wave >> 2, wj = wave & 3, glane = (wj << 6) | lane;
+    float* A = smem + 2 * W_FLOATS + grp * TILE_FLOATS;
+    unsigned short* Xb = reinterpret_cast<unsigned short*>(A + KN * PA);
+    unsigned short* Tb = Xb + KN * PB;
+    stage_weights_bf16<D, GROUPS * 256>(a.w, Wb, WTb);
+
+    f32x4 dw[NT][NTW];  // rows 16 ti.., this wave's column tiles wj * NTW + t
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) dw[ti][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int stride = (int)gridDim.x * GROUPS;
+    const int first_of_block = (int)blockIdx.x * GROUPS;
+    const int iters = first_of_block < a.R ? (int)((a.R - first_of_block + stride - 1) / stride) : 0;  // of the block's FIRST group: the most
+    PointWalk w(first_of_block + grp, stride, (int)a.n_q);
+
+    // this lane's share of a point's tile: elements glane, glane + 256, ...
+    float4 regs[NVG];
+    float gnext[NTW];
+    auto fetch = [&](const PointWalk& pw) {
+        const int64_t p = pw.p;
+        const int64_t base = (int64_t)pw.cloud * a.n_src;
+#pragma unroll
+        for (int i = 0; i < NVG; ++i) {
+            const int e = 256 * i + glane;
+            const int row = e / Q, q = e - row * Q;
+            if (!a.fl)
+                regs[i] = *reinterpret_cast<const float4*>(a.f + (size_t)(p * KN + row) * a.ld + 4 * q);
+            else if (q < QH)
+                regs[i] = *reinterpret_cast<const float4*>(a.fl + (size_t)(base + a.idx[p * KN + row]) * a.ldl + 4 * q);
+            else
+                regs[i] = *reinterpret_cast<const float4*>(a.f + (size_t)(p * KN + row) * a.ld + 4 * (q - QH));
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) gnext[t] = a.dagg[(size_t)p * D + (wj * NTW + t) * 16 + c16];
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NVG; ++i) {
+            const int e = 256 * i + glane;
+            const int row = e / Q, q = e - row * Q;
+            const float4 v = regs[i];
+            float* dst = A + row * PA + 4 * q;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            uint2 pk;
+            pk.x = bf16_pair(v.x, v.y);
+            pk.y = bf16_pair(v.z, v.w);
+            *reinterpret_cast<uint2*>(Xb + row * PB + 4 * q) = pk;
+        }
+    };
+    if (w.p < a.R) {
+        fetch(w);
+        commit();
+    }
+    __syncthreads();  // weights and the first tiles
+    for (int it = 0; it < iters; ++it, w = w.next()) {
+        const bool live = w.p < a.R;
+        const int64_t p = w.p;
+        const PointWalk wn = w.next();
+        const bool more = wn.p < a.R;
+        float gcur[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) gcur[t] = gnext[t];
+        if (more) fetch(wn);
+        f32x4 dfd[NTW];
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int ct = wj * NTW + t;
+                const f32x4 s = tile_mma_bf16<D>(Xb, WTb, ct, lane, f32x4{0.f, 0.f, 0.f, 0.f});
+                float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+                m = xor_max(m);
+                float e[4], fv[4], ssum = 0.f, num = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = __expf(s[r] - m);
+                    fv[r] = A[(4 * g + r) * PA + ct * 16 + c16];
+                    ssum += e[r];
+                    num = __builtin_fmaf(e[r], fv[r], num);
+                }
+                ssum = xor_sum(ssum);
+                num = xor_sum(num);
+                const float inv = __builtin_amdgcn_rcpf(ssum), agg = num * inv;
+                const float gch = gcur[t];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = e[r] * inv;
+                    dfd[t][r] = pr * gch;
+                    Tb[(4 * g + r) * PB + ct * 16 + c16] = (unsigned short)bf16_bits(pr * gch * (fv[r] - agg));
+                }
+            }
+            wave_lds_sync();  // (this wave's own dS columns)
+            // dWfc columns of this wave += F^T . dS: one 16-row contraction per tile pair
+            bf16x4s fa[NT], db[NTW];
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) {
+                const unsigned short* xp = Xb + (4 * g) * PB + ti * 16 + c16;
+                fa[ti] = bf16x4s{(short)xp[0], (short)xp[PB], (short)xp[2 * PB], (short)xp[3 * PB]};
+            }
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const unsigned short* tp = Tb + (4 * g) * PB + (wj * NTW + t) * 16 + c16;
+                db[t] = bf16x4s{(short)tp[0], (short)tp[PB], (short)tp[2 * PB], (short)tp[3 * PB]};
+            }
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) dw[ti][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fa[ti], db[t], dw[ti][t], 0, 0, 0);
+        }
+        __syncthreads();  // all of dS is in LDS
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int tj = wj * NTW + t;
+                const f32x4 acc = tile_mma_bf16<D>(Tb, Wb, tj, lane, dfd[t]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[(4 * g + r) * PA + tj * 16 + c16] = acc[r];  // (the value tile is dead: it stages dF)
+            }
+        }
+        __syncthreads();  // dF staged, dS read by everyone
+        float4 out[NVG];
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < NVG; ++i) {
+                const int e = 256 * i + glane;
+                const int row = e / Q, q = e - row * Q;
+                const float2 lo = *reinterpret_cast<const float2*>(A + row * PA + 4 * q);
+                const float2 hi = *reinterpret_cast<const float2*>(A + row * PA + 4 * q + 2);
+                out[i] = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+        __syncthreads();  // the staged tile is in registers: the next point's tile may land
+        if (more) commit();
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < NVG; ++i) {
+                const int e = 256 * i + glane;
+                const int row = e / Q, q = e - row * Q;
+                float4 o = out[i];
+                float4* dst;
+                if (!a.fl) {
+                    dst = reinterpret_cast<float4*>(a.df + (size_t)(p * KN + row) * a.lddf + 4 * q);
+                } else if (q < QH) {
+                    dst = reinterpret_cast<float4*>(a.dfl_rows + (size_t)(p * KN + row) * a.ld_rows + 4 * q);
+                } else {
+                    dst = reinterpret_cast<float4*>(a.df + (size_t)(p * KN + row) * a.lddf + 4 * (q - QH));
+                    if (a.df_accum) {
+                        const float4 h = *dst;
+                        o.x += h.x; o.y += h.y; o.z += h.z; o.w += h.w;
+                    }
+                }
+                *dst = o;
+            }
+        }
+        __syncthreads();  // the next tile is visible
+    }
+    // the group's dWfc partial: its four waves hold disjoint column tiles
+    float* dst = a.dw_part + ((size_t)blockIdx.x * GROUPS + grp) * D * D;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(ti * 16 + 4 * g + r) * D + (wj * NTW + t) * 16 + c16] = dw[ti][t][r];
+}
+
 // Workgroups per launch: every workgroup walks the points with the same stride, so a grid that is not a multiple of what the chip holds at
 // once ends with a round at partial occupancy (the d = 16 backward: 77 VGPRs allow three 8-wave workgroups per CU where the LDS footprint
 // alone allows four -- 1024 workgroups ran as 768 + 256, the second round as long as the first).  Ask the runtime what fits.
@@ -738,6 +926,21 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
             const int occ = std::min(per_cu, att_resident_blocks(reinterpret_cast<const void*>(kern), WAVES_F * 64, smem, per_cu));
             const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + WAVES_F - 1) / WAVES_F, 256 * occ));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES_F * 64), smem, c->stream, a);
+        } else if (D == 128 && a.vec_store && !getenv("PS_ATT128_NO_SPLIT")) {
+            // four waves per point (att_train_bwd_bf16_cs_kernel): two groups per workgroup share the 74 KB of weights
+            if constexpr (D == 128) {
+                constexpr int GROUPS = 2;
+                const size_t sm = sizeof(float) * (2 * (size_t)(D * PB / 2) + (size_t)GROUPS * (KN * PA + 2 * (KN * PB / 2)));
+                auto kern = att_train_bwd_bf16_cs_kernel<D, KN, GROUPS>;
+                PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+                const int occ = std::max(1, att_resident_blocks(reinterpret_cast<const void*>(kern), GROUPS * 256, sm, 1));
+                const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + GROUPS - 1) / GROUPS, 256 * occ));
+                const int parts = blocks * GROUPS;
+                PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)parts * D * D + 256));
+                a.dw_part = c->red_ws.as<float>();
+                hipLaunchKernelGGL(kern, dim3(blocks), dim3(GROUPS * 256), sm, c->stream, a);
+                hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(ceil_div(D * D, 16)), dim3(256), 0, c->stream, static_cast<const float*>(a.dw_part), parts, D * D, dW);
+            }
         } else {
             auto kern = att_train_bwd_bf16_kernel<D, KN, WAVES_B>;
             if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
