@@ -926,10 +926,12 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
             const int occ = std::min(per_cu, att_resident_blocks(reinterpret_cast<const void*>(kern), WAVES_F * 64, smem, per_cu));
             const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + WAVES_F - 1) / WAVES_F, 256 * occ));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES_F * 64), smem, c->stream, a);
-        } else if (D == 128 && a.vec_store && !getenv("PS_ATT128_NO_SPLIT")) {
-            // four waves per point (att_train_bwd_bf16_cs_kernel): two groups per workgroup share the 74 KB of weights
+        } else if (D == 128 && a.vec_store && !getenv("PS_ATT_NO_SPLIT")) {
+            // four waves per point (att_train_bwd_bf16_cs_kernel): three groups per workgroup share the 74 KB of weights: 897 us against
+            // 1 192 us for the one-wave-per-point kernel.  (d = 64, four groups: 1 334 us against 1 100 us -- the barriers of a sixteen-wave
+            // workgroup cost more than its shorter chains gain: not used there.)
             if constexpr (D == 128) {
-                constexpr int GROUPS = 2;
+                constexpr int GROUPS = 3;
                 const size_t sm = sizeof(float) * (2 * (size_t)(D * PB / 2) + (size_t)GROUPS * (KN * PA + 2 * (KN * PB / 2)));
                 auto kern = att_train_bwd_bf16_cs_kernel<D, KN, GROUPS>;
                 PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
