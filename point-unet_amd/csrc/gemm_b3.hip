@@ -38,35 +38,60 @@ __device__ __forceinline__ void b3_split_pair(float x, float y, unsigned& q1, un
     q2 = __builtin_amdgcn_perm(yru, xru, 0x07060302u);
     q3 = __builtin_amdgcn_perm(__float_as_uint(y3), __float_as_uint(x3), 0x07060302u);
 }
-struct B3Planes {
-    uint4 p[3];
+// P = 3: the exact three-way split (fp32 products on the bf16 pipe).  P = 1: ONE plane of round-to-nearest-even bfloat16 -- the bf16-MLP
+// mode of the training step (operands rounded to bfloat16, fp32 accumulation), which so runs its large products through the same tiling
+// with a sixth of the matrix work: HBM bound ([360k, 256] x [256, 256]: 0.63 ms in rowgemm_direct_bf16 before).
+template <int P>
+struct BPlanes {
+    uint4 p[P];
 };
-__device__ __forceinline__ B3Planes b3_split8(const float4& lo, const float4& hi)
+typedef BPlanes<3> B3Planes;
+typedef __bf16 b3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float b3_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned b3_rne_pair(float a, float b)  // (low half = a: v_cvt_pk_bf16_f32)
 {
-    B3Planes r;
-    b3_split_pair(lo.x, lo.y, r.p[0].x, r.p[1].x, r.p[2].x);
-    b3_split_pair(lo.z, lo.w, r.p[0].y, r.p[1].y, r.p[2].y);
-    b3_split_pair(hi.x, hi.y, r.p[0].z, r.p[1].z, r.p[2].z);
-    b3_split_pair(hi.z, hi.w, r.p[0].w, r.p[1].w, r.p[2].w);
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(b3_f32x2{a, b}, b3_bf16x2));
+}
+template <int P>
+__device__ __forceinline__ BPlanes<P> b3_split8(const float4& lo, const float4& hi)
+{
+    BPlanes<P> r;
+    if constexpr (P == 3) {
+        b3_split_pair(lo.x, lo.y, r.p[0].x, r.p[1].x, r.p[2].x);
+        b3_split_pair(lo.z, lo.w, r.p[0].y, r.p[1].y, r.p[2].y);
+        b3_split_pair(hi.x, hi.y, r.p[0].z, r.p[1].z, r.p[2].z);
+        b3_split_pair(hi.z, hi.w, r.p[0].w, r.p[1].w, r.p[2].w);
+    } else {
+        r.p[0].x = b3_rne_pair(lo.x, lo.y);
+        r.p[0].y = b3_rne_pair(lo.z, lo.w);
+        r.p[0].z = b3_rne_pair(hi.x, hi.y);
+        r.p[0].w = b3_rne_pair(hi.z, hi.w);
+    }
     return r;
 }
 __device__ __forceinline__ f32x16 b3_mfma(const uint4& a, const uint4& b, f32x16 acc)
 {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
-__device__ __forceinline__ f32x16 b3_mfma6(const B3Planes& a, const B3Planes& b, f32x16 acc)
+template <int P>
+__device__ __forceinline__ f32x16 b3_mfma6(const BPlanes<P>& a, const BPlanes<P>& b, f32x16 acc)
 {
-    acc = b3_mfma(a.p[2], b.p[0], acc);
-    acc = b3_mfma(a.p[0], b.p[2], acc);
-    acc = b3_mfma(a.p[1], b.p[1], acc);
-    acc = b3_mfma(a.p[1], b.p[0], acc);
-    acc = b3_mfma(a.p[0], b.p[1], acc);
-    acc = b3_mfma(a.p[0], b.p[0], acc);
+    if constexpr (P == 3) {
+        acc = b3_mfma(a.p[2], b.p[0], acc);
+        acc = b3_mfma(a.p[0], b.p[2], acc);
+        acc = b3_mfma(a.p[1], b.p[1], acc);
+        acc = b3_mfma(a.p[1], b.p[0], acc);
+        acc = b3_mfma(a.p[0], b.p[1], acc);
+        acc = b3_mfma(a.p[0], b.p[0], acc);
+    } else {
+        acc = b3_mfma(a.p[0], b.p[0], acc);
+    }
     return acc;
 }
 
 // W[K, N] (row-major, ldw) -> planes [K/16][N/32][3][64] x 8 bfloat16: lane l of (chunk q, column tile cb) holds
 // W[16 q + 8 (l >> 5) + j][32 cb + (l & 31)], j = 0..7.  One thread per (q, cb, lane).
+template <int P>
 __global__ __launch_bounds__(256) void gemm_b3_pack_kernel(const float* __restrict__ w, int64_t sk, int64_t sn, int K, int N, uint4* __restrict__ out)
 {
     // element (k, n) of the [K, N] matrix sits at w[k * sk + n * sn] (sk = N, sn = 1 row-major; sk = 1, sn = K for a matrix stored [N, K])
@@ -78,21 +103,22 @@ __global__ __launch_bounds__(256) void gemm_b3_pack_kernel(const float* __restri
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)j * sk];
-    const B3Planes p = b3_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
-    uint4* dst = out + ((size_t)(q * ncb + cb) * 3) * 64 + lane;
-    dst[0] = p.p[0]; dst[64] = p.p[1]; dst[128] = p.p[2];
+    const BPlanes<P> p = b3_split8<P>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+    uint4* dst = out + ((size_t)(q * ncb + cb) * P) * 64 + lane;
+#pragma unroll
+    for (int pl = 0; pl < P; ++pl) dst[64 * pl] = p.p[pl];
 }
 
 // RT = 32-row tiles per wave: a weight fragment read from LDS feeds RT x 6 MFMAs (RT = 1 was LDS-bandwidth bound: 24 KB of fragments
 // per wave and step against 1 536 cycles of products, twelve waves per CU)
 constexpr int kB3RT = 2;
 
-template <bool ACC>
+template <int P, bool ACC>
 __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmB3Args a)
 {
     constexpr int RT = kB3RT;
-    // LDS: two buffers of one 32-K step of the workgroup's column panel: [2 chunks][4 column tiles][3 planes][64 lanes] uint4 = 24 KB each
-    __shared__ uint4 Bs[2][2 * 4 * 3 * 64];
+    // LDS: two buffers of one 32-K step of the workgroup's column panel: [2 chunks][4 column tiles][P planes][64 lanes] uint4 = 24 KB each (P = 3)
+    __shared__ uint4 Bs[2][2 * 4 * P * 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hl = lane >> 5, c32 = lane & 31;
     const int ncb = a.N / 32, panels = a.N / 128;
@@ -106,31 +132,35 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmB3Args a)
         xr[i] = a.x + (size_t)row * a.ldx + 8 * hl;
     }
     // a step's B sub-tile in the global image: chunk q = 2 s + u, column tiles 4 panel .. 4 panel + 3 (contiguous: 4 * 3 * 64 uint4)
-    auto bsrc = [&](int s, int i) {  // i in [0, 1536): (u, rest)
-        const int u = i / 768, rest = i - u * 768;
-        return a.wp + ((size_t)((2 * s + u) * ncb + 4 * panel) * 3) * 64 + rest;
+    auto bsrc = [&](int s, int i) {  // i in [0, 512 P): (u, rest)
+        const int u = i / (256 * P), rest = i - u * (256 * P);
+        return a.wp + ((size_t)((2 * s + u) * ncb + 4 * panel) * P) * 64 + rest;
     };
     // (six named registers, not an array behind a lambda: the array form stayed an alloca -- 112 bytes of private segment -- and every
     //  prefetched weight plane went global -> scratch -> LDS with an s_waitcnt in front of each scratch store)
     uint4 breg0, breg1, breg2, breg3, breg4, breg5;
     float4 areg[RT][4];
-#define PS_B3_LOAD_B(s_)                              \
-    do {                                              \
-        breg0 = *bsrc((s_), 0 * 256 + threadIdx.x);   \
-        breg1 = *bsrc((s_), 1 * 256 + threadIdx.x);   \
-        breg2 = *bsrc((s_), 2 * 256 + threadIdx.x);   \
-        breg3 = *bsrc((s_), 3 * 256 + threadIdx.x);   \
-        breg4 = *bsrc((s_), 4 * 256 + threadIdx.x);   \
-        breg5 = *bsrc((s_), 5 * 256 + threadIdx.x);   \
+#define PS_B3_LOAD_B(s_)                                  \
+    do {                                                  \
+        breg0 = *bsrc((s_), 0 * 256 + threadIdx.x);       \
+        breg1 = *bsrc((s_), 1 * 256 + threadIdx.x);       \
+        if constexpr (P == 3) {                           \
+            breg2 = *bsrc((s_), 2 * 256 + threadIdx.x);   \
+            breg3 = *bsrc((s_), 3 * 256 + threadIdx.x);   \
+            breg4 = *bsrc((s_), 4 * 256 + threadIdx.x);   \
+            breg5 = *bsrc((s_), 5 * 256 + threadIdx.x);   \
+        }                                                 \
     } while (0)
-#define PS_B3_STORE_B(buf_)                           \
-    do {                                              \
-        Bs[(buf_)][0 * 256 + threadIdx.x] = breg0;    \
-        Bs[(buf_)][1 * 256 + threadIdx.x] = breg1;    \
-        Bs[(buf_)][2 * 256 + threadIdx.x] = breg2;    \
-        Bs[(buf_)][3 * 256 + threadIdx.x] = breg3;    \
-        Bs[(buf_)][4 * 256 + threadIdx.x] = breg4;    \
-        Bs[(buf_)][5 * 256 + threadIdx.x] = breg5;    \
+#define PS_B3_STORE_B(buf_)                               \
+    do {                                                  \
+        Bs[(buf_)][0 * 256 + threadIdx.x] = breg0;        \
+        Bs[(buf_)][1 * 256 + threadIdx.x] = breg1;        \
+        if constexpr (P == 3) {                           \
+            Bs[(buf_)][2 * 256 + threadIdx.x] = breg2;    \
+            Bs[(buf_)][3 * 256 + threadIdx.x] = breg3;    \
+            Bs[(buf_)][4 * 256 + threadIdx.x] = breg4;    \
+            Bs[(buf_)][5 * 256 + threadIdx.x] = breg5;    \
+        }                                                 \
     } while (0)
     // one 16-K half (u) of a step's activations: 2 x 16 bytes per row tile and lane
     auto load_a_half = [&](int s, int u) {
@@ -163,9 +193,9 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmB3Args a)
         const bool more = s + 1 < steps;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            B3Planes ap[RT];
+            BPlanes<P> ap[RT];
 #pragma unroll
-            for (int i = 0; i < RT; ++i) ap[i] = b3_split8(areg[i][2 * u], areg[i][2 * u + 1]);
+            for (int i = 0; i < RT; ++i) ap[i] = b3_split8<P>(areg[i][2 * u], areg[i][2 * u + 1]);
             __builtin_amdgcn_sched_barrier(0);
             if (more) {  // the next step's operands travel under this step's products
                 load_a_half(s + 1, u);
@@ -174,11 +204,11 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmB3Args a)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                B3Planes bp;
+                BPlanes<P> bp;
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bp.p[pl] = Bs[buf][((u * 4 + t) * 3 + pl) * 64 + lane];
+                for (int pl = 0; pl < P; ++pl) bp.p[pl] = Bs[buf][((u * 4 + t) * P + pl) * 64 + lane];
 #pragma unroll
-                for (int i = 0; i < RT; ++i) acc[i][t] = b3_mfma6(ap[i], bp, acc[i][t]);
+                for (int i = 0; i < RT; ++i) acc[i][t] = b3_mfma6<P>(ap[i], bp, acc[i][t]);
             }
         }
         if (more) PS_B3_STORE_B(buf ^ 1);  // (the other buffer: its last readers passed the barrier at the end of step s - 1)
@@ -238,10 +268,11 @@ struct WgradB3Args {
     float* dbpart;  // [slabs][cout] or nullptr
 };
 
+template <int P>
 __global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradB3Args a)
 {
-    // [operand: 0 = X (A), 1 = dY (B)][k-step][plane][32-column tile][lane] : 48 KB
-    __shared__ uint4 Ops[2][2][3][4][64];
+    // [operand: 0 = X (A), 1 = dY (B)][k-step][plane][32-column tile][lane] : 48 KB (P = 3)
+    __shared__ uint4 Ops[2][2][P][4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hl = lane >> 5, c32 = lane & 31;
     const int wi = wave & 1, wj = wave >> 1;  // this wave's 64 x 64 block: cin tiles 2 wi, 2 wi + 1; cout tiles 2 wj, 2 wj + 1
@@ -283,9 +314,9 @@ __global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradB3Args a)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float* v = cols[e];
-                const B3Planes p = b3_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+                const BPlanes<P> p = b3_split8<P>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) Ops[op][ks][pl][t][l0 + e] = p.p[pl];
+                for (int pl = 0; pl < P; ++pl) Ops[op][ks][pl][t][l0 + e] = p.p[pl];
                 bsum[e] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
             }
         }
@@ -293,18 +324,18 @@ __global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradB3Args a)
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            B3Planes av[2], bv[2];
+            BPlanes<P> av[2], bv[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
+                for (int pl = 0; pl < P; ++pl) {
                     av[i].p[pl] = Ops[0][k][pl][2 * wi + i][lane];
                     bv[i].p[pl] = Ops[1][k][pl][2 * wj + i][lane];
                 }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = b3_mfma6(av[i], bv[j], acc[i][j]);
+                for (int j = 0; j < 2; ++j) acc[i][j] = b3_mfma6<P>(av[i], bv[j], acc[i][j]);
         }
     }
     // accumulator register r of tile (i, j) = dW row 32 (2 wi + i) + (r & 3) + 8 (r >> 2) + 4 hl, column 32 (2 wj + j) + c32
@@ -364,7 +395,9 @@ int wgrad_b3_partial(ps_context* c, const float* x, int64_t ldx, const float* dy
     a.x = x; a.ldx = (int)ldx; a.dy = dy; a.lddy = (int)lddy; a.R = R; a.cin = (int)cin; a.cout = (int)cout; a.part = part; a.dbpart = dbpart;
     int64_t slabs;
     wgrad_b3_plan(R, cin, cout, a.rows_per_slab, slabs);
-    hipLaunchKernelGGL(wgrad_b3_kernel, dim3((unsigned)slabs, (unsigned)(cin / 128), (unsigned)(cout / 128)), dim3(256), 0, c->stream, a);
+    const dim3 grid((unsigned)slabs, (unsigned)(cin / 128), (unsigned)(cout / 128));
+    if (c->train_bf16) hipLaunchKernelGGL(wgrad_b3_kernel<1>, grid, dim3(256), 0, c->stream, a);  // bf16-MLP mode: operands rounded, one product
+    else hipLaunchKernelGGL(wgrad_b3_kernel<3>, grid, dim3(256), 0, c->stream, a);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -385,15 +418,25 @@ size_t gemm_b3_plane_bytes(int64_t K, int64_t N) { return (size_t)K * N * 6; }
 int gemm_b3(ps_context* c, const float* x, int64_t ldx, const float* w, int64_t sk, int64_t sn, const float* bias, int64_t R, int64_t K, int64_t N, int leaky,
             int accumulate, float* y, int64_t ldy, void* planes)
 {
-    hipLaunchKernelGGL(gemm_b3_pack_kernel, dim3(ceil_div((K / 16) * (N / 32) * 64, 256)), dim3(256), 0, c->stream, w, sk, sn, (int)K, (int)N,
-                       static_cast<uint4*>(planes));
+    const bool one = c->train_bf16;  // bf16-MLP mode: one plane of RNE-rounded operands (the buffer is sized for three)
+    if (one)
+        hipLaunchKernelGGL(gemm_b3_pack_kernel<1>, dim3(ceil_div((K / 16) * (N / 32) * 64, 256)), dim3(256), 0, c->stream, w, sk, sn, (int)K, (int)N,
+                           static_cast<uint4*>(planes));
+    else
+        hipLaunchKernelGGL(gemm_b3_pack_kernel<3>, dim3(ceil_div((K / 16) * (N / 32) * 64, 256)), dim3(256), 0, c->stream, w, sk, sn, (int)K, (int)N,
+                           static_cast<uint4*>(planes));
     GemmB3Args a;
     a.x = x; a.ldx = (int)ldx; a.wp = static_cast<const uint4*>(planes); a.bias = bias; a.y = y; a.ldy = (int)ldy;
     a.R = (int)R; a.K = (int)K; a.N = (int)N; a.leaky = leaky; a.accum = accumulate ? 1 : 0;
     const int64_t rows_wg = 128 * kB3RT;
     const int64_t blocks = ((R + rows_wg - 1) / rows_wg) * (N / 128);
-    if (a.accum) hipLaunchKernelGGL(gemm_b3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL(gemm_b3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
+    if (one) {
+        if (a.accum) hipLaunchKernelGGL((gemm_b3_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((gemm_b3_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
+    } else {
+        if (a.accum) hipLaunchKernelGGL((gemm_b3_kernel<3, true>), dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((gemm_b3_kernel<3, false>), dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
+    }
     PS_HIP(hipGetLastError());
     return PS_OK;
 }

@@ -330,7 +330,7 @@ extern "C" int ps_op_conv1x1_ex(ps_context* c, const float* x, int64_t ldx, cons
         PS_HIP(hipGetLastError());
         return PS_OK;
     }
-    if (c->train_b3 && !c->train_bf16 && gemm_b3_fits(R, cin, cout, x, ldx)) {
+    if (c->train_b3 && gemm_b3_fits(R, cin, cout, x, ldx)) {  // (bf16-MLP mode: the same tiling on ONE plane of rounded operands)
         // matrix-pipe bound shapes (att_pooling's score products at d >= 128): bf16 MFMA over exact splits, fp32-level error
         ps::DevBuf& pw = c->ops_ring[c->ops_ring_pos];
         c->ops_ring_pos = (c->ops_ring_pos + 1) & 3;
