@@ -907,7 +907,7 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
     constexpr int PW = AttTrainGeom<D>::PW, PA = AttTrainGeom<D>::PA;
     // d = 128 exists on the bf16 matrix pipe only (both weight orientations as bfloat16: 74 KB; in fp32 they are 147 KB): four waves per
     // workgroup in the backward (17.5 KB of tiles per wave, the 64 x 4 dWfc accumulators in AGPRs: one wave per SIMD), eight in the forward
-    constexpr int WAVES_F = 8, WAVES_B = D == 128 ? 4 : 8;
+    constexpr int WAVES_F = 8, WAVES_B = D == 128 ? 4 : 8;  // (d = 64 with twelve waves: 168 VGPRs, 34 spilled, 1.85 against 1.12 ms)
     if (backward) {
         auto al = [](const void* q, int ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0; };
         const bool rows_out = !a.fl || a.dfl_rows;  // (the atomic scatter form keeps its per-element path)
