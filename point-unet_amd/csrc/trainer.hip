@@ -1301,6 +1301,7 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
         t->next_id = 0;
         t->ops.clear();
         t->grad_of.clear();
+        t->deferred.clear();
         t->section_names.clear();
         t->section = 0;
         c->train_bf16 = bf16;
@@ -1330,6 +1331,7 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
     c->train_bf16 = was_bf16;  // the context may be shared with inference-side op calls: never leave the mode on
     t->ops.clear();
     t->grad_of.clear();
+    t->deferred.clear();  // (closures hold tensors: nothing of a failed step may survive it)
     t->wjobs.clear();
     t->wkeep.clear();
     t->inv_cache.clear();
@@ -1426,6 +1428,7 @@ int ps_trainer_destroy(ps_trainer* t)
     if (!t) return PS_OK;
     t->ops.clear();
     t->grad_of.clear();
+    t->deferred.clear();
     t->wkeep.clear();
     t->inv_cache.clear();
     t->pool.destroy();
