@@ -75,6 +75,43 @@ struct StageTimer {
 
 }  // namespace ps
 
+namespace ps {
+// One weight image of ps_op_conv1x1_ex: which matrix (pointer + strides), which kernel's layout, where it goes.
+// kind 0: pack_weights (rowgemm LDS form), 1: k-permuted (direct-load form), 2: bfloat16 k-permuted, 3: split-bf16 planes (gemm_b3), 4: one
+// RNE bfloat16 plane (gemm_b3 in the bf16-MLP mode)
+struct PackJob {
+    const float* w;
+    int64_t sk, sn;
+    int kind, cin, cout, ntb, p0, cblocks;
+    void* out;
+    int64_t total;  // threads of the stand-alone packing kernel
+    bool same_key(const PackJob& o) const
+    {
+        return w == o.w && sk == o.sk && sn == o.sn && kind == o.kind && cin == o.cin && cout == o.cout && ntb == o.ntb && p0 == o.p0 && cblocks == o.cblocks;
+    }
+};
+// The weight images of a training step, recorded during one step and from then on produced by one launch per source file at the start of
+// every step (the weights only change in Adam, at the end): a step packs ~75 matrices, 5 us of launch each.  mode 0: off (every call packs
+// for itself into the ring), 1: recording, 2: replaying -- calls are matched to the recorded sequence in order; a call that does not match
+// (another batch size, another option set) drops the cache for the rest of the step and the next step records again.
+struct PackCache {
+    int mode = 0;
+    bool broken = false;
+    size_t cursor = 0;
+    std::vector<PackJob> jobs;
+    std::vector<DevBuf> bufs;
+    DevBuf table;       // device copy of `jobs`
+    int n_ops = 0, n_b3 = 0;  // jobs of ops.hip's kinds / gemm_b3.hip's kinds (tables are split: [ops jobs | b3 jobs])
+};
+// returns the image's buffer; launch = the caller still has to run its packing kernel into it
+void* pack_slot(ps_context* c, const PackJob& key, size_t bytes, bool& launch);
+int pack_cache_finish_recording(ps_context* c, PackCache& pc);
+int pack_cache_replay(ps_context* c, PackCache& pc);
+void pack_cache_clear(PackCache& pc);  // (releases the images)
+int pack_batch_ops(ps_context* c, const PackJob* table, int n);  // ops.hip
+int pack_batch_b3(ps_context* c, const PackJob* table, int n);   // gemm_b3.hip
+}  // namespace ps
+
 struct ps_context {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -85,6 +122,7 @@ struct ps_context {
     ps::DevBuf stage_out;
     ps::DevBuf red_ws;       // per-block partial sums of the per-channel reductions (ops_train.hip)
     ps::DevBuf wgrad_ws;     // per-slab partials of ps_op_linear_wgrad[_ex] (ops_train.hip)
+    ps::PackCache* pack_cache = nullptr;  // (set by the native training step around its work: the step's weight images, packed by ONE launch)
     ps::DevBuf ops_ring[4];  // packed weights of ps_op_conv1x1 (a ring: consecutive calls never repack into the buffer the previous GEMM is still reading)
     int ops_ring_pos = 0;
     bool att_bf16x3 = true;   // ps_set_att_bf16x3: attentive pooling at d = 64 / 128 on bf16 MFMA over three-way splits (attpool32b.hip)

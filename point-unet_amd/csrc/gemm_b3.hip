@@ -415,11 +415,44 @@ bool gemm_b3_fits(int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx)
 
 size_t gemm_b3_plane_bytes(int64_t K, int64_t N) { return (size_t)K * N * 6; }
 
+// the element function of gemm_b3_pack_kernel for the batched form (PackCache): thread i of job j
+template <int P>
+__device__ __forceinline__ void b3_pack_elem(const PackJob& j, int64_t i)
+{
+    const int ncb = j.cout / 32;
+    const int lane = (int)(i & 63), cb = (int)((i >> 6) % ncb), q = (int)((i >> 6) / ncb);
+    const float* src = j.w + (int64_t)(16 * q + 8 * (lane >> 5)) * j.sk + (int64_t)(32 * cb + (lane & 31)) * j.sn;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[(int64_t)e * j.sk];
+    const BPlanes<P> p = b3_split8<P>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+    uint4* dst = static_cast<uint4*>(j.out) + ((size_t)(q * ncb + cb) * P) * 64 + lane;
+#pragma unroll
+    for (int pl = 0; pl < P; ++pl) dst[64 * pl] = p.p[pl];
+}
+__global__ __launch_bounds__(256) void pack_batch_b3_kernel(const PackJob* __restrict__ jobs)
+{
+    const PackJob j = jobs[blockIdx.y];
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < j.total; i += (int64_t)gridDim.x * 256) {
+        if (j.kind == 3) b3_pack_elem<3>(j, i);
+        else b3_pack_elem<1>(j, i);
+    }
+}
+int pack_batch_b3(ps_context* c, const PackJob* table, int n)
+{
+    if (n <= 0) return PS_OK;
+    hipLaunchKernelGGL(pack_batch_b3_kernel, dim3(32, (unsigned)n), dim3(256), 0, c->stream, table);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
 int gemm_b3(ps_context* c, const float* x, int64_t ldx, const float* w, int64_t sk, int64_t sn, const float* bias, int64_t R, int64_t K, int64_t N, int leaky,
-            int accumulate, float* y, int64_t ldy, void* planes)
+            int accumulate, float* y, int64_t ldy, void* planes, int pack)
 {
     const bool one = c->train_bf16;  // bf16-MLP mode: one plane of RNE-rounded operands (the buffer is sized for three)
-    if (one)
+    if (!pack) {
+        // (the planes were packed at the start of the step: PackCache)
+    } else if (one)
         hipLaunchKernelGGL(gemm_b3_pack_kernel<1>, dim3(ceil_div((K / 16) * (N / 32) * 64, 256)), dim3(256), 0, c->stream, w, sk, sn, (int)K, (int)N,
                            static_cast<uint4*>(planes));
     else

@@ -122,6 +122,110 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ W, int64_t sk
     out[t] = (__bf16)((k < cin && col < cout) ? W[k * sk + col * sn] : 0.f);
 }
 
+// ---- the weight images of a training step in one launch (PackCache, common.h): grid.y = job, grid.x strides over its elements ----------
+__global__ __launch_bounds__(256) void pack_batch_ops_kernel(const PackJob* __restrict__ jobs)
+{
+    const PackJob j = jobs[blockIdx.y];
+    const float* __restrict__ W = j.w;
+    const int ntb = j.ntb;
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < j.total; t += (int64_t)gridDim.x * 256) {
+        if (j.kind == 0) {  // pack_weights_kernel
+            const int ks = j.p0;
+            const int jj = (int)(t % ntb), l = (int)((t / ntb) % 64), s = (int)((t / ntb / 64) % ks), cb = (int)(t / ntb / 64 / ks);
+            const int k = s * 4 + (l >> 4), col = (cb * ntb + jj) * 16 + (l & 15);
+            static_cast<float*>(j.out)[t] = (k < j.cin && col < j.cout) ? W[k * j.sk + col * j.sn] : 0.f;
+        } else if (j.kind == 1) {  // pack_weights_kperm_kernel
+            const int nc = j.p0;
+            const int jj = (int)(t % ntb), l = (int)((t / ntb) % 64), s = (int)((t / ntb / 64) % 16), c = (int)((t / ntb / 64 / 16) % nc),
+                      cb = (int)(t / ntb / 64 / 16 / nc);
+            const int k = c * 64 + 16 * (l >> 4) + s, col = (cb * ntb + jj) * 16 + (l & 15);
+            static_cast<float*>(j.out)[t] = (k < j.cin && col < j.cout) ? W[k * j.sk + col * j.sn] : 0.f;
+        } else {  // pack_weights_bf16_kernel
+            const int nc = j.p0;
+            const int e = (int)(t % 8), jj = (int)((t / 8) % ntb), l = (int)((t / 8 / ntb) % 64), s = (int)((t / 8 / ntb / 64) % 2),
+                      c = (int)((t / 8 / ntb / 64 / 2) % nc), cb = (int)(t / 8 / ntb / 64 / 2 / nc);
+            const int k = c * 64 + 16 * (l >> 4) + 8 * s + e, col = (cb * ntb + jj) * 16 + (l & 15);
+            static_cast<__bf16*>(j.out)[t] = (__bf16)((k < j.cin && col < j.cout) ? W[k * j.sk + col * j.sn] : 0.f);
+        }
+    }
+}
+
+int pack_batch_ops(ps_context* c, const PackJob* table, int n)
+{
+    if (n <= 0) return PS_OK;
+    hipLaunchKernelGGL(pack_batch_ops_kernel, dim3(32, (unsigned)n), dim3(256), 0, c->stream, table);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+void pack_cache_clear(PackCache& pc)
+{
+    for (auto& b : pc.bufs) b.release();
+    pc.bufs.clear();
+    pc.jobs.clear();
+    pc.table.release();
+    pc.mode = 0;
+    pc.broken = false;
+    pc.cursor = 0;
+    pc.n_ops = pc.n_b3 = 0;
+}
+
+void* pack_slot(ps_context* c, const PackJob& key, size_t bytes, bool& launch)
+{
+    PackCache* pc = c->pack_cache;
+    launch = true;
+    if (pc && !pc->broken && pc->mode == 2) {
+        if (pc->cursor < pc->jobs.size() && pc->jobs[pc->cursor].same_key(key)) {
+            launch = false;  // packed at the start of the step
+            return pc->jobs[pc->cursor++].out;
+        }
+        pc->broken = true;  // another sequence of products than the recorded one: this step packs call by call, the next one records again
+    }
+    if (pc && !pc->broken && pc->mode == 1) {
+        DevBuf b;
+        if (b.reserve(bytes) == PS_OK) {
+            PackJob j = key;
+            j.out = b.p;
+            pc->jobs.push_back(j);
+            pc->bufs.push_back(b);
+            return b.p;
+        }
+        pc->broken = true;
+    }
+    ps::DevBuf& ws = c->ops_ring[c->ops_ring_pos];  // a small ring: consecutive calls on the stream must not overwrite weights still being read
+    c->ops_ring_pos = (c->ops_ring_pos + 1) & 3;
+    if (ws.reserve(bytes) != PS_OK) return nullptr;
+    return ws.p;
+}
+
+int pack_cache_finish_recording(ps_context* c, PackCache& pc)
+{
+    // table order: ops.hip's kinds first, then gemm_b3.hip's (each batched kernel gets a contiguous slice); `jobs` keeps the call order
+    std::vector<PackJob> tab;
+    for (const auto& j : pc.jobs)
+        if (j.kind <= 2) tab.push_back(j);
+    pc.n_ops = (int)tab.size();
+    for (const auto& j : pc.jobs)
+        if (j.kind > 2) tab.push_back(j);
+    pc.n_b3 = (int)tab.size() - pc.n_ops;
+    if (tab.empty()) return PS_OK;
+    PS_TRY(pc.table.reserve(sizeof(PackJob) * tab.size()));
+    PS_HIP(hipMemcpyAsync(pc.table.p, tab.data(), sizeof(PackJob) * tab.size(), hipMemcpyHostToDevice, c->stream));
+    PS_HIP(hipStreamSynchronize(c->stream));  // (`tab` is a local; once per recording)
+    pc.mode = 2;
+    return PS_OK;
+}
+
+int pack_cache_replay(ps_context* c, PackCache& pc)
+{
+    pc.cursor = 0;
+    if (pc.mode != 2 || pc.broken) return PS_OK;
+    Stage st(c, "op_conv1x1", 2);
+    PS_TRY(pack_batch_ops(c, pc.table.as<PackJob>(), pc.n_ops));
+    PS_TRY(pack_batch_b3(c, pc.table.as<PackJob>() + pc.n_ops, pc.n_b3));
+    return PS_OK;
+}
+
 // agg[r, col] = sum_k fset[r,k,col] * softmax_k( (fset[r] . wfc)[k, col] )    (RandLANet.py:394-398)
 template <int KMAX>
 __global__ __launch_bounds__(256) void att_pool_op_kernel(const float* __restrict__ fset, const float* __restrict__ wfc, float* __restrict__ agg,
@@ -332,11 +436,14 @@ extern "C" int ps_op_conv1x1_ex(ps_context* c, const float* x, int64_t ldx, cons
     }
     if (c->train_b3 && gemm_b3_fits(R, cin, cout, x, ldx)) {  // (bf16-MLP mode: the same tiling on ONE plane of rounded operands)
         // matrix-pipe bound shapes (att_pooling's score products at d >= 128): bf16 MFMA over exact splits, fp32-level error
-        ps::DevBuf& pw = c->ops_ring[c->ops_ring_pos];
-        c->ops_ring_pos = (c->ops_ring_pos + 1) & 3;
-        PS_TRY(pw.reserve(gemm_b3_plane_bytes(cin, cout)));
+        PackJob key = {};
+        key.w = w; key.sk = sk; key.sn = sn; key.kind = c->train_bf16 ? 4 : 3; key.cin = (int)cin; key.cout = (int)cout;
+        key.total = (int64_t)(cin / 16) * (cout / 32) * 64;
+        bool launch = true;
+        void* planes = pack_slot(c, key, gemm_b3_plane_bytes(cin, cout), launch);
+        PS_CHECK(planes != nullptr, "ps_op_conv1x1: out of device memory for the weight planes");
         Stage st(c, "op_conv1x1", 2);
-        return gemm_b3(c, x, ldx, w, sk, sn, b, R, cin, cout, leaky, accumulate, y, ldy, pw.as<void>());
+        return gemm_b3(c, x, ldx, w, sk, sn, b, R, cin, cout, leaky, accumulate, y, ldy, planes, launch ? 1 : 0);
     }
     PackedLinear L;
     L.cin = (int)cin; L.cout = (int)cout; L.leaky = leaky; L.accum = accumulate ? 1 : 0;
@@ -346,24 +453,29 @@ extern "C" int ps_op_conv1x1_ex(ps_context* c, const float* x, int64_t ldx, cons
     const bool kperm = (cin % 16) == 0 && (ldx % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;  // the direct-load kernel's layout (rowgemm.h)
     const bool bf16 = kperm && c->train_bf16;
     const size_t need = bf16 ? L.bf16_bytes() : (kperm ? L.kperm_floats() : L.packed_floats()) * sizeof(float);
-    // a small ring of packing buffers: consecutive calls on the stream must not overwrite weights still being read
-    ps::DevBuf& ws = c->ops_ring[c->ops_ring_pos];
-    c->ops_ring_pos = (c->ops_ring_pos + 1) & 3;
-    PS_TRY(ws.reserve(need));
+    PackJob key = {};
+    key.w = w; key.sk = sk; key.sn = sn; key.kind = bf16 ? 2 : (kperm ? 1 : 0); key.cin = L.cin; key.cout = L.cout; key.ntb = L.ntb;
+    key.p0 = (bf16 || kperm) ? L.nchunks() : L.ks; key.cblocks = L.cblocks;
+    key.total = bf16 ? (int64_t)(L.bf16_bytes() / 2) : (int64_t)(kperm ? L.kperm_floats() : L.packed_floats());
+    bool launch = true;
+    void* wsp = pack_slot(c, key, need, launch);  // (the step's image when the native trainer replays its pack list, else a ring buffer)
+    PS_CHECK(wsp != nullptr, "ps_op_conv1x1: out of device memory for the packed weights");
     Stage st(c, "op_conv1x1", 2);
-    if (bf16)
-        hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(ceil_div(L.bf16_bytes() / 2, 256)), dim3(256), 0, c->stream, w, sk, sn, L.cin, L.cout, L.ntb, L.nchunks(),
-                           L.cblocks, ws.as<__bf16>());
-    else if (kperm)
-        hipLaunchKernelGGL(pack_weights_kperm_kernel, dim3(ceil_div(L.kperm_floats(), 256)), dim3(256), 0, c->stream, w, sk, sn, L.cin, L.cout, L.ntb, L.nchunks(),
-                           L.cblocks, ws.as<float>());
-    else
-        hipLaunchKernelGGL(pack_weights_kernel, dim3(ceil_div(L.packed_floats(), 256)), dim3(256), 0, c->stream, w, sk, sn, L.cin, L.cout, L.ntb, L.ks, L.cblocks,
-                           ws.as<float>());
-    PS_HIP(hipGetLastError());
-    L.wp = kperm ? nullptr : ws.as<float>();
-    L.wq = (kperm && !bf16) ? ws.as<float>() : nullptr;
-    L.wb = bf16 ? ws.as<void>() : nullptr;
+    if (launch) {
+        if (bf16)
+            hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(ceil_div(L.bf16_bytes() / 2, 256)), dim3(256), 0, c->stream, w, sk, sn, L.cin, L.cout, L.ntb,
+                               L.nchunks(), L.cblocks, static_cast<__bf16*>(wsp));
+        else if (kperm)
+            hipLaunchKernelGGL(pack_weights_kperm_kernel, dim3(ceil_div(L.kperm_floats(), 256)), dim3(256), 0, c->stream, w, sk, sn, L.cin, L.cout, L.ntb,
+                               L.nchunks(), L.cblocks, static_cast<float*>(wsp));
+        else
+            hipLaunchKernelGGL(pack_weights_kernel, dim3(ceil_div(L.packed_floats(), 256)), dim3(256), 0, c->stream, w, sk, sn, L.cin, L.cout, L.ntb, L.ks,
+                               L.cblocks, static_cast<float*>(wsp));
+        PS_HIP(hipGetLastError());
+    }
+    L.wp = kperm ? nullptr : static_cast<float*>(wsp);
+    L.wq = (kperm && !bf16) ? static_cast<float*>(wsp) : nullptr;
+    L.wb = bf16 ? wsp : nullptr;
     L.bias = b;
     RowSrc s1, none;
     s1.x = x; s1.ld = (int)ldx; s1.c = L.cin;

@@ -102,6 +102,6 @@ int rowchain(ps_context* c, const ChainStep* steps, int n_steps, const RowSrc& s
 bool gemm_b3_fits(int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx);
 size_t gemm_b3_plane_bytes(int64_t K, int64_t N);
 int gemm_b3(ps_context* c, const float* x, int64_t ldx, const float* w, int64_t sk, int64_t sn, const float* bias, int64_t R, int64_t K, int64_t N, int leaky,
-            int accumulate, float* y, int64_t ldy, void* planes);
+            int accumulate, float* y, int64_t ldy, void* planes, int pack = 1);  // pack = 0: `planes` already hold this matrix (PackCache)
 
 }  // namespace ps

@@ -372,6 +372,7 @@ struct ps_trainer {
     std::vector<Op> ops;
     std::unordered_map<int, Tn> grad_of;
     std::unordered_map<int, std::vector<std::function<void()>>> deferred;  // input-gradient GEMMs waiting for another consumer's plain store
+    ps::PackCache pack;  // the step's weight images (recorded during the first step, then packed by one launch per step: common.h)
     // inverse indices of the step's gather tables (deterministic mode): built at their first use in the backward pass, kept to its end
     struct Inv {
         Tn offsets, src;
@@ -1305,6 +1306,14 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
         t->section_names.clear();
         t->section = 0;
         c->train_bf16 = bf16;
+        // weight images: replay the recorded list (ONE packing launch per source file, the products then skip their own), or record it
+        if (t->pack.mode == 2) {
+            TK(ps::pack_cache_replay(c, t->pack));
+        } else {
+            ps::pack_cache_clear(t->pack);
+            t->pack.mode = 1;
+        }
+        c->pack_cache = &t->pack;
         Tn logits = t->forward(pyr, features);
         const int64_t R = logits.R, C = logits.C;
         const int32_t* lab = labels;
@@ -1329,6 +1338,13 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
         rc = PS_ENOMEM;
     }
     c->train_bf16 = was_bf16;  // the context may be shared with inference-side op calls: never leave the mode on
+    c->pack_cache = nullptr;
+    if (rc != PS_OK || t->pack.broken || (t->pack.mode == 2 && t->pack.cursor != t->pack.jobs.size())) {
+        ps::pack_cache_clear(t->pack);  // another sequence of products than the recorded one (or a failed step): the next step records again
+    } else if (t->pack.mode == 1) {
+        const int prc = ps::pack_cache_finish_recording(c, t->pack);
+        if (prc != PS_OK) ps::pack_cache_clear(t->pack);
+    }
     t->ops.clear();
     t->grad_of.clear();
     t->deferred.clear();  // (closures hold tensors: nothing of a failed step may survive it)
@@ -1431,6 +1447,7 @@ int ps_trainer_destroy(ps_trainer* t)
     t->deferred.clear();
     t->wkeep.clear();
     t->inv_cache.clear();
+    ps::pack_cache_clear(t->pack);
     t->pool.destroy();
     t->label_map.release();
     delete t;
