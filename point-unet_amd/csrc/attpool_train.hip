@@ -233,20 +233,21 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_fwd_kernel(AttTrainArgs 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
-    float* A = smem + D * PW + wave * (a.bf16 ? 2 : 1) * KN * PA;
-    float* Ab = a.bf16 ? A + KN * PA : nullptr;
-    stage_weights<D, WAVES * 64>(a.w, W, nullptr, a.bf16 != 0);
+    // (fp32 operands only: the bf16-MLP mode has its own kernels below -- the run-time rounding switch these once carried cost a select
+    //  chain per element in an issue-bound loop)
+    float* A = smem + D * PW + wave * KN * PA;
+    stage_weights<D, WAVES * 64>(a.w, W, nullptr, false);
     __syncthreads();
     PointWalk w((int)(blockIdx.x * WAVES + wave), (int)(gridDim.x * WAVES), (int)a.n_q);
     TileRegs<D, KN> regs;
     if (w.p < a.R) regs.fetch(a, w, lane);
     for (; w.p < a.R; w = w.next()) {
         const int64_t p = w.p;
-        regs.template commit<PA>(A, Ab, lane);
+        regs.template commit<PA>(A, nullptr, lane);
         wave_lds_sync();
         const PointWalk wn = w.next();
         if (wn.p < a.R) regs.fetch(a, wn, lane);  // the next point's tile travels while this one is worked on
-        const float* X = a.bf16 ? Ab : A;
+        const float* X = A;
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
             const f32x4 s = score_tile<D>(X, W, ct, lane);  // (tile by tile here: the all-tiles form measured 3 % slower in the forward)
@@ -276,11 +277,11 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
     float* W = smem;
     float* WT = smem + D * PW;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
-    const int per_wave = (a.bf16 ? 3 : 2) * KN * PA;
+    constexpr int per_wave = 2 * KN * PA;
     float* A = smem + 2 * D * PW + wave * per_wave;
     float* T = A + KN * PA;                            // dS (rounded in bf16 mode: it only ever feeds the two products)
-    float* Ab = a.bf16 ? T + KN * PA : nullptr;
-    stage_weights<D, WAVES * 64>(a.w, W, WT, a.bf16 != 0);
+    constexpr float* Ab = nullptr;  // (fp32 operands only: see the forward kernel)
+    stage_weights<D, WAVES * 64>(a.w, W, WT, false);
     __syncthreads();
 
     f32x4 dw[NT][NT];  // this wave's share of dWfc: tile (ti, tj) = rows 16 ti.., columns 16 tj..
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) gnext[ct] = a.dagg[(size_t)wn.p * D + ct * 16 + c16];
         }
-        const float* X = a.bf16 ? Ab : A;
+        const float* X = A;
         f32x4 dfd[NT];  // direct term p * g of every column tile (seeds the second product)
         f32x4 sc_all[NT];
         score_tiles<D>(X, W, lane, sc_all);
@@ -337,9 +338,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
             for (int r = 0; r < 4; ++r) {
                 const float pr = e[r] * inv;
                 dfd[ct][r] = pr * gch;
-                float ds = pr * gch * (fv[r] - agg);
-                if (a.bf16) ds = round_bf16(ds);
-                T[(4 * g + r) * PA + ct * 16 + c16] = ds;
+                T[(4 * g + r) * PA + ct * 16 + c16] = pr * gch * (fv[r] - agg);
             }
         }
         wave_lds_sync();
