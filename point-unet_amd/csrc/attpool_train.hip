@@ -110,19 +110,22 @@ struct TileRegs {
     float4 v[NV];
     __device__ __forceinline__ void fetch(const AttTrainArgs& a, const PointWalk& w, int lane)
     {
-        const int64_t p = w.p;
-        const int64_t base = (int64_t)w.cloud * a.n_src;
+        // wave-uniform 64-bit bases (scalar unit), 32-bit element offsets per lane (a tile spans KN * ld elements; the gathered rows of one
+        // cloud n_src * ldl: both far below 2^31 -- checked on the host)
+        const float* frow = a.f + (size_t)w.p * KN * a.ld;
+        const float* fsrc = a.fl ? a.fl + (size_t)w.cloud * a.n_src * a.ldl : nullptr;
+        const int32_t* irow = a.idx ? a.idx + (size_t)w.p * KN : nullptr;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int e = 64 * i + lane;
             if (TOT % 64 == 0 || e < TOT) {
-                const int row = e / Q, q = e - row * Q;
+                const unsigned row = (unsigned)e / Q, q = (unsigned)e - row * Q;
                 if (!a.fl)
-                    v[i] = *reinterpret_cast<const float4*>(a.f + (size_t)(p * KN + row) * a.ld + 4 * q);
-                else if (q < QH)
-                    v[i] = *reinterpret_cast<const float4*>(a.fl + (size_t)(base + a.idx[p * KN + row]) * a.ldl + 4 * q);
+                    v[i] = *reinterpret_cast<const float4*>(frow + (row * (unsigned)a.ld + 4u * q));
+                else if (q < (unsigned)QH)
+                    v[i] = *reinterpret_cast<const float4*>(fsrc + ((unsigned)irow[row] * (unsigned)a.ldl + 4u * q));
                 else
-                    v[i] = *reinterpret_cast<const float4*>(a.f + (size_t)(p * KN + row) * a.ld + 4 * (q - QH));
+                    v[i] = *reinterpret_cast<const float4*>(frow + (row * (unsigned)a.ld + 4u * (q - QH)));
             }
         }
     }
@@ -169,19 +172,21 @@ struct RowStore {
     }
     __device__ __forceinline__ void put(const AttTrainArgs& a, int64_t p, int lane) const
     {
+        float* drow = a.df + (size_t)p * KN * a.lddf;  // (wave-uniform bases, 32-bit lane offsets: as TileRegs::fetch)
+        float* lrow = a.dfl_rows ? a.dfl_rows + (size_t)p * KN * a.ld_rows : nullptr;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int e = 64 * i + lane;
             if (TOT % 64 == 0 || e < TOT) {
-                const int row = e / Q, q = e - row * Q;
+                const unsigned row = (unsigned)e / Q, q = (unsigned)e - row * Q;
                 float4 o = v[i];
                 float4* dst;
                 if (!a.fl) {
-                    dst = reinterpret_cast<float4*>(a.df + (size_t)(p * KN + row) * a.lddf + 4 * q);
-                } else if (q < QH) {
-                    dst = reinterpret_cast<float4*>(a.dfl_rows + (size_t)(p * KN + row) * a.ld_rows + 4 * q);
+                    dst = reinterpret_cast<float4*>(drow + (row * (unsigned)a.lddf + 4u * q));
+                } else if (q < (unsigned)QH) {
+                    dst = reinterpret_cast<float4*>(lrow + (row * (unsigned)a.ld_rows + 4u * q));
                 } else {
-                    dst = reinterpret_cast<float4*>(a.df + (size_t)(p * KN + row) * a.lddf + 4 * (q - QH));
+                    dst = reinterpret_cast<float4*>(drow + (row * (unsigned)a.lddf + 4u * (q - QH)));
                     if (a.df_accum) {
                         const float4 h = *dst;
                         o.x += h.x; o.y += h.y; o.z += h.z; o.w += h.w;
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_fwd_kernel(AttTrainArgs 
     constexpr int PW = AttTrainGeom<D>::PW, PA = AttTrainGeom<D>::PA, NT = D / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;  // (wave: an SGPR -- the point walk and every row base derived from it stay on the scalar unit)
     // (fp32 operands only: the bf16-MLP mode has its own kernels below -- the run-time rounding switch these once carried cost a select
     //  chain per element in an issue-bound loop)
     float* A = smem + D * PW + wave * KN * PA;
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;
     float* WT = smem + D * PW;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;  // (wave: an SGPR -- the point walk and every row base derived from it stay on the scalar unit)
     constexpr int per_wave = 2 * KN * PA;
     float* A = smem + 2 * D * PW + wave * per_wave;
     float* T = A + KN * PA;                            // dS (rounded in bf16 mode: it only ever feeds the two products)
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_fwd_bf16_kernel(AttTrain
     constexpr int PB = AttBf16Geom<D>::PB, PA = AttBf16Geom<D>::PA, NT = D / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short* WTb = reinterpret_cast<unsigned short*>(smem);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;  // (wave: an SGPR -- the point walk and every row base derived from it stay on the scalar unit)
     constexpr int W_FLOATS = D * PB / 2, TILE_FLOATS = KN * PA + KN * PB / 2;
     float* A = smem + W_FLOATS + wave * TILE_FLOATS;
     unsigned short* Xb = reinterpret_cast<unsigned short*>(A + KN * PA);
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
     constexpr int W_FLOATS = D * PB / 2, TILE_FLOATS = KN * PA + 2 * (KN * PB / 2);
     unsigned short* Wb = reinterpret_cast<unsigned short*>(smem);
     unsigned short* WTb = reinterpret_cast<unsigned short*>(smem + W_FLOATS);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;  // (wave: an SGPR -- the point walk and every row base derived from it stay on the scalar unit)
     float* A = smem + 2 * W_FLOATS + wave * TILE_FLOATS;
     unsigned short* Xb = reinterpret_cast<unsigned short*>(A + KN * PA);
     unsigned short* Tb = Xb + KN * PB;  // dS, rounded: it only ever feeds the two products
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(GROUPS * 256) void att_train_bwd_bf16_cs_kernel(Att
     constexpr int W_FLOATS = D * PB / 2, TILE_FLOATS = KN * PA + 2 * (KN * PB / 2);
     unsigned short* Wb = reinterpret_cast<unsigned short*>(smem);
     unsigned short* WTb = reinterpret_cast<unsigned short*>(smem + W_FLOATS);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;  // (wave: an SGPR -- the point walk and every row base derived from it stay on the scalar unit)
     const int grp = wave >> 2, wj = wave & 3, glane = (wj << 6) | lane;
     float* A = smem + 2 * W_FLOATS + grp * TILE_FLOATS;
     unsigned short* Xb = reinterpret_cast<unsigned short*>(A + KN * PA);
@@ -1045,7 +1050,7 @@ extern "C" int ps_op_att_pool_train_fwd_split(ps_context* c, const float* fl, in
                                               const float* fr, int64_t ldr, const float* wfc, int64_t K, int64_t d, float* agg)
 {
     PS_CHECK(c && fl && idx && fr && wfc && agg, "ps_op_att_pool_train_fwd_split: NULL argument");
-    PS_CHECK(att_train_ok(K, d, ldr, fr) && ldl % 4 == 0 && (reinterpret_cast<uintptr_t>(fl) & 15) == 0 && B >= 0 && n_src > 0 && n_q >= 0,
+    PS_CHECK(att_train_ok(K, d, ldr, fr) && ldl % 4 == 0 && (reinterpret_cast<uintptr_t>(fl) & 15) == 0 && n_src * ldl < (1ll << 31) && B >= 0 && n_src > 0 && n_q >= 0,
              "ps_op_att_pool_train_fwd_split: K = 16, d in {16, 32, 64}, rows 16-byte aligned (got K %lld, d %lld)", (long long)K, (long long)d);
     const int64_t R = B * n_q;
     if (R <= 0) return PS_OK;
@@ -1087,7 +1092,7 @@ static int att_bwd_split_impl(ps_context* c, const float* fl, int64_t ldl, const
                               float* dwfc, float* dfl_rows, int64_t ld_rows)
 {
     PS_CHECK(c && fl && idx && fr && wfc && dagg && dfl && dfr && dwfc, "ps_op_att_pool_train_bwd_split: NULL argument");
-    PS_CHECK(att_train_ok(K, d, ldr, fr) && ldl % 4 == 0 && (reinterpret_cast<uintptr_t>(fl) & 15) == 0 && lddl >= d / 2 && lddr >= d / 2 && n_src > 0,
+    PS_CHECK(att_train_ok(K, d, ldr, fr) && ldl % 4 == 0 && (reinterpret_cast<uintptr_t>(fl) & 15) == 0 && n_src * ldl < (1ll << 31) && lddl >= d / 2 && lddr >= d / 2 && n_src > 0,
              "ps_op_att_pool_train_bwd_split: K = 16, d in {16, 32, 64}, rows 16-byte aligned");
     PS_HIP(hipSetDevice(c->device));
     const int64_t R = B * n_q;
