@@ -78,7 +78,7 @@ struct RcTile {
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (TOT % 64 == 0 || e < TOT) {
                 const int row = e / Q, q = e - row * Q;
-                if (r0 + row < R) v[i] = *reinterpret_cast<const float4*>(x + (size_t)(r0 + row) * ldx + 4 * q);
+                if (r0 + row < R) v[i] = *reinterpret_cast<const float4*>(x + (size_t)r0 * ldx + (unsigned)(row * ldx + 4 * q));  // (wave-uniform base, 32-bit lane offset)
             }
         }
     }
@@ -126,7 +126,7 @@ struct RcTile {
             const int e = 64 * i + lane;
             if (TOT % 64 == 0 || e < TOT) {
                 const int row = e / Q, q = e - row * Q;
-                if (r0 + row < R) *reinterpret_cast<float4*>(out + (size_t)(r0 + row) * ldo + 4 * q) = v[i];
+                if (r0 + row < R) *reinterpret_cast<float4*>(out + (size_t)r0 * ldo + (unsigned)(row * ldo + 4 * q)) = v[i];
             }
         }
     }
@@ -164,7 +164,7 @@ __global__ __launch_bounds__((RcGeom<CI, CO>::WAVES * 64)) void rc_sums_kernel(R
     constexpr int NT = G::NTO;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     float* X = smem + G::CIP * G::PWO + wave * 16 * G::PX;
     double* red = reinterpret_cast<double*>(smem + G::CIP * G::PWO + kRcWaves * 16 * G::PX);  // [kRcWaves][2 COP]
     rc_stage_w<CI, CO>(a.w, W, nullptr, a.bf16 != 0);
@@ -226,7 +226,7 @@ __global__ __launch_bounds__((RcGeom<CI, CO>::WAVES * 64)) void rc_apply_kernel(
     constexpr int NT = G::NTO;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     float* X = smem + G::CIP * G::PWO + wave * 16 * (G::PX + G::PZ);
     float* Z = X + 16 * G::PX;
     rc_stage_w<CI, CO>(a.w, W, nullptr, a.bf16 != 0);
@@ -268,7 +268,7 @@ __global__ __launch_bounds__((RcGeom<CI, CO>::WAVES * 64)) void rc_bwd_sums_kern
     constexpr int NT = G::NTO, COP = G::COP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     float* X = smem + G::CIP * G::PWO + wave * 16 * (G::PX + G::PZ);
     float* Z = X + 16 * G::PX;
     float* red = smem + G::CIP * G::PWO + kRcWaves * 16 * (G::PX + G::PZ);  // [kRcWaves][2 COP]
@@ -344,7 +344,7 @@ __global__ __launch_bounds__((RcGeom<CI, CO>::WAVES * 64)) void rc_bwd_apply_ker
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;
     float* WT = smem + CIP * G::PWO;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     float* X = smem + CIP * G::PWO + COP * G::PWI + wave * 16 * (G::PX + G::PZ);
     float* Z = X + 16 * G::PX;  // dz, replaced in place by dy
     rc_stage_w<CI, CO>(a.w, W, WT, a.bf16 != 0);

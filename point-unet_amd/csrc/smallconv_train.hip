@@ -83,7 +83,7 @@ struct ScTile {
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (TOT % 64 == 0 || e < TOT) {
                 const int row = e / Q, q = e - row * Q;
-                if (r0 + row < R) v[i] = *reinterpret_cast<const float4*>(x + (size_t)(r0 + row) * ldx + 4 * q);
+                if (r0 + row < R) v[i] = *reinterpret_cast<const float4*>(x + (size_t)r0 * ldx + (unsigned)(row * ldx + 4 * q));  // (wave-uniform base, 32-bit lane offset)
             }
         }
     }
@@ -131,7 +131,7 @@ struct ScTile {
             const int e = 64 * i + lane;
             if (TOT % 64 == 0 || e < TOT) {
                 const int row = e / Q, q = e - row * Q;
-                if (r0 + row < R) *reinterpret_cast<float4*>(out + (size_t)(r0 + row) * ldo + 4 * q) = v[i];
+                if (r0 + row < R) *reinterpret_cast<float4*>(out + (size_t)r0 * ldo + (unsigned)(row * ldo + 4 * q)) = v[i];
             }
         }
     }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_sums_kernel(ScArgs a)
     constexpr int NT = G::NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     float* A = smem + G::CP * G::PW + wave * 16 * G::PA;
     double* red = reinterpret_cast<double*>(smem + G::CP * G::PW + kScWaves * 16 * G::PA);  // [kScWaves][3 CP]
     sc_stage_w<C, kScWaves * 64>(a.w, W, nullptr, a.bf16 != 0);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_apply_kernel(ScArgs a)
     constexpr int NT = G::NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     float* A = smem + G::CP * G::PW + wave * 16 * G::PA;
     sc_stage_w<C, kScWaves * 64>(a.w, W, nullptr, a.bf16 != 0);
     __syncthreads();
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_sums_kernel(ScArgs a)
     constexpr int NT = G::NT, CP = G::CP, NV = FULL ? 3 * CP + 2 * CP * CP : 3 * CP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     float* A = smem + CP * G::PW + wave * 3 * 16 * G::PA;  // x tile | g tile | xh tile
     float* T1 = A + 16 * G::PA;
     float* T2 = T1 + 16 * G::PA;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;
     float* WT = smem + CP * G::PW;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     float* A = smem + 2 * CP * G::PW + wave * 2 * 16 * G::PA;  // x tile | dy tile
     float* T1 = A + 16 * G::PA;
     sc_stage_w<C, kScWaves * 64>(a.w, W, WT, a.bf16 != 0);
