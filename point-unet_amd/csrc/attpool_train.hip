@@ -740,20 +740,24 @@ __global__ __launch_bounds__(GROUPS * 256) void att_train_bwd_bf16_cs_kernel(Att
     float gnext[NTW];
     auto fetch = [&](const PointWalk& pw) {
         const int64_t p = pw.p;
-        const int64_t base = (int64_t)pw.cloud * a.n_src;
+        // (wave-uniform bases, 32-bit lane offsets: as TileRegs::fetch)
+        const float* frow = a.f + (size_t)p * KN * a.ld;
+        const float* fsrc = a.fl ? a.fl + (size_t)pw.cloud * a.n_src * a.ldl : nullptr;
+        const int32_t* irow = a.idx ? a.idx + (size_t)p * KN : nullptr;
 #pragma unroll
         for (int i = 0; i < NVG; ++i) {
-            const int e = 256 * i + glane;
-            const int row = e / Q, q = e - row * Q;
+            const unsigned e = 256u * i + glane;
+            const unsigned row = e / Q, q = e - row * Q;
             if (!a.fl)
-                regs[i] = *reinterpret_cast<const float4*>(a.f + (size_t)(p * KN + row) * a.ld + 4 * q);
-            else if (q < QH)
-                regs[i] = *reinterpret_cast<const float4*>(a.fl + (size_t)(base + a.idx[p * KN + row]) * a.ldl + 4 * q);
+                regs[i] = *reinterpret_cast<const float4*>(frow + (row * (unsigned)a.ld + 4u * q));
+            else if (q < (unsigned)QH)
+                regs[i] = *reinterpret_cast<const float4*>(fsrc + ((unsigned)irow[row] * (unsigned)a.ldl + 4u * q));
             else
-                regs[i] = *reinterpret_cast<const float4*>(a.f + (size_t)(p * KN + row) * a.ld + 4 * (q - QH));
+                regs[i] = *reinterpret_cast<const float4*>(frow + (row * (unsigned)a.ld + 4u * (q - QH)));
         }
+        const float* grow = a.dagg + (size_t)p * D;
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) gnext[t] = a.dagg[(size_t)p * D + (wj * NTW + t) * 16 + c16];
+        for (int t = 0; t < NTW; ++t) gnext[t] = grow[(wj * NTW + t) * 16 + c16];
     };
     auto commit = [&]() {
 #pragma unroll
@@ -859,12 +863,14 @@ __global__ __launch_bounds__(GROUPS * 256) void att_train_bwd_bf16_cs_kernel(Att
                 const int row = e / Q, q = e - row * Q;
                 float4 o = out[i];
                 float4* dst;
+                float* drow = a.df + (size_t)p * KN * a.lddf;
+                float* lrow = a.dfl_rows ? a.dfl_rows + (size_t)p * KN * a.ld_rows : nullptr;
                 if (!a.fl) {
-                    dst = reinterpret_cast<float4*>(a.df + (size_t)(p * KN + row) * a.lddf + 4 * q);
+                    dst = reinterpret_cast<float4*>(drow + ((unsigned)row * (unsigned)a.lddf + 4u * q));
                 } else if (q < QH) {
-                    dst = reinterpret_cast<float4*>(a.dfl_rows + (size_t)(p * KN + row) * a.ld_rows + 4 * q);
+                    dst = reinterpret_cast<float4*>(lrow + ((unsigned)row * (unsigned)a.ld_rows + 4u * q));
                 } else {
-                    dst = reinterpret_cast<float4*>(a.df + (size_t)(p * KN + row) * a.lddf + 4 * (q - QH));
+                    dst = reinterpret_cast<float4*>(drow + ((unsigned)row * (unsigned)a.lddf + 4u * (q - QH)));
                     if (a.df_accum) {
                         const float4 h = *dst;
                         o.x += h.x; o.y += h.y; o.z += h.z; o.w += h.w;
