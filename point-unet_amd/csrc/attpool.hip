@@ -67,7 +67,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_kernel(AttArgs a)
     using bfD = typename BFrag<NTB_D>::type;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int g = lane >> 4, c16 = lane & 15;
     float* T1 = smem + (SPLITN ? 0 : wave) * (KN * PITCH * (STAGE == 2 ? 2 : 1));
     float* T2 = T1 + KN * PITCH;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
     using bfD = typename BFrag<NTB_D>::type;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int g = lane >> 4, c16 = lane & 15;
     float* A = smem + wave * PER_WAVE;
     float* T1 = A + ROWS * PA;

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmB3Args a)
     constexpr int RT = kB3RT;
     // LDS: two buffers of one 32-K step of the workgroup's column panel: [2 chunks][4 column tiles][P planes][64 lanes] uint4 = 24 KB each (P = 3)
     __shared__ uint4 Bs[2][2 * 4 * P * 64];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hl = lane >> 5, c32 = lane & 31;
     const int ncb = a.N / 32, panels = a.N / 128;
     const int panel = blockIdx.x % panels;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradB3Args a)
 {
     // [operand: 0 = X (A), 1 = dY (B)][k-step][plane][32-column tile][lane] : 48 KB (P = 3)
     __shared__ uint4 Ops[2][2][P][4][64];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hl = lane >> 5, c32 = lane & 31;
     const int wi = wave & 1, wj = wave >> 1;  // this wave's 64 x 64 block: cin tiles 2 wi, 2 wi + 1; cout tiles 2 wj, 2 wj + 1
     const int c0 = blockIdx.y * 128, n0 = blockIdx.z * 128;

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void locse_sums_kernel(LocseArgs a)
     using LL = LocseLanes<H>;
     __shared__ double red[4 * 2 * H];
     const LL L(a);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
     double s[4] = {0., 0., 0., 0.}, q2[4] = {0., 0., 0., 0.};
     const int64_t wstride = (int64_t)gridDim.x * 4 * LL::RPW;
     for (int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * LL::RPW; t0 < a.rows; t0 += wstride) {
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void locse_apply_kernel(LocseArgs a)
 {
     using LL = LocseLanes<H>;
     const LL L(a);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
     const float4 sc = *reinterpret_cast<const float4*>(a.scale + L.c0), sh = *reinterpret_cast<const float4*>(a.shift + L.c0);
     const float4 mu = *reinterpret_cast<const float4*>(a.mean + L.c0);
     const int64_t wstride = (int64_t)gridDim.x * 4 * LL::RPW;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void locse_bwd_kernel(LocseArgs a)
     __shared__ float red[4 * NV];
     for (int i = threadIdx.x; i < H; i += 256) { Ss[i] = a.scale[i]; Ss[H + i] = a.shift[i]; Ss[2 * H + i] = a.mean[i]; Ss[3 * H + i] = a.invstd[i]; }
     locse_stage_w<H>(a, Ws);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int part = lane % LPR, rw = lane / LPR, c0 = 4 * part;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, xs[4] = {0.f, 0.f, 0.f, 0.f};
     float A[10][4], G[10][4], E[10];

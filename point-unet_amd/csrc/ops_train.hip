@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x,
     constexpr int SX = BF16 ? CI + 4 : wg_stride(CI), SD = BF16 ? CJ + 4 : wg_stride(CJ);
     constexpr int CH = BF16 ? (wg_chunk(CI + CJ) > 16 * WK ? wg_chunk(CI + CJ) : 16 * WK) : wg_chunk(CI + CJ);
     __shared__ float xs[CH * SX], ds[CH * SD];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i16 = lane & 15, k4 = lane >> 4;
     const int wi = wave % WI, wk = wave / WI;
     const int c0 = blockIdx.y * CI, n0 = blockIdx.z * CJ;
