@@ -223,7 +223,7 @@ def ranks_seen(dist, device):
     return int(round(float(t.item())))
 
 
-def preheat(step_fn, sync_fn, seconds=0.4):
+def preheat(step_fn, sync_fn, seconds=0.4, batch=8):
     """Untimed GPU work in front of the W warm-up steps: a device that sat idle (a fresh process on a box another process just left) ramps
     its clocks over the first few hundred milliseconds of load -- with W = 20 forward steps (20 ms) the timed region of the SECOND and later
     processes on a box measured 1.3-1.5 ms per step where the first, and any run with W >= 200, measured 0.90 ms (round 3: `--warmup 20`
@@ -231,10 +231,10 @@ def preheat(step_fn, sync_fn, seconds=0.4):
     t0 = time.perf_counter()
     n = 0
     while time.perf_counter() - t0 < seconds:
-        for _ in range(8):
+        for _ in range(batch):
             step_fn()
         sync_fn()
-        n += 8
+        n += batch
     return n
 
 
@@ -338,9 +338,11 @@ def sub_train_b8(cfg, xyz_list, local_rank, bf16, steps=2, warmup=1, determinist
         ctx.synchronize()
         torch.cuda.synchronize()
 
+    step()  # (the first step also grows the activation pool)
+    preheat(step, sync, 0.25, batch=2)
     for _ in range(warmup):
         step()
-    sync()  # (steps of 40 ms: the warm-up itself brings the clocks up -- no pre-heat here)
+    sync()
     elapsed, loss = timed_region(step, steps, sync, None)
     ms = 1e3 * elapsed / steps
     out = {"ms_per_step": ms, "points_per_s": B * n0 * steps / elapsed, "steps": steps, "warmup": warmup, "batch": B, "points": n0,
@@ -452,6 +454,8 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
         ctx.synchronize()
         torch.cuda.synchronize()
 
+    step()  # (the first step also grows the activation pool)
+    preheat(step, sync, 0.3, batch=2)
     for _ in range(args.warmup):
         step()
     sync()
