@@ -146,4 +146,4 @@ def train_step(params, num_layers, xyz, neigh_idx, sub_idx, interp_idx, features
         new_params[k] = P[k].detach().numpy() - lr_t * m / (np.sqrt(v) + eps)
     for k, v in new_buf.items():
         new_params[k] = v.numpy()
-    return dict(loss=float(loss), grads=grads, new_params=new_params, logits=logits.detach().numpy())
+    return dict(loss=float(loss.detach()), grads=grads, new_params=new_params, logits=logits.detach().numpy())

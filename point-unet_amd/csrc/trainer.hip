@@ -1476,6 +1476,9 @@ int ps_trainer_layout(const ps_trainer* t, int row, char* name, int name_cap, in
 int ps_trainer_bind(ps_trainer* t, float* params, float* grads, float* adam_m, float* adam_v, float* bn_buffers)
 {
     PS_CHECK(t && params && grads && bn_buffers, "ps_trainer_bind: params, grads and bn_buffers are required");
+    // the recorded weight-image list holds pointers INTO the parameter buffer and replays its packing launches at the start of the
+    // next step, before any product could notice a mismatch: a new buffer (checkpoint reload, buffer swap) drops the recording
+    if (params != t->params) ps::pack_cache_clear(t->pack);
     t->params = params;
     t->grads = grads;
     t->adam_m = adam_m;

@@ -567,6 +567,33 @@ class Trainer:
             o.ignored_label_inds[i] = v
         return o
 
+    def rebind(self, flat=None, grad=None, m=None, v=None, flat_buffers=None):
+        """Hands the native trainer other flat buffers (a reloaded checkpoint, a buffer swap): ps_trainer_bind.  Buffers not given
+        are replaced by fresh copies of the current ones; the per-name views P / G / buffers are rebuilt over the new storage."""
+        lib = _lib.lib()
+        old = (self.flat, self.flat_buffers)
+        self.flat = flat if flat is not None else self.flat.clone()
+        self.grad = grad if grad is not None else self.grad.clone()
+        self.m = m if m is not None else self.m.clone()
+        self.v = v if v is not None else self.v.clone()
+        self.flat_buffers = flat_buffers if flat_buffers is not None else self.flat_buffers.clone()
+        for n, t in list(self.P.items()):
+            off = t.storage_offset()
+            self.P[n] = self.flat[off:off + t.numel()].view(t.shape)
+            self.G[n] = self.grad[off:off + t.numel()].view(t.shape)
+        for n, t in list(self.buffers.items()):
+            off = t.storage_offset()
+            self.buffers[n] = self.flat_buffers[off:off + t.numel()].view(t.shape)
+        _lib.check(lib.ps_trainer_bind(self._h, _p(self.flat), _p(self.grad), _p(self.m), _p(self.v), _p(self.flat_buffers)))
+        return old
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

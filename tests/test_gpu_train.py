@@ -212,14 +212,50 @@ def test_training_step_at_the_true_width_ladder(oracle, mode):
         assert _grad_stats(got, full["grads"], tr.names)[0] > 0.5 * _grad_stats(want["grads"], full["grads"], tr.names)[0]
 
 
+def test_one_full_size_cloud_training_step_against_float64_autograd(oracle):
+    """The per-rank work of BASELINE configs[3] (and one eighth of configs[2]) at its real size: ONE 180 000-point BraTS-shaped
+    cloud, ConfigBraTS widths, Trainer(mlp_dtype="fp32"): loss, logits, EVERY gradient tensor and the moving statistics of one step
+    against torch-CPU float64 autograd (about 25 s and 14 GB on 8 cores).  At this size the tape takes the branches the bench times:
+    the >= 16 384-row gemm_b3 / wgrad_b3 products, the 2.9 M-row recomputed conv + BatchNorm passes, the radix-sorted inverse index
+    (RandLANet.py:62-90 through :110-152).  Bars as in the width-ladder test: loss 2e-5 relative, logits 1e-4, every gradient tensor
+    within 3e-2 of its own max + 1e-4 of the global max, relative L2 of the whole gradient 5e-3."""
+    import torch
+    from conftest import brats_cloud
+    from oracle import randla_train_oracle as rto
+    from point_unet_amd.helper_tool import ConfigBraTS as cfg
+    n0 = 180000
+    xyz = brats_cloud(n0, 0)[None]
+    rng = np.random.default_rng(9)
+    feats = np.concatenate([xyz, rng.standard_normal((1, n0, 4)).astype(np.float32)], -1)
+    tr, pyr, params, labels, cw, (pts, nbr, pool, up) = _setup(cfg, xyz, feats, lr=1e-4)
+    for i in range(cfg.num_layers):
+        assert np.array_equal(pyr.neigh_idx[i].cpu().numpy(), nbr[i]) and np.array_equal(pyr.interp_idx[i].cpu().numpy(), up[i])
+    loss = tr.train_step(pyr, torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda())
+    torch.cuda.synchronize()
+    want = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-4, step=1)
+    got = {n: tr.G[n].cpu().numpy() for n in tr.names}
+    rel_loss = abs(float(loss) - want["loss"]) / max(1.0, abs(want["loss"]))
+    logit_err = float(np.abs(tr.last_logits.cpu().numpy().reshape(want["logits"].shape) - want["logits"]).max())
+    rel_l2, worst = _grad_stats(got, want["grads"], tr.names)
+    print("180 000 points: loss rel %.2e, logits %.2e, grad rel L2 %.2e, worst tensors %s" % (rel_loss, logit_err, rel_l2, worst[:3]))
+    assert rel_loss <= 2e-5 and logit_err < 1e-4
+    assert worst[0][0] <= 1.0, worst[:5]
+    assert rel_l2 <= 5e-3
+    new = tr.export_params()
+    for k, v in want["new_params"].items():
+        if k.endswith(("moving_mean", "moving_variance")):
+            assert np.abs(new[k] - v).max() <= 1e-5 * max(1.0, np.abs(v).max()), k
+    tr.close()
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_full_size_config3_step_properties(mode):
     """BASELINE configs[2] at FULL size: batch 8 x 180 000-point BraTS-shaped clouds, true widths, one training step (the oracle cannot
     run this size, so size-independent properties): (1) the loss is finite and equals the class-weighted cross-entropy re-evaluated
     on the host in float64 from the step's own logits (1e-5 relative); (2) the logits of two runs from the same state are
-    bit-identical (no float atomics in the forward); (3) the flat gradient buffer repeats between the two runs within the
-    atomic-summation tolerance (relative L2 <= 1e-4 fp32; the bf16 mode rounds the same operands both times, same bar) and is
-    non-trivial (no NaN, norm > 0); (4) after Adam every parameter moved by at most lr * (1 + 1e-3) (|m / sqrt(v)| = 1 at step 1)."""
+    bit-identical (no float atomics in the forward); (3) the flat gradient buffer of the two runs is BIT-IDENTICAL (torch.equal: the
+    default step has no float atomics anywhere -- fixed-order partial sums and gather-reductions over inverse indices) and is
+    non-trivial (no NaN, norm > 0); the float-atomics variant (deterministic=False) agrees with it to summation order; (4) after Adam every parameter moved by at most lr * (1 + 1e-3) (|m / sqrt(v)| = 1 at step 1)."""
     import torch
     from conftest import brats_cloud
     from point_unet_amd import weights
@@ -795,6 +831,36 @@ def test_streaming_gemm_for_millions_of_rows():
         assert (y.double() - refb).abs().max() <= 2e-5 * refb.abs().max(), (R, cin, cout)
         del buf, x, y, ref, refb, want
     torch.cuda.synchronize()
+
+
+def test_rebinding_the_parameter_buffer_between_steps_drops_the_recorded_weight_images():
+    """ps_trainer_bind with another parameter buffer (checkpoint reload, buffer swap) between two steps: the trainer replays its
+    recorded weight-packing launches at the start of every step, over pointers into the parameter buffer of the step that recorded
+    them -- a rebind must drop that recording.  Three steps with a rebind to fresh buffers after each (the old ones poisoned with NaN,
+    standing in for freed memory) equal three steps of an undisturbed trainer bit for bit."""
+    import torch
+    from point_unet_amd import weights
+    from point_unet_amd.pyramid import build_pyramid
+    from point_unet_amd.train import Trainer
+    cfg, xyz, feats = netcase.small_deep(6000, seed=21, B=2)
+    params = weights.init_params(cfg, seed=5, randomize_bn=True)
+    labels = np.random.default_rng(3).integers(0, cfg.num_classes, xyz.shape[:2]).astype(np.int32)
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    d_feats, d_lab = torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
+    out = {}
+    for rebind in (False, True):
+        with Trainer(cfg, params=params, learning_rate=1e-3, keep_prob=1.0) as tr:
+            losses = []
+            for _ in range(3):
+                losses.append(float(tr.train_step(pyr, d_feats, d_lab)))
+                torch.cuda.synchronize()
+                if rebind:
+                    for t in tr.rebind():
+                        t.fill_(float("nan"))
+            out[rebind] = (losses, tr.flat.clone(), tr.grad.clone(), tr.flat_buffers.clone())
+    assert out[True][0] == out[False][0] and all(np.isfinite(out[True][0]))
+    for a, b in zip(out[True][1:], out[False][1:]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
