@@ -228,6 +228,8 @@ def preheat(step_fn, sync_fn, seconds=0.4, batch=8):
     its clocks over the first few hundred milliseconds of load -- with W = 20 forward steps (20 ms) the timed region of the SECOND and later
     processes on a box measured 1.3-1.5 ms per step where the first, and any run with W >= 200, measured 0.90 ms (round 3: `--warmup 20`
     0.904 / 1.465; `--warmup 200` 0.907 / 0.904; `--warmup 1000` 0.908 / 0.907).  The W warm-up steps and the K timed steps follow unchanged."""
+    if os.environ.get("PS_BENCH_NO_PREHEAT"):  # (counter passes under rocprofv3 --pmc: a known number of steps, profiles/run_pmc_train.sh)
+        return 0
     t0 = time.perf_counter()
     n = 0
     while time.perf_counter() - t0 < seconds:
@@ -303,15 +305,27 @@ def train_roofline(cfg, n0, B, ms, bf16):
     peak = BF16_MFMA_PEAK_TF if bf16 else F32_MFMA_PEAK_TF
     tfs, gbs = step_flops / (ms * 1e-3) / 1e12, step_bytes / (ms * 1e-3) / 1e9
     mf = tfs / peak > gbs / HBM_PEAK_GBS
-    return {"bound": "mfma" if mf else "hbm", "kernel": "whole training step", "achieved": round(tfs if mf else gbs, 3), "peak": peak if mf else HBM_PEAK_GBS,
-            "unit": "TFLOP/s" if mf else "GB/s", "frac": round(max(tfs / peak, gbs / HBM_PEAK_GBS), 5), "traffic": None,
-            "algorithmic_flops_per_step": step_flops, "algorithmic_bytes_per_step": step_bytes,
-            "mfma_frac": round(tfs / peak, 5), "hbm_frac": round(gbs / HBM_PEAK_GBS, 5)}
+    out = {"bound": "mfma" if mf else "hbm", "kernel": "whole training step", "achieved": round(tfs if mf else gbs, 3), "peak": peak if mf else HBM_PEAK_GBS,
+           "unit": "TFLOP/s" if mf else "GB/s", "frac": round(max(tfs / peak, gbs / HBM_PEAK_GBS), 5), "traffic": None,
+           "algorithmic_flops_per_step": step_flops, "algorithmic_bytes_per_step": step_bytes,
+           "mfma_frac": round(tfs / peak, 5), "hbm_frac": round(gbs / HBM_PEAK_GBS, 5)}
+    # HBM bytes of one step from the committed rocprofv3 --pmc passes of `bench.py --mode train` (profiles/regen_r4.sh), labelled with their source
+    pmc = os.path.join(ROOT, "profiles", "r4_pmc_traffic_train.json")
+    key = "b%d_%s" % (B, "bf16" if bf16 else "f32")
+    if os.path.exists(pmc):
+        t = json.load(open(pmc))
+        if key in t:
+            out["traffic"] = t[key]["bytes_per_step"]
+            out["traffic_over_algorithmic"] = round(t[key]["bytes_per_step"] / step_bytes, 3)
+            out["traffic_source"] = "profiles/r4_pmc_traffic_train.json: rocprofv3 --pmc passes of `%s` at commit %s (not measured in this run)" % (
+                t[key].get("command", "?"), t.get("_commit", "?"))
+    return out
 
 
-def sub_train_b8(cfg, xyz_list, local_rank, bf16, steps=2, warmup=1, deterministic=True):
-    """BASELINE configs[2] inside the default line: batch 8 x 180 000-point clouds, pyramid + forward + backward + Adam through
-    ps_randla_train_step, `steps` timed steps after `warmup` (the first step also grows the activation pool)."""
+def sub_train(cfg, xyz_list, local_rank, bf16, steps=5, warmup=1, deterministic=True):
+    """BASELINE configs[2] (batch 8) / the per-rank work of configs[3] (batch 1) inside the default line: B x 180 000-point clouds, pyramid +
+    forward + backward + Adam through ps_randla_train_step; `steps` timed steps after `warmup` (the first step also grows the activation
+    pool), every step also bracketed by its own event pair: `step_ms` = min / median / max of the single steps."""
     import torch
     from point_unet_amd import runtime, weights
     from point_unet_amd.pyramid import alloc_pyramid, build_pyramid
@@ -329,28 +343,50 @@ def sub_train_b8(cfg, xyz_list, local_rank, bf16, steps=2, warmup=1, determinist
                  deterministic=deterministic)
     d_xyz, d_feats, d_lab = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
     pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
+    marks = []
 
     def step():
         build_pyramid(d_xyz, cfg, ctx=ctx, out=pyr)
         return tr.train_step(pyr, d_feats, d_lab)
+
+    def marked_step():
+        out = step()
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()  # (the context runs on torch's current stream here: ctx.use_torch_stream())
+        marks.append(e)
+        return out
 
     def sync():
         ctx.synchronize()
         torch.cuda.synchronize()
 
     step()  # (the first step also grows the activation pool)
+    sync()
+    pool_first = tr.pool_peak_bytes()
     preheat(step, sync, 0.25, batch=2)
     for _ in range(warmup):
         step()
     sync()
-    elapsed, loss = timed_region(step, steps, sync, None)
+    ctx.timing_begin()  # one more untimed step with hipEvent pairs around every op group: launches per step
+    step()
+    sync()
+    launches = sum(ln for _, _, ln in ctx.timing_end())
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    marks.append(e0)
+    elapsed, loss = timed_region(marked_step, steps, sync, None)
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1))
     ms = 1e3 * elapsed / steps
     out = {"ms_per_step": ms, "points_per_s": B * n0 * steps / elapsed, "steps": steps, "warmup": warmup, "batch": B, "points": n0,
+           "step_ms": {"min": round(per_step[0], 3), "median": round(per_step[len(per_step) // 2], 3), "max": round(per_step[-1], 3)},
+           "launches_per_step": launches,
            "dtype": "bf16" if bf16 else "f32", "loss": float(loss), "pool_peak_gb": tr.pool_peak_bytes() / 2 ** 30,
+           "pool_peak_gb_after_first_step": pool_first / 2 ** 30,
            "gradients": "bit-reproducible (fixed-order reductions, csrc/invidx.hip)" if deterministic else "float-atomic scatter-adds (repeat to ~2e-6)",
            "roofline": train_roofline(cfg, n0, B, ms, bf16),
-           "what": "BASELINE configs[2]: one training step (pyramid + train-mode forward + weighted CE + backward + Adam) = ONE ps_pyramid_build + ONE "
-                   "ps_randla_train_step call, batch %d x %d points, %s" % (B, n0, "bf16 MLP GEMMs (fp32 accumulate), rest fp32" if bf16 else "fp32")}
+           "what": "BASELINE configs[%s]: one training step (pyramid + train-mode forward + weighted CE + backward + Adam) = ONE ps_pyramid_build + ONE "
+                   "ps_randla_train_step call, batch %d x %d points, %s" % ("2" if B > 1 else "3], the work of ONE rank [no collective", B, n0,
+                                                                            "bf16 MLP GEMMs (fp32 accumulate), rest fp32" if bf16 else "fp32")}
     tr.close()
     del tr, pyr, d_xyz, d_feats, d_lab
     torch.cuda.empty_cache()
@@ -469,12 +505,13 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
         prof_rows = ctx.timing_end()
     elapsed, loss = timed_region(step, args.steps, sync, dist)
     assert bool(torch.isfinite(loss).all())
-    sections = None
+    sections, collectives = None, None
     if tr.engine == "native" and not args.no_stage_timing:  # per-level device time of one more step (outside the timed region)
         tr.set_profile(True)
         step()
         sync()
         sections = [{"name": nm, "ms": round(t, 4)} for nm, t in tr.profile()]
+        collectives = tr.collective_stats()  # (of that profiled step: event pairs around every callback)
         tr.set_profile(False)
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -499,6 +536,12 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
             "roofline": roofline, "sections": sections, "stages": stages, "launches_per_step": sum(r["launches_per_step"] for r in stages) if stages else None,
             "engine": tr.engine, "loss": float(loss), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
             "pool_peak_gb": tr.pool_peak_bytes() / 2 ** 30 if tr.engine == "native" else None,
+            # calls into the all-reduce callback per step (1 flat gradient buffer + 2 per BatchNorm layer with shared statistics), the bytes they
+            # carry, the host time inside the callback and the device time between event pairs around every call (one profiled step)
+            "collectives_per_step": collectives["calls"] if collectives else None,
+            "collective_bytes_per_step": collectives["bytes"] if collectives else None,
+            "collective_ms": round(collectives["device_ms"], 4) if collectives else None,
+            "collective_host_ms": round(collectives["host_ms"], 4) if collectives else None,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_train(cfg, params, min(n0, 45000))
@@ -609,6 +652,15 @@ def main():
     # finds its own inputs, trees or index tables from the previous step in L2 / MALL
     n_clouds = max(1, args.clouds)
     xyz_all = [np.stack([brats_cloud(n0, 1000 * rank + 17 * i + b) for b in range(B)]) for i in range(n_clouds)]
+    if os.environ.get("PS_BENCH_SORTED"):  # EXPERIMENT ONLY (profiles/tools): clouds stored in Morton order -- what a spatially coherent layout is worth
+        def morton(x):
+            ijk = np.rint(x * np.array([240, 240, 155])).astype(np.uint64)
+            code = np.zeros(len(x), np.uint64)
+            for b in range(8):
+                for a in range(3):
+                    code |= ((ijk[:, a] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + a)
+            return np.argsort(code, kind="stable")
+        xyz_all = [np.stack([c[morton(c)] for c in x]) for x in xyz_all]
     feats_all = [np.concatenate([x, np.random.default_rng(7 + rank + 31 * i).standard_normal((B, n0, cfg.in_channels - 3)).astype(np.float32)], -1)
                  for i, x in enumerate(xyz_all)]
     xyz, feats = xyz_all[0], feats_all[0]
@@ -898,12 +950,31 @@ def main():
             t_sub = time.perf_counter()
             out["config5"] = sub_config5(local_rank, args.lanes, pipe)
             pipe = None
-            out["train_b8"] = {"f32": sub_train_b8(cfg, xyz_all[:8], local_rank, False), "bf16": sub_train_b8(cfg, xyz_all[:8], local_rank, True),
-                               "f32_atomic_scatter": sub_train_b8(cfg, xyz_all[:8], local_rank, False, deterministic=False)} if len(xyz_all) >= 8 else None
+            out["train_b8"] = {"f32": sub_train(cfg, xyz_all[:8], local_rank, False), "bf16": sub_train(cfg, xyz_all[:8], local_rank, True),
+                               "f32_atomic_scatter": sub_train(cfg, xyz_all[:8], local_rank, False, deterministic=False)} if len(xyz_all) >= 8 else None
+            # the per-rank work of BASELINE configs[3] (8 GPUs x 1 cloud): the batch-1 step on this one GPU, no collective
+            out["train_b1"] = {"f32": sub_train(cfg, xyz_all[:1], local_rank, False, steps=10, warmup=2),
+                               "bf16": sub_train(cfg, xyz_all[:1], local_rank, True, steps=10, warmup=2)}
             out["sub_results_seconds"] = round(time.perf_counter() - t_sub, 2)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, xyz[:1], feats[:1], params)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        # LAST in the line (the driver keeps the tail of it): the numbers a reader needs, compact
+        r3 = lambda v: None if v is None else round(v, 3)  # noqa: E731
+        tb8, tb1, c5 = out.get("train_b8") or {}, out.get("train_b1") or {}, out.get("config5") or {}
+        out["summary"] = {
+            "ms_per_step": r3(out["ms_per_step"]), "serial_ms": r3(serial_ms), "pcie_ms": r3((sub.get("include_pcie") or {}).get("ms_per_step")),
+            "knn_us": r3(1e3 * roofline["avg_launch_ms"]) if roofline else None, "knn_frac": roofline["frac"] if roofline else None,
+            "config5_ms": r3(c5.get("ms_per_step")), "config5_serial_ms": r3(c5.get("serial_ms_per_cloud")),
+            "train_f32_ms": r3((tb8.get("f32") or {}).get("ms_per_step")), "train_f32_minmedmax": (tb8.get("f32") or {}).get("step_ms"),
+            "train_bf16_ms": r3((tb8.get("bf16") or {}).get("ms_per_step")), "train_bf16_minmedmax": (tb8.get("bf16") or {}).get("step_ms"),
+            "train_atomic_ms": r3((tb8.get("f32_atomic_scatter") or {}).get("ms_per_step")),
+            "train_b1_f32_ms": r3((tb1.get("f32") or {}).get("ms_per_step")), "train_b1_bf16_ms": r3((tb1.get("bf16") or {}).get("ms_per_step")),
+            "launches": {"train_b8_f32": (tb8.get("f32") or {}).get("launches_per_step"), "train_b8_bf16": (tb8.get("bf16") or {}).get("launches_per_step"),
+                         "train_b1_f32": (tb1.get("f32") or {}).get("launches_per_step"),
+                         "forward": sum(s_["launches_per_step"] for s_ in stages) if stages else None},
+            "cpu_pts_s": r3((out.get("cpu_baseline") or {}).get("value")),
+        }
         print(json.dumps(out))
     if dist:
         dist.barrier()

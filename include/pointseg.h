@@ -489,6 +489,11 @@ int64_t ps_trainer_pool_peak_bytes(const ps_trainer* t);                 /* acti
  * (name, device ms; `launches` unused).  Off by default. */
 int ps_trainer_set_profile(ps_trainer* t, int on);
 int ps_trainer_profile(const ps_trainer* t, ps_timing_row* rows, int cap, int* n_rows);
+/* The collectives of the last step: calls into the ps_allreduce_fn callback (the flat-gradient all-reduce + two per BatchNorm layer
+ * with sync_bn), bytes handed over, host time spent inside the callback, and -- on profiled steps (ps_trainer_set_profile) -- the
+ * device time between an event pair around every call.  A callback given with world_size 1 is still called (the latency floor of the
+ * host's collective on one rank); a NULL callback means no calls.  Any out pointer may be NULL. */
+int ps_trainer_collective_stats(const ps_trainer* t, int64_t* calls, int64_t* bytes, double* host_ms, double* device_ms);
 /* Training-mode forward + class-weighted cross-entropy + backward: fills the bound gradient buffer (this rank's gradients, no
  * collective), updates the BatchNorm moving statistics, writes the loss (device float) and optionally the logits
  * f32[B*N0, classes] (NULL: not wanted).  features f32[B,N0,in_channels], labels i32[B,N0], class_weights f32[classes]; device pointers. */

@@ -186,6 +186,7 @@ PROTOTYPES = {
     "ps_trainer_pool_peak_bytes": (ctypes.c_int64, [c_vp]),
     "ps_trainer_set_profile": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "ps_trainer_profile": (ctypes.c_int, [c_vp, ctypes.POINTER(PsTimingRow), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "ps_trainer_collective_stats": (ctypes.c_int, [c_vp, c_i64p, c_i64p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ps_randla_backward": (ctypes.c_int, [c_vp, ctypes.POINTER(PsPyramid), c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ps_randla_train_step": (ctypes.c_int, [c_vp, ctypes.POINTER(PsPyramid), c_vp, c_vp, c_vp, c_vp, c_vp]),
 }

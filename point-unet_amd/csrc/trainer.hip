@@ -19,6 +19,7 @@
 
 #include <cmath>
 #include <functional>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <unordered_map>
@@ -316,6 +317,11 @@ struct ps_trainer {
     void* coll_user = nullptr;
     int world = 1, rank = 0;
     bool sync_bn = false;
+    // collectives of the last step (ps_trainer_collective_stats): calls into the host's callback, bytes handed over, host time inside
+    // the callback, and -- on profiled steps -- the device time between an event pair around every call
+    int64_t coll_calls = 0, coll_bytes = 0;
+    double coll_host_ms = 0.0, coll_device_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> coll_marks;
     int64_t step = 0;
     Pool pool;
     DevBuf label_map;  // int32 [num_classes + ignored]
@@ -359,6 +365,15 @@ struct ps_trainer {
         }
         for (auto& m : marks) (void)hipEventDestroy(m.second);
         marks.clear();
+        coll_device_ms = 0.0;
+        for (auto& m : coll_marks) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, m.first, m.second);
+            coll_device_ms += ms;
+            (void)hipEventDestroy(m.first);
+            (void)hipEventDestroy(m.second);
+        }
+        coll_marks.clear();
         profile_rows.clear();
         for (const std::string& n : order) profile_rows.emplace_back(n, acc[n]);
     }
@@ -483,8 +498,22 @@ struct ps_trainer {
     }
     void allreduce(void* buf, int64_t count, int dtype)
     {
-        if (!coll || world <= 1) return;
+        if (!coll) return;  // (a world of ONE rank with a callback still goes through it: the latency floor of the host's collective)
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profile) {
+            TK_HIP(hipEventCreate(&e0));
+            TK_HIP(hipEventCreate(&e1));
+            TK_HIP(hipEventRecord(e0, stream()));
+        }
+        const auto h0 = std::chrono::steady_clock::now();
         const int rc = coll(coll_user, buf, count, dtype, (void*)stream());
+        coll_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+        coll_calls += 1;
+        coll_bytes += count * (dtype == 1 ? 8 : 4);
+        if (profile) {
+            (void)hipEventRecord(e1, stream());
+            coll_marks.emplace_back(e0, e1);
+        }
         if (rc != 0) {
             ps::set_error("the host's all-reduce callback failed with code %d", rc);
             throw TrainError{PS_ESTATE};
@@ -657,7 +686,7 @@ struct ps_trainer {
         Tn stats = alloc(5, C, false);  // mean, invstd, var, [sum x | sum x^2]
         float *mean = stats.p, *invstd = stats.p + C, *var = stats.p + 2 * C, *sums = stats.p + 3 * C;
         const float *gamma = params + lp.gamma, *beta = params + lp.beta;
-        const bool sync = sync_bn && coll && world > 1;
+        const bool sync = sync_bn && coll;
         const int64_t R_total = sync ? R * world : R;
         if (!sync) {
             // statistics, moving-statistics update and the apply pass: three launches
@@ -701,7 +730,7 @@ struct ps_trainer {
     Tn locse_bn_act(const float* xyz, const int32_t* idx, int64_t B, int64_t N, int64_t K, const LayerP& lp, const Tn* out = nullptr)
     {
         const int64_t h = lp.cout, R = B * N * K;
-        const bool sync = sync_bn && coll && world > 1;
+        const bool sync = sync_bn && coll;
         const int64_t R_total = sync ? R * world : R;
         const float *W = params + lp.w, *b = params + lp.b, *gamma = params + lp.gamma, *beta = params + lp.beta;
         Tn sums = alloc(1, 4 * h, false);  // 2h doubles: the variance is a difference of nearly equal sums
@@ -751,7 +780,7 @@ struct ps_trainer {
     Tn conv_bn_fused(const Tn& x, const LayerP& lp, bool defer_dgrad, const Tn* out = nullptr)
     {
         const int64_t R = x.R, h = lp.cout, CP = h < 16 ? 16 : h;
-        const bool sync = sync_bn && coll && world > 1;
+        const bool sync = sync_bn && coll;
         const int64_t R_total = sync ? R * world : R;
         const float *W = params + lp.w, *b = params + lp.b, *gamma = params + lp.gamma, *beta = params + lp.beta;
         Tn sums = alloc(1, 6 * CP, false);  // 3 CP doubles: sum y | sum y^2 | sum x
@@ -820,7 +849,7 @@ struct ps_trainer {
     Tn conv_bn_rect(const Tn& x, const LayerP& lp, bool leaky)
     {
         const int64_t R = x.R, ci = lp.cin, co = lp.cout;
-        const bool sync = sync_bn && coll && world > 1;
+        const bool sync = sync_bn && coll;
         const int64_t R_total = sync ? R * world : R;
         const float *W = params + lp.w, *b = params + lp.b, *gamma = params + lp.gamma, *beta = params + lp.beta;
         Tn sums = alloc(1, 4 * co, false);  // 2 cout doubles: sum y | sum y^2
@@ -1299,6 +1328,8 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
     int rc = PS_OK;
     try {
         t->pool.begin_step();
+        t->coll_calls = t->coll_bytes = 0;
+        t->coll_host_ms = 0.0;
         t->next_id = 0;
         t->ops.clear();
         t->grad_of.clear();
@@ -1366,12 +1397,14 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
         return e.rc;
     }
     try {
-        if (t->coll && t->world > 1) {
+        if (t->coll) {
             // gradient synchronisation of config 4: ONE all-reduce of the flat fp32 gradient buffer, then the mean over the ranks
             t->allreduce(t->grads, t->n_params, 0);
-            Stage st(c, "train_adam", 1);
-            hipLaunchKernelGGL(tr_scale_kernel, dim3(tr_grid(t->n_params)), dim3(256), 0, c->stream, t->grads, t->n_params, 1.0f / (float)t->world);
-            TK_HIP(hipGetLastError());
+            if (t->world > 1) {
+                Stage st(c, "train_adam", 1);
+                hipLaunchKernelGGL(tr_scale_kernel, dim3(tr_grid(t->n_params)), dim3(256), 0, c->stream, t->grads, t->n_params, 1.0f / (float)t->world);
+                TK_HIP(hipGetLastError());
+            }
         }
     } catch (const TrainError& e) {
         return e.rc;
@@ -1523,6 +1556,16 @@ int ps_trainer_set_profile(ps_trainer* t, int on)
 {
     PS_CHECK(t, "ps_trainer_set_profile: trainer is NULL");
     t->profile = on != 0;
+    return PS_OK;
+}
+
+int ps_trainer_collective_stats(const ps_trainer* t, int64_t* calls, int64_t* bytes, double* host_ms, double* device_ms)
+{
+    PS_CHECK(t, "ps_trainer_collective_stats: trainer is NULL");
+    if (calls) *calls = t->coll_calls;
+    if (bytes) *bytes = t->coll_bytes;
+    if (host_ms) *host_ms = t->coll_host_ms;
+    if (device_ms) *device_ms = t->coll_device_ms;
     return PS_OK;
 }
 

@@ -836,6 +836,14 @@ class Trainer:
         _lib.check(_lib.lib().ps_trainer_profile(self._h, rows, 64, ctypes.byref(n)))
         return [(rows[i].name.decode(), rows[i].ms) for i in range(n.value)]
 
+    def collective_stats(self):
+        """Collectives of the last step (ps_trainer_collective_stats): dict(calls, bytes, host_ms, device_ms); device_ms is filled on
+        profiled steps only (set_profile)."""
+        calls, nbytes = ctypes.c_int64(0), ctypes.c_int64(0)
+        host, dev = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        _lib.check(_lib.lib().ps_trainer_collective_stats(self._h, ctypes.byref(calls), ctypes.byref(nbytes), ctypes.byref(host), ctypes.byref(dev)))
+        return dict(calls=calls.value, bytes=nbytes.value, host_ms=host.value, device_ms=dev.value)
+
     def pool_peak_bytes(self):
         return int(_lib.lib().ps_trainer_pool_peak_bytes(self._h))
 
