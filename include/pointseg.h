@@ -180,6 +180,10 @@ int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const float* featur
  * which: 0 fc0 [N0,8]; 10+i enc_i [N_i,2d_i]; 20+i pool_i [N_{i+1},2d_i]; 30 decoder_0; 40+j dec_j.
  * Returns PS_EINVAL if count does not match the tensor's size. */
 int ps_randla_tap(ps_randla* net, int which, float* host_out, int64_t count);
+/* on != 0: forwards also STORE the activations nobody but ps_randla_tap reads -- today the output rows of the last decoder step
+ * (tap 40 + num_layers - 1: 23 MB per 180 000-point cloud), which otherwise live only in the registers of the head's layer chain.
+ * Off by default. */
+int ps_randla_keep_taps(ps_randla* net, int on);
 
 /* ---- op-by-op surface (Network.* static methods, RandLANet.py:337-401); device pointers --------------- */
 /* gather_neighbour: pc f32[B,N,d], idx i32[B,M,K] -> out f32[B,M,K,d] */

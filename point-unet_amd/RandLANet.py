@@ -81,6 +81,10 @@ class Network:
         _lib.check(_lib.lib().ps_randla_forward(self._h, ctypes.byref(pyr.struct), runtime.ptr(feats), runtime.ptr(logits)))
         return logits
 
+    def keep_taps(self, on=True):
+        """Forwards also store the activations only tap() reads (the last decoder step's rows); off by default."""
+        _lib.check(_lib.lib().ps_randla_keep_taps(self._h, 1 if on else 0))
+
     def tap(self, which, shape):
         """Copy an internal activation of the last forward to the host (parity tests)."""
         out = np.empty(shape, np.float32)

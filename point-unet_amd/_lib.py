@@ -89,6 +89,7 @@ PROTOTYPES = {
     "ps_randla_set_weights": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64]),
     "ps_randla_forward": (ctypes.c_int, [c_vp, ctypes.POINTER(PsPyramid), c_vp, c_vp]),
     "ps_randla_tap": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, ctypes.c_int64]),
+    "ps_randla_keep_taps": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "ps_op_gather_neighbour": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 5 + [c_vp]),
     "ps_op_relative_pos_encoding": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp]),
     "ps_op_random_sample": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 5 + [c_vp]),

@@ -57,6 +57,11 @@ struct TreeView {
     const float4* pts;
     const TreeMeta* meta;
     int32_t n;
+    // optional "fat" image of the inner nodes, three records per node id: fat[3*id] = nodes[id], fat[3*id + 1] / [3*id + 2] = the records
+    // of its left / right child where that child is an inner node.  One 48-byte fetch then decides TWO levels of a descent: the
+    // search is a chain of dependent loads, and the chain gets a third shorter (55 -> 37 round trips per K = 16 self query of a
+    // 180 000-point cloud).  Written by fatten_kernel (kdtree_build.hip) behind the builders; nullptr = walk `nodes`.
+    const int4* fat = nullptr;
 };
 
 // fp32 arithmetic with one rounding per operation, never contracted into FMA (the reference is built without
@@ -84,12 +89,39 @@ PS_HD float sq_dist(float qx, float qy, float qz, float px, float py, float pz)
     return f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz));
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Device insertion, slot J downwards, with a WAVE-UNIFORM exit: the lists are ascending, so once no lane of the wave has
+// dist[J-1] > d nothing at or below slot J-1 changes for anybody -- and the predicate of slot J-1 is a compare the insertion
+// needs anyway, so the test is its mask against zero and a scalar branch.  A candidate's rank is uniform over the list, and late in
+// a search only a few lanes of a wave have one at all: the deepest slot any of them reaches is usually well above slot 0.  Template
+// recursion instead of a loop with a break: every slot index stays a compile-time constant, the lists stay in registers.
+template <int K, int J>
+struct TopkInsertFrom {
+    static __device__ __forceinline__ void run(float (&dist)[K], int (&idx)[K], float d, int p, bool mine)
+    {
+        if constexpr (J == 0) {
+            idx[0] = mine ? p : idx[0];
+            dist[0] = fminf(dist[0], d);
+        } else {
+            const bool prev = dist[J - 1] > d;
+            const int ni = prev ? idx[J - 1] : p;
+            idx[J] = mine ? ni : idx[J];
+            dist[J] = __builtin_amdgcn_fmed3f(dist[J - 1], dist[J], d);
+            if (__builtin_amdgcn_ballot_w64(prev) == 0ull) return;
+            TopkInsertFrom<K, J - 1>::run(dist, idx, d, p, prev);
+        }
+    }
+};
+#endif
+
 // Ascending list of the K best (distance, index); first-visited wins among equals (shift while stored > d).
 // Written with compile-time indices only so that dist/idx stay in registers on the device.
 template <int K>
 PS_HD void topk_insert(float (&dist)[K], int (&idx)[K], float d, int p)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PS_KNN_FULL_INSERT)
+    TopkInsertFrom<K, K - 1>::run(dist, idx, d, p, dist[K - 1] > d);
+#elif defined(__HIP_DEVICE_COMPILE__)
     // the list is ascending, so the new value of slot j is the MEDIAN of (dist[j-1], dist[j], d): dist[j] when d is not below it,
     // d when it falls between the two, dist[j-1] when both move up -- one v_med3_f32 instead of a compare and two selects; the
     // indices follow the same two predicates
@@ -163,24 +195,47 @@ PS_HD bool knn_search_one(const TreeView& t, float qx, float qy, float qz, float
     int cur = mt.root;
     for (;;) {
         // ---- descend to a leaf, deferring the far children (searchLevel, nanoflann.hpp:1372-1406) ----
-        while (cur & 1) {
-            const int4 nd = gload(t.nodes + cur);
-            const int ax = (int)((unsigned)nd.x >> 30);
-            const int c1 = nd.x & 0x3fffffff, c2 = nd.y;
-            const float divlow = as_f(nd.z), divhigh = as_f(nd.w);
-            const float val = ax == 0 ? qx : (ax == 1 ? qy : qz);
-            const float diff1 = f_sub(val, divlow), diff2 = f_sub(val, divhigh);
-            const bool left_first = f_add(diff1, diff2) < 0.f;
-            const float e = left_first ? diff2 : diff1;  // accum_dist(val, divhigh) or (val, divlow)
-            const float cut = f_mul(e, e);
-            const float dax = ax == 0 ? d0 : (ax == 1 ? d1 : d2);
-            const float m2 = f_sub(f_add(m, cut), dax);
-            // The reference tests `m2 <= worstDist()` AFTER the near subtree returns; worstDist() only ever
-            // decreases, so a far child that already fails now can never pass later: do not defer it.
-            if (m2 <= dist[K - 1])
-                ok &= st.push(left_first ? c2 : c1, m2, ax == 0 ? cut : d0, ax == 1 ? cut : d1, ax == 2 ? cut : d2);
-            cur = left_first ? c1 : c2;
+        // one inner node: decide the near child, defer the far one (a macro, not a lambda: a closure over the stack object and the
+        // lists made the compiler keep them in memory)
+#define PS_KD_VISIT(nd, left_first)                                                                                          \
+    {                                                                                                                        \
+        const int ax = (int)((unsigned)(nd).x >> 30);                                                                        \
+        const int c1 = (nd).x & 0x3fffffff, c2 = (nd).y;                                                                     \
+        const float divlow = as_f((nd).z), divhigh = as_f((nd).w);                                                           \
+        const float val = ax == 0 ? qx : (ax == 1 ? qy : qz);                                                                \
+        const float diff1 = f_sub(val, divlow), diff2 = f_sub(val, divhigh);                                                 \
+        left_first = f_add(diff1, diff2) < 0.f;                                                                              \
+        const float e = left_first ? diff2 : diff1; /* accum_dist(val, divhigh) or (val, divlow) */                          \
+        const float cut = f_mul(e, e);                                                                                       \
+        const float dax = ax == 0 ? d0 : (ax == 1 ? d1 : d2);                                                                \
+        const float m2 = f_sub(f_add(m, cut), dax);                                                                          \
+        /* The reference tests `m2 <= worstDist()` AFTER the near subtree returns; worstDist() only ever decreases, so a far \
+           child that already fails now can never pass later: do not defer it. */                                            \
+        if (m2 <= dist[K - 1])                                                                                               \
+            ok &= st.push(left_first ? c2 : c1, m2, ax == 0 ? cut : d0, ax == 1 ? cut : d1, ax == 2 ? cut : d2);             \
+        cur = left_first ? c1 : c2;                                                                                          \
+    }
+        if (t.fat) {
+            while (cur & 1) {
+                const int4* f = t.fat + 3 * (size_t)cur;
+                const int4 nd = gload(f), kl = gload(f + 1), kr = gload(f + 2);  // the node and both children's records: one round trip
+                bool left;
+                PS_KD_VISIT(nd, left)
+                if (cur & 1) {  // the near child is an inner node: its record is already here
+                    int4 kid;
+                    kid.x = left ? kl.x : kr.x; kid.y = left ? kl.y : kr.y; kid.z = left ? kl.z : kr.z; kid.w = left ? kl.w : kr.w;
+                    bool left2;
+                    PS_KD_VISIT(kid, left2)
+                }
+            }
+        } else {
+            while (cur & 1) {
+                const int4 nd = gload(t.nodes + cur);
+                bool left;
+                PS_KD_VISIT(nd, left)
+            }
         }
+#undef PS_KD_VISIT
         // ---- leaf: scan its points in vind order (nanoflann.hpp:1355-1369) ----
         {
             const int lf_x = (cur & kRefIdMask) >> 1, lf_y = lf_x + (cur >> kRefIdBits);  // from the reference, no node load

@@ -15,6 +15,7 @@ struct TreeSetPlan {
     int extra_jobs = 0;              // additional KnnJob slots wanted in d_jobs (beyond one per tree)
     // carved device storage
     std::vector<int4*> d_nodes;      // [2n] per tree
+    std::vector<int4*> d_fat;        // [3 * 2n] per tree: every inner node with its children's records (TreeView::fat)
     std::vector<float4*> d_pts;      // [n]  per tree (vind order, w = original index)
     TreeMeta* d_meta = nullptr;      // [trees]
     void* d_jobs = nullptr;          // KnnJob table (trees + extra_jobs entries of 64 B)
@@ -29,6 +30,7 @@ struct TreeSetPlan {
         n.push_back(count);
         src.push_back(nullptr);
         d_nodes.push_back(nullptr);
+        d_fat.push_back(nullptr);
         d_pts.push_back(nullptr);
     }
     size_t total_points() const
@@ -42,6 +44,7 @@ struct TreeSetPlan {
     {
         TreeView v;
         v.nodes = d_nodes[i];
+        v.fat = d_fat[i];
         v.pts = d_pts[i];
         v.meta = d_meta + i;
         v.n = n[i];

@@ -45,6 +45,7 @@ struct BuildTree {
     const float* src;
     float4* pts;
     int4* nodes;
+    int4* fat;      // [3 * 2n] (TreeView::fat), filled by fatten_kernel
     TreeMeta* meta;
     int32_t* posL;  // scratch [n]
     int32_t* posR;  // scratch [n]
@@ -1570,6 +1571,26 @@ __global__ void build_finish_kernel(BuildQueues Q)
     Q.flags[2] = 0;
 }
 
+// ---- fat node image (TreeView::fat): every inner node's record next to the records of its two children -------------------------------
+// One thread per node id.  Odd ids that no inner node owns (positions inside a leaf) hold whatever the arena held before: their
+// slots are never visited by a search, so the only care they need is that a stale child reference is not followed out of bounds.
+__global__ __launch_bounds__(256) void fatten_kernel(const BuildTree* __restrict__ trees, int ids_x)
+{
+    const BuildTree tr = trees[blockIdx.y];
+    const int limit = 2 * tr.n;
+    for (int id = 2 * (int)(blockIdx.x * 256 + threadIdx.x) + 1; id < limit; id += 2 * ids_x * 256) {
+        const int4 nd = gload(tr.nodes + id);
+        const int c1 = nd.x & 0x3fffffff, c2 = nd.y;
+        int4 k1 = make_int4(0, 0, 0, 0), k2 = k1;
+        if ((c1 & 1) && c1 > 0 && c1 < limit) k1 = gload(tr.nodes + c1);
+        if ((c2 & 1) && c2 > 0 && c2 < limit) k2 = gload(tr.nodes + c2);
+        int4* f = tr.fat + 3 * (size_t)id;
+        gstore(f, nd);
+        gstore(f + 1, k1);
+        gstore(f + 2, k2);
+    }
+}
+
 static int launch_mid_and_subtrees(ps_context* c, const BuildTree* d_trees, const BuildQueues& Q, size_t tot, size_t T, size_t small_cap)
 {
     constexpr size_t mid_lds = sizeof(float4) * kMid + sizeof(short) * kMid;
@@ -1592,6 +1613,7 @@ void TreeSetPlan::carve(Arena& a)
     const size_t tot = total_points();
     for (size_t i = 0; i < T; ++i) {
         d_nodes[i] = a.take<int4>(2 * (size_t)(n[i] > 0 ? n[i] : 1));
+        d_fat[i] = a.take<int4>(6 * (size_t)(n[i] > 0 ? n[i] : 1));
         d_pts[i] = a.take<float4>((size_t)(n[i] > 0 ? n[i] : 1) + kLeafMax);  // (+ kLeafMax: the search reads whole leaf slots, kdtree.h)
     }
     d_meta = a.take<TreeMeta>(T);
@@ -1651,6 +1673,7 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
         t.src = plan.src[i];
         t.pts = plan.d_pts[i];
         t.nodes = plan.d_nodes[i];
+        t.fat = plan.d_fat[i];
         t.meta = plan.d_meta + i;
         t.posL = d_pos + pos_off;
         t.posR = d_pos + pos_off + (size_t)plan.n[i] + 1;
@@ -1719,7 +1742,13 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     // (the level queues are indexed by the level a task was pushed FOR: chunked level L pushes for L + 1, the roots for 0)
     hipLaunchKernelGGL(build_level_kernel, dim3(grid_big), dim3(kBigThreads), 0, st, d_trees, Q, huge_levels);
     PS_TRY(launch_mid_and_subtrees(c, d_trees, Q, tot, T, small_cap));
-    plan.launches = 6 + 5 * huge_levels;
+    {
+        // the searches' image of the finished trees: every inner node next to its children's records (TreeView::fat)
+        const int ids_x = std::max(1, std::min(ceil_div(max_n, 256), 1024));
+        hipLaunchKernelGGL(fatten_kernel, dim3(ids_x, (unsigned)T), dim3(256), 0, st, d_trees, ids_x);
+        PS_HIP(hipGetLastError());
+    }
+    plan.launches = 7 + 5 * huge_levels;
     return PS_OK;
 }
 

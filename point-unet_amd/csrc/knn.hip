@@ -28,6 +28,8 @@ struct KnnJob {
     int32_t prefix = 0; // != 0: the tree holds exactly the rows [0, tree.n) of the cloud the q4 queries come from (up-sampling queries)
 };
 
+static_assert(sizeof(KnnJob) <= 128, "TreeSetPlan::carve reserves 128 bytes per job");
+
 // Deferred-node stack of the search kernels: the kWin most recent entries of every lane live in LDS
 // ([slot][word][thread]: a wave's access to one word is one conflict-free row), older ones spill to per-lane scratch
 // and come back only when the window has drained.  A pop is the head of the next dependent node load, so its latency

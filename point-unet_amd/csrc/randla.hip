@@ -133,6 +133,7 @@ struct ps_randla {
     // taps of the last forward (device pointers into ctx->net_arena) and their sizes
     struct Tap { int which; const float* p; int64_t count; };
     std::vector<Tap> taps;
+    bool keep_taps = false;  // ps_randla_keep_taps: also store the rows only ps_randla_tap reads (last decoder step)
 };
 
 namespace {
@@ -520,13 +521,14 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
         std::snprintf(nm, sizeof nm, "dec%d", j);
         if (j == L - 1) {
             // last decoder step + the whole head as one chain over the level-0 rows: [skip | up] -> dec -> fc1 -> fc2 -> fc
-            ChainStep ch[4] = {step(net->dec[j], decb[j], skip_c), step(net->fc1, nullptr, 0), step(net->fc2, nullptr, 0),
+            // (the decoder step's own rows feed nothing but fc1: they stay in the chain's registers unless somebody wants the tap)
+            ChainStep ch[4] = {step(net->dec[j], net->keep_taps ? decb[j] : nullptr, skip_c), step(net->fc1, nullptr, 0), step(net->fc2, nullptr, 0),
                                step(net->fc, logits, cfg.num_classes)};
             const RowSrc s1 = src(skip, skip_c, skip_c);
             if (rowchain_fits(ch, 4, s1, s2)) {
                 Stage st(c, "head", 1);
                 PS_TRY(rowchain(c, ch, 4, s1, s2, B * n[lvl], &net->chains));
-                tap(40 + j, decb[j], B * n[lvl] * skip_c);
+                if (net->keep_taps) tap(40 + j, decb[j], B * n[lvl] * skip_c);
                 return PS_OK;
             }
         }
@@ -545,6 +547,13 @@ extern "C" int ps_randla_forward(ps_randla* net, const ps_pyramid* pyr, const fl
     return PS_OK;
 }
 
+extern "C" int ps_randla_keep_taps(ps_randla* net, int on)
+{
+    PS_CHECK(net, "ps_randla_keep_taps: net is NULL");
+    net->keep_taps = on != 0;
+    return PS_OK;
+}
+
 extern "C" int ps_randla_tap(ps_randla* net, int which, float* host_out, int64_t count)
 {
     PS_CHECK(net && host_out, "ps_randla_tap: NULL argument");
@@ -555,6 +564,6 @@ extern "C" int ps_randla_tap(ps_randla* net, int which, float* host_out, int64_t
             PS_HIP(hipStreamSynchronize(net->ctx->stream));
             return PS_OK;
         }
-    set_error("ps_randla_tap: no tensor %d (run a forward first)", which);
+    set_error("ps_randla_tap: no tensor %d (run a forward first; the last decoder step's rows are only kept after ps_randla_keep_taps)", which);
     return PS_EINVAL;
 }

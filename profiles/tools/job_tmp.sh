@@ -1,8 +1,7 @@
-bash profiles/run_pmc_train.sh tr_f32_fetch FETCH_SIZE --batch 8
-bash profiles/run_pmc_train.sh tr_f32_write WRITE_SIZE --batch 8
-bash profiles/run_pmc_train.sh tr_bf16_fetch FETCH_SIZE --batch 8 --bf16-mlp
-bash profiles/run_pmc_train.sh tr_bf16_write WRITE_SIZE --batch 8 --bf16-mlp
-bash profiles/run_pmc_train.sh tr1_f32_fetch FETCH_SIZE --batch 1
-bash profiles/run_pmc_train.sh tr1_f32_write WRITE_SIZE --batch 1
-python3 bench.py > gpurun_out/r4_line2.json 2> gpurun_out/r4_line2.err; tail -c 1800 gpurun_out/r4_line2.json
-python3 bench.py --mode train --batch 1 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r4_train_b1.json
+python -m pytest tests/test_gpu_knn.py -m gpu -x -q 2>&1 | tail -3
+python3 bench.py --no-cpu-baseline --no-sub-results --steps 200 --warmup 20 2>/dev/null | tail -1 > gpurun_out/exp_pipe.json
+python3 -c "
+import json
+d=json.load(open('gpurun_out/exp_pipe.json')); print(d['ms_per_step'], d['serial_ms_per_cloud'], d['roofline']['avg_launch_ms'])
+print({s['name']:s['ms_per_step'] for s in d['stages']})
+"

@@ -19,6 +19,7 @@ def _run_case(oracle, cfg, xyz, feats, seed=2, taps=True):
 
     params = weights.init_params(cfg, seed=seed, randomize_bn=True)
     net = Network(cfg, params=params)
+    net.keep_taps(taps)
     pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
     logits = net.inference({"pyramid": pyr, "features": torch.from_numpy(feats).cuda()}).cpu().numpy()
     # oracle on the oracle's own pyramid (bit-exact equality of the two pyramids is test_gpu_knn's job)
@@ -117,6 +118,7 @@ def _whole_cloud_vs_oracle(oracle, cfg, xyz, feats_dev, feats_oracle):
     from point_unet_amd.pyramid import build_pyramid
     params = weights.init_params(cfg, seed=2, randomize_bn=True)
     net = Network(cfg, params=params)
+    net.keep_taps(True)
     pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
     logits = net.inference({"pyramid": pyr, "features": torch.from_numpy(feats_dev).cuda()}).cpu().numpy()
     assert np.isfinite(logits).all()
