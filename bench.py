@@ -416,10 +416,10 @@ def sub_config5(local_rank, lanes, reuse, steps=40, warmup=8, n_clouds=4):
     pipe.prime(*clouds[0])
     k = [0]
 
-    def step(overlap=True):
+    def step(overlap=True, lane=None):
         x, f = clouds[k[0] % n_clouds]
         k[0] += 1
-        return pipe.submit(x, f, overlap=overlap)
+        return pipe.submit(x, f, overlap=overlap, lane=lane)
 
     def sync():
         pipe.synchronize()
@@ -431,7 +431,7 @@ def sub_config5(local_rank, lanes, reuse, steps=40, warmup=8, n_clouds=4):
     elapsed, logits = timed_region(step, steps, sync, None)
     assert bool(torch.isfinite(logits).all())
     n_serial = max(4, steps // 4)
-    t_serial, _ = timed_region(lambda: step(overlap=False), n_serial, sync, None)
+    t_serial, _ = timed_region(lambda: step(lane=0), n_serial, sync, None)  # (one cloud in flight: consecutive clouds on one lane)
     costs = algorithmic_costs(cfg5, n0, 1)
     net_flops = sum(v["flops"] for kk, v in costs.items() if not kk.startswith(("knn", "kdtree", "pyramid")))
     out = {"ms_per_step": 1e3 * elapsed / steps, "points_per_s": n0 * steps / elapsed, "steps": steps, "warmup": warmup,
@@ -460,7 +460,7 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
     params = weights.init_params(cfg, seed=2)
     tr = Trainer(cfg, params=params, device=local_rank, ctx=ctx, keep_prob=0.5, sync_bn=dist is not None and not args.local_bn,
                  mlp_dtype="bf16" if args.bf16_mlp else "fp32", fused_att=not args.no_fused_att, fused_locse=not args.no_fused_locse, fused_convbn=True if args.fused_convbn else (False if args.no_fused_convbn else None),
-                 engine=args.train_engine, deterministic=not args.atomic_scatter)
+                 engine=args.train_engine, deterministic=not args.atomic_scatter, overlap_wgrad=args.overlap_wgrad)
     d_xyz, d_feats, d_lab = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
     pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
     seen = ranks_seen(dist, "cuda" if args.dist_backend == "nccl" else "cpu") if dist is not None else 1
@@ -547,6 +547,7 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
             out["cpu_baseline"] = cpu_baseline_train(cfg, params, min(n0, 45000))
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
+    tr.close()  # (the activation pool is the trainer's own device memory, not torch's)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -588,6 +589,7 @@ def main():
     ap.add_argument("--atomic-scatter", action="store_true",
                     help="train mode: the scatter-adds of the backward pass with float atomics (run-to-run differences in the last bits) instead of "
                          "fixed-order gather-reductions over inverse indices (A/B of csrc/invidx.hip)")
+    ap.add_argument("--overlap-wgrad", action="store_true", help="train mode: weight-gradient products on a second HIP stream of the trainer (A/B: measured slower)")
     ap.add_argument("--local-bn", action="store_true", help="train mode, N > 1: per-GPU BatchNorm statistics instead of statistics shared by all ranks")
     ap.add_argument("--clouds", type=int, default=8, help="distinct resident clouds every rank rotates through (one per step)")
     ap.add_argument("--no-sub-results", action="store_true", help="skip the PCIe-inclusive sub-result of the default line")
@@ -699,9 +701,9 @@ def main():
         contexts = pipe.contexts
         pipe.prime(d_xyz, d_feats)  # every lane's workspace allocated before the warmup / timed steps
 
-        def step(overlap=True):
+        def step(overlap=True, lane=None):
             x, f = d_clouds[next_cloud()]
-            return pipe.submit(x, f, overlap=overlap)
+            return pipe.submit(x, f, overlap=overlap, lane=lane)
 
         def sync():
             pipe.synchronize()
@@ -789,9 +791,15 @@ def main():
         t_serial, _ = timed_region(lambda: step(overlap=False), dom_steps, sync, None)
         if dominant:
             dom_rows = [r for r in timing_end() if r[0] == dominant]
-        serial_ms = 1e3 * t_serial / dom_steps
+        # ... and the same clouds one after the other on ONE lane: stream order alone, no cross-stream event between consecutive clouds
+        # (rotating over the lanes, every cloud starts behind an event of another hardware queue: ~0.15 ms per cloud on this runtime)
+        t_lane, _ = timed_region(lambda: step(lane=0), dom_steps, sync, None)
+        serial_ms = 1e3 * t_lane / dom_steps
         sub["serial"] = {"ms_per_cloud": serial_ms, "points_per_s": B * n0 / (serial_ms * 1e-3), "steps": dom_steps,
-                         "what": "one cloud in flight: every step waits for the previous cloud (per-cloud latency of pyramid + forward on this rank)"}
+                         "ms_per_cloud_rotating_lanes": 1e3 * t_serial / dom_steps,
+                         "what": "one cloud in flight: consecutive clouds on one lane (one HIP stream), each behind the previous one -- the per-cloud "
+                                 "latency of pyramid + forward on this rank; ms_per_cloud_rotating_lanes = the same with every cloud on the next lane, "
+                                 "waiting for an event of the previous cloud's stream"}
         if not args.no_sub_results and not args.include_pcie:
             # untimed warm-up of the service path itself: the first transfers through freshly pinned host buffers and fresh device slots
             # are slow (page registration with the DMA engines), and at the driver's --steps 20 they WERE the number (r2: 1.66 ms

@@ -451,7 +451,18 @@ int ps_op_dropout(ps_context* ctx, const float* x, int64_t n, uint32_t seed, flo
  * Collectives: the library links no communication library.  A data-parallel host passes an all-reduce callback
  * (RCCL: `ncclAllReduce(buf, buf, count, dtype ? ncclDouble : ncclFloat, ncclSum, comm, (hipStream_t)hip_stream)`); the step
  * calls it once for the flat gradient buffer (then divides by world_size) and, with sync_bn != 0, twice per BatchNorm layer for
- * the [sum | sum of squares] / [sum g | sum g*xhat] vectors, so that "N GPUs x 1 cloud" is the same optimisation step as "1 GPU x N clouds". */
+ * the [sum | sum of squares] / [sum g | sum g*xhat] vectors, so that "N GPUs x 1 cloud" is the same optimisation step as "1 GPU x N clouds"
+ * -- exactly so when every rank holds the same number of NON-IGNORED points (always, without ignored labels): each rank's loss is the
+ * mean over its own valid points and the ranks' gradients are averaged with equal weights, where the one-GPU batch takes one mean over
+ * all valid points; with ignored labels unevenly spread over the ranks the two differ by that weighting.
+ *
+ * Labels: raw labels in [0, num_classes + num_ignored); the ignored ones are dropped and the rest renumbered like the reference's
+ * reducing_list (RandLANet.py:68-81).  A label OUTSIDE that range is treated as ignored (the reference's tf.gather would raise).
+ *
+ * Pyramids: ps_randla_train_step / ps_randla_backward accept any caller-filled ps_pyramid.  The deterministic max-pool backward walks the
+ * neighbour table's inverse index and therefore needs sub_idx[i] to be the first n[i+1] rows per cloud of neigh_idx[i] (what
+ * ps_pyramid_build writes); the trainer compares the two tables once per table (one synchronising check when a new table pointer is first
+ * seen) and takes the float-atomic form for a pooling table that is something else. */
 typedef struct ps_trainer ps_trainer;
 typedef struct {
     float learning_rate;            /* cfg.learning_rate (helper_tool.py:33); Adam beta1 0.9, beta2 0.999, eps 1e-8 (TF defaults) */
@@ -468,6 +479,8 @@ typedef struct {
                                      * MLPs (Encoder mlp2 / shortcut, fc1: ps_op_convbn_train_supported) with the pre-BatchNorm
                                      * product recomputed instead of stored (h <= 64; in the bf16-MLP mode the operands of its three products are
                                      * rounded like the GEMMs it replaces -- h % 16 == 0 --, the 8-channel layer stays fp32 in both forms) */
+    int32_t overlap_wgrad;          /* the weight-gradient products of the backward pass on a second HIP stream of the trainer (they feed nothing
+                                     * before the step's one reduction launch): same kernels, same results, bit for bit */
 } ps_train_options;
 /* In-place sum over the ranks of `count` elements at device pointer `buf` (dtype 0: float32, 1: float64), ordered on `hip_stream`
  * (the context's stream).  Returns 0 on success. */

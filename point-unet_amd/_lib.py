@@ -51,6 +51,7 @@ class PsTrainOptions(ctypes.Structure):
         ("ignored_label_inds", ctypes.c_int32 * 8),
         ("deterministic", ctypes.c_int32),
         ("fused_convbn", ctypes.c_int32),
+        ("overlap_wgrad", ctypes.c_int32),
     ]
 
 

@@ -119,7 +119,13 @@ struct TopkInsertFrom {
 template <int K>
 PS_HD void topk_insert(float (&dist)[K], int (&idx)[K], float d, int p)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PS_KNN_FULL_INSERT)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PS_KNN_EXP_DISTONLY)
+    // EXPERIMENT (wrong indices, timing only): what the kernel costs when an insertion moves distances alone
+#pragma unroll
+    for (int j = K - 1; j >= 1; --j) dist[j] = __builtin_amdgcn_fmed3f(dist[j - 1], dist[j], d);
+    dist[0] = fminf(dist[0], d);
+    idx[0] = p;
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(PS_KNN_FULL_INSERT)
     TopkInsertFrom<K, K - 1>::run(dist, idx, d, p, dist[K - 1] > d);
 #elif defined(__HIP_DEVICE_COMPILE__)
     // the list is ascending, so the new value of slot j is the MEDIAN of (dist[j-1], dist[j], d): dist[j] when d is not below it,

@@ -19,6 +19,7 @@
 
 #include <cmath>
 #include <functional>
+#include <array>
 #include <chrono>
 #include <map>
 #include <memory>
@@ -199,6 +200,18 @@ __global__ __launch_bounds__(256) void tr_copy2d_kernel(const float* __restrict_
     }
 }
 
+// is pool_idx [B, M, K] the first M rows per cloud of neigh [B, N, K]?  (the deterministic max-pool backward walks the neighbour
+// table's inverse index and relies on it: ps_pyramid_build's tables are, a caller-filled pyramid need not be)
+__global__ __launch_bounds__(256) void tr_prefix_check_kernel(const int32_t* __restrict__ pool_idx, const int32_t* __restrict__ neigh, int64_t B, int64_t N, int64_t M,
+                                                              int64_t K, int32_t* __restrict__ mismatch)
+{
+    const int64_t per = M * K, total = B * per;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / per, r = i - b * per;
+        if (pool_idx[i] != neigh[b * N * K + r]) *mismatch = 1;
+    }
+}
+
 __global__ __launch_bounds__(256) void tr_scale_kernel(float* __restrict__ x, int64_t n, float s)
 {
     for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) x[e] *= s;
@@ -323,6 +336,51 @@ struct ps_trainer {
     double coll_host_ms = 0.0, coll_device_ms = 0.0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> coll_marks;
     int64_t step = 0;
+    // ---- second stream (ps_train_options.overlap_wgrad): the weight-gradient products of the backward pass feed nothing before the step's
+    // one reduction launch, so they run on `side` behind an event of the main stream (their operands exist by then) while the main
+    // stream goes on with the input-gradient chain; the reduction waits for the side stream.  The operands stay referenced until then
+    // (wkeep): the pool hands a released block to the NEXT main-stream kernel, which would overwrite it under a product still reading.
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> fork_events;
+    size_t forks_used = 0;
+    hipEvent_t join_event = nullptr;
+    bool side_busy = false;
+    bool use_side() const { return opt.overlap_wgrad != 0; }
+    void fork_to_side()
+    {
+        if (!side) {
+            TK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            TK_HIP(hipEventCreateWithFlags(&join_event, hipEventDisableTiming));
+        }
+        if (forks_used == fork_events.size()) {
+            hipEvent_t e;
+            TK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            fork_events.push_back(e);
+        }
+        hipEvent_t e = fork_events[forks_used++];
+        TK_HIP(hipEventRecord(e, stream()));
+        TK_HIP(hipStreamWaitEvent(side, e, 0));
+        side_busy = true;
+    }
+    void join_side()
+    {
+        if (!side_busy) return;
+        TK_HIP(hipEventRecord(join_event, side));
+        TK_HIP(hipStreamWaitEvent(stream(), join_event, 0));
+        side_busy = false;
+    }
+    void destroy_side()
+    {
+        if (side) {
+            (void)hipStreamSynchronize(side);
+            (void)hipStreamDestroy(side);
+            side = nullptr;
+        }
+        for (hipEvent_t e : fork_events) (void)hipEventDestroy(e);
+        fork_events.clear();
+        if (join_event) (void)hipEventDestroy(join_event);
+        join_event = nullptr;
+    }
     Pool pool;
     DevBuf label_map;  // int32 [num_classes + ignored]
     int n_label_map = 0;
@@ -407,10 +465,30 @@ struct ps_trainer {
                                reinterpret_cast<int32_t*>(ws.p)));
         return inv_cache.emplace(idx, v).first->second;
     }
+    // pooling tables already compared with their neighbour tables (key: both pointers and the shape; value: is a prefix).  One
+    // synchronising check per distinct table -- a pyramid slot that is rebuilt in place keeps its pointers.
+    std::map<std::array<int64_t, 6>, bool> prefix_checked;
+    bool pool_is_prefix(const int32_t* pool_idx, const int32_t* neigh, int64_t B, int64_t N, int64_t M, int64_t K)
+    {
+        if (pool_idx == neigh && B == 1) return true;
+        const std::array<int64_t, 6> key = {(int64_t)reinterpret_cast<uintptr_t>(pool_idx), (int64_t)reinterpret_cast<uintptr_t>(neigh), B, N, M, K};
+        auto it = prefix_checked.find(key);
+        if (it != prefix_checked.end()) return it->second;
+        Tn flag = alloc(1, 1, false);
+        TK_HIP(hipMemsetAsync(flag.p, 0, sizeof(int32_t), stream()));
+        hipLaunchKernelGGL(tr_prefix_check_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(B * M * K, 256), 2048)), dim3(256), 0, stream(), pool_idx, neigh, B, N,
+                           M, K, reinterpret_cast<int32_t*>(flag.p));
+        TK_HIP(hipGetLastError());
+        int32_t h = 0;
+        TK_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream()));
+        TK_HIP(hipStreamSynchronize(stream()));
+        return prefix_checked[key] = h == 0;
+    }
     std::vector<WgradJob> wjobs;  // weight / bias gradient partials waiting for the step's one reduction launch
     std::vector<Tn> wkeep;
     void finish_wgrads()
     {
+        join_side();  // (the partial products may still be running on the second stream)
         if (wjobs.empty()) return;
         Stage st(c, "train_wgrad", 1);
         Tn table = alloc(1, (int64_t)((sizeof(WgradJob) * wjobs.size() + 3) / 4), false);
@@ -639,11 +717,26 @@ struct ps_trainer {
             {
                 // weight / bias gradient: per-slab partials now (plain stores), summed in slab order by the ONE wgrad_finish launch at the
                 // end of the backward pass -- deterministic, no memsets, and the [out, in] layout of the transposed kernels is just a flag
-                Stage st(c, "train_wgrad", 1);
                 const int64_t nb = wgrad_partial_slabs(c, x.p, x.ld, dy.p, dy.ld, R, cin, cout);
                 Tn part = alloc(nb, cin * cout, false);
                 Tn dbp = gb ? alloc(nb, cout, false) : Tn();
-                TK(wgrad_partial(c, x.p, x.ld, dy.p, dy.ld, R, cin, cout, part.p, gb ? dbp.p : nullptr));
+                {
+                    struct StreamScope {  // the product is enqueued on the second stream: the context's stream is what every launch below uses
+                        ps_context* c;
+                        hipStream_t was;
+                        StreamScope(ps_context* ctx, hipStream_t s) : c(ctx), was(ctx->stream) { if (s) c->stream = s; }
+                        ~StreamScope() { c->stream = was; }
+                    };
+                    const bool on_side = use_side();
+                    if (on_side) fork_to_side();
+                    StreamScope ss(c, on_side ? side : nullptr);
+                    Stage st(c, "train_wgrad", 1);
+                    TK(wgrad_partial(c, x.p, x.ld, dy.p, dy.ld, R, cin, cout, part.p, gb ? dbp.p : nullptr));
+                    if (on_side) {
+                        wkeep.push_back(x);
+                        wkeep.push_back(dy);
+                    }
+                }
                 wjobs.push_back(WgradJob{part.p, gW.p, (int)nb, (int)cin, (int)cout, transposed ? 1 : 0});
                 wkeep.push_back(part);
                 if (gb) {
@@ -1020,7 +1113,10 @@ struct ps_trainer {
         const int64_t N = x.R / B, d = x.C;
         Tn out = alloc(B * M, d);
         Tn ties;  // deterministic mode: the forward leaves the tie counts for the backward (one byte per output)
-        if (opt.deterministic && d % 4 == 0 && K <= 255) {
+        // the fixed-order backward walks the PREFIX of the neighbour table's inverse index: only for pooling tables that are that prefix
+        // (a caller-filled pyramid whose pooling table is something else takes the float-atomic form: still correct)
+        const bool by_inverse = opt.deterministic && pool_is_prefix(pool_idx, neigh, B, N, M, K);
+        if (by_inverse && d % 4 == 0 && K <= 255) {
             ties = alloc(1, (B * M * d + 3) / 4, false);
             TK(ps_op_random_sample_ties(c, x.p, pool_idx, B, N, M, K, d, out.p, reinterpret_cast<uint8_t*>(ties.p)));
         } else {
@@ -1031,7 +1127,11 @@ struct ps_trainer {
             const Tn dy = contig(dy_in);
             // (first gradient of x, tie-count form: the kernel stores -- zeros where nothing was pooled from a row -- instead of adding into a
             //  zero-filled buffer)
-            const bool fresh = opt.deterministic && ties && !grad_of.count(xin.id) && xin.contiguous() && (reinterpret_cast<uintptr_t>(dy.p) & 15) == 0;
+            // (the overwriting kernel's own conditions, csrc/invidx.hip maxpool_bwd_inv4_kernel: tie counts, 16-byte rows, 32-bit element and
+            //  table offsets -- a batch beyond them takes the additive form instead of failing)
+            const bool fresh = by_inverse && ties && !grad_of.count(xin.id) && xin.contiguous() && d % 4 == 0 && B * N * d < (1ll << 32) &&
+                               B * N * K < (1ll << 31) &&
+                               ((reinterpret_cast<uintptr_t>(dy.p) | reinterpret_cast<uintptr_t>(out.p) | reinterpret_cast<uintptr_t>(x.p)) & 15) == 0;
             Tn buf = fresh ? alloc(xin.R, xin.C) : accum_buffer(xin);
             if (fresh) grad_of[xin.id] = buf;
             struct Flag {
@@ -1039,7 +1139,7 @@ struct ps_trainer {
                 Flag(ps_context* ctx, bool on) : c(ctx) { c->pool_bwd_overwrite = on; }
                 ~Flag() { c->pool_bwd_overwrite = false; }
             } flag(c, fresh);
-            if (opt.deterministic && buf.contiguous()) {
+            if (by_inverse && buf.contiguous()) {
                 const Inv& iv = inverse(neigh, B, N, N * K);  // (shared with the level's gathers: the pooling rows are a prefix of every segment)
                 Tn share = ties ? Tn() : alloc(B * M, d, false);
                 TK(ps_op_random_sample_bwd_inv(c, dy.p, out.p, x.p, pool_idx, reinterpret_cast<const int32_t*>(iv.offsets.p),
@@ -1328,6 +1428,7 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
     int rc = PS_OK;
     try {
         t->pool.begin_step();
+        t->forks_used = 0;
         t->coll_calls = t->coll_bytes = 0;
         t->coll_host_ms = 0.0;
         t->next_id = 0;
@@ -1379,6 +1480,19 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
     t->ops.clear();
     t->grad_of.clear();
     t->deferred.clear();  // (closures hold tensors: nothing of a failed step may survive it)
+    if (rc != PS_OK) {  // (a failed profiled step: its pending events are not read by anybody)
+        for (auto& m : t->marks) (void)hipEventDestroy(m.second);
+        t->marks.clear();
+        for (auto& m : t->coll_marks) {
+            (void)hipEventDestroy(m.first);
+            (void)hipEventDestroy(m.second);
+        }
+        t->coll_marks.clear();
+    }
+    if (t->side_busy) {  // (a failed step: nothing of it may still run when its tensors go back to the pool)
+        (void)hipStreamSynchronize(t->side);
+        t->side_busy = false;
+    }
     t->wjobs.clear();
     t->wkeep.clear();
     t->inv_cache.clear();
@@ -1481,6 +1595,7 @@ int ps_trainer_destroy(ps_trainer* t)
     t->wkeep.clear();
     t->inv_cache.clear();
     ps::pack_cache_clear(t->pack);
+    t->destroy_side();
     t->pool.destroy();
     t->label_map.release();
     delete t;

@@ -70,11 +70,13 @@ class ForwardPipeline:
     def contexts(self):
         return [ln.ctx for ln in self.lanes]
 
-    def submit(self, xyz, features, overlap=True):
+    def submit(self, xyz, features, overlap=True, lane=None):
         """xyz [B,N0,3], features [B,N0,Cin]: float32 CUDA tensors (ready on torch's current stream).  Enqueues the
         pyramid build and the forward on the next lane; returns the logits tensor [B,N0,classes], complete after
         synchronize() (or after waiting on `last_done`).  overlap=False makes the lane wait for the previously submitted
-        cloud first: bench.py's per-stage profile pass uses it to time kernels without a neighbour on the chip."""
+        cloud first: bench.py's per-stage profile pass uses it to time kernels without a neighbour on the chip.  lane=k pins the cloud
+        to lane k instead of the next one in turn (consecutive clouds on ONE lane run one after the other by stream order alone: the
+        per-cloud latency without any cross-stream event in the chain)."""
         B, n0 = xyz.shape[0], xyz.shape[1]
         if self._shape != (B, n0):
             self.synchronize()
@@ -82,7 +84,7 @@ class ForwardPipeline:
             for ln in self.lanes:
                 ln.pyramid = alloc_pyramid(B, n0, ratios, self.cfg.k_n, xyz.device)
             self._shape = (B, n0)
-        ln = self.lanes[self._i % len(self.lanes)]
+        ln = self.lanes[(self._i if lane is None else int(lane)) % len(self.lanes)]
         ln.submissions.append(self._i)
         self._i += 1
         ln.stream.wait_stream(torch.cuda.current_stream(self.device))  # the inputs were produced on the caller's stream

@@ -2,6 +2,7 @@
 computation goes through the C ABI."""
 import ctypes
 import threading
+import weakref
 
 import numpy as np
 
@@ -17,7 +18,13 @@ class Context:
     def __init__(self, device=0):
         self.device = int(device)
         self._h = ctypes.c_void_p()
+        # objects created on this context that own device memory outside torch's allocator (train.Trainer: its activation pool):
+        # close() destroys the ones still alive before the context goes
+        self._dependents = weakref.WeakSet()
         _lib.check(_lib.lib().ps_create(self.device, ctypes.byref(self._h)))
+
+    def register(self, obj):
+        self._dependents.add(obj)
 
     @property
     def handle(self):
@@ -57,6 +64,11 @@ class Context:
 
     def close(self):
         if self._h:
+            for obj in list(self._dependents):
+                try:
+                    obj.close()
+                except Exception:
+                    pass
             _lib.lib().ps_destroy(self._h)
             self._h = ctypes.c_void_p()
 

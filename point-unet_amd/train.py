@@ -470,7 +470,8 @@ class Trainer:
     """Parameters (flat fp32 buffer + named views), Adam state and the train step."""
 
     def __init__(self, config, params=None, device=0, seed=0, learning_rate=None, class_weights=None, keep_prob=0.5, ctx=None, sync_bn=False,
-                 mlp_dtype="fp32", ignored_label_inds=None, fused_att=True, fused_locse=True, fused_convbn=None, engine="native", deterministic=True):
+                 mlp_dtype="fp32", ignored_label_inds=None, fused_att=True, fused_locse=True, fused_convbn=None, engine="native", deterministic=True,
+                 overlap_wgrad=False):
         """sync_bn: with a `dist` passed to train_step, BatchNorm uses the statistics of all ranks' rows, which makes "W GPUs x
         one cloud" numerically the same step as "one GPU x W clouds" (SURVEY 8e); off = per-GPU statistics.
         mlp_dtype: "fp32" (default) or "bf16" -- BASELINE configs[2]'s "bf16 MLPs": the shared-MLP GEMMs (forward, input gradient,
@@ -498,6 +499,10 @@ class Trainer:
         # issue bound and measured SLOWER than the streaming kernels they replace (batch 8: +0.7 / +0.2 / +1.0 ms with c = 8 / 32 / 64
         # alone, 58.8 vs 56.9 ms with all three) -- correct (tests/test_gpu_train.py) and kept as the starting point for wider tiles
         self.fused_convbn = bool(fused_convbn) and not self.mlp_bf16
+        # native engine (ps_train_options.overlap_wgrad): weight-gradient products on a second HIP stream of the trainer.  OFF by default:
+        # measured on MI355X (round 4, same box): batch 1 9.23 -> 9.74 ms (every fork is an event wait across hardware queues, and dependent
+        # kernels spread over more queues are scheduled later), batch 8 42.56 -> 42.46 ms (the step is already HBM-bound end to end)
+        self.overlap_wgrad = bool(overlap_wgrad)
         # native engine (ps_train_options.fused_convbn): c = 8 on one-thread-per-row kernels (csrc/convbn_rows.hip; fp32 also in the bf16-MLP
         # mode: an 8 x 8 product has no matrix-pipe shape), wider layers on the tile kernels, which round their operands in the bf16 mode
         self._fused_convbn_native = bool(fused_convbn)
@@ -518,6 +523,7 @@ class Trainer:
             rc.d_out[i] = config.d_out[i]
         self._h = ctypes.c_void_p()
         _lib.check(lib.ps_trainer_create(self.ctx.handle, ctypes.byref(rc), ctypes.byref(self._options()), ctypes.byref(self._h)))
+        self.ctx.register(self)  # (Context.close() destroys the trainers still alive on it: the pool is not torch's memory)
         n_par, n_buf = lib.ps_trainer_param_count(self._h), lib.ps_trainer_buffer_count(self._h)
         self.flat = torch.empty(n_par, dtype=torch.float32, device=self.device)
         self.grad = torch.zeros_like(self.flat)
@@ -562,6 +568,7 @@ class Trainer:
         o.mlp_bf16, o.fused_att, o.fused_locse = int(self.mlp_bf16), int(self.fused_att), int(self.fused_locse)
         o.deterministic = int(self.deterministic)
         o.fused_convbn = int(self._fused_convbn_native)
+        o.overlap_wgrad = int(self.overlap_wgrad)
         o.num_ignored = len(self.ignored_label_inds)
         for i, v in enumerate(self.ignored_label_inds):
             o.ignored_label_inds[i] = v
@@ -601,8 +608,7 @@ class Trainer:
 
     def __del__(self):
         try:
-            if getattr(self.ctx, "handle", None):
-                self.close()
+            self.close()  # (ps_trainer_destroy only touches the trainer's own pool, events and stream: safe after the context is gone)
         except Exception:
             pass
 

@@ -4,6 +4,8 @@ the barriers and the MAX-reduce around the timed region, and in training mode `a
 buffer plus the BatchNorm-statistics all-reduces (Trainer(sync_bn=True) whenever a process group exists).  Each run is a fresh
 child process launched the way `torch.distributed.run` would (RANK / WORLD_SIZE / MASTER_* in the environment, 127.0.0.1)."""
 import json
+
+import numpy as np
 import os
 import socket
 import subprocess
@@ -51,12 +53,19 @@ def test_forward_bench_through_rccl_world_size_one():
 
 
 def test_train_bench_through_rccl_world_size_one():
-    """Training mode, batch 1 (BASELINE configs[3]'s per-GPU work): gradient all-reduce of the flat buffer and the SyncBN all-reduces
-    execute through RCCL; the loss must equal the run without a process group (a one-rank mean is the identity) to float rounding."""
-    common = ["--gpus", "1", "--mode", "train", "--batch", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-stage-timing"]
+    """Training mode, batch 1 (BASELINE configs[3]'s per-GPU work): the gradient all-reduce of the flat buffer and the SyncBN all-reduces
+    really execute through RCCL -- a callback given with world size 1 is still called (ps_trainer_set_collective), and the line reports how
+    many calls a step makes (1 flat gradient buffer + 2 per BatchNorm layer) and what they cost.  The shared-statistics form sums in another
+    order than the one-rank kernels, and the bench line's loss is the one after some forty optimisation steps (pre-heat + warm-up + timed):
+    the two trajectories agree to a few per cent, not to rounding -- the numerics of SyncBN are test_gpu_train.py's business
+    (two ranks on this GPU = one rank with batch 2)."""
+    common = ["--gpus", "1", "--mode", "train", "--batch", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
     with_pg = _bench(common + ["--dist-backend", "nccl"], True)
-    without = _bench(common, False)
+    without = _bench(common + ["--no-stage-timing"], False)
     assert with_pg["ranks_seen"] == 1 and with_pg["metric"] == "points_per_sec_train_step"
     assert with_pg["config"]["parameters"] == 4992852
-    assert abs(with_pg["loss"] - without["loss"]) <= 1e-3 * abs(without["loss"]), (with_pg["loss"], without["loss"])
-    print("train ms/step: RCCL world-1 %.3f, no process group %.3f" % (with_pg["ms_per_step"], without["ms_per_step"]))
+    assert with_pg["collectives_per_step"] is not None and with_pg["collectives_per_step"] >= 50, with_pg["collectives_per_step"]
+    assert with_pg["collective_bytes_per_step"] >= 4 * 4992852
+    assert np.isfinite(with_pg["loss"]) and abs(with_pg["loss"] - without["loss"]) <= 5e-2 * abs(without["loss"]), (with_pg["loss"], without["loss"])
+    print("train ms/step: RCCL world-1 %.3f (%d collectives per step, %.3f ms between their event pairs, %.3f ms of host time), no process group %.3f" % (
+        with_pg["ms_per_step"], with_pg["collectives_per_step"], with_pg["collective_ms"], with_pg["collective_host_ms"], without["ms_per_step"]))

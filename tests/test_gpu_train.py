@@ -833,6 +833,59 @@ def test_streaming_gemm_for_millions_of_rows():
     torch.cuda.synchronize()
 
 
+def test_a_pooling_table_that_is_not_the_neighbour_prefix_still_gets_correct_gradients():
+    """ps_randla_train_step accepts any caller-filled ps_pyramid.  The deterministic max-pool backward walks the PREFIX of the neighbour
+    table's inverse index, which is only right when sub_idx[i] = neigh_idx[i][:, :M] (what ps_pyramid_build writes).  The trainer compares
+    the two tables once per table and takes the float-atomic form for a pooling table that is something else: here level 0 pools over the
+    neighbour rows of OTHER points, and the default (deterministic) trainer must agree with the all-atomic one to summation order."""
+    import torch
+    from point_unet_amd import weights
+    from point_unet_amd.pyramid import build_pyramid
+    from point_unet_amd.train import Trainer
+    cfg, xyz, feats = netcase.small_deep(6000, seed=31, B=2)
+    params = weights.init_params(cfg, seed=5, randomize_bn=True)
+    labels = np.random.default_rng(3).integers(0, cfg.num_classes, xyz.shape[:2]).astype(np.int32)
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    M = pyr.sub_idx[0].shape[1]
+    pyr.sub_idx[0].copy_(pyr.neigh_idx[0][:, M:2 * M, :])  # pool every output over some other point's neighbourhood
+    d_feats, d_lab = torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
+    grads = {}
+    for det in (True, False):
+        with Trainer(cfg, params=params, learning_rate=1e-3, keep_prob=1.0, deterministic=det) as tr:
+            loss = float(tr.train_step(pyr, d_feats, d_lab))
+            torch.cuda.synchronize()
+            grads[det] = (loss, tr.grad.double().clone())
+    assert grads[True][0] == grads[False][0]
+    rel = float((grads[True][1] - grads[False][1]).norm() / grads[False][1].norm())
+    assert rel <= 1e-5, rel
+
+
+def test_weight_gradients_on_the_second_stream_change_nothing():
+    """Trainer(overlap_wgrad=True) (ps_train_options.overlap_wgrad): the weight-gradient products run on a second HIP stream of the trainer
+    behind events of the main one, their operands held until the step's reduction launch.  Same kernels on the same data: losses,
+    gradients, parameters and moving statistics of three steps equal the one-stream step bit for bit."""
+    import torch
+    from point_unet_amd import weights
+    from point_unet_amd.pyramid import build_pyramid
+    from point_unet_amd.train import Trainer
+    cfg, xyz, feats = netcase.small_deep(6000, seed=23, B=2)
+    params = weights.init_params(cfg, seed=5, randomize_bn=True)
+    labels = np.random.default_rng(3).integers(0, cfg.num_classes, xyz.shape[:2]).astype(np.int32)
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    d_feats, d_lab = torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
+    out = {}
+    for side in (False, True):
+        with Trainer(cfg, params=params, learning_rate=1e-3, keep_prob=0.5, overlap_wgrad=side) as tr:
+            losses = []
+            for _ in range(3):
+                losses.append(float(tr.train_step(pyr, d_feats, d_lab)))
+            torch.cuda.synchronize()
+            out[side] = (losses, tr.flat.clone(), tr.grad.clone(), tr.flat_buffers.clone())
+    assert out[True][0] == out[False][0]
+    for a, b in zip(out[True][1:], out[False][1:]):
+        assert torch.equal(a, b)
+
+
 def test_rebinding_the_parameter_buffer_between_steps_drops_the_recorded_weight_images():
     """ps_trainer_bind with another parameter buffer (checkpoint reload, buffer swap) between two steps: the trainer replays its
     recorded weight-packing launches at the start of every step, over pointers into the parameter buffer of the step that recorded
