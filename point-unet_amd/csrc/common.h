@@ -125,6 +125,11 @@ struct ps_context {
     ps::PackCache* pack_cache = nullptr;  // (set by the native training step around its work: the step's weight images, packed by ONE launch)
     ps::DevBuf ops_ring[4];  // packed weights of ps_op_conv1x1 (a ring: consecutive calls never repack into the buffer the previous GEMM is still reading)
     int ops_ring_pos = 0;
+    // dense layers of the deep levels / the decoder with at least this many FLOPs on bf16 MFMA over exact three-way splits (gemm32b.hip)
+    // instead of the fp32 MFMA (gemm32.hip); switched with the attention's form by ps_set_att_bf16x3.  PS_GEMM32B_MIN_FLOPS / _RW / _CW:
+    // A/B overrides read once at ps_create
+    double gemm32b_min_flops = 3e8;
+    int gemm32b_rw = 0, gemm32b_cw = 0;
     bool att_bf16x3 = true;   // ps_set_att_bf16x3: attentive pooling at d = 64 / 128 on bf16 MFMA over three-way splits (attpool32b.hip)
     bool train_b3 = true;     // ps_set_train_gemm_b3: large fp32 op-level GEMMs on bf16 MFMA over exact three-way splits (gemm_b3.hip)
     bool conv_w_transposed = false;  // (internal, set around a call by the native trainer) ps_op_conv1x1_ex: w is stored [cout, cin]

@@ -1,6 +1,8 @@
 // context.hip -- ps_context lifetime, error text, workspace buffers, hipEvent stage timing.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace ps {
 
 static thread_local char g_err[512] = "";
@@ -165,6 +167,10 @@ int ps_create(int device, ps_context** out)
         return PS_EHIP;
     }
     c->stream = c->own_stream;
+    // A/B overrides of the split-bf16 dense layers (gemm32b.hip): FLOP threshold (0 = every shape that fits, 1e30 = none), tile shape
+    if (const char* v = std::getenv("PS_GEMM32B_MIN_FLOPS")) c->gemm32b_min_flops = std::atof(v);
+    if (const char* v = std::getenv("PS_GEMM32B_RW")) c->gemm32b_rw = std::atoi(v);
+    if (const char* v = std::getenv("PS_GEMM32B_CW")) c->gemm32b_cw = std::atoi(v);
     *out = c;
     return PS_OK;
 }

@@ -227,7 +227,7 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
         net->chains.clear();
     }
     std::vector<float> host;  // packed image of everything, then one upload
-    struct Pending { PackedLinear* L; size_t wp_off, b_off, wq_off, w32_off; };
+    struct Pending { PackedLinear* L; size_t wp_off, b_off, wq_off, w32_off, w32b_off; };
     std::vector<Pending> pend;
     auto emit = [&](PackedLinear& L, const float* W, const float* b, int cin, int cout, int leaky) {
         L = PackedLinear();
@@ -253,7 +253,13 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
             host.resize(roff + (size_t)cin * cout);
             pack_p32(W, cin, cout, host.data() + roff);
         }
-        pend.push_back({&L, off, boff, qoff, roff});
+        size_t boff3 = 0;
+        if (cin % 16 == 0 && cout % 32 == 0 && (size_t)cin * cout >= 32768) {  // three-plane bfloat16 image for the same shapes (gemm32b.hip)
+            boff3 = (host.size() + 63) & ~size_t(63);
+            host.resize(boff3 + (size_t)cin * cout * 3 / 2);
+            pack_p32b(W, cin, cout, reinterpret_cast<uint16_t*>(host.data() + boff3));
+        }
+        pend.push_back({&L, off, boff, qoff, roff, boff3});
     };
     struct PendingRaw { const float** dst; size_t off; };
     std::vector<PendingRaw> pend_raw;
@@ -344,6 +350,7 @@ extern "C" int ps_randla_set_weights(ps_randla* net, const float* blob, int64_t 
         p.L->bias = net->wbuf.as<float>() + p.b_off;
         p.L->wq = p.wq_off ? net->wbuf.as<float>() + p.wq_off : nullptr;
         p.L->w32 = p.w32_off ? net->wbuf.as<float>() + p.w32_off : nullptr;
+        p.L->w32b = p.w32b_off ? net->wbuf.as<float>() + p.w32b_off : nullptr;
     }
     for (auto& p : pend_raw) *p.dst = net->wbuf.as<float>() + p.off;
     net->have_weights = true;

@@ -32,6 +32,8 @@ struct PackedLinear {
     const void* wb = nullptr;
     // device, pack_p32 image (attpool.h) for the 32x32x2 kernel of the deep levels (gemm32.hip); nullptr when not built
     const float* w32 = nullptr;
+    // device, pack_p32b image (three bfloat16 planes, 6 bytes per weight) for the split-bf16 form of that kernel (gemm32b.hip); nullptr when not built
+    const void* w32b = nullptr;
     const float* bias = nullptr;  // device [cout_pad] (zeros when the layer has no bias)
     int cin = 0, cout = 0;
     int ks = 0;       // k-steps = ceil(cin/4)
@@ -64,6 +66,11 @@ struct RowSrc {
 // route by itself when the layer carries a w32 image and the shape qualifies
 bool gemm32_fits(const PackedLinear& L, const RowSrc& s1, const RowSrc& s2, int64_t R, int ldy);
 int gemm32(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc& s2, int64_t R, float* y, int ldy);
+// ... and on v_mfma_f32_32x32x16_bf16 over exact three-way bfloat16 splits of both operands (gemm32b.hip): the products large enough
+// to be bound by the matrix pipe
+void pack_p32b(const float* W, int cin, int cout, uint16_t* out);  // [cin, cout], cin % 16 == 0, cout % 32 == 0 -> cin*cout*3 uint16
+bool gemm32b_fits(const PackedLinear& L, const RowSrc& s1, const RowSrc& s2, int64_t R, int ldy);
+int gemm32b(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc& s2, int64_t R, float* y, int ldy);
 
 // y[r, 0:cout] (row stride ldy) for r in [0, R)
 int rowgemm(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc& s2, int64_t R, float* y, int ldy);

@@ -743,6 +743,8 @@ int rowgemm(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc
 {
     if (R <= 0) return PS_OK;
     PS_CHECK(s1.c + s2.c == L.cin, "rowgemm: sources give %d channels, layer expects %d", s1.c + s2.c, L.cin);
+    if (c->att_bf16x3 && 2.0 * (double)R * L.cin * L.cout >= c->gemm32b_min_flops && gemm32b_fits(L, s1, s2, R, ldy))
+        return gemm32b(c, L, s1, s2, R, y, ldy);                                  // ... the large ones on split-bf16 MFMA (gemm32b.hip)
     if (gemm32_fits(L, s1, s2, R, ldy)) return gemm32(c, L, s1, s2, R, y, ldy);  // deep levels: 32x32x2 tiles (gemm32.hip)
     PS_CHECK(R < (1ll << 31), "rowgemm: too many rows");
     RowGemmArgs a;
