@@ -878,7 +878,7 @@ def main():
             # HBM bytes per launch cannot be counted from inside this process: they come from separate rocprofv3 --pmc passes of this
             # same command (profiles/run_pmc.sh; FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), committed with the commit they
             # were taken at.  The number is labelled with that source; null when no such file exists for this round.
-            pmc = next((q for q in (os.path.join(ROOT, "profiles", "r%d_pmc_traffic.json" % k) for k in (3, 2)) if os.path.exists(q)), "")
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", "r%d_pmc_traffic.json" % k) for k in (4, 3, 2)) if os.path.exists(q)), "")
             if pmc:
                 t = json.load(open(pmc))
                 roofline["traffic"] = t.get(dominant)
