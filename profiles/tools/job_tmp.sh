@@ -1,12 +1,6 @@
-export PS_EXP_G32B_TWICE=1
-TOPN=1 bash profiles/run_kernel_stats.sh g32b2 --no-pipeline --steps 10 --warmup 3 --no-sub-results > /dev/null 2>&1
-python3 - <<'PY'
-import csv,glob
-f=glob.glob("gpurun_out/prof_g32b2/**/*kernel_trace.csv",recursive=True)[0]
-rows=list(csv.DictReader(open(f)))
-rows.sort(key=lambda r:int(r['Start_Timestamp']))
-names=[r for r in rows if 'gemm32b' in r['Kernel_Name']]
-last=names[-14:]
-for a,b in zip(last[0::2],last[1::2]):
-    print(a['Kernel_Name'][40:70], a['Grid_Size'], 'first', int(a['End_Timestamp'])-int(a['Start_Timestamp']), 'second', int(b['End_Timestamp'])-int(b['Start_Timestamp']), 'gap', int(b['Start_Timestamp'])-int(a['End_Timestamp']))
-PY
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --mode train --batch 1 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r4_bench_line_train_b1_rccl_world1.json
+python3 -c "
+import json
+d=json.load(open('gpurun_out/r4_bench_line_train_b1_rccl_world1.json'))
+print({k:d[k] for k in ('ms_per_step','collectives_per_step','collective_bytes_per_step','collective_ms','collective_host_ms','launches_per_step')})
+print(d['sections'])"
