@@ -31,7 +31,9 @@ namespace ps {
 
 constexpr int kSmall = 256;     // nodes up to this many points are finished by one workgroup, one thread per point (build_flat_kernel;
                                 // 1 024 was measured: flat kernel 44 -> 88 us, mid kernel 106 -> 73 us, no gain)
-constexpr int kMid = 8192;      // nodes up to this many points are split down to <= kSmall by one workgroup in LDS
+constexpr int kMid = 4096;      // nodes up to this many points are split down to <= kSmall by one workgroup in LDS.  Round 4: 8 192 -> 4 096
+                                // (one more chunked level, +30 us, for a mid kernel of 57 instead of 104 us: its levels cost a workgroup
+                                // time in proportion to its points; 2 048 measured no better: 55 us, another +30 us of chunked passes)
 constexpr int kMidThreads = 1024;
 constexpr int kBigThreads = 512;
 constexpr int kMaxLevels = 96;  // per-level task counters

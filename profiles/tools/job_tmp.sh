@@ -1,6 +1,5 @@
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --mode train --batch 1 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r4_bench_line_train_b1_rccl_world1.json
-python3 -c "
-import json
-d=json.load(open('gpurun_out/r4_bench_line_train_b1_rccl_world1.json'))
-print({k:d[k] for k in ('ms_per_step','collectives_per_step','collective_bytes_per_step','collective_ms','collective_host_ms','launches_per_step')})
-print(d['sections'])"
+python3 bench.py --no-cpu-baseline --no-sub-results --steps 100 --warmup 20 2>/dev/null | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); st={s['name']:(s['ms_per_step'],s['launches_per_step']) for s in d['stages']}
+print(round(d['ms_per_step'],4), round(d['serial_ms_per_cloud'],4), st['kdtree_build'], st['knn_search'])"
+TOPN=40 bash profiles/run_kernel_stats.sh kmid --no-pipeline --steps 20 --warmup 3 --no-sub-results 2>&1 | grep -i "build_\|huge\|fatten\|init_points"
