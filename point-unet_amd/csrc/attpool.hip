@@ -391,7 +391,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int j = 0; j < NTB_H; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < NTB_H; ++j) acc[rt][j] = f32x4{b1r[cb][j], b1r[cb][j], b1r[cb][j], b1r[cb][j]};  // bias-seeded: no add in the epilogue
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -404,11 +404,10 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
             for (int j = 0; j < NTB_H; ++j) {
                 const int col = (cb * NTB_H + j) * 16 + c16;
                 if (col < H) {
-                    const float bb = b1r[cb][j];
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) X1[(rt * 16 + g * 4 + r) * P1 + col] = leaky02(acc[rt][j][r] + bb);
+                        for (int r = 0; r < 4; ++r) X1[(rt * 16 + g * 4 + r) * P1 + col] = leaky02(acc[rt][j][r]);
                 }
             }
         }
@@ -420,7 +419,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                    for (int j = 0; j < NTB_H; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < NTB_H; ++j) acc[rt][j] = f32x4{b2r[cb][j], b2r[cb][j], b2r[cb][j], b2r[cb][j]};
 #pragma unroll
                 for (int ks = 0; ks < KS_H; ++ks)
 #pragma unroll
@@ -434,11 +433,10 @@ __global__ __launch_bounds__(WAVES * 64) void att_direct_kernel(AttArgs a)
                 for (int j = 0; j < NTB_H; ++j) {
                     const int col = (cb * NTB_H + j) * 16 + c16;
                     if (col < H) {
-                        const float bb = b2r[cb][j];
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) A[(rt * 16 + g * 4 + r) * PA + H + col] = leaky02(acc[rt][j][r] + bb);
+                            for (int r = 0; r < 4; ++r) A[(rt * 16 + g * 4 + r) * PA + H + col] = leaky02(acc[rt][j][r]);
                     }
                 }
             }
