@@ -393,6 +393,39 @@ def sub_train(cfg, xyz_list, local_rank, bf16, steps=5, warmup=1, deterministic=
     return out
 
 
+def sub_batch2(cfg, params, d_clouds, local_rank, lanes, reuse, steps=40, warmup=8):
+    """TWO clouds of configs[1] per launch on every lane (ps_pyramid_build / ps_randla_forward with B = 2): what the launch-level effects of
+    batch 1 cost -- tails, 352-tile grids on 256 CUs, the launch floor of the deep levels.  Information only: the reference runs batch 1
+    (helper_tool.py:29) and so does the headline.  Returns (sub-result, the pipeline whose lanes the next sub-result takes over)."""
+    import torch
+    from point_unet_amd.pipeline import ForwardPipeline
+    pairs = [(torch.cat([d_clouds[2 * i][0], d_clouds[2 * i + 1][0]], 0), torch.cat([d_clouds[2 * i][1], d_clouds[2 * i + 1][1]], 0))
+             for i in range(len(d_clouds) // 2)]
+    pipe = ForwardPipeline(cfg, params=params, device=local_rank, lanes=lanes, reuse=reuse)
+    pipe.prime(*pairs[0])
+    k = [0]
+
+    def step():
+        x, f = pairs[k[0] % len(pairs)]
+        k[0] += 1
+        return pipe.submit(x, f)
+
+    def sync():
+        pipe.synchronize()
+        torch.cuda.synchronize()
+
+    preheat(step, sync, 0.2)
+    for _ in range(warmup):
+        step()
+    elapsed, logits = timed_region(step, steps, sync, None)
+    assert bool(torch.isfinite(logits).all())
+    n0 = pairs[0][0].shape[1]
+    out = {"ms_per_cloud": 1e3 * elapsed / (2 * steps), "points_per_s": 2 * n0 * steps / elapsed, "steps": steps, "warmup": warmup, "clouds_per_launch": 2,
+           "lanes": lanes, "what": "two clouds per launch on every lane (B = 2 through the same C-ABI calls): NOT the headline -- the reference runs batch 1"}
+    del pairs
+    return out, pipe
+
+
 def sub_config5(local_rank, lanes, reuse, steps=40, warmup=8, n_clouds=4):
     """BASELINE configs[4] inside the default line: 262 144-point cloud, K = 32, 4 input channels, 2 classes, fp16 feature hand-over,
     int32 indices; pyramid + forward, `lanes` clouds in flight and one cloud in flight."""
@@ -956,6 +989,8 @@ def main():
             # the other single-GPU BASELINE configurations, timed in the same run (a few seconds each, after the headline's timed region):
             # configs[2] = the batch-8 training step (fp32 and "bf16 MLPs"), configs[4] = the 262 144-point / K = 32 forward
             t_sub = time.perf_counter()
+            if len(d_clouds) >= 2:
+                out["batch2"], pipe = sub_batch2(cfg, params, d_clouds, local_rank, args.lanes, pipe)
             out["config5"] = sub_config5(local_rank, args.lanes, pipe)
             pipe = None
             out["train_b8"] = {"f32": sub_train(cfg, xyz_all[:8], local_rank, False), "bf16": sub_train(cfg, xyz_all[:8], local_rank, True),
@@ -973,6 +1008,7 @@ def main():
         out["summary"] = {
             "ms_per_step": r3(out["ms_per_step"]), "serial_ms": r3(serial_ms), "pcie_ms": r3((sub.get("include_pcie") or {}).get("ms_per_step")),
             "knn_us": r3(1e3 * roofline["avg_launch_ms"]) if roofline else None, "knn_frac": roofline["frac"] if roofline else None,
+            "batch2_ms_per_cloud": r3((out.get("batch2") or {}).get("ms_per_cloud")),
             "config5_ms": r3(c5.get("ms_per_step")), "config5_serial_ms": r3(c5.get("serial_ms_per_cloud")),
             "train_f32_ms": r3((tb8.get("f32") or {}).get("ms_per_step")), "train_f32_minmedmax": (tb8.get("f32") or {}).get("step_ms"),
             "train_bf16_ms": r3((tb8.get("bf16") or {}).get("ms_per_step")), "train_bf16_minmedmax": (tb8.get("bf16") or {}).get("step_ms"),

@@ -12,6 +12,7 @@ struct TreeSetPlan {
     // inputs
     std::vector<int32_t> n;          // points per tree
     std::vector<const float*> src;   // device pointer to that tree's [n,3] fp32 rows
+    std::vector<float*> copy_dst;    // optional, per tree: device [n,3] buffer that also receives the tree's source rows (may be short / empty)
     int extra_jobs = 0;              // additional KnnJob slots wanted in d_jobs (beyond one per tree)
     // carved device storage
     std::vector<int4*> d_nodes;      // [2n] per tree

@@ -48,6 +48,7 @@ struct BuildTree {
     float4* pts;
     int4* nodes;
     int4* fat;      // [3 * 2n] (TreeView::fat), filled by fatten_kernel
+    float* copy_dst;  // optional [n, 3]: the source rows are also written here (ps_pyramid.xyz[level]: no separate slice launch)
     TreeMeta* meta;
     int32_t* posL;  // scratch [n]
     int32_t* posR;  // scratch [n]
@@ -105,6 +106,11 @@ __global__ __launch_bounds__(256) void init_points_kernel(const BuildTree* __res
     for (int i = blockIdx.x * 256 + threadIdx.x; i < t.n; i += chunks_x * 256) {
         const float x = gload(t.src + 3 * (size_t)i), y = gload(t.src + 3 * (size_t)i + 1), z = gload(t.src + 3 * (size_t)i + 2);
         gstore(t.pts + i, make_float4(x, y, z, __int_as_float(i)));
+        if (t.copy_dst) {
+            gstore(t.copy_dst + 3 * (size_t)i, x);
+            gstore(t.copy_dst + 3 * (size_t)i + 1, y);
+            gstore(t.copy_dst + 3 * (size_t)i + 2, z);
+        }
         mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
         mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
         mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
@@ -1676,6 +1682,7 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
         t.pts = plan.d_pts[i];
         t.nodes = plan.d_nodes[i];
         t.fat = plan.d_fat[i];
+        t.copy_dst = i < plan.copy_dst.size() ? plan.copy_dst[i] : nullptr;
         t.meta = plan.d_meta + i;
         t.posL = d_pos + pos_off;
         t.posR = d_pos + pos_off + (size_t)plan.n[i] + 1;

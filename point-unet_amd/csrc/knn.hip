@@ -26,6 +26,8 @@ struct KnnJob {
     int32_t* overflow;  // set to 1 if any query overflowed the deferred-node stack
     int32_t* order;     // optional [nq]: order[t] = row of the t-th query (self queries: the tree's leaf order, for ps_pyramid.order)
     int32_t prefix = 0; // != 0: the tree holds exactly the rows [0, tree.n) of the cloud the q4 queries come from (up-sampling queries)
+    int32_t sub_m = 0;  // rows [0, sub_m) are ALSO written to sub_out [sub_m, K]: the pooling table of tf_map, pool = neigh_idx[:, :N // r]
+    int32_t* sub_out = nullptr;  // (runBraTS.py:150) -- written by the lane that owns the row, no slice launch behind the search
 };
 
 static_assert(sizeof(KnnJob) <= 128, "TreeSetPlan::carve reserves 128 bytes per job");
@@ -113,6 +115,8 @@ __device__ __forceinline__ void knn_body(const KnnJob& job, float* win)
     }
     if (broken) {
         for (int j = 0; j < K; ++j) gstore(job.out + (size_t)row * K + j, 0);
+        if (row < job.sub_m)
+            for (int j = 0; j < K; ++j) gstore(job.sub_out + (size_t)row * K + j, 0);
         return;
     }
     float dist[K];
@@ -186,12 +190,21 @@ __device__ __forceinline__ void knn_body(const KnnJob& job, float* win)
     const bool ok = knn_search_one<K, WindowStack>(job.tree, qx, qy, qz, dist, idx, st);
     if (!ok) gstore(job.overflow, 1);
     int32_t* o = job.out + (size_t)row * K;
+    int32_t* o2 = row < job.sub_m ? job.sub_out + (size_t)row * K : nullptr;
     if constexpr (K % 4 == 0) {
 #pragma unroll
         for (int j = 0; j < K; j += 4) gstore(reinterpret_cast<int4*>(o + j), make_int4(idx[j], idx[j + 1], idx[j + 2], idx[j + 3]));
+        if (o2) {
+#pragma unroll
+            for (int j = 0; j < K; j += 4) gstore(reinterpret_cast<int4*>(o2 + j), make_int4(idx[j], idx[j + 1], idx[j + 2], idx[j + 3]));
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < K; ++j) gstore(o + j, idx[j]);
+        if (o2) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) gstore(o2 + j, idx[j]);
+        }
     }
 }
 
@@ -370,26 +383,6 @@ extern "C" int ps_knn_batch_i64(ps_context* c, const float* support, const float
 // --------------------------------------------------------------------------------------------------------
 namespace ps {
 
-// dst[b, i, :] = src[b, i, :] for i < n_dst (prefix slice of every cloud), for all pyramid levels in ONE launch
-// (blockIdx.y = level): ten dependent 4-us launches per cloud otherwise.
-struct SliceTable {
-    const int32_t* src[PS_MAX_LAYERS];  // (float rows are copied as 32-bit words)
-    int32_t* dst[PS_MAX_LAYERS];
-    int64_t n_src[PS_MAX_LAYERS], n_dst[PS_MAX_LAYERS];
-    int64_t B;
-    int width;
-};
-__global__ void slice_rows_kernel(SliceTable t)
-{
-    const int l = blockIdx.y;
-    if (!t.dst[l]) return;
-    const size_t per = (size_t)t.n_dst[l] * t.width, total = (size_t)t.B * per;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t b = i / per, r = i % per;
-        t.dst[l][i] = t.src[l][b * (size_t)t.n_src[l] * t.width + r];
-    }
-}
-
 }  // namespace ps
 
 extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int64_t n0, int32_t L, const int32_t* ratios, int32_t K,
@@ -413,27 +406,6 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
     for (int i = 0; i < L; ++i)
         PS_CHECK(pyr->xyz[i] && pyr->neigh_idx[i] && pyr->sub_idx[i] && pyr->interp_idx[i], "ps_pyramid_build: NULL buffer at layer %d", i);
 
-    // xyz[i] = prefix slices (xyz[0] is a plain copy unless the caller aliased it)
-    {
-        Stage st(c, "pyramid_slices", 1);
-        SliceTable t = {};
-        size_t most = 0;
-        for (int i = 0; i < L; ++i) {
-            if (i == 0 && pyr->xyz[0] == xyz0) continue;
-            t.src[i] = reinterpret_cast<const int32_t*>(xyz0);
-            t.dst[i] = reinterpret_cast<int32_t*>(pyr->xyz[i]);
-            t.n_src[i] = n0;
-            t.n_dst[i] = n[i];
-            most = std::max(most, (size_t)B * n[i] * 3);
-        }
-        t.B = B;
-        t.width = 3;
-        if (most > 0) {  // (one layer whose xyz[0] is the caller's own buffer: nothing to copy)
-            hipLaunchKernelGGL(slice_rows_kernel, dim3((unsigned)std::min<size_t>(ceil_div(most, 256), 2048), L), dim3(256), 0, c->stream, t);
-            PS_HIP(hipGetLastError());
-        }
-    }
-
     // trees: (level l in 0..L) x (cloud b).  Level l's point set is the first n[l] points of every cloud.
     TreeSetPlan plan;
     for (int l = 0; l <= L; ++l)
@@ -444,8 +416,14 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
         plan.carve(c->knn_arena);
         if (pass == 0) PS_TRY(c->knn_arena.buf.reserve(c->knn_arena.off));
     }
+    // every tree reads its prefix of the caller's cloud; the builders' first pass also writes those rows to ps_pyramid.xyz[level]
+    // (xyz[i] = xyz[:, :n_i], runBraTS.py:149; xyz[0] may be the caller's own buffer) -- no slice launch
+    plan.copy_dst.assign((size_t)(L + 1) * B, nullptr);
     for (int l = 0; l <= L; ++l)
-        for (int64_t b = 0; b < B; ++b) plan.src[l * B + b] = xyz0 + (size_t)b * n0 * 3;
+        for (int64_t b = 0; b < B; ++b) {
+            plan.src[l * B + b] = xyz0 + (size_t)b * n0 * 3;
+            if (l < L && !(l == 0 && pyr->xyz[0] == xyz0)) plan.copy_dst[l * B + b] = pyr->xyz[l] + (size_t)b * n[l] * 3;
+        }
     {
         Stage st(c, "kdtree_build", 1);
         PS_TRY(build_trees(c, plan));
@@ -467,6 +445,8 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
             j.out = pyr->neigh_idx[l] + (size_t)b * n[l] * K;
             j.overflow = plan.d_flags;
             j.order = pyr->order[l] ? pyr->order[l] + (size_t)b * n[l] : nullptr;
+            j.sub_m = (int32_t)n[l + 1];
+            j.sub_out = pyr->sub_idx[l] + (size_t)b * n[l + 1] * K;
             jobs.push_back(j);
             max_nq = std::max(max_nq, j.nq);
         }
@@ -493,22 +473,6 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
         {
             Stage st(c, "knn_search", 1);  // K-NN self queries and 1-NN up-sampling queries of every level, one launch
             PS_TRY(launch_knn_pair(c, dj, (int)n_self, (int)jobs.size(), max_nq, (int)K));
-        }
-        {
-            Stage st(c, "pyramid_slices", 1);
-            SliceTable t = {};
-            size_t most = 0;
-            for (int l = 0; l < L; ++l) {
-                t.src[l] = pyr->neigh_idx[l];
-                t.dst[l] = pyr->sub_idx[l];
-                t.n_src[l] = n[l];
-                t.n_dst[l] = n[l + 1];
-                most = std::max(most, (size_t)B * n[l + 1] * K);
-            }
-            t.B = B;
-            t.width = K;
-            hipLaunchKernelGGL(slice_rows_kernel, dim3((unsigned)std::min<size_t>(ceil_div(most, 256), 2048), L), dim3(256), 0, c->stream, t);
-            PS_HIP(hipGetLastError());
         }
         if (c->deferred) {
             // no host synchronisation: the status words go to a pinned slot that ps_synchronize() validates; the host
