@@ -42,7 +42,7 @@ for n0 in sizes:
         print("pyramid n0 %6d B %d %-7s exact" % (n0, B, kind), flush=True)
 
 worst = 0.0
-for n0, B, k in [(4099, 1, 16), (6007, 1, 16), (10001, 2, 16), (4610, 3, 16), (8193, 1, 32), (5003, 2, 32), (17001, 1, 16)]  # (the 40 x 40 x 30 lattice of netcase.small_deep holds ~18 000 ellipsoid cells: no larger n0):
+for n0, B, k in [(4099, 1, 16), (6007, 1, 16), (10001, 2, 16), (4610, 3, 16), (8193, 1, 32), (5003, 2, 32), (17001, 1, 16)]:  # (netcase.small_deep's 40 x 40 x 30 lattice holds ~18 000 ellipsoid cells: no larger n0)
     cfg, xyz, feats = netcase.small_deep(n0, seed=n0, k_n=k, B=B)
     err, mag, _ = T._run_case(bindings, cfg, xyz, feats, taps=False)
     worst = max(worst, err)
