@@ -130,6 +130,7 @@ struct ps_context {
     // A/B overrides read once at ps_create
     double gemm32b_min_flops = 3e8;
     int gemm32b_rw = 0, gemm32b_cw = 0;
+    bool gemm32_no_sk8 = false;  // PS_GEMM32_NO_SK8: A/B of the eight-wave split-K form of gemm32.hip
     bool att_bf16x3 = true;   // ps_set_att_bf16x3: attentive pooling at d = 64 / 128 on bf16 MFMA over three-way splits (attpool32b.hip)
     bool train_b3 = true;     // ps_set_train_gemm_b3: large fp32 op-level GEMMs on bf16 MFMA over exact three-way splits (gemm_b3.hip)
     bool conv_w_transposed = false;  // (internal, set around a call by the native trainer) ps_op_conv1x1_ex: w is stored [cout, cin]

@@ -171,6 +171,7 @@ int ps_create(int device, ps_context** out)
     if (const char* v = std::getenv("PS_GEMM32B_MIN_FLOPS")) c->gemm32b_min_flops = std::atof(v);
     if (const char* v = std::getenv("PS_GEMM32B_RW")) c->gemm32b_rw = std::atoi(v);
     if (const char* v = std::getenv("PS_GEMM32B_CW")) c->gemm32b_cw = std::atoi(v);
+    c->gemm32_no_sk8 = std::getenv("PS_GEMM32_NO_SK8") != nullptr;
     *out = c;
     return PS_OK;
 }

@@ -28,11 +28,12 @@ struct Gemm32Args {
     int rgroups, cgroups;  // workgroup grid: row groups x column groups (see the XCD mapping in the kernel)
 };
 
-// waves of a workgroup: SK along K (same output block), 4 / SK consecutive row blocks
+// waves of a workgroup: SK along K (same output block), 4 / SK consecutive row blocks (SK = 8: eight waves, one row block -- the
+// few-row / long-K layers of levels 3-4 and the decoder, whose launch is one exposed chain of loads and MFMAs per wave: half the chain)
 template <int CW, int SK>
-__global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Args a)
+__global__ __launch_bounds__(SK > 4 ? 64 * SK : 256) void gemm32_kernel(Gemm32Args a)
 {
-    constexpr int RB = 4 / SK;  // row blocks per workgroup
+    constexpr int RB = SK > 4 ? 1 : 4 / SK;  // row blocks per workgroup
     __shared__ float red[SK > 1 ? RB * (SK - 1) * CW * 16 * 64 : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hl = lane >> 5, c32 = lane & 31;
@@ -140,15 +141,18 @@ int gemm32(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc&
     // split K across the waves of a workgroup while the plain grid leaves SIMDs idle (1 024 of them) and the slices stay >= 8 chunks
     const int64_t units = (int64_t)rblocks * cgroups;
     int sk = 1;
-    while (sk < 4 && units * sk < 1536 && L.cin / 8 / (sk * 2) >= 8) sk *= 2;
-    const dim3 block(256);
+    while (sk < 8 && units * sk < 1536 && L.cin / 8 / (sk * 2) >= 8) sk *= 2;
+    if (sk == 8 && c->gemm32_no_sk8) sk = 4;
+    const dim3 block(sk > 4 ? 64 * sk : 256);
+    const int rb_per_wg = sk > 4 ? 1 : 4 / sk;
     a.cgroups = cgroups;
-    a.rgroups = (rblocks + (4 / sk) - 1) / (4 / sk);
+    a.rgroups = (rblocks + rb_per_wg - 1) / rb_per_wg;
     const unsigned grid = 8u * (unsigned)((a.rgroups * a.cgroups + 7) / 8);
 #define PS_G32(CW)                                                                                       \
     if (sk == 1) hipLaunchKernelGGL((gemm32_kernel<CW, 1>), dim3(grid), block, 0, c->stream, a);         \
     else if (sk == 2) hipLaunchKernelGGL((gemm32_kernel<CW, 2>), dim3(grid), block, 0, c->stream, a);    \
-    else hipLaunchKernelGGL((gemm32_kernel<CW, 4>), dim3(grid), block, 0, c->stream, a)
+    else if (sk == 4) hipLaunchKernelGGL((gemm32_kernel<CW, 4>), dim3(grid), block, 0, c->stream, a);    \
+    else hipLaunchKernelGGL((gemm32_kernel<CW, 8>), dim3(grid), block, 0, c->stream, a)
     if (cw == 2) { PS_G32(2); } else { PS_G32(1); }
 #undef PS_G32
     PS_HIP(hipGetLastError());

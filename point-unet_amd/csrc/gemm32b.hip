@@ -93,9 +93,9 @@ struct Gemm32bArgs {
 
 // waves of a workgroup: SK along K (same output block), 4 / SK consecutive row units of 32 RW rows
 template <int RW, int CW, int SK>
-__global__ __launch_bounds__(256) void gemm32b_kernel(Gemm32bArgs a)
+__global__ __launch_bounds__(SK > 4 ? 64 * SK : 256) void gemm32b_kernel(Gemm32bArgs a)
 {
-    constexpr int RU = 4 / SK;  // row units per workgroup
+    constexpr int RU = SK > 4 ? 1 : 4 / SK;  // row units per workgroup (SK = 8: eight waves on one row unit)
     __shared__ float red[SK > 1 ? RU * (SK - 1) * RW * CW * 16 * 64 : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hl = lane >> 5, c32 = lane & 31;
@@ -294,15 +294,19 @@ int gemm32b(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc
     // split K across the waves of a workgroup while the plain grid leaves SIMDs idle (1 024 of them) and the slices keep >= 4 chunks
     const int64_t units = (int64_t)runits * cgroups;
     int sk = 1;
+    // (eight waves per workgroup -- gemm32.hip's form for the long-K layers -- measured SLOWER here: dec1 24.8 -> 30.8 us, pipelined step
+    //  0.857 -> 0.875 ms: twice the partial sums through LDS for a chain that the register ring already keeps fed)
     while (sk < 4 && units * sk < 1536 && L.cin / 16 / (sk * 2) >= 4) sk *= 2;
+    const int ru_per_wg = sk > 4 ? 1 : 4 / sk;
     a.cgroups = cgroups;
-    a.rgroups = (runits + (4 / sk) - 1) / (4 / sk);
+    a.rgroups = (runits + ru_per_wg - 1) / ru_per_wg;
     const unsigned grid = 8u * (unsigned)((a.rgroups * a.cgroups + 7) / 8);
-    const dim3 block(256);
+    const dim3 block(sk > 4 ? 64 * sk : 256);
 #define PS_G32B(RW_, CW_)                                                                                            \
     if (sk == 1) hipLaunchKernelGGL((gemm32b_kernel<RW_, CW_, 1>), dim3(grid), block, 0, c->stream, a);              \
     else if (sk == 2) hipLaunchKernelGGL((gemm32b_kernel<RW_, CW_, 2>), dim3(grid), block, 0, c->stream, a);         \
-    else hipLaunchKernelGGL((gemm32b_kernel<RW_, CW_, 4>), dim3(grid), block, 0, c->stream, a)
+    else if (sk == 4 || RW_ * CW_ > 2) hipLaunchKernelGGL((gemm32b_kernel<RW_, CW_, 4>), dim3(grid), block, 0, c->stream, a); \
+    else hipLaunchKernelGGL((gemm32b_kernel<RW_, CW_, (RW_ * CW_ > 2 ? 4 : 8)>), dim3(grid), block, 0, c->stream, a)
     if (rw == 2 && cw == 2) { PS_G32B(2, 2); }
     else if (rw == 2) { PS_G32B(2, 1); }
     else if (cw == 2) { PS_G32B(1, 2); }
