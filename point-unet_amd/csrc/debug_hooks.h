@@ -24,6 +24,12 @@ int ps_debug_pack_weights(const float* W, int cin, int cout, int ntb, float* out
 /* Three-plane bfloat16 image of a row-major W[cin,cout] for the split-bf16 attention kernels (csrc/attpool32b.hip: pack_b3):
  * out = uint16 [cout/32][cin/16][3 planes][64 lanes][8]. */
 int ps_debug_pack_b3(const float* W, int cin, int cout, uint16_t* out);
+/* One dense layer of the deep levels, Y = act([X1[g1] | X2[g2]] . W + b), through gemm32b.hip (split_bf16 != 0: bf16 MFMA over exact
+ * three-way splits) or gemm32.hip (fp32 MFMA); needs a GPU.  x1 / x2 / g1 / g2 / y: DEVICE pointers (g* may be NULL: plain rows; gm / gn:
+ * batched gather, row r reads x[(r / gm) * gn + g[r]] when gm != 0), W [c1 + c2, cout] and bias [cout]: HOST.  Returns PS_EINVAL when the
+ * shape does not fit the kernel. */
+int ps_debug_gemm32(ps_context* ctx, int split_bf16, const float* x1, int ld1, int c1, const int32_t* g1, const float* x2, int ld2, int c2,
+                    const int32_t* g2, int gm, int gn, const float* W, const float* bias, int64_t R, int cout, int leaky, float* y, int ldy);
 
 #ifdef __cplusplus
 }

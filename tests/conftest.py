@@ -40,6 +40,8 @@ def dbg(lib):
         "ps_debug_kdtree_device": [c_vp, c_vp, i64, c_vp, c_vp, c_vp, c_vp, c_vp],
         "ps_debug_pack_weights": [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp],
         "ps_debug_pack_b3": [c_vp, ctypes.c_int, ctypes.c_int, c_vp],
+        "ps_debug_gemm32": [c_vp, ctypes.c_int, c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, ctypes.c_int,
+                            c_vp, c_vp, i64, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int],
     }
     for name, args in protos.items():
         fn = getattr(h, name)

@@ -46,3 +46,55 @@ def test_awkward_configuration(oracle, case):
         assert np.array_equal(pyr.interp_idx[i].cpu().numpy(), up[i]), i
     want = ro.inference(params, cfg.num_layers, pts, nbr, pool, up, feats, np.float64)
     assert np.abs(got - want).max() <= 1e-4
+
+
+# (R, c1, c2, cout, gather on the second source, leaky): the deep levels' layers and the decoder's concat steps, ragged row counts,
+# one / two / four column blocks, K split over one, two, four and (fp32 form) eight waves
+_GEMM32_CASES = [
+    (703, 1024, 0, 1024, False, 1),     # decoder_0-like: few rows, long K
+    (351, 512, 1024, 512, True, 1),     # first decoder step: [skip | nearest-interpolated], K = 1 536
+    (2812, 256, 512, 256, True, 1),
+    (11250, 128, 128, 256, False, 1),   # [mlp2 ; shortcut] of level 2 (two plain sources)
+    (4097, 64, 0, 96, False, 0),        # three column blocks, no activation
+    (33, 16, 0, 32, False, 1),          # a single ragged row block, one K chunk
+    (32768, 32, 16, 64, True, 1),       # the row limit of the kernels, K = 48
+]
+
+
+@pytest.mark.parametrize("split_bf16", [1, 0])
+@pytest.mark.parametrize("case", _GEMM32_CASES)
+def test_deep_level_dense_layers_against_float64(lib, dbg, case, split_bf16):
+    """csrc/gemm32b.hip (bf16 MFMA over exact three-way splits of both operands) and csrc/gemm32.hip (fp32 MFMA) on their own, through the
+    test-only door ps_debug_gemm32: Y = act([X1 | X2[g]] . W + b) against a float64 product.  Both carry fp32-level error: the bar is
+    2e-6 of the row's |x| . |w| sum (an fp32 dot product of K terms in MFMA order), the same for the split form."""
+    import ctypes
+    import torch
+    from point_unet_amd import runtime
+    R, c1, c2, cout, gather, leaky = case
+    rng = np.random.default_rng(R + cout)
+    n2 = max(R // 4, 1)
+    x1 = rng.standard_normal((R, c1)).astype(np.float32) * rng.uniform(0.01, 4.0, (1, c1)).astype(np.float32)
+    x2 = rng.standard_normal((n2 if gather else R, max(c2, 1))).astype(np.float32)
+    g2 = rng.integers(0, n2, R).astype(np.int32) if gather else None
+    W = (rng.standard_normal((c1 + c2, cout)) / np.sqrt(c1 + c2)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    d_x1, d_x2 = torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda()
+    d_g2 = torch.from_numpy(g2).cuda() if gather else None
+    y = torch.full((R, cout), float("nan"), dtype=torch.float32, device="cuda")
+    ctx = runtime.default_context(0)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)  # noqa: E731
+    torch.cuda.synchronize()
+    rc = dbg.ps_debug_gemm32(ctx.handle, split_bf16, p(d_x1), c1, c1, None, p(d_x2) if c2 else None, max(c2, 1), c2, p(d_g2), 0, 0,
+                             W.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p), R, cout, leaky, p(y), cout)
+    assert rc == 0, lib.ps_last_error()
+    torch.cuda.synchronize()
+    X = x1.astype(np.float64) if not c2 else np.concatenate([x1.astype(np.float64), (x2[g2] if gather else x2).astype(np.float64)], 1)
+    want = X @ W.astype(np.float64) + b.astype(np.float64)
+    scale = np.abs(X) @ np.abs(W.astype(np.float64)) + np.abs(b)
+    if leaky:
+        want = np.where(want >= 0, want, 0.2 * want)
+    got = y.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    rel = float((np.abs(got - want) / scale).max())
+    print("R %d K %d N %d split %d: max err / (|x|.|w|) = %.2e" % (R, c1 + c2, cout, split_bf16, rel))
+    assert rel <= 2e-6, rel
