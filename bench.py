@@ -878,6 +878,10 @@ def main():
             # attentive pooling at d_out >= 64 runs its products as SIX bf16 MFMAs per fp32 product (exact three-way splits,
             # csrc/attpool32b.hip): the matrix-pipe ceiling of those stages, in fp32 FLOPs, is the dense bf16 peak / 6
             split = (not args.att_fp32_mfma) and "_att" in name and name.startswith("enc") and cfg.d_out[int(name[3])] >= 64
+            # ... and so do the single-launch decoder stages whose product is >= 0.3 GFLOP (csrc/gemm32b.hip; the [mlp2 ; shortcut] launches of
+            # levels 2-4 share their `encN_dense` stage with fp32-MFMA launches and stay listed with the fp32 pipe)
+            if (not args.att_fp32_mfma) and name in ("decoder_0", "dec0", "dec1", "dec2") and cst["flops"] >= 3e8 and os.environ.get("PS_GEMM32B_MIN_FLOPS") is None:
+                split = True
             mfma_peak = BF16_MFMA_PEAK_TF / 6 if split else F32_MFMA_PEAK_TF
             f_h, f_m = gbs / HBM_PEAK_GBS, tfs / mfma_peak
             bound = "mfma" if f_m > f_h else "hbm"
@@ -944,11 +948,11 @@ def main():
             pipe: dict(algorithmic_flops_per_step=fl, ms_per_step=round(ms_p, 4), achieved=round(fl / (ms_p * 1e-3) / 1e12, 3) if ms_p > 0 else 0.0,
                        unit="TFLOP/s", peak=round(BF16_MFMA_PEAK_TF / 6, 1) if pipe == "bf16x3" else F32_MFMA_PEAK_TF,
                        frac=round(fl / (ms_p * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TF / 6 if pipe == "bf16x3" else F32_MFMA_PEAK_TF), 5) if ms_p > 0 else 0.0,
-                       what=("attentive pooling at d_out >= 64: six bf16 MFMAs per fp32 product over exact splits (ceiling = dense bf16 peak / 6, in fp32 FLOPs)"
+                       what=("attentive pooling at d_out >= 64 and the decoder's large products: six bf16 MFMAs per fp32 product over exact splits (ceiling = dense bf16 peak / 6, in fp32 FLOPs)"
                              if pipe == "bf16x3" else "everything else: fp32 MFMA / HBM-bound stages"))
             for pipe, (fl, ms_p) in by_pipe.items()}
         if not args.att_fp32_mfma:
-            roofline_network["note"] = ("the single figure above is quoted against the fp32 MFMA peak although ten stages run on the bf16 pipe: it is a "
+            roofline_network["note"] = ("the single figure above is quoted against the fp32 MFMA peak although fourteen stages run on the bf16 pipe: it is a "
                                         "rate in reference-formulation FLOPs, not the utilisation of one pipe -- see by_pipe")
         out = {
             "metric": "points_per_sec_forward",
