@@ -589,8 +589,9 @@ static int launch_att32b(ps_context* c, const Att32bArgs& a)
     constexpr int H = D / 2, PITCH = H + 4, TILE = 32 * PITCH;
     constexpr int CBH = H / 32, CBD = D / 32, NQ = H / 16;
     // d = 128: 78 KB of weight planes + eight 8.8 KB tiles = 148 KB: one workgroup of eight waves per CU; d = 64: 21 KB + twelve 4.7 KB
-    // tiles, one workgroup of twelve waves (134 registers: three waves per SIMD)
-    constexpr int WAVES = D == 128 ? 8 : 12;
+    // tiles, one workgroup of twelve waves (134 registers: three waves per SIMD) in stage 2
+    // (d = 64, stage 1: sixteen waves -- 126 registers, four waves per SIMD: 43.5 -> 41.2 us; stage 2 needs 134 and spills at sixteen: 50.0 -> 51.0)
+    constexpr int WAVES = D == 128 ? 8 : (STAGE == 1 ? 16 : 12);
     constexpr int PER_CU = 1;
     constexpr size_t planes = (size_t)(CBH + (STAGE == 2 ? CBH * NQ : 0) + CBD * NQ) * 3 * 64 * 16;
     constexpr size_t smem = planes + sizeof(float) * (2 * H + (size_t)WAVES * (32 + TILE));
