@@ -494,6 +494,9 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
     tr = Trainer(cfg, params=params, device=local_rank, ctx=ctx, keep_prob=0.5, sync_bn=dist is not None and not args.local_bn,
                  mlp_dtype="bf16" if args.bf16_mlp else "fp32", fused_att=not args.no_fused_att, fused_locse=not args.no_fused_locse, fused_convbn=True if args.fused_convbn else (False if args.no_fused_convbn else None),
                  engine=args.train_engine, deterministic=not args.atomic_scatter, overlap_wgrad=args.overlap_wgrad)
+    # under a ONE-rank process group the step still goes through the all-reduce callback: that is how collectives_per_step / collective_ms
+    # are measured on a 1-GPU box; a training script would let the trainer skip it
+    tr.collective_at_world_one = True
     d_xyz, d_feats, d_lab = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
     pyr = alloc_pyramid(B, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
     seen = ranks_seen(dist, "cuda" if args.dist_backend == "nccl" else "cpu") if dist is not None else 1

@@ -503,6 +503,7 @@ class Trainer:
         # measured on MI355X (round 4, same box): batch 1 9.23 -> 9.74 ms (every fork is an event wait across hardware queues, and dependent
         # kernels spread over more queues are scheduled later), batch 8 42.56 -> 42.46 ms (the step is already HBM-bound end to end)
         self.overlap_wgrad = bool(overlap_wgrad)
+        self.collective_at_world_one = False  # call the all-reduce callback even when the process group has ONE rank (measurement)
         # native engine (ps_train_options.fused_convbn): c = 8 on one-thread-per-row kernels (csrc/convbn_rows.hip; fp32 also in the bf16-MLP
         # mode: an 8 x 8 product has no matrix-pipe shape), wider layers on the tile kernels, which round their operands in the bf16 mode
         self._fused_convbn_native = bool(fused_convbn)
@@ -796,7 +797,9 @@ class Trainer:
         lib = _lib.lib()
         self._rank = dist.get_rank() if dist is not None else 0
         self._world = dist.get_world_size() if dist is not None else 1
-        if dist is not None:
+        # (one rank under a process group: the library would call the callback -- useful to measure what the collectives cost, bench.py
+        #  sets collective_at_world_one for that -- but a one-rank mean is the identity: the plain single-rank step is 15 % faster)
+        if dist is not None and (self._world > 1 or self.collective_at_world_one):
             _lib.check(lib.ps_trainer_set_collective(self._h, self._collective(dist), None, self._world, self._rank, 1 if self.sync_bn else 0))
         else:
             _lib.check(lib.ps_trainer_set_collective(self._h, _lib.PS_ALLREDUCE_FN(), None, 1, 0, 0))  # NULL callback: single rank
