@@ -1,0 +1,35 @@
+"""Round-4 soak of the training step (not part of the test-suite): ragged cloud sizes and batch counts at the true widths through
+ps_randla_train_step against torch-CPU float64 autograd (oracle/randla_train_oracle.py); bars of tests/test_gpu_train.py's width-ladder
+test.  Sizes keep >= 23 rows at the deepest level (BatchNorm over fewer rows than K amplifies fp32 rounding past the 1e-4 logits bar:
+5 003 points alone measured 1.4e-4 with loss 1.5e-7 and gradients 4e-5).  usage (GPU box): python profiles/tools/soak_train_r4.py"""
+import os
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root)
+sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import netcase  # noqa: E402
+import test_gpu_train as T  # noqa: E402
+from oracle import randla_train_oracle as rto  # noqa: E402
+
+for n0, B, mode in [(12345, 1, "fp32"), (7777, 3, "fp32"), (12001, 2, "fp32"), (9001, 2, "bf16"), (16001, 1, "fp32")]:
+    cfg, xyz, feats = netcase.small_deep(n0, seed=n0, B=B)
+    tr, pyr, params, labels, cw, (pts, nbr, pool, up) = T._setup(cfg, xyz, feats, mlp_dtype=mode)
+    loss = tr.train_step(pyr, torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda())
+    torch.cuda.synchronize()
+    rule = T._bf16_rule if mode == "bf16" else None
+    want = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, step=1, bf16_rule=rule)
+    got = {n: tr.G[n].cpu().numpy() for n in tr.names}
+    rel_loss = abs(float(loss) - want["loss"]) / max(1.0, abs(want["loss"]))
+    logit_err = float(np.abs(tr.last_logits.cpu().numpy().reshape(want["logits"].shape) - want["logits"]).max())
+    rel_l2, worst = T._grad_stats(got, want["grads"], tr.names)
+    print("n0 %6d B %d %s: loss rel %.2e, logits %.2e, grad rel L2 %.2e, worst tensor %.3f (%s)" % (n0, B, mode, rel_loss, logit_err, rel_l2, worst[0][0], worst[0][1]), flush=True)
+    if mode == "fp32":
+        assert rel_loss <= 2e-5 and logit_err < 1e-4 and rel_l2 <= 5e-3 and worst[0][0] <= 1.0
+    else:
+        assert np.isfinite(rel_l2) and rel_l2 < 0.5
+    tr.close()
+print("ok")
