@@ -38,6 +38,14 @@ static_assert(sizeof(KnnJob) <= 128, "TreeSetPlan::carve reserves 128 bytes per 
 // (LDS ~100 cycles vs a scratch round trip through L2/HBM) is on the critical path of every query; the first descent
 // pushes ~log2(n/10) entries, of which the shallow ones -- spilled -- are almost always pruned by their `m` alone.
 constexpr int kWin = 8;
+// Threads per search workgroup (the LDS window is [slot][word][thread]).  ONE wave: the kernel has no workgroup-level step, and a
+// workgroup retires as soon as its own 64 queries are done instead of with the slowest of four waves -- its LDS and wave slot go to the next
+// workgroup (or to another lane's kernel) that much earlier.  Measured (round 4, same box): 256 threads 0.182 ms / pipelined step 0.860,
+// 128: 0.172 / 0.850, 64: 0.168 / 0.833, 512: 0.211 / 0.880.
+#ifndef PS_KNN_THREADS
+#define PS_KNN_THREADS 64
+#endif
+constexpr int kKnnThreads = PS_KNN_THREADS;
 // the spill arrays live in their own object: indexed dynamically, they stay in scratch memory, and as members of WindowStack they
 // kept its sp / lo counters there too (a scratch store per push, a scratch load in front of every pop)
 struct SpillStore {
@@ -53,12 +61,12 @@ struct WindowStack {
     {
         if (sp >= kStackMax) return false;
         if (sp - lo == kWin) {  // spill the oldest windowed entry
-            const lds_float* e = w + (lo & (kWin - 1)) * 5 * 256;
-            sp_->sid[lo] = __float_as_int(e[0]); sp_->sm[lo] = e[256]; sp_->s0[lo] = e[512]; sp_->s1[lo] = e[768]; sp_->s2[lo] = e[1024];
+            const lds_float* e = w + (lo & (kWin - 1)) * 5 * kKnnThreads;
+            sp_->sid[lo] = __float_as_int(e[0]); sp_->sm[lo] = e[kKnnThreads]; sp_->s0[lo] = e[2 * kKnnThreads]; sp_->s1[lo] = e[3 * kKnnThreads]; sp_->s2[lo] = e[4 * kKnnThreads];
             ++lo;
         }
-        lds_float* e = w + (sp & (kWin - 1)) * 5 * 256;
-        e[0] = __int_as_float(node); e[256] = mm; e[512] = a; e[768] = b; e[1024] = c;
+        lds_float* e = w + (sp & (kWin - 1)) * 5 * kKnnThreads;
+        e[0] = __int_as_float(node); e[kKnnThreads] = mm; e[2 * kKnnThreads] = a; e[3 * kKnnThreads] = b; e[4 * kKnnThreads] = c;
         ++sp;
         return true;
     }
@@ -67,10 +75,10 @@ struct WindowStack {
         while (sp > 0) {
             --sp;
             if (sp >= lo) {
-                const lds_float* e = w + (sp & (kWin - 1)) * 5 * 256;
-                const float em = e[256];
+                const lds_float* e = w + (sp & (kWin - 1)) * 5 * kKnnThreads;
+                const float em = e[kKnnThreads];
                 if (em <= worst) {
-                    node = __float_as_int(e[0]); mm = em; a = e[512]; b = e[768]; c = e[1024];
+                    node = __float_as_int(e[0]); mm = em; a = e[2 * kKnnThreads]; b = e[3 * kKnnThreads]; c = e[4 * kKnnThreads];
                     return true;
                 }
             } else {
@@ -209,9 +217,9 @@ __device__ __forceinline__ void knn_body(const KnnJob& job, float* win)
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void knn_kernel(const KnnJob* __restrict__ jobs)
+__global__ __launch_bounds__(kKnnThreads) void knn_kernel(const KnnJob* __restrict__ jobs)
 {
-    __shared__ float win[kWin * 5 * 256];
+    __shared__ float win[kWin * 5 * kKnnThreads];
     knn_body<K>(jobs[blockIdx.y], win);
 }
 
@@ -219,9 +227,9 @@ __global__ __launch_bounds__(256) void knn_kernel(const KnnJob* __restrict__ job
 // K-NN search ends with a long tail (its duration is its slowest wave's; the chip holds all of its waves at once), and a second launch
 // cannot start under it: here the 1-NN workgroups are dispatched as the K-NN ones retire.
 template <int K>
-__global__ __launch_bounds__(256) void knn_pair_kernel(const KnnJob* __restrict__ jobs, int n_first)
+__global__ __launch_bounds__(kKnnThreads) void knn_pair_kernel(const KnnJob* __restrict__ jobs, int n_first)
 {
-    __shared__ float win[kWin * 5 * 256];
+    __shared__ float win[kWin * 5 * kKnnThreads];
     if ((int)blockIdx.y < n_first) knn_body<K>(jobs[blockIdx.y], win);
     else knn_body<1>(jobs[blockIdx.y], win);
 }
@@ -234,12 +242,12 @@ __global__ void widen_kernel(const int32_t* __restrict__ in, int64_t* __restrict
 
 static int launch_knn(ps_context* c, const KnnJob* d_jobs, int n_jobs, int max_nq, int K)
 {
-    dim3 grid((ceil_div(max_nq, 256) + 7) & ~7, n_jobs);  // a multiple of 8: the XCD remap in the kernel covers [0, grid) exactly
+    dim3 grid((ceil_div(max_nq, kKnnThreads) + 7) & ~7, n_jobs);  // a multiple of 8: the XCD remap in the kernel covers [0, grid) exactly
     if (grid.x == 0 || n_jobs == 0) return PS_OK;
     switch (K) {
 #define PS_KCASE(k)                                                             \
     case k:                                                                     \
-        hipLaunchKernelGGL(knn_kernel<k>, grid, dim3(256), 0, c->stream, d_jobs); \
+        hipLaunchKernelGGL(knn_kernel<k>, grid, dim3(kKnnThreads), 0, c->stream, d_jobs); \
         break;
         PS_KCASE(1) PS_KCASE(2) PS_KCASE(3) PS_KCASE(4) PS_KCASE(5) PS_KCASE(6) PS_KCASE(7) PS_KCASE(8)
         PS_KCASE(9) PS_KCASE(10) PS_KCASE(11) PS_KCASE(12) PS_KCASE(13) PS_KCASE(14) PS_KCASE(15) PS_KCASE(16)
@@ -256,12 +264,12 @@ static int launch_knn(ps_context* c, const KnnJob* d_jobs, int n_jobs, int max_n
 static int launch_knn_pair(ps_context* c, const KnnJob* d_jobs, int n_first, int n_jobs, int max_nq, int K)
 {
     if (K == 1) return launch_knn(c, d_jobs, n_jobs, max_nq, 1);
-    dim3 grid((ceil_div(max_nq, 256) + 7) & ~7, n_jobs);
+    dim3 grid((ceil_div(max_nq, kKnnThreads) + 7) & ~7, n_jobs);
     if (grid.x == 0 || n_jobs == 0) return PS_OK;
     switch (K) {
 #define PS_KCASE(k)                                                                            \
     case k:                                                                                    \
-        hipLaunchKernelGGL(knn_pair_kernel<k>, grid, dim3(256), 0, c->stream, d_jobs, n_first); \
+        hipLaunchKernelGGL(knn_pair_kernel<k>, grid, dim3(kKnnThreads), 0, c->stream, d_jobs, n_first); \
         break;
         PS_KCASE(2) PS_KCASE(3) PS_KCASE(4) PS_KCASE(5) PS_KCASE(6) PS_KCASE(7) PS_KCASE(8)
         PS_KCASE(9) PS_KCASE(10) PS_KCASE(11) PS_KCASE(12) PS_KCASE(13) PS_KCASE(14) PS_KCASE(15) PS_KCASE(16)
