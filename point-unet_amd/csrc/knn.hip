@@ -37,7 +37,10 @@ static_assert(sizeof(KnnJob) <= 128, "TreeSetPlan::carve reserves 128 bytes per 
 // and come back only when the window has drained.  A pop is the head of the next dependent node load, so its latency
 // (LDS ~100 cycles vs a scratch round trip through L2/HBM) is on the critical path of every query; the first descent
 // pushes ~log2(n/10) entries, of which the shallow ones -- spilled -- are almost always pruned by their `m` alone.
-constexpr int kWin = 8;
+#ifndef PS_KNN_WIN
+#define PS_KNN_WIN 8
+#endif
+constexpr int kWin = PS_KNN_WIN;  // (a power of two)
 // Threads per search workgroup (the LDS window is [slot][word][thread]).  ONE wave: the kernel has no workgroup-level step, and a
 // workgroup retires as soon as its own 64 queries are done instead of with the slowest of four waves -- its LDS and wave slot go to the next
 // workgroup (or to another lane's kernel) that much earlier.  Measured (round 4, same box): 256 threads 0.182 ms / pipelined step 0.860,
