@@ -74,7 +74,8 @@ def algorithmic_costs(cfg, n0, B):
     # sum N_i * K * 4 (neigh_idx) + write sum N_i * 4 (interp_idx) = 19.2 MB for the 180 000-point cloud (the query point is counted once)
     c["knn_search"] = dict(flops=0, bytes=B * nq * (12 + K * 4 + 4))
     c["kdtree_build"] = dict(flops=0, bytes=B * (sum(n) * 12 + sum(n) * 16 + 2 * sum(n) * 16))
-    c["pyramid_slices"] = dict(flops=0, bytes=B * 2 * (sum(n[:L]) * 12 + sum(n[1:]) * K * 4))
+    # (the level slices of tf_map -- coordinate rows and pooling-table rows -- are written by the tree builders' first pass and by the
+    #  K-NN lanes themselves since round 4: no launch of their own, and SURVEY's two formulas above do not count them)
     c["fc0"] = dict(flops=2 * B * n0 * cfg.in_channels * 8, bytes=B * n0 * (cfg.in_channels + 8) * 4)
     d_in = 8
     for i in range(L):
@@ -468,7 +469,7 @@ def sub_config5(local_rank, lanes, reuse, steps=40, warmup=8, n_clouds=4):
     costs = algorithmic_costs(cfg5, n0, 1)
     net_flops = sum(v["flops"] for kk, v in costs.items() if not kk.startswith(("knn", "kdtree", "pyramid")))
     out = {"ms_per_step": 1e3 * elapsed / steps, "points_per_s": n0 * steps / elapsed, "steps": steps, "warmup": warmup,
-           "serial_ms_per_cloud": 1e3 * t_serial / n_serial, "points": n0, "k_n": 32, "lanes": lanes, "dtype": "f32 (fp16 feature input, int32 indices)",
+           "serial_one_lane_ms_per_cloud": 1e3 * t_serial / n_serial, "points": n0, "k_n": 32, "lanes": lanes, "dtype": "f32 (fp16 feature input, int32 indices)",
            "algorithmic_gflop_per_step": net_flops / 1e9, "achieved_tflops_serial": net_flops / (t_serial / n_serial) / 1e12,
            "what": "BASELINE configs[4]: 262 144-point cloud, K=32, 4 input channels, 2 classes, features handed over as fp16, pyramid + forward"}
     pipe.close()
@@ -830,12 +831,15 @@ def main():
         # ... and the same clouds one after the other on ONE lane: stream order alone, no cross-stream event between consecutive clouds
         # (rotating over the lanes, every cloud starts behind an event of another hardware queue: ~0.15 ms per cloud on this runtime)
         t_lane, _ = timed_region(lambda: step(lane=0), dom_steps, sync, None)
-        serial_ms = 1e3 * t_lane / dom_steps
+        # rounds 1-3 reported the rotating-lanes figure as "serial": it keeps that name (like-for-like over the rounds); the one-lane
+        # figure introduced in round 4 has its own key
+        serial_ms = 1e3 * t_serial / dom_steps
+        one_lane_ms = 1e3 * t_lane / dom_steps
         sub["serial"] = {"ms_per_cloud": serial_ms, "points_per_s": B * n0 / (serial_ms * 1e-3), "steps": dom_steps,
-                         "ms_per_cloud_rotating_lanes": 1e3 * t_serial / dom_steps,
-                         "what": "one cloud in flight: consecutive clouds on one lane (one HIP stream), each behind the previous one -- the per-cloud "
-                                 "latency of pyramid + forward on this rank; ms_per_cloud_rotating_lanes = the same with every cloud on the next lane, "
-                                 "waiting for an event of the previous cloud's stream"}
+                         "ms_per_cloud_one_lane": one_lane_ms,
+                         "what": "one cloud in flight.  ms_per_cloud (the definition of rounds 1-3): every cloud on the next lane, waiting for an "
+                                 "event of the previous cloud's stream; ms_per_cloud_one_lane (round 4's `serial`): consecutive clouds on ONE lane, "
+                                 "stream order alone -- the per-cloud latency of pyramid + forward on this rank"}
         if not args.no_sub_results and not args.include_pcie:
             # untimed warm-up of the service path itself: the first transfers through freshly pinned host buffers and fresh device slots
             # are slow (page registration with the DMA engines), and at the driver's --steps 20 they WERE the number (r2: 1.66 ms
@@ -984,6 +988,7 @@ def main():
             "roofline": roofline,
             "roofline_network": roofline_network,
             "serial_ms_per_cloud": serial_ms,
+            "serial_one_lane_ms_per_cloud": (sub.get("serial") or {}).get("ms_per_cloud_one_lane"),
             "serial": sub.get("serial"),
             "include_pcie": sub.get("include_pcie"),
             "att_fp32_mfma": sub.get("att_fp32_mfma"),
@@ -1013,10 +1018,10 @@ def main():
         r3 = lambda v: None if v is None else round(v, 3)  # noqa: E731
         tb8, tb1, c5 = out.get("train_b8") or {}, out.get("train_b1") or {}, out.get("config5") or {}
         out["summary"] = {
-            "ms_per_step": r3(out["ms_per_step"]), "serial_ms": r3(serial_ms), "pcie_ms": r3((sub.get("include_pcie") or {}).get("ms_per_step")),
+            "ms_per_step": r3(out["ms_per_step"]), "serial_ms": r3(serial_ms), "serial_one_lane_ms": r3((sub.get("serial") or {}).get("ms_per_cloud_one_lane")), "pcie_ms": r3((sub.get("include_pcie") or {}).get("ms_per_step")),
             "knn_us": r3(1e3 * roofline["avg_launch_ms"]) if roofline else None, "knn_frac": roofline["frac"] if roofline else None,
             "batch2_ms_per_cloud": r3((out.get("batch2") or {}).get("ms_per_cloud")),
-            "config5_ms": r3(c5.get("ms_per_step")), "config5_serial_ms": r3(c5.get("serial_ms_per_cloud")),
+            "config5_ms": r3(c5.get("ms_per_step")), "config5_serial_one_lane_ms": r3(c5.get("serial_one_lane_ms_per_cloud")),
             "train_f32_ms": r3((tb8.get("f32") or {}).get("ms_per_step")), "train_f32_minmedmax": (tb8.get("f32") or {}).get("step_ms"),
             "train_bf16_ms": r3((tb8.get("bf16") or {}).get("ms_per_step")), "train_bf16_minmedmax": (tb8.get("bf16") or {}).get("step_ms"),
             "train_atomic_ms": r3((tb8.get("f32_atomic_scatter") or {}).get("ms_per_step")),

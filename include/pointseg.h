@@ -79,10 +79,12 @@ int ps_set_train_gemm_bf16(ps_context* ctx, int on);
  * three-way bfloat16 splits of both operands with fp32 accumulation (csrc/gemm_b3.hip) -- fp32-level error at 2.7 x less matrix-pipe
  * time; on == 0: the fp32 MFMA for every shape.  Ignored while ps_set_train_gemm_bf16 is on. */
 int ps_set_train_gemm_b3(ps_context* ctx, int on);
-/* Matrix instruction of the fused attentive-pooling kernels of ps_randla_forward at d_out = 64 and 128 (att_pooling,
- * PointSegment/RandLANet.py:388-401, with LocSE and the neighbour gather fused in).  on != 0 (default): v_mfma_f32_32x32x16_bf16
- * over exact three-way bfloat16 splits of the fp32 operands with fp32 accumulation (csrc/attpool32b.hip) -- fp32-level error, 2.7 x
- * less matrix-pipe time; on == 0: the fp32 MFMA (csrc/attpool32.hip).  Both meet the same parity bar. */
+/* Matrix instruction of ps_randla_forward's matrix-pipe-bound stages: the fused attentive-pooling kernels at d_out >= 64 (att_pooling,
+ * PointSegment/RandLANet.py:388-401, with LocSE and the neighbour gather fused in; csrc/attpool32b.hip) AND the dense layers of at
+ * least 0.3 GFLOP -- [mlp2 ; shortcut] of levels 2-4, decoder_0, the first decoder steps (RandLANet.py:130-143, 314-321; csrc/gemm32b.hip).
+ * on != 0 (default): v_mfma_f32_32x32x16_bf16 over exact three-way bfloat16 splits of the fp32 operands with fp32 accumulation --
+ * fp32-level error, 2.7 x less matrix-pipe time; on == 0: the fp32 MFMA for all of them (csrc/attpool32.hip, csrc/gemm32.hip).  Both
+ * meet the same parity bar. */
 int ps_set_att_bf16x3(ps_context* ctx, int on);
 const char* ps_last_error(void);
 /* "pointseg-hip <version> gfx950" */
@@ -135,6 +137,11 @@ typedef struct {
      * the t-th point in kd-tree leaf order.  ps_pyramid_build fills it when a buffer is given; ps_randla_forward then walks the
      * points of the attentive-pooling kernels in that order, XCD by XCD (neighbour gathers hit the XCD's L2). */
     int32_t* order[PS_MAX_LAYERS];
+    /* written by ps_pyramid_build (0 in a caller-filled struct): a stamp over the table pointers and shapes that says "sub_idx[i] IS the
+     * first n[i+1] rows per cloud of neigh_idx[i]" -- what the deterministic max-pool backward of the training step relies on.  A caller
+     * that rewrites a table of a built pyramid in place, or fills the struct by hand, must leave / set this to 0: the trainer then
+     * compares the tables itself on every step. */
+    uint64_t built;
 } ps_pyramid;
 int ps_pyramid_build(ps_context* ctx, const float* xyz0, int64_t B, int64_t n0, int32_t num_layers,
                      const int32_t* ratios, int32_t K, ps_pyramid* pyr);
@@ -304,6 +311,17 @@ int ps_op_att_pool_train_fwd(ps_context* ctx, const float* fset, int64_t ld, con
                              float* agg);
 int ps_op_att_pool_train_bwd(ps_context* ctx, const float* fset, int64_t ld, const float* wfc, const float* dagg, int64_t R,
                              int64_t K, int64_t d, float* dfset, int64_t lddf, float* dwfc);
+/* The wide levels (d = 128 / 256: encoder levels 2-3; csrc/attpool_gemm.hip): the same fused op on the frame of the large split-bf16
+ * GEMMs -- a wave owns the 16 neighbour rows of two points, the scores live only in its accumulator registers.  fwd writes agg [R, d];
+ * bwd recomputes the scores and returns dfset (row stride lddf; accumulate != 0: added to what the rows hold) and dscores [R*K, d]
+ * (row stride ldds) -- the weight gradient is dwfc = fset^T . dscores (ps_op_linear_wgrad_ex).  K = 16, rows 16-byte aligned;
+ * follows ps_set_train_gemm_bf16 (one plane of rounded operands instead of the exact three-way split).
+ * Replaces: tf.layers.dense + tf.nn.softmax + tf.reduce_sum and their gradients, RandLANet.py:394-398. */
+int ps_op_att_pool_gemm_supported(int64_t K, int64_t d);
+int ps_op_att_pool_gemm_fwd(ps_context* ctx, const float* fset, int64_t ld, const float* wfc, int64_t R, int64_t K, int64_t d,
+                            float* agg);
+int ps_op_att_pool_gemm_bwd(ps_context* ctx, const float* fset, int64_t ld, const float* wfc, const float* dagg, int64_t R,
+                            int64_t K, int64_t d, float* dfset, int64_t lddf, int accumulate, float* dscores, int64_t ldds);
 /* The same with gather_neighbour and the concat folded in (RandLANet.py:326-333: fset = concat(gather_neighbour(f, neigh_idx), f_xyz)):
  * fset[b, n, k, :] = [ fl[b, idx[b,n,k], :] | fr[b, n, k, :] ] is never materialised.  fl [B*n_src, d/2] (row stride ldl), idx [B, n_q, K]
  * cloud-local, fr [B*n_q*K, d/2] (row stride ldr).  The backward writes dfr (row stride lddr, overwritten), ADDS the gathered half's
@@ -461,8 +479,8 @@ int ps_op_dropout(ps_context* ctx, const float* x, int64_t n, uint32_t seed, flo
  *
  * Pyramids: ps_randla_train_step / ps_randla_backward accept any caller-filled ps_pyramid.  The deterministic max-pool backward walks the
  * neighbour table's inverse index and therefore needs sub_idx[i] to be the first n[i+1] rows per cloud of neigh_idx[i] (what
- * ps_pyramid_build writes); the trainer compares the two tables once per table (one synchronising check when a new table pointer is first
- * seen) and takes the float-atomic form for a pooling table that is something else. */
+ * ps_pyramid_build writes, and vouches for in ps_pyramid.built); for any other pyramid the trainer compares the two tables on EVERY step
+ * (one synchronising check per level; only a negative answer is remembered, it selects the always-correct float-atomic form). */
 typedef struct ps_trainer ps_trainer;
 typedef struct {
     float learning_rate;            /* cfg.learning_rate (helper_tool.py:33); Adam beta1 0.9, beta2 0.999, eps 1e-8 (TF defaults) */
@@ -496,6 +514,10 @@ int ps_trainer_layout(const ps_trainer* t, int row, char* name, int name_cap, in
                       int* is_buffer);
 /* device pointers; adam_m / adam_v may be NULL for a host that only calls ps_randla_backward */
 int ps_trainer_bind(ps_trainer* t, float* params, float* grads, float* adam_m, float* adam_v, float* bn_buffers);
+/* sync_bn: bit 0 = share the BatchNorm statistics over the ranks (two 2*C-float all-reduces per layer and step); PS_COLLECTIVE_AT_WORLD_ONE
+ * = call fn even in a world of ONE rank.  Without that bit a one-rank world never calls fn (a one-rank sum is the identity) and keeps the
+ * cheaper one-rank BatchNorm kernels: a host that always passes its callback gets the single-GPU step, bit for bit. */
+#define PS_COLLECTIVE_AT_WORLD_ONE 2
 int ps_trainer_set_collective(ps_trainer* t, ps_allreduce_fn fn, void* user, int world_size, int rank, int sync_bn);
 int ps_trainer_set_options(ps_trainer* t, const ps_train_options* opt);  /* everything but the ignored labels */
 int ps_trainer_set_step(ps_trainer* t, int64_t step);                    /* optimisation steps taken so far (checkpoint resume) */
@@ -508,8 +530,8 @@ int ps_trainer_set_profile(ps_trainer* t, int on);
 int ps_trainer_profile(const ps_trainer* t, ps_timing_row* rows, int cap, int* n_rows);
 /* The collectives of the last step: calls into the ps_allreduce_fn callback (the flat-gradient all-reduce + two per BatchNorm layer
  * with sync_bn), bytes handed over, host time spent inside the callback, and -- on profiled steps (ps_trainer_set_profile) -- the
- * device time between an event pair around every call.  A callback given with world_size 1 is still called (the latency floor of the
- * host's collective on one rank); a NULL callback means no calls.  Any out pointer may be NULL. */
+ * device time between an event pair around every call.  A NULL callback, or world_size 1 without PS_COLLECTIVE_AT_WORLD_ONE, means no
+ * calls.  Any out pointer may be NULL. */
 int ps_trainer_collective_stats(const ps_trainer* t, int64_t* calls, int64_t* bytes, double* host_ms, double* device_ms);
 /* Training-mode forward + class-weighted cross-entropy + backward: fills the bound gradient buffer (this rank's gradients, no
  * collective), updates the BatchNorm moving statistics, writes the loss (device float) and optionally the logits

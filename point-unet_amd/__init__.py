@@ -9,6 +9,16 @@ include/pointseg.h).  Module names mirror the reference's PointSegment/ tree:
     utils.cpp_wrappers.cpp_subsampling.grid_subsampling.compute                               (wrapper.cpp)
     pyramid.build_pyramid                                                                     (runBraTS.py tf_map)
 """
-from ._lib import PointSegError, lib  # noqa: F401
+import os as _os
+
+# Environment contract of the pipelined forward (pipeline.py): HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default
+# 4) and reads the variable ONCE, when the runtime initialises.  ForwardPipeline's four lanes need a queue each next to the null stream
+# and RCCL's: 6 measured best (0.84 ms per 180 000-point cloud; with the default 4 the lanes share queues: 1.33 vs 1.23 ms in round 2's
+# sweep, DESIGN.md 4.2).  Set here -- importing this package is the first thing a user of the path does, before any HIP call -- unless
+# the user chose a value; ForwardPipeline warns when the runtime was already up with too few queues.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL / cross-process tensors need on this driver)
+
+from ._lib import PointSegError, lib  # noqa: E402,F401
 
 __all__ = ["PointSegError", "lib"]

@@ -27,6 +27,7 @@ class PsPyramid(ctypes.Structure):
         ("sub_idx", c_vp * PS_MAX_LAYERS),
         ("interp_idx", c_vp * PS_MAX_LAYERS),
         ("order", c_vp * PS_MAX_LAYERS),
+        ("built", ctypes.c_uint64),  # ps_pyramid_build's stamp: sub_idx IS the prefix of neigh_idx (0 = caller-filled, compared every step)
     ]
 
 
@@ -113,6 +114,9 @@ PROTOTYPES = {
     "ps_op_softmax_pool_bwd_scores": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp, c_vp]),
     "ps_op_att_pool_train_supported": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64]),
     "ps_op_att_pool_train_supported_ex": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
+    "ps_op_att_pool_gemm_supported": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64]),
+    "ps_op_att_pool_gemm_fwd": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp] + [ctypes.c_int64] * 3 + [c_vp]),
+    "ps_op_att_pool_gemm_bwd": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp, ctypes.c_int64, ctypes.c_int, c_vp, ctypes.c_int64]),
     "ps_op_att_pool_train_fwd": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp] + [ctypes.c_int64] * 3 + [c_vp]),
     "ps_op_att_pool_train_bwd": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp, ctypes.c_int64, c_vp]),
     "ps_op_conv_bn_train_supported": (ctypes.c_int, [ctypes.c_int64]),

@@ -1,0 +1,465 @@
+// attpool_gemm.hip -- attentive pooling of the TRAINING step at the wide levels (d = 128 / 256 / 512: encoder levels 2-4), forward and
+// backward, with the score tensor never in memory.
+//
+//   att_pooling (PointSegment/RandLANet.py:388-398):   s = F . Wfc   (F = [N*K, d] neighbour set, no bias)
+//                                                      p = softmax over the K rows of a point, per channel
+//                                                      agg[n, c] = sum_k p[n,k,c] * F[n,k,c]
+//
+// attpool_train.hip fuses this per POINT with the d x d weights resident in LDS -- which ends at d = 64 in fp32 (d = 128 as bfloat16):
+// the wide levels ran op by op (score GEMM -> s [N*K, d] -> softmax-pool kernel; backward: softmax-pool backward -> dS, dF -> input
+// gradient GEMM -> weight gradient GEMM: fourteen passes over [N*K, d] tensors per pooling).  Here the two row-side products ride on
+// gemm_b3.hip's frame instead -- v_mfma_f32_32x32x16_bf16 over exact three-way bfloat16 splits (P = 3: fp32 results) or one plane of
+// rounded operands (P = 1: the bf16-MLP mode), the weight planes streamed L2 -> LDS in 24 KB blocks shared by the four waves of a
+// workgroup -- and everything between them stays in the accumulator registers of the wave that owns the rows:
+//
+//   a wave owns 32 rows = the K = 16 neighbour rows of TWO points, all d columns, 128 columns (a "panel") at a time
+//   forward    S = F . W (panel)            accumulator tile: lane = column, registers = rows -> a point's 16 scores of a channel are
+//              8 registers of two lanes: softmax = in-lane + ONE v_permlane32_swap; agg = sum p F   -> only agg [N, d] is written
+//   backward   S recomputed the same way;   dS = p g (F - agg),  direct = p g   (g = dagg of the point)
+//              dS^T through the matrix pipe: T = dS^T . I (one MFMA per plane and 16 rows with an identity operand) turns the tile into
+//              lane = row, registers = columns -- which IS the row operand of the next product, register for register (its K axis is
+//              simply taken in accumulator order: the W^T image is packed to match, gemm_b3.hip b3_pack_elem<KMAP>) -- and the layout
+//              in which a row of dS leaves as 16-byte stores;
+//              dF = direct + dS . W^T       accumulated over the panels in registers, seeded with the direct term
+//              -> reads F and dagg, writes dF and dS; the weight gradient dW = F^T . dS is the step's ordinary wgrad product over
+//                 (F, dS) (wgrad_b3_kernel), whose d x d accumulators per row slab no row-owning wave could hold at d >= 256.
+// Passes over [N*K, d] per pooling: forward 1 (was 4), backward 3 + 2 for dW (was 9).
+#include "common.h"
+#include "mfma_tile.h"
+#include "b3_ops.h"
+
+namespace ps {
+
+struct AttGArgs {
+    const float* f; int ld;    // [rows, D] neighbour set, rows = points * 16
+    const uint4* w1;           // W planes, natural K order: [D/16][D/32][P][64]
+    const uint4* w2;           // W^T planes, accumulator K order (backward)
+    const float* dagg;         // [points, D] (backward)
+    float* agg;                // [points, D] (forward)
+    float* df; int lddf;       // [rows, D] (backward)
+    float* ds; int ldds;       // [rows, D] (backward)
+    int64_t rows, points;
+    int df_accum;              // df += instead of df =
+};
+
+__device__ __forceinline__ float attg_swap_max(float v)
+{
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float attg_swap_sum(float v)
+{
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// One stream of weight-plane blocks per workgroup: block = [2 chunks of 16 K][4 column tiles][P planes][64 lanes] uint4 (24 KB at P = 3),
+// cut out of an image [K/16][D/32][P][64] at (chunk pair s, tile group g).  Sequence per panel p: the D/32 K-steps of the score product
+// (image w1, group p), then per 32-column tile t of the panel and per group ig of four output tiles the blocks of dS . W^T (image w2,
+// chunk pair 4 p + t, group ig).
+template <int D, int P, bool BWD>
+struct AttGStream {
+    static constexpr int NCB = D / 32, NPAN = D / 128, STEPS = D / 32;
+    static constexpr int PER = BWD ? STEPS + 4 * NPAN : STEPS;
+    static constexpr int NB = NPAN * PER;
+    struct Blk {
+        const uint4* img;
+        int s, g;
+    };
+    static __device__ __forceinline__ Blk blk(const AttGArgs& a, int n)
+    {
+        const int p = n / PER, m = n - p * PER;
+        if (!BWD || m < STEPS) return Blk{a.w1, m, p};
+        const int m2 = m - STEPS, t = m2 / NPAN, ig = m2 - t * NPAN;
+        return Blk{a.w2, 4 * p + t, ig};
+    }
+    static __device__ __forceinline__ const uint4* src(const Blk& b, int i)  // i in [0, 512 P): (u, rest)
+    {
+        const int u = i / (256 * P), rest = i - u * (256 * P);
+        return b.img + ((size_t)((2 * b.s + u) * NCB + 4 * b.g) * P) * 64 + rest;
+    }
+};
+
+#define PS_ATTG_LOAD_B(n_)                                        \
+    do {                                                          \
+        const typename S::Blk nb_ = S::blk(a, (n_));              \
+        breg0 = *S::src(nb_, 0 * 256 + (int)threadIdx.x);         \
+        breg1 = *S::src(nb_, 1 * 256 + (int)threadIdx.x);         \
+        if constexpr (P == 3) {                                   \
+            breg2 = *S::src(nb_, 2 * 256 + (int)threadIdx.x);     \
+            breg3 = *S::src(nb_, 3 * 256 + (int)threadIdx.x);     \
+            breg4 = *S::src(nb_, 4 * 256 + (int)threadIdx.x);     \
+            breg5 = *S::src(nb_, 5 * 256 + (int)threadIdx.x);     \
+        }                                                         \
+    } while (0)
+#define PS_ATTG_STORE_B(buf_)                                     \
+    do {                                                          \
+        Bs[(buf_)][0 * 256 + threadIdx.x] = breg0;                \
+        Bs[(buf_)][1 * 256 + threadIdx.x] = breg1;                \
+        if constexpr (P == 3) {                                   \
+            Bs[(buf_)][2 * 256 + threadIdx.x] = breg2;            \
+            Bs[(buf_)][3 * 256 + threadIdx.x] = breg3;            \
+            Bs[(buf_)][4 * 256 + threadIdx.x] = breg4;            \
+            Bs[(buf_)][5 * 256 + threadIdx.x] = breg5;            \
+        }                                                         \
+    } while (0)
+
+// Row addressing: every global access of a wave is (wave-uniform 64-bit base of its 32 rows) + (32-bit lane offset inside them), so no
+// 64-bit address arithmetic sits in vector registers.  A wave whose rows end early (the last workgroup) computes on rows that exist --
+// a missing second point reads the first one's rows, a wave without rows reads the first 32 -- and stores nothing for them.
+struct AttGRows {
+    int64_t rbase;   // first row the wave READS
+    int nvalid;      // rows of the wave that exist: 0, 16 or 32 (stores)
+    int second;      // row offset of the second point's reads: 16, or 0 when only one point is readable
+};
+__device__ __forceinline__ AttGRows attg_rows(const AttGArgs& a, int wave)
+{
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    AttGRows r;
+    const int64_t left = a.rows - row0;
+    r.nvalid = left >= 32 ? 32 : (left >= 16 ? 16 : 0);
+    r.rbase = r.nvalid > 0 ? row0 : 0;
+    r.second = a.rows - r.rbase >= 32 ? 16 : 0;
+    return r;
+}
+
+// the score product of one panel: acc[t] (t = 0..3) += F[rows of the wave][:] . W[:, 128 p + 32 t ..]; consumes blocks n .. n + STEPS - 1
+// of the stream (block n is in Bs[n & 1] on entry, and block n + STEPS -- if any -- is in Bs[(n + STEPS) & 1] on exit)
+#define PS_ATTG_SCORES()                                                                                              \
+    do {                                                                                                              \
+        load_a_half(0, 0);                                                                                            \
+        load_a_half(0, 1);                                                                                            \
+        _Pragma("unroll 1") for (int s = 0; s < S::STEPS; ++s, ++n)                                                   \
+        {                                                                                                             \
+            const int buf = n & 1;                                                                                    \
+            const bool more = n + 1 < S::NB;                                                                          \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                             \
+            {                                                                                                         \
+                const BPlanes<P> ap = b3_split8<P>(areg[2 * u], areg[2 * u + 1]);                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                    \
+                if (s + 1 < S::STEPS) load_a_half(s + 1, u);                                                          \
+                if (u == 1 && more) PS_ATTG_LOAD_B(n + 1);                                                            \
+                __builtin_amdgcn_sched_barrier(0);                                                                    \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
+                {                                                                                                     \
+                    BPlanes<P> bp;                                                                                    \
+                    _Pragma("unroll") for (int pl = 0; pl < P; ++pl) bp.p[pl] = Bs[buf][((u * 4 + t) * P + pl) * 64 + lane]; \
+                    acc[t] = b3_mfma6<P>(ap, bp, acc[t]);                                                             \
+                }                                                                                                     \
+            }                                                                                                         \
+            if (more) PS_ATTG_STORE_B(buf ^ 1);                                                                       \
+            __syncthreads();                                                                                          \
+        }                                                                                                             \
+    } while (0)
+
+// value rows of (tile column col, point pi) in accumulator order: element j = row 16 pi + 4 hl + (j & 3) + 8 (j >> 2) of the wave
+#define PS_ATTG_VALUES(fv_, pi_)                                                                                      \
+    do {                                                                                                              \
+        const float* vb_ = fb + ((pi_) ? rw.second * a.ld : 0);                                                       \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) (fv_)[j] = vb_[voff + (unsigned)(((j & 3) + 8 * (j >> 2)) * a.ld)]; \
+    } while (0)
+
+template <int D, int P>
+__global__ __launch_bounds__(256) void attg_fwd_kernel(AttGArgs a)
+{
+    using S = AttGStream<D, P, false>;
+    __shared__ uint4 Bs[2][2 * 4 * P * 64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int hl = lane >> 5, c32 = lane & 31;
+    const AttGRows rw = attg_rows(a, wave);
+    const float* fb = a.f + (size_t)rw.rbase * a.ld;  // wave-uniform
+    const unsigned xoff = (unsigned)((c32 < 16 ? c32 : c32 - 16 + rw.second) * a.ld + 8 * hl);
+    uint4 breg0, breg1, breg2, breg3, breg4, breg5;
+    float4 areg[4];
+    auto load_a_half = [&](int s, int u) {
+        areg[2 * u] = *reinterpret_cast<const float4*>(fb + (xoff + (unsigned)(32 * s + 16 * u)));
+        areg[2 * u + 1] = *reinterpret_cast<const float4*>(fb + (xoff + (unsigned)(32 * s + 16 * u + 4)));
+    };
+    PS_ATTG_LOAD_B(0);
+    PS_ATTG_STORE_B(0);
+    __syncthreads();
+    int n = 0;
+#pragma unroll 1
+    for (int p = 0; p < S::NPAN; ++p) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        PS_ATTG_SCORES();
+        // softmax over the 16 rows of each of the wave's two points, weighted sum of the value rows (the tile itself: L1 / L2 hits)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            __builtin_amdgcn_sched_barrier(0);  // (one tile's value loads at a time)
+            const int col = 128 * p + 32 * t + c32;
+            const unsigned voff = (unsigned)(4 * hl * a.ld + col);
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {
+                float fv[8];
+                PS_ATTG_VALUES(fv, pi);
+                float m = acc[t][8 * pi];
+#pragma unroll
+                for (int j = 1; j < 8; ++j) m = fmaxf(m, acc[t][8 * pi + j]);
+                m = attg_swap_max(m);
+                float z = 0.f, num = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float e = __expf(acc[t][8 * pi + j] - m);
+                    z += e;
+                    num = __builtin_fmaf(e, fv[j], num);
+                }
+                z = attg_swap_sum(z);
+                num = attg_swap_sum(num);
+                if (hl == 0 && 16 * pi < rw.nvalid) a.agg[(size_t)((rw.rbase >> 4) + pi) * D + col] = num * __builtin_amdgcn_rcpf(z);
+            }
+        }
+    }
+}
+
+// (d = 128: 64 + 64 accumulators leave room for two waves per SIMD -- asked for, the P = 1 form otherwise hoists its way past 256 registers;
+//  d = 256 holds 64 + 128 accumulators: one wave per SIMD, the accumulators of dF in the second half of the register file)
+template <int D, int P>
+__global__ __launch_bounds__(256, D == 128 ? 2 : 1) void attg_bwd_kernel(AttGArgs a)
+{
+    using S = AttGStream<D, P, true>;
+    constexpr int NT = D / 32;
+    __shared__ uint4 Bs[2][2 * 4 * P * 64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int hl = lane >> 5, c32 = lane & 31;
+    const AttGRows rw = attg_rows(a, wave);
+    const float* fb = a.f + (size_t)rw.rbase * a.ld;  // wave-uniform
+    const unsigned xoff = (unsigned)((c32 < 16 ? c32 : c32 - 16 + rw.second) * a.ld + 8 * hl);
+    uint4 breg0, breg1, breg2, breg3, breg4, breg5;
+    float4 areg[4];
+    auto load_a_half = [&](int s, int u) {
+        areg[2 * u] = *reinterpret_cast<const float4*>(fb + (xoff + (unsigned)(32 * s + 16 * u)));
+        areg[2 * u + 1] = *reinterpret_cast<const float4*>(fb + (xoff + (unsigned)(32 * s + 16 * u + 4)));
+    };
+    // identity operand of the transposing product: k-slot (chunk kap, lane half hl, element j) of an accumulator tile is its row
+    // 16 kap + 8 (j >> 2) + 4 hl + (j & 3); lane (n = c32, hl) of chunk kap holds 1.0 in the slot whose row is n (one lane half has it)
+    uint4 ident[2];
+    {
+        const bool mine = ((c32 >> 2) & 1) == hl;
+        const int j = (c32 & 3) + 4 * ((c32 >> 3) & 1), kap = c32 >> 4;
+        const unsigned one = 0x3F80u << (16 * (j & 1));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool on = mine && kap == k;
+            ident[k].x = (on && (j >> 1) == 0) ? one : 0u;
+            ident[k].y = (on && (j >> 1) == 1) ? one : 0u;
+            ident[k].z = (on && (j >> 1) == 2) ? one : 0u;
+            ident[k].w = (on && (j >> 1) == 3) ? one : 0u;
+        }
+    }
+    f32x16 acc2[NT];  // dF of the wave's rows: tile it = columns 32 it .. (lane = column, registers = rows)
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[it][r] = 0.f;
+
+    PS_ATTG_LOAD_B(0);
+    PS_ATTG_STORE_B(0);
+    __syncthreads();
+    int n = 0;
+#pragma unroll
+    for (int p = 0; p < S::NPAN; ++p) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        PS_ATTG_SCORES();
+        // ---- softmax, direct term p g into the dF accumulators, dS = p g (F - agg) over the scores in place ----
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            __builtin_amdgcn_sched_barrier(0);  // (one tile's value loads at a time)
+            const int col = 128 * p + 32 * t + c32;
+            const unsigned voff = (unsigned)(4 * hl * a.ld + col);
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {
+                float fv[8];
+                PS_ATTG_VALUES(fv, pi);
+                const float g = 16 * pi < rw.nvalid ? a.dagg[(size_t)((rw.rbase >> 4) + pi) * D + col] : 0.f;
+                float m = acc[t][8 * pi];
+#pragma unroll
+                for (int j = 1; j < 8; ++j) m = fmaxf(m, acc[t][8 * pi + j]);
+                m = attg_swap_max(m);
+                float e[8], z = 0.f, num = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    e[j] = __expf(acc[t][8 * pi + j] - m);
+                    z += e[j];
+                    num = __builtin_fmaf(e[j], fv[j], num);
+                }
+                z = attg_swap_sum(z);
+                num = attg_swap_sum(num);
+                const float inv = __builtin_amdgcn_rcpf(z), agg = num * inv, ginv = g * inv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pg = e[j] * ginv;
+                    acc2[4 * p + t][8 * pi + j] += pg;
+                    acc[t][8 * pi + j] = pg * (fv[j] - agg);
+                }
+            }
+        }
+        // ---- per 32-column tile of the panel: transpose dS on the matrix pipe, store its rows, dF += dS . W^T ----
+        float* dsb = a.ds + (size_t)rw.rbase * a.ldds;  // wave-uniform
+        const unsigned dsoff = (unsigned)(c32 * a.ldds + 128 * p + 4 * hl);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 T;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[r] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const BPlanes<P> dp = b3_split8<P>(make_float4(acc[t][8 * k], acc[t][8 * k + 1], acc[t][8 * k + 2], acc[t][8 * k + 3]),
+                                                   make_float4(acc[t][8 * k + 4], acc[t][8 * k + 5], acc[t][8 * k + 6], acc[t][8 * k + 7]));
+#pragma unroll
+                for (int pl = P - 1; pl >= 0; --pl) T = b3_mfma(dp.p[pl], ident[k], T);  // (smallest pieces first: every partial sum is exact)
+            }
+            // T: lane = row c32 of the wave, register r = column 128 p + 32 t + (r & 3) + 8 (r >> 2) + 4 hl
+            if (c32 < rw.nvalid) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    *reinterpret_cast<float4*>(dsb + (dsoff + (unsigned)(32 * t + 8 * g4))) = make_float4(T[4 * g4], T[4 * g4 + 1], T[4 * g4 + 2], T[4 * g4 + 3]);
+            }
+            BPlanes<P> tp[2];
+            tp[0] = b3_split8<P>(make_float4(T[0], T[1], T[2], T[3]), make_float4(T[4], T[5], T[6], T[7]));
+            tp[1] = b3_split8<P>(make_float4(T[8], T[9], T[10], T[11]), make_float4(T[12], T[13], T[14], T[15]));
+#pragma unroll
+            for (int ig = 0; ig < S::NPAN; ++ig, ++n) {
+                const int buf = n & 1;
+                const bool more = n + 1 < S::NB;
+                if (more) PS_ATTG_LOAD_B(n + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        BPlanes<P> bp;
+#pragma unroll
+                        for (int pl = 0; pl < P; ++pl) bp.p[pl] = Bs[buf][((u * 4 + i4) * P + pl) * 64 + lane];
+                        acc2[4 * ig + i4] = b3_mfma6<P>(tp[u], bp, acc2[4 * ig + i4]);
+                    }
+                if (more) PS_ATTG_STORE_B(buf ^ 1);
+                __syncthreads();
+            }
+        }
+    }
+    // ---- dF: register r of tile it = row (r & 3) + 8 (r >> 2) + 4 hl of the wave, column 32 it + c32 ----
+    float* dfb = a.df + (size_t)rw.rbase * a.lddf;  // wave-uniform
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        const unsigned doff = (unsigned)(4 * hl * a.lddf + 32 * it + c32);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (16 * half < rw.nvalid) {  // (wave-uniform: registers 8 half .. are the rows of point `half`)
+                float old[8];
+                if (a.df_accum) {  // (the reads of a tile in flight before its first store)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) old[q] = dfb[doff + (unsigned)((16 * half + (q & 3) + 8 * (q >> 2)) * a.lddf)];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    dfb[doff + (unsigned)((16 * half + (q & 3) + 8 * (q >> 2)) * a.lddf)] = a.df_accum ? acc2[it][8 * half + q] + old[q] : acc2[it][8 * half + q];
+            }
+        }
+    }
+}
+#undef PS_ATTG_VALUES
+#undef PS_ATTG_SCORES
+#undef PS_ATTG_LOAD_B
+#undef PS_ATTG_STORE_B
+
+__global__ __launch_bounds__(256) void attg_pack_kernel(PackJob j)
+{
+    // (one matrix, outside a recorded step: the batched kernel's element function through a by-value job)
+    PackJob jj = j;
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < jj.total; i += (int64_t)gridDim.x * 256) b3_pack_elem_any(jj, i);
+}
+
+static int attg_planes(ps_context* c, const float* w, int64_t d, bool transposed_kmap, const uint4** out)
+{
+    PackJob key = {};
+    key.w = w;
+    key.sk = transposed_kmap ? 1 : d;
+    key.sn = transposed_kmap ? d : 1;
+    key.kind = (c->train_bf16 ? 4 : 3) + (transposed_kmap ? 2 : 0);
+    key.cin = (int)d; key.cout = (int)d;
+    key.total = (int64_t)(d / 16) * (d / 32) * 64;
+    bool launch = true;
+    void* planes = pack_slot(c, key, (size_t)d * d * 6, launch);
+    PS_CHECK(planes != nullptr, "att_pool_gemm: out of device memory for the weight planes");
+    if (launch) {
+        key.out = planes;
+        hipLaunchKernelGGL(attg_pack_kernel, dim3(ceil_div(key.total, 256)), dim3(256), 0, c->stream, key);
+        PS_HIP(hipGetLastError());
+    }
+    *out = static_cast<const uint4*>(planes);
+    return PS_OK;
+}
+
+template <int D, bool BWD>
+static int launch_attg(ps_context* c, const AttGArgs& a)
+{
+    const unsigned blocks = (unsigned)((a.rows + 127) / 128);
+    if constexpr (!BWD) {
+        if (c->train_bf16) hipLaunchKernelGGL((attg_fwd_kernel<D, 1>), dim3(blocks), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((attg_fwd_kernel<D, 3>), dim3(blocks), dim3(256), 0, c->stream, a);
+    } else {
+        if (c->train_bf16) hipLaunchKernelGGL((attg_bwd_kernel<D, 1>), dim3(blocks), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((attg_bwd_kernel<D, 3>), dim3(blocks), dim3(256), 0, c->stream, a);
+    }
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+static bool attg_ok(int64_t K, int64_t d, const void* f, int64_t ld)
+{
+    return K == 16 && (d == 128 || d == 256 || d == 512) && ld % 4 == 0 && ld >= d && (reinterpret_cast<uintptr_t>(f) & 15) == 0;
+}
+
+}  // namespace ps
+
+using namespace ps;
+
+extern "C" int ps_op_att_pool_gemm_supported(int64_t K, int64_t d) { return K == 16 && (d == 128 || d == 256) ? 1 : 0; }
+
+extern "C" int ps_op_att_pool_gemm_fwd(ps_context* c, const float* fset, int64_t ld, const float* wfc, int64_t R, int64_t K, int64_t d, float* agg)
+{
+    PS_CHECK(c && fset && wfc && agg, "ps_op_att_pool_gemm_fwd: NULL argument");
+    PS_CHECK(attg_ok(K, d, fset, ld) && R * K < (1ll << 31), "ps_op_att_pool_gemm_fwd: K = 16, d in {128, 256, 512}, rows 16-byte aligned (got K %lld, d %lld, ld %lld)",
+             (long long)K, (long long)d, (long long)ld);
+    if (R <= 0) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "train_att_gemm_fwd", 2);
+    AttGArgs a = {};
+    a.f = fset; a.ld = (int)ld; a.agg = agg; a.rows = R * K; a.points = R;
+    PS_TRY(attg_planes(c, wfc, d, false, &a.w1));
+    switch (d) {
+        case 128: return launch_attg<128, false>(c, a);
+        case 256: return launch_attg<256, false>(c, a);
+        default: return launch_attg<512, false>(c, a);
+    }
+}
+
+extern "C" int ps_op_att_pool_gemm_bwd(ps_context* c, const float* fset, int64_t ld, const float* wfc, const float* dagg, int64_t R, int64_t K, int64_t d,
+                                       float* dfset, int64_t lddf, int accumulate, float* dscores, int64_t ldds)
+{
+    PS_CHECK(c && fset && wfc && dagg && dfset && dscores, "ps_op_att_pool_gemm_bwd: NULL argument");
+    PS_CHECK(attg_ok(K, d, fset, ld) && R * K < (1ll << 31) && lddf >= d && attg_ok(K, d, dscores, ldds),
+             "ps_op_att_pool_gemm_bwd: K = 16, d in {128, 256, 512}, rows 16-byte aligned (got K %lld, d %lld, ld %lld)", (long long)K, (long long)d, (long long)ld);
+    if (R <= 0) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "train_att_gemm_bwd", 3);
+    AttGArgs a = {};
+    a.f = fset; a.ld = (int)ld; a.dagg = dagg; a.df = dfset; a.lddf = (int)lddf; a.ds = dscores; a.ldds = (int)ldds;
+    a.rows = R * K; a.points = R; a.df_accum = accumulate ? 1 : 0;
+    PS_TRY(attg_planes(c, wfc, d, false, &a.w1));
+    PS_TRY(attg_planes(c, wfc, d, true, &a.w2));
+    switch (d) {
+        case 128: return launch_attg<128, true>(c, a);
+        default: return launch_attg<256, true>(c, a);
+    }
+}

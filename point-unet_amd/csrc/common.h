@@ -78,7 +78,7 @@ struct StageTimer {
 namespace ps {
 // One weight image of ps_op_conv1x1_ex: which matrix (pointer + strides), which kernel's layout, where it goes.
 // kind 0: pack_weights (rowgemm LDS form), 1: k-permuted (direct-load form), 2: bfloat16 k-permuted, 3: split-bf16 planes (gemm_b3), 4: one
-// RNE bfloat16 plane (gemm_b3 in the bf16-MLP mode)
+// RNE bfloat16 plane (gemm_b3 in the bf16-MLP mode), 5 / 6: kinds 3 / 4 with the K axis in accumulator order (attpool_gemm.hip)
 struct PackJob {
     const float* w;
     int64_t sk, sn;
@@ -193,6 +193,18 @@ struct Stage {
 };
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ps_pyramid.built: what ps_pyramid_build leaves behind and the trainer recomputes -- any change of a table pointer or shape breaks it
+inline uint64_t pyramid_stamp(const ps_pyramid* p)
+{
+    uint64_t h = 0x50535059524D4944ull ^ (uint64_t)p->B ^ ((uint64_t)p->K << 32) ^ ((uint64_t)p->num_layers << 48);
+    for (int i = 0; i < p->num_layers && i < PS_MAX_LAYERS; ++i) {
+        h = (h ^ (uint64_t)reinterpret_cast<uintptr_t>(p->sub_idx[i])) * 0x9E3779B97F4A7C15ull;
+        h = (h ^ (uint64_t)reinterpret_cast<uintptr_t>(p->neigh_idx[i])) * 0x9E3779B97F4A7C15ull;
+        h = (h ^ (uint64_t)p->n[i] ^ ((uint64_t)p->n[i + 1] << 32)) * 0x9E3779B97F4A7C15ull;
+    }
+    return h | 1ull;
+}
 
 // random_sample forward, vector form (randla.hip): out[b, m, :] = max over k of feat[b, idx[b, m, k], :], ch % 4 == 0; order: optional row walk
 int pool_max(ps_context* c, const float* feat, const int32_t* idx, const int32_t* order, float* out, int64_t B, int64_t n, int64_t m, int K, int ch,

@@ -287,8 +287,9 @@ int gemm32b(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc
     // fragment feeds both: half the weight stream) once that still leaves every SIMD a wave
     int cw = L.cout % 64 == 0 ? 2 : 1;
     int rw = (int64_t)(rblocks / 2) * (L.cout / (32 * cw)) >= 1024 ? 2 : 1;
-    if (c->gemm32b_rw) rw = c->gemm32b_rw;  // (A/B overrides of the tile shape: PS_GEMM32B_RW / PS_GEMM32B_CW)
-    if (c->gemm32b_cw && L.cout % (32 * c->gemm32b_cw) == 0) cw = c->gemm32b_cw;
+    // (A/B overrides of the tile shape, PS_GEMM32B_RW / PS_GEMM32B_CW: only the compiled shapes 1 and 2; anything else is ignored)
+    if (c->gemm32b_rw == 1 || c->gemm32b_rw == 2) rw = c->gemm32b_rw;
+    if ((c->gemm32b_cw == 1 || c->gemm32b_cw == 2) && L.cout % (32 * c->gemm32b_cw) == 0) cw = c->gemm32b_cw;
     const int cgroups = L.cout / (32 * cw);
     const int runits = (rblocks + rw - 1) / rw;
     // split K across the waves of a workgroup while the plain grid leaves SIMDs idle (1 024 of them) and the slices keep >= 4 chunks
@@ -297,16 +298,15 @@ int gemm32b(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc
     // (eight waves per workgroup -- gemm32.hip's form for the long-K layers -- measured SLOWER here: dec1 24.8 -> 30.8 us, pipelined step
     //  0.857 -> 0.875 ms: twice the partial sums through LDS for a chain that the register ring already keeps fed)
     while (sk < 4 && units * sk < 1536 && L.cin / 16 / (sk * 2) >= 4) sk *= 2;
-    const int ru_per_wg = sk > 4 ? 1 : 4 / sk;
+    const int ru_per_wg = 4 / sk;
     a.cgroups = cgroups;
     a.rgroups = (runits + ru_per_wg - 1) / ru_per_wg;
     const unsigned grid = 8u * (unsigned)((a.rgroups * a.cgroups + 7) / 8);
-    const dim3 block(sk > 4 ? 64 * sk : 256);
+    const dim3 block(256);
 #define PS_G32B(RW_, CW_)                                                                                            \
     if (sk == 1) hipLaunchKernelGGL((gemm32b_kernel<RW_, CW_, 1>), dim3(grid), block, 0, c->stream, a);              \
     else if (sk == 2) hipLaunchKernelGGL((gemm32b_kernel<RW_, CW_, 2>), dim3(grid), block, 0, c->stream, a);         \
-    else if (sk == 4 || RW_ * CW_ > 2) hipLaunchKernelGGL((gemm32b_kernel<RW_, CW_, 4>), dim3(grid), block, 0, c->stream, a); \
-    else hipLaunchKernelGGL((gemm32b_kernel<RW_, CW_, (RW_ * CW_ > 2 ? 4 : 8)>), dim3(grid), block, 0, c->stream, a)
+    else hipLaunchKernelGGL((gemm32b_kernel<RW_, CW_, 4>), dim3(grid), block, 0, c->stream, a)
     if (rw == 2 && cw == 2) { PS_G32B(2, 2); }
     else if (rw == 2) { PS_G32B(2, 1); }
     else if (cw == 2) { PS_G32B(1, 2); }

@@ -57,7 +57,7 @@ struct SpillStore {
 };
 struct WindowStack {
     typedef __attribute__((address_space(3))) float lds_float;
-    lds_float* w;  // LDS base of this thread (already offset by threadIdx.x); word stride = 256 threads
+    lds_float* w;  // LDS base of this thread (already offset by threadIdx.x); word stride = kKnnThreads (one word per thread and slot)
     SpillStore* sp_;  // entries [0, lo)
     int sp = 0, lo = 0;  // entries [lo, sp) are in LDS at slot (depth % kWin); [0, lo) in scratch
     __device__ __forceinline__ bool push(int node, float mm, float a, float b, float c)
@@ -410,6 +410,7 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
         n[i + 1] = n[i] / ratios[i];
         PS_CHECK(n[i + 1] >= 1, "ps_pyramid_build: level %d would be empty", i + 1);
     }
+    pyr->built = 0;
     pyr->num_layers = L;
     pyr->K = K;
     pyr->B = B;
@@ -508,6 +509,7 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
             c->flag_serial[c->flag_slot] = c->builds;
             ++c->builds;
             c->flag_slot = (c->flag_slot + 1) & 7;
+            pyr->built = pyramid_stamp(pyr);
             return PS_OK;  // (all host tables went through the context's pinned upload ring)
         }
         PS_HIP(hipMemcpyAsync(flag, plan.d_flags, 12, hipMemcpyDeviceToHost, c->stream));
@@ -516,5 +518,6 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
     ++c->builds;
     PS_CHECK(flag[1] == 0, "ps_pyramid_build: kd-tree builder queue overflow (degenerate cloud)");
     PS_CHECK(flag[0] == 0, "ps_pyramid_build: kd-tree deeper than the %d-entry traversal stack", kStackMax);
+    pyr->built = pyramid_stamp(pyr);
     return PS_OK;
 }

@@ -330,6 +330,7 @@ struct ps_trainer {
     void* coll_user = nullptr;
     int world = 1, rank = 0;
     bool sync_bn = false;
+    bool coll_at_one = false;  // PS_COLLECTIVE_AT_WORLD_ONE: a one-rank world still goes through the callback
     // collectives of the last step (ps_trainer_collective_stats): calls into the host's callback, bytes handed over, host time inside
     // the callback, and -- on profiled steps -- the device time between an event pair around every call
     int64_t coll_calls = 0, coll_bytes = 0;
@@ -445,6 +446,7 @@ struct ps_trainer {
     std::vector<Op> ops;
     std::unordered_map<int, Tn> grad_of;
     std::unordered_map<int, std::vector<std::function<void()>>> deferred;  // input-gradient GEMMs waiting for another consumer's plain store
+    bool att_gemm_on = getenv("PS_TRAIN_ATT_GEMM") ? atoi(getenv("PS_TRAIN_ATT_GEMM")) != 0 : true;  // (A/B switch of attpool_gemm.hip, read at creation)
     ps::PackCache pack;  // the step's weight images (recorded during the first step, then packed by one launch per step: common.h)
     // inverse indices of the step's gather tables (deterministic mode): built at their first use in the backward pass, kept to its end
     struct Inv {
@@ -465,15 +467,19 @@ struct ps_trainer {
                                reinterpret_cast<int32_t*>(ws.p)));
         return inv_cache.emplace(idx, v).first->second;
     }
-    // pooling tables already compared with their neighbour tables (key: both pointers and the shape; value: is a prefix).  One
-    // synchronising check per distinct table -- a pyramid slot that is rebuilt in place keeps its pointers.
+    // Is sub_idx the prefix of neigh_idx (the precondition of the fixed-order max-pool backward)?  A pyramid ps_pyramid_build wrote says
+    // so itself (ps_pyramid.built).  Any other pyramid is compared on EVERY step -- its tables may have been rewritten in place, or a
+    // freed table's address handed to another pyramid of the same shape by the caller's allocator -- and only a NEGATIVE answer is
+    // remembered (key: both pointers and the shape): it selects the float-atomic form, which is correct for every table.
     std::map<std::array<int64_t, 6>, bool> prefix_checked;
+    bool pyramid_vouched = false;  // (set per step: pyr->built == pyramid_stamp(pyr))
     bool pool_is_prefix(const int32_t* pool_idx, const int32_t* neigh, int64_t B, int64_t N, int64_t M, int64_t K)
     {
         if (pool_idx == neigh && B == 1) return true;
+        if (pyramid_vouched) return true;
         const std::array<int64_t, 6> key = {(int64_t)reinterpret_cast<uintptr_t>(pool_idx), (int64_t)reinterpret_cast<uintptr_t>(neigh), B, N, M, K};
         auto it = prefix_checked.find(key);
-        if (it != prefix_checked.end()) return it->second;
+        if (it != prefix_checked.end() && !it->second) return false;
         Tn flag = alloc(1, 1, false);
         TK_HIP(hipMemsetAsync(flag.p, 0, sizeof(int32_t), stream()));
         hipLaunchKernelGGL(tr_prefix_check_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(B * M * K, 256), 2048)), dim3(256), 0, stream(), pool_idx, neigh, B, N,
@@ -482,7 +488,8 @@ struct ps_trainer {
         int32_t h = 0;
         TK_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream()));
         TK_HIP(hipStreamSynchronize(stream()));
-        return prefix_checked[key] = h == 0;
+        if (h != 0) prefix_checked[key] = false;
+        return h == 0;
     }
     std::vector<WgradJob> wjobs;  // weight / bias gradient partials waiting for the step's one reduction launch
     std::vector<Tn> wkeep;
@@ -574,14 +581,24 @@ struct ps_trainer {
         hipLaunchKernelGGL(tr_transpose_kernel, dim3(ceil_div(src.C, 32), ceil_div(src.R, 32)), dim3(256), 0, stream(), src.p, (int)src.R, (int)src.C, dst);
         TK_HIP(hipGetLastError());
     }
+    // a world of ONE rank is the identity: the callback is skipped (and the BatchNorm layers keep their cheaper one-rank form) unless
+    // ps_trainer_set_collective asked for it with PS_COLLECTIVE_AT_WORLD_ONE -- bench.py's measurement of the host collective's floor
+    bool coll_active() const { return coll != nullptr && (world > 1 || coll_at_one); }
     void allreduce(void* buf, int64_t count, int dtype)
     {
-        if (!coll) return;  // (a world of ONE rank with a callback still goes through it: the latency floor of the host's collective)
-        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (!coll_active()) return;
+        struct EventPair {  // (owned until handed to coll_marks: nothing leaks when a HIP call in between throws)
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            ~EventPair()
+            {
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+            }
+        } ev;
         if (profile) {
-            TK_HIP(hipEventCreate(&e0));
-            TK_HIP(hipEventCreate(&e1));
-            TK_HIP(hipEventRecord(e0, stream()));
+            TK_HIP(hipEventCreate(&ev.e0));
+            TK_HIP(hipEventCreate(&ev.e1));
+            TK_HIP(hipEventRecord(ev.e0, stream()));
         }
         const auto h0 = std::chrono::steady_clock::now();
         const int rc = coll(coll_user, buf, count, dtype, (void*)stream());
@@ -589,8 +606,9 @@ struct ps_trainer {
         coll_calls += 1;
         coll_bytes += count * (dtype == 1 ? 8 : 4);
         if (profile) {
-            (void)hipEventRecord(e1, stream());
-            coll_marks.emplace_back(e0, e1);
+            (void)hipEventRecord(ev.e1, stream());
+            coll_marks.emplace_back(ev.e0, ev.e1);
+            ev.e0 = ev.e1 = nullptr;
         }
         if (rc != 0) {
             ps::set_error("the host's all-reduce callback failed with code %d", rc);
@@ -779,7 +797,7 @@ struct ps_trainer {
         Tn stats = alloc(5, C, false);  // mean, invstd, var, [sum x | sum x^2]
         float *mean = stats.p, *invstd = stats.p + C, *var = stats.p + 2 * C, *sums = stats.p + 3 * C;
         const float *gamma = params + lp.gamma, *beta = params + lp.beta;
-        const bool sync = sync_bn && coll;
+        const bool sync = sync_bn && coll_active();
         const int64_t R_total = sync ? R * world : R;
         if (!sync) {
             // statistics, moving-statistics update and the apply pass: three launches
@@ -823,7 +841,7 @@ struct ps_trainer {
     Tn locse_bn_act(const float* xyz, const int32_t* idx, int64_t B, int64_t N, int64_t K, const LayerP& lp, const Tn* out = nullptr)
     {
         const int64_t h = lp.cout, R = B * N * K;
-        const bool sync = sync_bn && coll;
+        const bool sync = sync_bn && coll_active();
         const int64_t R_total = sync ? R * world : R;
         const float *W = params + lp.w, *b = params + lp.b, *gamma = params + lp.gamma, *beta = params + lp.beta;
         Tn sums = alloc(1, 4 * h, false);  // 2h doubles: the variance is a difference of nearly equal sums
@@ -873,7 +891,7 @@ struct ps_trainer {
     Tn conv_bn_fused(const Tn& x, const LayerP& lp, bool defer_dgrad, const Tn* out = nullptr)
     {
         const int64_t R = x.R, h = lp.cout, CP = h < 16 ? 16 : h;
-        const bool sync = sync_bn && coll;
+        const bool sync = sync_bn && coll_active();
         const int64_t R_total = sync ? R * world : R;
         const float *W = params + lp.w, *b = params + lp.b, *gamma = params + lp.gamma, *beta = params + lp.beta;
         Tn sums = alloc(1, 6 * CP, false);  // 3 CP doubles: sum y | sum y^2 | sum x
@@ -942,7 +960,7 @@ struct ps_trainer {
     Tn conv_bn_rect(const Tn& x, const LayerP& lp, bool leaky)
     {
         const int64_t R = x.R, ci = lp.cin, co = lp.cout;
-        const bool sync = sync_bn && coll;
+        const bool sync = sync_bn && coll_active();
         const int64_t R_total = sync ? R * world : R;
         const float *W = params + lp.w, *b = params + lp.b, *gamma = params + lp.gamma, *beta = params + lp.beta;
         Tn sums = alloc(1, 4 * co, false);  // 2 cout doubles: sum y | sum y^2
@@ -1064,6 +1082,34 @@ struct ps_trainer {
             Tn dfset = alloc(RK, d);
             TK(ps_op_att_pool_train_bwd(c, fset.p, fset.ld, W.p, dy.p, R, K, d, dfset.p, d, gW.p));
             accum(fset, dfset);
+        });
+        return agg;
+    }
+
+    // att_pooling's core at the wide levels (d = 128 / 256; attpool_gemm.hip): scores and probabilities only ever live in registers; the
+    // backward hands dS on to the step's ordinary weight-gradient product (partials now, summed by the one wgrad_finish launch)
+    Tn attpool_gemm(const Tn& fset, const Tn& W, const Tn& gW, int64_t K)
+    {
+        const int64_t RK = fset.R, d = fset.C, R = RK / K;
+        Tn agg = alloc(R, d);
+        TK(ps_op_att_pool_gemm_fwd(c, fset.p, fset.ld, W.p, R, K, d, agg.p));
+        record(agg, [=](const Tn& dy_in) {
+            const Tn dy = contig(dy_in);
+            Tn ds = alloc(RK, d, false);
+            // fset's gradient so far (none in this graph: the pooling is the concat buffer's only consumer) is added to in the epilogue
+            auto have = grad_of.find(fset.id);
+            const bool add = have != grad_of.end() && have->second.R == RK && have->second.C == d && have->second.ld % 4 == 0;
+            Tn dfset = add ? have->second : alloc(RK, d);
+            TK(ps_op_att_pool_gemm_bwd(c, fset.p, fset.ld, W.p, dy.p, R, K, d, dfset.p, dfset.ld, add ? 1 : 0, ds.p, ds.ld));
+            if (!add) accum(fset, dfset);
+            const int64_t nb = wgrad_partial_slabs(c, fset.p, fset.ld, ds.p, ds.ld, RK, d, d);
+            Tn part = alloc(nb, d * d, false);
+            {
+                Stage st(c, "train_wgrad", 1);
+                TK(wgrad_partial(c, fset.p, fset.ld, ds.p, ds.ld, RK, d, d, part.p, nullptr));
+            }
+            wjobs.push_back(WgradJob{part.p, gW.p, (int)nb, (int)d, (int)d, 0});
+            wkeep.push_back(part);
         });
         return agg;
     }
@@ -1232,6 +1278,9 @@ struct ps_trainer {
         Tn agg;
         if (opt.fused_att && ps_op_att_pool_train_supported(K, fcat.C)) {
             agg = attpool(fcat, W, gW, K);  // levels whose [N*K, d] tensors are large: one kernel per direction
+        } else if (opt.fused_att && att_gemm_on && ps_op_att_pool_gemm_supported(K, fcat.C) && fcat.ld % 4 == 0 &&
+                   (reinterpret_cast<uintptr_t>(fcat.p) & 15) == 0) {
+            agg = attpool_gemm(fcat, W, gW, K);  // the wide levels: scores in registers on the frame of the large GEMMs
         } else {
             Tn s = linear(fcat, W, nullptr, gW, nullptr);
             agg = softpool(fcat, s, K);
@@ -1283,7 +1332,7 @@ struct ps_trainer {
                 f_agg2 = att_split(f_agg, idx, B, N, K, f_xyz2, n + "LFAatt_pooling_2");
             } else {
                 // (d = 128: the pre-product form measured slower, HBM bound there; bf16 mode: its yardstick rounds the operands of the ONE d x d product)
-                const bool pre = !opt.mlp_bf16 && 2 * hc >= 256;
+                const bool pre = !opt.mlp_bf16 && 2 * hc >= 256 && !(opt.fused_att && att_gemm_on && ps_op_att_pool_gemm_supported(K, 2 * hc));
                 Tn cat1 = alloc(B * N * K, 2 * hc);
                 Tn right1 = cols(cat1, hc, hc);
                 Tn f_xyz = locse(&right1);
@@ -1428,6 +1477,7 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
     int rc = PS_OK;
     try {
         t->pool.begin_step();
+        t->pyramid_vouched = pyr->built != 0 && pyr->built == pyramid_stamp(pyr);
         t->forks_used = 0;
         t->coll_calls = t->coll_bytes = 0;
         t->coll_host_ms = 0.0;
@@ -1511,7 +1561,7 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
         return e.rc;
     }
     try {
-        if (t->coll) {
+        if (t->coll_active()) {
             // gradient synchronisation of config 4: ONE all-reduce of the flat fp32 gradient buffer, then the mean over the ranks
             t->allreduce(t->grads, t->n_params, 0);
             if (t->world > 1) {
@@ -1643,7 +1693,8 @@ int ps_trainer_set_collective(ps_trainer* t, ps_allreduce_fn fn, void* user, int
     t->coll_user = user;
     t->world = world_size;
     t->rank = rank;
-    t->sync_bn = sync_bn != 0;
+    t->sync_bn = (sync_bn & 1) != 0;
+    t->coll_at_one = (sync_bn & PS_COLLECTIVE_AT_WORLD_ONE) != 0;
     return PS_OK;
 }
 

@@ -17,11 +17,45 @@ get slower again.  Streams created BEFORE the lanes by somebody else (RCCL's int
 the pipeline first, the process group afterwards (bench.py does both).  Results are identical to the serial path (same kernels,
 same order per cloud) -- tests/test_gpu_network.py::test_pipeline_matches_serial.
 """
+import os
+import warnings
+
 import torch
 
 from . import _lib, runtime
 from .pyramid import alloc_pyramid, build_pyramid
 from .RandLANet import Network
+
+
+def hw_queues():
+    """GPU_MAX_HW_QUEUES as the HIP runtime sees it (the package sets 6 at import when the user set nothing; HIP's own default is 4)."""
+    try:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        return 4
+
+
+def _check_environment(lanes, reusing):
+    """The two traps of the lane pipeline, checked where the lanes are created (module docstring): too few hardware queues puts two
+    lanes on one queue (they then run one after the other: measured 1.33 against 1.23 ms per cloud with 3 effective lanes), and HIP
+    streams created by RCCL before the lanes shift the stream -> queue assignment (measured 1.72 against 1.31 ms)."""
+    q = hw_queues()
+    if q < lanes + 2:
+        warnings.warn("ForwardPipeline: %d lanes want GPU_MAX_HW_QUEUES >= %d (lanes + the null stream + RCCL's) but the HIP runtime has %d: lanes "
+                      "that share a hardware queue run one after the other (measured 1.33 vs 1.23 ms per 180 000-point cloud).  Set the variable "
+                      "before the first HIP call -- `import point_unet_amd` does when it is unset." % (lanes, lanes + 2, q), RuntimeWarning, stacklevel=3)
+    if reusing:
+        return  # (the streams exist already: created before whatever came later)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        try:
+            backend = str(dist.get_backend())
+        except Exception:  # noqa: BLE001
+            backend = ""
+        if "nccl" in backend and os.environ.get("PS_PIPELINE_AFTER_NCCL", "0") != "1":
+            raise RuntimeError("ForwardPipeline must be created (and prime()d) BEFORE torch.distributed.init_process_group('nccl'): RCCL's internal "
+                               "streams would take the hardware queues the lanes need (measured 1.72 vs 1.31 ms per cloud).  Create the pipeline "
+                               "first, or set PS_PIPELINE_AFTER_NCCL=1 to accept the slower assignment.")
 
 
 class _Lane:
@@ -46,6 +80,7 @@ class ForwardPipeline:
         on streams spread over more hardware queues are scheduled later."""
         self.cfg = config
         self.device = torch.device("cuda", device)
+        _check_environment(int(lanes), reuse is not None)
         if params is None:
             from . import weights
             params = weights.init_params(config, seed=seed)

@@ -797,10 +797,11 @@ class Trainer:
         lib = _lib.lib()
         self._rank = dist.get_rank() if dist is not None else 0
         self._world = dist.get_world_size() if dist is not None else 1
-        # (one rank under a process group: the library would call the callback -- useful to measure what the collectives cost, bench.py
-        #  sets collective_at_world_one for that -- but a one-rank mean is the identity: the plain single-rank step is 15 % faster)
+        # (one rank under a process group: the library skips the callback -- a one-rank mean is the identity, the plain single-rank step
+        #  is 15 % faster -- unless asked with PS_COLLECTIVE_AT_WORLD_ONE: bench.py sets collective_at_world_one to measure the calls)
         if dist is not None and (self._world > 1 or self.collective_at_world_one):
-            _lib.check(lib.ps_trainer_set_collective(self._h, self._collective(dist), None, self._world, self._rank, 1 if self.sync_bn else 0))
+            flags = (1 if self.sync_bn else 0) | (2 if self.collective_at_world_one else 0)  # (2 = PS_COLLECTIVE_AT_WORLD_ONE)
+            _lib.check(lib.ps_trainer_set_collective(self._h, self._collective(dist), None, self._world, self._rank, flags))
         else:
             _lib.check(lib.ps_trainer_set_collective(self._h, _lib.PS_ALLREDUCE_FN(), None, 1, 0, 0))  # NULL callback: single rank
         _lib.check(lib.ps_trainer_set_options(self._h, ctypes.byref(self._options())))

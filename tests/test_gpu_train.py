@@ -505,6 +505,70 @@ def test_fused_attentive_pooling_forward_backward(mode):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_wide_level_attentive_pooling_on_the_gemm_frame(mode):
+    """ps_op_att_pool_gemm_fwd / _bwd (csrc/attpool_gemm.hip: the score product, the softmax over K, the weighted sum and -- backward --
+    dS and dF = p g + dS . W^T with the scores only in accumulator registers; d = 128 / 256, forward also 512) against torch float64
+    autograd of  agg = sum_K softmax_K(F.W) * F  (RandLANet.py:394-398), the bf16 mode with the operands of the products rounded as the
+    kernel rounds them.  Strided input (a column block of a wider buffer), ragged point counts (the last workgroup holds an odd number
+    of points / waves without rows), accumulation into an existing dF, and the weight gradient through ps_op_linear_wgrad_ex over
+    (F, dS).  Bars as the narrow-level kernels: agg 2e-6 / 2e-5 of its max, dF and dW 2e-5 (fp32) and 2e-3 / 1e-3 (bf16: dS within
+    fp32 noise of a bfloat16 rounding boundary lands on the neighbour).  Transposes would show: W is not symmetric, rows are random."""
+    import ctypes
+    import torch
+    from point_unet_amd import _lib, runtime
+    L, ctx = _lib.lib(), runtime.default_context(0)
+    h = ctx.handle
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(23)
+    rb = (lambda t: t.float().bfloat16().double()) if mode == "bf16" else (lambda t: t)
+    K = 16
+    try:
+        _lib.check(L.ps_set_train_gemm_bf16(h, 1 if mode == "bf16" else 0))
+        for R, d, wide, bwd in [(1000, 128, 128, True), (1033, 128, 160, True), (7, 128, 128, True), (1500, 256, 256, True), (333, 256, 320, True),
+                                (1, 256, 256, True), (515, 512, 512, False)]:
+            assert L.ps_op_att_pool_gemm_supported(K, d) == (1 if bwd else 0) or not bwd
+            buf = torch.randn(R * K, wide, generator=g).cuda()
+            F = buf[:, wide - d:]
+            W = (torch.randn(d, d, generator=g) / d ** 0.5).cuda()
+            dagg = torch.randn(R, d, generator=g).cuda()
+            agg = torch.full((R + 1, d), 7.0).cuda()
+            _lib.check(L.ps_op_att_pool_gemm_fwd(h, p(F), wide, p(W), R, K, d, p(agg)))
+            assert bool((agg[R] == 7.0).all()), "wrote past the last point"
+            Fd, Wd = F.double().reshape(R, K, d), W.double()
+            S = rb(Fd) @ rb(Wd)
+            P = torch.softmax(S, 1)
+            ref = (P * Fd).sum(1)
+            assert (agg[:R].double() - ref).abs().max() <= (2e-6 if mode == "fp32" else 2e-5) * ref.abs().max(), (R, d)
+            if not bwd:
+                continue
+            seed = torch.randn(R * K + 16, d, generator=g).cuda()
+            dF, dF2 = torch.full((R * K + 16, d), 3.0).cuda(), seed.clone()
+            dS = torch.full((R * K + 16, d + 4), 5.0).cuda()
+            _lib.check(L.ps_op_att_pool_gemm_bwd(h, p(F), wide, p(W), p(dagg), R, K, d, p(dF), d, 0, p(dS), d + 4))
+            _lib.check(L.ps_op_att_pool_gemm_bwd(h, p(F), wide, p(W), p(dagg), R, K, d, p(dF2), d, 1, p(dS), d + 4))
+            assert bool((dF[R * K:] == 3.0).all()) and bool((dS[R * K:] == 5.0).all()) and bool((dS[:, d:] == 5.0).all()), "wrote past the last row"
+            gd = dagg.double()[:, None, :]
+            dS_ref = P * gd * (Fd - ref[:, None, :])
+            dF_ref = P * gd + rb(dS_ref) @ rb(Wd).T
+            bar = 2e-5 if mode == "fp32" else 2e-3
+            assert (dS[:R * K, :d].double().reshape(R, K, d) - rb(dS_ref)).abs().max() <= (2e-5 if mode == "fp32" else 8e-3) * dS_ref.abs().max(), (R, d)
+            assert (dF[:R * K].double().reshape(R, K, d) - dF_ref).abs().max() <= bar * dF_ref.abs().max(), (R, d)
+            assert ((dF2[:R * K] - seed[:R * K]).double().reshape(R, K, d) - dF_ref).abs().max() <= 2 * bar * dF_ref.abs().max(), (R, d)
+            dW = torch.empty(d, d).cuda()
+            _lib.check(L.ps_op_linear_wgrad_ex(h, p(F), wide, p(dS), d + 4, R * K, d, d, p(dW), None))
+            dW_ref = rb(Fd).reshape(-1, d).T @ rb(dS_ref).reshape(-1, d)
+            assert (dW.double() - dW_ref).abs().max() <= (2e-5 if mode == "fp32" else 2e-3) * dW_ref.abs().max(), (R, d)
+            if mode == "fp32" and R <= 1100:  # and the closed form agrees with autograd
+                Fa, Wa = F.double().reshape(R, K, d).clone().requires_grad_(True), W.double().clone().requires_grad_(True)
+                ((torch.softmax(Fa @ Wa, 1) * Fa).sum(1) * dagg.double()).sum().backward()
+                assert (dF_ref - Fa.grad).abs().max() < 1e-10 and (dW_ref - Wa.grad).abs().max() < 1e-9
+        assert L.ps_op_att_pool_gemm_supported(K, 64) == 0 and L.ps_op_att_pool_gemm_supported(32, 128) == 0
+    finally:
+        _lib.check(L.ps_set_train_gemm_bf16(h, 0))
+    torch.cuda.synchronize()
+
+
 def test_split_source_attentive_pooling_equals_gather_concat_attpool():
     """ps_op_att_pool_train_*_split (gather_neighbour + concat folded into the fused attention) against the materialised form through
     the SAME fused kernels: agg, the f_xyz half of the gradient and dWfc bit-identical (same arithmetic, fixed summation order); the
@@ -846,13 +910,21 @@ def test_a_pooling_table_that_is_not_the_neighbour_prefix_still_gets_correct_gra
     params = weights.init_params(cfg, seed=5, randomize_bn=True)
     labels = np.random.default_rng(3).integers(0, cfg.num_classes, xyz.shape[:2]).astype(np.int32)
     pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    assert pyr.struct.built != 0  # ps_pyramid_build vouches for its own tables ...
+    pyr.struct.built = 0          # ... a caller that is about to rewrite one takes that back (include/pointseg.h, ps_pyramid.built)
     M = pyr.sub_idx[0].shape[1]
-    pyr.sub_idx[0].copy_(pyr.neigh_idx[0][:, M:2 * M, :])  # pool every output over some other point's neighbourhood
+    prefix = pyr.sub_idx[0].clone()
     d_feats, d_lab = torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
     grads = {}
     for det in (True, False):
         with Trainer(cfg, params=params, learning_rate=1e-3, keep_prob=1.0, deterministic=det) as tr:
-            loss = float(tr.train_step(pyr, d_feats, d_lab))
+            # first a pass over the pyramid as built (the table IS the prefix: the fixed-order form runs) ...
+            pyr.sub_idx[0].copy_(prefix)
+            tr.backward_only(pyr, d_feats, d_lab)
+            # ... then the SAME buffers rewritten in place -- same pointers, same shapes: a remembered "is a prefix" would now be stale
+            # (the gradients were silently wrong) -- pooling every output over some other point's neighbourhood
+            pyr.sub_idx[0].copy_(pyr.neigh_idx[0][:, M:2 * M, :])
+            loss = float(tr.backward_only(pyr, d_feats, d_lab))
             torch.cuda.synchronize()
             grads[det] = (loss, tr.grad.double().clone())
     assert grads[True][0] == grads[False][0]

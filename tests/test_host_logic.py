@@ -2,6 +2,7 @@
 routine that the HIP kernel instantiates (run on the host through the ps_debug_* doors), the MFMA weight packing,
 and the BatchNorm folding / blob layout (checked by replaying the device's launch plan in NumPy)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -276,3 +277,38 @@ def test_iou_from_confusions_matches_the_reference_formula():
     want = iou + mask * (iou.sum(-1, keepdims=True) / ((1 - mask).sum(-1, keepdims=True) + 1e-6))
     assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
     assert np.allclose(DP.get_class_weights("BraTS_Block64"), 1 / (np.array([1403, 22, 80, 11]) / 1516.0 + 0.02))
+
+
+def test_package_import_sets_the_pipeline_environment_contract():
+    """point_unet_amd/__init__.py: a fresh interpreter WITHOUT GPU_MAX_HW_QUEUES gets 6 (the lanes of ForwardPipeline need a hardware queue
+    each; HIP reads the variable once, when its runtime starts), a user's own value is left alone, and ForwardPipeline's check warns when
+    the runtime has fewer queues than lanes + 2 and refuses to create lanes behind an RCCL process group (pipeline.py::_check_environment)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, sys; sys.path.insert(0, %r); import point_unet_amd; print(os.environ['GPU_MAX_HW_QUEUES'], os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % root
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["6", "0"]
+    env["GPU_MAX_HW_QUEUES"] = "5"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out[0] == "5"
+    import warnings
+    from point_unet_amd import pipeline
+    old = os.environ.get("GPU_MAX_HW_QUEUES")
+    try:
+        os.environ["GPU_MAX_HW_QUEUES"] = "4"
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            pipeline._check_environment(4, False)
+        assert len(w) == 1 and "GPU_MAX_HW_QUEUES" in str(w[0].message)
+        os.environ["GPU_MAX_HW_QUEUES"] = "6"
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            pipeline._check_environment(4, False)
+        assert not w
+    finally:
+        if old is None:
+            os.environ.pop("GPU_MAX_HW_QUEUES", None)
+        else:
+            os.environ["GPU_MAX_HW_QUEUES"] = old
