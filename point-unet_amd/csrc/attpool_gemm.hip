@@ -27,6 +27,8 @@
 #include "common.h"
 #include "mfma_tile.h"
 #include "b3_ops.h"
+#include "attpool_train.h"
+#include "reduce_partials.h"
 
 namespace ps {
 
@@ -413,6 +415,314 @@ static int launch_attg(ps_context* c, const AttGArgs& a)
     }
     PS_HIP(hipGetLastError());
     return PS_OK;
+}
+
+// ---- d = 64 (encoder level 1) -----------------------------------------------------------------------------------------------------------
+// 5.76 M neighbour rows per batch of 8 clouds: the level where the [N*K, d] tensors are largest and where attpool_train.hip's per-point
+// kernels (fp32 MFMA 16x16x4, a wave per point) were bound by the matrix pipe: 0.63 ms forward / 1.71 ms backward per pooling for 0.74 GB
+// read / 2.9 GB moved.  Same computation as the wide-level kernels above with what d = 64 allows on top:
+//   * both weight images (W planes for the scores, W^T planes in accumulator K order for dF: 24 KB each at P = 3) stay in LDS for the
+//     whole kernel -- no stream, no workgroup barrier: the four waves of a workgroup walk their 32-row tiles independently (persistent grid);
+//   * the weight gradient dW = F^T . dS (a third product, contraction over the 32 rows of the tile) accumulates in 64 registers per
+//     wave: its row operand is the tile's value rows in exactly the register order the softmax epilogue loads them in (lane = column,
+//     k-slots = rows), its column operand the planes of dS the transposing product consumes anyway -- per-wave partials, summed by
+//     reduce_partials_kernel in a fixed order (deterministic: the grid does not depend on the data);
+//   * split-source form (RandLANet.py:326-333: F = [gather(f, idx) | f_xyz]): the gathered half is read through idx (row operand: the
+//     lane's own row; value rows: two int4 index loads per point), its gradient leaves as plain rows for the gather-reduction.
+//   * per tile the only global reads are the 32 operand rows (the gathered half through one index per lane) and dagg: the rows are
+//     requested ONE TILE AHEAD (the index two tiles ahead) and go to a per-wave LDS tile as they are split, which is where the softmax
+//     epilogue and the weight-gradient product read their column-wise "value rows" from (the first form read them from global memory a
+//     second time, behind the scores: 6.4 us per tile of exposed latency, 0.56 ms per forward pooling).
+template <int P, bool BWD, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attg64_kernel(AttTrainArgs a, const uint4* __restrict__ w1, const uint4* __restrict__ w2, float* __restrict__ dw_part)
+{
+    constexpr int NQ = 4, NT = 2, IMG = NQ * NT * P * 64;  // uint4 per weight image
+    constexpr int PITCH = 68;                               // floats per row of the value tile: 16-byte rows, the two lane halves on disjoint banks
+    extern __shared__ __attribute__((aligned(16))) uint4 Wl[];
+    for (int i = threadIdx.x; i < IMG; i += WAVES * 64) {
+        Wl[i] = w1[i];
+        if constexpr (BWD) Wl[IMG + i] = w2[i];
+    }
+    __syncthreads();
+    const uint4* W1 = Wl;
+    const uint4* W2 = Wl + IMG;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int hl = lane >> 5, c32 = lane & 31;
+    float* V = reinterpret_cast<float*>(Wl + (BWD ? 2 : 1) * IMG) + wave * (32 * PITCH);
+    const bool split = a.fl != nullptr;
+    uint4 ident[2];
+    {
+        const bool mine = ((c32 >> 2) & 1) == hl;
+        const int j = (c32 & 3) + 4 * ((c32 >> 3) & 1), kap = c32 >> 4;
+        const unsigned one = 0x3F80u << (16 * (j & 1));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool on = mine && kap == k;
+            ident[k].x = (on && (j >> 1) == 0) ? one : 0u;
+            ident[k].y = (on && (j >> 1) == 1) ? one : 0u;
+            ident[k].z = (on && (j >> 1) == 2) ? one : 0u;
+            ident[k].w = (on && (j >> 1) == 3) ? one : 0u;
+        }
+    }
+    f32x16 acc3[2][2];  // dW of this wave: tile (it, ct) = rows 32 it .., columns 32 ct .. (lane = column, registers = rows)
+    if constexpr (BWD) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc3[i][j][r] = 0.f;
+    }
+    const int64_t rows = a.R * 16;
+    const int64_t ntiles = (rows + 31) >> 5;
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    // the operand row of this lane in tile `tile` (rows is a multiple of 16: the last tile may hold ONE point, whose rows are then read twice)
+    auto my_row = [&](int64_t tile) {
+        const int64_t row0 = tile << 5;
+        const int second = rows - row0 >= 32 ? 16 : 0;
+        return row0 + (c32 < 16 ? c32 : c32 - 16 + second);
+    };
+    float4 nrow[8];   // the NEXT tile's operand row of this lane: chunks q = 0..3 x two float4
+    int nidx = 0;     // split form: the lane's gathered row of the tile after that
+    auto fetch_idx = [&](int64_t tile) { if (split && tile < ntiles) nidx = a.idx[my_row(tile)]; };
+    auto fetch_row = [&](int64_t tile) {
+        if (tile >= ntiles) return;
+        const int64_t row = my_row(tile);
+        const float *pL, *pR;
+        if (split) {
+            pL = a.fl + (size_t)(((row >> 4) / a.n_q) * a.n_src + nidx) * a.ldl + 8 * hl;
+            pR = a.f + (size_t)row * a.ld + 8 * hl;
+        } else {
+            pL = a.f + (size_t)row * a.ld + 8 * hl;
+            pR = pL + 32;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float* src = q < 2 ? pL + 16 * q : pR + 16 * (q - 2);
+            nrow[2 * q] = *reinterpret_cast<const float4*>(src);
+            nrow[2 * q + 1] = *reinterpret_cast<const float4*>(src + 4);
+        }
+    };
+    int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+    fetch_idx(tile);
+    fetch_row(tile);
+    fetch_idx(tile + stride);
+#pragma unroll 1
+    for (; tile < ntiles; tile += stride) {
+        const int64_t row0 = tile << 5;
+        const int nvalid = rows - row0 >= 32 ? 32 : 16;
+        const int second = nvalid == 32 ? 16 : 0;
+        float gd[2][2];  // dagg of (tile column block t, point pi): requested before the products
+        if constexpr (BWD) {
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    gd[t][pi] = 16 * pi < nvalid ? a.dagg[(size_t)((row0 >> 4) + pi) * 64 + 32 * t + c32] : 0.f;
+        }
+        // ---- scores; the rows go to the value tile as they are split ----
+        f32x16 acc[2], acc2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[t][r] = 0.f;
+                acc2[t][r] = 0.f;
+            }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float4 x0 = nrow[2 * q], x1 = nrow[2 * q + 1];
+            *reinterpret_cast<float4*>(V + c32 * PITCH + 16 * q + 8 * hl) = x0;
+            *reinterpret_cast<float4*>(V + c32 * PITCH + 16 * q + 8 * hl + 4) = x1;
+            const BPlanes<P> ap = b3_split8<P>(x0, x1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                BPlanes<P> bp;
+#pragma unroll
+                for (int pl = 0; pl < P; ++pl) bp.p[pl] = W1[((q * NT + t) * P + pl) * 64 + lane];
+                acc[t] = b3_mfma6<P>(ap, bp, acc[t]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_row(tile + stride);       // (uses the index fetched one iteration ago)
+        fetch_idx(tile + 2 * stride);
+        __builtin_amdgcn_sched_barrier(0);
+        wave_lds_sync();
+        // ---- per point: value rows (LDS), softmax, (backward) dS, direct term, dW ----
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            const bool pvalid = 16 * pi < nvalid;
+            float fv[2][8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fv[t][j] = V[(16 * pi + 4 * hl + (j & 3) + 8 * (j >> 2)) * PITCH + 32 * t + c32];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float m = acc[t][8 * pi];
+#pragma unroll
+                for (int j = 1; j < 8; ++j) m = fmaxf(m, acc[t][8 * pi + j]);
+                m = attg_swap_max(m);
+                float e[8], z = 0.f, num = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    e[j] = __expf(acc[t][8 * pi + j] - m);
+                    z += e[j];
+                    num = __builtin_fmaf(e[j], fv[t][j], num);
+                }
+                z = attg_swap_sum(z);
+                num = attg_swap_sum(num);
+                const float inv = __builtin_amdgcn_rcpf(z), agg = num * inv;
+                if constexpr (!BWD) {
+                    if (hl == 0 && pvalid) a.agg[(size_t)((row0 >> 4) + pi) * 64 + 32 * t + c32] = agg;
+                } else {
+                    const float ginv = gd[t][pi] * inv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float pg = e[j] * ginv;
+                        acc2[t][8 * pi + j] = pg;
+                        acc[t][8 * pi + j] = pg * (fv[t][j] - agg);
+                    }
+                }
+            }
+            if constexpr (BWD) {
+                BPlanes<P> fvp[2], dp[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fvp[t] = b3_split8<P>(make_float4(fv[t][0], fv[t][1], fv[t][2], fv[t][3]), make_float4(fv[t][4], fv[t][5], fv[t][6], fv[t][7]));
+                    dp[t] = b3_split8<P>(make_float4(acc[t][8 * pi], acc[t][8 * pi + 1], acc[t][8 * pi + 2], acc[t][8 * pi + 3]),
+                                         make_float4(acc[t][8 * pi + 4], acc[t][8 * pi + 5], acc[t][8 * pi + 6], acc[t][8 * pi + 7]));
+                }
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) acc3[it][ct] = b3_mfma6<P>(fvp[it], dp[ct], acc3[it][ct]);
+            }
+        }
+        wave_lds_sync();  // (the value tile is rewritten by the next iteration)
+        if constexpr (BWD) {
+            // ---- dF = direct + dS . W^T: the transposed tile of dS (lane = row, registers = columns) is the row operand, register for register ----
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                __builtin_amdgcn_sched_barrier(0);
+                // (the planes of dS a second time rather than a transposed tile kept alive through the loop over the points: 16 registers
+                //  for 44 VALU instructions)
+                f32x16 T;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T[r] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const BPlanes<P> dp = b3_split8<P>(make_float4(acc[ct][8 * k], acc[ct][8 * k + 1], acc[ct][8 * k + 2], acc[ct][8 * k + 3]),
+                                                       make_float4(acc[ct][8 * k + 4], acc[ct][8 * k + 5], acc[ct][8 * k + 6], acc[ct][8 * k + 7]));
+#pragma unroll
+                    for (int pl = P - 1; pl >= 0; --pl) T = b3_mfma(dp.p[pl], ident[k], T);
+                }
+                BPlanes<P> tp[2];
+                tp[0] = b3_split8<P>(make_float4(T[0], T[1], T[2], T[3]), make_float4(T[4], T[5], T[6], T[7]));
+                tp[1] = b3_split8<P>(make_float4(T[8], T[9], T[10], T[11]), make_float4(T[12], T[13], T[14], T[15]));
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        BPlanes<P> bp;
+#pragma unroll
+                        for (int pl = 0; pl < P; ++pl) bp.p[pl] = W2[(((2 * ct + u) * NT + it) * P + pl) * 64 + lane];
+                        acc2[it] = b3_mfma6<P>(tp[u], bp, acc2[it]);
+                    }
+            }
+            // ---- stores: register 8 half + q of tile it = row 16 half + 4 hl + (q & 3) + 8 (q >> 2) of the wave, column 32 it + c32 ----
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                float* base;
+                int pitch;
+                bool accum = false;
+                if (!split) {
+                    base = a.df + (size_t)row0 * a.lddf + 32 * it + c32;
+                    pitch = a.lddf;
+                } else if (it == 0) {
+                    base = a.dfl_rows + (size_t)row0 * a.ld_rows + c32;
+                    pitch = a.ld_rows;
+                } else {
+                    base = a.df + (size_t)row0 * a.lddf + c32;
+                    pitch = a.lddf;
+                    accum = a.df_accum != 0;
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if (16 * half < nvalid) {
+                        float old[8];
+                        if (accum) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) old[q] = base[(unsigned)((16 * half + 4 * hl + (q & 3) + 8 * (q >> 2)) * pitch)];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            base[(unsigned)((16 * half + 4 * hl + (q & 3) + 8 * (q >> 2)) * pitch)] = accum ? acc2[it][8 * half + q] + old[q] : acc2[it][8 * half + q];
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (BWD) {
+        float* out = dw_part + (size_t)(blockIdx.x * WAVES + wave) * 4096;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[(32 * it + (r & 3) + 8 * (r >> 2) + 4 * hl) * 64 + 32 * ct + c32] = acc3[it][ct][r];
+    }
+}
+
+bool att64_gemm_fits(const AttTrainArgs& a, bool backward)
+{
+    static const bool on = [] { const char* e = getenv("PS_ATT64_GEMM"); return e ? atoi(e) != 0 : true; }();  // (A/B switch)
+    if (!on) return false;
+    auto al = [](const void* q, int ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0; };
+    if (!al(a.f, a.ld)) return false;
+    if (a.fl) {
+        if (!al(a.fl, a.ldl) || (reinterpret_cast<uintptr_t>(a.idx) & 15) != 0 || a.n_q <= 0) return false;
+        if (backward && !a.dfl_rows) return false;  // (the float-atomic scatter form: attpool_train.hip)
+    }
+    return a.R > 0 && a.R * 16 < (1ll << 31);
+}
+
+template <int P, bool BWD, int WAVES>
+static int launch_attg64(ps_context* c, const AttTrainArgs& a, const uint4* w1, const uint4* w2, float* dW)
+{
+    const size_t smem = (size_t)4 * 2 * P * 64 * 16 * (BWD ? 2 : 1) + sizeof(float) * WAVES * 32 * 68;
+    auto kern = attg64_kernel<P, BWD, WAVES>;
+    if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const int per_cu = std::max(1, (int)(160 * 1024 / smem));
+    const int64_t tiles = (a.R * 16 + 31) / 32;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((tiles + WAVES - 1) / WAVES, 256 * per_cu));
+    float* part = nullptr;
+    if (BWD) {
+        PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * WAVES * 4096 + 256));
+        part = c->red_ws.as<float>();
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, c->stream, a, w1, w2, part);
+    if (BWD) hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(ceil_div(4096, 16)), dim3(256), 0, c->stream, static_cast<const float*>(part), blocks * WAVES, 4096, dW);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+int att64_gemm(ps_context* c, AttTrainArgs a, bool backward, float* dW)
+{
+    const uint4 *w1 = nullptr, *w2 = nullptr;
+    PS_TRY(attg_planes(c, a.w, 64, false, &w1));
+    if (backward) PS_TRY(attg_planes(c, a.w, 64, true, &w2));
+    // forward: twelve waves per workgroup (weights 24 KB + 8.5 KB of value tile per wave: three waves per SIMD); backward: 160 accumulator
+    // registers + the prefetched rows -- four waves per workgroup (one per SIMD, no scratch) or eight (two per SIMD with 23 / 57 registers
+    // of scratch at P = 1 / 3).  Measured on MI355X, 8 x 45 000 points (profiles/tools/exp_att64.py): fp32 1.349 ms with four, 1.443 with
+    // eight; bf16 0.858 with four, 0.713 with eight (attpool_train.hip's kernels: 1.720 / 1.123).  PS_ATT64_OCC = 1 | 2 overrides.
+    static const int occ_env = [] { const char* e = getenv("PS_ATT64_OCC"); return e ? atoi(e) : 0; }();
+    if (c->train_bf16) {
+        if (!backward) return launch_attg64<1, false, 12>(c, a, w1, w2, dW);
+        return occ_env == 1 ? launch_attg64<1, true, 4>(c, a, w1, w2, dW) : launch_attg64<1, true, 8>(c, a, w1, w2, dW);
+    }
+    if (!backward) return launch_attg64<3, false, 12>(c, a, w1, w2, dW);
+    return occ_env == 2 ? launch_attg64<3, true, 8>(c, a, w1, w2, dW) : launch_attg64<3, true, 4>(c, a, w1, w2, dW);
 }
 
 static bool attg_ok(int64_t K, int64_t d, const void* f, int64_t ld)

@@ -23,6 +23,7 @@
 #include "common.h"
 #include "mfma_tile.h"
 #include "reduce_partials.h"
+#include "attpool_train.h"
 
 #include <map>
 #include <mutex>
@@ -35,29 +36,6 @@ __device__ __forceinline__ float round_bf16(float x)
     u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (finite inputs)
     return __uint_as_float(u & 0xffff0000u);
 }
-
-struct AttTrainArgs {
-    const float* f;     // [R*K, ld]
-    const float* w;     // [D, D] row-major
-    const float* dagg;  // [R, D] (backward)
-    float* agg;         // [R, D] (forward)
-    float* df;          // [R*K, lddf] (backward)
-    float* dw_part;     // [gridDim.x, D*D] (backward)
-    int64_t R;
-    int ld, lddf, bf16;
-    // split-source form (gather_neighbour + concat folded in, RandLANet.py:326-333): F = [fl[idx] | f]; `f` / `df` then hold only the
-    // right half ([R*K, D/2] rows); the left half's gradient is added into dfl with float atomics (a scatter-add like
-    // ps_op_scatter_add_rows)
-    const float* fl;     // [B*n_src, D/2] rows (ldl), nullptr = F is materialised in f
-    const int32_t* idx;  // [R, K] cloud-local source rows
-    float* dfl;          // [B*n_src, D/2] rows (lddl), accumulated into (backward)
-    int64_t n_src, n_q;  // rows per cloud of fl / points per cloud
-    int ldl, lddl;
-    float* dfl_rows;     // non-null: the gathered half's gradient goes HERE as plain rows [R*K, D/2] (ld_rows) instead of being scatter-added into
-    int ld_rows;         // dfl with float atomics; ps_op_gather_reduce_rows then adds the rows up in a fixed order (deterministic step)
-    int df_accum;        // split form: df (the f_xyz half's gradient) is ADDED to what the rows already hold (a second gradient of the same tensor)
-    int vec_store;       // backward: the row outputs (df, dfl_rows) are 16-byte aligned with pitches % 4 == 0 -> staged through LDS, float4 stores
-};
 
 template <int D>
 struct AttTrainGeom {
@@ -922,6 +900,11 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
         auto al = [](const void* q, int ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0; };
         const bool rows_out = !a.fl || a.dfl_rows;  // (the atomic scatter form keeps its per-element path)
         a.vec_store = rows_out && al(a.df, a.lddf) && (!a.fl || al(a.dfl_rows, a.ld_rows)) ? 1 : 0;
+    }
+    if constexpr (D == 64) {
+        // level 1: the 32x32x16 bf16 matrix pipe (exact three-way splits in fp32 mode), weights resident in LDS, dWfc in registers
+        // (attpool_gemm.hip: 0.63 -> 0.3 ms forward, 1.71 -> 0.9 ms backward per pooling of 5.76 M rows)
+        if (att64_gemm_fits(a, backward)) return att64_gemm(c, a, backward, dW);
     }
     if (a.bf16) {  // the bf16-MLP mode: operands kept as bfloat16 in LDS, products on the bf16 matrix pipe
         constexpr int PB = AttBf16Geom<D>::PB;

@@ -604,9 +604,19 @@ def test_split_source_attentive_pooling_equals_gather_concat_attpool():
         _lib.check(L.ps_op_att_pool_train_fwd_split(h, p(fsrc), hh, p(idx), B, N, M, p(fx), hh, p(W), K, d, p(agg1)))
         _lib.check(L.ps_op_att_pool_train_bwd_split(h, p(fsrc), hh, p(idx), B, N, M, p(fx), hh, p(W), p(dagg), K, d, p(dsrc1), hh, p(dfx), hh, p(dW1)))
         assert torch.equal(agg0, agg1), d
-        assert torch.equal(dcat[:, hh:], dfx), d
-        assert torch.equal(dW0, dW1), d
-        assert (dsrc0 - dsrc1).abs().max() <= 2e-6 * dsrc0.abs().max(), d
+        # the float-atomic scatter form runs attpool_train.hip's per-point kernels at every width; the materialised form takes
+        # attpool_gemm.hip's matrix-pipe kernel at d = 64: same values to fp32 rounding there, bit for bit elsewhere
+        if d == 64:
+            assert (dcat[:, hh:] - dfx).abs().max() <= 2e-5 * dfx.abs().max() and (dW0 - dW1).abs().max() <= 2e-5 * dW0.abs().max(), d
+        else:
+            assert torch.equal(dcat[:, hh:], dfx), d
+            assert torch.equal(dW0, dW1), d
+        assert (dsrc0 - dsrc1).abs().max() <= (2e-5 if d == 64 else 2e-6) * dsrc0.abs().max(), d
+        # the row-output form (the deterministic step's): the same kernel as the materialised form at every width -- bit-identical, the
+        # gathered half as plain rows equal to the left columns of the materialised gradient
+        rows, dfx2, dW2 = torch.empty(B * M * K, hh).cuda(), torch.empty(B * M * K, hh).cuda(), torch.empty(d, d).cuda()
+        _lib.check(L.ps_op_att_pool_train_bwd_split_rows(h, p(fsrc), hh, p(idx), B, N, M, p(fx), hh, p(W), p(dagg), K, d, p(rows), hh, p(dfx2), hh, p(dW2)))
+        assert torch.equal(dcat[:, hh:], dfx2) and torch.equal(dcat[:, :hh].contiguous(), rows) and torch.equal(dW0, dW2), d
     torch.cuda.synchronize()
 
 
