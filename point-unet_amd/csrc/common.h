@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/pointseg.h"
+#include "../../include/pointseg_train_ops.h"
 
 namespace ps {
 

@@ -1,8 +1,8 @@
 // kdtree_host.hip -- host-side construction of the kd-tree in the device layout of kdtree.h.
 //
-// Used (a) by the C-ABI debug hooks ps_debug_* that let the CPU test-suite drive the very search routine the
-// HIP kernel runs, and (b) as the bring-up builder behind PS_TREE_BUILD=host.  The production path builds the
-// tree on the device (kdtree_build.hip); both must produce identical arrays (tests/test_gpu_knn.py).
+// TEST-ONLY: linked into libpointseg_debug.so (and the host sanitizer binary), not into the product library.  The C-ABI debug
+// doors ps_debug_* use it to let the CPU test-suite drive the very search routine the HIP kernel runs, and the GPU tests compare
+// the device builder (kdtree_build.hip, the only builder of the product) against it array for array (tests/test_gpu_knn.py).
 //
 // The construction rules are nanoflann 1.2.3's (PointSegment/utils/nearest_neighbors/nanoflann.hpp:916-1043,
 // 1321-1343) re-stated for an explicit work stack and the id scheme of kdtree.h.
