@@ -155,6 +155,13 @@ int ps_pyramid_build(ps_context* ctx, const float* xyz0, int64_t B, int64_t n0, 
 int ps_grid_subsample(ps_context* ctx, const float* points, int64_t n, const float* features, int64_t fdim,
                       const int32_t* classes, int64_t ldim, float sampleDl, int64_t* M, float* out_points,
                       float* out_features, int32_t* out_classes);
+/* The same on DEVICE memory, in one call (every pointer but M is a device pointer; inputs are read in place, the outputs are written by
+ * the reduction kernel itself): `capacity` = rows the output buffers hold (n always suffices); *M = the sub-cloud's size (host word,
+ * valid on return: the call synchronises twice, for the bounding box and for M, like the host form).  Lets the dataset preparation of
+ * dataPrepareBraTS.py:75-116 run volume -> cloud -> grid -> 1-NN projection without leaving HBM (point-unet_amd/prepare.py). */
+int ps_grid_subsample_dev(ps_context* ctx, const float* points, int64_t n, const float* features, int64_t fdim,
+                          const int32_t* classes, int64_t ldim, float sampleDl, int64_t capacity, int64_t* M,
+                          float* out_points, float* out_features, int32_t* out_classes);
 
 /* ---- volume -> point cloud ------------------------------------------------------------------------------ */
 /* First half of the reference's dataset preparation (PointSegment/utils/dataPrepareBraTS.py:33-49 itensity_normalize_one_volume,
@@ -165,6 +172,10 @@ int ps_grid_subsample(ps_context* ctx, const float* points, int64_t n, const flo
  * the row capacity in *n and returns the count.  Host pointers only. */
 int ps_volume_to_cloud(ps_context* ctx, const float* volumes, const int32_t* seg, int64_t X, int64_t Y, int64_t Z, int64_t* n,
                        float* xyz, float* colors, int32_t* labels, int32_t* xyz_origin);
+/* The same on DEVICE memory, in one call: volumes / seg and the four outputs are device pointers (xyz and colors required), *n holds the
+ * row capacity of the outputs on entry (X*Y*Z always suffices) and the number of points on return (host word; one synchronisation). */
+int ps_volume_to_cloud_dev(ps_context* ctx, const float* volumes, const int32_t* seg, int64_t X, int64_t Y, int64_t Z, int64_t* n,
+                           float* xyz, float* colors, int32_t* labels, int32_t* xyz_origin);
 
 /* ---- RandLA-Net forward ------------------------------------------------------------------------------- */
 typedef struct {

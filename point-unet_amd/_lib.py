@@ -103,6 +103,9 @@ PROTOTYPES = {
     "ps_op_bn_train_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int] + [c_vp] * 5),
     "ps_op_bn_train_bwd": (ctypes.c_int, [c_vp] * 7 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int] + [c_vp] * 3),
     "ps_volume_to_cloud": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [ctypes.POINTER(ctypes.c_int64)] + [c_vp] * 4),
+    "ps_volume_to_cloud_dev": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 3 + [ctypes.POINTER(ctypes.c_int64)] + [c_vp] * 4),
+    "ps_grid_subsample_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, ctypes.c_int64, c_vp, ctypes.c_int64, ctypes.c_float, ctypes.c_int64,
+                                             c_i64p, c_vp, c_vp, c_vp]),
     "ps_op_half_to_float": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp]),
     "ps_op_bn_train_sums": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, c_vp]),
     "ps_op_bn_train_apply": (ctypes.c_int, [c_vp] * 5 + [ctypes.c_int64] * 3 + [ctypes.c_float, ctypes.c_int] + [c_vp] * 4),

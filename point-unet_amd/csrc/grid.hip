@@ -133,8 +133,11 @@ __global__ __launch_bounds__(128) void cell_reduce_kernel(const float* __restric
 
 using namespace ps;
 
-extern "C" int ps_grid_subsample(ps_context* c, const float* points, int64_t n, const float* features, int64_t fdim, const int32_t* classes,
-                                 int64_t ldim, float sampleDl, int64_t* M_out, float* out_points, float* out_features, int32_t* out_classes)
+// dev: every pointer but M_out is DEVICE memory (inputs read in place, outputs written by the reduction kernel itself: no staging copy);
+// capacity: rows the output buffers hold (dev only; the host form sizes its buffers from the count call)
+static int grid_subsample_impl(ps_context* c, const float* points, int64_t n, const float* features, int64_t fdim, const int32_t* classes,
+                               int64_t ldim, float sampleDl, int64_t* M_out, float* out_points, float* out_features, int32_t* out_classes,
+                               bool dev, int64_t capacity)
 {
     PS_CHECK(c && points && M_out, "ps_grid_subsample: NULL argument");
     PS_CHECK(n >= 1 && n < (1ll << 32), "ps_grid_subsample: n out of range");
@@ -155,9 +158,9 @@ extern "C" int ps_grid_subsample(ps_context* c, const float* points, int64_t n, 
     unsigned *tmp1 = nullptr, *tmp2 = nullptr;
     for (int pass = 0; pass < 2; ++pass) {
         A.begin(pass == 0);
-        d_pts = A.take<float>(3 * (size_t)n);
-        d_feat = A.take<float>((size_t)n * fdim + 1);
-        d_cls = A.take<int32_t>((size_t)n * ldim + 1);
+        d_pts = A.take<float>(dev ? 1 : 3 * (size_t)n);
+        d_feat = A.take<float>(dev ? 1 : (size_t)n * fdim + 1);
+        d_cls = A.take<int32_t>(dev ? 1 : (size_t)n * ldim + 1);
         k0 = A.take<unsigned long long>(n);
         k1 = A.take<unsigned long long>(n);
         v0 = A.take<unsigned>(n);
@@ -168,15 +171,24 @@ extern "C" int ps_grid_subsample(ps_context* c, const float* points, int64_t n, 
         mm = A.take<unsigned>(8);
         tmp1 = A.take<unsigned>(sort_words);
         tmp2 = A.take<unsigned>(scan_words);
-        o_pts = A.take<float>(3 * (size_t)n);
-        o_feat = A.take<float>((size_t)n * fdim + 1);
-        o_cls = A.take<int32_t>((size_t)n * ldim + 1);
+        o_pts = A.take<float>(dev ? 1 : 3 * (size_t)n);
+        o_feat = A.take<float>(dev ? 1 : (size_t)n * fdim + 1);
+        o_cls = A.take<int32_t>(dev ? 1 : (size_t)n * ldim + 1);
         if (pass == 0) PS_TRY(A.buf.reserve(A.off));
     }
     Stage stg(c, "grid_subsample", 8);
-    PS_HIP(hipMemcpyAsync(d_pts, points, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
-    if (fdim) PS_HIP(hipMemcpyAsync(d_feat, features, sizeof(float) * (size_t)n * fdim, hipMemcpyHostToDevice, st));
-    if (ldim) PS_HIP(hipMemcpyAsync(d_cls, classes, sizeof(int32_t) * (size_t)n * ldim, hipMemcpyHostToDevice, st));
+    if (dev) {
+        d_pts = const_cast<float*>(points);
+        d_feat = const_cast<float*>(features);
+        d_cls = const_cast<int32_t*>(classes);
+        o_pts = out_points;
+        o_feat = out_features;
+        o_cls = out_classes;
+    } else {
+        PS_HIP(hipMemcpyAsync(d_pts, points, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+        if (fdim) PS_HIP(hipMemcpyAsync(d_feat, features, sizeof(float) * (size_t)n * fdim, hipMemcpyHostToDevice, st));
+        if (ldim) PS_HIP(hipMemcpyAsync(d_cls, classes, sizeof(int32_t) * (size_t)n * ldim, hipMemcpyHostToDevice, st));
+    }
     const unsigned init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
     PS_HIP(hipMemcpyAsync(mm, init, sizeof init, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(minmax_kernel, dim3(std::min(ceil_div(n, 256), 1024)), dim3(256), 0, st, d_pts, (size_t)n, mm);
@@ -229,12 +241,28 @@ extern "C" int ps_grid_subsample(ps_context* c, const float* points, int64_t n, 
     const unsigned M = last_cell + last_flag;
     *M_out = M;
     if (!out_points) return PS_OK;
+    if (dev) PS_CHECK((int64_t)M <= capacity, "ps_grid_subsample_dev: the output buffers hold %lld rows, the sub-cloud has %u", (long long)capacity, M);
     hipLaunchKernelGGL(cell_reduce_kernel, dim3(ceil_div(M, 128)), dim3(128), 0, st, d_pts, d_feat, d_cls, v1, start, M, (size_t)n, (int)fdim,
                        (int)ldim, o_pts, (fdim && out_features) ? o_feat : nullptr, (ldim && out_classes) ? o_cls : nullptr);
     PS_HIP(hipGetLastError());
+    if (dev) return PS_OK;  // (stream-ordered: the caller's next kernel on this stream reads the rows)
     PS_HIP(hipMemcpyAsync(out_points, o_pts, sizeof(float) * 3 * (size_t)M, hipMemcpyDeviceToHost, st));
     if (fdim && out_features) PS_HIP(hipMemcpyAsync(out_features, o_feat, sizeof(float) * (size_t)M * fdim, hipMemcpyDeviceToHost, st));
     if (ldim && out_classes) PS_HIP(hipMemcpyAsync(out_classes, o_cls, sizeof(int32_t) * (size_t)M * ldim, hipMemcpyDeviceToHost, st));
     PS_HIP(hipStreamSynchronize(st));
     return PS_OK;
+}
+
+extern "C" int ps_grid_subsample(ps_context* c, const float* points, int64_t n, const float* features, int64_t fdim, const int32_t* classes,
+                                 int64_t ldim, float sampleDl, int64_t* M_out, float* out_points, float* out_features, int32_t* out_classes)
+{
+    return grid_subsample_impl(c, points, n, features, fdim, classes, ldim, sampleDl, M_out, out_points, out_features, out_classes, false, 0);
+}
+
+extern "C" int ps_grid_subsample_dev(ps_context* c, const float* points, int64_t n, const float* features, int64_t fdim, const int32_t* classes,
+                                     int64_t ldim, float sampleDl, int64_t capacity, int64_t* M_out, float* out_points, float* out_features,
+                                     int32_t* out_classes)
+{
+    PS_CHECK(out_points && capacity >= 1, "ps_grid_subsample_dev: out_points is NULL or capacity < 1 (one call: size the buffers for n rows, or for a known bound)");
+    return grid_subsample_impl(c, points, n, features, fdim, classes, ldim, sampleDl, M_out, out_points, out_features, out_classes, true, capacity);
 }

@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void vol_scatter_kernel(const float* __restric
 
 using namespace ps;
 
-extern "C" int ps_volume_to_cloud(ps_context* c, const float* volumes, const int32_t* seg, int64_t X, int64_t Y, int64_t Z, int64_t* n_out,
-                                  float* xyz, float* colors, int32_t* labels, int32_t* xyz_origin)
+// dev: every pointer but n_out is DEVICE memory -- the volumes are read in place and the compaction kernel writes the caller's buffers
+static int volume_to_cloud_impl(ps_context* c, const float* volumes, const int32_t* seg, int64_t X, int64_t Y, int64_t Z, int64_t* n_out,
+                                float* xyz, float* colors, int32_t* labels, int32_t* xyz_origin, bool dev)
 {
     PS_CHECK(c && volumes && n_out, "ps_volume_to_cloud: NULL argument");
     PS_CHECK(X >= 1 && Y >= 1 && Z >= 1 && X * Y * Z < (1ll << 31), "ps_volume_to_cloud: bad volume shape");
@@ -114,21 +115,27 @@ extern "C" int ps_volume_to_cloud(ps_context* c, const float* volumes, const int
     const bool fill = xyz != nullptr;
     for (int pass = 0; pass < 2; ++pass) {
         A.begin(pass == 0);
-        d_vol = A.take<float>(4 * nvox);
-        d_seg = A.take<int32_t>(seg ? nvox : 1);
+        d_vol = A.take<float>(dev ? 1 : 4 * nvox);
+        d_seg = A.take<int32_t>(seg && !dev ? nvox : 1);
         flag = A.take<unsigned>(nvox + 1);
         pos = A.take<unsigned>(nvox + 1);
         stats = A.take<VolStats>(1);
         tmp = A.take<unsigned>(scan_words);
-        d_xyz = A.take<float>(fill ? 3 * nvox : 1);
-        d_col = A.take<float>(fill ? 4 * nvox : 1);
-        d_lab = A.take<int32_t>(fill ? nvox : 1);
-        d_org = A.take<int32_t>(fill ? 3 * nvox : 1);
+        d_xyz = A.take<float>(fill && !dev ? 3 * nvox : 1);
+        d_col = A.take<float>(fill && !dev ? 4 * nvox : 1);
+        d_lab = A.take<int32_t>(fill && !dev ? nvox : 1);
+        d_org = A.take<int32_t>(fill && !dev ? 3 * nvox : 1);
         if (pass == 0) PS_TRY(A.buf.reserve(A.off));
     }
     Stage stg(c, "volume_to_cloud", 6);
-    PS_HIP(hipMemcpyAsync(d_vol, volumes, sizeof(float) * 4 * nvox, hipMemcpyHostToDevice, st));
-    if (seg) PS_HIP(hipMemcpyAsync(d_seg, seg, sizeof(int32_t) * nvox, hipMemcpyHostToDevice, st));
+    if (dev) {
+        d_vol = const_cast<float*>(volumes);
+        d_seg = const_cast<int32_t*>(seg);
+        d_xyz = xyz; d_col = colors; d_lab = labels; d_org = xyz_origin;
+    } else {
+        PS_HIP(hipMemcpyAsync(d_vol, volumes, sizeof(float) * 4 * nvox, hipMemcpyHostToDevice, st));
+        if (seg) PS_HIP(hipMemcpyAsync(d_seg, seg, sizeof(int32_t) * nvox, hipMemcpyHostToDevice, st));
+    }
     PS_HIP(hipMemsetAsync(stats, 0, sizeof(VolStats), st));
     const dim3 grid((unsigned)std::min<size_t>(ceil_div(nvox, 256), 1024), 4);
     hipLaunchKernelGGL(vol_sum_kernel, grid, dim3(256), 0, st, d_vol, nvox, stats);
@@ -154,10 +161,24 @@ extern "C" int ps_volume_to_cloud(ps_context* c, const float* volumes, const int
     hipLaunchKernelGGL(vol_scatter_kernel, dim3(grid.x), dim3(256), 0, st, d_vol, seg ? d_seg : nullptr, nvox, (int)X, (int)Y, (int)Z, stats, flag, pos,
                        d_xyz, d_col, labels ? d_lab : nullptr, xyz_origin ? d_org : nullptr);
     PS_HIP(hipGetLastError());
+    if (dev) return PS_OK;  // (stream-ordered: the caller's next kernel on this stream reads the rows)
     PS_HIP(hipMemcpyAsync(xyz, d_xyz, sizeof(float) * 3 * n_pts, hipMemcpyDeviceToHost, st));
     PS_HIP(hipMemcpyAsync(colors, d_col, sizeof(float) * 4 * n_pts, hipMemcpyDeviceToHost, st));
     if (labels) PS_HIP(hipMemcpyAsync(labels, d_lab, sizeof(int32_t) * n_pts, hipMemcpyDeviceToHost, st));
     if (xyz_origin) PS_HIP(hipMemcpyAsync(xyz_origin, d_org, sizeof(int32_t) * 3 * n_pts, hipMemcpyDeviceToHost, st));
     PS_HIP(hipStreamSynchronize(st));
     return PS_OK;
+}
+
+extern "C" int ps_volume_to_cloud(ps_context* c, const float* volumes, const int32_t* seg, int64_t X, int64_t Y, int64_t Z, int64_t* n_out,
+                                  float* xyz, float* colors, int32_t* labels, int32_t* xyz_origin)
+{
+    return volume_to_cloud_impl(c, volumes, seg, X, Y, Z, n_out, xyz, colors, labels, xyz_origin, false);
+}
+
+extern "C" int ps_volume_to_cloud_dev(ps_context* c, const float* volumes, const int32_t* seg, int64_t X, int64_t Y, int64_t Z, int64_t* n_out,
+                                      float* xyz, float* colors, int32_t* labels, int32_t* xyz_origin)
+{
+    PS_CHECK(xyz && colors, "ps_volume_to_cloud_dev: xyz and colors are required (one call: *n holds the row capacity of the buffers, X*Y*Z at most)");
+    return volume_to_cloud_impl(c, volumes, seg, X, Y, Z, n_out, xyz, colors, labels, xyz_origin, true);
 }

@@ -151,3 +151,38 @@ def test_volume_to_cloud_against_the_reference_functions():
     # count-only call, missing-modality error
     with pytest.raises(Exception, match="no voxel above zero"):
         volume_to_cloud(np.zeros((4, 4, 4, 4), np.float32))
+
+
+def test_chained_preparation_on_the_device_equals_the_three_hop_form():
+    """prepare_brats_volume(chained=True) -- ps_volume_to_cloud_dev -> ps_grid_subsample_dev -> ps_knn_batch on device pointers: the volume goes
+    up once and the rows stay in HBM between the ops, as dataPrepareBraTS.py:75-116 is ONE pipeline on the host -- against the three
+    host-pointer entry points (three PCIe round trips): every array bit for bit, on the golden volume of make_golden.py (which the
+    test above holds against the reference's own functions) and on a synthetic BraTS-sized case (240 x 240 x 155 voxels, an ellipsoid
+    of ~1.2 M non-zero voxels: the order of magnitude of dataPrepareBraTS.py:78).  Prints both timings."""
+    import os
+    import time
+    from point_unet_amd.prepare import prepare_brats_volume
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "volume_to_cloud.npz"))
+    cases = [("golden", g["raw"], g["seg"], float(g["sub_grid_size"]))]
+    rng = np.random.default_rng(7)
+    X, Y, Z = 240, 240, 155
+    ii, jj, kk = np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing="ij")
+    inside = ((ii - 120) / 70.0) ** 2 + ((jj - 120) / 85.0) ** 2 + ((kk - 77) / 60.0) ** 2 <= 1.0
+    raw = np.zeros((4, X, Y, Z), np.float32)
+    for m in range(4):
+        raw[m][inside] = (200.0 + 50.0 * m + 40.0 * rng.standard_normal(int(inside.sum()))).clip(1.0, None).astype(np.float32)
+    seg = np.zeros((X, Y, Z), np.int32)
+    seg[inside] = rng.integers(0, 5, int(inside.sum()))
+    cases.append(("240x240x155", raw, seg, 0.01))
+    for name, vol, sg, grid in cases:
+        out = {}
+        for chained in (False, True):
+            prepare_brats_volume(vol, sg, sub_grid_size=grid, chained=chained)  # (warm-up: workspaces, pinned staging)
+            t0 = time.perf_counter()
+            out[chained] = prepare_brats_volume(vol, sg, sub_grid_size=grid, chained=chained)
+            out[chained]["seconds"] = time.perf_counter() - t0
+        a, b = out[True], out[False]
+        for k in ("xyz", "colors", "labels", "xyz_origin", "sub_xyz", "sub_colors", "sub_labels", "proj_idx"):
+            assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), (name, k)
+        print("%s: %d points -> %d sub-cloud points; chained on the device %.3f s, three host-pointer hops %.3f s" % (
+            name, len(a["xyz"]), len(a["sub_xyz"]), a["seconds"], b["seconds"]))
