@@ -311,15 +311,15 @@ def train_roofline(cfg, n0, B, ms, bf16):
            "algorithmic_flops_per_step": step_flops, "algorithmic_bytes_per_step": step_bytes,
            "mfma_frac": round(tfs / peak, 5), "hbm_frac": round(gbs / HBM_PEAK_GBS, 5)}
     # HBM bytes of one step from the committed rocprofv3 --pmc passes of `bench.py --mode train` (profiles/regen_r4.sh), labelled with their source
-    pmc = os.path.join(ROOT, "profiles", "r4_pmc_traffic_train.json")
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", "r%d_pmc_traffic_train.json" % k) for k in (5, 4)) if os.path.exists(q)), "")
     key = "b%d_%s" % (B, "bf16" if bf16 else "f32")
-    if os.path.exists(pmc):
+    if pmc:
         t = json.load(open(pmc))
         if key in t:
             out["traffic"] = t[key]["bytes_per_step"]
             out["traffic_over_algorithmic"] = round(t[key]["bytes_per_step"] / step_bytes, 3)
-            out["traffic_source"] = "profiles/r4_pmc_traffic_train.json: rocprofv3 --pmc passes of `%s` at commit %s (not measured in this run)" % (
-                t[key].get("command", "?"), t.get("_commit", "?"))
+            out["traffic_source"] = "profiles/%s: rocprofv3 --pmc passes of `%s` at commit %s (not measured in this run)" % (
+                os.path.basename(pmc), t[key].get("command", "?"), t.get("_commit", "?"))
     return out
 
 
@@ -476,6 +476,51 @@ def sub_config5(local_rank, lanes, reuse, steps=40, warmup=8, n_clouds=4):
     del pipe, clouds
     torch.cuda.empty_cache()
     return out
+
+
+def sub_train_ranks(cfg, n0, rank, local_rank, world, dist, local_bn, steps=8, warmup=2):
+    """BASELINE configs[3] inside the default line of an N > 1 run (every rank calls this): one 180 000-point cloud per GPU, pyramid + forward +
+    backward + ONE all-reduce of the flat gradient buffer + Adam through ps_randla_train_step, BatchNorm statistics shared by all ranks
+    (two small all-reduces per BatchNorm layer) or kept per GPU (local_bn: the reference's own batch-1 semantics, helper_tool.py:29).
+    Timed like the headline: barrier + device sync on both sides, MAX over ranks; one more profiled step gives the collective counts."""
+    import torch
+    from point_unet_amd import runtime, weights
+    from point_unet_amd.pyramid import alloc_pyramid, build_pyramid
+    from point_unet_amd.train import Trainer
+    xyz = np.stack([brats_cloud(n0, 1000 * rank + 5)])
+    rng = np.random.default_rng(7 + rank)
+    feats = np.concatenate([xyz, rng.standard_normal((1, n0, cfg.in_channels - 3)).astype(np.float32)], -1)
+    labels = rng.integers(0, cfg.num_classes, (1, n0)).astype(np.int32)
+    ctx = runtime.default_context(local_rank)
+    ctx.use_torch_stream()
+    ctx.set_deferred_checks(False)
+    tr = Trainer(cfg, params=weights.init_params(cfg, seed=2), device=local_rank, ctx=ctx, keep_prob=0.5, sync_bn=not local_bn)
+    d_xyz, d_feats, d_lab = torch.from_numpy(xyz).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
+    pyr = alloc_pyramid(1, n0, cfg.sub_sampling_ratio[:cfg.num_layers], cfg.k_n, d_xyz.device)
+
+    def step():
+        build_pyramid(d_xyz, cfg, ctx=ctx, out=pyr)
+        return tr.train_step(pyr, d_feats, d_lab, dist=dist)
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(1 + warmup):  # (the first step also grows the activation pool; every rank takes the same number of steps)
+        step()
+    sync()
+    elapsed, loss = timed_region(step, steps, sync, dist)
+    tr.set_profile(True)
+    step()
+    sync()
+    coll = tr.collective_stats()
+    tr.set_profile(False)
+    finite = bool(torch.isfinite(loss).all())
+    tr.close()
+    ms = 1e3 * elapsed / steps
+    return {"ms_per_step": ms, "points_per_s": whole_job_value(world, 1, n0, steps, elapsed), "steps": steps, "warmup": warmup, "loss_finite": finite,
+            "batchnorm": "per GPU" if local_bn else "shared by all ranks", "collectives_per_step": coll["calls"], "collective_bytes_per_step": coll["bytes"],
+            "collective_ms": round(coll["device_ms"], 4), "collective_host_ms": round(coll["host_ms"], 4)}
 
 
 def bench_train(args, cfg, rank, local_rank, world, dist):
@@ -866,6 +911,19 @@ def main():
                                     "what": "attentive pooling at d_out >= 64 on the fp32 MFMA instead of bf16 MFMA over exact three-way splits "
                                             "(ps_set_att_bf16x3(ctx, 0)); both forms measure 4e-6 on the logits against the float64 restatement"}
 
+    train_ranks = None
+    if world > 1 and dist is not None and not args.no_sub_results and args.workload == "config2" and B == 1 and not args.include_pcie:
+        # BASELINE configs[3] in the same run (every rank takes part; a few seconds): the training step with one cloud per GPU, both
+        # BatchNorm forms -- the numbers an 8-GPU line is judged by next to the forward's scaling
+        t_sub = time.perf_counter()
+        if pipe is not None:
+            pipe.close()
+            pipe = None
+        torch.cuda.empty_cache()
+        train_ranks = {"sync_bn": sub_train_ranks(cfg, n0, rank, local_rank, world, dist, False),
+                       "local_bn": sub_train_ranks(cfg, n0, rank, local_rank, world, dist, True)}
+        train_ranks["seconds"] = round(time.perf_counter() - t_sub, 2)
+
     if rank == 0:
         costs = algorithmic_costs(cfg, n0, B)
         last_dec = "dec%d" % (cfg.num_layers - 1)
@@ -922,7 +980,7 @@ def main():
             # HBM bytes per launch cannot be counted from inside this process: they come from separate rocprofv3 --pmc passes of this
             # same command (profiles/run_pmc.sh; FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), committed with the commit they
             # were taken at.  The number is labelled with that source; null when no such file exists for this round.
-            pmc = next((q for q in (os.path.join(ROOT, "profiles", "r%d_pmc_traffic.json" % k) for k in (4, 3, 2)) if os.path.exists(q)), "")
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", "r%d_pmc_traffic.json" % k) for k in (5, 4, 3, 2)) if os.path.exists(q)), "")
             if pmc:
                 t = json.load(open(pmc))
                 roofline["traffic"] = t.get(dominant)
@@ -1014,6 +1072,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, xyz[:1], feats[:1], params)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        if train_ranks is not None:
+            out["train_config3"] = train_ranks
         # LAST in the line (the driver keeps the tail of it): the numbers a reader needs, compact
         r3 = lambda v: None if v is None else round(v, 3)  # noqa: E731
         tb8, tb1, c5 = out.get("train_b8") or {}, out.get("train_b1") or {}, out.get("config5") or {}
@@ -1031,6 +1091,9 @@ def main():
                          "forward": sum(s_["launches_per_step"] for s_ in stages) if stages else None},
             "cpu_pts_s": r3((out.get("cpu_baseline") or {}).get("value")),
         }
+        if train_ranks is not None:  # N > 1: configs[3], one cloud per GPU (SyncBN / per-GPU BatchNorm): ms per step, calls into the collective, their device ms
+            out["summary"]["train_config3"] = {k: [r3(v["ms_per_step"]), v["collectives_per_step"], r3(v["collective_ms"])]
+                                               for k, v in train_ranks.items() if isinstance(v, dict)}
         print(json.dumps(out))
     if dist:
         dist.barrier()

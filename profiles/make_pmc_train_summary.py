@@ -6,8 +6,8 @@ prescribes) of `bench.py --mode train ...` (profiles/run_pmc_train.sh).
 
 A step = the dispatches between two consecutive Adam kernels (the LAST complete step of the run is taken).  Units / corrections
 (MI355X_MICROARCH.md, section HBM): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide
-coalesced stream, so the read side is doubled; WRITE_SIZE is taken as is.  Writes profiles/r4_pmc_traffic_train.json (what bench.py reads
-for train_*.roofline.traffic) and profiles/r4_pmc_train_per_kernel_<key>.json (per kernel: launches and bytes of that step)."""
+coalesced stream, so the read side is doubled; WRITE_SIZE is taken as is.  Writes profiles/<round>_pmc_traffic_train.json (what bench.py reads
+for train_*.roofline.traffic) and profiles/<round>_pmc_train_per_kernel_<key>.json (per kernel: launches and bytes of that step)."""
 import collections
 import csv
 import json
@@ -15,6 +15,7 @@ import os
 import sys
 
 here = os.path.dirname(os.path.abspath(__file__))
+ROUND = os.environ.get("PS_PROFILE_ROUND", "r5")  # file-name prefix of the round the passes belong to
 
 
 def last_step(d):
@@ -32,7 +33,7 @@ def last_step(d):
 
 
 args = sys.argv[1:]
-out_path = os.path.join(here, "r4_pmc_traffic_train.json")
+out_path = os.path.join(here, "%s_pmc_traffic_train.json" % ROUND)
 out = json.load(open(out_path)) if os.path.exists(out_path) else {}
 while len(args) >= 5:
     key, fdir, wdir, commit, command = args[:5]
@@ -44,7 +45,7 @@ while len(args) >= 5:
         rows.append(dict(kernel=k, launches=f.get(k, w.get(k))[0], fetch_bytes=fb, write_bytes=wb, bytes=fb + wb))
     rows.sort(key=lambda r: -r["bytes"])
     total = sum(r["bytes"] for r in rows)
-    json.dump(rows, open(os.path.join(here, "r4_pmc_train_per_kernel_%s.json" % key), "w"), indent=1)
+    json.dump(rows, open(os.path.join(here, "%s_pmc_train_per_kernel_%s.json" % (ROUND, key)), "w"), indent=1)
     out[key] = dict(bytes_per_step=total, fetch_bytes_per_step=sum(r["fetch_bytes"] for r in rows), write_bytes_per_step=sum(r["write_bytes"] for r in rows),
                     launches_per_step=sum(r["launches"] for r in rows), command=command,
                     top_kernels=[dict(kernel=r["kernel"][:100], launches=r["launches"], gbytes=round(r["bytes"] / 1e9, 3)) for r in rows[:8]])
