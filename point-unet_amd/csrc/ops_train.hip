@@ -272,6 +272,128 @@ __global__ void bn_finish_stats_kernel(const float* __restrict__ sum, const floa
     invstd[c] = rsqrtf(v + eps);
 }
 
+// ---- BatchNorm of a SMALL tensor in one launch -------------------------------------------------------------------------------------------
+// The deep levels and the decoder of a one-cloud step see a few hundred to ~11 000 rows: statistics + finish + apply were three launches
+// (backward: three more) of a few microseconds each, i.e. the launch floor six times per layer.  Here a workgroup owns FOUR channels --
+// 16 bytes of every row -- and ALL rows: it sums them (fixed order: per-thread strided partials, then a tree over the 1 024 threads),
+// finishes the statistics (and the moving-statistics update of the reference's extra_update_ops, RandLANet.py:90,163) and applies them in a
+// second pass over rows that are still in L2 -- no hand-over between workgroups, hence no second launch.  R <= kBnSliceRows, C % 4 == 0.
+constexpr int64_t kBnSliceRows = 4096;  // (11 250 rows measured SLOWER than three launches: 9.74 against 8.65 ms per one-cloud step)
+constexpr int kBnSliceThreads = 1024;
+
+__device__ __forceinline__ void bn_slice_reduce(float (&a)[4], float (&b)[4], float (*red)[8])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[threadIdx.x][j] = a[j]; red[threadIdx.x][4 + j] = b[j]; }
+    __syncthreads();
+    for (int o = kBnSliceThreads / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[threadIdx.x][j] += red[threadIdx.x + o][j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = red[0][j]; b[j] = red[0][4 + j]; }
+}
+
+__global__ __launch_bounds__(kBnSliceThreads) void bn_slice_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, int R,
+                                                           int C, float eps, int leaky, float* __restrict__ y, int64_t ldy, float* __restrict__ mean,
+                                                           float* __restrict__ invstd, float* __restrict__ var, float* __restrict__ sums,
+                                                           float* __restrict__ mov_mean, float* __restrict__ mov_var, float momentum)
+{
+    __shared__ float red[kBnSliceThreads][8];
+    const int c0 = 4 * blockIdx.x;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = threadIdx.x; r < R; r += kBnSliceThreads) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+    }
+    bn_slice_reduce(s, q, red);
+    float m[4], is[4], ga[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        m[j] = s[j] / (float)R;
+        float v = q[j] / (float)R - m[j] * m[j];  // population variance (tf.nn.moments)
+        v = v < 0.f ? 0.f : v;
+        is[j] = rsqrtf(v + eps);
+        ga[j] = gamma[c0 + j];
+        be[j] = beta[c0 + j];
+        if (threadIdx.x == 0) {
+            mean[c0 + j] = m[j];
+            var[c0 + j] = v;
+            invstd[c0 + j] = is[j];
+            if (sums) { sums[c0 + j] = s[j]; sums[C + c0 + j] = q[j]; }
+            if (mov_mean) {
+                mov_mean[c0 + j] = mov_mean[c0 + j] * momentum + m[j] * (1.f - momentum);
+                mov_var[c0 + j] = mov_var[c0 + j] * momentum + v * (1.f - momentum);
+            }
+        }
+    }
+    for (int r = threadIdx.x; r < R; r += kBnSliceThreads) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0);
+        float z[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            z[j] = ga[j] * ((z[j] - m[j]) * is[j]) + be[j];
+            if (leaky && z[j] < 0.f) z[j] *= 0.2f;
+        }
+        *reinterpret_cast<float4*>(y + (size_t)r * ldy + c0) = float4{z[0], z[1], z[2], z[3]};
+    }
+}
+
+__global__ __launch_bounds__(kBnSliceThreads) void bn_slice_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           int R, int C, int leaky, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    __shared__ float red[kBnSliceThreads][8];
+    const int c0 = 4 * blockIdx.x;
+    float m[4], is[4], ga[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { m[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j]; }
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sgx[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = threadIdx.x; r < R; r += kBnSliceThreads) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0), gv = *reinterpret_cast<const float4*>(dy + (size_t)r * lddy + c0);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        float g[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (xs[j] - m[j]) * is[j];
+            if (leaky && ga[j] * xh + be[j] < 0.f) g[j] *= 0.2f;
+            sg[j] += g[j];
+            sgx[j] += g[j] * xh;
+        }
+    }
+    bn_slice_reduce(sg, sgx, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dbeta[c0 + j] = sg[j]; dgamma[c0 + j] = sgx[j]; }
+    }
+    const float invR = 1.0f / (float)R;
+    for (int r = threadIdx.x; r < R; r += kBnSliceThreads) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0), gv = *reinterpret_cast<const float4*>(dy + (size_t)r * lddy + c0);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        float g[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (xs[j] - m[j]) * is[j];
+            if (leaky && ga[j] * xh + be[j] < 0.f) g[j] *= 0.2f;
+            g[j] = ga[j] * is[j] * (g[j] - sg[j] * invR - xh * sgx[j] * invR);
+        }
+        *reinterpret_cast<float4*>(dx + (size_t)r * C + c0) = float4{g[0], g[1], g[2], g[3]};
+    }
+}
+
+static bool bn_slice_ok(int64_t R, int64_t C, const void* x, const void* y, int64_t ldy)
+{
+    // OFF by default: measured on MI355X the one-cloud step makes 39 launches fewer with it (644 -> 605) and takes the same time
+    // (8.56 against 8.61 ms; with 11 250-row layers included 9.74) -- the step's small kernels already run back to back, a launch less is
+    // not time less.  PS_BN_SLICE=1 switches it on for A/B.
+    static const bool on = [] { const char* e = getenv("PS_BN_SLICE"); return e ? atoi(e) != 0 : false; }();
+    return on && R <= kBnSliceRows && C % 4 == 0 && ldy % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+}
+
 // Elementwise BatchNorm kernels.  VEC: float4 per thread with a grid stride that is a multiple of C (1024 % C == 0), so a
 // thread's four channels never change and their parameters are loaded once.
 template <bool VEC>
@@ -993,6 +1115,13 @@ int ps_op_bn_train_fwd_ex(ps_context* c, const float* x, const float* gamma, con
     PS_CHECK(c && x && gamma && beta && y && mean && invstd && var && scratch2C, "ps_op_bn_train_fwd: NULL argument");
     PS_CHECK(R >= 1 && C >= 1 && ldy >= C, "ps_op_bn_train_fwd: empty tensor");
     PS_HIP(hipSetDevice(c->device));
+    if (bn_slice_ok(R, C, x, y, ldy)) {
+        Stage st1(c, "train_bn_fwd", 1);
+        hipLaunchKernelGGL(bn_slice_fwd_kernel, dim3((unsigned)(C / 4)), dim3(kBnSliceThreads), 0, c->stream, x, gamma, beta, (int)R, (int)C, eps, leaky, y, ldy, mean, invstd,
+                           var, scratch2C, static_cast<float*>(nullptr), static_cast<float*>(nullptr), 0.f);
+        PS_HIP(hipGetLastError());
+        return PS_OK;
+    }
     Stage st(c, "train_bn_fwd", 3);
     PS_TRY(colreduce2(c, SumSq{x}, R, (int)C, scratch2C, scratch2C + C));
     hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, c->stream, scratch2C, scratch2C + C, R, (int)C, eps, mean, invstd, var);
@@ -1012,6 +1141,13 @@ int ps_op_bn_train_fwd_mov(ps_context* c, const float* x, const float* gamma, co
     PS_CHECK(c && x && gamma && beta && y && mean && invstd && var && scratch2C && moving_mean && moving_var, "ps_op_bn_train_fwd_mov: NULL argument");
     PS_CHECK(R >= 1 && C >= 1 && ldy >= C, "ps_op_bn_train_fwd_mov: empty tensor");
     PS_HIP(hipSetDevice(c->device));
+    if (bn_slice_ok(R, C, x, y, ldy)) {
+        Stage st1(c, "train_bn_fwd", 1);
+        hipLaunchKernelGGL(bn_slice_fwd_kernel, dim3((unsigned)(C / 4)), dim3(kBnSliceThreads), 0, c->stream, x, gamma, beta, (int)R, (int)C, eps, leaky, y, ldy, mean, invstd,
+                           var, scratch2C, moving_mean, moving_var, momentum);
+        PS_HIP(hipGetLastError());
+        return PS_OK;
+    }
     Stage st(c, "train_bn_fwd", 3);
     const BnFinish bn = {mean, invstd, var, moving_mean, moving_var, (float)R, eps, momentum};
     PS_TRY(colreduce2(c, SumSq{x}, R, (int)C, scratch2C, scratch2C + C, &bn));
@@ -1037,6 +1173,13 @@ int ps_op_bn_train_bwd_ex(ps_context* c, const float* dy, int64_t lddy, const fl
     PS_CHECK(c && dy && x && gamma && beta && mean && invstd && dx && dgamma && dbeta, "ps_op_bn_train_bwd: NULL argument");
     PS_CHECK(lddy >= C, "ps_op_bn_train_bwd: row stride of dy below the channel count");
     PS_HIP(hipSetDevice(c->device));
+    if (R >= 1 && bn_slice_ok(R, C, x, dy, lddy) && (reinterpret_cast<uintptr_t>(dx) & 15) == 0) {
+        Stage st1(c, "train_bn_bwd", 1);
+        hipLaunchKernelGGL(bn_slice_bwd_kernel, dim3((unsigned)(C / 4)), dim3(kBnSliceThreads), 0, c->stream, dy, lddy, x, gamma, beta, mean, invstd, (int)R, (int)C, leaky, dx,
+                           dgamma, dbeta);
+        PS_HIP(hipGetLastError());
+        return PS_OK;
+    }
     Stage st(c, "train_bn_bwd", 2);
     // dbeta = sum g, dgamma = sum g*xhat
     PS_TRY(colreduce2(c, BnBwdSums{dy, x, gamma, beta, mean, invstd, leaky, (int)C, lddy}, R, (int)C, dbeta, dgamma));
