@@ -113,6 +113,22 @@ int ps_op_att_pool_gemm_fwd(ps_context* ctx, const float* fset, int64_t ld, cons
                             float* agg);
 int ps_op_att_pool_gemm_bwd(ps_context* ctx, const float* fset, int64_t ld, const float* wfc, const float* dagg, int64_t R,
                             int64_t K, int64_t d, float* dfset, int64_t lddf, int accumulate, float* dscores, int64_t ldds);
+/* ... and with gather_neighbour and the concat folded in (RandLANet.py:326-333: fset[b,n,k,:] = [ fl[b, idx[b,n,k], :] | fr[b,n,k,:] ], never
+ * materialised; d = 128 / 256): fl [B*n_src, d/2] (row stride ldl), idx i32[B, n_q, K] cloud-local rows of fl, fr [B*n_q*K, d/2] (ldr).  bwd: the
+ * gathered half's gradient leaves as plain rows dfl_rows [B*n_q*K, d/2] (ld_rows; follow with ps_op_gather_reduce_rows over the inverse
+ * index of idx), the fr half goes to dfr (lddr; accumulate != 0: added), dscores [B*n_q*K, d] as above; the weight gradient over the split
+ * source is ps_op_linear_wgrad_split (>= 16 384 rows, d a multiple of 128: the split-bf16 weight-gradient kernel with the row gather in
+ * its loader). */
+int ps_op_att_pool_gemm_fwd_split(ps_context* ctx, const float* fl, int64_t ldl, const int32_t* idx, int64_t B, int64_t n_src,
+                                  int64_t n_q, const float* fr, int64_t ldr, const float* wfc, int64_t K, int64_t d, float* agg);
+int ps_op_att_pool_gemm_bwd_split(ps_context* ctx, const float* fl, int64_t ldl, const int32_t* idx, int64_t B, int64_t n_src,
+                                  int64_t n_q, const float* fr, int64_t ldr, const float* wfc, const float* dagg, int64_t K, int64_t d,
+                                  float* dfl_rows, int64_t ld_rows, float* dfr, int64_t lddr, int accumulate, float* dscores,
+                                  int64_t ldds);
+/* dW [cin, cout] = X^T . dy for X = [xl[xidx] | xr] (cin = twice the width of each half), rows = B * n_q * K */
+int ps_op_linear_wgrad_split(ps_context* ctx, const float* xl, int64_t ldxl, const int32_t* xidx, int64_t B, int64_t n_src, int64_t n_q,
+                             int64_t K, const float* xr, int64_t ldxr, const float* dy, int64_t lddy, int64_t cin, int64_t cout,
+                             float* dW);
 /* The same with gather_neighbour and the concat folded in (RandLANet.py:326-333: fset = concat(gather_neighbour(f, neigh_idx), f_xyz)):
  * fset[b, n, k, :] = [ fl[b, idx[b,n,k], :] | fr[b, n, k, :] ] is never materialised.  fl [B*n_src, d/2] (row stride ldl), idx [B, n_q, K]
  * cloud-local, fr [B*n_q*K, d/2] (row stride ldr).  The backward writes dfr (row stride lddr, overwritten), ADDS the gathered half's

@@ -120,6 +120,12 @@ PROTOTYPES = {
     "ps_op_att_pool_gemm_supported": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64]),
     "ps_op_att_pool_gemm_fwd": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp] + [ctypes.c_int64] * 3 + [c_vp]),
     "ps_op_att_pool_gemm_bwd": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp, ctypes.c_int64, ctypes.c_int, c_vp, ctypes.c_int64]),
+    "ps_op_att_pool_gemm_fwd_split": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, ctypes.c_int64, c_vp,
+                                                     ctypes.c_int64, ctypes.c_int64, c_vp]),
+    "ps_op_att_pool_gemm_bwd_split": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, ctypes.c_int64, c_vp, c_vp,
+                                                     ctypes.c_int64, ctypes.c_int64, c_vp, ctypes.c_int64, c_vp, ctypes.c_int64, ctypes.c_int, c_vp, ctypes.c_int64]),
+    "ps_op_linear_wgrad_split": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, ctypes.c_int64,
+                                                c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp]),
     "ps_op_att_pool_train_fwd": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp] + [ctypes.c_int64] * 3 + [c_vp]),
     "ps_op_att_pool_train_bwd": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp] + [ctypes.c_int64] * 3 + [c_vp, ctypes.c_int64, c_vp]),
     "ps_op_conv_bn_train_supported": (ctypes.c_int, [ctypes.c_int64]),

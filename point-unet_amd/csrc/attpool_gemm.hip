@@ -42,6 +42,12 @@ struct AttGArgs {
     float* ds; int ldds;       // [rows, D] (backward)
     int64_t rows, points;
     int df_accum;              // df += instead of df =
+    // split-source form (gather_neighbour + concat folded in, RandLANet.py:326-333): F = [fl[idx] | f] -- `f` / `df` then hold only the
+    // right half ([rows, D/2]); the gathered half's gradient leaves as plain rows dfl_rows [rows, D/2] for the gather-reduction
+    const float* fl; int ldl;  // [B * n_src, D/2]
+    const int32_t* idx;        // [points, 16] cloud-local source rows
+    int64_t n_src, n_q;        // rows per cloud of fl / points per cloud
+    float* dfl_rows; int ld_rows;
 };
 
 __device__ __forceinline__ float attg_swap_max(float v)
@@ -157,11 +163,35 @@ __device__ __forceinline__ AttGRows attg_rows(const AttGArgs& a, int wave)
 // value rows of (tile column col, point pi) in accumulator order: element j = row 16 pi + 4 hl + (j & 3) + 8 (j >> 2) of the wave
 #define PS_ATTG_VALUES(fv_, pi_)                                                                                      \
     do {                                                                                                              \
-        const float* vb_ = fb + ((pi_) ? rw.second * a.ld : 0);                                                       \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) (fv_)[j] = vb_[voff + (unsigned)(((j & 3) + 8 * (j >> 2)) * a.ld)]; \
+        if (SPLIT && col < D / 2) { /* gathered half: the rows' sources (vidx, loaded once per kernel), column col of each */ \
+            const float* vb_ = flc[(pi_)] + col;                                                                      \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) (fv_)[j] = vb_[(unsigned)vidx[(pi_)][j] * (unsigned)a.ldl]; \
+        } else {                                                                                                      \
+            const float* vb_ = fb + ((pi_) ? rw.second * a.ld : 0) - (SPLIT ? D / 2 : 0);                             \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) (fv_)[j] = vb_[voff + (unsigned)(((j & 3) + 8 * (j >> 2)) * a.ld)]; \
+        }                                                                                                             \
     } while (0)
 
-template <int D, int P>
+// split-source form: the operand row of the lane (its gathered source row for the left half of K, its own row of `f` for the right half),
+// and the sources of the value rows in accumulator order (two int4 per point, once per kernel)
+#define PS_ATTG_SPLIT_SETUP()                                                                                         \
+    const float* pL = nullptr;                                                                                        \
+    const float* flc[2] = {nullptr, nullptr};                                                                         \
+    int vidx[2][8] = {};                                                                                              \
+    if constexpr (SPLIT) {                                                                                            \
+        const int64_t row = rw.rbase + (c32 < 16 ? c32 : c32 - 16 + rw.second);                                       \
+        pL = a.fl + (size_t)(((row >> 4) / a.n_q) * a.n_src + a.idx[row]) * a.ldl + 8 * hl;                           \
+        _Pragma("unroll") for (int pi = 0; pi < 2; ++pi)                                                              \
+        {                                                                                                             \
+            const int64_t rb = rw.rbase + (pi ? rw.second : 0);                                                       \
+            flc[pi] = a.fl + (size_t)(((rb >> 4) / a.n_q) * a.n_src) * a.ldl;                                         \
+            const int4 g0 = *reinterpret_cast<const int4*>(a.idx + rb + 4 * hl), g1 = *reinterpret_cast<const int4*>(a.idx + rb + 8 + 4 * hl); \
+            vidx[pi][0] = g0.x; vidx[pi][1] = g0.y; vidx[pi][2] = g0.z; vidx[pi][3] = g0.w;                           \
+            vidx[pi][4] = g1.x; vidx[pi][5] = g1.y; vidx[pi][6] = g1.z; vidx[pi][7] = g1.w;                           \
+        }                                                                                                             \
+    }
+
+template <int D, int P, bool SPLIT>
 __global__ __launch_bounds__(256) void attg_fwd_kernel(AttGArgs a)
 {
     using S = AttGStream<D, P, false>;
@@ -173,9 +203,16 @@ __global__ __launch_bounds__(256) void attg_fwd_kernel(AttGArgs a)
     const unsigned xoff = (unsigned)((c32 < 16 ? c32 : c32 - 16 + rw.second) * a.ld + 8 * hl);
     uint4 breg0, breg1, breg2, breg3, breg4, breg5;
     float4 areg[4];
+    PS_ATTG_SPLIT_SETUP();
     auto load_a_half = [&](int s, int u) {
-        areg[2 * u] = *reinterpret_cast<const float4*>(fb + (xoff + (unsigned)(32 * s + 16 * u)));
-        areg[2 * u + 1] = *reinterpret_cast<const float4*>(fb + (xoff + (unsigned)(32 * s + 16 * u + 4)));
+        if (SPLIT && 32 * s < D / 2) {  // (a K step lies in one half: D/2 is a multiple of 32)
+            areg[2 * u] = *reinterpret_cast<const float4*>(pL + (32 * s + 16 * u));
+            areg[2 * u + 1] = *reinterpret_cast<const float4*>(pL + (32 * s + 16 * u + 4));
+        } else {
+            const unsigned k = (unsigned)(32 * s + 16 * u - (SPLIT ? D / 2 : 0));
+            areg[2 * u] = *reinterpret_cast<const float4*>(fb + (xoff + k));
+            areg[2 * u + 1] = *reinterpret_cast<const float4*>(fb + (xoff + k + 4));
+        }
     };
     PS_ATTG_LOAD_B(0);
     PS_ATTG_STORE_B(0);
@@ -220,7 +257,7 @@ __global__ __launch_bounds__(256) void attg_fwd_kernel(AttGArgs a)
 
 // (d = 128: 64 + 64 accumulators leave room for two waves per SIMD -- asked for, the P = 1 form otherwise hoists its way past 256 registers;
 //  d = 256 holds 64 + 128 accumulators: one wave per SIMD, the accumulators of dF in the second half of the register file)
-template <int D, int P>
+template <int D, int P, bool SPLIT>
 __global__ __launch_bounds__(256, D == 128 ? 2 : 1) void attg_bwd_kernel(AttGArgs a)
 {
     using S = AttGStream<D, P, true>;
@@ -233,9 +270,16 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 1) void attg_bwd_kernel(AttGArg
     const unsigned xoff = (unsigned)((c32 < 16 ? c32 : c32 - 16 + rw.second) * a.ld + 8 * hl);
     uint4 breg0, breg1, breg2, breg3, breg4, breg5;
     float4 areg[4];
+    PS_ATTG_SPLIT_SETUP();
     auto load_a_half = [&](int s, int u) {
-        areg[2 * u] = *reinterpret_cast<const float4*>(fb + (xoff + (unsigned)(32 * s + 16 * u)));
-        areg[2 * u + 1] = *reinterpret_cast<const float4*>(fb + (xoff + (unsigned)(32 * s + 16 * u + 4)));
+        if (SPLIT && 32 * s < D / 2) {  // (a K step lies in one half: D/2 is a multiple of 32)
+            areg[2 * u] = *reinterpret_cast<const float4*>(pL + (32 * s + 16 * u));
+            areg[2 * u + 1] = *reinterpret_cast<const float4*>(pL + (32 * s + 16 * u + 4));
+        } else {
+            const unsigned k = (unsigned)(32 * s + 16 * u - (SPLIT ? D / 2 : 0));
+            areg[2 * u] = *reinterpret_cast<const float4*>(fb + (xoff + k));
+            areg[2 * u + 1] = *reinterpret_cast<const float4*>(fb + (xoff + k + 4));
+        }
     };
     // identity operand of the transposing product: k-slot (chunk kap, lane half hl, element j) of an accumulator tile is its row
     // 16 kap + 8 (j >> 2) + 4 hl + (j & 3); lane (n = c32, hl) of chunk kap holds 1.0 in the slot whose row is n (one lane half has it)
@@ -350,26 +394,31 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 1) void attg_bwd_kernel(AttGArg
         }
     }
     // ---- dF: register r of tile it = row (r & 3) + 8 (r >> 2) + 4 hl of the wave, column 32 it + c32 ----
-    float* dfb = a.df + (size_t)rw.rbase * a.lddf;  // wave-uniform
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
-        const unsigned doff = (unsigned)(4 * hl * a.lddf + 32 * it + c32);
+        // split form: the gathered half (tiles below D/2) leaves as plain rows for the gather-reduction, the right half goes to df
+        const bool left = SPLIT && 32 * it < D / 2;
+        float* dfb = left ? a.dfl_rows + (size_t)rw.rbase * a.ld_rows : a.df + (size_t)rw.rbase * a.lddf;  // wave-uniform
+        const int pitch = left ? a.ld_rows : a.lddf;
+        const bool accum = !left && a.df_accum != 0;
+        const unsigned doff = (unsigned)(4 * hl * pitch + 32 * it + c32 - (SPLIT && !left ? D / 2 : 0));
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (16 * half < rw.nvalid) {  // (wave-uniform: registers 8 half .. are the rows of point `half`)
                 float old[8];
-                if (a.df_accum) {  // (the reads of a tile in flight before its first store)
+                if (accum) {  // (the reads of a tile in flight before its first store)
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) old[q] = dfb[doff + (unsigned)((16 * half + (q & 3) + 8 * (q >> 2)) * a.lddf)];
+                    for (int q = 0; q < 8; ++q) old[q] = dfb[doff + (unsigned)((16 * half + (q & 3) + 8 * (q >> 2)) * pitch)];
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    dfb[doff + (unsigned)((16 * half + (q & 3) + 8 * (q >> 2)) * a.lddf)] = a.df_accum ? acc2[it][8 * half + q] + old[q] : acc2[it][8 * half + q];
+                    dfb[doff + (unsigned)((16 * half + (q & 3) + 8 * (q >> 2)) * pitch)] = accum ? acc2[it][8 * half + q] + old[q] : acc2[it][8 * half + q];
             }
         }
     }
 }
 #undef PS_ATTG_VALUES
+#undef PS_ATTG_SPLIT_SETUP
 #undef PS_ATTG_SCORES
 #undef PS_ATTG_LOAD_B
 #undef PS_ATTG_STORE_B
@@ -402,19 +451,25 @@ static int attg_planes(ps_context* c, const float* w, int64_t d, bool transposed
     return PS_OK;
 }
 
-template <int D, bool BWD>
-static int launch_attg(ps_context* c, const AttGArgs& a)
+template <int D, bool BWD, bool SPLIT>
+static int launch_attg_s(ps_context* c, const AttGArgs& a)
 {
     const unsigned blocks = (unsigned)((a.rows + 127) / 128);
     if constexpr (!BWD) {
-        if (c->train_bf16) hipLaunchKernelGGL((attg_fwd_kernel<D, 1>), dim3(blocks), dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL((attg_fwd_kernel<D, 3>), dim3(blocks), dim3(256), 0, c->stream, a);
+        if (c->train_bf16) hipLaunchKernelGGL((attg_fwd_kernel<D, 1, SPLIT>), dim3(blocks), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((attg_fwd_kernel<D, 3, SPLIT>), dim3(blocks), dim3(256), 0, c->stream, a);
     } else {
-        if (c->train_bf16) hipLaunchKernelGGL((attg_bwd_kernel<D, 1>), dim3(blocks), dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL((attg_bwd_kernel<D, 3>), dim3(blocks), dim3(256), 0, c->stream, a);
+        if (c->train_bf16) hipLaunchKernelGGL((attg_bwd_kernel<D, 1, SPLIT>), dim3(blocks), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((attg_bwd_kernel<D, 3, SPLIT>), dim3(blocks), dim3(256), 0, c->stream, a);
     }
     PS_HIP(hipGetLastError());
     return PS_OK;
+}
+template <int D, bool BWD>
+static int launch_attg(ps_context* c, const AttGArgs& a)
+{
+    if constexpr (D == 512) return launch_attg_s<D, BWD, false>(c, a);  // (forward only, materialised form only)
+    else return a.fl ? launch_attg_s<D, BWD, true>(c, a) : launch_attg_s<D, BWD, false>(c, a);
 }
 
 // ---- d = 64 (encoder level 1) -----------------------------------------------------------------------------------------------------------
@@ -772,4 +827,48 @@ extern "C" int ps_op_att_pool_gemm_bwd(ps_context* c, const float* fset, int64_t
         case 128: return launch_attg<128, true>(c, a);
         default: return launch_attg<256, true>(c, a);
     }
+}
+
+/* split-source forms: F = [fl[idx] | fr] is never materialised (include/pointseg_train_ops.h) */
+static bool attg_split_ok(const float* fl, int64_t ldl, const int32_t* idx, int64_t B, int64_t n_src, int64_t n_q, const float* fr, int64_t ldr, int64_t K, int64_t d)
+{
+    return K == 16 && (d == 128 || d == 256) && fl && idx && fr && ldl % 4 == 0 && ldr % 4 == 0 && ldl >= d / 2 && ldr >= d / 2 &&
+           ((reinterpret_cast<uintptr_t>(fl) | reinterpret_cast<uintptr_t>(fr) | reinterpret_cast<uintptr_t>(idx)) & 15) == 0 && B >= 0 && n_src > 0 && n_q > 0 &&
+           n_src * ldl < (1ll << 31) && B * n_q * K < (1ll << 31);
+}
+
+extern "C" int ps_op_att_pool_gemm_fwd_split(ps_context* c, const float* fl, int64_t ldl, const int32_t* idx, int64_t B, int64_t n_src, int64_t n_q,
+                                             const float* fr, int64_t ldr, const float* wfc, int64_t K, int64_t d, float* agg)
+{
+    PS_CHECK(c && wfc && agg && attg_split_ok(fl, ldl, idx, B, n_src, n_q, fr, ldr, K, d),
+             "ps_op_att_pool_gemm_fwd_split: K = 16, d in {128, 256}, rows and the index table 16-byte aligned (got K %lld, d %lld)", (long long)K, (long long)d);
+    const int64_t R = B * n_q;
+    if (R <= 0) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "train_att_gemm_fwd", 2);
+    AttGArgs a = {};
+    a.f = fr; a.ld = (int)ldr; a.fl = fl; a.ldl = (int)ldl; a.idx = idx; a.n_src = n_src; a.n_q = n_q;
+    a.agg = agg; a.rows = R * K; a.points = R;
+    PS_TRY(attg_planes(c, wfc, d, false, &a.w1));
+    return d == 128 ? launch_attg<128, false>(c, a) : launch_attg<256, false>(c, a);
+}
+
+extern "C" int ps_op_att_pool_gemm_bwd_split(ps_context* c, const float* fl, int64_t ldl, const int32_t* idx, int64_t B, int64_t n_src, int64_t n_q,
+                                             const float* fr, int64_t ldr, const float* wfc, const float* dagg, int64_t K, int64_t d, float* dfl_rows,
+                                             int64_t ld_rows, float* dfr, int64_t lddr, int accumulate, float* dscores, int64_t ldds)
+{
+    PS_CHECK(c && wfc && dagg && dfl_rows && dfr && dscores && attg_split_ok(fl, ldl, idx, B, n_src, n_q, fr, ldr, K, d) && ld_rows >= d / 2 && lddr >= d / 2 &&
+                 attg_ok(K, d, dscores, ldds),
+             "ps_op_att_pool_gemm_bwd_split: K = 16, d in {128, 256}, rows and the index table 16-byte aligned (got K %lld, d %lld)", (long long)K, (long long)d);
+    const int64_t R = B * n_q;
+    if (R <= 0) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "train_att_gemm_bwd", 3);
+    AttGArgs a = {};
+    a.f = fr; a.ld = (int)ldr; a.fl = fl; a.ldl = (int)ldl; a.idx = idx; a.n_src = n_src; a.n_q = n_q;
+    a.dagg = dagg; a.df = dfr; a.lddf = (int)lddr; a.df_accum = accumulate ? 1 : 0; a.dfl_rows = dfl_rows; a.ld_rows = (int)ld_rows;
+    a.ds = dscores; a.ldds = (int)ldds; a.rows = R * K; a.points = R;
+    PS_TRY(attg_planes(c, wfc, d, false, &a.w1));
+    PS_TRY(attg_planes(c, wfc, d, true, &a.w2));
+    return d == 128 ? launch_attg<128, true>(c, a) : launch_attg<256, true>(c, a);
 }

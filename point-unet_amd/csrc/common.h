@@ -227,5 +227,11 @@ bool wgrad_b3_fits(int64_t R, int64_t cin, int64_t cout, const float* x, int64_t
 int64_t wgrad_b3_slabs(int64_t R, int64_t cin, int64_t cout);
 int wgrad_b3_partial(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout, float* part,
                      float* dbpart);
+int64_t wgrad_split_slabs(ps_context* c, const float* xl, int64_t ldxl, const int32_t* xidx, const float* xr, int64_t ldxr, const float* dy, int64_t lddy,
+                          int64_t R, int64_t cin, int64_t cout);  // 0: the split-source weight gradient does not apply to these operands
+bool wgrad_b3_split_fits(int64_t R, int64_t cin, int64_t cout, const float* xl, int64_t ldxl, const int32_t* xidx, const float* xr, int64_t ldxr, const float* dy,
+                         int64_t lddy);
+int wgrad_b3_partial_split(ps_context* c, const float* xl, int64_t ldxl, const int32_t* xidx, int64_t n_src, int64_t rows_per_cloud, const float* xr, int64_t ldxr,
+                           const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout, float* part);
 int wgrad_finish(ps_context* c, const WgradJob* d_jobs, int n_jobs, int64_t max_elems);
 }  // namespace ps

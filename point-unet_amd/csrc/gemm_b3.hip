@@ -203,6 +203,12 @@ struct WgradB3Args {
     int cin, cout;
     float* part;    // [slabs][cin][cout]
     float* dbpart;  // [slabs][cout] or nullptr
+    // split-source X (the neighbour set of att_pooling without its concat buffer, RandLANet.py:326-333): columns [0, xh) of row r are
+    // xl[(cloud(r) * n_src + xidx[r]) * ldxl + column], columns [xh, cin) are x[r * ldx + column - xh]; xidx == nullptr: X is x
+    const float* xl; int ldxl;
+    const int32_t* xidx;
+    int64_t n_src, rows_per_cloud;
+    int xh;
 };
 
 template <int P>
@@ -218,10 +224,29 @@ __global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradB3Args a)
     const int64_t r1 = r0 + a.rows_per_slab < a.R ? r0 + a.rows_per_slab : a.R;
     // loader role of this wave
     const int op = wave >> 1, ks = wave & 1;
-    const float* src = (op == 0 ? a.x : a.dy) + (op == 0 ? c0 : n0) + 4 * c32;
-    const int ld = op == 0 ? a.ldx : a.lddy;
+    // (this thread's four columns of X lie in one half of a split source: xh is a multiple of 4)
+    const bool gathered = op == 0 && a.xidx != nullptr && c0 + 4 * c32 < a.xh;
+    const float* src = op == 0 ? (gathered ? a.xl + c0 + 4 * c32 : a.x + c0 + 4 * c32 - (a.xidx ? a.xh : 0)) : a.dy + n0 + 4 * c32;
+    const int ld = op == 0 ? (gathered ? a.ldxl : a.ldx) : a.lddy;
     float4 pre[8];
+    // gathered half: the source rows of the NEXT chunk are looked up while this chunk's rows travel (the index load and the row load it
+    // addresses were one dependent chain per chunk: 0.70 against 0.40 ms for the materialised operand at [1.44 M, 128])
+    int at[8];
+    auto load_sources = [&](int64_t rbase) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t row = rbase + 16 * ks + 8 * hl + j;
+            at[j] = row < r1 ? (int)((row / a.rows_per_cloud) * a.n_src) + a.xidx[row] : -1;
+        }
+    };
+    if (gathered) load_sources(r0);
     auto load_patch = [&](int64_t rbase) {
+        if (gathered) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pre[j] = at[j] >= 0 ? *reinterpret_cast<const float4*>(src + (size_t)at[j] * ld) : float4{0.f, 0.f, 0.f, 0.f};
+            load_sources(rbase + 32);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int64_t row = rbase + 16 * ks + 8 * hl + j;
@@ -328,12 +353,34 @@ int64_t wgrad_b3_slabs(int64_t R, int64_t cin, int64_t cout)
 int wgrad_b3_partial(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout, float* part,
                      float* dbpart)
 {
-    WgradB3Args a;
+    WgradB3Args a = {};
     a.x = x; a.ldx = (int)ldx; a.dy = dy; a.lddy = (int)lddy; a.R = R; a.cin = (int)cin; a.cout = (int)cout; a.part = part; a.dbpart = dbpart;
     int64_t slabs;
     wgrad_b3_plan(R, cin, cout, a.rows_per_slab, slabs);
     const dim3 grid((unsigned)slabs, (unsigned)(cin / 128), (unsigned)(cout / 128));
     if (c->train_bf16) hipLaunchKernelGGL(wgrad_b3_kernel<1>, grid, dim3(256), 0, c->stream, a);  // bf16-MLP mode: operands rounded, one product
+    else hipLaunchKernelGGL(wgrad_b3_kernel<3>, grid, dim3(256), 0, c->stream, a);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+// X = [xl[xidx] | xr] (split source, see WgradB3Args): the weight gradient of the fused attentive pooling of the wide levels
+bool wgrad_b3_split_fits(int64_t R, int64_t cin, int64_t cout, const float* xl, int64_t ldxl, const int32_t* xidx, const float* xr, int64_t ldxr, const float* dy,
+                         int64_t lddy)
+{
+    return wgrad_b3_fits(R, cin, cout, xr, ldxr, dy, lddy) && xl && xidx && ldxl % 4 == 0 && (reinterpret_cast<uintptr_t>(xl) & 15) == 0 && (cin / 2) % 4 == 0;
+}
+
+int wgrad_b3_partial_split(ps_context* c, const float* xl, int64_t ldxl, const int32_t* xidx, int64_t n_src, int64_t rows_per_cloud, const float* xr, int64_t ldxr,
+                           const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout, float* part)
+{
+    WgradB3Args a = {};
+    a.x = xr; a.ldx = (int)ldxr; a.dy = dy; a.lddy = (int)lddy; a.R = R; a.cin = (int)cin; a.cout = (int)cout; a.part = part; a.dbpart = nullptr;
+    a.xl = xl; a.ldxl = (int)ldxl; a.xidx = xidx; a.n_src = n_src; a.rows_per_cloud = rows_per_cloud; a.xh = (int)(cin / 2);
+    int64_t slabs;
+    wgrad_b3_plan(R, cin, cout, a.rows_per_slab, slabs);
+    const dim3 grid((unsigned)slabs, (unsigned)(cin / 128), (unsigned)(cout / 128));
+    if (c->train_bf16) hipLaunchKernelGGL(wgrad_b3_kernel<1>, grid, dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL(wgrad_b3_kernel<3>, grid, dim3(256), 0, c->stream, a);
     PS_HIP(hipGetLastError());
     return PS_OK;

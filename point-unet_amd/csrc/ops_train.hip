@@ -1023,6 +1023,15 @@ int wgrad_partial(ps_context* c, const float* x, int64_t ldx, const float* dy, i
     return PS_OK;
 }
 
+// the same for X = [xl[xidx] | xr] (the neighbour set of att_pooling without its concat buffer): split-bf16 kernel only -- the caller
+// checks wgrad_split_slabs() > 0 and takes the materialised form otherwise
+int64_t wgrad_split_slabs(ps_context* c, const float* xl, int64_t ldxl, const int32_t* xidx, const float* xr, int64_t ldxr, const float* dy, int64_t lddy,
+                          int64_t R, int64_t cin, int64_t cout)
+{
+    if (!c->train_b3 || !wgrad_b3_split_fits(R, cin, cout, xl, ldxl, xidx, xr, ldxr, dy, lddy)) return 0;
+    return wgrad_b3_slabs(R, cin, cout);
+}
+
 // dst = sum over the slabs, in slab order (fixed order: deterministic).  blockIdx.y walks a table of jobs, so every weight and bias
 // gradient of a training step is finished by ONE launch; transposed: dst is [cols][rows] (the conv2d_transpose kernels, stored [out, in])
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradJob* __restrict__ jobs)
@@ -1426,3 +1435,22 @@ int ps_op_mul(ps_context* c, const float* a, const float* b, int64_t n, float* y
 }
 
 }  // extern "C"
+
+extern "C" int ps_op_linear_wgrad_split(ps_context* c, const float* xl, int64_t ldxl, const int32_t* xidx, int64_t B, int64_t n_src, int64_t n_q, int64_t K,
+                                        const float* xr, int64_t ldxr, const float* dy, int64_t lddy, int64_t cin, int64_t cout, float* dW)
+{
+    PS_CHECK(c && xl && xidx && xr && dy && dW && B >= 0 && n_src > 0 && n_q > 0 && K > 0, "ps_op_linear_wgrad_split: NULL argument");
+    const int64_t R = B * n_q * K;
+    PS_HIP(hipSetDevice(c->device));
+    const int64_t nb = ps::wgrad_split_slabs(c, xl, ldxl, xidx, xr, ldxr, dy, lddy, R, cin, cout);
+    PS_CHECK(nb > 0, "ps_op_linear_wgrad_split: needs >= 16384 rows, cin and cout multiples of 128, 16-byte aligned rows (and ps_set_train_gemm_b3 on)");
+    const size_t wfl = (size_t)nb * cin * cout;
+    PS_TRY(c->wgrad_ws.reserve(sizeof(float) * wfl + sizeof(ps::WgradJob) + 256));
+    Stage st(c, "train_wgrad", 2);
+    PS_TRY(ps::wgrad_b3_partial_split(c, xl, ldxl, xidx, n_src, n_q * K, xr, ldxr, dy, lddy, R, cin, cout, c->wgrad_ws.as<float>()));
+    // (one job, finished on the spot: the native step batches its jobs instead)
+    const ps::WgradJob job = {c->wgrad_ws.as<float>(), dW, (int)nb, (int)cin, (int)cout, 0};
+    ps::WgradJob* dj = reinterpret_cast<ps::WgradJob*>(c->wgrad_ws.as<char>() + ((sizeof(float) * wfl + 255) & ~size_t(255)));
+    PS_TRY(c->upload_async(dj, &job, sizeof(job)));
+    return ps::wgrad_finish(c, dj, 1, cin * cout);
+}

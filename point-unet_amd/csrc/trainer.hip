@@ -446,6 +446,11 @@ struct ps_trainer {
     std::vector<Op> ops;
     std::unordered_map<int, Tn> grad_of;
     std::unordered_map<int, std::vector<std::function<void()>>> deferred;  // input-gradient GEMMs waiting for another consumer's plain store
+    // the wide levels without their concat buffers (attpool_gemm.hip, split-source forms).  Measured on MI355X, batch 8: the bf16-MLP step
+    // 35.20 -> 34.97 ms with it, the fp32 step 39.71 -> 39.97 ms (the gathering loader of the weight-gradient kernel: 0.71 against 0.40 ms
+    // per level-2 pooling, and the forward kernel drops from three to two waves per SIMD) -- on by default in the bf16-MLP mode only;
+    // PS_TRAIN_ATT_GEMM_SPLIT = 0 | 1 overrides (-1: by mode)
+    int att_split_env = getenv("PS_TRAIN_ATT_GEMM_SPLIT") ? atoi(getenv("PS_TRAIN_ATT_GEMM_SPLIT")) : -1;
     bool att_gemm_on = getenv("PS_TRAIN_ATT_GEMM") ? atoi(getenv("PS_TRAIN_ATT_GEMM")) != 0 : true;  // (A/B switch of attpool_gemm.hip, read at creation)
     ps::PackCache pack;  // the step's weight images (recorded during the first step, then packed by one launch per step: common.h)
     // inverse indices of the step's gather tables (deterministic mode): built at their first use in the backward pass, kept to its end
@@ -1114,6 +1119,59 @@ struct ps_trainer {
         return agg;
     }
 
+    // the wide-level pooling over fset = [gather(f_src, idx) | f_xyz] without the gather and the concat buffer (attpool_gemm.hip, split-source
+    // forms): the gathered half's gradient leaves as rows for the fixed-order gather-reduction, the f_xyz half is added in place, dS feeds the
+    // split-bf16 weight-gradient kernel, whose loader gathers the rows of X it needs through idx
+    bool att_gemm_split_ok(const Tn& f_src, const int32_t* idx, const Tn& f_xyz, int64_t B, int64_t M, int64_t K) const
+    {
+        const int64_t d = 2 * f_src.C, rows = B * M * K;
+        auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        return opt.fused_att && att_gemm_on && c->train_b3 && ps_op_att_pool_gemm_supported(K, d) && rows >= 16384 && rows < (1ll << 31) && d % 128 == 0 &&
+               f_src.ld % 4 == 0 && f_xyz.ld % 4 == 0 && f_xyz.C == f_src.C && al(f_src.p) && al(f_xyz.p) && al(idx) && f_src.R / B * f_src.ld < (1ll << 31);
+    }
+    Tn attpool_gemm_split(const Tn& f_src_in, const int32_t* idx, int64_t B, int64_t M, int64_t K, const Tn& f_xyz, const Tn& W, const Tn& gW)
+    {
+        const Tn f_src = f_src_in;
+        const int64_t N = f_src.R / B, h = f_src.C, d = 2 * h, RK = B * M * K;
+        Tn agg = alloc(B * M, d);
+        TK(ps_op_att_pool_gemm_fwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, K, d, agg.p));
+        record(agg, [=](const Tn& dy_in) {
+            const Tn dy = contig(dy_in);
+            auto have = grad_of.find(f_xyz.id);
+            const bool add_in_place = have != grad_of.end() && have->second.C == h && have->second.R == RK && have->second.ld % 4 == 0;
+            Tn dfx = add_in_place ? have->second : alloc(RK, h);
+            Tn rows = alloc(RK, h, false), ds = alloc(RK, d, false);
+            TK(ps_op_att_pool_gemm_bwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, dy.p, K, d, rows.p, h, dfx.p, dfx.ld, add_in_place ? 1 : 0,
+                                             ds.p, ds.ld));
+            if (opt.deterministic) {
+                const bool fresh_src = !grad_of.count(f_src.id);  // (first gradient of f_src: written, not added into zeros)
+                Tn dsrc = fresh_src ? alloc(f_src.R, f_src.C) : accum_buffer(f_src);
+                const Inv& iv = inverse(idx, B, N, M * K);
+                TK(ps_op_gather_reduce_rows(c, rows.p, h, reinterpret_cast<const int32_t*>(iv.offsets.p), reinterpret_cast<const int32_t*>(iv.src.p), B * N, h, dsrc.p,
+                                            dsrc.ld, fresh_src ? 0 : 1));
+                if (fresh_src) grad_of[f_src.id] = dsrc;
+            } else {
+                Tn dsrc = accum_buffer(f_src);
+                TK(ps_op_scatter_add_rows_ex(c, rows.p, h, idx, B, N, M * K, h, dsrc.p));
+            }
+            const int64_t nb = wgrad_split_slabs(c, f_src.p, f_src.ld, idx, f_xyz.p, f_xyz.ld, ds.p, ds.ld, RK, d, d);
+            if (nb <= 0) {
+                ps::set_error("trainer: the split-source weight gradient does not apply (rows %lld, d %lld)", (long long)RK, (long long)d);
+                throw TrainError{PS_ESTATE};
+            }
+            Tn part = alloc(nb, d * d, false);
+            {
+                Stage st(c, "train_wgrad", 1);
+                TK(wgrad_b3_partial_split(c, f_src.p, f_src.ld, idx, N, M * K, f_xyz.p, f_xyz.ld, ds.p, ds.ld, RK, d, d, part.p));
+            }
+            wjobs.push_back(WgradJob{part.p, gW.p, (int)nb, (int)d, (int)d, 0});
+            wkeep.push_back(part);
+            if (!add_in_place) accum(f_xyz, dfx);
+            run_deferred(f_xyz.id);
+        });
+        return agg;
+    }
+
     // attpool over fset = [gather(f_src, idx) | f_xyz] without the gather, the concat buffer or the scatter-add of its gradient
     Tn attpool_split(const Tn& f_src_in, const int32_t* idx, int64_t B, int64_t M, int64_t K, const Tn& f_xyz, const Tn& W, const Tn& gW)
     {
@@ -1253,10 +1311,11 @@ struct ps_trainer {
         if (bn) y = bn_act(y, lp, act, out);
         return y;
     }
-    Tn att_split(const Tn& f_src, const int32_t* idx, int64_t B, int64_t M, int64_t K, const Tn& f_xyz, const std::string& name)
+    Tn att_split(const Tn& f_src, const int32_t* idx, int64_t B, int64_t M, int64_t K, const Tn& f_xyz, const std::string& name, bool on_gemm_frame = false)
     {
         const LayerP& fc = layer(name + "fc");
-        Tn agg = attpool_split(f_src, idx, B, M, K, f_xyz, P(fc.w, fc.cin, fc.cout), G(fc.w, fc.cin, fc.cout));
+        Tn agg = on_gemm_frame ? attpool_gemm_split(f_src, idx, B, M, K, f_xyz, P(fc.w, fc.cin, fc.cout), G(fc.w, fc.cin, fc.cout))
+                               : attpool_split(f_src, idx, B, M, K, f_xyz, P(fc.w, fc.cin, fc.cout), G(fc.w, fc.cin, fc.cout));
         return conv(agg, name + "mlp");
     }
     // att_pooling with the score product in the pre-product form of the inference kernels: fset . Wfc = (f . Wfc[:h])[idx] + f_xyz . Wfc[h:]
@@ -1322,14 +1381,25 @@ struct ps_trainer {
             // directly (no concat copy forward, no split copies backward)
             const int64_t hc = f_pc.C;
             Tn f_agg2;
-            if (opt.fused_att && ps_op_att_pool_train_supported_ex(K, 2 * hc, opt.mlp_bf16 ? 1 : 0)) {
+            const bool narrow = opt.fused_att && ps_op_att_pool_train_supported_ex(K, 2 * hc, opt.mlp_bf16 ? 1 : 0);
+            bool wide_split = false;
+            Tn f_xyz_s;
+            if (!narrow && (att_split_env < 0 ? opt.mlp_bf16 != 0 : att_split_env != 0)) {
+                // the wide levels in the split-source form: decided on shapes and on the operands' alignment (pool blocks are 256-byte
+                // aligned, so the LocSE rows -- allocated below -- qualify whenever f_pc does)
+                Tn probe = f_pc;
+                probe.p = nullptr;
+                wide_split = att_gemm_split_ok(f_pc, idx, probe, B, N, K);
+                if (wide_split) f_xyz_s = locse(nullptr);
+            }
+            if (narrow || wide_split) {
                 // gather_neighbour + concat + att_pooling's core as one kernel per direction
-                Tn f_xyz = locse(nullptr);
-                Tn f_agg = att_split(f_pc, idx, B, N, K, f_xyz, n + "LFAatt_pooling_1");
+                Tn f_xyz = narrow ? locse(nullptr) : f_xyz_s;
+                Tn f_agg = att_split(f_pc, idx, B, N, K, f_xyz, n + "LFAatt_pooling_1", wide_split);
                 const LayerP& l2 = layer(n + "LFAmlp2");
                 Tn f_xyz2 = convbn_fused_ok(f_xyz, l2) ? conv_bn_fused(f_xyz, l2, true)
                                                        : conv(f_xyz, n + "LFAmlp2", true, true, nullptr, false, /*defer_dgrad: pooling 1's backward stores first*/ true);
-                f_agg2 = att_split(f_agg, idx, B, N, K, f_xyz2, n + "LFAatt_pooling_2");
+                f_agg2 = att_split(f_agg, idx, B, N, K, f_xyz2, n + "LFAatt_pooling_2", wide_split && att_gemm_split_ok(f_agg, idx, f_xyz2, B, N, K));
             } else {
                 // (d = 128: the pre-product form measured slower, HBM bound there; bf16 mode: its yardstick rounds the operands of the ONE d x d product)
                 const bool pre = !opt.mlp_bf16 && 2 * hc >= 256 && !(opt.fused_att && att_gemm_on && ps_op_att_pool_gemm_supported(K, 2 * hc));

@@ -569,6 +569,53 @@ def test_wide_level_attentive_pooling_on_the_gemm_frame(mode):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_wide_level_split_source_forms_equal_the_materialised_ones(mode):
+    """ps_op_att_pool_gemm_fwd_split / _bwd_split and ps_op_linear_wgrad_split (gather_neighbour + concat folded into the wide-level fused
+    pooling and into the loader of the split-bf16 weight-gradient kernel, RandLANet.py:326-333) against the SAME kernels fed the
+    materialised concat buffer: same products in the same order, so agg, both halves of dF, dS and dW are bit-identical; the f_xyz half
+    is also checked in its accumulate form.  Two clouds (the gathered rows are cloud-local), 650 of 700 points queried, d = 128 / 256."""
+    import ctypes
+    import torch
+    from point_unet_amd import _lib, runtime
+    L, ctx = _lib.lib(), runtime.default_context(0)
+    h = ctx.handle
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(29)
+    B, N, M, K = 2, 700, 650, 16
+    try:
+        _lib.check(L.ps_set_train_gemm_bf16(h, 1 if mode == "bf16" else 0))
+        for d in (128, 256):
+            hh = d // 2
+            fsrc = torch.randn(B * N, hh, generator=g).cuda()
+            fx = torch.randn(B * M * K, hh, generator=g).cuda()
+            idx = torch.randint(0, N, (B, M, K), generator=g, dtype=torch.int32).cuda()
+            W = (torch.randn(d, d, generator=g) / d ** 0.5).cuda()
+            dagg = torch.randn(B * M, d, generator=g).cuda()
+            cat = torch.empty(B * M * K, d).cuda()
+            _lib.check(L.ps_op_gather_neighbour_ex(h, p(fsrc), p(idx), B, N, M, K, hh, p(cat), d))
+            cat[:, hh:] = fx
+            agg0, dcat, dS0, dW0 = torch.empty(B * M, d).cuda(), torch.empty(B * M * K, d).cuda(), torch.empty(B * M * K, d).cuda(), torch.empty(d, d).cuda()
+            _lib.check(L.ps_op_att_pool_gemm_fwd(h, p(cat), d, p(W), B * M, K, d, p(agg0)))
+            _lib.check(L.ps_op_att_pool_gemm_bwd(h, p(cat), d, p(W), p(dagg), B * M, K, d, p(dcat), d, 0, p(dS0), d))
+            _lib.check(L.ps_op_linear_wgrad_ex(h, p(cat), d, p(dS0), d, B * M * K, d, d, p(dW0), None))
+            agg1, rows, dfx, dS1, dW1 = (torch.empty(B * M, d).cuda(), torch.empty(B * M * K, hh).cuda(), torch.empty(B * M * K, hh).cuda(),
+                                         torch.empty(B * M * K, d).cuda(), torch.empty(d, d).cuda())
+            _lib.check(L.ps_op_att_pool_gemm_fwd_split(h, p(fsrc), hh, p(idx), B, N, M, p(fx), hh, p(W), K, d, p(agg1)))
+            _lib.check(L.ps_op_att_pool_gemm_bwd_split(h, p(fsrc), hh, p(idx), B, N, M, p(fx), hh, p(W), p(dagg), K, d, p(rows), hh, p(dfx), hh, 0, p(dS1), d))
+            _lib.check(L.ps_op_linear_wgrad_split(h, p(fsrc), hh, p(idx), B, N, M, K, p(fx), hh, p(dS1), d, d, d, p(dW1)))
+            assert torch.equal(agg0, agg1), d
+            assert torch.equal(dcat[:, :hh].contiguous(), rows) and torch.equal(dcat[:, hh:].contiguous(), dfx) and torch.equal(dS0, dS1), d
+            assert torch.equal(dW0, dW1), d
+            seed = torch.randn(B * M * K, hh, generator=g).cuda()
+            acc = seed.clone()
+            _lib.check(L.ps_op_att_pool_gemm_bwd_split(h, p(fsrc), hh, p(idx), B, N, M, p(fx), hh, p(W), p(dagg), K, d, p(rows), hh, p(acc), hh, 1, p(dS1), d))
+            assert torch.equal(acc, seed + dfx), d
+    finally:
+        _lib.check(L.ps_set_train_gemm_bf16(h, 0))
+    torch.cuda.synchronize()
+
+
 def test_split_source_attentive_pooling_equals_gather_concat_attpool():
     """ps_op_att_pool_train_*_split (gather_neighbour + concat folded into the fused attention) against the materialised form through
     the SAME fused kernels: agg, the f_xyz half of the gradient and dWfc bit-identical (same arithmetic, fixed summation order); the
