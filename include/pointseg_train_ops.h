@@ -18,6 +18,17 @@
 extern "C" {
 #endif
 
+/* bfloat16 STORAGE of the LFA branch's [N*K, h] activation rows (BASELINE configs[2], "bf16 MLPs": what the products of that mode
+ * round their operands to anyway).  While on != 0 -- and only together with ps_set_train_gemm_bf16 -- these pointers are rows of
+ * bfloat16 (row strides in ELEMENTS, rows 16-byte aligned), everything else stays fp32:
+ *   ps_op_locse_train_apply                  out               (written rounded to nearest even)
+ *   ps_op_conv_bn_train_sums / _apply / _bwd_sums[2] / _bwd_apply[_w]      x (read), and _apply's out (written)
+ *   ps_op_att_pool_train_fwd_split / _bwd_split[_rows]                      fr (read), K = 16, d in {16, 64, 128}
+ * Gradients (dz, dfr, dx) are fp32.  The value a consumer sees is the stored one: the weighted sum of att_pooling and the 8-channel
+ * convolution, which keep fp32 arithmetic in the bf16-MLP mode, read rounded inputs.  Off by default; ps_train_options.act_bf16 turns
+ * it on inside ps_randla_train_step for the levels whose kernels take it. */
+int ps_set_train_act_bf16(ps_context* ctx, int on);
+
 /* ---- training-step ops (device pointers; dense row-major fp32 [rows, channels]) --------------------------------------
  * The reference trains with TF autodiff over the same graph with tf.layers.batch_normalization(training=True)
  * (helper_tf_util.py:167,246; RandLANet.py:115), the class-weighted softmax cross-entropy of RandLANet.py:267-274 and

@@ -14,7 +14,8 @@ bench.py):
 Dropout is not modelled (tests run with keep_prob = 1; TF's RNG stream cannot be reproduced).
 `bf16_rule(kind, cin, cout)` (kind in "fwd", "dgrad", "wgrad") selects the GEMMs whose OPERANDS are rounded to bfloat16
 (round-to-nearest-even) before an exact product -- the yardstick for BASELINE configs[2]'s "bf16 MLPs" mode, whose product
-kernels round the same operands and accumulate in fp32.
+kernels round the same operands and accumulate in fp32.  `act_rule(h)` selects the levels whose LFA rows (the LocSE output and LFA
+mlp2's, [N, K, h]) are STORED as bfloat16 in that mode (ps_train_options.act_bf16): rounded once where they are produced.
 PARITY UNPINNED for the same reason as oracle/randla_oracle.py (TensorFlow 1.11 is not installable here); the eval-mode
 forward is cross-checked against the NumPy restatement in tests/test_oracle_network.py.
 """
@@ -28,6 +29,19 @@ BN_EPS = 1e-6
 def _rb(t):
     """bfloat16 rounding (RNE) of a tensor, kept in the tensor's own dtype."""
     return t.detach().float().bfloat16().to(t.dtype) if t.dtype != torch.float32 else t.detach().bfloat16().float()
+
+
+class _StoreRounded(torch.autograd.Function):
+    """A tensor STORED as bfloat16 (ps_train_options.act_bf16): consumers see the rounded value, its gradient passes through unchanged
+    (the producer's backward is computed against the value it stored)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _rb(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy
 
 
 class _RoundedLinear(torch.autograd.Function):
@@ -49,7 +63,7 @@ class _RoundedLinear(torch.autograd.Function):
         return dx, dW, None, None, None
 
 
-def _graph(P, num_layers, xyz, neigh_idx, sub_idx, interp_idx, features, dtype, training, new_buf, bf16_rule):
+def _graph(P, num_layers, xyz, neigh_idx, sub_idx, interp_idx, features, dtype, training, new_buf, bf16_rule, act_rule=None):
     def lin(x, W):
         cin, cout = W.shape
         if bf16_rule is None:
@@ -96,8 +110,13 @@ def _graph(P, num_layers, xyz, neigh_idx, sub_idx, interp_idx, features, dtype, 
         enc10 = torch.cat([rel.pow(2).sum(-1, keepdim=True).sqrt(), rel, ctr, nb], -1)
         f_pc = conv(X, n + "mlp1")
         f_xyz = conv(enc10, n + "LFAmlp1")
+        stored16 = act_rule is not None and bool(act_rule(f_xyz.shape[-1]))  # the level's [N, K, h] rows are stored as bfloat16
+        if stored16:
+            f_xyz = _StoreRounded.apply(f_xyz)
         f_agg = att(torch.cat([gather(f_pc, idx), f_xyz], -1), n + "LFAatt_pooling_1")
         f_xyz = conv(f_xyz, n + "LFAmlp2")
+        if stored16:
+            f_xyz = _StoreRounded.apply(f_xyz)
         f_agg = att(torch.cat([gather(f_agg, idx), f_xyz], -1), n + "LFAatt_pooling_2")
         f_enc = F.leaky_relu(conv(f_agg, n + "mlp2", act=False) + conv(X, n + "shortcut", act=False), 0.2)
         f = torch.amax(gather(f_enc, sub_idx[i]), dim=2)  # ties share the gradient evenly, like tf.reduce_max
@@ -118,7 +137,7 @@ def forward(params, num_layers, xyz, neigh_idx, sub_idx, interp_idx, features, d
 
 
 def train_step(params, num_layers, xyz, neigh_idx, sub_idx, interp_idx, features, labels, class_weights, lr, step=1, dtype=torch.float64,
-               bf16_rule=None):
+               bf16_rule=None, act_rule=None):
     """One optimisation step from zero Adam moments.  Labels outside [0, classes) mark ignored points (already renumbered by the
     caller like the reference's reducing_list).  Returns dict(loss, grads{name: array}, new_params{name: array}, logits)."""
     P = {}
@@ -128,7 +147,7 @@ def train_step(params, num_layers, xyz, neigh_idx, sub_idx, interp_idx, features
             t.requires_grad_(True)
         P[k] = t
     new_buf = {}
-    logits = _graph(P, num_layers, xyz, neigh_idx, sub_idx, interp_idx, features, dtype, True, new_buf, bf16_rule)
+    logits = _graph(P, num_layers, xyz, neigh_idx, sub_idx, interp_idx, features, dtype, True, new_buf, bf16_rule, act_rule)
     z = logits.reshape(-1, logits.shape[-1])
     y = torch.as_tensor(np.asarray(labels).reshape(-1)).long()
     valid = (y >= 0) & (y < z.shape[1])

@@ -53,6 +53,7 @@ class PsTrainOptions(ctypes.Structure):
         ("deterministic", ctypes.c_int32),
         ("fused_convbn", ctypes.c_int32),
         ("overlap_wgrad", ctypes.c_int32),
+        ("act_bf16", ctypes.c_int32),
     ]
 
 
@@ -74,6 +75,7 @@ PROTOTYPES = {
     "ps_last_error": (ctypes.c_char_p, []),
     "ps_version": (ctypes.c_char_p, []),
     "ps_set_train_gemm_bf16": (ctypes.c_int, [c_vp, ctypes.c_int]),
+    "ps_set_train_act_bf16": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "ps_set_att_bf16x3": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "ps_set_train_gemm_b3": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "ps_timing_begin": (ctypes.c_int, [c_vp]),

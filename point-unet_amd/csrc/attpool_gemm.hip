@@ -29,6 +29,7 @@
 #include "b3_ops.h"
 #include "attpool_train.h"
 #include "reduce_partials.h"
+#include "bf16_io.h"
 
 namespace ps {
 
@@ -488,7 +489,8 @@ static int launch_attg(ps_context* c, const AttGArgs& a)
 //     requested ONE TILE AHEAD (the index two tiles ahead) and go to a per-wave LDS tile as they are split, which is where the softmax
 //     epilogue and the weight-gradient product read their column-wise "value rows" from (the first form read them from global memory a
 //     second time, behind the scores: 6.4 us per tile of exposed latency, 0.56 ms per forward pooling).
-template <int P, bool BWD, int WAVES>
+template <int P, bool BWD, int WAVES, bool FRB>  // FRB: the f_xyz half is stored as bfloat16 (compile-time: a run-time branch around the
+                                                 // prefetch made the compiler wait for every load in flight at the join)
 __global__ __launch_bounds__(WAVES * 64) void attg64_kernel(AttTrainArgs a, const uint4* __restrict__ w1, const uint4* __restrict__ w2, float* __restrict__ dw_part)
 {
     constexpr int NQ = 4, NT = 2, IMG = NQ * NT * P * 64;  // uint4 per weight image
@@ -553,6 +555,12 @@ __global__ __launch_bounds__(WAVES * 64) void attg64_kernel(AttTrainArgs a, cons
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
+            if (FRB && q >= 2) {  // the f_xyz half stored as bfloat16 (split form only): one 16-byte load for the lane's eight values
+                // (kept as loaded: converting here would make the wave wait for its own prefetch; expanded where the chunk is consumed)
+                const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(a.f) + ((size_t)row * a.ld + 8 * hl + 16 * (q - 2)));
+                nrow[2 * q] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+                continue;
+            }
             const float* src = q < 2 ? pL + 16 * q : pR + 16 * (q - 2);
             nrow[2 * q] = *reinterpret_cast<const float4*>(src);
             nrow[2 * q + 1] = *reinterpret_cast<const float4*>(src + 4);
@@ -586,7 +594,11 @@ __global__ __launch_bounds__(WAVES * 64) void attg64_kernel(AttTrainArgs a, cons
             }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const float4 x0 = nrow[2 * q], x1 = nrow[2 * q + 1];
+            float4 x0 = nrow[2 * q], x1 = nrow[2 * q + 1];
+            if (FRB && q >= 2) {
+                x1 = unpack_bf16x4(make_uint2(__float_as_uint(x0.z), __float_as_uint(x0.w)));
+                x0 = unpack_bf16x4(make_uint2(__float_as_uint(x0.x), __float_as_uint(x0.y)));
+            }
             *reinterpret_cast<float4*>(V + c32 * PITCH + 16 * q + 8 * hl) = x0;
             *reinterpret_cast<float4*>(V + c32 * PITCH + 16 * q + 8 * hl + 4) = x1;
             const BPlanes<P> ap = b3_split8<P>(x0, x1);
@@ -735,6 +747,7 @@ bool att64_gemm_fits(const AttTrainArgs& a, bool backward)
     if (!on) return false;
     auto al = [](const void* q, int ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0; };
     if (!al(a.f, a.ld)) return false;
+    if (a.fr_bf16 && (!a.fl || a.ld % 8 != 0 || !a.bf16)) return false;  // (bfloat16 rows: split form, 16-byte loads of eight values, bf16-MLP mode)
     if (a.fl) {
         if (!al(a.fl, a.ldl) || (reinterpret_cast<uintptr_t>(a.idx) & 15) != 0 || a.n_q <= 0) return false;
         if (backward && !a.dfl_rows) return false;  // (the float-atomic scatter form: attpool_train.hip)
@@ -742,11 +755,11 @@ bool att64_gemm_fits(const AttTrainArgs& a, bool backward)
     return a.R > 0 && a.R * 16 < (1ll << 31);
 }
 
-template <int P, bool BWD, int WAVES>
-static int launch_attg64(ps_context* c, const AttTrainArgs& a, const uint4* w1, const uint4* w2, float* dW)
+template <int P, bool BWD, int WAVES, bool FRB>
+static int launch_attg64_f(ps_context* c, const AttTrainArgs& a, const uint4* w1, const uint4* w2, float* dW)
 {
     const size_t smem = (size_t)4 * 2 * P * 64 * 16 * (BWD ? 2 : 1) + sizeof(float) * WAVES * 32 * 68;
-    auto kern = attg64_kernel<P, BWD, WAVES>;
+    auto kern = attg64_kernel<P, BWD, WAVES, FRB>;
     if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int per_cu = std::max(1, (int)(160 * 1024 / smem));
     const int64_t tiles = (a.R * 16 + 31) / 32;
@@ -760,6 +773,15 @@ static int launch_attg64(ps_context* c, const AttTrainArgs& a, const uint4* w1, 
     if (BWD) hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(ceil_div(4096, 16)), dim3(256), 0, c->stream, static_cast<const float*>(part), blocks * WAVES, 4096, dW);
     PS_HIP(hipGetLastError());
     return PS_OK;
+}
+
+template <int P, bool BWD, int WAVES>
+static int launch_attg64(ps_context* c, const AttTrainArgs& a, const uint4* w1, const uint4* w2, float* dW)
+{
+    if constexpr (P == 1) {  // (bfloat16 rows exist in the bf16-MLP mode only)
+        if (a.fr_bf16) return launch_attg64_f<P, BWD, WAVES, true>(c, a, w1, w2, dW);
+    }
+    return launch_attg64_f<P, BWD, WAVES, false>(c, a, w1, w2, dW);
 }
 
 int att64_gemm(ps_context* c, AttTrainArgs a, bool backward, float* dW)

@@ -26,6 +26,7 @@ struct AttTrainArgs {
     float* dfl_rows;     // non-null: the gathered half's gradient goes HERE as plain rows [R*K, D/2] (ld_rows) instead of being scatter-added into
     int ld_rows;         // dfl with float atomics; ps_op_gather_reduce_rows then adds the rows up in a fixed order (deterministic step)
     int df_accum;        // split form: df (the f_xyz half's gradient) is ADDED to what the rows already hold (a second gradient of the same tensor)
+    int fr_bf16;         // split form: the rows of `f` (the f_xyz half) are STORED as bfloat16 (ps_set_train_act_bf16; ld in elements)
     int vec_store;       // backward: the row outputs (df, dfl_rows) are 16-byte aligned with pitches % 4 == 0 -> staged through LDS, float4 stores
 };
 

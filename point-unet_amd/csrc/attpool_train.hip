@@ -24,6 +24,7 @@
 #include "mfma_tile.h"
 #include "reduce_partials.h"
 #include "attpool_train.h"
+#include "bf16_io.h"
 
 #include <map>
 #include <mutex>
@@ -102,9 +103,24 @@ struct TileRegs {
                     v[i] = *reinterpret_cast<const float4*>(frow + (row * (unsigned)a.ld + 4u * q));
                 else if (q < (unsigned)QH)
                     v[i] = *reinterpret_cast<const float4*>(fsrc + ((unsigned)irow[row] * (unsigned)a.ldl + 4u * q));
+                else if (a.fr_bf16) {  // (the f_xyz half stored as bfloat16: 8 bytes for the four values, kept as loaded -- expand() in front of commit)
+                    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.f) + ((size_t)w.p * KN * a.ld + (row * (unsigned)a.ld + 4u * (q - QH))));
+                    v[i] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+                }
                 else
                     v[i] = *reinterpret_cast<const float4*>(frow + (row * (unsigned)a.ld + 4u * (q - QH)));
             }
+        }
+    }
+    // bfloat16-stored right half -> fp32, where the tile is consumed (converting at fetch would make the wave wait for its own prefetch)
+    __device__ __forceinline__ void expand(const AttTrainArgs& a, int lane)
+    {
+        if (!a.fr_bf16) return;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = 64 * i + lane;
+            const unsigned q = (unsigned)e % Q;
+            if ((TOT % 64 == 0 || e < TOT) && q >= (unsigned)QH) v[i] = unpack_bf16x4(make_uint2(__float_as_uint(v[i].x), __float_as_uint(v[i].y)));
         }
     }
     // fp32 tile (pitch PA); `Ab` receives the bf16-rounded copy when non-null
@@ -226,7 +242,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_fwd_kernel(AttTrainArgs 
     if (w.p < a.R) regs.fetch(a, w, lane);
     for (; w.p < a.R; w = w.next()) {
         const int64_t p = w.p;
-        regs.template commit<PA>(A, nullptr, lane);
+        regs.expand(a, lane), regs.template commit<PA>(A, nullptr, lane);
         wave_lds_sync();
         const PointWalk wn = w.next();
         if (wn.p < a.R) regs.fetch(a, wn, lane);  // the next point's tile travels while this one is worked on
@@ -282,7 +298,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
         regs.fetch(a, w, lane);
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) gnext[ct] = a.dagg[(size_t)w.p * D + ct * 16 + c16];
-        regs.template commit<PA>(A, Ab, lane);
+        regs.expand(a, lane), regs.template commit<PA>(A, Ab, lane);
     }
     wave_lds_sync();
     for (; w.p < a.R; w = w.next()) {
@@ -381,7 +397,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
             out.take(A, lane);
             wave_lds_sync();
         }
-        if (wn.p < a.R) regs.template commit<PA>(A, Ab, lane);
+        if (wn.p < a.R) regs.expand(a, lane), regs.template commit<PA>(A, Ab, lane);
         if (a.vec_store) out.put(a, p, lane);
         wave_lds_sync();
     }
@@ -495,7 +511,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_fwd_bf16_kernel(AttTrain
     if (w.p < a.R) regs.fetch(a, w, lane);
     for (; w.p < a.R; w = w.next()) {
         const int64_t p = w.p;
-        commit_tile_bf16<D, KN>(regs, A, Xb, lane);
+        regs.expand(a, lane), commit_tile_bf16<D, KN>(regs, A, Xb, lane);
         wave_lds_sync();
         const PointWalk wn = w.next();
         if (wn.p < a.R) regs.fetch(a, wn, lane);  // the next point's tile travels while this one is worked on
@@ -550,7 +566,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
         regs.fetch(a, w, lane);
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) gnext[ct] = a.dagg[(size_t)w.p * D + ct * 16 + c16];
-        commit_tile_bf16<D, KN>(regs, A, Xb, lane);
+        regs.expand(a, lane), commit_tile_bf16<D, KN>(regs, A, Xb, lane);
     }
     wave_lds_sync();
     for (; w.p < a.R; w = w.next()) {
@@ -642,7 +658,7 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
             out.take(A, lane);
             wave_lds_sync();
         }
-        if (wn.p < a.R) commit_tile_bf16<D, KN>(regs, A, Xb, lane);
+        if (wn.p < a.R) regs.expand(a, lane), commit_tile_bf16<D, KN>(regs, A, Xb, lane);
         if (a.vec_store) out.put(a, p, lane);
         wave_lds_sync();
     }
@@ -730,6 +746,10 @@ __global__ __launch_bounds__(GROUPS * 256) void att_train_bwd_bf16_cs_kernel(Att
                 regs[i] = *reinterpret_cast<const float4*>(frow + (row * (unsigned)a.ld + 4u * q));
             else if (q < (unsigned)QH)
                 regs[i] = *reinterpret_cast<const float4*>(fsrc + ((unsigned)irow[row] * (unsigned)a.ldl + 4u * q));
+            else if (a.fr_bf16) {  // (kept as loaded; expanded in commit)
+                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.f) + ((size_t)p * KN * a.ld + (row * (unsigned)a.ld + 4u * (q - QH))));
+                regs[i] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+            }
             else
                 regs[i] = *reinterpret_cast<const float4*>(frow + (row * (unsigned)a.ld + 4u * (q - QH)));
         }
@@ -742,7 +762,7 @@ __global__ __launch_bounds__(GROUPS * 256) void att_train_bwd_bf16_cs_kernel(Att
         for (int i = 0; i < NVG; ++i) {
             const int e = 256 * i + glane;
             const int row = e / Q, q = e - row * Q;
-            const float4 v = regs[i];
+            const float4 v = a.fr_bf16 && q >= QH ? unpack_bf16x4(make_uint2(__float_as_uint(regs[i].x), __float_as_uint(regs[i].y))) : regs[i];
             float* dst = A + row * PA + 4 * q;
             dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
             uint2 pk;
@@ -1048,6 +1068,7 @@ extern "C" int ps_op_att_pool_train_fwd_split(ps_context* c, const float* fl, in
     AttTrainArgs a = {};
     a.f = fr; a.ld = (int)ldr; a.fl = fl; a.ldl = (int)ldl; a.idx = idx; a.n_src = n_src; a.n_q = n_q;
     a.w = wfc; a.agg = agg; a.R = R; a.bf16 = c->train_bf16 ? 1 : 0;
+    a.fr_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (fr as bfloat16 rows: ps_set_train_act_bf16)
     switch (d) {
         case 16: return launch_att_train<16>(c, a, false, nullptr);
         case 32: return launch_att_train<32>(c, a, false, nullptr);
@@ -1094,6 +1115,7 @@ static int att_bwd_split_impl(ps_context* c, const float* fl, int64_t ldl, const
     a.f = fr; a.ld = (int)ldr; a.fl = fl; a.ldl = (int)ldl; a.idx = idx; a.n_src = n_src; a.n_q = n_q;
     a.w = wfc; a.dagg = dagg; a.df = dfr; a.lddf = (int)lddr; a.dfl = dfl; a.lddl = (int)lddl; a.R = R; a.bf16 = c->train_bf16 ? 1 : 0;
     a.dfl_rows = dfl_rows; a.ld_rows = (int)ld_rows; a.df_accum = c->att_df_accum ? 1 : 0;
+    a.fr_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (fr as bfloat16 rows: ps_set_train_act_bf16)
     switch (d) {
         case 16: return launch_att_train<16>(c, a, true, dwfc);
         case 32: return launch_att_train<32>(c, a, true, dwfc);

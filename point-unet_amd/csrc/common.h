@@ -138,6 +138,7 @@ struct ps_context {
     bool att_df_accum = false;  // (internal, set around a call by the native trainer) ps_op_att_pool_train_bwd_split*: dfr += instead of dfr =
     bool pool_bwd_overwrite = false;  // ps_op_random_sample_bwd_inv (tie-count form) STORES the gradient instead of adding into a zeroed buffer (trainer.hip)
     bool train_bf16 = false;  // ps_set_train_gemm_bf16: the op-level GEMMs round their operands to bf16 (fp32 accumulate)
+    bool train_act_bf16 = false;  // ps_set_train_act_bf16: the [N*K, h] activation rows of the LFA branch are STORED as bfloat16 (include/pointseg_train_ops.h)
     // per-device kernel attributes already raised by this context (dynamic LDS above the default limit)
     bool mid_lds_attr = false;
     size_t chain_lds_attr = 48 * 1024;

@@ -222,6 +222,13 @@ int ps_set_train_gemm_bf16(ps_context* c, int on)
     return PS_OK;
 }
 
+int ps_set_train_act_bf16(ps_context* c, int on)
+{
+    PS_CHECK(c != nullptr, "ps_set_train_act_bf16: ctx is NULL");
+    c->train_act_bf16 = on != 0;
+    return PS_OK;
+}
+
 int ps_set_train_gemm_b3(ps_context* c, int on)
 {
     PS_CHECK(c != nullptr, "ps_set_train_gemm_b3: ctx is NULL");

@@ -14,6 +14,7 @@
 //   gradient 3, weight gradient 2).  Deterministic: fixed grid, fixed reduction order, no atomics.
 #include "common.h"
 #include "reduce_partials.h"
+#include "bf16_io.h"
 
 namespace ps {
 
@@ -32,6 +33,7 @@ struct CbArgs {
     void* part;        // per-workgroup partial sums
     int64_t R;
     int ldx, lddz, ldo, accum;
+    int x_bf16;        // x rows (and apply's out rows) are bfloat16 (ps_set_train_act_bf16)
 };
 
 // the C x C weights and the bias: uniform addresses -> scalar loads, the products take them as SGPR operands (no LDS, no VGPRs)
@@ -58,6 +60,16 @@ struct CbWeights {
     }
 };
 
+// a row of x: fp32 or (ps_set_train_act_bf16) bfloat16 -- 16 bytes for the eight channels
+template <int C, bool XB>
+__device__ __forceinline__ void cb_load_x(const CbArgs& a, int64_t r, float (&v)[C])
+{
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+        const float4 t = load4_any(a.x, (size_t)r * a.ldx + 4 * q, XB);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+}
 template <int C>
 __device__ __forceinline__ void cb_load_row(const float* __restrict__ p, int64_t ld, int64_t r, float (&v)[C])
 {
@@ -99,7 +111,7 @@ __device__ __forceinline__ void cb_block_reduce(T (&v)[NV], T* red /* [waves][NV
 }
 
 // ---- forward: statistics.  partial layout per workgroup (doubles): sy[CP] | sq[CP] | sx[CP], CP = 16 (the layout of smallconv_train.hip)
-template <int C>
+template <int C, bool XB>
 __global__ __launch_bounds__(kCbThreads) void cb_sums_kernel(CbArgs a)
 {
     constexpr int CP = 16;
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(kCbThreads) void cb_sums_kernel(CbArgs a)
     for (int i = 0; i < 3 * C; ++i) acc[i] = 0.;
     for (int64_t r = blockIdx.x * (int64_t)kCbThreads + threadIdx.x; r < a.R; r += (int64_t)gridDim.x * kCbThreads) {
         float x[C], y[C];
-        cb_load_row<C>(a.x, a.ldx, r, x);
+        cb_load_x<C, XB>(a, r, x);
         wt.product(x, y);
 #pragma unroll
         for (int j = 0; j < C; ++j) {
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(kCbThreads) void cb_sums_kernel(CbArgs a)
 }
 
 // ---- forward: normalise + LeakyReLU -> rows
-template <int C>
+template <int C, bool XB>
 __global__ __launch_bounds__(kCbThreads) void cb_apply_kernel(CbArgs a)
 {
     CbWeights<C> wt;
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(kCbThreads) void cb_apply_kernel(CbArgs a)
     const CbCols<C> mu(a.mean), sc(a.scale), be(a.beta);
     for (int64_t r = blockIdx.x * (int64_t)kCbThreads + threadIdx.x; r < a.R; r += (int64_t)gridDim.x * kCbThreads) {
         float x[C], y[C];
-        cb_load_row<C>(a.x, a.ldx, r, x);
+        cb_load_x<C, XB>(a, r, x);
         wt.product(x, y);
 #pragma unroll
         for (int j = 0; j < C; ++j) {
@@ -149,12 +161,12 @@ __global__ __launch_bounds__(kCbThreads) void cb_apply_kernel(CbArgs a)
         }
 #pragma unroll
         for (int q = 0; q < C / 4; ++q)
-            *reinterpret_cast<float4*>(a.out + r * a.ldo + 4 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+            store4_any(a.out, (size_t)r * a.ldo + 4 * q, make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]), XB);
     }
 }
 
 // ---- backward: S1 = sum g, S2 = sum g xh.  partial layout per workgroup (floats): S1[C] | S2[C]
-template <int C>
+template <int C, bool XB>
 __global__ __launch_bounds__(kCbThreads) void cb_bwd_sums_kernel(CbArgs a)
 {
     __shared__ float red[(kCbThreads / 64) * 2 * C];
@@ -166,7 +178,7 @@ __global__ __launch_bounds__(kCbThreads) void cb_bwd_sums_kernel(CbArgs a)
     for (int i = 0; i < 2 * C; ++i) acc[i] = 0.f;
     for (int64_t r = blockIdx.x * (int64_t)kCbThreads + threadIdx.x; r < a.R; r += (int64_t)gridDim.x * kCbThreads) {
         float x[C], y[C], g[C];
-        cb_load_row<C>(a.x, a.ldx, r, x);
+        cb_load_x<C, XB>(a, r, x);
         cb_load_row<C>(a.dz, a.lddz, r, g);
         wt.product(x, y);
 #pragma unroll
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(kCbThreads) void cb_bwd_sums_kernel(CbArgs a)
 }
 
 // ---- backward: input gradient rows + weight / bias gradient.  partial layout per workgroup (floats): dW[C][C] | db[C]
-template <int C>
+template <int C, bool XB>
 __global__ __launch_bounds__(kCbThreads) void cb_bwd_apply_kernel(CbArgs a)
 {
     constexpr int NV = C * C + C;
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(kCbThreads) void cb_bwd_apply_kernel(CbArgs a)
     for (int i = 0; i < NV; ++i) acc[i] = 0.f;
     for (int64_t r = blockIdx.x * (int64_t)kCbThreads + threadIdx.x; r < a.R; r += (int64_t)gridDim.x * kCbThreads) {
         float x[C], y[C], g[C];
-        cb_load_row<C>(a.x, a.ldx, r, x);
+        cb_load_x<C, XB>(a, r, x);
         cb_load_row<C>(a.dz, a.lddz, r, g);
         float old[C];
         if (a.accum) cb_load_row<C>(a.out, a.ldo, r, old);
@@ -239,11 +251,13 @@ static int cb_blocks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int6
 int convbn_rows_sums(ps_context* c, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, double* sums)
 {
     CbArgs a = {};
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R;
     const int blocks = cb_blocks(R);
     PS_TRY(c->red_ws.reserve(sizeof(double) * (size_t)blocks * 48 + 256));
     a.part = c->red_ws.as<void>();
-    hipLaunchKernelGGL(cb_sums_kernel<8>, dim3(blocks), dim3(kCbThreads), 0, c->stream, a);
+    if (a.x_bf16) hipLaunchKernelGGL((cb_sums_kernel<8, true>), dim3(blocks), dim3(kCbThreads), 0, c->stream, a);
+    else hipLaunchKernelGGL((cb_sums_kernel<8, false>), dim3(blocks), dim3(kCbThreads), 0, c->stream, a);
     hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3(3), dim3(256), 0, c->stream, static_cast<const double*>(a.part), blocks, 48, sums);
     PS_HIP(hipGetLastError());
     return PS_OK;
@@ -253,8 +267,10 @@ int convbn_rows_apply(ps_context* c, const float* x, int64_t ldx, const float* w
                       const float* beta, float* out, int64_t ldo)
 {
     CbArgs a = {};
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.scale = scale; a.beta = beta; a.out = out; a.ldo = (int)ldo;
-    hipLaunchKernelGGL(cb_apply_kernel<8>, dim3(cb_blocks(R)), dim3(kCbThreads), 0, c->stream, a);
+    if (a.x_bf16) hipLaunchKernelGGL((cb_apply_kernel<8, true>), dim3(cb_blocks(R)), dim3(kCbThreads), 0, c->stream, a);
+    else hipLaunchKernelGGL((cb_apply_kernel<8, false>), dim3(cb_blocks(R)), dim3(kCbThreads), 0, c->stream, a);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }
@@ -263,11 +279,13 @@ int convbn_rows_bwd_sums(ps_context* c, const float* x, int64_t ldx, const float
                          const float* scale, const float* beta, const float* dz, int64_t lddz, float* s12)
 {
     CbArgs a = {};
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.invstd = invstd; a.scale = scale; a.beta = beta; a.dz = dz; a.lddz = (int)lddz;
     const int blocks = cb_blocks(R);
     PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * 16 + 256));
     a.part = c->red_ws.as<void>();
-    hipLaunchKernelGGL(cb_bwd_sums_kernel<8>, dim3(blocks), dim3(kCbThreads), 0, c->stream, a);
+    if (a.x_bf16) hipLaunchKernelGGL((cb_bwd_sums_kernel<8, true>), dim3(blocks), dim3(kCbThreads), 0, c->stream, a);
+    else hipLaunchKernelGGL((cb_bwd_sums_kernel<8, false>), dim3(blocks), dim3(kCbThreads), 0, c->stream, a);
     hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(1), dim3(256), 0, c->stream, static_cast<const float*>(a.part), blocks, 16, s12);
     PS_HIP(hipGetLastError());
     return PS_OK;
@@ -278,12 +296,14 @@ int convbn_rows_bwd_apply(ps_context* c, const float* x, int64_t ldx, const floa
                           int64_t lddx, float* dw, float* db)
 {
     CbArgs a = {};
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.invstd = invstd; a.scale = scale; a.beta = beta; a.s12 = s12;
     a.inv_rows = inv_rows; a.dz = dz; a.lddz = (int)lddz; a.out = dx; a.ldo = (int)lddx; a.accum = accumulate ? 1 : 0;
     const int blocks = cb_blocks(R);
     PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * 72 + 256));
     a.part = c->red_ws.as<void>();
-    hipLaunchKernelGGL(cb_bwd_apply_kernel<8>, dim3(blocks), dim3(kCbThreads), 0, c->stream, a);
+    if (a.x_bf16) hipLaunchKernelGGL((cb_bwd_apply_kernel<8, true>), dim3(blocks), dim3(kCbThreads), 0, c->stream, a);
+    else hipLaunchKernelGGL((cb_bwd_apply_kernel<8, false>), dim3(blocks), dim3(kCbThreads), 0, c->stream, a);
     hipLaunchKernelGGL(reduce_partials2_kernel<float>, dim3(ceil_div(72, 16)), dim3(256), 0, c->stream, static_cast<const float*>(a.part), blocks, 72, 64, dw, db);
     PS_HIP(hipGetLastError());
     return PS_OK;

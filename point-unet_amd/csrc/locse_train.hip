@@ -17,6 +17,7 @@
 // fp32 VALU work (10 h FMAs per row against 16 + 4 h bytes): HBM / issue bound, no MFMA.  All sums are per-block partials merged in a
 // fixed order (deterministic).  h in {8, 16, 32, 64}.
 #include "common.h"
+#include "bf16_io.h"
 #include "reduce_partials.h"
 #include "wave_ops.h"
 
@@ -38,6 +39,7 @@ struct LocseArgs {
     float* out;          // apply: [rows, H] (ldo)
     float* part;         // per-block partial sums
     int ldo, lddz;
+    int out_bf16;        // apply: out rows are bfloat16 (ps_set_train_act_bf16)
 };
 
 // (row counts are < 2^31 and point counts < 2^24 here -- checked on the host --, so the two divisions of the row index are a shift /
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void locse_apply_kernel(LocseArgs a)
                       __builtin_fmaf(y[3] - mu.w, sc.w, sh.w)};
 #pragma unroll
         for (int j = 0; j < 4; ++j) z[j] = z[j] < 0.f ? 0.2f * z[j] : z[j];
-        *reinterpret_cast<float4*>(a.out + t * a.ldo + L.c0) = make_float4(z[0], z[1], z[2], z[3]);  // the LPR lanes of a row write it whole
+        store4_any(a.out, (size_t)t * a.ldo + L.c0, make_float4(z[0], z[1], z[2], z[3]), a.out_bf16 != 0);  // the LPR lanes of a row write it whole
     }
 }
 
@@ -357,6 +359,8 @@ extern "C" int ps_op_locse_train_apply(ps_context* c, const float* xyz, const in
     LocseArgs a = {};
     a.xyz = xyz; a.idx = idx; a.rows = B * N * K; a.n_cloud = (int)N; a.K = (int)K; a.w = w; a.b = b;
     a.scale = scale; a.shift = shift; a.mean = mean; a.out = out; a.ldo = (int)ldo;
+    a.out_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (rows of bfloat16: ldo in elements)
+    PS_CHECK(!a.out_bf16 || (ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0), "ps_op_locse_train_apply: bfloat16 rows need ldo % 4 == 0 and 8-byte alignment");
     return locse_dispatch(c, h, a, 1, nullptr);
 }
 

@@ -16,6 +16,7 @@
 //   (train.py; under SyncBN that is also where the sums of all ranks meet).
 // 8 passes instead of 14.  Sums are per-workgroup partials merged in a fixed order (deterministic).  c in {8, 16, 32, 64}.
 #include "common.h"
+#include "bf16_io.h"
 #include "reduce_partials.h"
 #include "mfma_tile.h"
 
@@ -34,6 +35,7 @@ struct ScArgs {
     int64_t R;
     int ldx, lddz, ldo, accum;
     int vec;             // dz / out rows are 16-byte aligned with pitches % 4 == 0: tiles travel as float4 through LDS
+    int x_bf16;          // x rows (and apply's out rows) are STORED as bfloat16 (ps_set_train_act_bf16): ldx / ldo in elements
     int bf16;            // bf16-MLP mode: the operands of the three products (x and w; dy and w^T; x and dy) are rounded to bfloat16 (RNE) first and
                          // multiplied on the fp32 MFMA (exact products, fp32 accumulation: the values of a bf16 MFMA with fp32 accumulate)
 };
@@ -84,6 +86,49 @@ struct ScTile {
             if (TOT % 64 == 0 || e < TOT) {
                 const int row = e / Q, q = e - row * Q;
                 if (r0 + row < R) v[i] = *reinterpret_cast<const float4*>(x + (size_t)r0 * ldx + (unsigned)(row * ldx + 4 * q));  // (wave-uniform base, 32-bit lane offset)
+            }
+        }
+    }
+    // the same from / to rows of bfloat16 (8 bytes per lane and pass; converted at the register)
+    template <bool B16>
+    __device__ __forceinline__ void fetch_any(const float* __restrict__ x, int ldx, int64_t r0, int64_t R, int lane)
+    {
+        if constexpr (!B16) return fetch(x, ldx, r0, R, lane);
+        const unsigned short* xb = reinterpret_cast<const unsigned short*>(x) + (size_t)r0 * ldx;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = 64 * i + lane;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (TOT % 64 == 0 || e < TOT) {
+                const int row = e / Q, q = e - row * Q;
+                if (r0 + row < R) {  // (the raw 8 bytes: converting here would make the wave wait for its own prefetch)
+                    const uint2 u = *reinterpret_cast<const uint2*>(xb + (unsigned)(row * ldx + 4 * q));
+                    v[i].x = __uint_as_float(u.x);
+                    v[i].y = __uint_as_float(u.y);
+                }
+            }
+        }
+    }
+    // ... expanded to fp32 where the tile is consumed (in front of commit)
+    template <bool B16>
+    __device__ __forceinline__ void expand()
+    {
+        if constexpr (B16) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] = unpack_bf16x4(make_uint2(__float_as_uint(v[i].x), __float_as_uint(v[i].y)));
+        }
+    }
+    template <bool B16>
+    __device__ __forceinline__ void put_any(float* __restrict__ out, int ldo, int64_t r0, int64_t R, int lane) const
+    {
+        if constexpr (!B16) return put(out, ldo, r0, R, lane);
+        unsigned short* ob = reinterpret_cast<unsigned short*>(out) + (size_t)r0 * ldo;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = 64 * i + lane;
+            if (TOT % 64 == 0 || e < TOT) {
+                const int row = e / Q, q = e - row * Q;
+                if (r0 + row < R) *reinterpret_cast<uint2*>(ob + (unsigned)(row * ldo + 4 * q)) = pack_bf16x4(v[i]);
             }
         }
     }
@@ -165,7 +210,8 @@ constexpr int kScWaves = 4;
 
 // ---- forward: statistics (sum y, sum y^2 in fp64; sum x in fp32) ---------------------------------------------------------------
 // partial layout per workgroup (doubles): sy[CP] | sq[CP] | sx[CP]
-template <int C>
+template <int C, bool XB>  // XB: x rows (and apply's output rows) are stored as bfloat16 -- a compile-time switch: a run-time branch around the
+                           // tile loads made the compiler drain every load in flight at the join (bwd apply 0.66 -> 0.80 ms)
 __global__ __launch_bounds__(kScWaves * 64) void sc_sums_kernel(ScArgs a)
 {
     using G = ScGeom<C>;
@@ -184,12 +230,12 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_sums_kernel(ScArgs a)
     const int64_t tiles = (a.R + 15) / 16, tstride = (int64_t)gridDim.x * kScWaves;
     int64_t tl = (int64_t)blockIdx.x * kScWaves + wave;
     ScTile<C> xr;
-    if (tl < tiles) xr.fetch(a.x, a.ldx, tl * 16, a.R, lane);
+    if (tl < tiles) xr.template fetch_any<XB>(a.x, a.ldx, tl * 16, a.R, lane);
     for (; tl < tiles; tl += tstride) {
         const int64_t r0 = tl * 16;
-        xr.commit(A, lane, a.bf16 != 0);
+        xr.template expand<XB>(), xr.commit(A, lane, a.bf16 != 0);
         wave_lds_sync();
-        if (tl + tstride < tiles) xr.fetch(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
+        if (tl + tstride < tiles) xr.template fetch_any<XB>(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
             const f32x4 y = sc_y_tile<C>(A, W, ct, lane);
@@ -230,7 +276,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_sums_kernel(ScArgs a)
 }
 
 // ---- forward: normalise + LeakyReLU -> rows --------------------------------------------------------------------------------------
-template <int C>
+template <int C, bool XB>
 __global__ __launch_bounds__(kScWaves * 64) void sc_apply_kernel(ScArgs a)
 {
     using G = ScGeom<C>;
@@ -246,14 +292,14 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_apply_kernel(ScArgs a)
     int64_t tl = (int64_t)blockIdx.x * kScWaves + wave;
     ScTile<C> xr;
     if (tl < tiles) {
-        xr.fetch(a.x, a.ldx, tl * 16, a.R, lane);
-        xr.commit(A, lane, a.bf16 != 0);
+        xr.template fetch_any<XB>(a.x, a.ldx, tl * 16, a.R, lane);
+        xr.template expand<XB>(), xr.commit(A, lane, a.bf16 != 0);
     }
     wave_lds_sync();
     for (; tl < tiles; tl += tstride) {
         const int64_t r0 = tl * 16;
         const bool more = tl + tstride < tiles;
-        if (more) xr.fetch(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
+        if (more) xr.template fetch_any<XB>(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
         f32x4 z[NT];
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
@@ -274,8 +320,8 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_apply_kernel(ScArgs a)
             ScTile<C> o;
             o.take(A, lane);
             wave_lds_sync();
-            if (more) xr.commit(A, lane, a.bf16 != 0);
-            o.put(a.out, a.ldo, r0, a.R, lane);
+            if (more) xr.template expand<XB>(), xr.commit(A, lane, a.bf16 != 0);
+            o.template put_any<XB>(a.out, a.ldo, r0, a.R, lane);
         } else {
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
@@ -285,7 +331,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_apply_kernel(ScArgs a)
                     if (col < C && r0 + 4 * g + r < a.R) a.out[(size_t)(r0 + 4 * g + r) * a.ldo + col] = z[ct][r];
             }
             wave_lds_sync();
-            if (more) xr.commit(A, lane, a.bf16 != 0);
+            if (more) xr.template expand<XB>(), xr.commit(A, lane, a.bf16 != 0);
         }
         wave_lds_sync();
     }
@@ -293,8 +339,8 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_apply_kernel(ScArgs a)
 
 // ---- backward: sums --------------------------------------------------------------------------------------------------------------
 // partial layout per workgroup (floats): S1[CP] | S2[CP] | XS[CP] | A[CP][CP] | G[CP][CP]
-// FULL = false: only S1 | S2 | XS (the weight gradient then comes out of sc_bwd_apply_kernel<C, true> as x^T dy)
-template <int C, bool FULL>
+// FULL = false: only S1 | S2 | XS (the weight gradient then comes out of sc_bwd_apply_kernel<C, true, XB> as x^T dy)
+template <int C, bool FULL, bool XB>
 __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_sums_kernel(ScArgs a)
 {
     using G = ScGeom<C>;
@@ -322,16 +368,16 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_sums_kernel(ScArgs a)
     int64_t tl = (int64_t)blockIdx.x * kScWaves + wave;
     ScTile<C> xr, zr;
     if (tl < tiles) {
-        xr.fetch(a.x, a.ldx, tl * 16, a.R, lane);
+        xr.template fetch_any<XB>(a.x, a.ldx, tl * 16, a.R, lane);
         if (a.vec) zr.fetch(a.dz, a.lddz, tl * 16, a.R, lane);
     }
     for (; tl < tiles; tl += tstride) {
         const int64_t r0 = tl * 16;
-        xr.commit(A, lane, a.bf16 != 0);
+        xr.template expand<XB>(), xr.commit(A, lane, a.bf16 != 0);
         if (a.vec) zr.commit(T1, lane);
         wave_lds_sync();
         if (tl + tstride < tiles) {
-            xr.fetch(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
+            xr.template fetch_any<XB>(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
             if (a.vec) zr.fetch(a.dz, a.lddz, (tl + tstride) * 16, a.R, lane);
         }
 #pragma unroll
@@ -407,7 +453,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_sums_kernel(ScArgs a)
 
 // ---- backward: input gradient ----------------------------------------------------------------------------------------------------
 // WG = true: also the weight / bias gradient dW = x^T dy, db = sum dy as per-workgroup partials (dW[CP][CP] | db[CP]) in a.part
-template <int C, bool WG>
+template <int C, bool WG, bool XB>
 __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
 {
     using G = ScGeom<C>;
@@ -439,10 +485,10 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
     const bool vec = a.vec != 0, acc_old = vec && a.accum;
     ScTile<C> xr, zr, old_next;
     if (tl < tiles) {
-        xr.fetch(a.x, a.ldx, tl * 16, a.R, lane);
+        xr.template fetch_any<XB>(a.x, a.ldx, tl * 16, a.R, lane);
         if (vec) zr.fetch(a.dz, a.lddz, tl * 16, a.R, lane);
         if (acc_old) old_next.fetch(a.out, a.ldo, tl * 16, a.R, lane);
-        xr.commit(A, lane, a.bf16 != 0);
+        xr.template expand<XB>(), xr.commit(A, lane, a.bf16 != 0);
         if (vec) zr.commit(T1, lane);
     }
     wave_lds_sync();
@@ -451,7 +497,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
         const bool more = tl + tstride < tiles;
         ScTile<C> old_cur = old_next;
         if (more) {
-            xr.fetch(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
+            xr.template fetch_any<XB>(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
             if (vec) zr.fetch(a.dz, a.lddz, (tl + tstride) * 16, a.R, lane);
             if (acc_old) old_next.fetch(a.out, a.ldo, (tl + tstride) * 16, a.R, lane);
         }
@@ -517,7 +563,7 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
             wave_lds_sync();
         }
         if (more) {
-            xr.commit(A, lane, a.bf16 != 0);
+            xr.template expand<XB>(), xr.commit(A, lane, a.bf16 != 0);
             if (vec) zr.commit(T1, lane);
         }
         if (vec) o.put(a.out, a.ldo, r0, a.R, lane);
@@ -553,8 +599,8 @@ static bool sc_ok(int64_t C) { return C == 8 || C == 16 || C == 32 || C == 64; }
 
 // what: 0 forward sums, 1 forward apply, 2 backward sums (S1 | S2 | XS | A | G), 3 backward apply, 4 backward sums (S1 | S2 | XS only),
 //       5 backward apply + weight / bias gradient (result = dW, result2 = db)
-template <int C>
-static int sc_launch(ps_context* c, ScArgs a, int what, void* result, void* result2 = nullptr)
+template <int C, bool XB>
+static int sc_launch_x(ps_context* c, ScArgs a, int what, void* result, void* result2)
 {
     using G = ScGeom<C>;
     constexpr int CP = G::CP, NVB = 3 * CP + 2 * CP * CP, NVW = CP * CP + CP;
@@ -570,35 +616,35 @@ static int sc_launch(ps_context* c, ScArgs a, int what, void* result, void* resu
     const int64_t tiles = (a.R + 15) / 16;
     const int per_cu = std::max(1, std::min(4, (int)(160 * 1024 / smem)));
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((tiles + kScWaves - 1) / kScWaves, 256 * per_cu));
-    const void* kern = what == 0 ? reinterpret_cast<const void*>(sc_sums_kernel<C>)
-                     : what == 1 ? reinterpret_cast<const void*>(sc_apply_kernel<C>)
-                     : what == 2 ? reinterpret_cast<const void*>(sc_bwd_sums_kernel<C, true>)
-                     : what == 3 ? reinterpret_cast<const void*>(sc_bwd_apply_kernel<C, false>)
-                     : what == 4 ? reinterpret_cast<const void*>(sc_bwd_sums_kernel<C, false>)
-                                 : reinterpret_cast<const void*>(sc_bwd_apply_kernel<C, true>);
+    const void* kern = what == 0 ? reinterpret_cast<const void*>(sc_sums_kernel<C, XB>)
+                     : what == 1 ? reinterpret_cast<const void*>(sc_apply_kernel<C, XB>)
+                     : what == 2 ? reinterpret_cast<const void*>(sc_bwd_sums_kernel<C, true, XB>)
+                     : what == 3 ? reinterpret_cast<const void*>(sc_bwd_apply_kernel<C, false, XB>)
+                     : what == 4 ? reinterpret_cast<const void*>(sc_bwd_sums_kernel<C, false, XB>)
+                                 : reinterpret_cast<const void*>(sc_bwd_apply_kernel<C, true, XB>);
     if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     if (what == 0) {
         PS_TRY(c->red_ws.reserve(sizeof(double) * (size_t)blocks * 3 * CP + 256));
         a.part = c->red_ws.as<void>();
-        hipLaunchKernelGGL(sc_sums_kernel<C>, dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
+        hipLaunchKernelGGL((sc_sums_kernel<C, XB>), dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
         hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3(ceil_div(3 * CP, 16)), dim3(256), 0, c->stream, static_cast<const double*>(a.part), blocks, 3 * CP,
                            static_cast<double*>(result));
     } else if (what == 1) {
-        hipLaunchKernelGGL(sc_apply_kernel<C>, dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
+        hipLaunchKernelGGL((sc_apply_kernel<C, XB>), dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
     } else if (what == 2 || what == 4) {
         const int nv = what == 2 ? NVB : 3 * CP;
         PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * nv + 256));
         a.part = c->red_ws.as<void>();
-        if (what == 2) hipLaunchKernelGGL((sc_bwd_sums_kernel<C, true>), dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
-        else hipLaunchKernelGGL((sc_bwd_sums_kernel<C, false>), dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
+        if (what == 2) hipLaunchKernelGGL((sc_bwd_sums_kernel<C, true, XB>), dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
+        else hipLaunchKernelGGL((sc_bwd_sums_kernel<C, false, XB>), dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
         hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(ceil_div(nv, 16)), dim3(256), 0, c->stream, static_cast<const float*>(a.part), blocks, nv,
                            static_cast<float*>(result));
     } else if (what == 3) {
-        hipLaunchKernelGGL((sc_bwd_apply_kernel<C, false>), dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
+        hipLaunchKernelGGL((sc_bwd_apply_kernel<C, false, XB>), dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
     } else {
         PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * NVW + 256));
         a.part = c->red_ws.as<void>();
-        hipLaunchKernelGGL((sc_bwd_apply_kernel<C, true>), dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
+        hipLaunchKernelGGL((sc_bwd_apply_kernel<C, true, XB>), dim3(blocks), dim3(kScWaves * 64), smem, c->stream, a);
         hipLaunchKernelGGL(reduce_partials2_kernel<float>, dim3(ceil_div(NVW, 16)), dim3(256), 0, c->stream, static_cast<const float*>(a.part), blocks, NVW,
                            CP * CP, static_cast<float*>(result), static_cast<float*>(result2));
     }
@@ -606,11 +652,18 @@ static int sc_launch(ps_context* c, ScArgs a, int what, void* result, void* resu
     return PS_OK;
 }
 
+template <int C>
+static int sc_launch(ps_context* c, const ScArgs& a, int what, void* result, void* result2 = nullptr)
+{
+    return a.x_bf16 ? sc_launch_x<C, true>(c, a, what, result, result2) : sc_launch_x<C, false>(c, a, what, result, result2);
+}
+
 static int sc_dispatch(ps_context* c, int64_t C, const ScArgs& a_in, int what, void* result, void* result2 = nullptr)
 {
     ScArgs a = a_in;
     auto al = [](const void* q, int ld) { return !q || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0); };
     a.vec = al(a.dz, a.lddz) && al(a.out, a.ldo) ? 1 : 0;
+    PS_CHECK(!a.x_bf16 || what != 1 || a.vec, "ps_op_conv_bn_train_apply: bfloat16 output rows need 16-byte alignment and ldo %% 4 == 0");
     a.bf16 = c->train_bf16 && C % 16 == 0 ? 1 : 0;  // (ps_set_train_gemm_bf16; the rule of ps_op_conv1x1_ex: an 8-channel product stays fp32)
     switch (C) {
         case 8: return sc_launch<8>(c, a, what, result, result2);
@@ -650,6 +703,7 @@ extern "C" int ps_op_conv_bn_train_sums(ps_context* c, const float* x, int64_t l
     Stage st(c, "train_convbn_fwd", 2);
     if (C == 8) return convbn_rows_sums(c, x, ldx, w, b, R, sums);
     ScArgs a = {};
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R;
     return sc_dispatch(c, C, a, 0, sums);
 }
@@ -664,6 +718,7 @@ extern "C" int ps_op_conv_bn_train_apply(ps_context* c, const float* x, int64_t 
     Stage st(c, "train_convbn_fwd", 1);
     if (C == 8 && ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) return convbn_rows_apply(c, x, ldx, w, b, R, mean, scale, beta, out, ldo);
     ScArgs a = {};
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.scale = scale; a.beta = beta; a.out = out; a.ldo = (int)ldo;
     return sc_dispatch(c, C, a, 1, nullptr);
 }
@@ -682,6 +737,7 @@ extern "C" int ps_op_conv_bn_train_bwd_sums(ps_context* c, const float* x, int64
     }
     Stage st(c, "train_convbn_bwd", 2);
     ScArgs a = {};
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.invstd = invstd; a.scale = scale; a.beta = beta; a.dz = dz; a.lddz = (int)lddz;
     return sc_dispatch(c, C, a, 2, sums);
 }
@@ -696,6 +752,7 @@ extern "C" int ps_op_conv_bn_train_bwd_apply(ps_context* c, const float* x, int6
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_convbn_bwd", 1);
     ScArgs a = {};
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.invstd = invstd; a.scale = scale; a.beta = beta; a.m1 = m1; a.m2 = m2;
     a.dz = dz; a.lddz = (int)lddz; a.out = dx; a.ldo = (int)lddx; a.accum = accumulate ? 1 : 0; a.mscale = 1.f;
     return sc_dispatch(c, C, a, 3, nullptr);
@@ -716,6 +773,7 @@ extern "C" int ps_op_conv_bn_train_bwd_sums2(ps_context* c, const float* x, int6
     if (C == 8 && sc_rows_ok(dz, lddz, C)) return convbn_rows_bwd_sums(c, x, ldx, w, b, R, mean, invstd, scale, beta, dz, lddz, s12);
     PS_CHECK(C >= 16, "ps_op_conv_bn_train_bwd_sums2: C = 8 needs 16-byte aligned dz rows");
     ScArgs a = {};
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.invstd = invstd; a.scale = scale; a.beta = beta; a.dz = dz; a.lddz = (int)lddz;
     return sc_dispatch(c, C, a, 4, s12);
 }
@@ -737,6 +795,7 @@ extern "C" int ps_op_conv_bn_train_bwd_apply_w(ps_context* c, const float* x, in
         return convbn_rows_bwd_apply(c, x, ldx, w, b, R, mean, invstd, scale, beta, s12, inv_rows, dz, lddz, accumulate, dx, lddx, dw, db);
     PS_CHECK(C >= 16, "ps_op_conv_bn_train_bwd_apply_w: C = 8 needs 16-byte aligned dz / dx rows");
     ScArgs a = {};
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.invstd = invstd; a.scale = scale; a.beta = beta; a.m1 = s12; a.m2 = s12 + C;
     a.mscale = inv_rows; a.dz = dz; a.lddz = (int)lddz; a.out = dx; a.ldo = (int)lddx; a.accum = accumulate ? 1 : 0;
     return sc_dispatch(c, C, a, 5, dw, db);

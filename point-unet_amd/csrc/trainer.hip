@@ -167,6 +167,7 @@ struct Tn {
     int64_t R = 0, C = 0, ld = 0;
     int id = -1;
     bool req = false;  // takes part in the backward pass
+    bool b16 = false;  // rows STORED as bfloat16 (ps_train_options.act_bf16): only ever handed to the ops that read them that way
     std::shared_ptr<Block> own;
     bool contiguous() const { return ld == C; }
     int64_t numel() const { return R * C; }
@@ -450,6 +451,7 @@ struct ps_trainer {
     // 35.20 -> 34.97 ms with it, the fp32 step 39.71 -> 39.97 ms (the gathering loader of the weight-gradient kernel: 0.71 against 0.40 ms
     // per level-2 pooling, and the forward kernel drops from three to two waves per SIMD) -- on by default in the bf16-MLP mode only;
     // PS_TRAIN_ATT_GEMM_SPLIT = 0 | 1 overrides (-1: by mode)
+    bool act_bf16_on = getenv("PS_TRAIN_ACT_BF16") ? atoi(getenv("PS_TRAIN_ACT_BF16")) != 0 : true;  // (A/B switch next to ps_train_options.act_bf16)
     int att_split_env = getenv("PS_TRAIN_ATT_GEMM_SPLIT") ? atoi(getenv("PS_TRAIN_ATT_GEMM_SPLIT")) : -1;
     bool att_gemm_on = getenv("PS_TRAIN_ATT_GEMM") ? atoi(getenv("PS_TRAIN_ATT_GEMM")) != 0 : true;  // (A/B switch of attpool_gemm.hip, read at creation)
     ps::PackCache pack;  // the step's weight images (recorded during the first step, then packed by one launch per step: common.h)
@@ -513,6 +515,13 @@ struct ps_trainer {
     }
 
     hipStream_t stream() const { return c->stream; }
+    // tells the storage-aware ops (ps_set_train_act_bf16) that the [N*K, h] rows of this call are bfloat16, for the lifetime of the object
+    struct ActScope {
+        ps_context* c;
+        bool was;
+        ActScope(ps_context* ctx, bool on) : c(ctx), was(ctx->train_act_bf16) { c->train_act_bf16 = on; }
+        ~ActScope() { c->train_act_bf16 = was; }
+    };
 
     // ---- tensors
     Tn alloc(int64_t R, int64_t C, bool req = true)
@@ -843,7 +852,7 @@ struct ps_trainer {
 
     // f_xyz = LeakyReLU(BN_train(relative_pos_encoding(xyz, idx) . W + b)) -> [B*N*K, h] (out: optional column block), with nothing but
     // that output in memory: statistics, output and every gradient are recomputed from xyz [B*N,3] and idx [B,N,K] (locse_train.hip)
-    Tn locse_bn_act(const float* xyz, const int32_t* idx, int64_t B, int64_t N, int64_t K, const LayerP& lp, const Tn* out = nullptr)
+    Tn locse_bn_act(const float* xyz, const int32_t* idx, int64_t B, int64_t N, int64_t K, const LayerP& lp, const Tn* out = nullptr, bool act16 = false)
     {
         const int64_t h = lp.cout, R = B * N * K;
         const bool sync = sync_bn && coll_active();
@@ -863,7 +872,11 @@ struct ps_trainer {
         }
         Tn y = out ? *out : alloc(R, h);
         y.req = true;
-        TK(ps_op_locse_train_apply(c, xyz, idx, B, N, K, W, b, h, mean, scale, beta, y.p, y.ld));
+        y.b16 = act16;
+        {
+            ActScope as(c, act16);
+            TK(ps_op_locse_train_apply(c, xyz, idx, B, N, K, W, b, h, mean, scale, beta, y.p, y.ld));
+        }
         float *gW = grads + lp.w, *gb = grads + lp.b, *ggamma = grads + lp.gamma, *gbeta = grads + lp.beta;
         record(y, [=](const Tn& dz) {
             Tn acc = alloc(1, 23 * h + 16, false);
@@ -901,7 +914,11 @@ struct ps_trainer {
         const float *W = params + lp.w, *b = params + lp.b, *gamma = params + lp.gamma, *beta = params + lp.beta;
         Tn sums = alloc(1, 6 * CP, false);  // 3 CP doubles: sum y | sum y^2 | sum x
         double* s64 = reinterpret_cast<double*>(sums.p);
-        TK(ps_op_conv_bn_train_sums(c, x.p, x.ld, W, b, R, h, s64));
+        const bool act16 = x.b16;  // (bfloat16 rows in, bfloat16 rows out)
+        {
+            ActScope as(c, act16);
+            TK(ps_op_conv_bn_train_sums(c, x.p, x.ld, W, b, R, h, s64));
+        }
         if (sync) allreduce(s64, 2 * CP, 1);
         Tn st4 = alloc(4, h, false);  // mean | var | invstd | scale
         float *mean = st4.p, *invstd = st4.p + 2 * h, *scale = st4.p + 3 * h;
@@ -913,13 +930,20 @@ struct ps_trainer {
         }
         Tn z = out ? *out : alloc(R, h);
         z.req = true;
-        TK(ps_op_conv_bn_train_apply(c, x.p, x.ld, W, b, R, h, mean, scale, beta, z.p, z.ld));
+        z.b16 = act16;
+        {
+            ActScope as(c, act16);
+            TK(ps_op_conv_bn_train_apply(c, x.p, x.ld, W, b, R, h, mean, scale, beta, z.p, z.ld));
+        }
         float *gW = grads + lp.w, *gb = grads + lp.b, *ggamma = grads + lp.gamma, *gbeta = grads + lp.beta;
         record(z, [=](const Tn& dz_in) {
             const bool dz_ok = dz_in.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(dz_in.p) & 15) == 0;
             const Tn dz = dz_ok ? dz_in : contig(dz_in);
             Tn acc = alloc(1, 3 * h, false);
-            TK(ps_op_conv_bn_train_bwd_sums2(c, x.p, x.ld, W, b, R, h, mean, invstd, scale, beta, dz.p, dz.ld, acc.p));
+            {
+                ActScope as(c, act16);
+                TK(ps_op_conv_bn_train_bwd_sums2(c, x.p, x.ld, W, b, R, h, mean, invstd, scale, beta, dz.p, dz.ld, acc.p));
+            }
             Tn tot = alloc(2, h, false);
             {
                 Stage st(c, "train_convbn_bwd", 1);
@@ -935,8 +959,11 @@ struct ps_trainer {
                     ps::set_error("trainer: conv_bn_fused: unexpected gradient layout");
                     throw TrainError{PS_ESTATE};
                 }
-                TK(ps_op_conv_bn_train_bwd_apply_w(c, x.p, x.ld, W, b, R, h, mean, invstd, scale, beta, tot.p, 1.0f / (float)R_total, dz.p, dz.ld, add ? 1 : 0,
-                                                   dx.p, dx.ld, gW, gb));
+                {
+                    ActScope as(c, act16);
+                    TK(ps_op_conv_bn_train_bwd_apply_w(c, x.p, x.ld, W, b, R, h, mean, invstd, scale, beta, tot.p, 1.0f / (float)R_total, dz.p, dz.ld, add ? 1 : 0,
+                                                       dx.p, dx.ld, gW, gb));
+                }
                 if (!add) accum(x, dx);
                 (void)st4;
             };
@@ -1178,8 +1205,13 @@ struct ps_trainer {
         const Tn f_src = f_src_in;
         const int64_t N = f_src.R / B, h = f_src.C, d = 2 * h;
         Tn agg = alloc(B * M, d);
-        TK(ps_op_att_pool_train_fwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, K, d, agg.p));
+        const bool act16 = f_xyz.b16;  // (the f_xyz half as bfloat16 rows)
+        {
+            ActScope as(c, act16);
+            TK(ps_op_att_pool_train_fwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, K, d, agg.p));
+        }
         record(agg, [=](const Tn& dy_in) {
+            ActScope as(c, act16);
             const Tn dy = contig(dy_in);
             // f_xyz usually has a gradient already (the h -> h convolution's input gradient ran first): the kernel adds into it instead of
             // writing a second tensor that an axpy pass then folds in (4 passes over [N*K, h] -> 2)
@@ -1373,15 +1405,23 @@ struct ps_trainer {
                 rel = alloc(B * N * K, 10, false);
                 TK(ps_op_relative_pos_encoding(c, pyr->xyz[i], idx, B, N, K, rel.p));
             }
+            bool act16 = false;  // (set below for the levels that store their [N*K, h] rows as bfloat16)
             auto locse = [&](const Tn* out) -> Tn {
                 if (!locse_fused) return conv(rel, n + "LFAmlp1", true, true, out, true);
-                return locse_bn_act(pyr->xyz[i], idx, B, N, K, lfa1, out);
+                return locse_bn_act(pyr->xyz[i], idx, B, N, K, lfa1, out, act16 && out == nullptr);
             };
             // tf.concat([f_neighbours, f_xyz]) (RandLANet.py:328,332): both producers write their column block of the concat buffer
             // directly (no concat copy forward, no split copies backward)
             const int64_t hc = f_pc.C;
             Tn f_agg2;
             const bool narrow = opt.fused_att && ps_op_att_pool_train_supported_ex(K, 2 * hc, opt.mlp_bf16 ? 1 : 0);
+            {
+                // bfloat16 storage of f_xyz and of LFA mlp2's output (ps_train_options.act_bf16): only where EVERY consumer of the two tensors
+                // reads them that way -- the fused LocSE branch, the recompute-form convolution and the split-source pooling kernels
+                Tn probe = f_pc;
+                probe.p = nullptr;
+                act16 = opt.mlp_bf16 && opt.act_bf16 && act_bf16_on && narrow && locse_fused && hc % 8 == 0 && convbn_fused_ok(probe, layer(n + "LFAmlp2"));
+            }
             bool wide_split = false;
             Tn f_xyz_s;
             if (!narrow && (att_split_env < 0 ? opt.mlp_bf16 != 0 : att_split_env != 0)) {

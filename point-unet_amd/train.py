@@ -471,7 +471,7 @@ class Trainer:
 
     def __init__(self, config, params=None, device=0, seed=0, learning_rate=None, class_weights=None, keep_prob=0.5, ctx=None, sync_bn=False,
                  mlp_dtype="fp32", ignored_label_inds=None, fused_att=True, fused_locse=True, fused_convbn=None, engine="native", deterministic=True,
-                 overlap_wgrad=False):
+                 overlap_wgrad=False, act_bf16=None):
         """sync_bn: with a `dist` passed to train_step, BatchNorm uses the statistics of all ranks' rows, which makes "W GPUs x
         one cloud" numerically the same step as "one GPU x W clouds" (SURVEY 8e); off = per-GPU statistics.
         mlp_dtype: "fp32" (default) or "bf16" -- BASELINE configs[2]'s "bf16 MLPs": the shared-MLP GEMMs (forward, input gradient,
@@ -503,6 +503,9 @@ class Trainer:
         # measured on MI355X (round 4, same box): batch 1 9.23 -> 9.74 ms (every fork is an event wait across hardware queues, and dependent
         # kernels spread over more queues are scheduled later), batch 8 42.56 -> 42.46 ms (the step is already HBM-bound end to end)
         self.overlap_wgrad = bool(overlap_wgrad)
+        # native engine, bf16-MLP mode (ps_train_options.act_bf16): the [N*K, h] rows of the LFA branch stored as bfloat16 at levels 0-2.
+        # None = on with mlp_dtype="bf16" (BASELINE configs[2]); the Python tape keeps fp32 storage.
+        self.act_bf16 = (mlp_dtype == "bf16") if act_bf16 is None else bool(act_bf16)
         self.collective_at_world_one = False  # call the all-reduce callback even when the process group has ONE rank (measurement)
         # native engine (ps_train_options.fused_convbn): c = 8 on one-thread-per-row kernels (csrc/convbn_rows.hip; fp32 also in the bf16-MLP
         # mode: an 8 x 8 product has no matrix-pipe shape), wider layers on the tile kernels, which round their operands in the bf16 mode
@@ -570,6 +573,7 @@ class Trainer:
         o.deterministic = int(self.deterministic)
         o.fused_convbn = int(self._fused_convbn_native)
         o.overlap_wgrad = int(self.overlap_wgrad)
+        o.act_bf16 = int(self.act_bf16 and self.mlp_bf16)
         o.num_ignored = len(self.ignored_label_inds)
         for i, v in enumerate(self.ignored_label_inds):
             o.ignored_label_inds[i] = v

@@ -39,7 +39,7 @@ def test_the_stable_header_stays_small():
     assert len(stable) <= 60, sorted(stable)
     assert {"ps_knn_batch", "ps_pyramid_build", "ps_grid_subsample", "ps_volume_to_cloud", "ps_randla_forward", "ps_randla_train_step",
             "ps_op_gather_neighbour", "ps_op_relative_pos_encoding", "ps_op_att_pool", "ps_op_random_sample", "ps_op_nearest_interpolation"} <= stable
-    assert all(n.startswith("ps_op_") for n in ops)
+    assert all(n.startswith("ps_op_") or n == "ps_set_train_act_bf16" for n in ops)  # (the one setter that only concerns those kernels)
 
 
 def test_version_and_error_strings(lib):

@@ -135,6 +135,13 @@ def _bf16_rule(kind, cin, cout):
     return True if kind == "wgrad" else ((cin if kind == "fwd" else cout) % 16 == 0)
 
 
+def _act_rule(h):
+    """Which levels of Trainer(mlp_dtype="bf16") STORE their [N*K, h] LFA rows as bfloat16 (ps_train_options.act_bf16, csrc/trainer.hip:
+    where the fused LocSE branch, the recompute-form convolution and the split-source pooling kernels all apply: h a multiple of 8 up
+    to 64)."""
+    return h % 8 == 0 and h <= 64
+
+
 def _grad_stats(got, ref, names):
     """(relative L2 over the whole gradient, worst per-tensor max error in units of 3e-2 of the tensor's own max + 1e-4 of the global max)"""
     gscale = max(np.abs(ref[n]).max() for n in names)
@@ -179,7 +186,8 @@ def test_training_step_at_the_true_width_ladder(oracle, mode):
     loss = tr.train_step(pyr, torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda())
     torch.cuda.synchronize()
     rule = _bf16_rule if mode == "bf16" else None
-    want = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, step=1, bf16_rule=rule)
+    arule = _act_rule if mode == "bf16" else None
+    want = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, step=1, bf16_rule=rule, act_rule=arule)
     got = {n: tr.G[n].cpu().numpy() for n in tr.names}
     rel_loss = abs(float(loss) - want["loss"]) / max(1.0, abs(want["loss"]))
     logit_err = float(np.abs(tr.last_logits.cpu().numpy().reshape(want["logits"].shape) - want["logits"]).max())
@@ -199,7 +207,7 @@ def test_training_step_at_the_true_width_ladder(oracle, mode):
                 assert np.abs(new[name] - want["new_params"][name])[mask].max() <= 5e-5, name
         assert checked > 1000
     else:
-        alt = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, step=1, bf16_rule=rule, dtype=torch.float32)
+        alt = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, step=1, bf16_rule=rule, act_rule=arule, dtype=torch.float32)
         s_loss = abs(alt["loss"] - want["loss"]) / max(1.0, abs(want["loss"]))
         s_logit = float(np.abs(alt["logits"] - want["logits"]).max())
         s_l2, _ = _grad_stats(alt["grads"], want["grads"], tr.names)
@@ -613,6 +621,83 @@ def test_wide_level_split_source_forms_equal_the_materialised_ones(mode):
             assert torch.equal(acc, seed + dfx), d
     finally:
         _lib.check(L.ps_set_train_gemm_bf16(h, 0))
+    torch.cuda.synchronize()
+
+
+def test_bf16_storage_of_the_lfa_rows_changes_only_the_format():
+    """ps_set_train_act_bf16 (ps_train_options.act_bf16; BASELINE configs[2]): the [N*K, h] rows of the LFA branch STORED as bfloat16.
+    A storage format, not another algorithm -- so every op is held to that: with the flag on,
+      * ps_op_locse_train_apply and ps_op_conv_bn_train_apply write exactly bfloat16(RNE) of what they write with the flag off;
+      * ps_op_conv_bn_train_sums / _apply / _bwd_sums2 / _bwd_apply_w fed bfloat16 rows x, and ps_op_att_pool_train_fwd_split /
+        _bwd_split_rows fed bfloat16 rows fr, return bit for bit what they return for the same values handed over as fp32 rows.
+    h = 8 (one thread per row), 32 and 64 (tile kernels); d = 2h = 16 (per-point kernels), 64 (attpool_gemm.hip's attg64), 128 (the
+    column-split bf16 kernel).  Two clouds, 600 points, bf16-MLP mode on."""
+    import ctypes
+    import torch
+    from point_unet_amd import _lib, runtime
+    L, ctx = _lib.lib(), runtime.default_context(0)
+    hd = ctx.handle
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(41)
+    B, N, K = 2, 600, 16
+    R = B * N * K
+    xyz = torch.rand(B * N, 3, generator=g).cuda()
+    idx = torch.randint(0, N, (B, N, K), generator=g, dtype=torch.int32).cuda()
+
+    def act(on):
+        _lib.check(L.ps_set_train_act_bf16(hd, 1 if on else 0))
+    try:
+        _lib.check(L.ps_set_train_gemm_bf16(hd, 1))
+        for h in (8, 32, 64):
+            d = 2 * h
+            # -- LocSE apply: the output format
+            W1 = (torch.randn(10, h, generator=g) * 0.5).cuda(); b1 = (torch.randn(h, generator=g) * 0.1).cuda()
+            mean, scale, beta = (0.1 * torch.randn(h, generator=g)).cuda(), (1 + 0.2 * torch.rand(h, generator=g)).cuda(), (0.1 * torch.randn(h, generator=g)).cuda()
+            y32 = torch.empty(R, h).cuda(); y16 = torch.empty(R, h, dtype=torch.bfloat16).cuda()
+            act(False); _lib.check(L.ps_op_locse_train_apply(hd, p(xyz), p(idx), B, N, K, p(W1), p(b1), h, p(mean), p(scale), p(beta), p(y32), h))
+            act(True); _lib.check(L.ps_op_locse_train_apply(hd, p(xyz), p(idx), B, N, K, p(W1), p(b1), h, p(mean), p(scale), p(beta), p(y16), h))
+            assert torch.equal(y16, y32.bfloat16()), h
+            # -- LFA mlp2 in the recompute form: x as bfloat16 rows
+            x16, xf = y16, y16.float()
+            W2 = (torch.randn(h, h, generator=g) / h ** 0.5).cuda(); b2 = (torch.randn(h, generator=g) * 0.1).cuda()
+            CP = max(h, 16)
+            s_a, s_b = torch.zeros(3 * CP, dtype=torch.float64).cuda(), torch.zeros(3 * CP, dtype=torch.float64).cuda()
+            act(False); _lib.check(L.ps_op_conv_bn_train_sums(hd, p(xf), h, p(W2), p(b2), R, h, p(s_a)))
+            act(True); _lib.check(L.ps_op_conv_bn_train_sums(hd, p(x16), h, p(W2), p(b2), R, h, p(s_b)))
+            assert torch.equal(s_a, s_b), h
+            m2, inv2 = (0.1 * torch.randn(h, generator=g)).cuda(), (1 + 0.2 * torch.rand(h, generator=g)).cuda()
+            sc2, be2 = (inv2 * 1.1).contiguous(), (0.1 * torch.randn(h, generator=g)).cuda()
+            z32 = torch.empty(R, h).cuda(); z16 = torch.empty(R, h, dtype=torch.bfloat16).cuda()
+            act(False); _lib.check(L.ps_op_conv_bn_train_apply(hd, p(xf), h, p(W2), p(b2), R, h, p(m2), p(sc2), p(be2), p(z32), h))
+            act(True); _lib.check(L.ps_op_conv_bn_train_apply(hd, p(x16), h, p(W2), p(b2), R, h, p(m2), p(sc2), p(be2), p(z16), h))
+            assert torch.equal(z16, z32.bfloat16()), h
+            dz = torch.randn(R, h, generator=g).cuda()
+            outs = {}
+            for on, xx in ((False, xf), (True, x16)):
+                act(on)
+                s12 = torch.zeros(3 * h).cuda(); dx = torch.empty(R, h).cuda(); dw = torch.empty(h, h).cuda(); db = torch.empty(h).cuda()
+                _lib.check(L.ps_op_conv_bn_train_bwd_sums2(hd, p(xx), h, p(W2), p(b2), R, h, p(m2), p(inv2), p(sc2), p(be2), p(dz), h, p(s12)))
+                _lib.check(L.ps_op_conv_bn_train_bwd_apply_w(hd, p(xx), h, p(W2), p(b2), R, h, p(m2), p(inv2), p(sc2), p(be2), p(s12), 1.0 / R, p(dz), h, 0,
+                                                             p(dx), h, p(dw), p(db)))
+                outs[on] = (s12[:2 * h].clone(), dx, dw, db)
+            for a_, b_ in zip(outs[False], outs[True]):
+                assert torch.equal(a_, b_), h
+            # -- the split-source pooling: fr as bfloat16 rows
+            assert L.ps_op_att_pool_train_supported_ex(K, d, 1) == 1
+            fsrc = torch.randn(B * N, h, generator=g).cuda()
+            Wfc = (torch.randn(d, d, generator=g) / d ** 0.5).cuda(); dagg = torch.randn(B * N, d, generator=g).cuda()
+            res = {}
+            for on, fr in ((False, xf), (True, x16)):
+                act(on)
+                agg = torch.empty(B * N, d).cuda(); rows = torch.empty(R, h).cuda(); dfr = torch.empty(R, h).cuda(); dW = torch.empty(d, d).cuda()
+                _lib.check(L.ps_op_att_pool_train_fwd_split(hd, p(fsrc), h, p(idx), B, N, N, p(fr), h, p(Wfc), K, d, p(agg)))
+                _lib.check(L.ps_op_att_pool_train_bwd_split_rows(hd, p(fsrc), h, p(idx), B, N, N, p(fr), h, p(Wfc), p(dagg), K, d, p(rows), h, p(dfr), h, p(dW)))
+                res[on] = (agg, rows, dfr, dW)
+            for a_, b_ in zip(res[False], res[True]):
+                assert torch.equal(a_, b_), (h, d)
+    finally:
+        _lib.check(L.ps_set_train_act_bf16(hd, 0))
+        _lib.check(L.ps_set_train_gemm_bf16(hd, 0))
     torch.cuda.synchronize()
 
 
