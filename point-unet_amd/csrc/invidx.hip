@@ -10,6 +10,8 @@
 #include "common.h"
 #include "sortscan.h"
 
+#include <cstdlib>
+
 namespace ps {
 
 __global__ __launch_bounds__(256) void inv_count_kernel(const int32_t* __restrict__ idx, int64_t rows, int rows_per_cloud, int n_cloud,
@@ -60,6 +62,256 @@ __global__ __launch_bounds__(256) void inv_keys_kernel(const int32_t* __restrict
         vals[r] = (unsigned)r;
     }
 }
+// ---- the inverse index in ONE stable bucket pass + a sort inside every bucket (tables of >= kInvBucketRows rows) ----
+// The radix sort above moves (key, row) pairs three times (8 B read + 8 B written per pass, a histogram read in front of each).  It does not
+// use what the table is: rows come cloud by cloud (the high part of the key is sorted already), a key is < N, and a row number inside its
+// cloud needs far fewer than 32 bits.  Here a destination id splits as (bucket = id >> lo, low = id & (2^lo - 1)) with at most 512 buckets
+// per cloud:
+//   1. bk_hist:    per 8192-row tile of a cloud, rows per bucket -> table[(cloud, bucket), tile]; an exclusive scan of the table is where
+//                  every tile's run of every bucket starts (and, at tile 0, where the bucket itself starts);
+//   2. bk_scatter: a tile is sorted by bucket in LDS (stable: wave-ordered ranks from ballot match masks, as radix_scatter_kernel does) and
+//                  leaves as runs of ONE word per row, (row inside the cloud) << lo | low;
+//   3. bk_local:   a workgroup owns a bucket (<= 512 destinations, ~8 K rows at level 0: L2 resident), counts per destination, scans,
+//                  writes the destinations' offsets, places the rows -- stable again, so ascending inside a segment -- through an LDS image
+//                  of the bucket and streams `src` out.
+// 20 bytes per row instead of 72, four launches + the table scan instead of fifteen.  Identical output (offsets and src) to the two other
+// forms.  Measured, batch 8 x 180 000 points: DESIGN 4.2.
+constexpr int kBkTile = 4096;    // rows per workgroup of passes 1 and 2 (a wave owns 1024 consecutive rows).  PS_INV_TILE = 8192 | 6144 | 4096: measured 0.303 /
+                                 // 0.267 / 0.250 ms for the 23 M-row table of level 0 (LDS per workgroup 58 / 46 / 34 KB: 2 / 3 / 4 workgroups per CU)
+constexpr int kBkDigits = 512;   // buckets per cloud (pass 2) and destinations per bucket (pass 3) the LDS counters hold
+constexpr int kBkStage = 10240;  // rows of a bucket sorted through LDS; a larger bucket (skewed tables) writes its rows straight to `src`
+
+struct BkPlan {
+    int lo, nb, tpc, nb_bits;
+    size_t table;  // entries (the scan runs over table + 1)
+};
+
+__device__ __forceinline__ unsigned bk_wave_inclusive_sum(unsigned v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = (unsigned)__shfl_up((int)v, o);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
+// (kBkHistTiles consecutive tiles per workgroup; 4 measured slower than 1 -- 76 against 50 us at level 0: fewer, longer workgroups)
+constexpr int kBkHistTiles = 1;
+template <int TILE>
+__global__ __launch_bounds__(256) void bk_hist_kernel(const int32_t* __restrict__ idx, int rpc, int tpc, int lo, int nb, unsigned* __restrict__ table,
+                                                      size_t table_n)
+{
+    __shared__ unsigned h[kBkHistTiles][kBkDigits];
+#pragma unroll
+    for (int j = 0; j < kBkHistTiles * kBkDigits / 256; ++j) (&h[0][0])[j * 256 + threadIdx.x] = 0;
+    __syncthreads();
+    const int groups = (tpc + kBkHistTiles - 1) / kBkHistTiles;
+    const int b = blockIdx.x / groups, t0 = (blockIdx.x - b * groups) * kBkHistTiles;
+    const int tiles = min(kBkHistTiles, tpc - t0);
+    for (int q = 0; q < tiles; ++q) {
+        const int r0 = (t0 + q) * TILE;
+        const int n = min(TILE, rpc - r0);
+        const int32_t* p = idx + (size_t)b * rpc + r0;
+#pragma unroll 8
+        for (int j = 0; j < TILE / 256; ++j) {
+            const int i = j * 256 + threadIdx.x;
+            if (i < n) atomicAdd(&h[q][min((unsigned)p[i] >> lo, (unsigned)nb - 1u)], 1u);  // (clamped: a value outside [0, N) stays memory-safe)
+        }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < nb; d += 256) {
+        unsigned* o = table + ((size_t)b * nb + d) * tpc + t0;
+        for (int q = 0; q < tiles; ++q) o[q] = h[q][d];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) table[table_n] = 0;  // scanned: the total, where the bucket after the last one would start
+}
+
+// exclusive scan over the 512 per-digit totals of a workgroup's four waves (thread t owns digits 2t, 2t+1), IN PLACE: s[w][d] = rows of digit
+// d in wave w's share -> first slot of those rows inside the sorted tile / bucket; returns the slot where digit 2t starts (2t+1: + tot0)
+__device__ __forceinline__ unsigned bk_scan_digits(unsigned (*s)[kBkDigits], unsigned* s_w, unsigned& tot0)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d0 = 2 * threadIdx.x;
+    uint2 c[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) c[w] = *reinterpret_cast<const uint2*>(&s[w][d0]);
+    tot0 = c[0].x + c[1].x + c[2].x + c[3].x;
+    const unsigned tot1 = c[0].y + c[1].y + c[2].y + c[3].y;
+    const unsigned inc = bk_wave_inclusive_sum(tot0 + tot1, lane);
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    unsigned woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_w[w];
+    const unsigned loc0 = woff + inc - (tot0 + tot1);
+    unsigned a0 = loc0, a1 = loc0 + tot0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        *reinterpret_cast<uint2*>(&s[w][d0]) = make_uint2(a0, a1);
+        a0 += c[w].x;
+        a1 += c[w].y;
+    }
+    return loc0;
+}
+
+template <int TILE>
+__global__ __launch_bounds__(256) void bk_scatter_kernel(const int32_t* __restrict__ idx, int rpc, int tpc, int lo, int nb, int nb_bits,
+                                                         const unsigned* __restrict__ start /* scanned table */, unsigned* __restrict__ payload)
+{
+    constexpr int ROUNDS = TILE / 256;
+    __shared__ __attribute__((aligned(8))) unsigned s_off[4][kBkDigits];
+    __shared__ unsigned s_delta[kBkDigits], s_w[4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    unsigned* sv = reinterpret_cast<unsigned*>(s_raw);
+    unsigned short* sd = reinterpret_cast<unsigned short*>(s_raw + sizeof(unsigned) * TILE);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / tpc, t = blockIdx.x - b * tpc;
+    const int r0 = t * TILE;
+    const int tile_n = min(TILE, rpc - r0);
+    const int w0 = wave * (TILE / 4);
+    const int32_t* p = idx + (size_t)b * rpc + r0;
+    unsigned k[ROUNDS];
+#pragma unroll
+    for (int s = 0; s < ROUNDS; ++s) {
+        const int i = w0 + s * 64 + lane;
+        k[s] = i < tile_n ? (unsigned)p[i] : 0u;
+    }
+    // this thread's two entries of the scanned table (used after the digit scan: requested now, under the counting)
+    const int d0 = 2 * threadIdx.x;
+    const unsigned g0 = d0 < nb ? start[((size_t)b * nb + d0) * tpc + t] : 0u, g1 = d0 + 1 < nb ? start[((size_t)b * nb + d0 + 1) * tpc + t] : 0u;
+#pragma unroll
+    for (int j = 0; j < kBkDigits / 64; ++j) s_off[wave][j * 64 + lane] = 0;
+    // (a wave's LDS operations execute in order: its own zeroes precede its own atomics)
+#pragma unroll
+    for (int s = 0; s < ROUNDS; ++s)
+        if (w0 + s * 64 + lane < tile_n) atomicAdd(&s_off[wave][min(k[s] >> lo, (unsigned)nb - 1u)], 1u);
+    __syncthreads();
+    {
+        unsigned tot0;
+        const unsigned loc0 = bk_scan_digits(s_off, s_w, tot0);
+        // global position = delta + slot (unsigned wrap-around is fine)
+        s_delta[d0] = g0 - loc0;
+        s_delta[d0 + 1] = g1 - (loc0 + tot0);
+    }
+    __syncthreads();
+    // (s_off[wave] is private to the wave from here on)
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned low_mask = (1u << lo) - 1u;
+#pragma unroll 4
+    for (int s = 0; s < ROUNDS; ++s) {
+        const int i = w0 + s * 64 + lane;
+        const bool valid = i < tile_n;
+        const unsigned d = min(k[s] >> lo, (unsigned)nb - 1u);
+        unsigned long long same = __ballot(valid);
+        for (int bit = 0; bit < nb_bits; ++bit) {
+            const unsigned long long has = __ballot((d >> bit) & 1u);
+            same &= ((d >> bit) & 1u) ? has : ~has;
+        }
+        const unsigned rank = (unsigned)__popcll(same & below);
+        if (valid) {
+            const unsigned slot = s_off[wave][d] + rank;
+            sv[slot] = ((unsigned)(r0 + i) << lo) | (k[s] & low_mask);
+            sd[slot] = (unsigned short)d;
+            if (rank == 0) s_off[wave][d] = slot + (unsigned)__popcll(same);  // the lowest lane of the group moves the cursor on
+        }
+    }
+    __syncthreads();
+    if (tile_n == TILE) {
+#pragma unroll 8
+        for (int j = 0; j < ROUNDS; ++j) {
+            const int slot = j * 256 + threadIdx.x;
+            payload[s_delta[sd[slot]] + slot] = sv[slot];
+        }
+    } else {
+        for (int slot = threadIdx.x; slot < tile_n; slot += 256) payload[s_delta[sd[slot]] + slot] = sv[slot];
+    }
+}
+
+__global__ __launch_bounds__(256) void bk_local_kernel(const unsigned* __restrict__ payload, const unsigned* __restrict__ start, int rpc, int tpc, int lo,
+                                                       int nb, int n_cloud, int64_t n_dst, unsigned rows, unsigned* __restrict__ offsets,
+                                                       int32_t* __restrict__ src)
+{
+    constexpr int MAXR = kBkStage / 256;  // rounds of 64 a wave's share of a staged bucket has at most
+    __shared__ __attribute__((aligned(8))) unsigned s_off[4][kBkDigits];
+    __shared__ unsigned s_w[4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    unsigned* sv = reinterpret_cast<unsigned*>(s_raw);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / nb, d = blockIdx.x - b * nb;
+    const unsigned first = start[(size_t)blockIdx.x * tpc], n = start[((size_t)blockIdx.x + 1) * tpc] - first;
+    const unsigned mask = (1u << lo) - 1u;
+    const unsigned* pl = payload + first;
+    const bool staged = n <= (unsigned)kBkStage;
+    const unsigned chunk = ((n + 255u) / 256u) * 64u;  // a wave's share of the bucket: consecutive rows, whole rounds of 64
+    const unsigned w_lo = min(n, (unsigned)wave * chunk), w_hi = min(n, w_lo + chunk);
+    // a staged bucket's rows are read ONCE, all loads in flight together (a loop of dependent loads per round is one memory latency per 64 rows)
+    unsigned k[MAXR];
+    if (staged) {
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            const unsigned i = w_lo + r * 64 + lane;
+            k[r] = i < w_hi ? pl[i] : 0u;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kBkDigits / 64; ++j) s_off[wave][j * 64 + lane] = 0;
+    if (staged) {
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r)
+            if (w_lo + r * 64 + lane < w_hi) atomicAdd(&s_off[wave][k[r] & mask], 1u);
+    } else {
+        for (unsigned i = w_lo + lane; i < w_hi; i += 64) atomicAdd(&s_off[wave][pl[i] & mask], 1u);
+    }
+    __syncthreads();
+    {
+        unsigned tot0;
+        const unsigned loc0 = bk_scan_digits(s_off, s_w, tot0);
+        const int id0 = (d << lo) + 2 * (int)threadIdx.x;  // (digits >= 2^lo hold nothing: their ids belong to the next bucket, which writes them)
+        if (2 * threadIdx.x < (1u << lo)) {
+            unsigned* o = offsets + (size_t)b * n_cloud;
+            if (id0 < n_cloud) o[id0] = first + loc0;
+            if (id0 + 1 < n_cloud && 2 * threadIdx.x + 1 < (1u << lo)) o[id0 + 1] = first + loc0 + tot0;
+        }
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) offsets[n_dst] = rows;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned row0 = (unsigned)b * (unsigned)rpc;
+    auto place = [&](unsigned pv, bool valid, bool to_lds) {
+        const unsigned key = pv & mask;
+        unsigned long long same = __ballot(valid);
+        for (int bit = 0; bit < lo; ++bit) {
+            const unsigned long long has = __ballot((key >> bit) & 1u);
+            same &= ((key >> bit) & 1u) ? has : ~has;
+        }
+        const unsigned rank = (unsigned)__popcll(same & below);
+        if (valid) {
+            const unsigned slot = s_off[wave][key] + rank;
+            const unsigned val = row0 + (pv >> lo);
+            if (to_lds)
+                sv[slot] = val;
+            else
+                src[first + slot] = (int32_t)val;
+            if (rank == 0) s_off[wave][key] = slot + (unsigned)__popcll(same);
+        }
+    };
+    if (!staged) {
+        for (unsigned base = w_lo; base < w_hi; base += 64) {
+            const unsigned i = base + lane;
+            place(i < w_hi ? pl[i] : 0u, i < w_hi, false);
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        if (w_lo + r * 64 >= w_hi) break;  // (uniform per wave)
+        place(k[r], w_lo + r * 64 + lane < w_hi, true);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (unsigned i = threadIdx.x; i < n; i += 256) src[first + i] = (int32_t)sv[i];
+}
+
 // sorted keys -> offsets: position i opens the segments of every destination in (keys[i-1], keys[i]]; the last position closes the rest
 __global__ __launch_bounds__(256) void inv_offsets_kernel(const unsigned* __restrict__ keys, int64_t rows, int64_t n_dst, unsigned* __restrict__ offsets)
 {
@@ -222,7 +474,28 @@ using namespace ps;
 
 extern "C" {
 
-static constexpr int64_t kInvSortRows = 1 << 20;  // tables of at least this many rows are inverted by the radix sort
+static constexpr int64_t kInvSortRows = 1 << 16;  // tables of at least this many rows are inverted by the bucket pass (or, when its plan does not fit, the radix sort)
+
+// the bucket form's shape for a table, or false: more than 512 x 512 destinations per cloud, or (row inside the cloud, low id bits) past 32 bits
+static bool bk_plan(int64_t B, int64_t N, int64_t rpc, int tile, BkPlan* pl)
+{
+    int lo = 0;
+    while (((N + (1ll << lo) - 1) >> lo) > kBkDigits) ++lo;  // at most 512 buckets per cloud
+    // ... of ~1024 rows or more each where the table has them (a bucket is a workgroup of pass 3), within the 512 destinations a bucket may hold
+    while (lo < 9 && (rpc << lo) < 1024 * N) ++lo;
+    if (lo > 9) return false;
+    int rbits = 0;
+    while ((1ll << rbits) < rpc) ++rbits;
+    if (rbits + lo > 32) return false;
+    pl->lo = lo;
+    pl->nb = (int)((N + (1ll << lo) - 1) >> lo);
+    pl->nb_bits = 0;
+    while ((1 << pl->nb_bits) < pl->nb) ++pl->nb_bits;
+    pl->tpc = (int)((rpc + tile - 1) / tile);
+    pl->table = (size_t)B * pl->nb * pl->tpc;
+    return B * (int64_t)pl->tpc < (1ll << 31) && B * (int64_t)pl->nb < (1ll << 31);
+}
+static size_t bk_workspace_words(const BkPlan& pl, int64_t rows) { return (size_t)rows + ((pl.table + 1 + 63) & ~size_t(63)) + scan_workspace_words(pl.table + 1); }
 
 int64_t ps_op_inverse_index_workspace(int64_t n_dst, int64_t rows)
 {
@@ -238,6 +511,42 @@ int ps_op_inverse_index(ps_context* c, const int32_t* idx, int64_t B, int64_t N,
     PS_HIP(hipSetDevice(c->device));
     const int64_t n_dst = B * N, rows = B * rows_per_cloud;
     unsigned* off = reinterpret_cast<unsigned*>(offsets);
+    BkPlan pl;
+    static const bool bucket_on = !(getenv("PS_INV_BUCKET") && atoi(getenv("PS_INV_BUCKET")) == 0);  // (A/B switch: 0 = the radix-sort form)
+    static const int tile = getenv("PS_INV_TILE") ? atoi(getenv("PS_INV_TILE")) : kBkTile;
+    if (rows >= kInvSortRows && bucket_on && bk_plan(B, N, rows_per_cloud, tile, &pl) &&
+        (int64_t)bk_workspace_words(pl, rows) + 64 <= ps_op_inverse_index_workspace(n_dst, rows)) {
+        Stage st(c, "train_inverse_index", 6);
+        unsigned* payload = reinterpret_cast<unsigned*>(workspace);
+        unsigned* table = payload + rows;
+        unsigned* scan_ws = table + ((pl.table + 1 + 63) & ~size_t(63));
+        const int stage2 = (int)((sizeof(unsigned) + sizeof(unsigned short)) * tile), stage3 = (int)(sizeof(unsigned) * kBkStage);
+        static const bool attr = [&] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bk_scatter_kernel<8192>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(6 * 8192));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bk_local_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, stage3);
+            return true;
+        }();
+        (void)attr;
+        const unsigned tiles = (unsigned)(B * pl.tpc), buckets = (unsigned)(B * pl.nb);
+        const unsigned hgroups = (unsigned)(B * ((pl.tpc + kBkHistTiles - 1) / kBkHistTiles));
+#define PS_BK_PASSES(T)                                                                                                                                   \
+    hipLaunchKernelGGL(bk_hist_kernel<T>, dim3(hgroups), dim3(256), 0, c->stream, idx, (int)rows_per_cloud, pl.tpc, pl.lo, pl.nb, table, pl.table);      \
+    exclusive_scan_u32(c->stream, table, table, pl.table + 1, scan_ws);                                                                                   \
+    hipLaunchKernelGGL(bk_scatter_kernel<T>, dim3(tiles), dim3(256), stage2, c->stream, idx, (int)rows_per_cloud, pl.tpc, pl.lo, pl.nb, pl.nb_bits, table, \
+                       payload)
+        if (tile == 4096) {
+            PS_BK_PASSES(4096);
+        } else if (tile == 6144) {
+            PS_BK_PASSES(6144);
+        } else {
+            PS_BK_PASSES(8192);
+        }
+#undef PS_BK_PASSES
+        hipLaunchKernelGGL(bk_local_kernel, dim3(buckets), dim3(256), stage3, c->stream, payload, table, (int)rows_per_cloud, pl.tpc, pl.lo, pl.nb, (int)N, n_dst,
+                           (unsigned)rows, off, src);
+        PS_HIP(hipGetLastError());
+        return PS_OK;
+    }
     if (rows >= kInvSortRows) {
         Stage st(c, "train_inverse_index", 12);
         PS_CHECK((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "ps_op_inverse_index: workspace must be 8-byte aligned");

@@ -1234,8 +1234,15 @@ def test_inverse_index_and_gather_reduction(oracle):
     h = ctx.handle
     p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
     g = torch.Generator().manual_seed(5)
-    for B, N, M, K, d in [(2, 700, 700, 16, 8), (1, 300, 1200, 1, 64), (3, 500, 125, 16, 32), (1, 40, 40, 16, 5), (2, 40000, 40000, 16, 4)]:  # (the last: the radix-sort form)
+    # (2, 700, ...) .. (1, 40, ...): the count / fill / sort form of small tables; from 65 536 rows on the bucket form (one stable bucket pass
+    # + a sort inside every bucket): ragged bucket and tile counts, a 1-NN table, destinations nobody gathers, and "skew" = most rows gather
+    # ONE destination (a bucket far beyond what is sorted through LDS).  PS_INV_BUCKET=0 in the environment runs the radix-sort form instead.
+    for B, N, M, K, d, skew in [(2, 700, 700, 16, 8, 0), (1, 300, 1200, 1, 64, 0), (3, 500, 125, 16, 32, 0), (1, 40, 40, 16, 5, 0), (2, 40000, 40000, 16, 4, 0),
+                                (3, 4133, 4133, 16, 8, 0), (2, 70001, 70001, 1, 4, 0), (1, 1000, 9000, 16, 4, 1), (5, 513, 1100, 16, 4, 0),
+                                (1, 262144, 30000, 16, 4, 0)]:
         idx = torch.randint(0, N, (B, M, K), generator=g).int()
+        if skew:
+            idx[:, M // 8:, 1:] = 77
         idx[:, : M // 7, K // 2:] = 0                       # zero padding / duplicates inside a list
         idx[idx == N - 1] = 0                                # a source row nobody gathers
         d_idx = idx.cuda()
