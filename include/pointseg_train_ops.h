@@ -226,13 +226,19 @@ int ps_op_convbn_train_bwd_apply(ps_context* ctx, const float* x, int64_t ldx, c
  * additions changes from run to run.  ps_op_inverse_index inverts a gather table idx i32[B, rows_per_cloud] (values in [0, N)):
  * offsets i32[B*N + 1], src i32[B*rows_per_cloud] = the flat rows r that read source row j = b*N + idx[r], ASCENDING, for
  * j's segment offsets[j] .. offsets[j+1]; workspace: ps_op_inverse_index_workspace(B*N, B*rows_per_cloud) int32 words, 8-byte aligned
- * (tables of a million rows and more go through a stable radix sort of (destination, row) pairs, smaller ones through count / scan / fill).  ps_op_gather_reduce_rows then
+ * (tables of 65 536 rows and more: one stable bucket pass + a sort inside every bucket; smaller ones: count / scan / fill / per-segment sort).  ps_op_gather_reduce_rows then
  * forms dst[j, :] (+)= sum over the segment, in that order, of rows[src, :] -- every backward scatter as a gather-reduction, no atomics. */
 int64_t ps_op_inverse_index_workspace(int64_t n_dst, int64_t rows);
 int ps_op_inverse_index(ps_context* ctx, const int32_t* idx, int64_t B, int64_t N, int64_t rows_per_cloud, int32_t* offsets,
                         int32_t* src, int32_t* workspace);
 int ps_op_gather_reduce_rows(ps_context* ctx, const float* rows, int64_t ldr, const int32_t* offsets, const int32_t* src,
                              int64_t n_dst, int64_t d, float* dst, int64_t ldd, int accumulate);
+/* The same sums with the destinations WALKED in the order i32[n_dst / n_cloud, n_cloud] (cloud-local rows: ps_pyramid.order of the
+ * destinations' level; NULL = ascending), one contiguous eighth per XCD: the rows of a segment belong to the destination's spatial
+ * neighbours, so a spatially coherent walk finds them in the XCD's L2.  Results are bit-identical to ps_op_gather_reduce_rows. */
+int ps_op_gather_reduce_rows_ordered(ps_context* ctx, const float* rows, int64_t ldr, const int32_t* offsets, const int32_t* src,
+                                     int64_t n_dst, int64_t d, float* dst, int64_t ldd, int accumulate, const int32_t* order,
+                                     int64_t n_cloud);
 /* ps_op_random_sample_bwd through an inverse index.  pool_idx i32[B, M, K] must be the first M rows per cloud of a table
  * i32[B, N', K] with N' >= M (the pyramid's sub_idx = neigh_idx[:, :M], runBraTS.py:150) and offsets / src the inverse index of THAT
  * table (rows_per_cloud = N'*K, here N' = N): the pooling rows are a prefix of every segment, no second index is built.

@@ -163,6 +163,8 @@ PROTOTYPES = {
     "ps_op_inverse_index_workspace": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64]),
     "ps_op_inverse_index": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, c_vp]),
     "ps_op_gather_reduce_rows": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, c_vp, ctypes.c_int64, ctypes.c_int]),
+    "ps_op_gather_reduce_rows_ordered": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, c_vp, ctypes.c_int64, ctypes.c_int,
+                                                        c_vp, ctypes.c_int64]),
     "ps_op_random_sample_bwd_inv": (ctypes.c_int, [c_vp] * 7 + [ctypes.c_int64] * 5 + [c_vp, c_vp, c_vp]),
     "ps_op_random_sample_ties": (ctypes.c_int, [c_vp, c_vp, c_vp] + [ctypes.c_int64] * 5 + [c_vp, c_vp]),
     "ps_op_att_pool_train_bwd_split_rows": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, ctypes.c_int64, c_vp, c_vp,

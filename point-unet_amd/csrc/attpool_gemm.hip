@@ -536,7 +536,7 @@ __global__ __launch_bounds__(WAVES * 64) void attg64_kernel(AttTrainArgs a, cons
     // the operand row of this lane in tile `tile` (rows is a multiple of 16: the last tile may hold ONE point, whose rows are then read twice)
     auto my_row = [&](int64_t tile) {
         const int64_t row0 = tile << 5;
-        const int second = rows - row0 >= 32 ? 16 : 0;
+        [[maybe_unused]] const int second = rows - row0 >= 32 ? 16 : 0;
         return row0 + (c32 < 16 ? c32 : c32 - 16 + second);
     };
     float4 nrow[8];   // the NEXT tile's operand row of this lane: chunks q = 0..3 x two float4
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(WAVES * 64) void attg64_kernel(AttTrainArgs a, cons
     for (; tile < ntiles; tile += stride) {
         const int64_t row0 = tile << 5;
         const int nvalid = rows - row0 >= 32 ? 32 : 16;
-        const int second = nvalid == 32 ? 16 : 0;
+        [[maybe_unused]] const int second = nvalid == 32 ? 16 : 0;
         float gd[2][2];  // dagg of (tile column block t, point pi): requested before the products
         if constexpr (BWD) {
 #pragma unroll

@@ -136,6 +136,10 @@ struct ps_context {
     bool train_b3 = true;     // ps_set_train_gemm_b3: large fp32 op-level GEMMs on bf16 MFMA over exact three-way splits (gemm_b3.hip)
     bool conv_w_transposed = false;  // (internal, set around a call by the native trainer) ps_op_conv1x1_ex: w is stored [cout, cin]
     bool att_df_accum = false;  // (internal, set around a call by the native trainer) ps_op_att_pool_train_bwd_split*: dfr += instead of dfr =
+    // a hint of the trainer for the op it enqueues next: i32[B, walk_order_n], the spatially coherent processing order (ps_pyramid.order) of the
+    // walk_order_n points per cloud the op's destinations are; NULL = none (ops called through the C ABI on their own never see one)
+    const int32_t* walk_order = nullptr;
+    int64_t walk_order_n = 0;
     bool pool_bwd_overwrite = false;  // ps_op_random_sample_bwd_inv (tie-count form) STORES the gradient instead of adding into a zeroed buffer (trainer.hip)
     bool train_bf16 = false;  // ps_set_train_gemm_bf16: the op-level GEMMs round their operands to bf16 (fp32 accumulate)
     bool train_act_bf16 = false;  // ps_set_train_act_bf16: the [N*K, h] activation rows of the LFA branch are STORED as bfloat16 (include/pointseg_train_ops.h)

@@ -10,6 +10,7 @@
 #include "common.h"
 #include "sortscan.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace ps {
@@ -366,6 +367,47 @@ __global__ __launch_bounds__(256) void gather_reduce_kernel(const float* __restr
     }
 }
 
+// The same reduction with the destinations walked in a SPATIALLY COHERENT order (order[b, t] = row of cloud b's t-th point in kd-tree leaf
+// order, ps_pyramid.order), one contiguous eighth of that order per XCD.  A destination's segment lists rows (q, k) of its spatial
+// neighbours q; the K rows of one q form one 64 x d / 16-byte block whose other rows belong to destinations next to this one -- walked in
+// cloud order (a shuffled cloud: runBraTS.py:114) every 32-byte row of level 0 costs its own memory transaction, walked in leaf order the
+// block is fetched once into the XCD's L2 and its rows are consumed by the neighbouring lanes and workgroups.  Same sums, same order.
+__global__ __launch_bounds__(256) void gather_reduce_ordered_kernel(const float* __restrict__ rows, int64_t ldr, const unsigned* __restrict__ offsets,
+                                                                    const int32_t* __restrict__ src, const int32_t* __restrict__ order, unsigned n_dst,
+                                                                    unsigned n_cloud, unsigned per /* d / 4 lanes per destination */,
+                                                                    float* __restrict__ dst, int64_t ldd, int accumulate)
+{
+    const unsigned dpw = 256u / per;                                      // destinations per workgroup and pass (per divides 256: host)
+    const unsigned per_xcd = (((n_dst + 7u) >> 3) + dpw - 1u) / dpw * dpw;
+    const unsigned xcd = blockIdx.x & 7u, slots = gridDim.x >> 3;         // (the host launches a multiple of 8 workgroups)
+    const unsigned end = min(n_dst, (xcd + 1u) * per_xcd);
+    const unsigned sub = threadIdx.x / per, q = threadIdx.x - sub * per;
+    for (unsigned t = xcd * per_xcd + (blockIdx.x >> 3) * dpw + sub; t < end; t += slots * dpw) {
+        const unsigned b = t / n_cloud;
+        const int64_t j = (int64_t)b * n_cloud + order[t];
+        const unsigned lo = offsets[j], hi = offsets[j + 1];
+        const float* base = rows + 4 * q;
+        float4 acc = accumulate ? *reinterpret_cast<const float4*>(dst + j * ldd + 4 * q) : float4{0.f, 0.f, 0.f, 0.f};
+        unsigned s = lo;
+        for (; s + 4 <= hi; s += 4) {
+            const int32_t i0 = src[s], i1 = src[s + 1], i2 = src[s + 2], i3 = src[s + 3];
+            const float4 v0 = *reinterpret_cast<const float4*>(base + (int64_t)i0 * ldr);
+            const float4 v1 = *reinterpret_cast<const float4*>(base + (int64_t)i1 * ldr);
+            const float4 v2 = *reinterpret_cast<const float4*>(base + (int64_t)i2 * ldr);
+            const float4 v3 = *reinterpret_cast<const float4*>(base + (int64_t)i3 * ldr);
+            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+            acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+            acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+        }
+        for (; s < hi; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)src[s] * ldr);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dst + j * ldd + 4 * q) = acc;
+    }
+}
+
 // random_sample backward, step 1: share[m, c] = dout[m, c] / (number of the K gathered rows that attain the maximum) -- ties share the
 // gradient evenly like tf.reduce_max's
 __global__ __launch_bounds__(256) void maxpool_share_kernel(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ feat,
@@ -462,6 +504,68 @@ __global__ __launch_bounds__(256) void maxpool_bwd_inv4_kernel(const float* __re
     }
 }
 
+// maxpool_bwd_inv4_kernel with (a) the destinations walked in a spatially coherent order, one contiguous eighth per XCD (the rows of `out` /
+// `dout` a destination compares against are those of the pooled points around it, each shared by its K gatherers: L2 hits instead of one
+// memory transaction per compare) and (b) four segment entries per iteration: their index loads, then their `out` loads, are independent --
+// the one-entry loop is a chain of three dependent round trips per entry.  Same additions in the same order.
+__global__ __launch_bounds__(256) void maxpool_bwd_inv4_ordered_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ ties,
+                                                                       const float* __restrict__ out, const float* __restrict__ feat,
+                                                                       const unsigned* __restrict__ offsets, const int32_t* __restrict__ src,
+                                                                       const int32_t* __restrict__ order, unsigned n_dst, unsigned n_cloud, unsigned m_cloud,
+                                                                       unsigned K, unsigned d4, float* __restrict__ dfeat, int overwrite)
+{
+    const float4* out4 = reinterpret_cast<const float4*>(out);
+    const float4* dout4 = reinterpret_cast<const float4*>(dout);
+    const uchar4* ties4 = reinterpret_cast<const uchar4*>(ties);
+    const unsigned dpw = 256u / d4;
+    const unsigned per_xcd = (((n_dst + 7u) >> 3) + dpw - 1u) / dpw * dpw;
+    const unsigned xcd = blockIdx.x & 7u, slots = gridDim.x >> 3;
+    const unsigned end = min(n_dst, (xcd + 1u) * per_xcd);
+    const unsigned sub = threadIdx.x / d4, q = threadIdx.x - sub * d4;
+    for (unsigned w = xcd * per_xcd + (blockIdx.x >> 3) * dpw + sub; w < end; w += slots * dpw) {
+        const unsigned b = w / n_cloud;
+        const unsigned first = b * n_cloud, mbase = b * m_cloud;
+        const unsigned j = order ? first + (unsigned)order[w] : w;
+        const unsigned t = j * d4 + q;
+        const unsigned lo = offsets[j], hi = offsets[j + 1];
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (lo != hi) {
+            const float4 f = reinterpret_cast<const float4*>(feat)[t];
+            for (unsigned s = lo; s < hi; s += 4) {
+                unsigned n[4];
+                float4 o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) n[u] = s + u < hi ? (unsigned)src[s + u] / K - first : 0xffffffffu;  // src: flat (point * K + k) positions
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (n[u] < m_cloud) o[u] = out4[(mbase + n[u]) * d4 + q];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (n[u] >= m_cloud) break;  // (ascending: the rest of the segment is not part of the pooling table)
+                    if (o[u].x == f.x || o[u].y == f.y || o[u].z == f.z || o[u].w == f.w) {
+                        const unsigned e = (mbase + n[u]) * d4 + q;
+                        const float4 g = dout4[e];
+                        const uchar4 c = ties4[e];
+                        if (o[u].x == f.x) acc.x += g.x / (float)c.x;
+                        if (o[u].y == f.y) acc.y += g.y / (float)c.y;
+                        if (o[u].z == f.z) acc.z += g.z / (float)c.z;
+                        if (o[u].w == f.w) acc.w += g.w / (float)c.w;
+                    }
+                }
+                if (n[3] >= m_cloud) break;
+            }
+        }
+        float4* dst = reinterpret_cast<float4*>(dfeat) + t;
+        if (overwrite) {
+            *dst = acc;
+        } else if (lo != hi) {
+            float4 h = *dst;
+            h.x += acc.x; h.y += acc.y; h.z += acc.z; h.w += acc.w;
+            *dst = h;
+        }
+    }
+}
+
 static inline unsigned iv_grid(int64_t n)
 {
     const int64_t b = (n + 255) / 256;
@@ -474,7 +578,7 @@ using namespace ps;
 
 extern "C" {
 
-static constexpr int64_t kInvSortRows = 1 << 16;  // tables of at least this many rows are inverted by the bucket pass (or, when its plan does not fit, the radix sort)
+static constexpr int64_t kInvSortRows = 1 << 11;  // tables of at least this many rows are inverted by the bucket pass (or, when its plan does not fit, the radix sort)
 
 // the bucket form's shape for a table, or false: more than 512 x 512 destinations per cloud, or (row inside the cloud, low id bits) past 32 bits
 static bool bk_plan(int64_t B, int64_t N, int64_t rpc, int tile, BkPlan* pl)
@@ -581,24 +685,40 @@ int ps_op_inverse_index(ps_context* c, const int32_t* idx, int64_t B, int64_t N,
     return PS_OK;
 }
 
-int ps_op_gather_reduce_rows(ps_context* c, const float* rows, int64_t ldr, const int32_t* offsets, const int32_t* src, int64_t n_dst, int64_t d, float* dst,
-                             int64_t ldd, int accumulate)
+int ps_op_gather_reduce_rows_ordered(ps_context* c, const float* rows, int64_t ldr, const int32_t* offsets, const int32_t* src, int64_t n_dst, int64_t d,
+                                     float* dst, int64_t ldd, int accumulate, const int32_t* order, int64_t n_cloud)
 {
     PS_CHECK(c && rows && offsets && src && dst, "ps_op_gather_reduce_rows: NULL argument");
     PS_CHECK(n_dst >= 0 && d >= 1 && ldr >= d && ldd >= d, "ps_op_gather_reduce_rows: bad shape");
+    PS_CHECK(!order || (n_cloud >= 1 && n_dst % n_cloud == 0), "ps_op_gather_reduce_rows_ordered: n_dst must be a multiple of n_cloud");
     if (!n_dst) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_scatter_add", 1);
     const bool vec = (d % 4) == 0 && (ldr % 4) == 0 && (ldd % 4) == 0 && ((reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     const unsigned* off = reinterpret_cast<const unsigned*>(offsets);
-    if (vec)
+    static const bool ordered_on = !(getenv("PS_GATHER_REDUCE_ORDERED") && atoi(getenv("PS_GATHER_REDUCE_ORDERED")) == 0);  // (A/B switch)
+    const int64_t per = d / 4;
+    if (order && ordered_on && vec && per >= 1 && per <= 256 && 256 % per == 0 && n_dst < (1ll << 31)) {
+        const int64_t dpw = 256 / per;
+        int64_t wgs = ceil_div(n_dst, dpw);
+        wgs = std::min<int64_t>((wgs + 7) / 8 * 8, 8 * 2048);
+        hipLaunchKernelGGL(gather_reduce_ordered_kernel, dim3((unsigned)wgs), dim3(256), 0, c->stream, rows, ldr, off, src, order, (unsigned)n_dst, (unsigned)n_cloud,
+                           (unsigned)per, dst, ldd, accumulate);
+    } else if (vec) {
         hipLaunchKernelGGL(gather_reduce_kernel<true>, dim3(iv_grid(n_dst * (d / 4))), dim3(256), 0, c->stream, rows, ldr, off, src, n_dst, (int)d, dst, ldd,
                            accumulate);
-    else
+    } else {
         hipLaunchKernelGGL(gather_reduce_kernel<false>, dim3(iv_grid(n_dst * d)), dim3(256), 0, c->stream, rows, ldr, off, src, n_dst, (int)d, dst, ldd,
                            accumulate);
+    }
     PS_HIP(hipGetLastError());
     return PS_OK;
+}
+
+int ps_op_gather_reduce_rows(ps_context* c, const float* rows, int64_t ldr, const int32_t* offsets, const int32_t* src, int64_t n_dst, int64_t d, float* dst,
+                             int64_t ldd, int accumulate)
+{
+    return ps_op_gather_reduce_rows_ordered(c, rows, ldr, offsets, src, n_dst, d, dst, ldd, accumulate, nullptr, 0);
 }
 
 int ps_op_random_sample_bwd_inv(ps_context* c, const float* dout, const float* out, const float* feature, const int32_t* pool_idx, const int32_t* offsets,
@@ -613,9 +733,21 @@ int ps_op_random_sample_bwd_inv(ps_context* c, const float* dout, const float* o
     const bool al16 = ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(feature) |
                         reinterpret_cast<uintptr_t>(dfeature)) & 15) == 0 && (reinterpret_cast<uintptr_t>(ties) & 3) == 0;
     if (ties && d % 4 == 0 && al16 && B * N * d < (1ll << 32) && B * N * K < (1ll << 31)) {
-        hipLaunchKernelGGL(maxpool_bwd_inv4_kernel, dim3(iv_grid(B * N * (d / 4))), dim3(256), 0, c->stream, dout, ties, out, feature,
-                           reinterpret_cast<const unsigned*>(offsets), src, (unsigned)(B * N), (unsigned)N, (unsigned)M, (unsigned)K, (unsigned)(d / 4), dfeature,
-                           c->pool_bwd_overwrite ? 1 : 0);
+        static const int mode = getenv("PS_MAXPOOL_BWD_ORDERED") ? atoi(getenv("PS_MAXPOOL_BWD_ORDERED")) : 1;  // (A/B: 0 = the one-entry cloud-order walk)
+        const int64_t d4 = d / 4;
+        if (mode && d4 <= 256 && 256 % d4 == 0) {
+            // (c->walk_order: the trainer's hint for the op it is about to enqueue -- the leaf order of the N points of this level, or NULL)
+            const int32_t* order = c->walk_order && c->walk_order_n == N ? c->walk_order : nullptr;
+            const int64_t dpw = 256 / d4;
+            const int64_t wgs = std::min<int64_t>((ceil_div(B * N, dpw) + 7) / 8 * 8, 8 * 4096);
+            hipLaunchKernelGGL(maxpool_bwd_inv4_ordered_kernel, dim3((unsigned)wgs), dim3(256), 0, c->stream, dout, ties, out, feature,
+                               reinterpret_cast<const unsigned*>(offsets), src, order, (unsigned)(B * N), (unsigned)N, (unsigned)M, (unsigned)K, (unsigned)d4,
+                               dfeature, c->pool_bwd_overwrite ? 1 : 0);
+        } else {
+            hipLaunchKernelGGL(maxpool_bwd_inv4_kernel, dim3(iv_grid(B * N * (d / 4))), dim3(256), 0, c->stream, dout, ties, out, feature,
+                               reinterpret_cast<const unsigned*>(offsets), src, (unsigned)(B * N), (unsigned)N, (unsigned)M, (unsigned)K, (unsigned)(d / 4),
+                               dfeature, c->pool_bwd_overwrite ? 1 : 0);
+        }
         PS_HIP(hipGetLastError());
         return PS_OK;
     }

@@ -177,7 +177,10 @@ static int colreduce2(ps_context* c, F f, int64_t R, int C, float* out0, float* 
         if (out1) PS_HIP(hipMemsetAsync(out1, 0, sizeof(float) * C, c->stream));
         return PS_OK;
     }
-    int64_t blocks = (R * C + 256 * 64 - 1) / (256 * 64);
+    // (4 096 elements per block while that keeps the grid within 2 048 blocks: a thread's walk is a chain of dependent round trips -- two
+    //  16-byte loads per trip -- and the small layers of a one-cloud step spent 8 of them per launch: 10.4 us floor for the BatchNorm
+    //  backward sums at 16 384 elements per block)
+    int64_t blocks = (R * C + 256 * 16 - 1) / (256 * 16);
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
     if ((256 % C) != 0) blocks = blocks > 512 ? 512 : blocks;
     const int rpb = (int)((R + blocks - 1) / blocks);
@@ -1036,12 +1039,48 @@ int64_t wgrad_split_slabs(ps_context* c, const float* xl, int64_t ldxl, const in
 // gradient of a training step is finished by ONE launch; transposed: dst is [cols][rows] (the conv2d_transpose kernels, stored [out, in])
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradJob* __restrict__ jobs)
 {
-    // 64 elements per workgroup pass, the slabs dealt over 4 thread groups x 4 accumulators (slab b goes to group b % 4, accumulator
-    // (b / 4) % 4): sixteen independent load chains per element instead of one `slabs`-long chain (768 slabs for a small matrix), and
-    // still one fixed summation order
     __shared__ float red[4][64];
     const WgradJob j = jobs[blockIdx.y];
     const int64_t n = (int64_t)j.rows * j.cols;
+    if (j.slabs <= 16 && (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(j.part) | reinterpret_cast<uintptr_t>(j.dst)) & 15) == 0) {
+        // few slabs (the large matrices: most of the bytes): a thread owns four consecutive elements and walks the slabs itself, slab b into
+        // accumulator b % 4 -- 16-byte loads, four independent chains, no LDS round; one fixed summation order
+        const float4* part = reinterpret_cast<const float4*>(j.part);
+        const int64_t n4 = n >> 2;
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+            float4 a[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            int b = 0;
+            for (; b + 4 <= j.slabs; b += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 v = part[(size_t)(b + u) * n4 + e];
+                    a[u].x += v.x; a[u].y += v.y; a[u].z += v.z; a[u].w += v.w;
+                }
+            }
+            for (int u = 0; b + u < j.slabs; ++u) {
+                const float4 v = part[(size_t)(b + u) * n4 + e];
+                a[u].x += v.x; a[u].y += v.y; a[u].z += v.z; a[u].w += v.w;
+            }
+            const float4 sum = {(a[0].x + a[1].x) + (a[2].x + a[3].x), (a[0].y + a[1].y) + (a[2].y + a[3].y), (a[0].z + a[1].z) + (a[2].z + a[3].z),
+                                (a[0].w + a[1].w) + (a[2].w + a[3].w)};
+            if (j.transposed) {
+                const int64_t e1 = e << 2;
+                const int64_t r = e1 / j.cols, cc = e1 - r * j.cols;  // (cols % 4 == 0 is NOT implied by n % 4 == 0: per element)
+                const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t c1 = cc + u, rr = r + c1 / j.cols, c2 = c1 % j.cols;
+                    j.dst[c2 * j.rows + rr] = sv[u];
+                }
+            } else {
+                reinterpret_cast<float4*>(j.dst)[e] = sum;
+            }
+        }
+        return;
+    }
+    // many slabs (small matrices): 64 elements per workgroup pass, the slabs dealt over 4 thread groups x 4 accumulators (slab b goes to group
+    // b % 4, accumulator (b / 4) % 4): sixteen independent load chains per element instead of one `slabs`-long chain (768 slabs for a small
+    // matrix), and still one fixed summation order
     const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
     for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < n; e0 += (int64_t)gridDim.x * 64) {
         const int64_t e = e0 + el;

@@ -459,14 +459,25 @@ struct ps_trainer {
     struct Inv {
         Tn offsets, src;
         int64_t n_dst;
+        const int32_t* order = nullptr;  // the destinations' spatially coherent processing order (ps_pyramid.order of their level), or NULL
+        int64_t n_cloud = 0;
     };
     std::map<const int32_t*, Inv> inv_cache;
+    std::map<const int32_t*, const int32_t*> order_of;  // gather table -> leaf order of the level it gathers FROM (set per step from the pyramid)
+    void reduce_rows(const Inv& iv, const float* rows, int64_t ldr, int64_t d, float* dst, int64_t ldd, int accumulate)
+    {
+        TK(ps_op_gather_reduce_rows_ordered(c, rows, ldr, reinterpret_cast<const int32_t*>(iv.offsets.p), reinterpret_cast<const int32_t*>(iv.src.p), iv.n_dst, d, dst,
+                                            ldd, accumulate, iv.order, iv.n_cloud));
+    }
     const Inv& inverse(const int32_t* idx, int64_t B, int64_t N, int64_t rows_per_cloud)
     {
         auto it = inv_cache.find(idx);
         if (it != inv_cache.end()) return it->second;
         Inv v;
         v.n_dst = B * N;
+        v.n_cloud = N;
+        auto oo = order_of.find(idx);
+        v.order = oo != order_of.end() ? oo->second : nullptr;
         v.offsets = alloc(1, v.n_dst + 1, false);
         v.src = alloc(1, std::max<int64_t>(B * rows_per_cloud, 1), false);
         Tn ws = alloc(1, ps_op_inverse_index_workspace(v.n_dst, B * rows_per_cloud), false);
@@ -1051,8 +1062,7 @@ struct ps_trainer {
                 // first gradient of x: the gather-reduction writes every row (empty segments as zeros): no zero-filled buffer to add into
                 Tn fresh = alloc(xin.R, xin.C);
                 const Inv& iv = inverse(idx, B, N, M * K);
-                TK(ps_op_gather_reduce_rows(c, dy.p, dy.ld, reinterpret_cast<const int32_t*>(iv.offsets.p), reinterpret_cast<const int32_t*>(iv.src.p), B * N, d,
-                                            fresh.p, fresh.ld, 0));
+                reduce_rows(iv, dy.p, dy.ld, d, fresh.p, fresh.ld, 0);
                 grad_of[xin.id] = fresh;
                 return;
             }
@@ -1063,8 +1073,7 @@ struct ps_trainer {
             }
             if (opt.deterministic) {
                 const Inv& iv = inverse(idx, B, N, M * K);
-                TK(ps_op_gather_reduce_rows(c, dy.p, dy.ld, reinterpret_cast<const int32_t*>(iv.offsets.p), reinterpret_cast<const int32_t*>(iv.src.p), B * N, d,
-                                            buf.p, buf.ld, 1));
+                reduce_rows(iv, dy.p, dy.ld, d, buf.p, buf.ld, 1);
             } else {
                 TK(ps_op_scatter_add_rows_ex(c, dy.p, dy.ld, idx, B, N, M * K, d, buf.p));
             }
@@ -1174,8 +1183,7 @@ struct ps_trainer {
                 const bool fresh_src = !grad_of.count(f_src.id);  // (first gradient of f_src: written, not added into zeros)
                 Tn dsrc = fresh_src ? alloc(f_src.R, f_src.C) : accum_buffer(f_src);
                 const Inv& iv = inverse(idx, B, N, M * K);
-                TK(ps_op_gather_reduce_rows(c, rows.p, h, reinterpret_cast<const int32_t*>(iv.offsets.p), reinterpret_cast<const int32_t*>(iv.src.p), B * N, h, dsrc.p,
-                                            dsrc.ld, fresh_src ? 0 : 1));
+                reduce_rows(iv, rows.p, h, h, dsrc.p, dsrc.ld, fresh_src ? 0 : 1);
                 if (fresh_src) grad_of[f_src.id] = dsrc;
             } else {
                 Tn dsrc = accum_buffer(f_src);
@@ -1230,8 +1238,7 @@ struct ps_trainer {
                 Tn rows = alloc(B * M * K, h, false);
                 TK(ps_op_att_pool_train_bwd_split_rows(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, dy.p, K, d, rows.p, h, dfx.p, dfx.ld, gW.p));
                 const Inv& iv = inverse(idx, B, N, M * K);
-                TK(ps_op_gather_reduce_rows(c, rows.p, h, reinterpret_cast<const int32_t*>(iv.offsets.p), reinterpret_cast<const int32_t*>(iv.src.p), B * N, h,
-                                            dsrc.p, dsrc.ld, fresh_src ? 0 : 1));
+                reduce_rows(iv, rows.p, h, h, dsrc.p, dsrc.ld, fresh_src ? 0 : 1);
                 if (fresh_src) grad_of[f_src.id] = dsrc;
             } else {
                 TK(ps_op_att_pool_train_bwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, dy.p, K, d, dsrc.p, dsrc.ld, dfx.p, dfx.ld, gW.p));
@@ -1273,10 +1280,16 @@ struct ps_trainer {
             struct Flag {
                 ps_context* c;
                 Flag(ps_context* ctx, bool on) : c(ctx) { c->pool_bwd_overwrite = on; }
-                ~Flag() { c->pool_bwd_overwrite = false; }
+                ~Flag()
+                {
+                    c->pool_bwd_overwrite = false;
+                    c->walk_order = nullptr;
+                }
             } flag(c, fresh);
             if (by_inverse && buf.contiguous()) {
                 const Inv& iv = inverse(neigh, B, N, N * K);  // (shared with the level's gathers: the pooling rows are a prefix of every segment)
+                c->walk_order = iv.order;  // (the level's leaf order: the kernel walks its destinations in it, XCD by XCD)
+                c->walk_order_n = iv.n_cloud;
                 Tn share = ties ? Tn() : alloc(B * M, d, false);
                 TK(ps_op_random_sample_bwd_inv(c, dy.p, out.p, x.p, pool_idx, reinterpret_cast<const int32_t*>(iv.offsets.p),
                                                reinterpret_cast<const int32_t*>(iv.src.p), B, N, M, K, d,
@@ -1588,6 +1601,13 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
     try {
         t->pool.begin_step();
         t->pyramid_vouched = pyr->built != 0 && pyr->built == pyramid_stamp(pyr);
+        t->order_of.clear();
+        for (int i = 0; i < pyr->num_layers && t->pyramid_vouched; ++i) {  // (only orders ps_pyramid_build wrote are trusted as permutations)
+            // (a table's destinations: neigh_idx[i] / sub_idx[i] gather from level i, interp_idx[i] from level i + 1)
+            if (pyr->order[i]) t->order_of[pyr->neigh_idx[i]] = pyr->order[i];
+            if (pyr->order[i] && pyr->sub_idx[i]) t->order_of[pyr->sub_idx[i]] = pyr->order[i];
+            if (i + 1 < pyr->num_layers && pyr->order[i + 1] && pyr->interp_idx[i]) t->order_of[pyr->interp_idx[i]] = pyr->order[i + 1];
+        }
         t->forks_used = 0;
         t->coll_calls = t->coll_bytes = 0;
         t->coll_host_ms = 0.0;

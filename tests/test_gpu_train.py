@@ -1271,6 +1271,11 @@ def test_inverse_index_and_gather_reduction(oracle):
             again = base.clone()
             _lib.check(L.ps_op_gather_reduce_rows(h, p(rows), d + 4, p(off), p(src), n_dst, d, p(again), d, acc))
             assert torch.equal(out, again)
+            if d % 4 == 0:  # destinations walked in another order (the trainer: kd-tree leaf order, XCD by XCD): the same sums, bit for bit
+                perm = torch.stack([torch.randperm(N, generator=g) for _ in range(B)]).int().cuda()
+                walked = base.clone()
+                _lib.check(L.ps_op_gather_reduce_rows_ordered(h, p(rows), d + 4, p(off), p(src), n_dst, d, p(walked), d, acc, p(perm), N))
+                assert torch.equal(out, walked)
         # random_sample backward through the inverse index of the table whose first M2 rows per cloud are the pooling table (the pyramid's
         # sub_idx = neigh_idx[:, :M2]) == the atomics form on that prefix (ties included: quantised features)
         if K > 1 and M == N:
