@@ -13,6 +13,8 @@
 //   * per wave and step: 96 MFMAs (3 072 cycles) against ~180 VALU (the splits), 24 ds_read_b128, 14 global accesses.
 // Row counts need not be multiples of 128 (clamped loads, predicated stores); K % 32 == 0, N % 128 == 0.
 #include "common.h"
+
+#include <cstdlib>
 #include "mfma_tile.h"
 #include "b3_ops.h"
 
@@ -49,11 +51,11 @@ __global__ __launch_bounds__(256) void gemm_b3_pack_kernel(const float* __restri
 // RT = 32-row tiles per wave: a weight fragment read from LDS feeds RT x 6 MFMAs (RT = 1 was LDS-bandwidth bound: 24 KB of fragments
 // per wave and step against 1 536 cycles of products, twelve waves per CU)
 constexpr int kB3RT = 2;
+constexpr int64_t kB3SmallRows = 16384;  // below: one row tile per wave (gemm_b3)
 
-template <int P, bool ACC>
+template <int P, bool ACC, int RT = kB3RT>
 __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmB3Args a)
 {
-    constexpr int RT = kB3RT;
     // LDS: two buffers of one 32-K step of the workgroup's column panel: [2 chunks][4 column tiles][P planes][64 lanes] uint4 = 24 KB each (P = 3)
     __shared__ uint4 Bs[2][2 * 4 * P * 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -328,7 +330,8 @@ __global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradB3Args a)
 
 bool wgrad_b3_fits(int64_t R, int64_t cin, int64_t cout, const float* x, int64_t ldx, const float* dy, int64_t lddy)
 {
-    return R >= 16384 && R < (1ll << 40) && cin % 128 == 0 && cout % 128 == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
+    static const int64_t min_rows = getenv("PS_WGRAD_B3_MIN_ROWS") ? atoll(getenv("PS_WGRAD_B3_MIN_ROWS")) : 16384;  // (experiment switch)
+    return R >= min_rows && R < (1ll << 40) && cin % 128 == 0 && cout % 128 == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
 }
 
@@ -392,9 +395,11 @@ bool gemm_b3_fits(int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx)
     //   [360k, 256] x [256, 128] 0.177 vs 0.340 ms, [90k, 512] x [512, 256] 0.148 vs 0.279, [90k, 256] x [256, 512] 0.164 vs 0.298,
     //   [22k, 256] x [256, 512] 0.056 vs 0.085; K = 128: [1.44M, 128] x [128, 128] 0.457 vs 0.530 (1.5 GB of rows: HBM bound),
     //   [360k, 128] x [128, 256] 0.219 vs 0.289.
-    // R >= 16384: a workgroup owns 256 rows x 128 columns, so the few-row GEMMs of the deep levels leave most CUs without one ([5624, 1536]
+    // R >= 16384 (the measurements above): a workgroup owns 256 rows x 128 columns, so the few-row GEMMs of the deep levels leave most CUs without one ([5624, 1536]
     // x [1536, 512] 0.276 ms here against 0.125 on the split-K fp32 kernel, [5624, 512] x [512, 256] 0.078 against 0.024)
-    return R >= 16384 && K >= 128 && K % 32 == 0 && N % 128 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && R < (1ll << 31);
+    // (8 192 <= R < 16 384 runs the 128-row workgroup form: one-cloud step 8.05 -> 7.97 ms; 4 096: 7.99, 2 048: 8.12)
+    static const int64_t min_rows = getenv("PS_GEMM_B3_MIN_ROWS") ? atoll(getenv("PS_GEMM_B3_MIN_ROWS")) : 8192;  // (experiment switch)
+    return R >= min_rows && K >= 128 && K % 32 == 0 && N % 128 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && R < (1ll << 31);
 }
 
 size_t gemm_b3_plane_bytes(int64_t K, int64_t N) { return (size_t)K * N * 6; }
@@ -430,15 +435,24 @@ int gemm_b3(ps_context* c, const float* x, int64_t ldx, const float* w, int64_t 
     GemmB3Args a;
     a.x = x; a.ldx = (int)ldx; a.wp = static_cast<const uint4*>(planes); a.bias = bias; a.y = y; a.ldy = (int)ldy;
     a.R = (int)R; a.K = (int)K; a.N = (int)N; a.leaky = leaky; a.accum = accumulate ? 1 : 0;
-    const int64_t rows_wg = 128 * kB3RT;
+    // few rows (the deep levels of a one-cloud step): 128-row workgroups -- twice as many of them; with many rows that form is bound by the
+    // LDS reads of the weight fragments (kB3RT)
+    const bool small = R < kB3SmallRows;
+    const int64_t rows_wg = small ? 128 : 128 * kB3RT;
     const int64_t blocks = ((R + rows_wg - 1) / rows_wg) * (N / 128);
+#define PS_B3_LAUNCH(P_, ACC_)                                                                                                          \
+    do {                                                                                                                                \
+        if (small) hipLaunchKernelGGL((gemm_b3_kernel<P_, ACC_, 1>), dim3((unsigned)blocks), dim3(256), 0, c->stream, a);               \
+        else hipLaunchKernelGGL((gemm_b3_kernel<P_, ACC_, kB3RT>), dim3((unsigned)blocks), dim3(256), 0, c->stream, a);                 \
+    } while (0)
     if (one) {
-        if (a.accum) hipLaunchKernelGGL((gemm_b3_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL((gemm_b3_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
+        if (a.accum) PS_B3_LAUNCH(1, true);
+        else PS_B3_LAUNCH(1, false);
     } else {
-        if (a.accum) hipLaunchKernelGGL((gemm_b3_kernel<3, true>), dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL((gemm_b3_kernel<3, false>), dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
+        if (a.accum) PS_B3_LAUNCH(3, true);
+        else PS_B3_LAUNCH(3, false);
     }
+#undef PS_B3_LAUNCH
     PS_HIP(hipGetLastError());
     return PS_OK;
 }

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void pack_batch_ops_kernel(const PackJob* __re
 int pack_batch_ops(ps_context* c, const PackJob* table, int n)
 {
     if (n <= 0) return PS_OK;
-    hipLaunchKernelGGL(pack_batch_ops_kernel, dim3(64, (unsigned)n), dim3(256), 0, c->stream, table);
+    hipLaunchKernelGGL(pack_batch_ops_kernel, dim3(256, (unsigned)n), dim3(256), 0, c->stream, table);
     PS_HIP(hipGetLastError());
     return PS_OK;
 }

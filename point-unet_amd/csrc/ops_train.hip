@@ -1078,30 +1078,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradJob* __res
         }
         return;
     }
-    // many slabs (small matrices): 64 elements per workgroup pass, the slabs dealt over 4 thread groups x 4 accumulators (slab b goes to group
-    // b % 4, accumulator (b / 4) % 4): sixteen independent load chains per element instead of one `slabs`-long chain (768 slabs for a small
-    // matrix), and still one fixed summation order
-    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < n; e0 += (int64_t)gridDim.x * 64) {
+    // many slabs (small matrices under millions of rows: 768 slabs for the 8 x 8 layers of level 0): 16 elements per workgroup pass, the slabs
+    // dealt over 16 thread groups x 4 accumulators (slab b goes to group b % 16, accumulator (b / 16) % 4): 64 independent load chains per
+    // element -- 12 dependent round trips for 768 slabs, where 4 groups took 48 (the whole launch waited for these few workgroups: 112 us
+    // of a one-cloud step) -- and still one fixed summation order
+    const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    float (*red16)[16] = reinterpret_cast<float (*)[16]>(&red[0][0]);  // [16 groups][16 elements]
+    for (int64_t e0 = (int64_t)blockIdx.x * 16; e0 < n; e0 += (int64_t)gridDim.x * 16) {
         const int64_t e = e0 + el;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         if (e < n) {
             int b = grp;
-            for (; b + 12 < j.slabs; b += 16) {
+            for (; b + 48 < j.slabs; b += 64) {
                 a0 += j.part[(size_t)b * n + e];
-                a1 += j.part[(size_t)(b + 4) * n + e];
-                a2 += j.part[(size_t)(b + 8) * n + e];
-                a3 += j.part[(size_t)(b + 12) * n + e];
+                a1 += j.part[(size_t)(b + 16) * n + e];
+                a2 += j.part[(size_t)(b + 32) * n + e];
+                a3 += j.part[(size_t)(b + 48) * n + e];
             }
             if (b < j.slabs) a0 += j.part[(size_t)b * n + e];
-            if (b + 4 < j.slabs) a1 += j.part[(size_t)(b + 4) * n + e];
-            if (b + 8 < j.slabs) a2 += j.part[(size_t)(b + 8) * n + e];
+            if (b + 16 < j.slabs) a1 += j.part[(size_t)(b + 16) * n + e];
+            if (b + 32 < j.slabs) a2 += j.part[(size_t)(b + 32) * n + e];
         }
         __syncthreads();
-        red[grp][el] = (a0 + a1) + (a2 + a3);
+        red16[grp][el] = (a0 + a1) + (a2 + a3);
         __syncthreads();
         if (grp == 0 && e < n) {
-            const float sum = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+            float sum = 0.f;
+#pragma unroll
+            for (int g4 = 0; g4 < 16; g4 += 4) sum += (red16[g4][el] + red16[g4 + 1][el]) + (red16[g4 + 2][el] + red16[g4 + 3][el]);
             if (j.transposed) {
                 const int64_t r = e / j.cols, cc = e - r * j.cols;
                 j.dst[cc * j.rows + r] = sum;
@@ -1115,7 +1119,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradJob* __res
 int wgrad_finish(ps_context* c, const WgradJob* d_jobs, int n_jobs, int64_t max_elems)
 {
     if (n_jobs <= 0) return PS_OK;
-    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((max_elems + 63) / 64, 256));
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((max_elems + 15) / 16, 256));
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, (unsigned)n_jobs), dim3(256), 0, c->stream, d_jobs);
     PS_HIP(hipGetLastError());
     return PS_OK;
