@@ -338,7 +338,8 @@ bool wgrad_b3_fits(int64_t R, int64_t cin, int64_t cout, const float* x, int64_t
 static void wgrad_b3_plan(int64_t R, int64_t cin, int64_t cout, int64_t& rows_per_slab, int64_t& slabs)
 {
     const int64_t blocks = (cin / 128) * (cout / 128);
-    int64_t want = 768 / blocks;  // ~3 workgroups per CU
+    static const int64_t total = getenv("PS_WGRAD_WGS") ? atoll(getenv("PS_WGRAD_WGS")) : 512;  // (768 / 512 / 384 / 256 measured: one-cloud step 8.03 / 7.95 / 7.96 / 8.17 ms, batch 8: 39.0 / 38.1 / 38.8 / 39.3 -- every slab is a partial the finish reads back)
+    int64_t want = total / blocks;  // ~2 workgroups per CU
     want = want < 1 ? 1 : want;
     rows_per_slab = (R + want - 1) / want;
     rows_per_slab = ((rows_per_slab + 31) / 32) * 32;

@@ -284,20 +284,35 @@ __global__ void bn_finish_stats_kernel(const float* __restrict__ sum, const floa
 constexpr int64_t kBnSliceRows = 4096;  // (11 250 rows measured SLOWER than three launches: 9.74 against 8.65 ms per one-cloud step)
 constexpr int kBnSliceThreads = 1024;
 
-__device__ __forceinline__ void bn_slice_reduce(float (&a)[4], float (&b)[4], float (*red)[8])
+// A workgroup owns 32 channels = ONE 128-byte line of every row: thread t reads channels 4 (t & 7) .. + 3 of rows t >> 3, + 128, ...  (the
+// first form gave a workgroup four channels: 16 bytes of a line per row, every line fetched by eight workgroups -- 29 us per launch for the
+// few-thousand-row layers it exists for).  Sums in a fixed order: a shuffle tree over the eight row slots of a wave that share a channel
+// quad, then the sixteen wave totals in wave order -- one workgroup barrier.
+constexpr int kBnSliceCh = 32;
+__device__ __forceinline__ void bn_slice_reduce(float (&a)[4], float (&b)[4], float (*red)[8][8])
 {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cq = lane & 7;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { red[threadIdx.x][j] = a[j]; red[threadIdx.x][4 + j] = b[j]; }
-    __syncthreads();
-    for (int o = kBnSliceThreads / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
+    for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) red[threadIdx.x][j] += red[threadIdx.x + o][j];
+        for (int o = 32; o >= 8; o >>= 1) {
+            a[j] += __shfl_down(a[j], o);
+            b[j] += __shfl_down(b[j], o);
         }
-        __syncthreads();
     }
+    if (lane < 8) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { a[j] = red[0][j]; b[j] = red[0][4 + j]; }
+        for (int j = 0; j < 4; ++j) { red[wave][cq][j] = a[j]; red[wave][cq][4 + j] = b[j]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < kBnSliceThreads / 64; ++w) { s += red[w][cq][j]; q += red[w][cq][4 + j]; }
+        a[j] = s;
+        b[j] = q;
+    }
 }
 
 __global__ __launch_bounds__(kBnSliceThreads) void bn_slice_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, int R,
@@ -305,13 +320,20 @@ __global__ __launch_bounds__(kBnSliceThreads) void bn_slice_fwd_kernel(const flo
                                                            float* __restrict__ invstd, float* __restrict__ var, float* __restrict__ sums,
                                                            float* __restrict__ mov_mean, float* __restrict__ mov_var, float momentum)
 {
-    __shared__ float red[kBnSliceThreads][8];
-    const int c0 = 4 * blockIdx.x;
+    __shared__ float red[kBnSliceThreads / 64][8][8];
+    const int c0 = kBnSliceCh * blockIdx.x + 4 * (threadIdx.x & 7), r0 = threadIdx.x >> 3;
+    constexpr int RS = kBnSliceThreads / 8;  // row slots
     float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = threadIdx.x; r < R; r += kBnSliceThreads) {
-        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0);
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-        q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+    // (eight rows per trip: a thread's walk is a chain of dependent round trips -- one row per trip is 32 of them for 4 096 rows)
+    for (int r = r0; r < R; r += 8 * RS) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = r + u * RS < R ? *reinterpret_cast<const float4*>(x + (size_t)(r + u * RS) * C + c0) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w;
+            q[0] += v[u].x * v[u].x; q[1] += v[u].y * v[u].y; q[2] += v[u].z * v[u].z; q[3] += v[u].w * v[u].w;
+        }
     }
     bn_slice_reduce(s, q, red);
     float m[4], is[4], ga[4], be[4];
@@ -323,7 +345,7 @@ __global__ __launch_bounds__(kBnSliceThreads) void bn_slice_fwd_kernel(const flo
         is[j] = rsqrtf(v + eps);
         ga[j] = gamma[c0 + j];
         be[j] = beta[c0 + j];
-        if (threadIdx.x == 0) {
+        if (threadIdx.x < 8) {
             mean[c0 + j] = m[j];
             var[c0 + j] = v;
             invstd[c0 + j] = is[j];
@@ -334,15 +356,20 @@ __global__ __launch_bounds__(kBnSliceThreads) void bn_slice_fwd_kernel(const flo
             }
         }
     }
-    for (int r = threadIdx.x; r < R; r += kBnSliceThreads) {
-        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0);
-        float z[4] = {v.x, v.y, v.z, v.w};
+    for (int r = r0; r < R; r += 8 * RS) {
+        float4 v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            z[j] = ga[j] * ((z[j] - m[j]) * is[j]) + be[j];
-            if (leaky && z[j] < 0.f) z[j] *= 0.2f;
+        for (int u = 0; u < 8; ++u) v[u] = r + u * RS < R ? *reinterpret_cast<const float4*>(x + (size_t)(r + u * RS) * C + c0) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float z[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                z[j] = ga[j] * ((z[j] - m[j]) * is[j]) + be[j];
+                if (leaky && z[j] < 0.f) z[j] *= 0.2f;
+            }
+            if (r + u * RS < R) *reinterpret_cast<float4*>(y + (size_t)(r + u * RS) * ldy + c0) = float4{z[0], z[1], z[2], z[3]};
         }
-        *reinterpret_cast<float4*>(y + (size_t)r * ldy + c0) = float4{z[0], z[1], z[2], z[3]};
     }
 }
 
@@ -350,41 +377,61 @@ __global__ __launch_bounds__(kBnSliceThreads) void bn_slice_bwd_kernel(const flo
                                                            const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            int R, int C, int leaky, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta)
 {
-    __shared__ float red[kBnSliceThreads][8];
-    const int c0 = 4 * blockIdx.x;
+    __shared__ float red[kBnSliceThreads / 64][8][8];
+    const int c0 = kBnSliceCh * blockIdx.x + 4 * (threadIdx.x & 7), r0 = threadIdx.x >> 3;
+    constexpr int RS = kBnSliceThreads / 8;
     float m[4], is[4], ga[4], be[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { m[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j]; }
     float sg[4] = {0.f, 0.f, 0.f, 0.f}, sgx[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = threadIdx.x; r < R; r += kBnSliceThreads) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0), gv = *reinterpret_cast<const float4*>(dy + (size_t)r * lddy + c0);
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-        float g[4] = {gv.x, gv.y, gv.z, gv.w};
+    const float4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < R; r += 4 * RS) {
+        float4 xv[4], gv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float xh = (xs[j] - m[j]) * is[j];
-            if (leaky && ga[j] * xh + be[j] < 0.f) g[j] *= 0.2f;
-            sg[j] += g[j];
-            sgx[j] += g[j] * xh;
+        for (int u = 0; u < 4; ++u) {
+            const bool in = r + u * RS < R;
+            xv[u] = in ? *reinterpret_cast<const float4*>(x + (size_t)(r + u * RS) * C + c0) : zero4;
+            gv[u] = in ? *reinterpret_cast<const float4*>(dy + (size_t)(r + u * RS) * lddy + c0) : zero4;  // (g = 0: adds nothing)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            float g[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xs[j] - m[j]) * is[j];
+                if (leaky && ga[j] * xh + be[j] < 0.f) g[j] *= 0.2f;
+                sg[j] += g[j];
+                sgx[j] += g[j] * xh;
+            }
         }
     }
     bn_slice_reduce(sg, sgx, red);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 8) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { dbeta[c0 + j] = sg[j]; dgamma[c0 + j] = sgx[j]; }
     }
     const float invR = 1.0f / (float)R;
-    for (int r = threadIdx.x; r < R; r += kBnSliceThreads) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0), gv = *reinterpret_cast<const float4*>(dy + (size_t)r * lddy + c0);
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-        float g[4] = {gv.x, gv.y, gv.z, gv.w};
+    for (int r = r0; r < R; r += 4 * RS) {
+        float4 xv[4], gv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float xh = (xs[j] - m[j]) * is[j];
-            if (leaky && ga[j] * xh + be[j] < 0.f) g[j] *= 0.2f;
-            g[j] = ga[j] * is[j] * (g[j] - sg[j] * invR - xh * sgx[j] * invR);
+        for (int u = 0; u < 4; ++u) {
+            const bool in = r + u * RS < R;
+            xv[u] = in ? *reinterpret_cast<const float4*>(x + (size_t)(r + u * RS) * C + c0) : zero4;
+            gv[u] = in ? *reinterpret_cast<const float4*>(dy + (size_t)(r + u * RS) * lddy + c0) : zero4;
         }
-        *reinterpret_cast<float4*>(dx + (size_t)r * C + c0) = float4{g[0], g[1], g[2], g[3]};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            float g[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xs[j] - m[j]) * is[j];
+                if (leaky && ga[j] * xh + be[j] < 0.f) g[j] *= 0.2f;
+                g[j] = ga[j] * is[j] * (g[j] - sg[j] * invR - xh * sgx[j] * invR);
+            }
+            if (r + u * RS < R) *reinterpret_cast<float4*>(dx + (size_t)(r + u * RS) * C + c0) = float4{g[0], g[1], g[2], g[3]};
+        }
     }
 }
 
@@ -394,7 +441,7 @@ static bool bn_slice_ok(int64_t R, int64_t C, const void* x, const void* y, int6
     // (8.56 against 8.61 ms; with 11 250-row layers included 9.74) -- the step's small kernels already run back to back, a launch less is
     // not time less.  PS_BN_SLICE=1 switches it on for A/B.
     static const bool on = [] { const char* e = getenv("PS_BN_SLICE"); return e ? atoi(e) != 0 : false; }();
-    return on && R <= kBnSliceRows && C % 4 == 0 && ldy % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    return on && R <= kBnSliceRows && C % kBnSliceCh == 0 && ldy % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
 }
 
 // Elementwise BatchNorm kernels.  VEC: float4 per thread with a grid stride that is a multiple of C (1024 % C == 0), so a
@@ -679,8 +726,9 @@ static void wgrad_slabs(int64_t R, int cin, int cout, int64_t& rpb, int64_t& nb)
     constexpr int CI = TI * (4 / WK) * 16, CJ = TJ * 16;
     constexpr int kWgChunk = wg_chunk(CI + CJ) > 16 * WK ? wg_chunk(CI + CJ) : 16 * WK;  // >= either flavour's chunk
     const int ty = (cin + CI - 1) / CI, tz = (cout + CJ - 1) / CJ;
-    // ~3 workgroups per CU; fewer, longer slabs when the dW block is large (every slab is a [cin, cout] partial the reduction reads back)
-    int64_t slabs = 768 / ((int64_t)ty * tz);
+    // ~2 workgroups per CU; fewer, longer slabs when the dW block is large (every slab is a [cin, cout] partial the reduction reads back)
+    static const int64_t total = getenv("PS_WGRAD_WGS") ? atoll(getenv("PS_WGRAD_WGS")) : 512;  // (768 / 512 / 384 / 256 measured: one-cloud step 8.03 / 7.95 / 7.96 / 8.17 ms, batch 8: 39.0 / 38.1 / 38.8 / 39.3 -- every slab is a partial the finish reads back)
+    int64_t slabs = total / ((int64_t)ty * tz);
     slabs = slabs < 1 ? 1 : slabs;
     rpb = (R + slabs - 1) / slabs;
     rpb = ((rpb + kWgChunk - 1) / kWgChunk) * kWgChunk;
@@ -1169,7 +1217,7 @@ int ps_op_bn_train_fwd_ex(ps_context* c, const float* x, const float* gamma, con
     PS_HIP(hipSetDevice(c->device));
     if (bn_slice_ok(R, C, x, y, ldy)) {
         Stage st1(c, "train_bn_fwd", 1);
-        hipLaunchKernelGGL(bn_slice_fwd_kernel, dim3((unsigned)(C / 4)), dim3(kBnSliceThreads), 0, c->stream, x, gamma, beta, (int)R, (int)C, eps, leaky, y, ldy, mean, invstd,
+        hipLaunchKernelGGL(bn_slice_fwd_kernel, dim3((unsigned)(C / kBnSliceCh)), dim3(kBnSliceThreads), 0, c->stream, x, gamma, beta, (int)R, (int)C, eps, leaky, y, ldy, mean, invstd,
                            var, scratch2C, static_cast<float*>(nullptr), static_cast<float*>(nullptr), 0.f);
         PS_HIP(hipGetLastError());
         return PS_OK;
@@ -1195,7 +1243,7 @@ int ps_op_bn_train_fwd_mov(ps_context* c, const float* x, const float* gamma, co
     PS_HIP(hipSetDevice(c->device));
     if (bn_slice_ok(R, C, x, y, ldy)) {
         Stage st1(c, "train_bn_fwd", 1);
-        hipLaunchKernelGGL(bn_slice_fwd_kernel, dim3((unsigned)(C / 4)), dim3(kBnSliceThreads), 0, c->stream, x, gamma, beta, (int)R, (int)C, eps, leaky, y, ldy, mean, invstd,
+        hipLaunchKernelGGL(bn_slice_fwd_kernel, dim3((unsigned)(C / kBnSliceCh)), dim3(kBnSliceThreads), 0, c->stream, x, gamma, beta, (int)R, (int)C, eps, leaky, y, ldy, mean, invstd,
                            var, scratch2C, moving_mean, moving_var, momentum);
         PS_HIP(hipGetLastError());
         return PS_OK;
@@ -1227,7 +1275,7 @@ int ps_op_bn_train_bwd_ex(ps_context* c, const float* dy, int64_t lddy, const fl
     PS_HIP(hipSetDevice(c->device));
     if (R >= 1 && bn_slice_ok(R, C, x, dy, lddy) && (reinterpret_cast<uintptr_t>(dx) & 15) == 0) {
         Stage st1(c, "train_bn_bwd", 1);
-        hipLaunchKernelGGL(bn_slice_bwd_kernel, dim3((unsigned)(C / 4)), dim3(kBnSliceThreads), 0, c->stream, dy, lddy, x, gamma, beta, mean, invstd, (int)R, (int)C, leaky, dx,
+        hipLaunchKernelGGL(bn_slice_bwd_kernel, dim3((unsigned)(C / kBnSliceCh)), dim3(kBnSliceThreads), 0, c->stream, dy, lddy, x, gamma, beta, mean, invstd, (int)R, (int)C, leaky, dx,
                            dgamma, dbeta);
         PS_HIP(hipGetLastError());
         return PS_OK;

@@ -520,6 +520,10 @@ struct ps_trainer {
         TK(c->upload_async(table.p, wjobs.data(), sizeof(WgradJob) * wjobs.size()));
         int64_t most = 1;
         for (const WgradJob& j : wjobs) most = std::max<int64_t>(most, (int64_t)j.rows * j.cols);
+        if (getenv("PS_WGRAD_DEBUG") && step < 1)
+            for (const WgradJob& j : wjobs)
+                fprintf(stderr, "wgrad job: slabs %d rows %d cols %d transposed %d part%%16 %d dst%%16 %d\n", j.slabs, j.rows, j.cols, j.transposed,
+                        (int)(reinterpret_cast<uintptr_t>(j.part) & 15), (int)(reinterpret_cast<uintptr_t>(j.dst) & 15));
         TK(wgrad_finish(c, reinterpret_cast<const WgradJob*>(table.p), (int)wjobs.size(), most));
         wjobs.clear();
         wkeep.clear();
