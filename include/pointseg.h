@@ -292,7 +292,8 @@ typedef struct {
     int32_t act_bf16;               /* with mlp_bf16: the [N*K, h] activation rows of the LFA branch (the LocSE output and LFA mlp2's, RandLANet.py:325,
                                      * 331) are STORED as bfloat16 at the levels whose kernels read them that way (h = 8 / 32 / 64: levels 0-2 of the
                                      * BraTS network) -- what that mode's products round them to anyway; the weighted sum of att_pooling and the
-                                     * 8-channel convolution then see the rounded values too (ps_set_train_act_bf16, pointseg_train_ops.h) */
+                                     * 8-channel convolution then see the rounded values too -- and so are the rows of their GRADIENTS
+                                     * (ps_set_train_act_bf16, pointseg_train_ops.h) */
 } ps_train_options;
 /* In-place sum over the ranks of `count` elements at device pointer `buf` (dtype 0: float32, 1: float64), ordered on `hip_stream`
  * (the context's stream).  Returns 0 on success. */

@@ -32,8 +32,8 @@ def _rb(t):
 
 
 class _StoreRounded(torch.autograd.Function):
-    """A tensor STORED as bfloat16 (ps_train_options.act_bf16): consumers see the rounded value, its gradient passes through unchanged
-    (the producer's backward is computed against the value it stored)."""
+    """A tensor STORED as bfloat16 (ps_train_options.act_bf16): consumers see the rounded value, and the rows of its GRADIENT are stored
+    in the same format -- the producer's backward reads bfloat16(dy)."""
 
     @staticmethod
     def forward(ctx, x):
@@ -41,7 +41,22 @@ class _StoreRounded(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        return dy
+        return _rb(dy)
+
+
+class _StoreRoundedFork(torch.autograd.Function):
+    """The same for a stored tensor with TWO consumers (f_xyz: the first pooling and LFA mlp2, RandLANet.py:328-331): returns the rounded
+    value twice; the gradient buffer is written by the convolution's backward (second output) and the pooling's backward then adds into
+    the stored rows: bfloat16(bfloat16(g_conv) + g_pool)  (csrc/trainer.hip attpool_split / conv_bn_fused)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        r = _rb(x)
+        return r, r.clone()
+
+    @staticmethod
+    def backward(ctx, g_pool, g_conv):
+        return _rb(_rb(g_conv) + g_pool)
 
 
 class _RoundedLinear(torch.autograd.Function):
@@ -111,9 +126,10 @@ def _graph(P, num_layers, xyz, neigh_idx, sub_idx, interp_idx, features, dtype, 
         f_pc = conv(X, n + "mlp1")
         f_xyz = conv(enc10, n + "LFAmlp1")
         stored16 = act_rule is not None and bool(act_rule(f_xyz.shape[-1]))  # the level's [N, K, h] rows are stored as bfloat16
+        f_xyz_pool = f_xyz
         if stored16:
-            f_xyz = _StoreRounded.apply(f_xyz)
-        f_agg = att(torch.cat([gather(f_pc, idx), f_xyz], -1), n + "LFAatt_pooling_1")
+            f_xyz_pool, f_xyz = _StoreRoundedFork.apply(f_xyz)
+        f_agg = att(torch.cat([gather(f_pc, idx), f_xyz_pool], -1), n + "LFAatt_pooling_1")
         f_xyz = conv(f_xyz, n + "LFAmlp2")
         if stored16:
             f_xyz = _StoreRounded.apply(f_xyz)

@@ -179,6 +179,16 @@ struct RowStore {
                     dst = reinterpret_cast<float4*>(drow + (row * (unsigned)a.lddf + 4u * q));
                 } else if (q < (unsigned)QH) {
                     dst = reinterpret_cast<float4*>(lrow + (row * (unsigned)a.ld_rows + 4u * q));
+                } else if (a.fr_bf16) {
+                    // the f_xyz half's gradient has the format of the f_xyz rows (ps_set_train_act_bf16): bfloat16, lddf in elements; a second
+                    // gradient of the same tensor is added to the stored (rounded) value and the sum is rounded again
+                    uint2* d16 = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.df) + ((size_t)p * KN * a.lddf + (row * (unsigned)a.lddf + 4u * (q - QH))));
+                    if (a.df_accum) {
+                        const float4 h = unpack_bf16x4(*d16);
+                        o.x += h.x; o.y += h.y; o.z += h.z; o.w += h.w;
+                    }
+                    *d16 = pack_bf16x4(o);
+                    continue;
                 } else {
                     dst = reinterpret_cast<float4*>(drow + (row * (unsigned)a.lddf + 4u * (q - QH)));
                     if (a.df_accum) {
@@ -372,7 +382,13 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
                 for (int r = 0; r < 4; ++r) a.df[(size_t)(p * KN + 4 * g + r) * a.lddf + tj * 16 + c16] = acc[r];
             } else {
                 const int col = tj * 16 + c16;
-                if (col >= D / 2) {  // f_xyz half: plain rows
+                if (col >= D / 2 && a.fr_bf16) {  // f_xyz half as bfloat16 rows (the float-atomic scatter form: element by element)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        __bf16* q = reinterpret_cast<__bf16*>(a.df) + (size_t)(p * KN + 4 * g + r) * a.lddf + col - D / 2;
+                        *q = (__bf16)(a.df_accum ? (float)*q + acc[r] : acc[r]);
+                    }
+                } else if (col >= D / 2) {  // f_xyz half: plain rows
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float* q = a.df + (size_t)(p * KN + 4 * g + r) * a.lddf + col - D / 2;
@@ -618,7 +634,13 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
                 for (int r = 0; r < 4; ++r) a.df[(size_t)(p * KN + 4 * g + r) * a.lddf + tj * 16 + c16] = acc[r];
             } else {
                 const int col = tj * 16 + c16;
-                if (col >= D / 2) {  // f_xyz half: plain rows
+                if (col >= D / 2 && a.fr_bf16) {  // f_xyz half as bfloat16 rows (the float-atomic scatter form: element by element)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        __bf16* q = reinterpret_cast<__bf16*>(a.df) + (size_t)(p * KN + 4 * g + r) * a.lddf + col - D / 2;
+                        *q = (__bf16)(a.df_accum ? (float)*q + acc[r] : acc[r]);
+                    }
+                } else if (col >= D / 2) {  // f_xyz half: plain rows
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float* q = a.df + (size_t)(p * KN + 4 * g + r) * a.lddf + col - D / 2;
@@ -867,6 +889,14 @@ __global__ __launch_bounds__(GROUPS * 256) void att_train_bwd_bf16_cs_kernel(Att
                     dst = reinterpret_cast<float4*>(drow + ((unsigned)row * (unsigned)a.lddf + 4u * q));
                 } else if (q < QH) {
                     dst = reinterpret_cast<float4*>(lrow + ((unsigned)row * (unsigned)a.ld_rows + 4u * q));
+                } else if (a.fr_bf16) {  // (the f_xyz half's gradient as bfloat16 rows: RowStore::put)
+                    uint2* d16 = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.df) + ((size_t)p * KN * a.lddf + ((unsigned)row * (unsigned)a.lddf + 4u * (q - QH))));
+                    if (a.df_accum) {
+                        const float4 h = unpack_bf16x4(*d16);
+                        o.x += h.x; o.y += h.y; o.z += h.z; o.w += h.w;
+                    }
+                    *d16 = pack_bf16x4(o);
+                    continue;
                 } else {
                     dst = reinterpret_cast<float4*>(drow + ((unsigned)row * (unsigned)a.lddf + 4u * (q - QH)));
                     if (a.df_accum) {
@@ -920,6 +950,7 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
         auto al = [](const void* q, int ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0; };
         const bool rows_out = !a.fl || a.dfl_rows;  // (the atomic scatter form keeps its per-element path)
         a.vec_store = rows_out && al(a.df, a.lddf) && (!a.fl || al(a.dfl_rows, a.ld_rows)) ? 1 : 0;
+        PS_CHECK(!a.fr_bf16 || a.vec_store || a.bf16, "att_pool_train backward: bfloat16 rows (ps_set_train_act_bf16) belong to the bf16-MLP mode");
     }
     if constexpr (D == 64) {
         // level 1: the 32x32x16 bf16 matrix pipe (exact three-way splits in fp32 mode), weights resident in LDS, dWfc in registers

@@ -33,7 +33,7 @@ struct CbArgs {
     void* part;        // per-workgroup partial sums
     int64_t R;
     int ldx, lddz, ldo, accum;
-    int x_bf16;        // x rows (and apply's out rows) are bfloat16 (ps_set_train_act_bf16)
+    int x_bf16;        // x rows, apply's out rows AND the gradient rows dz / dx are bfloat16 (ps_set_train_act_bf16)
 };
 
 // the C x C weights and the bias: uniform addresses -> scalar loads, the products take them as SGPR operands (no LDS, no VGPRs)
@@ -67,6 +67,16 @@ __device__ __forceinline__ void cb_load_x(const CbArgs& a, int64_t r, float (&v)
 #pragma unroll
     for (int q = 0; q < C / 4; ++q) {
         const float4 t = load4_any(a.x, (size_t)r * a.ldx + 4 * q, XB);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+}
+// a row of a gradient tensor (dz, dx): the format of the activation rows it belongs to (B16: bfloat16, ld in elements)
+template <int C, bool B16>
+__device__ __forceinline__ void cb_load_g(const float* __restrict__ p, int64_t ld, int64_t r, float (&v)[C])
+{
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+        const float4 t = load4_any(p, (size_t)r * ld + 4 * q, B16);
         v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
     }
 }
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(kCbThreads) void cb_bwd_sums_kernel(CbArgs a)
     for (int64_t r = blockIdx.x * (int64_t)kCbThreads + threadIdx.x; r < a.R; r += (int64_t)gridDim.x * kCbThreads) {
         float x[C], y[C], g[C];
         cb_load_x<C, XB>(a, r, x);
-        cb_load_row<C>(a.dz, a.lddz, r, g);
+        cb_load_g<C, XB>(a.dz, a.lddz, r, g);
         wt.product(x, y);
 #pragma unroll
         for (int j = 0; j < C; ++j) {
@@ -214,9 +224,9 @@ __global__ __launch_bounds__(kCbThreads) void cb_bwd_apply_kernel(CbArgs a)
     for (int64_t r = blockIdx.x * (int64_t)kCbThreads + threadIdx.x; r < a.R; r += (int64_t)gridDim.x * kCbThreads) {
         float x[C], y[C], g[C];
         cb_load_x<C, XB>(a, r, x);
-        cb_load_row<C>(a.dz, a.lddz, r, g);
+        cb_load_g<C, XB>(a.dz, a.lddz, r, g);
         float old[C];
-        if (a.accum) cb_load_row<C>(a.out, a.ldo, r, old);
+        if (a.accum) cb_load_g<C, XB>(a.out, a.ldo, r, old);
         wt.product(x, y);
         float dy[C];
 #pragma unroll
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(kCbThreads) void cb_bwd_apply_kernel(CbArgs a)
         }
 #pragma unroll
         for (int q = 0; q < C / 4; ++q)
-            *reinterpret_cast<float4*>(a.out + r * a.ldo + 4 * q) = make_float4(dx[4 * q], dx[4 * q + 1], dx[4 * q + 2], dx[4 * q + 3]);
+            store4_any(a.out, (size_t)r * a.ldo + 4 * q, make_float4(dx[4 * q], dx[4 * q + 1], dx[4 * q + 2], dx[4 * q + 3]), XB);
     }
     cb_block_reduce<float, NV>(acc, red, static_cast<float*>(a.part) + (size_t)blockIdx.x * NV);
 }
@@ -251,7 +261,7 @@ static int cb_blocks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int6
 int convbn_rows_sums(ps_context* c, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, double* sums)
 {
     CbArgs a = {};
-    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x, apply's out and the gradient rows dz / dx as bfloat16: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R;
     const int blocks = cb_blocks(R);
     PS_TRY(c->red_ws.reserve(sizeof(double) * (size_t)blocks * 48 + 256));
@@ -267,7 +277,7 @@ int convbn_rows_apply(ps_context* c, const float* x, int64_t ldx, const float* w
                       const float* beta, float* out, int64_t ldo)
 {
     CbArgs a = {};
-    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x, apply's out and the gradient rows dz / dx as bfloat16: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.scale = scale; a.beta = beta; a.out = out; a.ldo = (int)ldo;
     if (a.x_bf16) hipLaunchKernelGGL((cb_apply_kernel<8, true>), dim3(cb_blocks(R)), dim3(kCbThreads), 0, c->stream, a);
     else hipLaunchKernelGGL((cb_apply_kernel<8, false>), dim3(cb_blocks(R)), dim3(kCbThreads), 0, c->stream, a);
@@ -279,7 +289,7 @@ int convbn_rows_bwd_sums(ps_context* c, const float* x, int64_t ldx, const float
                          const float* scale, const float* beta, const float* dz, int64_t lddz, float* s12)
 {
     CbArgs a = {};
-    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x, apply's out and the gradient rows dz / dx as bfloat16: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.invstd = invstd; a.scale = scale; a.beta = beta; a.dz = dz; a.lddz = (int)lddz;
     const int blocks = cb_blocks(R);
     PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * 16 + 256));
@@ -296,7 +306,7 @@ int convbn_rows_bwd_apply(ps_context* c, const float* x, int64_t ldx, const floa
                           int64_t lddx, float* dw, float* db)
 {
     CbArgs a = {};
-    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x, apply's out and the gradient rows dz / dx as bfloat16: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.invstd = invstd; a.scale = scale; a.beta = beta; a.s12 = s12;
     a.inv_rows = inv_rows; a.dz = dz; a.lddz = (int)lddz; a.out = dx; a.ldo = (int)lddx; a.accum = accumulate ? 1 : 0;
     const int blocks = cb_blocks(R);

@@ -39,7 +39,7 @@ struct LocseArgs {
     float* out;          // apply: [rows, H] (ldo)
     float* part;         // per-block partial sums
     int ldo, lddz;
-    int out_bf16;        // apply: out rows are bfloat16 (ps_set_train_act_bf16)
+    int out_bf16;        // apply: out rows -- backward: dz rows -- are bfloat16 (ps_set_train_act_bf16; ldo / lddz in elements)
 };
 
 // (row counts are < 2^31 and point counts < 2^24 here -- checked on the host --, so the two divisions of the row index are a shift /
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void locse_bwd_kernel(LocseArgs a)
         locse_enc(a, t, e);
         float y[4];
         locse_y4<H>(Ws, e, c0, y);
-        const float4 dv = *reinterpret_cast<const float4*>(a.dz + t * a.lddz + c0);
+        const float4 dv = load4_any(a.dz, (size_t)t * a.lddz + c0, a.out_bf16 != 0);  // (the gradient rows have the format of the rows apply wrote)
         const float dzv[4] = {dv.x, dv.y, dv.z, dv.w};
         float g[4], xh[4];
 #pragma unroll
@@ -381,5 +381,6 @@ extern "C" int ps_op_locse_train_bwd(ps_context* c, const float* xyz, const int3
     LocseArgs a = {};
     a.xyz = xyz; a.idx = idx; a.rows = B * N * K; a.n_cloud = (int)N; a.K = (int)K; a.w = w; a.b = b;
     a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.dz = dz; a.lddz = (int)lddz;
+    a.out_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (dz as bfloat16 rows)
     return locse_dispatch(c, h, a, 2, sums);
 }

@@ -369,16 +369,16 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_sums_kernel(ScArgs a)
     ScTile<C> xr, zr;
     if (tl < tiles) {
         xr.template fetch_any<XB>(a.x, a.ldx, tl * 16, a.R, lane);
-        if (a.vec) zr.fetch(a.dz, a.lddz, tl * 16, a.R, lane);
+        if (a.vec) zr.template fetch_any<XB>(a.dz, a.lddz, tl * 16, a.R, lane);  // (gradient rows in the format of the activation rows)
     }
     for (; tl < tiles; tl += tstride) {
         const int64_t r0 = tl * 16;
         xr.template expand<XB>(), xr.commit(A, lane, a.bf16 != 0);
-        if (a.vec) zr.commit(T1, lane);
+        if (a.vec) zr.template expand<XB>(), zr.commit(T1, lane);
         wave_lds_sync();
         if (tl + tstride < tiles) {
             xr.template fetch_any<XB>(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
-            if (a.vec) zr.fetch(a.dz, a.lddz, (tl + tstride) * 16, a.R, lane);
+            if (a.vec) zr.template fetch_any<XB>(a.dz, a.lddz, (tl + tstride) * 16, a.R, lane);
         }
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
@@ -486,10 +486,10 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
     ScTile<C> xr, zr, old_next;
     if (tl < tiles) {
         xr.template fetch_any<XB>(a.x, a.ldx, tl * 16, a.R, lane);
-        if (vec) zr.fetch(a.dz, a.lddz, tl * 16, a.R, lane);
-        if (acc_old) old_next.fetch(a.out, a.ldo, tl * 16, a.R, lane);
+        if (vec) zr.template fetch_any<XB>(a.dz, a.lddz, tl * 16, a.R, lane);  // (gradient rows dz / dx: the format of the activation rows)
+        if (acc_old) old_next.template fetch_any<XB>(a.out, a.ldo, tl * 16, a.R, lane);
         xr.template expand<XB>(), xr.commit(A, lane, a.bf16 != 0);
-        if (vec) zr.commit(T1, lane);
+        if (vec) zr.template expand<XB>(), zr.commit(T1, lane);
     }
     wave_lds_sync();
     for (; tl < tiles; tl += tstride) {
@@ -498,8 +498,8 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
         ScTile<C> old_cur = old_next;
         if (more) {
             xr.template fetch_any<XB>(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
-            if (vec) zr.fetch(a.dz, a.lddz, (tl + tstride) * 16, a.R, lane);
-            if (acc_old) old_next.fetch(a.out, a.ldo, (tl + tstride) * 16, a.R, lane);
+            if (vec) zr.template fetch_any<XB>(a.dz, a.lddz, (tl + tstride) * 16, a.R, lane);
+            if (acc_old) old_next.template fetch_any<XB>(a.out, a.ldo, (tl + tstride) * 16, a.R, lane);
         }
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
@@ -559,14 +559,14 @@ __global__ __launch_bounds__(kScWaves * 64) void sc_bwd_apply_kernel(ScArgs a)
         ScTile<C> o;
         if (vec) {
             o.take(A, lane);
-            if (acc_old) o.add(old_cur);
+            if (acc_old) old_cur.template expand<XB>(), o.add(old_cur);
             wave_lds_sync();
         }
         if (more) {
             xr.template expand<XB>(), xr.commit(A, lane, a.bf16 != 0);
-            if (vec) zr.commit(T1, lane);
+            if (vec) zr.template expand<XB>(), zr.commit(T1, lane);
         }
-        if (vec) o.put(a.out, a.ldo, r0, a.R, lane);
+        if (vec) o.template put_any<XB>(a.out, a.ldo, r0, a.R, lane);
         wave_lds_sync();
     }
     if (WG) {  // the workgroup's partial: waves add up through LDS in order (weights and tiles are dead)
@@ -663,7 +663,7 @@ static int sc_dispatch(ps_context* c, int64_t C, const ScArgs& a_in, int what, v
     ScArgs a = a_in;
     auto al = [](const void* q, int ld) { return !q || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0); };
     a.vec = al(a.dz, a.lddz) && al(a.out, a.ldo) ? 1 : 0;
-    PS_CHECK(!a.x_bf16 || what != 1 || a.vec, "ps_op_conv_bn_train_apply: bfloat16 output rows need 16-byte alignment and ldo %% 4 == 0");
+    PS_CHECK(!a.x_bf16 || a.vec, "ps_op_conv_bn_train_*: bfloat16 rows (x, the output, dz, dx: ps_set_train_act_bf16) need 16-byte aligned bases and pitches %% 4 == 0");
     a.bf16 = c->train_bf16 && C % 16 == 0 ? 1 : 0;  // (ps_set_train_gemm_bf16; the rule of ps_op_conv1x1_ex: an 8-channel product stays fp32)
     switch (C) {
         case 8: return sc_launch<8>(c, a, what, result, result2);
@@ -703,7 +703,7 @@ extern "C" int ps_op_conv_bn_train_sums(ps_context* c, const float* x, int64_t l
     Stage st(c, "train_convbn_fwd", 2);
     if (C == 8) return convbn_rows_sums(c, x, ldx, w, b, R, sums);
     ScArgs a = {};
-    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x, apply's out and the gradient rows dz / dx as bfloat16: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R;
     return sc_dispatch(c, C, a, 0, sums);
 }
@@ -718,7 +718,7 @@ extern "C" int ps_op_conv_bn_train_apply(ps_context* c, const float* x, int64_t 
     Stage st(c, "train_convbn_fwd", 1);
     if (C == 8 && ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) return convbn_rows_apply(c, x, ldx, w, b, R, mean, scale, beta, out, ldo);
     ScArgs a = {};
-    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x, apply's out and the gradient rows dz / dx as bfloat16: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.scale = scale; a.beta = beta; a.out = out; a.ldo = (int)ldo;
     return sc_dispatch(c, C, a, 1, nullptr);
 }
@@ -737,7 +737,7 @@ extern "C" int ps_op_conv_bn_train_bwd_sums(ps_context* c, const float* x, int64
     }
     Stage st(c, "train_convbn_bwd", 2);
     ScArgs a = {};
-    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x, apply's out and the gradient rows dz / dx as bfloat16: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.invstd = invstd; a.scale = scale; a.beta = beta; a.dz = dz; a.lddz = (int)lddz;
     return sc_dispatch(c, C, a, 2, sums);
 }
@@ -752,7 +752,7 @@ extern "C" int ps_op_conv_bn_train_bwd_apply(ps_context* c, const float* x, int6
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_convbn_bwd", 1);
     ScArgs a = {};
-    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x, apply's out and the gradient rows dz / dx as bfloat16: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.invstd = invstd; a.scale = scale; a.beta = beta; a.m1 = m1; a.m2 = m2;
     a.dz = dz; a.lddz = (int)lddz; a.out = dx; a.ldo = (int)lddx; a.accum = accumulate ? 1 : 0; a.mscale = 1.f;
     return sc_dispatch(c, C, a, 3, nullptr);
@@ -773,7 +773,7 @@ extern "C" int ps_op_conv_bn_train_bwd_sums2(ps_context* c, const float* x, int6
     if (C == 8 && sc_rows_ok(dz, lddz, C)) return convbn_rows_bwd_sums(c, x, ldx, w, b, R, mean, invstd, scale, beta, dz, lddz, s12);
     PS_CHECK(C >= 16, "ps_op_conv_bn_train_bwd_sums2: C = 8 needs 16-byte aligned dz rows");
     ScArgs a = {};
-    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x, apply's out and the gradient rows dz / dx as bfloat16: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.invstd = invstd; a.scale = scale; a.beta = beta; a.dz = dz; a.lddz = (int)lddz;
     return sc_dispatch(c, C, a, 4, s12);
 }
@@ -795,7 +795,7 @@ extern "C" int ps_op_conv_bn_train_bwd_apply_w(ps_context* c, const float* x, in
         return convbn_rows_bwd_apply(c, x, ldx, w, b, R, mean, invstd, scale, beta, s12, inv_rows, dz, lddz, accumulate, dx, lddx, dw, db);
     PS_CHECK(C >= 16, "ps_op_conv_bn_train_bwd_apply_w: C = 8 needs 16-byte aligned dz / dx rows");
     ScArgs a = {};
-    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x -- and apply's out -- as bfloat16 rows: ps_set_train_act_bf16)
+    a.x_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (x, apply's out and the gradient rows dz / dx as bfloat16: ps_set_train_act_bf16)
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.invstd = invstd; a.scale = scale; a.beta = beta; a.m1 = s12; a.m2 = s12 + C;
     a.mscale = inv_rows; a.dz = dz; a.lddz = (int)lddz; a.out = dx; a.ldo = (int)lddx; a.accum = accumulate ? 1 : 0;
     return sc_dispatch(c, C, a, 5, dw, db);

@@ -654,6 +654,10 @@ struct ps_trainer {
             return;
         }
         Tn& have = it->second;
+        if (have.b16 || g.b16) {  // (bfloat16-stored gradient rows are only ever accumulated by the ops that read them that way)
+            ps::set_error("trainer: a second gradient of a bfloat16-stored tensor reached the generic accumulation");
+            throw TrainError{PS_ESTATE};
+        }
         if (have.contiguous() && g.contiguous())
             TK(ps_op_axpy(c, 1.0f, g.p, g.numel(), have.p));
         else
@@ -895,7 +899,14 @@ struct ps_trainer {
         float *gW = grads + lp.w, *gb = grads + lp.b, *ggamma = grads + lp.gamma, *gbeta = grads + lp.beta;
         record(y, [=](const Tn& dz) {
             Tn acc = alloc(1, 23 * h + 16, false);
-            TK(ps_op_locse_train_bwd(c, xyz, idx, B, N, K, W, b, h, scale, beta, mean, invstd, dz.p, dz.ld, acc.p));
+            if (dz.b16 != act16) {  // (the gradient rows of a bfloat16-stored tensor are bfloat16 themselves: attpool_split, conv_bn_fused)
+                ps::set_error("trainer: locse_bn_act: gradient rows in the wrong storage format");
+                throw TrainError{PS_ESTATE};
+            }
+            {
+                ActScope as(c, act16);
+                TK(ps_op_locse_train_bwd(c, xyz, idx, B, N, K, W, b, h, scale, beta, mean, invstd, dz.p, dz.ld, acc.p));
+            }
             Tn tot = alloc(2, h, false);
             Stage st(c, "train_locse_bwd", 2);
             hipLaunchKernelGGL(tr_locse_local_kernel, dim3(ceil_div(h, 64)), dim3(64), 0, stream(), acc.p, (int)h, ggamma, gbeta, tot.p);
@@ -953,6 +964,10 @@ struct ps_trainer {
         float *gW = grads + lp.w, *gb = grads + lp.b, *ggamma = grads + lp.gamma, *gbeta = grads + lp.beta;
         record(z, [=](const Tn& dz_in) {
             const bool dz_ok = dz_in.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(dz_in.p) & 15) == 0;
+            if (dz_in.b16 != act16 || (act16 && !dz_ok)) {  // (bfloat16 rows in and out: so are the gradient rows dz and dx)
+                ps::set_error("trainer: conv_bn_fused: gradient rows in the wrong storage format");
+                throw TrainError{PS_ESTATE};
+            }
             const Tn dz = dz_ok ? dz_in : contig(dz_in);
             Tn acc = alloc(1, 3 * h, false);
             {
@@ -970,7 +985,8 @@ struct ps_trainer {
                 auto it = grad_of.find(x.id);
                 const bool add = it != grad_of.end();
                 Tn dx = add ? it->second : alloc(R, h);
-                if (add && !(dx.ld % 4 == 0 && dx.R == R && dx.C == h)) {
+                if (!add) dx.b16 = act16;
+                if (add && !(dx.ld % 4 == 0 && dx.R == R && dx.C == h && dx.b16 == act16)) {
                     ps::set_error("trainer: conv_bn_fused: unexpected gradient layout");
                     throw TrainError{PS_ESTATE};
                 }
@@ -1228,8 +1244,9 @@ struct ps_trainer {
             // f_xyz usually has a gradient already (the h -> h convolution's input gradient ran first): the kernel adds into it instead of
             // writing a second tensor that an axpy pass then folds in (4 passes over [N*K, h] -> 2)
             auto have = grad_of.find(f_xyz.id);
-            const bool add_in_place = have != grad_of.end() && have->second.C == h && have->second.R == B * M * K;
+            const bool add_in_place = have != grad_of.end() && have->second.C == h && have->second.R == B * M * K && have->second.b16 == act16;
             Tn dfx = add_in_place ? have->second : alloc(B * M * K, h);
+            if (!add_in_place) dfx.b16 = act16;  // (the gradient rows of the bfloat16-stored half are bfloat16 as well)
             struct Flag {
                 ps_context* c;
                 Flag(ps_context* ctx, bool on) : c(ctx) { c->att_df_accum = on; }

@@ -629,7 +629,9 @@ def test_bf16_storage_of_the_lfa_rows_changes_only_the_format():
     A storage format, not another algorithm -- so every op is held to that: with the flag on,
       * ps_op_locse_train_apply and ps_op_conv_bn_train_apply write exactly bfloat16(RNE) of what they write with the flag off;
       * ps_op_conv_bn_train_sums / _apply / _bwd_sums2 / _bwd_apply_w fed bfloat16 rows x, and ps_op_att_pool_train_fwd_split /
-        _bwd_split_rows fed bfloat16 rows fr, return bit for bit what they return for the same values handed over as fp32 rows.
+        _bwd_split_rows fed bfloat16 rows fr, return bit for bit what they return for the same values handed over as fp32 rows;
+      * the GRADIENT rows of those tensors travel in the same format: dz into (and dx out of, plain or accumulating) the convolution's
+        backward, dz into ps_op_locse_train_bwd, dfr out of the pooling's backward -- bfloat16(RNE) of the fp32 form's values.
     h = 8 (one thread per row), 32 and 64 (tile kernels); d = 2h = 16 (per-point kernels), 64 (attpool_gemm.hip's attg64), 128 (the
     column-split bf16 kernel).  Two clouds, 600 points, bf16-MLP mode on."""
     import ctypes
@@ -671,28 +673,43 @@ def test_bf16_storage_of_the_lfa_rows_changes_only_the_format():
             act(False); _lib.check(L.ps_op_conv_bn_train_apply(hd, p(xf), h, p(W2), p(b2), R, h, p(m2), p(sc2), p(be2), p(z32), h))
             act(True); _lib.check(L.ps_op_conv_bn_train_apply(hd, p(x16), h, p(W2), p(b2), R, h, p(m2), p(sc2), p(be2), p(z16), h))
             assert torch.equal(z16, z32.bfloat16()), h
-            dz = torch.randn(R, h, generator=g).cuda()
-            outs = {}
-            for on, xx in ((False, xf), (True, x16)):
+            # (the gradient rows dz / dx have the format of the activation rows: bfloat16 dz in, bfloat16 dx out -- plain and accumulating)
+            dz16 = torch.randn(R, h, generator=g).cuda().bfloat16(); dzf = dz16.float()
+            old16 = torch.randn(R, h, generator=g).cuda().bfloat16()
+            for accumulate in (0, 1):
+                outs = {}
+                for on, xx, dzz in ((False, xf, dzf), (True, x16, dz16)):
+                    act(on)
+                    s12 = torch.zeros(3 * h).cuda(); dw = torch.empty(h, h).cuda(); db = torch.empty(h).cuda()
+                    dx = old16.clone() if on else old16.float()
+                    _lib.check(L.ps_op_conv_bn_train_bwd_sums2(hd, p(xx), h, p(W2), p(b2), R, h, p(m2), p(inv2), p(sc2), p(be2), p(dzz), h, p(s12)))
+                    _lib.check(L.ps_op_conv_bn_train_bwd_apply_w(hd, p(xx), h, p(W2), p(b2), R, h, p(m2), p(inv2), p(sc2), p(be2), p(s12), 1.0 / R, p(dzz), h,
+                                                                 accumulate, p(dx), h, p(dw), p(db)))
+                    outs[on] = (s12[:2 * h].clone(), dx if on else dx.bfloat16(), dw, db)
+                for a_, b_ in zip(outs[False], outs[True]):
+                    assert torch.equal(a_, b_), (h, accumulate)
+            # -- LocSE backward: dz as bfloat16 rows
+            sums = {}
+            inv1 = (1 + 0.2 * torch.rand(h, generator=g)).cuda()
+            for on, dzz in ((False, dzf), (True, dz16)):
                 act(on)
-                s12 = torch.zeros(3 * h).cuda(); dx = torch.empty(R, h).cuda(); dw = torch.empty(h, h).cuda(); db = torch.empty(h).cuda()
-                _lib.check(L.ps_op_conv_bn_train_bwd_sums2(hd, p(xx), h, p(W2), p(b2), R, h, p(m2), p(inv2), p(sc2), p(be2), p(dz), h, p(s12)))
-                _lib.check(L.ps_op_conv_bn_train_bwd_apply_w(hd, p(xx), h, p(W2), p(b2), R, h, p(m2), p(inv2), p(sc2), p(be2), p(s12), 1.0 / R, p(dz), h, 0,
-                                                             p(dx), h, p(dw), p(db)))
-                outs[on] = (s12[:2 * h].clone(), dx, dw, db)
-            for a_, b_ in zip(outs[False], outs[True]):
-                assert torch.equal(a_, b_), h
+                acc = torch.empty(23 * h + 16).cuda()
+                _lib.check(L.ps_op_locse_train_bwd(hd, p(xyz), p(idx), B, N, K, p(W1), p(b1), h, p(scale), p(beta), p(mean), p(inv1), p(dzz), h, p(acc)))
+                sums[on] = acc
+            assert torch.equal(sums[False], sums[True]), h
             # -- the split-source pooling: fr as bfloat16 rows
             assert L.ps_op_att_pool_train_supported_ex(K, d, 1) == 1
             fsrc = torch.randn(B * N, h, generator=g).cuda()
             Wfc = (torch.randn(d, d, generator=g) / d ** 0.5).cuda(); dagg = torch.randn(B * N, d, generator=g).cuda()
+            # (... and the gradient of that half, dfr, as bfloat16 rows)
             res = {}
             for on, fr in ((False, xf), (True, x16)):
                 act(on)
-                agg = torch.empty(B * N, d).cuda(); rows = torch.empty(R, h).cuda(); dfr = torch.empty(R, h).cuda(); dW = torch.empty(d, d).cuda()
+                agg = torch.empty(B * N, d).cuda(); rows = torch.empty(R, h).cuda(); dW = torch.empty(d, d).cuda()
+                dfr = torch.empty(R, h, dtype=torch.bfloat16 if on else torch.float32).cuda()
                 _lib.check(L.ps_op_att_pool_train_fwd_split(hd, p(fsrc), h, p(idx), B, N, N, p(fr), h, p(Wfc), K, d, p(agg)))
                 _lib.check(L.ps_op_att_pool_train_bwd_split_rows(hd, p(fsrc), h, p(idx), B, N, N, p(fr), h, p(Wfc), p(dagg), K, d, p(rows), h, p(dfr), h, p(dW)))
-                res[on] = (agg, rows, dfr, dW)
+                res[on] = (agg, rows, dfr if on else dfr.bfloat16(), dW)
             for a_, b_ in zip(res[False], res[True]):
                 assert torch.equal(a_, b_), (h, d)
     finally:
