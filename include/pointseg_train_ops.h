@@ -25,8 +25,9 @@ extern "C" {
  *   ps_op_conv_bn_train_sums / _apply / _bwd_sums[2] / _bwd_apply[_w]      x (read), _apply's out (written), dz (read), dx (written)
  *   ps_op_att_pool_train_fwd_split / _bwd_split[_rows]                      fr (read), dfr (written), K = 16, d in {16, 64, 128}
  * The GRADIENT rows of those tensors (dz, dx, dfr) travel in the same format: written rounded to nearest even; an accumulating op
- * (accumulate != 0, or dfr under the trainer's add-in-place form) adds to the stored value and rounds the sum.  The gathered half's
- * gradient rows (dfl_rows) and every weight gradient stay fp32.  The value a consumer sees is the stored one: the weighted sum of att_pooling and the 8-channel
+ * (accumulate != 0, or dfr under the trainer's add-in-place form) adds to the stored value and rounds the sum.  So do the gathered
+ * half's gradient rows: ps_op_att_pool_train_bwd_split_rows writes dfl_rows as bfloat16 and ps_op_gather_reduce_rows[_ordered] reads
+ * `rows` as bfloat16 (sums and dst in fp32).  Every weight gradient and the float-atomic form's dfl stay fp32.  The value a consumer sees is the stored one: the weighted sum of att_pooling and the 8-channel
  * convolution, which keep fp32 arithmetic in the bf16-MLP mode, read rounded inputs.  Off by default; ps_train_options.act_bf16 turns
  * it on inside ps_randla_train_step for the levels whose kernels take it. */
 int ps_set_train_act_bf16(ps_context* ctx, int on);

@@ -44,6 +44,19 @@ class _StoreRounded(torch.autograd.Function):
         return _rb(dy)
 
 
+class _GradRounded(torch.autograd.Function):
+    """Identity whose GRADIENT is stored as bfloat16 rows: the gathered half of a pooling's neighbour set at the levels of act_rule (the rows
+    the fused backward leaves for the gather-reduction, csrc/attpool_train.hip RowStore)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _rb(dy)
+
+
 class _StoreRoundedFork(torch.autograd.Function):
     """The same for a stored tensor with TWO consumers (f_xyz: the first pooling and LFA mlp2, RandLANet.py:328-331): returns the rounded
     value twice; the gradient buffer is written by the convolution's backward (second output) and the pooling's backward then adds into
@@ -129,11 +142,12 @@ def _graph(P, num_layers, xyz, neigh_idx, sub_idx, interp_idx, features, dtype, 
         f_xyz_pool = f_xyz
         if stored16:
             f_xyz_pool, f_xyz = _StoreRoundedFork.apply(f_xyz)
-        f_agg = att(torch.cat([gather(f_pc, idx), f_xyz_pool], -1), n + "LFAatt_pooling_1")
+        gr = _GradRounded.apply if stored16 else (lambda t: t)
+        f_agg = att(torch.cat([gr(gather(f_pc, idx)), f_xyz_pool], -1), n + "LFAatt_pooling_1")
         f_xyz = conv(f_xyz, n + "LFAmlp2")
         if stored16:
             f_xyz = _StoreRounded.apply(f_xyz)
-        f_agg = att(torch.cat([gather(f_agg, idx), f_xyz], -1), n + "LFAatt_pooling_2")
+        f_agg = att(torch.cat([gr(gather(f_agg, idx)), f_xyz], -1), n + "LFAatt_pooling_2")
         f_enc = F.leaky_relu(conv(f_agg, n + "mlp2", act=False) + conv(X, n + "shortcut", act=False), 0.2)
         f = torch.amax(gather(f_enc, sub_idx[i]), dim=2)  # ties share the gradient evenly, like tf.reduce_max
         if i == 0:

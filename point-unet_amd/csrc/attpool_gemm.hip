@@ -714,11 +714,13 @@ __global__ __launch_bounds__(WAVES * 64) void attg64_kernel(AttTrainArgs a, cons
                     pitch = a.lddf;
                     accum = a.df_accum != 0;
                 }
-                if (FRB && split && it == 1) {
+                if (FRB && split) {
                     // the f_xyz half's gradient in the format of the f_xyz rows (ps_set_train_act_bf16): bfloat16, lddf in elements.  A lane owns
                     // a column; neighbouring lanes swap every second row (one DPP move each), so the even lane holds columns (c, c + 1) of row q
                     // and the odd lane those of row q + 1: 4-byte stores of packed pairs (2-byte stores: 1.07 against 0.53 ms per launch)
-                    unsigned* b32 = reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(a.df) + (size_t)row0 * a.lddf + (c32 & ~1));
+                    // (both halves: it == 0 is the gathered half's gradient, plain rows for the gather-reduction -- same format, never accumulated)
+                    unsigned* b32 = it == 0 ? reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(a.dfl_rows) + (size_t)row0 * a.ld_rows + (c32 & ~1))
+                                            : reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(a.df) + (size_t)row0 * a.lddf + (c32 & ~1));
                     const bool odd = (c32 & 1) != 0;
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {

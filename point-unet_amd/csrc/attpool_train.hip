@@ -177,6 +177,10 @@ struct RowStore {
                 float4* dst;
                 if (!a.fl) {
                     dst = reinterpret_cast<float4*>(drow + (row * (unsigned)a.lddf + 4u * q));
+                } else if (q < (unsigned)QH && a.fr_bf16) {
+                    // (the gathered half's gradient rows, read back once by the gather-reduction, in the same storage format: ld_rows in elements)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.dfl_rows) + ((size_t)p * KN * a.ld_rows + (row * (unsigned)a.ld_rows + 4u * q))) = pack_bf16x4(o);
+                    continue;
                 } else if (q < (unsigned)QH) {
                     dst = reinterpret_cast<float4*>(lrow + (row * (unsigned)a.ld_rows + 4u * q));
                 } else if (a.fr_bf16) {
@@ -394,6 +398,9 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_kernel(AttTrainArgs 
                         float* q = a.df + (size_t)(p * KN + 4 * g + r) * a.lddf + col - D / 2;
                         *q = a.df_accum ? *q + acc[r] : acc[r];
                     }
+                } else if (a.dfl_rows && a.fr_bf16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) reinterpret_cast<__bf16*>(a.dfl_rows)[(size_t)(p * KN + 4 * g + r) * a.ld_rows + col] = (__bf16)acc[r];
                 } else if (a.dfl_rows) {  // gathered half as plain rows: summed per source row by a gather-reduction afterwards
 #pragma unroll
                     for (int r = 0; r < 4; ++r) a.dfl_rows[(size_t)(p * KN + 4 * g + r) * a.ld_rows + col] = acc[r];
@@ -646,6 +653,9 @@ __global__ __launch_bounds__(WAVES * 64) void att_train_bwd_bf16_kernel(AttTrain
                         float* q = a.df + (size_t)(p * KN + 4 * g + r) * a.lddf + col - D / 2;
                         *q = a.df_accum ? *q + acc[r] : acc[r];
                     }
+                } else if (a.dfl_rows && a.fr_bf16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) reinterpret_cast<__bf16*>(a.dfl_rows)[(size_t)(p * KN + 4 * g + r) * a.ld_rows + col] = (__bf16)acc[r];
                 } else if (a.dfl_rows) {  // gathered half as plain rows: summed per source row by a gather-reduction afterwards
 #pragma unroll
                     for (int r = 0; r < 4; ++r) a.dfl_rows[(size_t)(p * KN + 4 * g + r) * a.ld_rows + col] = acc[r];
@@ -887,6 +897,9 @@ __global__ __launch_bounds__(GROUPS * 256) void att_train_bwd_bf16_cs_kernel(Att
                 float* lrow = a.dfl_rows ? a.dfl_rows + (size_t)p * KN * a.ld_rows : nullptr;
                 if (!a.fl) {
                     dst = reinterpret_cast<float4*>(drow + ((unsigned)row * (unsigned)a.lddf + 4u * q));
+                } else if (q < QH && a.fr_bf16) {  // (the gathered half's gradient rows as bfloat16: RowStore::put)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.dfl_rows) + ((size_t)p * KN * a.ld_rows + ((unsigned)row * (unsigned)a.ld_rows + 4u * q))) = pack_bf16x4(o);
+                    continue;
                 } else if (q < QH) {
                     dst = reinterpret_cast<float4*>(lrow + ((unsigned)row * (unsigned)a.ld_rows + 4u * q));
                 } else if (a.fr_bf16) {  // (the f_xyz half's gradient as bfloat16 rows: RowStore::put)

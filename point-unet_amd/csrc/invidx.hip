@@ -9,6 +9,7 @@
 // short (a point sits in about K neighbour lists), wide rows (d >= 64 floats at levels 2-4) make the gather itself efficient.
 #include "common.h"
 #include "sortscan.h"
+#include "bf16_io.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -372,6 +373,8 @@ __global__ __launch_bounds__(256) void gather_reduce_kernel(const float* __restr
 // neighbours q; the K rows of one q form one 64 x d / 16-byte block whose other rows belong to destinations next to this one -- walked in
 // cloud order (a shuffled cloud: runBraTS.py:114) every 32-byte row of level 0 costs its own memory transaction, walked in leaf order the
 // block is fetched once into the XCD's L2 and its rows are consumed by the neighbouring lanes and workgroups.  Same sums, same order.
+// RB: the rows are bfloat16 (ldr in elements): the gathered half's gradient rows of the bf16-MLP mode (ps_set_train_act_bf16)
+template <bool RB>
 __global__ __launch_bounds__(256) void gather_reduce_ordered_kernel(const float* __restrict__ rows, int64_t ldr, const unsigned* __restrict__ offsets,
                                                                     const int32_t* __restrict__ src, const int32_t* __restrict__ order, unsigned n_dst,
                                                                     unsigned n_cloud, unsigned per /* d / 4 lanes per destination */,
@@ -384,24 +387,23 @@ __global__ __launch_bounds__(256) void gather_reduce_ordered_kernel(const float*
     const unsigned sub = threadIdx.x / per, q = threadIdx.x - sub * per;
     for (unsigned t = xcd * per_xcd + (blockIdx.x >> 3) * dpw + sub; t < end; t += slots * dpw) {
         const unsigned b = t / n_cloud;
-        const int64_t j = (int64_t)b * n_cloud + order[t];
+        const int64_t j = order ? (int64_t)b * n_cloud + order[t] : (int64_t)t;
         const unsigned lo = offsets[j], hi = offsets[j + 1];
-        const float* base = rows + 4 * q;
         float4 acc = accumulate ? *reinterpret_cast<const float4*>(dst + j * ldd + 4 * q) : float4{0.f, 0.f, 0.f, 0.f};
         unsigned s = lo;
         for (; s + 4 <= hi; s += 4) {
             const int32_t i0 = src[s], i1 = src[s + 1], i2 = src[s + 2], i3 = src[s + 3];
-            const float4 v0 = *reinterpret_cast<const float4*>(base + (int64_t)i0 * ldr);
-            const float4 v1 = *reinterpret_cast<const float4*>(base + (int64_t)i1 * ldr);
-            const float4 v2 = *reinterpret_cast<const float4*>(base + (int64_t)i2 * ldr);
-            const float4 v3 = *reinterpret_cast<const float4*>(base + (int64_t)i3 * ldr);
+            const float4 v0 = load4_any(rows, (size_t)((int64_t)i0 * ldr) + 4 * q, RB);
+            const float4 v1 = load4_any(rows, (size_t)((int64_t)i1 * ldr) + 4 * q, RB);
+            const float4 v2 = load4_any(rows, (size_t)((int64_t)i2 * ldr) + 4 * q, RB);
+            const float4 v3 = load4_any(rows, (size_t)((int64_t)i3 * ldr) + 4 * q, RB);
             acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
             acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
             acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
             acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
         }
         for (; s < hi; ++s) {
-            const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)src[s] * ldr);
+            const float4 v = load4_any(rows, (size_t)((int64_t)src[s] * ldr) + 4 * q, RB);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
         *reinterpret_cast<float4*>(dst + j * ldd + 4 * q) = acc;
@@ -698,12 +700,21 @@ int ps_op_gather_reduce_rows_ordered(ps_context* c, const float* rows, int64_t l
     const unsigned* off = reinterpret_cast<const unsigned*>(offsets);
     static const bool ordered_on = !(getenv("PS_GATHER_REDUCE_ORDERED") && atoi(getenv("PS_GATHER_REDUCE_ORDERED")) == 0);  // (A/B switch)
     const int64_t per = d / 4;
-    if (order && ordered_on && vec && per >= 1 && per <= 256 && 256 % per == 0 && n_dst < (1ll << 31)) {
+    // rows of bfloat16 (ps_set_train_act_bf16 inside the bf16-MLP mode; ldr in elements, 8-byte aligned rows): the ordered kernel only
+    const bool rb = c->train_act_bf16 && c->train_bf16;
+    const bool can_walk = per >= 1 && per <= 256 && 256 % per == 0 && n_dst < (1ll << 31) && (d % 4) == 0 && (ldd % 4) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    PS_CHECK(!rb || (can_walk && ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(rows) & 7) == 0),
+             "ps_op_gather_reduce_rows: bfloat16 rows need d %% 4 == 0, d / 4 a divisor of 256, ldr %% 4 == 0 and 8-byte aligned rows");
+    if (rb || (order && ordered_on && vec && can_walk)) {
         const int64_t dpw = 256 / per;
         int64_t wgs = ceil_div(n_dst, dpw);
         wgs = std::min<int64_t>((wgs + 7) / 8 * 8, 8 * 2048);
-        hipLaunchKernelGGL(gather_reduce_ordered_kernel, dim3((unsigned)wgs), dim3(256), 0, c->stream, rows, ldr, off, src, order, (unsigned)n_dst, (unsigned)n_cloud,
-                           (unsigned)per, dst, ldd, accumulate);
+        if (rb)
+            hipLaunchKernelGGL(gather_reduce_ordered_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, c->stream, rows, ldr, off, src, order, (unsigned)n_dst,
+                               (unsigned)(order ? n_cloud : n_dst), (unsigned)per, dst, ldd, accumulate);
+        else
+            hipLaunchKernelGGL(gather_reduce_ordered_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, c->stream, rows, ldr, off, src, order, (unsigned)n_dst,
+                               (unsigned)n_cloud, (unsigned)per, dst, ldd, accumulate);
     } else if (vec) {
         hipLaunchKernelGGL(gather_reduce_kernel<true>, dim3(iv_grid(n_dst * (d / 4))), dim3(256), 0, c->stream, rows, ldr, off, src, n_dst, (int)d, dst, ldd,
                            accumulate);

@@ -701,17 +701,35 @@ def test_bf16_storage_of_the_lfa_rows_changes_only_the_format():
             assert L.ps_op_att_pool_train_supported_ex(K, d, 1) == 1
             fsrc = torch.randn(B * N, h, generator=g).cuda()
             Wfc = (torch.randn(d, d, generator=g) / d ** 0.5).cuda(); dagg = torch.randn(B * N, d, generator=g).cuda()
-            # (... and the gradient of that half, dfr, as bfloat16 rows)
+            # (... and both halves of the gradient: dfr, and the gathered half's rows for the gather-reduction, as bfloat16 rows)
             res = {}
             for on, fr in ((False, xf), (True, x16)):
                 act(on)
-                agg = torch.empty(B * N, d).cuda(); rows = torch.empty(R, h).cuda(); dW = torch.empty(d, d).cuda()
+                agg = torch.empty(B * N, d).cuda(); dW = torch.empty(d, d).cuda()
+                rows = torch.empty(R, h, dtype=torch.bfloat16 if on else torch.float32).cuda()
                 dfr = torch.empty(R, h, dtype=torch.bfloat16 if on else torch.float32).cuda()
                 _lib.check(L.ps_op_att_pool_train_fwd_split(hd, p(fsrc), h, p(idx), B, N, N, p(fr), h, p(Wfc), K, d, p(agg)))
                 _lib.check(L.ps_op_att_pool_train_bwd_split_rows(hd, p(fsrc), h, p(idx), B, N, N, p(fr), h, p(Wfc), p(dagg), K, d, p(rows), h, p(dfr), h, p(dW)))
-                res[on] = (agg, rows, dfr if on else dfr.bfloat16(), dW)
+                res[on] = (agg, rows if on else rows.bfloat16(), dfr if on else dfr.bfloat16(), dW)
             for a_, b_ in zip(res[False], res[True]):
                 assert torch.equal(a_, b_), (h, d)
+            # -- the gather-reduction over bfloat16 rows: the sums of the same values handed over as fp32 rows, bit for bit
+            act(False)
+            off = torch.empty(B * N + 1, dtype=torch.int32, device="cuda"); src = torch.empty(R, dtype=torch.int32, device="cuda")
+            ws = torch.empty(int(L.ps_op_inverse_index_workspace(B * N, R)), dtype=torch.int32, device="cuda")
+            _lib.check(L.ps_op_inverse_index(hd, p(idx), B, N, N * K, p(off), p(src), p(ws)))
+            rows16 = res[True][1]
+            rows32 = rows16.float()
+            perm = torch.stack([torch.randperm(N, generator=g) for _ in range(B)]).int().cuda()
+            for accumulate in (0, 1):
+                base = torch.randn(B * N, h, generator=g).cuda()
+                want, got, got_o = base.clone(), base.clone(), base.clone()
+                _lib.check(L.ps_op_gather_reduce_rows(hd, p(rows32), h, p(off), p(src), B * N, h, p(want), h, accumulate))
+                act(True)
+                _lib.check(L.ps_op_gather_reduce_rows(hd, p(rows16), h, p(off), p(src), B * N, h, p(got), h, accumulate))
+                _lib.check(L.ps_op_gather_reduce_rows_ordered(hd, p(rows16), h, p(off), p(src), B * N, h, p(got_o), h, accumulate, p(perm), N))
+                act(False)
+                assert torch.equal(want, got) and torch.equal(want, got_o), (h, accumulate)
     finally:
         _lib.check(L.ps_set_train_act_bf16(hd, 0))
         _lib.check(L.ps_set_train_gemm_bf16(hd, 0))
