@@ -1274,7 +1274,7 @@ def test_inverse_index_and_gather_reduction(oracle):
     # ONE destination (a bucket far beyond what is sorted through LDS).  PS_INV_BUCKET=0 in the environment runs the radix-sort form instead.
     for B, N, M, K, d, skew in [(2, 700, 700, 16, 8, 0), (1, 300, 1200, 1, 64, 0), (3, 500, 125, 16, 32, 0), (1, 40, 40, 16, 5, 0), (2, 40000, 40000, 16, 4, 0),
                                 (3, 4133, 4133, 16, 8, 0), (2, 70001, 70001, 1, 4, 0), (1, 1000, 9000, 16, 4, 1), (5, 513, 1100, 16, 4, 0),
-                                (1, 262144, 30000, 16, 4, 0)]:
+                                (1, 262144, 30000, 16, 4, 0), (1, 300000, 5000, 16, 4, 0)]:  # (the last: beyond 512 x 512 destinations per cloud -> the radix-sort form)
         idx = torch.randint(0, N, (B, M, K), generator=g).int()
         if skew:
             idx[:, M // 8:, 1:] = 77
