@@ -49,6 +49,7 @@ struct AttGArgs {
     const int32_t* idx;        // [points, 16] cloud-local source rows
     int64_t n_src, n_q;        // rows per cloud of fl / points per cloud
     float* dfl_rows; int ld_rows;
+    int f_bf16;                // forward, split form, bf16-MLP mode: the rows of `f` are STORED as bfloat16 (ps_set_train_act_bf16; ld in elements)
 };
 
 __device__ __forceinline__ float attg_swap_max(float v)
@@ -144,7 +145,7 @@ __device__ __forceinline__ AttGRows attg_rows(const AttGArgs& a, int wave)
             const bool more = n + 1 < S::NB;                                                                          \
             _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                             \
             {                                                                                                         \
-                const BPlanes<P> ap = b3_split8<P>(areg[2 * u], areg[2 * u + 1]);                                     \
+                const BPlanes<P> ap = a_planes(u, s);                                                                  \
                 __builtin_amdgcn_sched_barrier(0);                                                                    \
                 if (s + 1 < S::STEPS) load_a_half(s + 1, u);                                                          \
                 if (u == 1 && more) PS_ATTG_LOAD_B(n + 1);                                                            \
@@ -167,6 +168,9 @@ __device__ __forceinline__ AttGRows attg_rows(const AttGArgs& a, int wave)
         if (SPLIT && col < D / 2) { /* gathered half: the rows' sources (vidx, loaded once per kernel), column col of each */ \
             const float* vb_ = flc[(pi_)] + col;                                                                      \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) (fv_)[j] = vb_[(unsigned)vidx[(pi_)][j] * (unsigned)a.ldl]; \
+        } else if constexpr (FRB) { /* rows of bfloat16 (the pointer arithmetic in elements) */                       \
+            const __bf16* vb_ = reinterpret_cast<const __bf16*>(a.f) + (size_t)rw.rbase * a.ld + ((pi_) ? rw.second * a.ld : 0) - D / 2; \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) (fv_)[j] = (float)vb_[voff + (unsigned)(((j & 3) + 8 * (j >> 2)) * a.ld)]; \
         } else {                                                                                                      \
             const float* vb_ = fb + ((pi_) ? rw.second * a.ld : 0) - (SPLIT ? D / 2 : 0);                             \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) (fv_)[j] = vb_[voff + (unsigned)(((j & 3) + 8 * (j >> 2)) * a.ld)]; \
@@ -192,9 +196,12 @@ __device__ __forceinline__ AttGRows attg_rows(const AttGArgs& a, int wave)
         }                                                                                                             \
     }
 
-template <int D, int P, bool SPLIT>
+// FRB (split form, one plane): the rows of `f` are bfloat16 -- eight of them ARE a lane's operand fragment (no split, no rounding: the
+// sixteen bytes go to the matrix pipe as loaded)
+template <int D, int P, bool SPLIT, bool FRB = false>
 __global__ __launch_bounds__(256) void attg_fwd_kernel(AttGArgs a)
 {
+    static_assert(!FRB || (SPLIT && P == 1), "bfloat16 rows: split-source form of the bf16-MLP mode");
     using S = AttGStream<D, P, false>;
     __shared__ uint4 Bs[2][2 * 4 * P * 64];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -209,11 +216,24 @@ __global__ __launch_bounds__(256) void attg_fwd_kernel(AttGArgs a)
         if (SPLIT && 32 * s < D / 2) {  // (a K step lies in one half: D/2 is a multiple of 32)
             areg[2 * u] = *reinterpret_cast<const float4*>(pL + (32 * s + 16 * u));
             areg[2 * u + 1] = *reinterpret_cast<const float4*>(pL + (32 * s + 16 * u + 4));
+        } else if constexpr (FRB) {  // (eight bfloat16 = the fragment itself; kept as loaded)
+            const unsigned k = (unsigned)(32 * s + 16 * u - D / 2);
+            areg[2 * u] = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(a.f) + (size_t)rw.rbase * a.ld + (xoff + k));
         } else {
             const unsigned k = (unsigned)(32 * s + 16 * u - (SPLIT ? D / 2 : 0));
             areg[2 * u] = *reinterpret_cast<const float4*>(fb + (xoff + k));
             areg[2 * u + 1] = *reinterpret_cast<const float4*>(fb + (xoff + k + 4));
         }
+    };
+    auto a_planes = [&](int u, int s) -> BPlanes<P> {
+        if constexpr (FRB) {
+            if (32 * s >= D / 2) {
+                BPlanes<P> r;
+                r.p[0] = __builtin_bit_cast(uint4, areg[2 * u]);
+                return r;
+            }
+        }
+        return b3_split8<P>(areg[2 * u], areg[2 * u + 1]);
     };
     PS_ATTG_LOAD_B(0);
     PS_ATTG_STORE_B(0);
@@ -271,6 +291,7 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 1) void attg_bwd_kernel(AttGArg
     const unsigned xoff = (unsigned)((c32 < 16 ? c32 : c32 - 16 + rw.second) * a.ld + 8 * hl);
     uint4 breg0, breg1, breg2, breg3, breg4, breg5;
     float4 areg[4];
+    constexpr bool FRB = false;  // (bfloat16 rows: forward only)
     PS_ATTG_SPLIT_SETUP();
     auto load_a_half = [&](int s, int u) {
         if (SPLIT && 32 * s < D / 2) {  // (a K step lies in one half: D/2 is a multiple of 32)
@@ -304,6 +325,7 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 1) void attg_bwd_kernel(AttGArg
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[it][r] = 0.f;
 
+    auto a_planes = [&](int u, int) -> BPlanes<P> { return b3_split8<P>(areg[2 * u], areg[2 * u + 1]); };
     PS_ATTG_LOAD_B(0);
     PS_ATTG_STORE_B(0);
     __syncthreads();
@@ -457,6 +479,15 @@ static int launch_attg_s(ps_context* c, const AttGArgs& a)
 {
     const unsigned blocks = (unsigned)((a.rows + 127) / 128);
     if constexpr (!BWD) {
+        if constexpr (SPLIT && D == 128) {
+            if (a.f_bf16) {
+                PS_CHECK(c->train_bf16, "att_pool_gemm: bfloat16 rows belong to the bf16-MLP mode");
+                hipLaunchKernelGGL((attg_fwd_kernel<D, 1, true, true>), dim3(blocks), dim3(256), 0, c->stream, a);
+                PS_HIP(hipGetLastError());
+                return PS_OK;
+            }
+        }
+        PS_CHECK(!a.f_bf16, "att_pool_gemm: bfloat16 rows are taken by the split-source forward at d = 128 only");
         if (c->train_bf16) hipLaunchKernelGGL((attg_fwd_kernel<D, 1, SPLIT>), dim3(blocks), dim3(256), 0, c->stream, a);
         else hipLaunchKernelGGL((attg_fwd_kernel<D, 3, SPLIT>), dim3(blocks), dim3(256), 0, c->stream, a);
     } else {
@@ -903,6 +934,8 @@ extern "C" int ps_op_att_pool_gemm_fwd_split(ps_context* c, const float* fl, int
     AttGArgs a = {};
     a.f = fr; a.ld = (int)ldr; a.fl = fl; a.ldl = (int)ldl; a.idx = idx; a.n_src = n_src; a.n_q = n_q;
     a.agg = agg; a.rows = R * K; a.points = R;
+    a.f_bf16 = c->train_act_bf16 && c->train_bf16 ? 1 : 0;  // (fr as bfloat16 rows, ldr in elements: ps_set_train_act_bf16; d = 128)
+    PS_CHECK(!a.f_bf16 || (d == 128 && ldr % 8 == 0), "ps_op_att_pool_gemm_fwd_split: bfloat16 rows: d = 128, ldr %% 8 == 0");
     PS_TRY(attg_planes(c, wfc, d, false, &a.w1));
     return d == 128 ? launch_attg<128, false>(c, a) : launch_attg<256, false>(c, a);
 }

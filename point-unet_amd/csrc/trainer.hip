@@ -1236,7 +1236,15 @@ struct ps_trainer {
         const bool act16 = f_xyz.b16;  // (the f_xyz half as bfloat16 rows)
         {
             ActScope as(c, act16);
-            TK(ps_op_att_pool_train_fwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, K, d, agg.p));
+            // d = 128 in the bf16-MLP mode: the forward on the frame of the large GEMMs (attpool_gemm.hip: scores in accumulator tiles,
+            // the bfloat16 rows of f_xyz ARE operand fragments) -- 0.37 -> 0.2x ms per pooling; the backward stays with the per-point
+            // kernel, which owns the weight gradient
+            static const bool fwd_gemm = !(getenv("PS_TRAIN_ATT128_FWD_GEMM") && atoi(getenv("PS_TRAIN_ATT128_FWD_GEMM")) == 0);
+            const bool al = ((reinterpret_cast<uintptr_t>(f_src.p) | reinterpret_cast<uintptr_t>(f_xyz.p) | reinterpret_cast<uintptr_t>(idx)) & 15) == 0;
+            if (fwd_gemm && d == 128 && opt.mlp_bf16 && act16 && al && f_src.ld % 4 == 0 && f_xyz.ld % 8 == 0 && B * M * K < (1ll << 31) && N * f_src.ld < (1ll << 31))
+                TK(ps_op_att_pool_gemm_fwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, K, d, agg.p));
+            else
+                TK(ps_op_att_pool_train_fwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, K, d, agg.p));
         }
         record(agg, [=](const Tn& dy_in) {
             ActScope as(c, act16);

@@ -713,6 +713,15 @@ def test_bf16_storage_of_the_lfa_rows_changes_only_the_format():
                 res[on] = (agg, rows if on else rows.bfloat16(), dfr if on else dfr.bfloat16(), dW)
             for a_, b_ in zip(res[False], res[True]):
                 assert torch.equal(a_, b_), (h, d)
+            if d == 128:  # the forward on the frame of the large GEMMs (attpool_gemm.hip): the bfloat16 rows are operand fragments as loaded
+                aggs = {}
+                for on, fr in ((False, xf), (True, x16)):
+                    act(on)
+                    agg = torch.empty(B * N, d).cuda()
+                    _lib.check(L.ps_op_att_pool_gemm_fwd_split(hd, p(fsrc), h, p(idx), B, N, N, p(fr), h, p(Wfc), K, d, p(agg)))
+                    aggs[on] = agg
+                assert torch.equal(aggs[False], aggs[True])
+                assert (aggs[True] - res[True][0]).abs().max() <= 2e-5 * max(1.0, float(res[True][0].abs().max()))  # (and the per-point kernel's result)
             # -- the gather-reduction over bfloat16 rows: the sums of the same values handed over as fp32 rows, bit for bit
             act(False)
             off = torch.empty(B * N + 1, dtype=torch.int32, device="cuda"); src = torch.empty(R, dtype=torch.int32, device="cuda")
