@@ -217,6 +217,12 @@ int ps_op_convbn_train_sums(ps_context* ctx, const float* x, int64_t ldx, const 
                             int64_t cout, double* sums);
 int ps_op_convbn_train_apply(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t cin,
                              int64_t cout, const float* mean, const float* scale, const float* beta, int leaky, float* out, int64_t ldo);
+/* _apply_add : out[r, :] = LeakyReLU((y - mean) scale + beta + addend[r, :]) -- the residual sum of dilated_res_block (mlp2's output +
+ * the shortcut's, RandLANet.py:306-307) inside the pass that writes the second summand; bit-identical to _apply (leaky = 0) followed by
+ * ps_op_add_lrelu.  addend [R, cout] rows (ld_add), 16-byte aligned. */
+int ps_op_convbn_train_apply_add(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t cin,
+                                 int64_t cout, const float* mean, const float* scale, const float* beta, const float* addend,
+                                 int64_t ld_add, float* out, int64_t ldo);
 int ps_op_convbn_train_bwd_sums(ps_context* ctx, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t cin,
                                 int64_t cout, const float* mean, const float* invstd, const float* scale, const float* beta, int leaky,
                                 const float* dz, int64_t lddz, float* s12);

@@ -146,6 +146,8 @@ PROTOTYPES = {
     "ps_op_convbn_train_sums": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp]),
     "ps_op_convbn_train_apply": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, c_vp,
                                                 ctypes.c_int, c_vp, ctypes.c_int64]),
+    "ps_op_convbn_train_apply_add": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, c_vp,
+                                                    c_vp, ctypes.c_int64, c_vp, ctypes.c_int64]),
     "ps_op_convbn_train_bwd_sums": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, c_vp,
                                                    c_vp, ctypes.c_int, c_vp, ctypes.c_int64, c_vp]),
     "ps_op_convbn_train_bwd_apply": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_vp, c_vp,

@@ -31,6 +31,8 @@ struct RcArgs {
     void* part;          // per-workgroup partial sums
     int64_t R;
     int ldx, lddz, ldo, accum, leaky, bf16;
+    const float* addend;  // apply: non-null -> out = LeakyReLU(BN(x . W + b) + addend) (rows [R, CO], ld_add): the residual sum of dilated_res_block
+    int ld_add;          // (RandLANet.py:306-307) in the pass that writes the second summand instead of a pass of its own
 };
 
 template <int CI, int CO>
@@ -118,6 +120,14 @@ struct RcTile {
     {
 #pragma unroll
         for (int i = 0; i < NV; ++i) { v[i].x += o.v[i].x; v[i].y += o.v[i].y; v[i].z += o.v[i].z; v[i].w += o.v[i].w; }
+    }
+    __device__ __forceinline__ void lrelu()
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i].x = v[i].x < 0.f ? 0.2f * v[i].x : v[i].x; v[i].y = v[i].y < 0.f ? 0.2f * v[i].y : v[i].y;
+            v[i].z = v[i].z < 0.f ? 0.2f * v[i].z : v[i].z; v[i].w = v[i].w < 0.f ? 0.2f * v[i].w : v[i].w;
+        }
     }
     __device__ __forceinline__ void put(float* __restrict__ out, int ldo, int64_t r0, int64_t R, int lane) const
     {
@@ -217,8 +227,9 @@ __global__ __launch_bounds__((RcGeom<CI, CO>::WAVES * 64)) void rc_sums_kernel(R
     }
 }
 
-// ---- forward: normalise (+ LeakyReLU) -> rows
-template <int CI, int CO>
+// ---- forward: normalise (+ LeakyReLU) -> rows.  ADD: + addend rows, then LeakyReLU (a template parameter: a run-time branch around the addend
+// tile's prefetch would make the compiler wait for every load in flight at the join)
+template <int CI, int CO, bool ADD>
 __global__ __launch_bounds__((RcGeom<CI, CO>::WAVES * 64)) void rc_apply_kernel(RcArgs a)
 {
     using G = RcGeom<CI, CO>;
@@ -235,12 +246,20 @@ __global__ __launch_bounds__((RcGeom<CI, CO>::WAVES * 64)) void rc_apply_kernel(
     const int64_t tiles = (a.R + 15) / 16, tstride = (int64_t)gridDim.x * kRcWaves;
     int64_t tl = (int64_t)blockIdx.x * kRcWaves + wave;
     RcTile<CI, G::PX> xr;
-    if (tl < tiles) xr.fetch(a.x, a.ldx, tl * 16, a.R, lane);
+    RcTile<CO, G::PZ> ad;
+    if (tl < tiles) {
+        xr.fetch(a.x, a.ldx, tl * 16, a.R, lane);
+        if constexpr (ADD) ad.fetch(a.addend, a.ld_add, tl * 16, a.R, lane);
+    }
     for (; tl < tiles; tl += tstride) {
         const int64_t r0 = tl * 16;
         xr.commit(X, lane, a.bf16 != 0);
         wave_lds_sync();
-        if (tl + tstride < tiles) xr.fetch(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
+        [[maybe_unused]] const RcTile<CO, G::PZ> ad_cur = ad;
+        if (tl + tstride < tiles) {
+            xr.fetch(a.x, a.ldx, (tl + tstride) * 16, a.R, lane);
+            if constexpr (ADD) ad.fetch(a.addend, a.ld_add, (tl + tstride) * 16, a.R, lane);
+        }
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
             const f32x4 y = rc_y_tile<CI, CO>(X, W, ct, lane);
@@ -254,6 +273,10 @@ __global__ __launch_bounds__((RcGeom<CI, CO>::WAVES * 64)) void rc_apply_kernel(
         wave_lds_sync();
         RcTile<CO, G::PZ> o;
         o.take(Z, lane);
+        if constexpr (ADD) {
+            o.add(ad_cur);
+            o.lrelu();
+        }
         o.put(a.out, a.ldo, r0, a.R, lane);
         wave_lds_sync();
     }
@@ -487,7 +510,7 @@ static int rc_launch(ps_context* c, RcArgs a, int what, void* result, void* resu
     const int per_cu = std::max(1, std::min(4, (int)(160 * 1024 / smem)));
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((tiles + kRcWaves - 1) / kRcWaves, 256 * per_cu));
     const void* kern = what == 0 ? reinterpret_cast<const void*>(rc_sums_kernel<CI, CO>)
-                     : what == 1 ? reinterpret_cast<const void*>(rc_apply_kernel<CI, CO>)
+                     : what == 1 ? (a.addend ? reinterpret_cast<const void*>(rc_apply_kernel<CI, CO, true>) : reinterpret_cast<const void*>(rc_apply_kernel<CI, CO, false>))
                      : what == 2 ? reinterpret_cast<const void*>(rc_bwd_sums_kernel<CI, CO>)
                                  : reinterpret_cast<const void*>(rc_bwd_apply_kernel<CI, CO>);
     if (smem > 48 * 1024) PS_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -498,7 +521,8 @@ static int rc_launch(ps_context* c, RcArgs a, int what, void* result, void* resu
         hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3(ceil_div(2 * COP, 16)), dim3(256), 0, c->stream, static_cast<const double*>(a.part), blocks,
                            2 * COP, static_cast<double*>(result));
     } else if (what == 1) {
-        hipLaunchKernelGGL((rc_apply_kernel<CI, CO>), dim3(blocks), dim3(kRcWaves * 64), smem, c->stream, a);
+        if (a.addend) hipLaunchKernelGGL((rc_apply_kernel<CI, CO, true>), dim3(blocks), dim3(kRcWaves * 64), smem, c->stream, a);
+        else hipLaunchKernelGGL((rc_apply_kernel<CI, CO, false>), dim3(blocks), dim3(kRcWaves * 64), smem, c->stream, a);
     } else if (what == 2) {
         PS_TRY(c->red_ws.reserve(sizeof(float) * (size_t)blocks * 2 * COP + 256));
         a.part = c->red_ws.as<void>();
@@ -567,6 +591,21 @@ extern "C" int ps_op_convbn_train_apply(ps_context* c, const float* x, int64_t l
     Stage st(c, "train_convbn_fwd", 1);
     RcArgs a = {};
     a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.scale = scale; a.beta = beta; a.leaky = leaky ? 1 : 0; a.out = out; a.ldo = (int)ldo;
+    return rc_dispatch(c, cin, cout, a, 1, nullptr);
+}
+
+extern "C" int ps_op_convbn_train_apply_add(ps_context* c, const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t cin, int64_t cout,
+                                            const float* mean, const float* scale, const float* beta, const float* addend, int64_t ld_add, float* out,
+                                            int64_t ldo)
+{
+    PS_CHECK(c && w && b && mean && scale && beta && rc_ok(cin, cout) && rc_rows_ok(x, ldx, cin) && rc_rows_ok(out, ldo, cout) && rc_rows_ok(addend, ld_add, cout),
+             "ps_op_convbn_train_apply_add: unsupported (cin, cout) or unaligned rows");
+    if (R <= 0) return PS_OK;
+    PS_HIP(hipSetDevice(c->device));
+    Stage st(c, "train_convbn_fwd", 1);
+    RcArgs a = {};
+    a.x = x; a.ldx = (int)ldx; a.w = w; a.b = b; a.R = R; a.mean = mean; a.scale = scale; a.beta = beta; a.leaky = 0; a.out = out; a.ldo = (int)ldo;
+    a.addend = addend; a.ld_add = (int)ld_add;
     return rc_dispatch(c, cin, cout, a, 1, nullptr);
 }
 

@@ -1020,8 +1020,13 @@ struct ps_trainer {
         if (lp.cin * lp.cout > max_w) return false;
         return x.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x.p) & 15) == 0;
     }
-    Tn conv_bn_rect(const Tn& x, const LayerP& lp, bool leaky)
+    // addend (optional): z = LeakyReLU(BN(x . W + b) + addend) -- the residual sum of dilated_res_block in the pass that writes the second
+    // summand (ps_op_convbn_train_apply_add); `leaky` must be false then.  Its backward first forms ds = dz lrelu'(z), which is the
+    // gradient of the addend AND of this layer's BatchNorm output.
+    Tn conv_bn_rect(const Tn& x, const LayerP& lp, bool leaky, const Tn* addend_in = nullptr)
     {
+        const bool fused_add = addend_in != nullptr;
+        const Tn addend = fused_add ? *addend_in : Tn();
         const int64_t R = x.R, ci = lp.cin, co = lp.cout;
         const bool sync = sync_bn && coll_active();
         const int64_t R_total = sync ? R * world : R;
@@ -1039,9 +1044,28 @@ struct ps_trainer {
             TK_HIP(hipGetLastError());
         }
         Tn z = alloc(R, co);
-        TK(ps_op_convbn_train_apply(c, x.p, x.ld, W, b, R, ci, co, mean, scale, beta, leaky ? 1 : 0, z.p, z.ld));
+        if (fused_add)
+            TK(ps_op_convbn_train_apply_add(c, x.p, x.ld, W, b, R, ci, co, mean, scale, beta, addend.p, addend.ld, z.p, z.ld));
+        else
+            TK(ps_op_convbn_train_apply(c, x.p, x.ld, W, b, R, ci, co, mean, scale, beta, leaky ? 1 : 0, z.p, z.ld));
         float *gW = grads + lp.w, *gb = grads + lp.b, *ggamma = grads + lp.gamma, *gbeta = grads + lp.beta;
-        record(z, [=](const Tn& dz_in) {
+        record(z, [=](const Tn& dz_raw) {
+            Tn dz_in = dz_raw;
+            if (fused_add) {
+                // ds = dz lrelu'(z): the gradient of both summands (add_lrelu's backward); the addend has no other consumer in this graph,
+                // so it takes the tensor itself when it holds no gradient yet
+                const Tn dy = contig(dz_raw);
+                Tn ds = alloc(R, co);
+                TK(ps_op_add_lrelu_bwd(c, dy.p, z.p, z.numel(), ds.p));
+                if (grad_of.count(addend.id)) {
+                    Tn ds2 = alloc(R, co);
+                    TK_HIP(hipMemcpyAsync(ds2.p, ds.p, sizeof(float) * (size_t)z.numel(), hipMemcpyDeviceToDevice, stream()));
+                    accum(addend, ds2);
+                } else {
+                    grad_of[addend.id] = ds;
+                }
+                dz_in = ds;
+            }
             const bool dz_ok = dz_in.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(dz_in.p) & 15) == 0;
             const Tn dz = dz_ok ? dz_in : contig(dz_in);
             Tn acc = alloc(1, 2 * co, false);
@@ -1503,8 +1527,18 @@ struct ps_trainer {
                 f_agg2 = pre ? att_pre(f_agg, idx, B, N, K, fcat2, f_xyz2, n + "LFAatt_pooling_2") : att(fcat2, n + "LFAatt_pooling_2", K);
             }
             Tn a = conv(f_agg2, n + "mlp2", true, false);
-            Tn b = conv(feature, n + "shortcut", true, false);
-            Tn f_enc = add_lrelu(a, b);
+            Tn f_enc;
+            {
+                // the residual sum + LeakyReLU inside the shortcut's apply pass where that layer runs in the recompute form (levels 0-1)
+                static const bool fuse = !(getenv("PS_TRAIN_FUSE_RESIDUAL") && atoi(getenv("PS_TRAIN_FUSE_RESIDUAL")) == 0);  // (A/B switch)
+                const LayerP& sl = layer(n + "shortcut");
+                if (fuse && sl.gamma >= 0 && convbn_rect_ok(feature, sl) && a.contiguous() && a.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.p) & 15) == 0 && a.req) {
+                    f_enc = conv_bn_rect(feature, sl, false, &a);
+                } else {
+                    Tn b = conv(feature, n + "shortcut", true, false);
+                    f_enc = add_lrelu(a, b);
+                }
+            }
             f = maxpool(f_enc, pyr->sub_idx[i], idx, B, pyr->n[i + 1], K);
             if (i == 0) enc.push_back(f_enc);
             enc.push_back(f);

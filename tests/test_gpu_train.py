@@ -1547,6 +1547,15 @@ def test_widening_conv_bn_passes_against_float64_autograd():
         assert L.ps_op_convbn_train_apply(ctx.handle, vp(x), ldx, vp(W), vp(b), R, CI, CO, vp(mean), vp(scale), vp(beta), leaky, vp(z), CO) == 0
         rel = lambda a, r: (a.double() - r).abs().max().item() / r.abs().max().item()  # noqa: E731
         assert rel(z, z_d.detach()) <= 2e-6, (CI, CO, rel(z, z_d.detach()))
+        if not leaky:  # the residual sum of dilated_res_block inside the apply pass == the apply pass followed by ps_op_add_lrelu, bit for bit
+            addw = torch.randn(R, CO + 4, generator=g).cuda()
+            addend = addw[:, :CO]  # (a strided addend: ld_add = CO + 4)
+            fused, two = torch.empty(R, CO).cuda(), torch.empty(R, CO).cuda()
+            assert L.ps_op_convbn_train_apply_add(ctx.handle, vp(x), ldx, vp(W), vp(b), R, CI, CO, vp(mean), vp(scale), vp(beta), vp(addend), CO + 4, vp(fused),
+                                                  CO) == 0
+            ac = addend.contiguous()
+            assert L.ps_op_add_lrelu(ctx.handle, vp(z), vp(ac), R * CO, vp(two)) == 0
+            assert torch.equal(fused, two), (CI, CO)
         s12 = torch.zeros(2 * CO).cuda()
         assert L.ps_op_convbn_train_bwd_sums(ctx.handle, vp(x), ldx, vp(W), vp(b), R, CI, CO, vp(mean), vp(invstd), vp(scale), vp(beta), leaky, vp(dz), CO,
                                              vp(s12)) == 0
