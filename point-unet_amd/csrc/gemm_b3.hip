@@ -328,9 +328,11 @@ __global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradB3Args a)
     }
 }
 
-bool wgrad_b3_fits(int64_t R, int64_t cin, int64_t cout, const float* x, int64_t ldx, const float* dy, int64_t lddy)
+bool wgrad_b3_fits(int64_t R, int64_t cin, int64_t cout, const float* x, int64_t ldx, const float* dy, int64_t lddy, bool one_plane)
 {
-    static const int64_t min_rows = getenv("PS_WGRAD_B3_MIN_ROWS") ? atoll(getenv("PS_WGRAD_B3_MIN_ROWS")) : 16384;  // (experiment switch)
+    // (three planes -- the fp32 step -- from 4 096 rows: batch 8 37.32 -> 37.15 ms; the one-plane products of the bf16-MLP mode from 16 384)
+    static const int64_t env_rows = getenv("PS_WGRAD_B3_MIN_ROWS") ? atoll(getenv("PS_WGRAD_B3_MIN_ROWS")) : 0;  // (experiment switch)
+    const int64_t min_rows = env_rows > 0 ? env_rows : (one_plane ? 16384 : 4096);
     return R >= min_rows && R < (1ll << 40) && cin % 128 == 0 && cout % 128 == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
 }
@@ -372,7 +374,7 @@ int wgrad_b3_partial(ps_context* c, const float* x, int64_t ldx, const float* dy
 bool wgrad_b3_split_fits(int64_t R, int64_t cin, int64_t cout, const float* xl, int64_t ldxl, const int32_t* xidx, const float* xr, int64_t ldxr, const float* dy,
                          int64_t lddy)
 {
-    return wgrad_b3_fits(R, cin, cout, xr, ldxr, dy, lddy) && xl && xidx && ldxl % 4 == 0 && (reinterpret_cast<uintptr_t>(xl) & 15) == 0 && (cin / 2) % 4 == 0;
+    return wgrad_b3_fits(R, cin, cout, xr, ldxr, dy, lddy, /*one_plane: the split form's own floor*/ true) && xl && xidx && ldxl % 4 == 0 && (reinterpret_cast<uintptr_t>(xl) & 15) == 0 && (cin / 2) % 4 == 0;
 }
 
 int wgrad_b3_partial_split(ps_context* c, const float* xl, int64_t ldxl, const int32_t* xidx, int64_t n_src, int64_t rows_per_cloud, const float* xr, int64_t ldxr,
@@ -390,7 +392,7 @@ int wgrad_b3_partial_split(ps_context* c, const float* xl, int64_t ldxl, const i
     return PS_OK;
 }
 
-bool gemm_b3_fits(int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx)
+bool gemm_b3_fits(int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx, bool one_plane)
 {
     // Measured against rowgemm.hip (profiles/tools/gemm_shapes_ab.py, round 3, after the prefetched weight planes left scratch memory):
     //   [360k, 256] x [256, 128] 0.177 vs 0.340 ms, [90k, 512] x [512, 256] 0.148 vs 0.279, [90k, 256] x [256, 512] 0.164 vs 0.298,
@@ -399,7 +401,10 @@ bool gemm_b3_fits(int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx)
     // R >= 16384 (the measurements above): a workgroup owns 256 rows x 128 columns, so the few-row GEMMs of the deep levels leave most CUs without one ([5624, 1536]
     // x [1536, 512] 0.276 ms here against 0.125 on the split-K fp32 kernel, [5624, 512] x [512, 256] 0.078 against 0.024)
     // (8 192 <= R < 16 384 runs the 128-row workgroup form: one-cloud step 8.05 -> 7.97 ms; 4 096: 7.99, 2 048: 8.12)
-    static const int64_t min_rows = getenv("PS_GEMM_B3_MIN_ROWS") ? atoll(getenv("PS_GEMM_B3_MIN_ROWS")) : 8192;  // (experiment switch)
+    //  Batch 8: from 4 096 rows the three-plane (fp32) products gain 0.2 ms per step -- 38.6 -> 38.4 --, the one-plane products of the bf16-MLP
+    //  mode lose 0.1 (what they replace there is a bf16-MFMA kernel already).)
+    static const int64_t env_rows = getenv("PS_GEMM_B3_MIN_ROWS") ? atoll(getenv("PS_GEMM_B3_MIN_ROWS")) : 0;  // (experiment switch)
+    const int64_t min_rows = env_rows > 0 ? env_rows : (one_plane ? 8192 : 4096);
     return R >= min_rows && K >= 128 && K % 32 == 0 && N % 128 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && R < (1ll << 31);
 }
 

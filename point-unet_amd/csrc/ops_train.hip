@@ -1044,7 +1044,7 @@ namespace ps {
 
 static bool wgrad_on_b3(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout)
 {
-    return c->train_b3 && wgrad_b3_fits(R, cin, cout, x, ldx, dy, lddy);  // (bf16-MLP mode: one plane of rounded operands)
+    return c->train_b3 && wgrad_b3_fits(R, cin, cout, x, ldx, dy, lddy, c->train_bf16);  // (bf16-MLP mode: one plane of rounded operands)
 }
 
 int64_t wgrad_partial_slabs(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout)

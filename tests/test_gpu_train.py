@@ -845,7 +845,7 @@ def test_fused_locse_branch_against_float64_autograd():
 
 
 def test_large_fp32_gemms_on_split_bf16_mfma():
-    """ps_op_conv1x1_ex at the matrix-pipe-bound shapes of the training step (>= 16384 rows, cin >= 128, cout % 128 == 0) runs on bf16 MFMA
+    """ps_op_conv1x1_ex at the matrix-pipe-bound shapes of the training step (>= 4096 rows -- 8192 in the bf16-MLP mode --, cin >= 128, cout % 128 == 0) runs on bf16 MFMA
     over exact three-way splits (csrc/gemm_b3.hip).  Against a float64 product: error no larger than the fp32-MFMA path's on the same
     inputs (+ 1e-6 of the output scale) -- measured 3e-7 both; ragged row count, strided input / output, bias + LeakyReLU, accumulate."""
     import ctypes
@@ -856,7 +856,8 @@ def test_large_fp32_gemms_on_split_bf16_mfma():
     p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
     g = torch.Generator().manual_seed(21)
     try:
-        for R, K, N, leaky, acc in [(16384, 256, 128, 0, 0), (20001, 256, 256, 1, 0), (17500, 128, 256, 0, 1), (16385, 512, 512, 0, 0), (19000, 320, 256, 1, 1), (30000, 128, 128, 1, 0)]:
+        for R, K, N, leaky, acc in [(16384, 256, 128, 0, 0), (20001, 256, 256, 1, 0), (17500, 128, 256, 0, 1), (16385, 512, 512, 0, 0), (19000, 320, 256, 1, 1), (30000, 128, 128, 1, 0),
+                                     (4097, 256, 128, 1, 0), (9001, 512, 256, 0, 1), (5624, 128, 384, 1, 1)]:  # (the last three: the 128-row workgroup form of few-row products)
             xw = torch.randn(R, K + 8, generator=g).cuda()
             x = xw[:, 4:K + 4]
             W = (torch.randn(K, N, generator=g) / K ** 0.5).cuda()
@@ -1347,7 +1348,7 @@ def test_inverse_index_and_gather_reduction(oracle):
 
 
 def test_weight_gradients_on_split_bf16_mfma():
-    """ps_op_linear_wgrad_ex for many-row, 128-multiple shapes (>= 16384 rows, cin % 128 == 0, cout % 128 == 0) runs csrc/gemm_b3.hip's
+    """ps_op_linear_wgrad_ex for many-row, 128-multiple shapes (>= 4096 rows -- 16384 in the bf16-MLP mode --, cin % 128 == 0, cout % 128 == 0) runs csrc/gemm_b3.hip's
     wgrad_b3_kernel: X^T . dY on bf16 MFMA over exact three-way splits, the row axis as K, per-slab partials summed in slab order.  Against
     a float64 product: error no larger than the fp32-MFMA kernel's on the same inputs (+ 1e-6 of the output scale); strided operands, ragged
     row counts, the bias gradient; two calls give bit-identical results (no float atomics)."""
@@ -1359,7 +1360,7 @@ def test_weight_gradients_on_split_bf16_mfma():
     p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
     g = torch.Generator().manual_seed(33)
     try:
-        for R, cin, cout in [(16384, 128, 128), (20001, 256, 128), (17003, 128, 384), (40000, 128, 128)]:
+        for R, cin, cout in [(16384, 128, 128), (20001, 256, 128), (17003, 128, 384), (40000, 128, 128), (4099, 256, 128), (5624, 128, 256)]:
             xw = torch.randn(R, cin + 8, generator=g).cuda()
             dw = torch.randn(R, cout + 4, generator=g).cuda()
             x, dy = xw[:, 4:cin + 4], dw[:, :cout]
