@@ -1,6 +1,6 @@
 """Round-4 soak of the training step (not part of the test-suite): ragged cloud sizes and batch counts at the true widths through
 ps_randla_train_step against torch-CPU float64 autograd (oracle/randla_train_oracle.py); bars of tests/test_gpu_train.py's width-ladder
-test.  Sizes keep >= 23 rows at the deepest level (BatchNorm over fewer rows than K amplifies fp32 rounding past the 1e-4 logits bar:
+test (a case outside them is re-judged against the float32 evaluation of the oracle: round 5 -- n0 = 12 001, B = 2 sits on a kink).  Sizes keep >= 23 rows at the deepest level (BatchNorm over fewer rows than K amplifies fp32 rounding past the 1e-4 logits bar:
 5 003 points alone measured 1.4e-4 with loss 1.5e-7 and gradients 4e-5).  usage (GPU box): python profiles/tools/soak_train_r4.py"""
 import os
 import sys
@@ -15,21 +15,35 @@ import netcase  # noqa: E402
 import test_gpu_train as T  # noqa: E402
 from oracle import randla_train_oracle as rto  # noqa: E402
 
+failed = False
 for n0, B, mode in [(12345, 1, "fp32"), (7777, 3, "fp32"), (12001, 2, "fp32"), (9001, 2, "bf16"), (16001, 1, "fp32")]:
     cfg, xyz, feats = netcase.small_deep(n0, seed=n0, B=B)
     tr, pyr, params, labels, cw, (pts, nbr, pool, up) = T._setup(cfg, xyz, feats, mlp_dtype=mode)
     loss = tr.train_step(pyr, torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda())
     torch.cuda.synchronize()
     rule = T._bf16_rule if mode == "bf16" else None
-    want = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, step=1, bf16_rule=rule)
+    arule = T._act_rule if mode == "bf16" else None
+    want = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, step=1, bf16_rule=rule, act_rule=arule)
     got = {n: tr.G[n].cpu().numpy() for n in tr.names}
     rel_loss = abs(float(loss) - want["loss"]) / max(1.0, abs(want["loss"]))
     logit_err = float(np.abs(tr.last_logits.cpu().numpy().reshape(want["logits"].shape) - want["logits"]).max())
     rel_l2, worst = T._grad_stats(got, want["grads"], tr.names)
     print("n0 %6d B %d %s: loss rel %.2e, logits %.2e, grad rel L2 %.2e, worst tensor %.3f (%s)" % (n0, B, mode, rel_loss, logit_err, rel_l2, worst[0][0], worst[0][1]), flush=True)
     if mode == "fp32":
-        assert rel_loss <= 2e-5 and logit_err < 1e-4 and rel_l2 <= 5e-3 and worst[0][0] <= 1.0
+        ok = rel_loss <= 2e-5 and logit_err < 1e-4 and rel_l2 <= 5e-3 and worst[0][0] <= 1.0
     else:
-        assert np.isfinite(rel_l2) and rel_l2 < 0.5
+        ok = np.isfinite(rel_l2) and rel_l2 < 0.5
+    if not ok and mode == "fp32":
+        # the case's own sensitivity?  (a leaky-ReLU / max-pool decision on a value within fp32 rounding noise of the kink: the float32
+        # evaluation of the oracle then moves by the same amount in the same tensors, and the product agrees with THAT evaluation)
+        alt = rto.train_step(params, cfg.num_layers, pts, nbr, pool, up, feats, labels, cw, lr=1e-3, step=1, dtype=torch.float32)
+        s_l2, s_worst = T._grad_stats(alt["grads"], want["grads"], tr.names)
+        p_l2, p_worst = T._grad_stats(got, alt["grads"], tr.names)
+        print("   ^ outside the bars; float32 oracle vs float64 oracle: rel L2 %.2e, worst %.3f (%s); product vs float32 oracle: rel L2 %.2e, worst %.3f" % (
+            s_l2, s_worst[0][0], s_worst[0][1], p_l2, p_worst[0][0]), flush=True)
+        ok = s_l2 > 0.5 * rel_l2 and p_l2 <= 5e-3 and p_worst[0][0] <= 1.0
+    if not ok:
+        failed = True
+        print("   ^ FAILED; worst tensors:", worst[:4], flush=True)
     tr.close()
-print("ok")
+print("FAILED" if failed else "ok")
