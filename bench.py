@@ -115,7 +115,9 @@ def cpu_baseline(cfg, xyz, feats, params):
     (BASELINE.md section 3):
       value / as shipped   the KNN pyramid on ONE thread -- the reference's own threading at batch 1 (knn_.cxx:108 parallelises over the
                            batch only) -- plus the network forward on every core (TF-CPU's intra-op pool; here torch-CPU fp32)
-      all_cores            the same with the KNN queries spread over every core as well (OpenMP over queries in the oracle)
+      best_of_threads      the same with the KNN queries spread over threads as well (OpenMP over queries in the oracle) and both legs at the
+                           best thread count of a sweep ({8, 16, 32, 64, all} capped at the host's cores; torch's inter-op pool pinned to one
+                           thread) -- `threads` says how many each leg actually used, `cores` what the host has
     The NumPy fp32 forward of round 1 is timed once more for continuity ("numpy_net_seconds")."""
     import torch
     from oracle import bindings as ob
@@ -134,21 +136,27 @@ def cpu_baseline(cfg, xyz, feats, params):
     # (more threads than work items slows both legs down on a many-core host: 256 OpenMP threads take 1.75 s for what one thread
     #  does in 0.43 s, 256 torch threads 76 s for a forward that NumPy's BLAS does in 4.5 s -- so the thread counts are swept)
     t_knn_all, knn_threads = None, 1
-    for th in sorted({min(cores, 8), min(cores, 32), cores}):
+    sweep = sorted({min(cores, t) for t in (8, 16, 32, 64)})
+    for th in sorted(set(sweep) | {cores}):
         t, _ = knn_leg(th, True)
         if t_knn_all is None or t < t_knn_all:
             t_knn_all, knn_threads = t, th
     if t_knn1 < t_knn_all:
         t_knn_all, knn_threads = t_knn1, 1
-    t_net, net_how = None, ""
-    for th in sorted({min(cores, 8), min(cores, 32)}):
+    try:
+        torch.set_num_interop_threads(1)  # (one operator at a time: the graph is a chain; must precede the first parallel region)
+    except RuntimeError:
+        pass
+    t_net, net_how, net_threads, net_sweep = None, "", 0, {}
+    for th in sweep:
         torch.set_num_threads(th)
         rto.forward(params, cfg.num_layers, pts, nbr, pool, up, feats, torch.float32)  # first call: thread pool start-up, page faults
         t0 = time.perf_counter()
         rto.forward(params, cfg.num_layers, pts, nbr, pool, up, feats, torch.float32)
         t = time.perf_counter() - t0
+        net_sweep[th] = round(t, 3)
         if t_net is None or t < t_net:
-            t_net, net_how = t, "torch-CPU fp32 forward on %d threads" % th
+            t_net, net_how, net_threads = t, "torch-CPU fp32 forward on %d threads" % th, th
     t0 = time.perf_counter()
     ro.inference(params, cfg.num_layers, pts, nbr, pool, up, feats, np.float32)
     t_numpy = time.perf_counter() - t0
@@ -158,10 +166,11 @@ def cpu_baseline(cfg, xyz, feats, params):
                 sample="1 cloud of %d points, full pyramid + forward: KNN pyramid %.2f s on 1 thread (the reference's threading at batch 1, "
                        "knn_.cxx:108) + %s %.2f s (the faster of NumPy and torch-CPU, thread count swept)" % (xyz.shape[1], t_knn1, net_how, t_net),
                 knn_seconds=t_knn1, net_seconds=t_net, numpy_net_seconds=t_numpy,
-                all_cores=dict(value=n / (t_knn_all + t_net), unit="points/s", cores=cores,
-                               sample="same cloud: KNN pyramid %.2f s with the queries spread over %d threads (best of a sweep up to %d) + the same forward"
-                                      % (t_knn_all, knn_threads, cores),
-                               knn_seconds=t_knn_all, knn_threads=knn_threads, net_seconds=t_net))
+                net_threads=net_threads, net_seconds_by_threads=net_sweep,
+                best_of_threads=dict(value=n / (t_knn_all + t_net), unit="points/s", cores=cores, threads=dict(knn=knn_threads, net=net_threads),
+                                     sample="same cloud: KNN pyramid %.2f s with the queries spread over %d threads (best of %s) + the forward at its best "
+                                            "thread count (%d of %s)" % (t_knn_all, knn_threads, sorted(set(sweep) | {cores}), net_threads, sweep),
+                                     knn_seconds=t_knn_all, knn_threads=knn_threads, net_seconds=t_net))
 
 
 def spawn_ranks(n, argv, script=None, extra_env=None, poll_s=0.05):
@@ -214,6 +223,51 @@ def spawn_ranks(n, argv, script=None, extra_env=None, poll_s=0.05):
         (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return worst
+
+
+def gpu_local_cpus(gpu_index):
+    """CPUs of the NUMA node GPU `gpu_index` hangs off, read from sysfs WITHOUT touching the GPU: the KFD topology lists the GPU nodes in the
+    order HIP enumerates them (no HIP_VISIBLE_DEVICES reordering assumed) with their PCI domain / location id; the PCI device directory names
+    the CPUs next to it.  Returns a set of CPU ids, or None when any piece is missing (containers without sysfs, other drivers)."""
+    try:
+        root = "/sys/class/kfd/kfd/topology/nodes"
+        gpus = []
+        for node in sorted(os.listdir(root), key=int):
+            props = dict(line.split() for line in open(os.path.join(root, node, "properties")) if len(line.split()) == 2)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        pr = gpus[gpu_index]
+        loc, dom = int(pr["location_id"]), int(pr.get("domain", "0"))
+        bdf = "%04x:%02x:%02x.%d" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+        cpus = set()
+        for part in open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read().strip().split(","):
+            if part:
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        return cpus or None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def rank_cpu_slice(local_rank, n_local, allowed, local_cpus=None):
+    """The CPUs rank `local_rank` of `n_local` ranks on this node pins itself to: the allowed CPUs of its GPU's NUMA node (sysfs) divided
+    evenly among the ranks whose GPUs share that node is not knowable here without the other ranks' lookups, so: the rank's own even slice of
+    `allowed`, intersected with its GPU's node when that leaves at least two CPUs.  Eight Python hosts each enqueueing ~90 k launches per
+    second must not share cores (nor migrate between sockets away from their GPU)."""
+    allowed = sorted(allowed)
+    per = max(1, len(allowed) // max(n_local, 1))
+    mine = set(allowed[local_rank * per:(local_rank + 1) * per] or allowed)
+    if local_cpus:
+        near = sorted(set(allowed) & set(local_cpus))
+        if len(near) >= 2:
+            # the ranks of one NUMA node split ITS cpus by their position among the node's ranks; without knowing the others' nodes the even
+            # slice of the node's CPUs by (local_rank modulo ranks per node) is taken, assuming GPUs are spread evenly over the nodes
+            nodes = max(1, round(len(allowed) / len(near)))
+            per_node_ranks = max(1, -(-n_local // nodes))
+            k = local_rank % per_node_ranks
+            per2 = max(1, len(near) // per_node_ranks)
+            mine = set(near[k * per2:(k + 1) * per2] or near)
+    return mine
 
 
 def ranks_seen(dist, device):
@@ -604,7 +658,7 @@ def bench_train(args, cfg, rank, local_rank, world, dist):
         roofline["measured"] = "timed region (whole step); stages: hipEvent pairs over %d extra steps" % prof_steps
         out = {
             "metric": "points_per_sec_train_step", "value": whole_job_value(world, B, n0, args.steps, elapsed), "unit": "points/s",
-            "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "n_gpus": world, "ranks_seen": seen, "rank0_pinned_cpus": args.pinned_cpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             # bf16: BASELINE configs[2]'s "bf16 MLPs" -- the shared-MLP GEMMs on bf16 operands with fp32 accumulate, the rest fp32
             "dtype": "bf16" if args.bf16_mlp else "f32", "data": "synthetic",
@@ -683,12 +737,27 @@ def main():
                     help="process-group backend (nccl = RCCL, the default; gloo lets several ranks share ONE GPU for a functional check "
                          "of the N > 1 path on a single-GPU box together with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="map every rank onto the GPUs that exist (local_rank %% device_count)")
+    ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the rank's process to a slice of the CPUs next to its GPU")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: no launcher set the rendezvous up, so this process (which has not touched the GPU and
         # never will) starts the N ranks itself and relays rank 0's line
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    pinned = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.no_pin and hasattr(os, "sched_setaffinity"):
+        # BEFORE any GPU call (and before torch starts its thread pools): this rank's own slice of the CPUs next to its GPU
+        lr, nl = int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        try:
+            allowed = os.sched_getaffinity(0)
+            mine = rank_cpu_slice(lr, nl, allowed, None if args.share_gpu else gpu_local_cpus(lr))
+            if mine and len(allowed) >= 2 * nl:  # (fewer than two CPUs per rank: pinning would only serialise the rank's own threads)
+                os.sched_setaffinity(0, mine)
+                pinned = len(mine)
+        except OSError:
+            pinned = None
+    args.pinned_cpus = pinned
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -889,13 +958,31 @@ def main():
             # untimed warm-up of the service path itself: the first transfers through freshly pinned host buffers and fresh device slots
             # are slow (page registration with the DMA engines), and at the driver's --steps 20 they WERE the number (r2: 1.66 ms
             # against 1.02 once warm, profiles/tools/exp_pcie.py)
+            n_warm = 0
             for _ in range(max(3 * n_clouds, 2 * args.lanes, args.warmup)):  # (every pinned host buffer has gone through the DMA engines)
                 pcie_step()
+                n_warm += 1
             sync()
+            # ... then batches of --steps until two consecutive ones agree within 3 % (at most eight): the driver box measured 1.43 ms where the
+            # builder's measured 1.23 with a fixed warm-up; the batch times say whether the path was still warming up when it was timed
+            warm_batches = []
+            while len(warm_batches) < 8:
+                t_b, _ = timed_region(pcie_step, args.steps, sync, None)
+                warm_batches.append(1e3 * t_b / args.steps)
+                n_warm += args.steps
+                if len(warm_batches) >= 2 and abs(warm_batches[-1] - warm_batches[-2]) <= 0.03 * warm_batches[-2]:
+                    break
             t_pcie, _ = timed_region(pcie_step, args.steps, sync, None)
+            # the same region once more in four quarters (a device sync between them: the lanes drain, so each quarter is a little slower than
+            # the whole) -- first against last quarter shows a drift inside the timed region if there is one
+            q = max(1, args.steps // 4)
+            quarters = [1e3 * timed_region(pcie_step, q, sync, None)[0] / q for _ in range(4)]
             sub["include_pcie"] = {"ms_per_step": 1e3 * t_pcie / args.steps, "points_per_s": B * n0 * args.steps / t_pcie, "steps": args.steps,
+                                   "warmup_steps": n_warm, "warmup_batches_ms_per_step": [round(v, 4) for v in warm_batches],
+                                   "first_quarter_ms_per_step": round(quarters[0], 4), "last_quarter_ms_per_step": round(quarters[-1], 4),
                                    "what": "every step also copies its cloud (xyz + features) from pinned host memory and its logits back, on the "
-                                           "lane's stream (this rank only; the service rate -- never the headline value)"}
+                                           "lane's stream (this rank only; the service rate -- never the headline value); untimed warm-up until two "
+                                           "consecutive batches of --steps agree within 3 %"}
         if not args.no_sub_results and not args.att_fp32_mfma and not args.include_pcie:
             # the same timed region with attentive pooling on the fp32 MFMA (the default runs it on bf16 MFMA over exact three-way splits
             # of the fp32 operands: same accuracy, see csrc/attpool32b.hip) -- the A/B number next to the headline, this rank only
@@ -1025,6 +1112,7 @@ def main():
             "unit": "points/s",
             "n_gpus": world,
             "ranks_seen": seen,
+            "rank0_pinned_cpus": args.pinned_cpus,  # CPUs rank 0's process is pinned to (N > 1: its slice next to its GPU; null = not pinned)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,

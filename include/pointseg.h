@@ -89,6 +89,11 @@ int ps_set_att_bf16x3(ps_context* ctx, int on);
 const char* ps_last_error(void);
 /* "pointseg-hip <version> gfx950" */
 const char* ps_version(void);
+/* Layout revision of the structs a caller fills (ps_pyramid, ps_train_options, ps_randla_config): bumped whenever one of them grows.
+ * A host built against an older header would make the library read past its struct -- compare ps_abi_version() with the
+ * PS_ABI_VERSION it was compiled with before the first call (point-unet_amd/_lib.py does).  6: ps_pyramid.built, ps_train_options.act_bf16. */
+#define PS_ABI_VERSION 6
+int ps_abi_version(void);
 
 /* Per-call kernel timing on the context's stream, measured with hipEvents recorded on THAT stream.
  * ps_timing_begin arms it; every subsequent API call accumulates per-stage device time; ps_timing_end

@@ -17,7 +17,8 @@ import os as _os
 # sweep).  Set here -- importing this package is the first thing a user of the path does, before any HIP call -- unless
 # the user chose a value; ForwardPipeline warns when the runtime was already up with too few queues.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
-_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL / cross-process tensors need on this driver)
+# (nothing else is touched at import: HSA_ENABLE_IPC_MODE_LEGACY=0, which RCCL / cross-process tensors need on this pool's driver, is a
+#  deployment setting of the LAUNCHER -- bench.py and tests/conftest.py set it for their own processes)
 
 from ._lib import PointSegError, lib  # noqa: E402,F401
 

@@ -8,6 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpointseg_hip.so")
+PS_ABI_VERSION = 6  # include/pointseg.h
 
 PS_MAX_LAYERS = 8
 c_f32p = ctypes.POINTER(ctypes.c_float)
@@ -74,6 +75,7 @@ PROTOTYPES = {
     "ps_set_deferred_checks": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "ps_last_error": (ctypes.c_char_p, []),
     "ps_version": (ctypes.c_char_p, []),
+    "ps_abi_version": (ctypes.c_int, []),
     "ps_set_train_gemm_bf16": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "ps_set_train_act_bf16": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "ps_set_att_bf16x3": (ctypes.c_int, [c_vp, ctypes.c_int]),
@@ -235,6 +237,9 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        if handle.ps_abi_version() != PS_ABI_VERSION:  # (the ctypes Structures below mirror include/pointseg.h at this revision)
+            raise PointSegError("libpointseg_hip.so has struct layout revision %d, this package was written against %d: rebuild the library"
+                                % (handle.ps_abi_version(), PS_ABI_VERSION))
         _lib = handle
     return _lib
 

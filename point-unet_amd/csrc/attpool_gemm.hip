@@ -804,10 +804,9 @@ __global__ __launch_bounds__(WAVES * 64) void attg64_kernel(AttTrainArgs a, cons
     }
 }
 
-bool att64_gemm_fits(const AttTrainArgs& a, bool backward)
+bool att64_gemm_fits(const Tuning& tn, const AttTrainArgs& a, bool backward)
 {
-    static const bool on = [] { const char* e = getenv("PS_ATT64_GEMM"); return e ? atoi(e) != 0 : true; }();  // (A/B switch)
-    if (!on) return false;
+    if (!tn.att64_gemm) return false;  // (A/B knob)
     auto al = [](const void* q, int ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0; };
     if (!al(a.f, a.ld)) return false;
     if (a.fr_bf16 && (!a.fl || a.ld % 8 != 0 || !a.bf16)) return false;  // (bfloat16 rows: split form, 16-byte loads of eight values, bf16-MLP mode)
@@ -856,7 +855,7 @@ int att64_gemm(ps_context* c, AttTrainArgs a, bool backward, float* dW)
     // registers + the prefetched rows -- four waves per workgroup (one per SIMD, no scratch) or eight (two per SIMD with 23 / 57 registers
     // of scratch at P = 1 / 3).  Measured on MI355X, 8 x 45 000 points (profiles/tools/exp_att64.py): fp32 1.349 ms with four, 1.443 with
     // eight; bf16 0.858 with four, 0.713 with eight (attpool_train.hip's kernels: 1.720 / 1.123).  PS_ATT64_OCC = 1 | 2 overrides.
-    static const int occ_env = [] { const char* e = getenv("PS_ATT64_OCC"); return e ? atoi(e) : 0; }();
+    const int occ_env = c->tune.att64_occ;
     if (c->train_bf16) {
         if (!backward) return launch_attg64<1, false, 12>(c, a, w1, w2, dW);
         return occ_env == 1 ? launch_attg64<1, true, 4>(c, a, w1, w2, dW) : launch_attg64<1, true, 8>(c, a, w1, w2, dW);
@@ -898,8 +897,11 @@ extern "C" int ps_op_att_pool_gemm_bwd(ps_context* c, const float* fset, int64_t
                                        float* dfset, int64_t lddf, int accumulate, float* dscores, int64_t ldds)
 {
     PS_CHECK(c && fset && wfc && dagg && dfset && dscores, "ps_op_att_pool_gemm_bwd: NULL argument");
-    PS_CHECK(attg_ok(K, d, fset, ld) && R * K < (1ll << 31) && lddf >= d && attg_ok(K, d, dscores, ldds),
-             "ps_op_att_pool_gemm_bwd: K = 16, d in {128, 256, 512}, rows 16-byte aligned (got K %lld, d %lld, ld %lld)", (long long)K, (long long)d, (long long)ld);
+    // (the backward is built for d = 128 / 256 only -- ps_op_att_pool_gemm_supported; d = 512, which the forward accepts, would run the 256-wide
+    //  kernel over 512-wide rows.  dfset / dscores leave in 16-byte stores: their bases and pitches are checked like the inputs')
+    PS_CHECK((d == 128 || d == 256) && attg_ok(K, d, fset, ld) && R * K < (1ll << 31) && attg_ok(K, d, dfset, lddf) && attg_ok(K, d, dscores, ldds),
+             "ps_op_att_pool_gemm_bwd: K = 16, d in {128, 256}, rows of fset / dfset / dscores 16-byte aligned with pitches %% 4 == 0 (got K %lld, d %lld, ld %lld, lddf %lld, ldds %lld)",
+             (long long)K, (long long)d, (long long)ld, (long long)lddf, (long long)ldds);
     if (R <= 0) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
     Stage st(c, "train_att_gemm_bwd", 3);
@@ -908,10 +910,7 @@ extern "C" int ps_op_att_pool_gemm_bwd(ps_context* c, const float* fset, int64_t
     a.rows = R * K; a.points = R; a.df_accum = accumulate ? 1 : 0;
     PS_TRY(attg_planes(c, wfc, d, false, &a.w1));
     PS_TRY(attg_planes(c, wfc, d, true, &a.w2));
-    switch (d) {
-        case 128: return launch_attg<128, true>(c, a);
-        default: return launch_attg<256, true>(c, a);
-    }
+    return d == 128 ? launch_attg<128, true>(c, a) : launch_attg<256, true>(c, a);
 }
 
 /* split-source forms: F = [fl[idx] | fr] is never materialised (include/pointseg_train_ops.h) */
@@ -945,8 +944,10 @@ extern "C" int ps_op_att_pool_gemm_bwd_split(ps_context* c, const float* fl, int
                                              int64_t ld_rows, float* dfr, int64_t lddr, int accumulate, float* dscores, int64_t ldds)
 {
     PS_CHECK(c && wfc && dagg && dfl_rows && dfr && dscores && attg_split_ok(fl, ldl, idx, B, n_src, n_q, fr, ldr, K, d) && ld_rows >= d / 2 && lddr >= d / 2 &&
+                 ld_rows % 4 == 0 && lddr % 4 == 0 && ((reinterpret_cast<uintptr_t>(dfl_rows) | reinterpret_cast<uintptr_t>(dfr)) & 15) == 0 &&
                  attg_ok(K, d, dscores, ldds),
-             "ps_op_att_pool_gemm_bwd_split: K = 16, d in {128, 256}, rows and the index table 16-byte aligned (got K %lld, d %lld)", (long long)K, (long long)d);
+             "ps_op_att_pool_gemm_bwd_split: K = 16, d in {128, 256}, every row array (inputs, dfl_rows, dfr, dscores) and the index table 16-byte aligned with pitches %% 4 == 0 (got K %lld, d %lld)",
+             (long long)K, (long long)d);
     const int64_t R = B * n_q;
     if (R <= 0) return PS_OK;
     PS_HIP(hipSetDevice(c->device));

@@ -33,7 +33,7 @@ struct AttTrainArgs {
 // d = 64 (encoder level 1) on v_mfma_f32_32x32x16_bf16 with both weight images resident in LDS (attpool_gemm.hip): forward, or backward with
 // the weight gradient accumulated in registers (dW: [64, 64], overwritten).  Handles the plain form and the split-source form with row
 // outputs (a.dfl_rows); the float-atomic scatter form stays with attpool_train.hip.
-bool att64_gemm_fits(const AttTrainArgs& a, bool backward);
+bool att64_gemm_fits(const Tuning& tn, const AttTrainArgs& a, bool backward);
 int att64_gemm(ps_context* c, AttTrainArgs a, bool backward, float* dW);
 
 }  // namespace ps

@@ -968,7 +968,7 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
     if constexpr (D == 64) {
         // level 1: the 32x32x16 bf16 matrix pipe (exact three-way splits in fp32 mode), weights resident in LDS, dWfc in registers
         // (attpool_gemm.hip: 0.63 -> 0.3 ms forward, 1.71 -> 0.9 ms backward per pooling of 5.76 M rows)
-        if (att64_gemm_fits(a, backward)) return att64_gemm(c, a, backward, dW);
+        if (att64_gemm_fits(c->tune, a, backward)) return att64_gemm(c, a, backward, dW);
     }
     if (a.bf16) {  // the bf16-MLP mode: operands kept as bfloat16 in LDS, products on the bf16 matrix pipe
         constexpr int PB = AttBf16Geom<D>::PB;
@@ -983,7 +983,7 @@ static int launch_att_train(ps_context* c, AttTrainArgs a, bool backward, float*
             const int occ = std::min(per_cu, att_resident_blocks(reinterpret_cast<const void*>(kern), WAVES_F * 64, smem, per_cu));
             const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((a.R + WAVES_F - 1) / WAVES_F, 256 * occ));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES_F * 64), smem, c->stream, a);
-        } else if (D == 128 && a.vec_store && !getenv("PS_ATT_NO_SPLIT")) {
+        } else if (D == 128 && a.vec_store && !c->tune.att_no_split) {
             // four waves per point (att_train_bwd_bf16_cs_kernel): three groups per workgroup share the 74 KB of weights: 897 us against
             // 1 192 us for the one-wave-per-point kernel.  (d = 64, four groups: 1 334 us against 1 100 us -- the barriers of a sixteen-wave
             // workgroup cost more than its shorter chains gain: not used there.)

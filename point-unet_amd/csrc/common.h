@@ -113,8 +113,46 @@ int pack_batch_ops(ps_context* c, const PackJob* table, int n);  // ops.hip
 int pack_batch_b3(ps_context* c, const PackJob* table, int n);   // gemm_b3.hip
 }  // namespace ps
 
+namespace ps {
+// Experiment knobs of profiles/tools/*.  The DEFAULT build never reads the environment: the values below are what ships, every context holds
+// the same ones, and nothing else in the library calls getenv.  A library built with -DPS_TUNING_ENV (profiles/tools/build_variant.sh) fills
+// the struct ONCE, in ps_create (tuning_from_env, context.hip), from the PS_* variables named here, clamped to what the kernels are compiled
+// for; the trainer reads its knobs from its context when it is created.  No function-static caches, no per-call getenv.
+struct Tuning {
+    // gemm32b.hip / gemm32.hip (forward dense layers of the deep levels)
+    double gemm32b_min_flops = 3e8;  // PS_GEMM32B_MIN_FLOPS: products at least this large run on split-bf16 MFMA (0 = all that fit, 1e30 = none)
+    int gemm32b_rw = 0, gemm32b_cw = 0;  // PS_GEMM32B_RW / _CW: tile shape override, 1 or 2 (0 = the heuristic)
+    bool gemm32_no_sk8 = false;      // PS_GEMM32_NO_SK8
+    // attpool_gemm.hip / attpool_train.hip
+    bool att64_gemm = true;          // PS_ATT64_GEMM=0: level 1's training pooling back on attpool_train.hip's per-point kernels
+    int att64_occ = 0;               // PS_ATT64_OCC: 1 | 2 = the other occupancy of the d = 64 backward (bf16 / fp32)
+    bool att_no_split = false;       // PS_ATT_NO_SPLIT: the one-wave-per-point bf16 backward at d = 128
+    // gemm_b3.hip / ops_train.hip
+    int64_t wgrad_b3_min_rows = 0;   // PS_WGRAD_B3_MIN_ROWS (0 = 4 096 three planes / 16 384 one plane)
+    int64_t gemm_b3_min_rows = 0;    // PS_GEMM_B3_MIN_ROWS (0 = 4 096 / 8 192)
+    int64_t wgrad_wgs = 512;         // PS_WGRAD_WGS, clamped to [64, 4096]: workgroups (= partial slabs x blocks) of a weight-gradient launch
+    bool bn_slice = false;           // PS_BN_SLICE=1: the one-launch BatchNorm for small tensors (measured no faster: DESIGN.md 4.3)
+    // invidx.hip
+    bool inv_bucket = true;          // PS_INV_BUCKET=0: the radix-sort form of the inverse index
+    int inv_tile = 4096;             // PS_INV_TILE in {4096, 8192}
+    bool gather_reduce_ordered = true;  // PS_GATHER_REDUCE_ORDERED=0
+    int maxpool_bwd_ordered = 1;     // PS_MAXPOOL_BWD_ORDERED=0: the one-entry cloud-order walk
+    // trainer.hip (read at ps_trainer_create)
+    bool train_act_bf16 = true;      // PS_TRAIN_ACT_BF16=0 (next to ps_train_options.act_bf16)
+    int train_att_gemm_split = -1;   // PS_TRAIN_ATT_GEMM_SPLIT: -1 = bf16-MLP mode only
+    bool train_att_gemm = true;      // PS_TRAIN_ATT_GEMM=0
+    bool train_att128_fwd_gemm = true;  // PS_TRAIN_ATT128_FWD_GEMM=0
+    bool train_fuse_residual = true; // PS_TRAIN_FUSE_RESIDUAL=0
+    int convbn_max_c = 64;           // PS_CONVBN_MAX_C
+    int convbn_rect_max = 1 << 30;   // PS_CONVBN_RECT_MAX (cin * cout)
+    bool wgrad_debug = false;        // PS_WGRAD_DEBUG: print the first step's weight-gradient shapes
+};
+void tuning_from_env(Tuning& t);  // context.hip: a no-op unless the library is built with -DPS_TUNING_ENV
+}  // namespace ps
+
 struct ps_context {
     int device = 0;
+    ps::Tuning tune;         // (see above: constants in the default build)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     ps::Arena knn_arena;     // kd-trees + query scratch
@@ -126,12 +164,8 @@ struct ps_context {
     ps::PackCache* pack_cache = nullptr;  // (set by the native training step around its work: the step's weight images, packed by ONE launch)
     ps::DevBuf ops_ring[4];  // packed weights of ps_op_conv1x1 (a ring: consecutive calls never repack into the buffer the previous GEMM is still reading)
     int ops_ring_pos = 0;
-    // dense layers of the deep levels / the decoder with at least this many FLOPs on bf16 MFMA over exact three-way splits (gemm32b.hip)
-    // instead of the fp32 MFMA (gemm32.hip); switched with the attention's form by ps_set_att_bf16x3.  PS_GEMM32B_MIN_FLOPS / _RW / _CW:
-    // A/B overrides read once at ps_create
-    double gemm32b_min_flops = 3e8;
-    int gemm32b_rw = 0, gemm32b_cw = 0;
-    bool gemm32_no_sk8 = false;  // PS_GEMM32_NO_SK8: A/B of the eight-wave split-K form of gemm32.hip
+    // (dense layers of the deep levels / the decoder with at least tune.gemm32b_min_flops FLOPs run on bf16 MFMA over exact three-way splits,
+    //  gemm32b.hip, instead of the fp32 MFMA, gemm32.hip; switched with the attention's form by ps_set_att_bf16x3)
     bool att_bf16x3 = true;   // ps_set_att_bf16x3: attentive pooling at d = 64 / 128 on bf16 MFMA over three-way splits (attpool32b.hip)
     bool train_b3 = true;     // ps_set_train_gemm_b3: large fp32 op-level GEMMs on bf16 MFMA over exact three-way splits (gemm_b3.hip)
     bool conv_w_transposed = false;  // (internal, set around a call by the native trainer) ps_op_conv1x1_ex: w is stored [cout, cin]
@@ -200,13 +234,18 @@ struct Stage {
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-// ps_pyramid.built: what ps_pyramid_build leaves behind and the trainer recomputes -- any change of a table pointer or shape breaks it
+// ps_pyramid.built: what ps_pyramid_build leaves behind and the trainer recomputes -- any change of a table pointer or shape breaks it.
+// It vouches for STRUCTURE (sub_idx is the prefix of neigh_idx, order[] is a permutation), which holds for every build, also one whose
+// status words later report a degenerate cloud (the searches then write index 0 rows and order[t] = t: kdtree.h / knn.hip); the CONTENTS of
+// the tables are the caller's to leave alone -- point-unet_amd/pyramid.py: Pyramid.invalidate() drops the stamp after an in-place edit.
 inline uint64_t pyramid_stamp(const ps_pyramid* p)
 {
     uint64_t h = 0x50535059524D4944ull ^ (uint64_t)p->B ^ ((uint64_t)p->K << 32) ^ ((uint64_t)p->num_layers << 48);
     for (int i = 0; i < p->num_layers && i < PS_MAX_LAYERS; ++i) {
         h = (h ^ (uint64_t)reinterpret_cast<uintptr_t>(p->sub_idx[i])) * 0x9E3779B97F4A7C15ull;
         h = (h ^ (uint64_t)reinterpret_cast<uintptr_t>(p->neigh_idx[i])) * 0x9E3779B97F4A7C15ull;
+        h = (h ^ (uint64_t)reinterpret_cast<uintptr_t>(p->interp_idx[i])) * 0x9E3779B97F4A7C15ull;
+        h = (h ^ (uint64_t)reinterpret_cast<uintptr_t>(p->order[i])) * 0x9E3779B97F4A7C15ull;  // (the trainer scatters through order[]: a swapped table breaks the stamp)
         h = (h ^ (uint64_t)p->n[i] ^ ((uint64_t)p->n[i + 1] << 32)) * 0x9E3779B97F4A7C15ull;
     }
     return h | 1ull;
@@ -228,13 +267,13 @@ struct WgradJob {
 int64_t wgrad_partial_slabs(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout);
 int wgrad_partial(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout, float* part,
                   float* dbpart);
-bool wgrad_b3_fits(int64_t R, int64_t cin, int64_t cout, const float* x, int64_t ldx, const float* dy, int64_t lddy, bool one_plane);
-int64_t wgrad_b3_slabs(int64_t R, int64_t cin, int64_t cout);
+bool wgrad_b3_fits(const ps::Tuning& tn, int64_t R, int64_t cin, int64_t cout, const float* x, int64_t ldx, const float* dy, int64_t lddy, bool one_plane);
+int64_t wgrad_b3_slabs(const ps::Tuning& tn, int64_t R, int64_t cin, int64_t cout);
 int wgrad_b3_partial(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout, float* part,
                      float* dbpart);
 int64_t wgrad_split_slabs(ps_context* c, const float* xl, int64_t ldxl, const int32_t* xidx, const float* xr, int64_t ldxr, const float* dy, int64_t lddy,
                           int64_t R, int64_t cin, int64_t cout);  // 0: the split-source weight gradient does not apply to these operands
-bool wgrad_b3_split_fits(int64_t R, int64_t cin, int64_t cout, const float* xl, int64_t ldxl, const int32_t* xidx, const float* xr, int64_t ldxr, const float* dy,
+bool wgrad_b3_split_fits(const ps::Tuning& tn, int64_t R, int64_t cin, int64_t cout, const float* xl, int64_t ldxl, const int32_t* xidx, const float* xr, int64_t ldxr, const float* dy,
                          int64_t lddy);
 int wgrad_b3_partial_split(ps_context* c, const float* xl, int64_t ldxl, const int32_t* xidx, int64_t n_src, int64_t rows_per_cloud, const float* xr, int64_t ldxr,
                            const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout, float* part);

@@ -149,7 +149,48 @@ extern "C" {
 
 const char* ps_last_error(void) { return ps::g_err; }
 
+}  // extern "C"
+
+namespace ps {
+void tuning_from_env(Tuning& t)
+{
+#ifdef PS_TUNING_ENV
+    auto num = [](const char* name, double& out) { const char* v = std::getenv(name); if (v && *v) { out = std::atof(v); return true; } return false; };
+    auto flag = [&](const char* name, bool& b) { double v; if (num(name, v)) b = v != 0; };
+    auto clampi = [&](const char* name, int64_t lo, int64_t hi, int64_t& x) { double v; if (num(name, v)) x = v < lo ? lo : (v > hi ? hi : (int64_t)v); };
+    double v;
+    if (num("PS_GEMM32B_MIN_FLOPS", v) && v >= 0) t.gemm32b_min_flops = v;
+    if (num("PS_GEMM32B_RW", v) && (v == 1 || v == 2)) t.gemm32b_rw = (int)v;
+    if (num("PS_GEMM32B_CW", v) && (v == 1 || v == 2)) t.gemm32b_cw = (int)v;
+    t.gemm32_no_sk8 = std::getenv("PS_GEMM32_NO_SK8") != nullptr;
+    flag("PS_ATT64_GEMM", t.att64_gemm);
+    if (num("PS_ATT64_OCC", v) && (v == 1 || v == 2)) t.att64_occ = (int)v;
+    t.att_no_split = std::getenv("PS_ATT_NO_SPLIT") != nullptr;
+    clampi("PS_WGRAD_B3_MIN_ROWS", 0, 1ll << 40, t.wgrad_b3_min_rows);
+    clampi("PS_GEMM_B3_MIN_ROWS", 0, 1ll << 40, t.gemm_b3_min_rows);
+    clampi("PS_WGRAD_WGS", 64, 4096, t.wgrad_wgs);
+    flag("PS_BN_SLICE", t.bn_slice);
+    flag("PS_INV_BUCKET", t.inv_bucket);
+    if (num("PS_INV_TILE", v) && (v == 4096 || v == 8192)) t.inv_tile = (int)v;
+    flag("PS_GATHER_REDUCE_ORDERED", t.gather_reduce_ordered);
+    if (num("PS_MAXPOOL_BWD_ORDERED", v)) t.maxpool_bwd_ordered = v != 0;
+    flag("PS_TRAIN_ACT_BF16", t.train_act_bf16);
+    if (num("PS_TRAIN_ATT_GEMM_SPLIT", v)) t.train_att_gemm_split = v < 0 ? -1 : (v != 0);
+    flag("PS_TRAIN_ATT_GEMM", t.train_att_gemm);
+    flag("PS_TRAIN_ATT128_FWD_GEMM", t.train_att128_fwd_gemm);
+    flag("PS_TRAIN_FUSE_RESIDUAL", t.train_fuse_residual);
+    if (num("PS_CONVBN_MAX_C", v) && v >= 0 && v <= 4096) t.convbn_max_c = (int)v;
+    if (num("PS_CONVBN_RECT_MAX", v) && v >= 0) t.convbn_rect_max = v > (double)(1 << 30) ? 1 << 30 : (int)v;
+    t.wgrad_debug = std::getenv("PS_WGRAD_DEBUG") != nullptr;
+#else
+    (void)t;
+#endif
+}
+}  // namespace ps
+
+extern "C" {
 const char* ps_version(void) { return "pointseg-hip 0.1 gfx950"; }
+int ps_abi_version(void) { return PS_ABI_VERSION; }
 
 int ps_create(int device, ps_context** out)
 {
@@ -167,11 +208,7 @@ int ps_create(int device, ps_context** out)
         return PS_EHIP;
     }
     c->stream = c->own_stream;
-    // A/B overrides of the split-bf16 dense layers (gemm32b.hip): FLOP threshold (0 = every shape that fits, 1e30 = none), tile shape
-    if (const char* v = std::getenv("PS_GEMM32B_MIN_FLOPS")) c->gemm32b_min_flops = std::atof(v);
-    if (const char* v = std::getenv("PS_GEMM32B_RW")) c->gemm32b_rw = std::atoi(v);
-    if (const char* v = std::getenv("PS_GEMM32B_CW")) c->gemm32b_cw = std::atoi(v);
-    c->gemm32_no_sk8 = std::getenv("PS_GEMM32_NO_SK8") != nullptr;
+    ps::tuning_from_env(c->tune);  // (nothing in the default build: common.h, struct Tuning)
     *out = c;
     return PS_OK;
 }

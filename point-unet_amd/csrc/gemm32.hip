@@ -142,7 +142,7 @@ int gemm32(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc&
     const int64_t units = (int64_t)rblocks * cgroups;
     int sk = 1;
     while (sk < 8 && units * sk < 1536 && L.cin / 8 / (sk * 2) >= 8) sk *= 2;
-    if (sk == 8 && c->gemm32_no_sk8) sk = 4;
+    if (sk == 8 && c->tune.gemm32_no_sk8) sk = 4;
     const dim3 block(sk > 4 ? 64 * sk : 256);
     const int rb_per_wg = sk > 4 ? 1 : 4 / sk;
     a.cgroups = cgroups;

@@ -288,8 +288,8 @@ int gemm32b(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc
     int cw = L.cout % 64 == 0 ? 2 : 1;
     int rw = (int64_t)(rblocks / 2) * (L.cout / (32 * cw)) >= 1024 ? 2 : 1;
     // (A/B overrides of the tile shape, PS_GEMM32B_RW / PS_GEMM32B_CW: only the compiled shapes 1 and 2; anything else is ignored)
-    if (c->gemm32b_rw == 1 || c->gemm32b_rw == 2) rw = c->gemm32b_rw;
-    if ((c->gemm32b_cw == 1 || c->gemm32b_cw == 2) && L.cout % (32 * c->gemm32b_cw) == 0) cw = c->gemm32b_cw;
+    if (c->tune.gemm32b_rw == 1 || c->tune.gemm32b_rw == 2) rw = c->tune.gemm32b_rw;
+    if ((c->tune.gemm32b_cw == 1 || c->tune.gemm32b_cw == 2) && L.cout % (32 * c->tune.gemm32b_cw) == 0) cw = c->tune.gemm32b_cw;
     const int cgroups = L.cout / (32 * cw);
     const int runits = (rblocks + rw - 1) / rw;
     // split K across the waves of a workgroup while the plain grid leaves SIMDs idle (1 024 of them) and the slices keep >= 4 chunks

@@ -328,19 +328,19 @@ __global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradB3Args a)
     }
 }
 
-bool wgrad_b3_fits(int64_t R, int64_t cin, int64_t cout, const float* x, int64_t ldx, const float* dy, int64_t lddy, bool one_plane)
+bool wgrad_b3_fits(const Tuning& tn, int64_t R, int64_t cin, int64_t cout, const float* x, int64_t ldx, const float* dy, int64_t lddy, bool one_plane)
 {
     // (three planes -- the fp32 step -- from 4 096 rows: batch 8 37.32 -> 37.15 ms; the one-plane products of the bf16-MLP mode from 16 384)
-    static const int64_t env_rows = getenv("PS_WGRAD_B3_MIN_ROWS") ? atoll(getenv("PS_WGRAD_B3_MIN_ROWS")) : 0;  // (experiment switch)
+    const int64_t env_rows = tn.wgrad_b3_min_rows;  // (experiment knob)
     const int64_t min_rows = env_rows > 0 ? env_rows : (one_plane ? 16384 : 4096);
     return R >= min_rows && R < (1ll << 40) && cin % 128 == 0 && cout % 128 == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
 }
 
-static void wgrad_b3_plan(int64_t R, int64_t cin, int64_t cout, int64_t& rows_per_slab, int64_t& slabs)
+static void wgrad_b3_plan(const Tuning& tn, int64_t R, int64_t cin, int64_t cout, int64_t& rows_per_slab, int64_t& slabs)
 {
     const int64_t blocks = (cin / 128) * (cout / 128);
-    static const int64_t total = getenv("PS_WGRAD_WGS") ? atoll(getenv("PS_WGRAD_WGS")) : 512;  // (768 / 512 / 384 / 256 measured: one-cloud step 8.03 / 7.95 / 7.96 / 8.17 ms, batch 8: 39.0 / 38.1 / 38.8 / 39.3 -- every slab is a partial the finish reads back)
+    const int64_t total = tn.wgrad_wgs;  // 512 (768 / 512 / 384 / 256 measured: one-cloud step 8.03 / 7.95 / 7.96 / 8.17 ms, batch 8: 39.0 / 38.1 / 38.8 / 39.3 -- every slab is a partial the finish reads back)
     int64_t want = total / blocks;  // ~2 workgroups per CU
     want = want < 1 ? 1 : want;
     rows_per_slab = (R + want - 1) / want;
@@ -349,10 +349,10 @@ static void wgrad_b3_plan(int64_t R, int64_t cin, int64_t cout, int64_t& rows_pe
     slabs = (R + rows_per_slab - 1) / rows_per_slab;
 }
 
-int64_t wgrad_b3_slabs(int64_t R, int64_t cin, int64_t cout)
+int64_t wgrad_b3_slabs(const Tuning& tn, int64_t R, int64_t cin, int64_t cout)
 {
     int64_t rps, slabs;
-    wgrad_b3_plan(R, cin, cout, rps, slabs);
+    wgrad_b3_plan(tn, R, cin, cout, rps, slabs);
     return slabs;
 }
 
@@ -362,7 +362,7 @@ int wgrad_b3_partial(ps_context* c, const float* x, int64_t ldx, const float* dy
     WgradB3Args a = {};
     a.x = x; a.ldx = (int)ldx; a.dy = dy; a.lddy = (int)lddy; a.R = R; a.cin = (int)cin; a.cout = (int)cout; a.part = part; a.dbpart = dbpart;
     int64_t slabs;
-    wgrad_b3_plan(R, cin, cout, a.rows_per_slab, slabs);
+    wgrad_b3_plan(c->tune, R, cin, cout, a.rows_per_slab, slabs);
     const dim3 grid((unsigned)slabs, (unsigned)(cin / 128), (unsigned)(cout / 128));
     if (c->train_bf16) hipLaunchKernelGGL(wgrad_b3_kernel<1>, grid, dim3(256), 0, c->stream, a);  // bf16-MLP mode: operands rounded, one product
     else hipLaunchKernelGGL(wgrad_b3_kernel<3>, grid, dim3(256), 0, c->stream, a);
@@ -371,10 +371,10 @@ int wgrad_b3_partial(ps_context* c, const float* x, int64_t ldx, const float* dy
 }
 
 // X = [xl[xidx] | xr] (split source, see WgradB3Args): the weight gradient of the fused attentive pooling of the wide levels
-bool wgrad_b3_split_fits(int64_t R, int64_t cin, int64_t cout, const float* xl, int64_t ldxl, const int32_t* xidx, const float* xr, int64_t ldxr, const float* dy,
+bool wgrad_b3_split_fits(const Tuning& tn, int64_t R, int64_t cin, int64_t cout, const float* xl, int64_t ldxl, const int32_t* xidx, const float* xr, int64_t ldxr, const float* dy,
                          int64_t lddy)
 {
-    return wgrad_b3_fits(R, cin, cout, xr, ldxr, dy, lddy, /*one_plane: the split form's own floor*/ true) && xl && xidx && ldxl % 4 == 0 && (reinterpret_cast<uintptr_t>(xl) & 15) == 0 && (cin / 2) % 4 == 0;
+    return wgrad_b3_fits(tn, R, cin, cout, xr, ldxr, dy, lddy, /*one_plane: the split form's own floor*/ true) && xl && xidx && ldxl % 4 == 0 && (reinterpret_cast<uintptr_t>(xl) & 15) == 0 && (cin / 2) % 4 == 0;
 }
 
 int wgrad_b3_partial_split(ps_context* c, const float* xl, int64_t ldxl, const int32_t* xidx, int64_t n_src, int64_t rows_per_cloud, const float* xr, int64_t ldxr,
@@ -384,7 +384,7 @@ int wgrad_b3_partial_split(ps_context* c, const float* xl, int64_t ldxl, const i
     a.x = xr; a.ldx = (int)ldxr; a.dy = dy; a.lddy = (int)lddy; a.R = R; a.cin = (int)cin; a.cout = (int)cout; a.part = part; a.dbpart = nullptr;
     a.xl = xl; a.ldxl = (int)ldxl; a.xidx = xidx; a.n_src = n_src; a.rows_per_cloud = rows_per_cloud; a.xh = (int)(cin / 2);
     int64_t slabs;
-    wgrad_b3_plan(R, cin, cout, a.rows_per_slab, slabs);
+    wgrad_b3_plan(c->tune, R, cin, cout, a.rows_per_slab, slabs);
     const dim3 grid((unsigned)slabs, (unsigned)(cin / 128), (unsigned)(cout / 128));
     if (c->train_bf16) hipLaunchKernelGGL(wgrad_b3_kernel<1>, grid, dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL(wgrad_b3_kernel<3>, grid, dim3(256), 0, c->stream, a);
@@ -392,7 +392,7 @@ int wgrad_b3_partial_split(ps_context* c, const float* xl, int64_t ldxl, const i
     return PS_OK;
 }
 
-bool gemm_b3_fits(int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx, bool one_plane)
+bool gemm_b3_fits(const Tuning& tn, int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx, bool one_plane)
 {
     // Measured against rowgemm.hip (profiles/tools/gemm_shapes_ab.py, round 3, after the prefetched weight planes left scratch memory):
     //   [360k, 256] x [256, 128] 0.177 vs 0.340 ms, [90k, 512] x [512, 256] 0.148 vs 0.279, [90k, 256] x [256, 512] 0.164 vs 0.298,
@@ -403,7 +403,7 @@ bool gemm_b3_fits(int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx, 
     // (8 192 <= R < 16 384 runs the 128-row workgroup form: one-cloud step 8.05 -> 7.97 ms; 4 096: 7.99, 2 048: 8.12)
     //  Batch 8: from 4 096 rows the three-plane (fp32) products gain 0.2 ms per step -- 38.6 -> 38.4 --, the one-plane products of the bf16-MLP
     //  mode lose 0.1 (what they replace there is a bf16-MFMA kernel already).)
-    static const int64_t env_rows = getenv("PS_GEMM_B3_MIN_ROWS") ? atoll(getenv("PS_GEMM_B3_MIN_ROWS")) : 0;  // (experiment switch)
+    const int64_t env_rows = tn.gemm_b3_min_rows;  // (experiment knob)
     const int64_t min_rows = env_rows > 0 ? env_rows : (one_plane ? 8192 : 4096);
     return R >= min_rows && K >= 128 && K % 32 == 0 && N % 128 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && R < (1ll << 31);
 }

@@ -618,8 +618,8 @@ int ps_op_inverse_index(ps_context* c, const int32_t* idx, int64_t B, int64_t N,
     const int64_t n_dst = B * N, rows = B * rows_per_cloud;
     unsigned* off = reinterpret_cast<unsigned*>(offsets);
     BkPlan pl;
-    static const bool bucket_on = !(getenv("PS_INV_BUCKET") && atoi(getenv("PS_INV_BUCKET")) == 0);  // (A/B switch: 0 = the radix-sort form)
-    static const int tile = getenv("PS_INV_TILE") ? atoi(getenv("PS_INV_TILE")) : kBkTile;
+    const bool bucket_on = c->tune.inv_bucket;  // (A/B knob: off = the radix-sort form)
+    const int tile = c->tune.inv_tile;          // (4 096 = kBkTile, or 8 192)
     if (rows >= kInvSortRows && bucket_on && bk_plan(B, N, rows_per_cloud, tile, &pl) &&
         (int64_t)bk_workspace_words(pl, rows) + 64 <= ps_op_inverse_index_workspace(n_dst, rows)) {
         Stage st(c, "train_inverse_index", 6);
@@ -698,7 +698,7 @@ int ps_op_gather_reduce_rows_ordered(ps_context* c, const float* rows, int64_t l
     Stage st(c, "train_scatter_add", 1);
     const bool vec = (d % 4) == 0 && (ldr % 4) == 0 && (ldd % 4) == 0 && ((reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     const unsigned* off = reinterpret_cast<const unsigned*>(offsets);
-    static const bool ordered_on = !(getenv("PS_GATHER_REDUCE_ORDERED") && atoi(getenv("PS_GATHER_REDUCE_ORDERED")) == 0);  // (A/B switch)
+    const bool ordered_on = c->tune.gather_reduce_ordered;  // (A/B knob)
     const int64_t per = d / 4;
     // rows of bfloat16 (ps_set_train_act_bf16 inside the bf16-MLP mode; ldr in elements, 8-byte aligned rows): the ordered kernel only
     const bool rb = c->train_act_bf16 && c->train_bf16;
@@ -744,7 +744,7 @@ int ps_op_random_sample_bwd_inv(ps_context* c, const float* dout, const float* o
     const bool al16 = ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(feature) |
                         reinterpret_cast<uintptr_t>(dfeature)) & 15) == 0 && (reinterpret_cast<uintptr_t>(ties) & 3) == 0;
     if (ties && d % 4 == 0 && al16 && B * N * d < (1ll << 32) && B * N * K < (1ll << 31)) {
-        static const int mode = getenv("PS_MAXPOOL_BWD_ORDERED") ? atoi(getenv("PS_MAXPOOL_BWD_ORDERED")) : 1;  // (A/B: 0 = the one-entry cloud-order walk)
+        const int mode = c->tune.maxpool_bwd_ordered;  // (A/B knob: 0 = the one-entry cloud-order walk)
         const int64_t d4 = d / 4;
         if (mode && d4 <= 256 && 256 % d4 == 0) {
             // (c->walk_order: the trainer's hint for the op it is about to enqueue -- the leaf order of the N points of this level, or NULL)

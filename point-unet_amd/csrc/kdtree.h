@@ -249,9 +249,16 @@ PS_HD bool knn_search_one(const TreeView& t, float qx, float qy, float qz, float
             // all (<= kLeafMax) point loads are issued before the first distance is needed: one memory round trip per
             // leaf instead of one per point
             float4 pv[kLeafMax];
+#ifdef PS_KNN_EXP_ONELEAFLOAD
+            // EXPERIMENT (wrong results, timing only): one record load per leaf visit instead of ten -- what the vector-memory address path costs
+            pv[0] = gload(t.pts + lf_x);
+#pragma unroll
+            for (int j = 1; j < kLeafMax; ++j) { pv[j] = pv[0]; pv[j].x += 1e-3f * j; }
+#else
 #pragma unroll
             for (int j = 0; j < kLeafMax; ++j) pv[j] = gload(t.pts + lf_x + j);  // one address, ten immediate offsets: the record
             // array is padded by kLeafMax entries (TreeSetPlan::carve), slots past the leaf's end are read and ignored below
+#endif
 #pragma unroll
             for (int j = 0; j < kLeafMax; ++j) {
                 // A slot past the leaf's end gets d = FLT_MAX, which never beats the current worst.  The insertion then runs

@@ -219,6 +219,359 @@ __device__ __forceinline__ void knn_body(const KnnJob& job, float* win)
     }
 }
 
+
+#ifdef PS_KNN_REFILL_EXP
+// ---- EXPERIMENT (measured and rejected, round 6; only compiled with -DPS_KNN_REFILL_EXP, profiles/tools/exp_knn_refill.py) ----------------
+// persistent form: a wave owns Q consecutive leaf-order queries and REFILLS the lanes whose query is finished.  Bit-identical tables, but the
+// search time is one wave's latency chain, not issue slots: Q = 64 / 128 / 256 / 512 -> 0.183 / 0.317 / 0.53 / 0.91 ms (one query per lane:
+// 0.175), i.e. +0.11 ms per 64 queries a wave owns whatever the number of waves on the chip.
+// The one-query-per-lane form above runs a wave as long as its slowest lane: over 64 consecutive leaf-order queries the mean lane does
+// 0.61-0.66 of the slowest one's leaf iterations, and the kernel is bound by VALU issue -- a third of the issued lane-slots is masked off.
+// Here a lane that has finished its query takes the next one of the wave's block as soon as kKnnRefillMin lanes are idle (the
+// while-while loop of Aila & Laine's persistent ray traversal): finished lanes hand their rows out, draw the next queries in order
+// (rank among the idle lanes), start them (seed, root distances) and join the others in the descent loop.  The arithmetic of a query
+// is exactly that of knn_search_one (kdtree.h): same visit order, same insertions, same result.
+// The finished rows leave through the lanes' own (drained, hence free) columns of the LDS stack window: K / 4 adjacent lanes write one
+// row's 4K contiguous bytes in ONE store instruction (a lane storing its own row as K / 4 16-byte pieces touches 64 different
+// lines a quarter-row at a time).
+#ifndef PS_KNN_Q
+#define PS_KNN_Q 256
+#endif
+#ifndef PS_KNN_REFILL_MIN
+#define PS_KNN_REFILL_MIN 16
+#endif
+static int knn_q() { const char* e = getenv("PS_KNN_Q"); return e ? atoi(e) : PS_KNN_Q; }                    // TEMPORARY (experiment)
+static int knn_refill_min() { const char* e = getenv("PS_KNN_REFILL_MIN"); return e ? atoi(e) : PS_KNN_REFILL_MIN; }
+
+#ifdef PS_KNN_PROF
+__device__ unsigned long long g_knn_prof[16];
+#define PS_PROF_T() __builtin_readcyclecounter()
+#endif
+
+// position of the r-th (0-based) set bit of m; r < popcount(m)
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int r)
+{
+    unsigned w = (unsigned)m;
+    int pos = 0;
+    int c = __popc(w);
+    if (r >= c) { r -= c; pos = 32; w = (unsigned)(m >> 32); }
+#pragma unroll
+    for (int s = 16; s >= 1; s >>= 1) {
+        c = __popc(w & ((1u << s) - 1u));
+        if (r >= c) { r -= c; pos += s; w >>= s; }
+    }
+    return pos;
+}
+
+template <int K>
+__device__ __forceinline__ void knn_body_refill(const KnnJob& job, float* win, const int kKnnQ, const int kKnnRefillMin)
+{
+    static_assert(kKnnThreads == 64, "one wave per workgroup");
+    typedef WindowStack::lds_float lds_float;
+    const int lane = threadIdx.x;
+    const int n_blocks = (job.nq + kKnnQ - 1) / kKnnQ;
+    const int per_xcd = (n_blocks + 7) >> 3;  // XCD-aware order, as in knn_body
+    if ((int)(blockIdx.x >> 3) >= per_xcd) return;
+    const int bx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int q_begin = bx * kKnnQ;
+    if (q_begin >= job.nq) return;
+    const int q_end = min(q_begin + kKnnQ, job.nq);
+    if (gload(job.overflow + 1) != 0) {  // broken tree (builder queue overflow): valid indices, the status word reports the failure
+        for (int t = q_begin + lane; t < q_end; t += 64) {
+            const int row = t;
+            if (job.q4 && job.order) gstore(job.order + t, row);
+            for (int j = 0; j < K; ++j) gstore(job.out + (size_t)row * K + j, 0);
+            if (row < job.sub_m)
+                for (int j = 0; j < K; ++j) gstore(job.sub_out + (size_t)row * K + j, 0);
+        }
+        return;
+    }
+    const TreeView tr = job.tree;
+    if (tr.n <= 0) {  // nothing to find: rows of zeros (the list's initial indices)
+        for (int t = q_begin + lane; t < q_end; t += 64) {
+            const int row = job.q4 ? as_i(gload(job.q4 + t).w) : t;
+            if (job.q4 && job.order) gstore(job.order + t, row);
+            for (int j = 0; j < K; ++j) gstore(job.out + (size_t)row * K + j, 0);
+            if (row < job.sub_m)
+                for (int j = 0; j < K; ++j) gstore(job.sub_out + (size_t)row * K + j, 0);
+        }
+        return;
+    }
+    const TreeMeta mt = *tr.meta;
+    const bool self_seed = K > 1 && job.q4 == tr.pts && job.nq >= K;
+    const bool wide_seed = self_seed && K <= 32 && job.nq >= 2 * K - 1;
+    const bool up_seed = K == 1 && job.prefix && job.q4 != nullptr && job.nq >= 32;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    float dist[K];
+    int idx[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { dist[j] = FLT_MAX; idx[j] = 0; }
+    SpillStore spill;
+    WindowStack st;
+    st.sp_ = &spill;
+    st.w = (lds_float*)(win + lane);
+    float qx = 0.f, qy = 0.f, qz = 0.f, m = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    int row = 0, cur = 0;
+    bool have = false, active = false, ok = true;
+    int next = q_begin;  // wave-uniform: first query of the block nobody has taken yet
+#ifdef PS_KNN_PROF
+    unsigned long long pf_t0 = PS_PROF_T(), pf_refill = 0, pf_desc = 0, pf_leaf = 0, pf_pop = 0, pf_iters = 0, pf_events = 0, pf_lanes = 0, pf_steps = 0;
+#endif
+
+    for (;;) {
+#ifdef PS_KNN_PROF
+        const unsigned long long pf_a = PS_PROF_T();
+#endif
+        const unsigned long long act = __ballot(active);
+        const int n_idle = 64 - __popcll(act);
+        if (act == 0ull || (next < q_end && n_idle >= kKnnRefillMin)) {
+            // ---- hand out the rows of the finished lanes ----
+            const unsigned long long fin = __ballot(!active && have);
+            if (fin != 0ull) {
+                if constexpr (K == 8 || K == 16 || K == 32) {
+                    constexpr int P = K / 4, RPI = 64 / P;  // lanes per row, rows per store instruction
+                    if (!active && have) {
+#pragma unroll
+                        for (int j = 0; j < K; ++j) st.w[j * kKnnThreads] = as_f(idx[j]);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int n_fin = __popcll(fin);
+                    const lds_float* wbase = (const lds_float*)win;
+                    for (int g0 = 0; g0 < n_fin; g0 += RPI) {
+                        const int r = g0 + lane / P, piece = lane % P;
+                        const int src = nth_set_bit(fin, min(r, n_fin - 1));
+                        const int rrow = __shfl(row, src);
+                        int4 v;
+                        v.x = as_i(wbase[(piece * 4 + 0) * kKnnThreads + src]);
+                        v.y = as_i(wbase[(piece * 4 + 1) * kKnnThreads + src]);
+                        v.z = as_i(wbase[(piece * 4 + 2) * kKnnThreads + src]);
+                        v.w = as_i(wbase[(piece * 4 + 3) * kKnnThreads + src]);
+                        if (r < n_fin) {
+                            gstore(reinterpret_cast<int4*>(job.out + (size_t)rrow * K + piece * 4), v);
+                            if (rrow < job.sub_m) gstore(reinterpret_cast<int4*>(job.sub_out + (size_t)rrow * K + piece * 4), v);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    if (!active && have) {
+                        int32_t* o = job.out + (size_t)row * K;
+                        int32_t* o2 = row < job.sub_m ? job.sub_out + (size_t)row * K : nullptr;
+                        if constexpr (K % 4 == 0) {
+#pragma unroll
+                            for (int j = 0; j < K; j += 4) gstore(reinterpret_cast<int4*>(o + j), make_int4(idx[j], idx[j + 1], idx[j + 2], idx[j + 3]));
+                            if (o2) {
+#pragma unroll
+                                for (int j = 0; j < K; j += 4)
+                                    gstore(reinterpret_cast<int4*>(o2 + j), make_int4(idx[j], idx[j + 1], idx[j + 2], idx[j + 3]));
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < K; ++j) gstore(o + j, idx[j]);
+                            if (o2) {
+#pragma unroll
+                                for (int j = 0; j < K; ++j) gstore(o2 + j, idx[j]);
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- the idle lanes draw the next queries of the block, in order ----
+            if (!active) {
+                const int t = next + __popcll(~act & lt_mask);
+                have = t < q_end;
+                if (have) {
+                    if (job.q4) {
+                        const float4 q = gload(job.q4 + t);
+                        qx = q.x; qy = q.y; qz = q.z;
+                        row = as_i(q.w);
+                        if (job.order) gstore(job.order + t, row);
+                    } else {
+                        qx = gload(job.q3 + 3 * (size_t)t);
+                        qy = gload(job.q3 + 3 * (size_t)t + 1);
+                        qz = gload(job.q3 + 3 * (size_t)t + 2);
+                        row = t;
+                    }
+                    // the seeded list of knn_body (same bounds, same arithmetic)
+                    float seed = FLT_MAX;
+                    if constexpr (K > 1 && K <= 32) {
+                        if (wide_seed) {
+                            const int w0 = min(max(t - (K - 1), 0), job.nq - (2 * K - 1));
+                            float d[2 * K - 1];
+#pragma unroll
+                            for (int j = 0; j < 2 * K - 1; ++j) {
+                                const float4 p = gload(job.q4 + w0 + j);
+                                d[j] = sq_dist(qx, qy, qz, p.x, p.y, p.z);
+                            }
+#pragma unroll
+                            for (int j = K - 3; j >= 0; --j) d[j] = fmaxf(d[j], d[j + 1]);
+#pragma unroll
+                            for (int j = K; j < 2 * K - 1; ++j) d[j] = fmaxf(d[j], d[j - 1]);
+                            float mm = d[K - 1 + K - 1];
+#pragma unroll
+                            for (int sft = 0; sft < K - 1; ++sft) mm = fminf(mm, fmaxf(d[sft], d[sft + K - 1]));
+                            seed = __fadd_rn(__fadd_rn(mm, __fmul_rn(mm, 1e-6f)), 1e-30f);
+                        }
+                    }
+                    if constexpr (K > 1) {
+                        if (self_seed && !wide_seed) {
+                            const int w0 = min(max(t - K / 2, 0), job.nq - K);
+                            float mm = 0.f;
+#pragma unroll
+                            for (int j = 0; j < K; ++j) {
+                                const float4 p = gload(job.q4 + w0 + j);
+                                mm = fmaxf(mm, sq_dist(qx, qy, qz, p.x, p.y, p.z));
+                            }
+                            seed = __fadd_rn(__fadd_rn(mm, __fmul_rn(mm, 1e-6f)), 1e-30f);
+                        }
+                    }
+                    if constexpr (K == 1) {
+                        if (up_seed) {
+                            const int w0 = min(max(t - 16, 0), job.nq - 32);
+                            float mm = FLT_MAX;
+#pragma unroll
+                            for (int j = 0; j < 32; ++j) {
+                                const float4 p = gload(job.q4 + w0 + j);
+                                const float dd = sq_dist(qx, qy, qz, p.x, p.y, p.z);
+                                mm = as_i(p.w) < tr.n ? fminf(mm, dd) : mm;
+                            }
+                            if (mm < FLT_MAX) seed = __fadd_rn(__fadd_rn(mm, __fmul_rn(mm, 1e-6f)), 1e-30f);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < K; ++j) { dist[j] = seed; idx[j] = 0; }
+                    // computeInitialDistances (nanoflann.hpp:1045-1061)
+                    d0 = 0.f; d1 = 0.f; d2 = 0.f; m = 0.f;
+                    if (qx < mt.lo[0]) { d0 = f_mul(f_sub(qx, mt.lo[0]), f_sub(qx, mt.lo[0])); m = f_add(m, d0); }
+                    if (qx > mt.hi[0]) { d0 = f_mul(f_sub(qx, mt.hi[0]), f_sub(qx, mt.hi[0])); m = f_add(m, d0); }
+                    if (qy < mt.lo[1]) { d1 = f_mul(f_sub(qy, mt.lo[1]), f_sub(qy, mt.lo[1])); m = f_add(m, d1); }
+                    if (qy > mt.hi[1]) { d1 = f_mul(f_sub(qy, mt.hi[1]), f_sub(qy, mt.hi[1])); m = f_add(m, d1); }
+                    if (qz < mt.lo[2]) { d2 = f_mul(f_sub(qz, mt.lo[2]), f_sub(qz, mt.lo[2])); m = f_add(m, d2); }
+                    if (qz > mt.hi[2]) { d2 = f_mul(f_sub(qz, mt.hi[2]), f_sub(qz, mt.hi[2])); m = f_add(m, d2); }
+                    cur = mt.root;
+                    st.sp = 0;
+                    st.lo = 0;
+                    active = true;
+                }
+            }
+            next += n_idle;
+#ifdef PS_KNN_PROF
+            ++pf_events;
+#endif
+            if (__ballot(active) == 0ull) break;
+        }
+#ifdef PS_KNN_PROF
+        const unsigned long long pf_b = PS_PROF_T();
+        pf_refill += pf_b - pf_a;
+        ++pf_iters;
+        pf_lanes += __popcll(__ballot(active));
+#endif
+        if (active) {
+            // ---- descend to a leaf, deferring the far children (searchLevel, nanoflann.hpp:1372-1406; as knn_search_one) ----
+#define PS_KD_VISIT(nd, left_first)                                                                                          \
+    {                                                                                                                        \
+        const int ax = (int)((unsigned)(nd).x >> 30);                                                                        \
+        const int c1 = (nd).x & 0x3fffffff, c2 = (nd).y;                                                                     \
+        const float divlow = as_f((nd).z), divhigh = as_f((nd).w);                                                           \
+        const float val = ax == 0 ? qx : (ax == 1 ? qy : qz);                                                                \
+        const float diff1 = f_sub(val, divlow), diff2 = f_sub(val, divhigh);                                                 \
+        left_first = f_add(diff1, diff2) < 0.f;                                                                              \
+        const float e = left_first ? diff2 : diff1;                                                                          \
+        const float cut = f_mul(e, e);                                                                                       \
+        const float dax = ax == 0 ? d0 : (ax == 1 ? d1 : d2);                                                                \
+        const float m2 = f_sub(f_add(m, cut), dax);                                                                          \
+        if (m2 <= dist[K - 1])                                                                                               \
+            ok &= st.push(left_first ? c2 : c1, m2, ax == 0 ? cut : d0, ax == 1 ? cut : d1, ax == 2 ? cut : d2);             \
+        cur = left_first ? c1 : c2;                                                                                          \
+    }
+            if (tr.fat) {
+                while (cur & 1) {
+#ifdef PS_KNN_PROF
+                    ++pf_steps;
+#endif
+                    const int4* f = tr.fat + 3 * (size_t)cur;
+                    const int4 nd = gload(f), kl = gload(f + 1), kr = gload(f + 2);
+                    bool left;
+                    PS_KD_VISIT(nd, left)
+                    if (cur & 1) {
+                        int4 kid;
+                        kid.x = left ? kl.x : kr.x; kid.y = left ? kl.y : kr.y; kid.z = left ? kl.z : kr.z; kid.w = left ? kl.w : kr.w;
+                        bool left2;
+                        PS_KD_VISIT(kid, left2)
+                    }
+                }
+            } else {
+                while (cur & 1) {
+                    const int4 nd = gload(tr.nodes + cur);
+                    bool left;
+                    PS_KD_VISIT(nd, left)
+                }
+            }
+#undef PS_KD_VISIT
+#ifdef PS_KNN_PROF
+            const unsigned long long pf_c = PS_PROF_T();
+            pf_desc += pf_c - pf_b;
+#endif
+            // ---- leaf: its points in vind order (nanoflann.hpp:1355-1369) ----
+            {
+                const int lf_x = (cur & kRefIdMask) >> 1, lf_y = lf_x + (cur >> kRefIdBits);
+                float4 pv[kLeafMax];
+#pragma unroll
+                for (int j = 0; j < kLeafMax; ++j) pv[j] = gload(tr.pts + lf_x + j);
+#pragma unroll
+                for (int j = 0; j < kLeafMax; ++j) {
+                    const float d = lf_x + j < lf_y ? sq_dist(qx, qy, qz, pv[j].x, pv[j].y, pv[j].z) : FLT_MAX;
+                    if (__ballot(d < dist[K - 1]) != 0ull) topk_insert<K>(dist, idx, d, as_i(pv[j].w));
+                }
+            }
+#ifdef PS_KNN_PROF
+            const unsigned long long pf_d = PS_PROF_T();
+            pf_leaf += pf_d - pf_c;
+#endif
+            // ---- resume at the most recent deferred child that still passes the prune test ----
+            if (!st.pop(dist[K - 1], cur, m, d0, d1, d2)) active = false;
+#ifdef PS_KNN_PROF
+            pf_pop += PS_PROF_T() - pf_d;
+#endif
+        }
+    }
+#ifdef PS_KNN_PROF
+    if (K > 1 && lane == 0) {
+        atomicAdd(&g_knn_prof[0], 1ull);
+        atomicAdd(&g_knn_prof[1], PS_PROF_T() - pf_t0);
+        atomicAdd(&g_knn_prof[2], pf_refill);
+        atomicAdd(&g_knn_prof[3], pf_desc);
+        atomicAdd(&g_knn_prof[4], pf_leaf);
+        atomicAdd(&g_knn_prof[5], pf_pop);
+        atomicAdd(&g_knn_prof[6], pf_iters);
+        atomicAdd(&g_knn_prof[7], pf_events);
+        atomicAdd(&g_knn_prof[8], pf_lanes);
+        atomicAdd(&g_knn_prof[9], pf_steps);
+    }
+#endif
+    if (!ok) gstore(job.overflow, 1);
+}
+
+template <int K>
+__global__ __launch_bounds__(kKnnThreads) void knn_refill_kernel(const KnnJob* __restrict__ jobs, int q, int rmin)
+{
+    __shared__ float win[kWin * 5 * kKnnThreads];
+    knn_body_refill<K>(jobs[blockIdx.y], win, q, rmin);
+}
+
+template <int K>
+__global__ __launch_bounds__(kKnnThreads) void knn_pair_refill_kernel(const KnnJob* __restrict__ jobs, int n_first, int q, int rmin)
+{
+    __shared__ float win[kWin * 5 * kKnnThreads];
+    if ((int)blockIdx.y < n_first) knn_body_refill<K>(jobs[blockIdx.y], win, q, rmin);
+    else knn_body_refill<1>(jobs[blockIdx.y], win, q, rmin);
+}
+
+#endif  // PS_KNN_REFILL_EXP
+
 template <int K>
 __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const KnnJob* __restrict__ jobs)
 {
@@ -243,18 +596,44 @@ __global__ void widen_kernel(const int32_t* __restrict__ in, int64_t* __restrict
     if (i < count) out[i] = in[i];
 }
 
+#ifdef PS_KNN_REFILL_EXP
+static bool knn_refill_on()
+{
+    const char* e = getenv("PS_KNN_REFILL");  // (experiment build only; uncached: flipped inside one process by exp_knn_refill.py)
+    return e ? atoi(e) != 0 : false;
+}
+#endif
+
+#ifdef PS_KNN_REFILL_EXP
+#define PS_KNN_REFILL_LAUNCH(kern, ...) if (refill) hipLaunchKernelGGL(kern, grid, dim3(kKnnThreads), 0, c->stream, __VA_ARGS__); else
+#else
+#define PS_KNN_REFILL_LAUNCH(kern, ...)
+#endif
+
 static int launch_knn(ps_context* c, const KnnJob* d_jobs, int n_jobs, int max_nq, int K)
 {
-    dim3 grid((ceil_div(max_nq, kKnnThreads) + 7) & ~7, n_jobs);  // a multiple of 8: the XCD remap in the kernel covers [0, grid) exactly
+#ifdef PS_KNN_REFILL_EXP
+    const bool refill = knn_refill_on();
+    const int kq = knn_q(), krm = knn_refill_min();
+#else
+    constexpr bool refill = false;
+    constexpr int kq = kKnnThreads;
+#endif
+    dim3 grid((ceil_div(max_nq, refill ? kq : kKnnThreads) + 7) & ~7, n_jobs);  // a multiple of 8: the XCD remap in the kernel covers [0, grid) exactly
     if (grid.x == 0 || n_jobs == 0) return PS_OK;
     switch (K) {
 #define PS_KCASE(k)                                                             \
     case k:                                                                     \
+        PS_KNN_REFILL_LAUNCH(knn_refill_kernel<k>, d_jobs, kq, krm)                                                   \
         hipLaunchKernelGGL(knn_kernel<k>, grid, dim3(kKnnThreads), 0, c->stream, d_jobs); \
         break;
+#ifdef PS_KNN_FEW_K
+        PS_KCASE(1) PS_KCASE(16) PS_KCASE(32)
+#else
         PS_KCASE(1) PS_KCASE(2) PS_KCASE(3) PS_KCASE(4) PS_KCASE(5) PS_KCASE(6) PS_KCASE(7) PS_KCASE(8)
         PS_KCASE(9) PS_KCASE(10) PS_KCASE(11) PS_KCASE(12) PS_KCASE(13) PS_KCASE(14) PS_KCASE(15) PS_KCASE(16)
         PS_KCASE(20) PS_KCASE(24) PS_KCASE(32) PS_KCASE(48) PS_KCASE(64)
+#endif
 #undef PS_KCASE
         default:
             set_error("ps_knn: K=%d is not a compiled size (1..16, 20, 24, 32, 48, 64)", K);
@@ -267,16 +646,28 @@ static int launch_knn(ps_context* c, const KnnJob* d_jobs, int n_jobs, int max_n
 static int launch_knn_pair(ps_context* c, const KnnJob* d_jobs, int n_first, int n_jobs, int max_nq, int K)
 {
     if (K == 1) return launch_knn(c, d_jobs, n_jobs, max_nq, 1);
-    dim3 grid((ceil_div(max_nq, kKnnThreads) + 7) & ~7, n_jobs);
+#ifdef PS_KNN_REFILL_EXP
+    const bool refill = knn_refill_on();
+    const int kq = knn_q(), krm = knn_refill_min();
+#else
+    constexpr bool refill = false;
+    constexpr int kq = kKnnThreads;
+#endif
+    dim3 grid((ceil_div(max_nq, refill ? kq : kKnnThreads) + 7) & ~7, n_jobs);
     if (grid.x == 0 || n_jobs == 0) return PS_OK;
     switch (K) {
 #define PS_KCASE(k)                                                                            \
     case k:                                                                                    \
+        PS_KNN_REFILL_LAUNCH(knn_pair_refill_kernel<k>, d_jobs, n_first, kq, krm)                                      \
         hipLaunchKernelGGL(knn_pair_kernel<k>, grid, dim3(kKnnThreads), 0, c->stream, d_jobs, n_first); \
         break;
+#ifdef PS_KNN_FEW_K
+        PS_KCASE(16) PS_KCASE(32)
+#else
         PS_KCASE(2) PS_KCASE(3) PS_KCASE(4) PS_KCASE(5) PS_KCASE(6) PS_KCASE(7) PS_KCASE(8)
         PS_KCASE(9) PS_KCASE(10) PS_KCASE(11) PS_KCASE(12) PS_KCASE(13) PS_KCASE(14) PS_KCASE(15) PS_KCASE(16)
         PS_KCASE(20) PS_KCASE(24) PS_KCASE(32) PS_KCASE(48) PS_KCASE(64)
+#endif
 #undef PS_KCASE
         default:
             set_error("ps_pyramid_build: K=%d is not a compiled size (1..16, 20, 24, 32, 48, 64)", K);
@@ -289,6 +680,18 @@ static int launch_knn_pair(ps_context* c, const KnnJob* d_jobs, int n_first, int
 }  // namespace ps
 
 using namespace ps;
+
+#ifdef PS_KNN_PROF
+extern "C" int ps_debug_knn_prof(unsigned long long* out16, int reset)
+{
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_knn_prof), 128) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_knn_prof), z, 128) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // --------------------------------------------------------------------------------------------------------
 // ps_knn_batch

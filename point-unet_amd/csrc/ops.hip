@@ -444,7 +444,7 @@ extern "C" int ps_op_conv1x1_ex(ps_context* c, const float* x, int64_t ldx, cons
         PS_HIP(hipGetLastError());
         return PS_OK;
     }
-    if (c->train_b3 && gemm_b3_fits(R, cin, cout, x, ldx, c->train_bf16)) {  // (bf16-MLP mode: the same tiling on ONE plane of rounded operands)
+    if (c->train_b3 && gemm_b3_fits(c->tune, R, cin, cout, x, ldx, c->train_bf16)) {  // (bf16-MLP mode: the same tiling on ONE plane of rounded operands)
         // matrix-pipe bound shapes (att_pooling's score products at d >= 128): bf16 MFMA over exact splits, fp32-level error
         PackJob key = {};
         key.w = w; key.sk = sk; key.sn = sn; key.kind = c->train_bf16 ? 4 : 3; key.cin = (int)cin; key.cout = (int)cout;

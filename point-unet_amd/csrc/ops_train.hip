@@ -435,13 +435,12 @@ __global__ __launch_bounds__(kBnSliceThreads) void bn_slice_bwd_kernel(const flo
     }
 }
 
-static bool bn_slice_ok(int64_t R, int64_t C, const void* x, const void* y, int64_t ldy)
+static bool bn_slice_ok(const Tuning& tn, int64_t R, int64_t C, const void* x, const void* y, int64_t ldy)
 {
     // OFF by default: measured on MI355X the one-cloud step makes 39 launches fewer with it (644 -> 605) and takes the same time
     // (8.56 against 8.61 ms; with 11 250-row layers included 9.74) -- the step's small kernels already run back to back, a launch less is
     // not time less.  PS_BN_SLICE=1 switches it on for A/B.
-    static const bool on = [] { const char* e = getenv("PS_BN_SLICE"); return e ? atoi(e) != 0 : false; }();
-    return on && R <= kBnSliceRows && C % kBnSliceCh == 0 && ldy % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    return tn.bn_slice && R <= kBnSliceRows && C % kBnSliceCh == 0 && ldy % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
 }
 
 // Elementwise BatchNorm kernels.  VEC: float4 per thread with a grid stride that is a multiple of C (1024 % C == 0), so a
@@ -721,13 +720,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x,
 
 // rows per slab and number of slabs of a weight-gradient launch (the partials are [slabs][cin][cout])
 template <int TI, int TJ, int WK>
-static void wgrad_slabs(int64_t R, int cin, int cout, int64_t& rpb, int64_t& nb)
+static void wgrad_slabs(const Tuning& tn, int64_t R, int cin, int cout, int64_t& rpb, int64_t& nb)
 {
     constexpr int CI = TI * (4 / WK) * 16, CJ = TJ * 16;
     constexpr int kWgChunk = wg_chunk(CI + CJ) > 16 * WK ? wg_chunk(CI + CJ) : 16 * WK;  // >= either flavour's chunk
     const int ty = (cin + CI - 1) / CI, tz = (cout + CJ - 1) / CJ;
     // ~2 workgroups per CU; fewer, longer slabs when the dW block is large (every slab is a [cin, cout] partial the reduction reads back)
-    static const int64_t total = getenv("PS_WGRAD_WGS") ? atoll(getenv("PS_WGRAD_WGS")) : 512;  // (768 / 512 / 384 / 256 measured: one-cloud step 8.03 / 7.95 / 7.96 / 8.17 ms, batch 8: 39.0 / 38.1 / 38.8 / 39.3 -- every slab is a partial the finish reads back)
+    const int64_t total = tn.wgrad_wgs;  // 512 (768 / 512 / 384 / 256 measured: one-cloud step 8.03 / 7.95 / 7.96 / 8.17 ms, batch 8: 39.0 / 38.1 / 38.8 / 39.3 -- every slab is a partial the finish reads back)
     int64_t slabs = total / ((int64_t)ty * tz);
     slabs = slabs < 1 ? 1 : slabs;
     rpb = (R + slabs - 1) / slabs;
@@ -742,7 +741,7 @@ static void launch_wgrad(ps_context* c, const float* x, int ldx, const float* dy
     constexpr int CI = TI * (4 / WK) * 16, CJ = TJ * 16;
     const int ty = (cin + CI - 1) / CI, tz = (cout + CJ - 1) / CJ;
     int64_t rpb, nb;
-    wgrad_slabs<TI, TJ, WK>(R, cin, cout, rpb, nb);
+    wgrad_slabs<TI, TJ, WK>(c->tune, R, cin, cout, rpb, nb);
     // float4 staging needs every row start and block origin on a 16-byte boundary (CI, CJ are multiples of 16 already)
     const bool vec = ((cin | cout | ldx | lddy) & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
     const dim3 grid((unsigned)nb, ty, tz);
@@ -1044,16 +1043,16 @@ namespace ps {
 
 static bool wgrad_on_b3(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout)
 {
-    return c->train_b3 && wgrad_b3_fits(R, cin, cout, x, ldx, dy, lddy, c->train_bf16);  // (bf16-MLP mode: one plane of rounded operands)
+    return c->train_b3 && wgrad_b3_fits(c->tune, R, cin, cout, x, ldx, dy, lddy, c->train_bf16);  // (bf16-MLP mode: one plane of rounded operands)
 }
 
 int64_t wgrad_partial_slabs(ps_context* c, const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t R, int64_t cin, int64_t cout)
 {
     if (R <= 0) return 0;
-    if (wgrad_on_b3(c, x, ldx, dy, lddy, R, cin, cout)) return wgrad_b3_slabs(R, cin, cout);
+    if (wgrad_on_b3(c, x, ldx, dy, lddy, R, cin, cout)) return wgrad_b3_slabs(c->tune, R, cin, cout);
     const int ti = (int)((cin + 15) / 16), tj = (int)((cout + 15) / 16);
     int64_t rpb = 0, nb = 0;
-#define PS_WG(TI, TJ, WK) wgrad_slabs<TI, TJ, WK>(R, (int)cin, (int)cout, rpb, nb)
+#define PS_WG(TI, TJ, WK) wgrad_slabs<TI, TJ, WK>(c->tune, R, (int)cin, (int)cout, rpb, nb)
     PS_WGRAD_DISPATCH(ti, tj, PS_WG);
 #undef PS_WG
     return nb;
@@ -1079,8 +1078,8 @@ int wgrad_partial(ps_context* c, const float* x, int64_t ldx, const float* dy, i
 int64_t wgrad_split_slabs(ps_context* c, const float* xl, int64_t ldxl, const int32_t* xidx, const float* xr, int64_t ldxr, const float* dy, int64_t lddy,
                           int64_t R, int64_t cin, int64_t cout)
 {
-    if (!c->train_b3 || !wgrad_b3_split_fits(R, cin, cout, xl, ldxl, xidx, xr, ldxr, dy, lddy)) return 0;
-    return wgrad_b3_slabs(R, cin, cout);
+    if (!c->train_b3 || !wgrad_b3_split_fits(c->tune, R, cin, cout, xl, ldxl, xidx, xr, ldxr, dy, lddy)) return 0;
+    return wgrad_b3_slabs(c->tune, R, cin, cout);
 }
 
 // dst = sum over the slabs, in slab order (fixed order: deterministic).  blockIdx.y walks a table of jobs, so every weight and bias
@@ -1215,7 +1214,7 @@ int ps_op_bn_train_fwd_ex(ps_context* c, const float* x, const float* gamma, con
     PS_CHECK(c && x && gamma && beta && y && mean && invstd && var && scratch2C, "ps_op_bn_train_fwd: NULL argument");
     PS_CHECK(R >= 1 && C >= 1 && ldy >= C, "ps_op_bn_train_fwd: empty tensor");
     PS_HIP(hipSetDevice(c->device));
-    if (bn_slice_ok(R, C, x, y, ldy)) {
+    if (bn_slice_ok(c->tune, R, C, x, y, ldy)) {
         Stage st1(c, "train_bn_fwd", 1);
         hipLaunchKernelGGL(bn_slice_fwd_kernel, dim3((unsigned)(C / kBnSliceCh)), dim3(kBnSliceThreads), 0, c->stream, x, gamma, beta, (int)R, (int)C, eps, leaky, y, ldy, mean, invstd,
                            var, scratch2C, static_cast<float*>(nullptr), static_cast<float*>(nullptr), 0.f);
@@ -1241,7 +1240,7 @@ int ps_op_bn_train_fwd_mov(ps_context* c, const float* x, const float* gamma, co
     PS_CHECK(c && x && gamma && beta && y && mean && invstd && var && scratch2C && moving_mean && moving_var, "ps_op_bn_train_fwd_mov: NULL argument");
     PS_CHECK(R >= 1 && C >= 1 && ldy >= C, "ps_op_bn_train_fwd_mov: empty tensor");
     PS_HIP(hipSetDevice(c->device));
-    if (bn_slice_ok(R, C, x, y, ldy)) {
+    if (bn_slice_ok(c->tune, R, C, x, y, ldy)) {
         Stage st1(c, "train_bn_fwd", 1);
         hipLaunchKernelGGL(bn_slice_fwd_kernel, dim3((unsigned)(C / kBnSliceCh)), dim3(kBnSliceThreads), 0, c->stream, x, gamma, beta, (int)R, (int)C, eps, leaky, y, ldy, mean, invstd,
                            var, scratch2C, moving_mean, moving_var, momentum);
@@ -1273,7 +1272,7 @@ int ps_op_bn_train_bwd_ex(ps_context* c, const float* dy, int64_t lddy, const fl
     PS_CHECK(c && dy && x && gamma && beta && mean && invstd && dx && dgamma && dbeta, "ps_op_bn_train_bwd: NULL argument");
     PS_CHECK(lddy >= C, "ps_op_bn_train_bwd: row stride of dy below the channel count");
     PS_HIP(hipSetDevice(c->device));
-    if (R >= 1 && bn_slice_ok(R, C, x, dy, lddy) && (reinterpret_cast<uintptr_t>(dx) & 15) == 0) {
+    if (R >= 1 && bn_slice_ok(c->tune, R, C, x, dy, lddy) && (reinterpret_cast<uintptr_t>(dx) & 15) == 0) {
         Stage st1(c, "train_bn_bwd", 1);
         hipLaunchKernelGGL(bn_slice_bwd_kernel, dim3((unsigned)(C / kBnSliceCh)), dim3(kBnSliceThreads), 0, c->stream, dy, lddy, x, gamma, beta, mean, invstd, (int)R, (int)C, leaky, dx,
                            dgamma, dbeta);

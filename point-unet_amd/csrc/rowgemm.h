@@ -106,7 +106,7 @@ int regchain(ps_context* c, const ChainStep* steps, int n_steps, const RowSrc& s
 int rowchain(ps_context* c, const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2, int64_t R, ChainCache* cache = nullptr);
 
 // gemm_b3.hip: large fp32 products of the training step on bf16 MFMA over exact three-way splits
-bool gemm_b3_fits(int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx, bool one_plane);
+bool gemm_b3_fits(const Tuning& tn, int64_t R, int64_t K, int64_t N, const float* x, int64_t ldx, bool one_plane);
 size_t gemm_b3_plane_bytes(int64_t K, int64_t N);
 int gemm_b3(ps_context* c, const float* x, int64_t ldx, const float* w, int64_t sk, int64_t sn, const float* bias, int64_t R, int64_t K, int64_t N, int leaky,
             int accumulate, float* y, int64_t ldy, void* planes, int pack = 1);  // pack = 0: `planes` already hold this matrix (PackCache)

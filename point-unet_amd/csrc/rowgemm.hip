@@ -632,19 +632,14 @@ __global__ __launch_bounds__(256) void rowchain_kernel(ChainArgs a)
     }
 }
 
-// A/B door for measurements: PS_OLD_CHAIN=1 in the environment sends every chain to the LDS-staged rowchain_kernel below
-// instead of regchain.hip (both are parity-tested; the network's own shapes are 1.2-2.4x faster in regchain).
-static bool use_regchain()
-{
-    static const bool on = std::getenv("PS_OLD_CHAIN") == nullptr;
-    return on;
-}
+// (the network's own chain shapes run in regchain.hip, 1.2-2.4x faster than the LDS-staged rowchain_kernel below, which stays as the
+//  form for every other shape; both are parity-tested)
 
 static bool lds_chain_fits(const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2);
 
 bool rowchain_fits(const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2)
 {
-    return (use_regchain() && regchain_fits(steps, n_steps, s1, s2)) || lds_chain_fits(steps, n_steps, s1, s2);
+    return regchain_fits(steps, n_steps, s1, s2) || lds_chain_fits(steps, n_steps, s1, s2);
 }
 
 static bool lds_chain_fits(const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2)
@@ -665,7 +660,7 @@ static bool lds_chain_fits(const ChainStep* steps, int n_steps, const RowSrc& s1
 int rowchain(ps_context* c, const ChainStep* steps, int n_steps, const RowSrc& s1, const RowSrc& s2, int64_t R, ChainCache* cache)
 {
     if (R <= 0) return PS_OK;
-    if (use_regchain() && regchain_fits(steps, n_steps, s1, s2)) return regchain(c, steps, n_steps, s1, s2, R, cache);
+    if (regchain_fits(steps, n_steps, s1, s2)) return regchain(c, steps, n_steps, s1, s2, R, cache);
     PS_CHECK(lds_chain_fits(steps, n_steps, s1, s2), "rowchain: the layer chain does not fit (channels above %d or mismatched)", kChainMaxC);
     PS_CHECK(R < (int64_t)1 << 31, "rowchain: too many rows");
     ChainArgs a = {};
@@ -743,7 +738,7 @@ int rowgemm(ps_context* c, const PackedLinear& L, const RowSrc& s1, const RowSrc
 {
     if (R <= 0) return PS_OK;
     PS_CHECK(s1.c + s2.c == L.cin, "rowgemm: sources give %d channels, layer expects %d", s1.c + s2.c, L.cin);
-    if (c->att_bf16x3 && 2.0 * (double)R * L.cin * L.cout >= c->gemm32b_min_flops && gemm32b_fits(L, s1, s2, R, ldy))
+    if (c->att_bf16x3 && 2.0 * (double)R * L.cin * L.cout >= c->tune.gemm32b_min_flops && gemm32b_fits(L, s1, s2, R, ldy))
         return gemm32b(c, L, s1, s2, R, y, ldy);                                  // ... the large ones on split-bf16 MFMA (gemm32b.hip)
     if (gemm32_fits(L, s1, s2, R, ldy)) return gemm32(c, L, s1, s2, R, y, ldy);  // deep levels: 32x32x2 tiles (gemm32.hip)
     PS_CHECK(R < (1ll << 31), "rowgemm: too many rows");

@@ -451,9 +451,10 @@ struct ps_trainer {
     // 35.20 -> 34.97 ms with it, the fp32 step 39.71 -> 39.97 ms (the gathering loader of the weight-gradient kernel: 0.71 against 0.40 ms
     // per level-2 pooling, and the forward kernel drops from three to two waves per SIMD) -- on by default in the bf16-MLP mode only;
     // PS_TRAIN_ATT_GEMM_SPLIT = 0 | 1 overrides (-1: by mode)
-    bool act_bf16_on = getenv("PS_TRAIN_ACT_BF16") ? atoi(getenv("PS_TRAIN_ACT_BF16")) != 0 : true;  // (A/B switch next to ps_train_options.act_bf16)
-    int att_split_env = getenv("PS_TRAIN_ATT_GEMM_SPLIT") ? atoi(getenv("PS_TRAIN_ATT_GEMM_SPLIT")) : -1;
-    bool att_gemm_on = getenv("PS_TRAIN_ATT_GEMM") ? atoi(getenv("PS_TRAIN_ATT_GEMM")) != 0 : true;  // (A/B switch of attpool_gemm.hip, read at creation)
+    // (copies of the context's experiment knobs, taken at ps_trainer_create: common.h, struct Tuning)
+    bool act_bf16_on = true;  // next to ps_train_options.act_bf16
+    int att_split_env = -1;
+    bool att_gemm_on = true;  // attpool_gemm.hip
     ps::PackCache pack;  // the step's weight images (recorded during the first step, then packed by one launch per step: common.h)
     // inverse indices of the step's gather tables (deterministic mode): built at their first use in the backward pass, kept to its end
     struct Inv {
@@ -520,7 +521,7 @@ struct ps_trainer {
         TK(c->upload_async(table.p, wjobs.data(), sizeof(WgradJob) * wjobs.size()));
         int64_t most = 1;
         for (const WgradJob& j : wjobs) most = std::max<int64_t>(most, (int64_t)j.rows * j.cols);
-        if (getenv("PS_WGRAD_DEBUG") && step < 1)
+        if (c->tune.wgrad_debug && step < 1)
             for (const WgradJob& j : wjobs)
                 fprintf(stderr, "wgrad job: slabs %d rows %d cols %d transposed %d part%%16 %d dst%%16 %d\n", j.slabs, j.rows, j.cols, j.transposed,
                         (int)(reinterpret_cast<uintptr_t>(j.part) & 15), (int)(reinterpret_cast<uintptr_t>(j.dst) & 15));
@@ -928,7 +929,7 @@ struct ps_trainer {
         if (!opt.fused_convbn || lp.cin != lp.cout || !ps_op_conv_bn_train_supported(lp.cout) || lp.kind == kDeconv || lp.b < 0) return false;
         // (bf16-MLP mode: the tile kernels round the operands of their three products like the GEMMs they replace -- cin % 16 == 0 --, the
         //  8-channel layer stays fp32 in both forms)
-        static const int max_c = [] { const char* e = getenv("PS_CONVBN_MAX_C"); return e ? atoi(e) : 64; }();  // (A/B knob of the experiments in DESIGN.md)
+        const int max_c = c->tune.convbn_max_c;  // 64 (A/B knob of the experiments in DESIGN.md)
         if (lp.cout > max_c) return false;
         return x.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x.p) & 15) == 0;  // (a column block of a concat buffer is fine)
     }
@@ -1016,7 +1017,7 @@ struct ps_trainer {
     bool convbn_rect_ok(const Tn& x, const LayerP& lp) const
     {
         if (!opt.fused_convbn || lp.kind == kDeconv || lp.b < 0 || lp.gamma < 0 || !ps_op_convbn_train_supported(lp.cin, lp.cout)) return false;
-        static const int max_w = [] { const char* e = getenv("PS_CONVBN_RECT_MAX"); return e ? atoi(e) : 1 << 30; }();  // (A/B knob: cin * cout)
+        const int max_w = c->tune.convbn_rect_max;  // (A/B knob: cin * cout)
         if (lp.cin * lp.cout > max_w) return false;
         return x.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x.p) & 15) == 0;
     }
@@ -1263,7 +1264,7 @@ struct ps_trainer {
             // d = 128 in the bf16-MLP mode: the forward on the frame of the large GEMMs (attpool_gemm.hip: scores in accumulator tiles,
             // the bfloat16 rows of f_xyz ARE operand fragments) -- 0.37 -> 0.2x ms per pooling; the backward stays with the per-point
             // kernel, which owns the weight gradient
-            static const bool fwd_gemm = !(getenv("PS_TRAIN_ATT128_FWD_GEMM") && atoi(getenv("PS_TRAIN_ATT128_FWD_GEMM")) == 0);
+            const bool fwd_gemm = c->tune.train_att128_fwd_gemm;
             const bool al = ((reinterpret_cast<uintptr_t>(f_src.p) | reinterpret_cast<uintptr_t>(f_xyz.p) | reinterpret_cast<uintptr_t>(idx)) & 15) == 0;
             if (fwd_gemm && d == 128 && opt.mlp_bf16 && act16 && al && f_src.ld % 4 == 0 && f_xyz.ld % 8 == 0 && B * M * K < (1ll << 31) && N * f_src.ld < (1ll << 31))
                 TK(ps_op_att_pool_gemm_fwd_split(c, f_src.p, f_src.ld, idx, B, N, M, f_xyz.p, f_xyz.ld, W.p, K, d, agg.p));
@@ -1530,7 +1531,7 @@ struct ps_trainer {
             Tn f_enc;
             {
                 // the residual sum + LeakyReLU inside the shortcut's apply pass where that layer runs in the recompute form (levels 0-1)
-                static const bool fuse = !(getenv("PS_TRAIN_FUSE_RESIDUAL") && atoi(getenv("PS_TRAIN_FUSE_RESIDUAL")) == 0);  // (A/B switch)
+                const bool fuse = c->tune.train_fuse_residual;  // (A/B knob)
                 const LayerP& sl = layer(n + "shortcut");
                 if (fuse && sl.gamma >= 0 && convbn_rect_ok(feature, sl) && a.contiguous() && a.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.p) & 15) == 0 && a.req) {
                     f_enc = conv_bn_rect(feature, sl, false, &a);
@@ -1660,6 +1661,10 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
     PS_HIP(hipSetDevice(c->device));
     const bool bf16 = t->opt.mlp_bf16 != 0;
     const bool was_bf16 = c->train_bf16;
+    // (ps_set_train_act_bf16 is a public setter of the op-level surface: a flag left on by an op-level caller of a shared context must not
+    //  reach the ops this step calls outside an ActScope -- the row reductions and the split-source pooling read it directly)
+    const bool was_act_bf16 = c->train_act_bf16;
+    c->train_act_bf16 = false;
     int rc = PS_OK;
     try {
         t->pool.begin_step();
@@ -1713,6 +1718,7 @@ static int run_step(ps_trainer* t, const ps_pyramid* pyr, const float* features,
         rc = PS_ENOMEM;
     }
     c->train_bf16 = was_bf16;  // the context may be shared with inference-side op calls: never leave the mode on
+    c->train_act_bf16 = was_act_bf16;
     c->pack_cache = nullptr;
     if (rc != PS_OK || t->pack.broken || (t->pack.mode == 2 && t->pack.cursor != t->pack.jobs.size())) {
         ps::pack_cache_clear(t->pack);  // another sequence of products than the recorded one (or a failed step): the next step records again
@@ -1795,6 +1801,9 @@ int ps_trainer_create(ps_context* c, const ps_randla_config* cfg, const ps_train
     for (int i = 0; i < cfg->num_layers; ++i) PS_CHECK(cfg->d_out[i] >= 2 && cfg->d_out[i] % 2 == 0, "ps_trainer_create: d_out must be even");
     ps_trainer* t = new ps_trainer();
     t->c = c;
+    t->act_bf16_on = c->tune.train_act_bf16;
+    t->att_split_env = c->tune.train_att_gemm_split;
+    t->att_gemm_on = c->tune.train_att_gemm;
     t->cfg = *cfg;
     t->opt = *opt;
     build_layout(t);

@@ -52,10 +52,15 @@ def _check_environment(lanes, reusing):
             backend = str(dist.get_backend())
         except Exception:  # noqa: BLE001
             backend = ""
-        if "nccl" in backend and os.environ.get("PS_PIPELINE_AFTER_NCCL", "0") != "1":
-            raise RuntimeError("ForwardPipeline must be created (and prime()d) BEFORE torch.distributed.init_process_group('nccl'): RCCL's internal "
-                               "streams would take the hardware queues the lanes need (measured 1.72 vs 1.31 ms per cloud).  Create the pipeline "
-                               "first, or set PS_PIPELINE_AFTER_NCCL=1 to accept the slower assignment.")
+        if "nccl" in backend:
+            # throughput only, never correctness: init_process_group first is the normal torchrun order, so this is a warning; a launcher that
+            # wants the fast order enforced sets PS_PIPELINE_STRICT_ORDER=1 (bench.py creates its pipeline first either way)
+            msg = ("ForwardPipeline created AFTER torch.distributed.init_process_group('nccl'): RCCL's internal streams take hardware queues the "
+                   "lanes would use (measured 1.72 vs 1.31 ms per cloud).  Create (and prime()) the pipeline before the process group for the "
+                   "faster assignment.")
+            if os.environ.get("PS_PIPELINE_STRICT_ORDER", "0") == "1":
+                raise RuntimeError(msg)
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
 
 class _Lane:

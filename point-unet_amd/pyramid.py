@@ -29,6 +29,11 @@ class Pyramid:
         s.n[L] = sub_idx[L - 1].shape[1]
         self.struct = s
 
+    def invalidate(self):
+        """Drop the stamp ps_pyramid_build left (ps_pyramid.built): call after editing any of the exposed tensors in place -- the training step
+        then re-checks the tables (prefix property) and stops trusting `order` as permutations instead of taking the build's word for them."""
+        self.struct.built = 0
+
     def flat_inputs(self):
         """The first 4*num_layers entries of the reference's flat input list (RandLANet.py:33-36)."""
         return list(self.xyz) + list(self.neigh_idx) + list(self.sub_idx) + list(self.interp_idx)

@@ -133,3 +133,24 @@ def test_bench_parent_never_touches_the_gpu_before_spawning():
     main = src[src.index("def main():"):]
     assert main.index("spawn_ranks(args.gpus") < main.index("import torch")
     assert "os.exec" not in src and "execv" not in src
+
+
+def test_ranks_pin_themselves_to_disjoint_cpu_slices_before_any_gpu_call():
+    """`bench.py --gpus N`: every rank pins its process (os.sched_setaffinity) to its own slice of the CPUs -- next to its GPU's NUMA node when
+    sysfs says which -- before `import torch` / any GPU call; `--no-pin` opts out.  Eight Python hosts must not share cores."""
+    sys.path.insert(0, ROOT)
+    import bench
+    allowed = set(range(128))
+    slices = [bench.rank_cpu_slice(r, 8, allowed, None) for r in range(8)]
+    assert all(len(s) == 16 for s in slices) and len(set().union(*slices)) == 128                      # disjoint, all CPUs used
+    # two NUMA nodes with four GPUs each: ranks 0-3 of a node get disjoint slices of ITS cpus
+    near = [set(range(0, 64)) if r < 4 else set(range(64, 128)) for r in range(8)]
+    slices = [bench.rank_cpu_slice(r, 8, allowed, near[r]) for r in range(8)]
+    for r in range(8):
+        assert slices[r] <= near[r] and len(slices[r]) == 16
+    assert len(set().union(*slices)) == 128
+    assert bench.rank_cpu_slice(0, 1, {3, 5}, None) == {3, 5}
+    assert bench.gpu_local_cpus(10 ** 6) is None                                                          # no such GPU / no sysfs: no pinning hint
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("os.sched_setaffinity(0, mine)") < main.index("import torch") and "--no-pin" in main

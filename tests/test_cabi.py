@@ -44,6 +44,8 @@ def test_the_stable_header_stays_small():
 
 def test_version_and_error_strings(lib):
     assert lib.ps_version().decode().startswith("pointseg-hip")
+    hdr = open(os.path.join(ROOT, "include", "pointseg.h")).read()
+    assert lib.ps_abi_version() == int(re.search(r"#define PS_ABI_VERSION (\d+)", hdr).group(1))  # header, library and ctypes table agree
     assert lib.ps_knn_batch(None, None, None, 1, 1, 1, 3, 16, None, 0) != 0   # argument check fails before any GPU call
     assert b"NULL" in lib.ps_last_error()
 

@@ -30,10 +30,10 @@ def _setup(cfg, xyz, feats, seed=3, lr=1e-3, keep_prob=1.0, labels=None, sync_bn
     return tr, pyr, params, labels, cw, host_pyr
 
 
-def syncbn_case():
+def syncbn_case(B=2):
     # 12000 points: the deepest level still has more points (23) than K, so no BatchNorm column is constant over its rows
     # (a constant column puts every row of it exactly on the leaky-ReLU kink, where the summation order decides the branch)
-    cfg, xyz, feats = netcase.small_deep(12000, seed=8, B=2)
+    cfg, xyz, feats = netcase.small_deep(12000, seed=8, B=B)
     cfg.d_out = [16, 32, 64, 32, 16]
     return cfg, xyz, feats
 
@@ -42,20 +42,26 @@ def syncbn_labels(cfg, xyz):
     return np.random.default_rng(11).integers(0, cfg.num_classes, xyz.shape[:2]).astype(np.int32)
 
 
-def test_sync_bn_two_ranks_equal_one_rank_batch_two(tmp_path):
-    """BASELINE configs[3] semantics: two ranks with one cloud each and shared BatchNorm statistics take the same
-    optimisation step as one rank with the batch of two clouds.  The ranks are two processes on this one GPU joined by gloo
-    (the collective is backend-agnostic; RCCL carries it on the 8-GPU node)."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_sync_bn_ranks_equal_one_rank_with_the_batch(tmp_path, world):
+    """BASELINE configs[3] semantics: `world` ranks with one cloud each and shared BatchNorm statistics take the same
+    optimisation step as one rank with the batch of `world` clouds -- at 2 and at the 8 ranks of the node configs[3] names.  The ranks are
+    processes on this one GPU joined by gloo (the collective is backend-agnostic; RCCL carries it on the 8-GPU node).  Also asserted at
+    that world size: the number of all-reduce calls a step makes (ps_trainer_collective_stats) -- one for the flat gradient buffer plus
+    two per BatchNorm layer with shared statistics (89 for the five-layer network), exactly one with per-GPU statistics."""
     import os
     import subprocess
     import sys
     import torch
-    cfg, xyz, feats = syncbn_case()
+    cfg, xyz, feats = syncbn_case(world)
     labels = syncbn_labels(cfg, xyz)
     tr, pyr, params, _, cw, _ = _setup(cfg, xyz, feats, labels=labels, oracle_pyramid=False)
     loss = tr.train_step(pyr, torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda())
     torch.cuda.synchronize()
     want_grad, want_flat, want_loss = tr.grad.cpu().numpy(), tr.flat.cpu().numpy(), float(loss)
+    n_bn = sum(1 for name in tr.names if name.endswith("gamma"))
+    del tr, pyr
+    torch.cuda.empty_cache()
     out = str(tmp_path / "syncbn")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "syncbn_worker.py")
     import socket
@@ -63,12 +69,12 @@ def test_sync_bn_two_ranks_equal_one_rank_batch_two(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, worker, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    logs = [p.communicate(timeout=600)[0] for p in procs]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-2000:] for l in logs)
-    got = [np.load(out + ".rank%d.npz" % r) for r in range(2)]
+    got = [np.load(out + ".rank%d.npz" % r) for r in range(world)]
     gscale = np.abs(want_grad).max()
     # every rank holds the same averaged gradient and takes the same Adam step.  The two runs sum the statistics in a different
     # order (per-rank partials first), which moves a handful of activations that sit within an ulp of a leaky-ReLU kink to the
@@ -79,10 +85,17 @@ def test_sync_bn_two_ranks_equal_one_rank_batch_two(tmp_path):
         diff = g["grad"] - want_grad
         assert np.linalg.norm(diff) <= 2e-3 * np.linalg.norm(want_grad), np.linalg.norm(diff) / np.linalg.norm(want_grad)
         assert np.abs(diff).max() <= 2e-2 * gscale, np.abs(diff).max() / gscale
-    assert np.array_equal(got[0]["grad"], got[1]["grad"]) and np.array_equal(got[0]["flat"], got[1]["flat"])
-    assert abs(0.5 * (float(got[0]["loss"]) + float(got[1]["loss"])) - want_loss) <= 1e-5 * max(1.0, abs(want_loss))
+    for g in got[1:]:
+        assert np.array_equal(got[0]["grad"], g["grad"]) and np.array_equal(got[0]["flat"], g["flat"])
+    assert abs(float(np.mean([float(g["loss"]) for g in got])) - want_loss) <= 1e-5 * max(1.0, abs(want_loss))
     big = np.abs(want_grad) > 5e-2 * gscale  # Adam normalises rounding-noise gradients to O(lr): compare where g is signal
     assert np.abs(got[0]["flat"] - want_flat)[big].max() <= 2e-4
+    # collectives of one step at this world size
+    assert n_bn == 44, n_bn
+    for g in got:
+        assert int(g["calls_sync_bn"]) == 1 + 2 * n_bn == 89, int(g["calls_sync_bn"])
+        assert int(g["calls_local_bn"]) == 1, int(g["calls_local_bn"])
+        assert int(g["bytes_local_bn"]) == 4 * want_grad.size
 
 
 def test_one_training_step_matches_autograd(oracle):

@@ -282,14 +282,15 @@ def test_iou_from_confusions_matches_the_reference_formula():
 def test_package_import_sets_the_pipeline_environment_contract():
     """point_unet_amd/__init__.py: a fresh interpreter WITHOUT GPU_MAX_HW_QUEUES gets 6 (the lanes of ForwardPipeline need a hardware queue
     each; HIP reads the variable once, when its runtime starts), a user's own value is left alone, and ForwardPipeline's check warns when
-    the runtime has fewer queues than lanes + 2 and refuses to create lanes behind an RCCL process group (pipeline.py::_check_environment)."""
+    the runtime has fewer queues than lanes + 2 (pipeline.py::_check_environment).  Nothing else in the environment is touched by the
+    import (HSA_ENABLE_IPC_MODE_LEGACY is the launcher's setting: bench.py, tests/conftest.py)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = "import os, sys; sys.path.insert(0, %r); import point_unet_amd; print(os.environ['GPU_MAX_HW_QUEUES'], os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % root
+    code = "import os, sys; sys.path.insert(0, %r); import point_unet_amd; print(os.environ['GPU_MAX_HW_QUEUES'], os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', 'unset'))" % root
     env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY")}
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
-    assert out == ["6", "0"]
+    assert out == ["6", "unset"]
     env["GPU_MAX_HW_QUEUES"] = "5"
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
     assert out[0] == "5"
@@ -312,3 +313,30 @@ def test_package_import_sets_the_pipeline_environment_contract():
             os.environ.pop("GPU_MAX_HW_QUEUES", None)
         else:
             os.environ["GPU_MAX_HW_QUEUES"] = old
+
+
+def test_the_default_library_never_reads_the_environment():
+    """VERDICT r5 item 6: the A/B knobs of profiles/tools/* are ONE struct (csrc/common.h, ps::Tuning) that only a library built with
+    -DPS_TUNING_ENV fills from PS_* variables, once, in ps_create.  The default build holds constants: every getenv in csrc/ sits inside an
+    #ifdef of an experiment macro, there is no function-static cache of a knob, and the shipped .so does not even contain the variables'
+    names -- PS_INV_BUCKET=0 in the environment of the default build cannot change what it runs."""
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "point-unet_amd", "csrc")
+    allowed_macros = ("PS_TUNING_ENV", "PS_KNN_REFILL_EXP", "PS_KNN_PROF")
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".h")):
+            continue
+        depth_of = []  # stack of the macro names of the open #if blocks
+        for ln, line in enumerate(open(os.path.join(csrc, name)), 1):
+            t = line.strip()
+            if t.startswith(("#ifdef", "#ifndef", "#if ")):
+                depth_of.append(t)
+            elif t.startswith("#endif") and depth_of:
+                depth_of.pop()
+            code = t.split("//")[0]
+            if "getenv" in code:
+                assert any(any(m in d for m in allowed_macros) for d in depth_of), "%s:%d reads the environment in the default build: %s" % (name, ln, t)
+            assert not re.search(r"static\s+const\s+\w+\s+\w+\s*=.*getenv", code), "%s:%d caches a knob in a function-static" % (name, ln)
+    so = open(os.path.join(os.path.dirname(csrc), "libpointseg_hip.so"), "rb").read()
+    for var in (b"PS_INV_BUCKET", b"PS_WGRAD_WGS", b"PS_INV_TILE", b"PS_TRAIN_ATT_GEMM", b"PS_GEMM32B_RW", b"PS_KNN_REFILL"):
+        assert var not in so, var
