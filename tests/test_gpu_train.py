@@ -1253,6 +1253,37 @@ def test_native_step_equals_the_python_tape(mode):
             assert np.abs(a["flat"] - b["flat"]).max() <= 4.2e-3
 
 
+def test_a_storage_flag_left_on_by_an_op_level_caller_does_not_reach_the_native_step():
+    """ps_set_train_act_bf16 is a public setter of the op-level surface.  A flag left on for a SHARED context (an op-level
+    experiment, a test that failed before its reset) must not leak into ps_randla_train_step, whose row reductions and split-source pooling
+    read the flag directly outside the trainer's own scopes: the bf16-MLP step with the flag set beforehand is bit-identical to the step
+    without it -- in both modes -- and the caller's flag is as it was afterwards."""
+    import torch
+    from point_unet_amd import _lib, runtime, weights
+    from point_unet_amd.pyramid import build_pyramid
+    from point_unet_amd.train import Trainer
+    cfg, xyz, feats = netcase.small_deep(6000, seed=23, B=2)
+    params = weights.init_params(cfg, seed=6, randomize_bn=True)
+    labels = np.random.default_rng(4).integers(0, cfg.num_classes, xyz.shape[:2]).astype(np.int32)
+    cw = np.linspace(1.0, 2.0, cfg.num_classes).astype(np.float32)
+    pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
+    d_feats, d_lab = torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda()
+    L = _lib.lib()
+    for mode in ("bf16", "fp32"):
+        got = []
+        for leaked in (0, 1):
+            tr = Trainer(cfg, params=params, learning_rate=1e-3, class_weights=cw, keep_prob=1.0, mlp_dtype=mode)
+            _lib.check(L.ps_set_train_act_bf16(tr.ctx.handle, leaked))
+            try:
+                loss = tr.train_step(pyr, d_feats, d_lab)
+                torch.cuda.synchronize()
+                got.append((float(loss), tr.grad.clone(), tr.flat.clone()))
+            finally:
+                _lib.check(L.ps_set_train_act_bf16(tr.ctx.handle, 0))
+        assert got[0][0] == got[1][0], (mode, got[0][0], got[1][0])
+        assert torch.equal(got[0][1], got[1][1]) and torch.equal(got[0][2], got[1][2]), mode
+
+
 def test_backward_only_leaves_the_parameters_alone():
     """ps_randla_backward = the step without the collective and without Adam: gradients as train_step computes them, parameters and
     Adam moments untouched, moving statistics updated."""
