@@ -143,6 +143,7 @@ struct Tuning {
     bool train_att_gemm = true;      // PS_TRAIN_ATT_GEMM=0
     bool train_att128_fwd_gemm = true;  // PS_TRAIN_ATT128_FWD_GEMM=0
     bool train_fuse_residual = true; // PS_TRAIN_FUSE_RESIDUAL=0
+    bool train_merge_syncbn = true;  // PS_TRAIN_MERGE_SYNCBN=0: every BatchNorm layer its own all-reduces (89 instead of 74 calls per step)
     int convbn_max_c = 64;           // PS_CONVBN_MAX_C
     int convbn_rect_max = 1 << 30;   // PS_CONVBN_RECT_MAX (cin * cout)
     bool wgrad_debug = false;        // PS_WGRAD_DEBUG: print the first step's weight-gradient shapes

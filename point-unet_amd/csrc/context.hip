@@ -179,6 +179,7 @@ void tuning_from_env(Tuning& t)
     flag("PS_TRAIN_ATT_GEMM", t.train_att_gemm);
     flag("PS_TRAIN_ATT128_FWD_GEMM", t.train_att128_fwd_gemm);
     flag("PS_TRAIN_FUSE_RESIDUAL", t.train_fuse_residual);
+    flag("PS_TRAIN_MERGE_SYNCBN", t.train_merge_syncbn);
     if (num("PS_CONVBN_MAX_C", v) && v >= 0 && v <= 4096) t.convbn_max_c = (int)v;
     if (num("PS_CONVBN_RECT_MAX", v) && v >= 0) t.convbn_rect_max = v > (double)(1 << 30) ? 1 << 30 : (int)v;
     t.wgrad_debug = std::getenv("PS_WGRAD_DEBUG") != nullptr;

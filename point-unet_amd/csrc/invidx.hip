@@ -619,6 +619,7 @@ int ps_op_inverse_index(ps_context* c, const int32_t* idx, int64_t B, int64_t N,
     unsigned* off = reinterpret_cast<unsigned*>(offsets);
     BkPlan pl;
     const bool bucket_on = c->tune.inv_bucket;  // (A/B knob: off = the radix-sort form)
+    static_assert(kBkTile == 4096, "common.h: Tuning::inv_tile defaults to kBkTile");
     const int tile = c->tune.inv_tile;          // (4 096 = kBkTile, or 8 192)
     if (rows >= kInvSortRows && bucket_on && bk_plan(B, N, rows_per_cloud, tile, &pl) &&
         (int64_t)bk_workspace_words(pl, rows) + 64 <= ps_op_inverse_index_workspace(n_dst, rows)) {

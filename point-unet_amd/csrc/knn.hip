@@ -572,8 +572,15 @@ __global__ __launch_bounds__(kKnnThreads) void knn_pair_refill_kernel(const KnnJ
 
 #endif  // PS_KNN_REFILL_EXP
 
+// (experiment knob: -DPS_KNN_WAVES_PER_EU=n makes the register allocator fit n waves per SIMD)
+#ifdef PS_KNN_WAVES_PER_EU
+#define PS_KNN_OCC __attribute__((amdgpu_waves_per_eu(PS_KNN_WAVES_PER_EU, PS_KNN_WAVES_PER_EU)))
+#else
+#define PS_KNN_OCC
+#endif
+
 template <int K>
-__global__ __launch_bounds__(kKnnThreads) void knn_kernel(const KnnJob* __restrict__ jobs)
+__global__ __launch_bounds__(kKnnThreads) PS_KNN_OCC void knn_kernel(const KnnJob* __restrict__ jobs)
 {
     __shared__ float win[kWin * 5 * kKnnThreads];
     knn_body<K>(jobs[blockIdx.y], win);
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const KnnJob* __restri
 // K-NN search ends with a long tail (its duration is its slowest wave's; the chip holds all of its waves at once), and a second launch
 // cannot start under it: here the 1-NN workgroups are dispatched as the K-NN ones retire.
 template <int K>
-__global__ __launch_bounds__(kKnnThreads) void knn_pair_kernel(const KnnJob* __restrict__ jobs, int n_first)
+__global__ __launch_bounds__(kKnnThreads) PS_KNN_OCC void knn_pair_kernel(const KnnJob* __restrict__ jobs, int n_first)
 {
     __shared__ float win[kWin * 5 * kKnnThreads];
     if ((int)blockIdx.y < n_first) knn_body<K>(jobs[blockIdx.y], win);

@@ -293,6 +293,18 @@ __global__ void tr_pair_copy_kernel(const float* __restrict__ a, const float* __
     out[C + c] = b[c];
 }
 
+// float <-> double copies of a handful of per-channel sums (the merged SyncBN all-reduces carry float sums in a double buffer)
+__global__ void tr_f2d_kernel(const float* __restrict__ in, int n, double* __restrict__ out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+__global__ void tr_d2f_kernel(const double* __restrict__ in, int n, float* __restrict__ out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
 static inline unsigned tr_grid(int64_t n)
 {
     const int64_t b = (n + 255) / 256;
@@ -455,6 +467,7 @@ struct ps_trainer {
     bool act_bf16_on = true;  // next to ps_train_options.act_bf16
     int att_split_env = -1;
     bool att_gemm_on = true;  // attpool_gemm.hip
+    bool merge_syncbn = true;  // shared BatchNorm statistics of INDEPENDENT layers in one all-reduce (mlp2 || shortcut, mlp1 || LocSE-mlp1)
     ps::PackCache pack;  // the step's weight images (recorded during the first step, then packed by one launch per step: common.h)
     // inverse indices of the step's gather tables (deterministic mode): built at their first use in the backward pass, kept to its end
     struct Inv {
@@ -870,18 +883,145 @@ struct ps_trainer {
         return y;
     }
 
+    // ---- shared statistics of INDEPENDENT BatchNorm layers in one all-reduce (SyncBN, world > 1) ---------------------------------------
+    // bn_act's shared-statistics form cut in two: bn_begin leaves this rank's [sum | sum x^2] in p.sums(); whoever all-reduces them (a
+    // companion layer's call) is followed by bn_end: apply pass, moving statistics, backward closure (its own all-reduce of the 2 C
+    // backward sums -- the backward of the two layers does not run at the same time).
+    struct PendingBn {
+        Tn x, x_in, y, stats, shared;  // shared: a [2 Ca + 2 Cb] buffer two pending layers put their sums into (kept alive by both)
+        const LayerP* lp = nullptr;
+        float* ext = nullptr;          // this layer's 2 C sums inside `shared`
+        bool leaky = false, open = false;
+        float* sums() const { return ext ? ext : stats.p + 3 * x.C; }
+    };
+    PendingBn bn_begin(const Tn& x_in, const LayerP& lp, bool leaky, const Tn* out = nullptr, const Tn* shared = nullptr, int64_t shared_off = 0)
+    {
+        PendingBn p;
+        p.x_in = x_in;
+        p.x = contig(x_in);
+        p.y = out ? *out : alloc(p.x.R, p.x.C);
+        p.y.req = true;
+        p.stats = alloc(5, p.x.C, false);
+        if (shared) {
+            p.shared = *shared;
+            p.ext = shared->p + shared_off;
+        }
+        p.lp = &lp;
+        p.leaky = leaky;
+        p.open = true;
+        TK(ps_op_bn_train_sums(c, p.x.p, p.x.R, p.x.C, p.sums()));
+        return p;
+    }
+    Tn bn_end(PendingBn& p)
+    {
+        const LayerP& lp = *p.lp;
+        const Tn x = p.x, xin = p.x_in, y = p.y, stats = p.stats;
+        const int64_t R = x.R, C = x.C, R_total = R * world;
+        const bool leaky = p.leaky;
+        float *mean = stats.p, *invstd = stats.p + C, *var = stats.p + 2 * C;
+        const float *gamma = params + lp.gamma, *beta = params + lp.beta;
+        TK(ps_op_bn_train_apply_ex(c, x.p, gamma, beta, p.sums(), R, R_total, C, kBnEps, leaky ? 1 : 0, y.p, y.ld, mean, invstd, var));
+        {
+            Stage st(c, "train_bn_fwd", 1);
+            hipLaunchKernelGGL(tr_ema2_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream(), buffers + lp.mov_mean, buffers + lp.mov_var, mean, var, (int)C,
+                               kBnMomentum);
+            TK_HIP(hipGetLastError());
+        }
+        float *ggamma = grads + lp.gamma, *gbeta = grads + lp.beta;
+        record(y, [=](const Tn& dy) {
+            Tn dx = alloc(R, C);
+            TK(ps_op_bn_train_bwd_sums_ex(c, dy.p, dy.ld, x.p, gamma, beta, mean, invstd, R, C, leaky ? 1 : 0, ggamma, gbeta));
+            Tn tot = alloc(2, C, false);
+            hipLaunchKernelGGL(tr_pair_copy_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream(), gbeta, ggamma, (int)C, tot.p);
+            TK_HIP(hipGetLastError());
+            allreduce(tot.p, 2 * C, 0);
+            TK(ps_op_bn_train_bwd_apply_ex(c, dy.p, dy.ld, x.p, gamma, beta, mean, invstd, tot.p, tot.p + C, R, R_total, C, leaky ? 1 : 0, dx.p));
+            (void)stats;
+            accum(xin, dx);
+        });
+        p.open = false;
+        p.shared = Tn();
+        return y;
+    }
+
+    // LeakyReLU(BN(xa) + BN(xb)) of dilated_res_block (RandLANet.py:303-307: mlp2 and the shortcut) with shared statistics: the two layers
+    // are independent and their output gradients are the SAME tensor, so both directions need ONE all-reduce for the pair -- [2 Ca + 2 Cb]
+    // floats forward, the same backward -- instead of two each.
+    Tn res_pair_sync(const Tn& xa_in, const LayerP& la, const Tn& xb_in, const LayerP& lb)
+    {
+        const Tn xa = contig(xa_in), xb = contig(xb_in);
+        const int64_t R = xa.R, C = xa.C, R_total = R * world;
+        if (xb.R != R || xb.C != C) {
+            ps::set_error("trainer: res_pair_sync: the two branches differ in shape");
+            throw TrainError{PS_ESTATE};
+        }
+        Tn st = alloc(10, C, false);  // per branch: mean | invstd | var, then the four sums [sum a | sum a^2 | sum b | sum b^2] contiguously
+        float *mean_a = st.p, *invstd_a = st.p + C, *var_a = st.p + 2 * C, *mean_b = st.p + 3 * C, *invstd_b = st.p + 4 * C, *var_b = st.p + 5 * C;
+        float* sums = st.p + 6 * C;
+        const float *ga = params + la.gamma, *ba = params + la.beta, *gb = params + lb.gamma, *bb = params + lb.beta;
+        TK(ps_op_bn_train_sums(c, xa.p, R, C, sums));
+        TK(ps_op_bn_train_sums(c, xb.p, R, C, sums + 2 * C));
+        allreduce(sums, 4 * C, 0);
+        Tn ya = alloc(R, C), yb = alloc(R, C);
+        TK(ps_op_bn_train_apply_ex(c, xa.p, ga, ba, sums, R, R_total, C, kBnEps, 0, ya.p, ya.ld, mean_a, invstd_a, var_a));
+        TK(ps_op_bn_train_apply_ex(c, xb.p, gb, bb, sums + 2 * C, R, R_total, C, kBnEps, 0, yb.p, yb.ld, mean_b, invstd_b, var_b));
+        {
+            Stage stg(c, "train_bn_fwd", 2);
+            hipLaunchKernelGGL(tr_ema2_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream(), buffers + la.mov_mean, buffers + la.mov_var, mean_a, var_a, (int)C, kBnMomentum);
+            hipLaunchKernelGGL(tr_ema2_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream(), buffers + lb.mov_mean, buffers + lb.mov_var, mean_b, var_b, (int)C, kBnMomentum);
+            TK_HIP(hipGetLastError());
+        }
+        Tn y = alloc(R, C);
+        y.req = true;
+        TK(ps_op_add_lrelu(c, ya.p, yb.p, y.numel(), y.p));
+        float *gga = grads + la.gamma, *gba = grads + la.beta, *ggb = grads + lb.gamma, *gbb = grads + lb.beta;
+        record(y, [=](const Tn& dy_in) {
+            const Tn dy = contig(dy_in);
+            Tn ds = alloc(R, C);
+            TK(ps_op_add_lrelu_bwd(c, dy.p, y.p, y.numel(), ds.p));
+            // this rank's dgamma / dbeta of both layers (averaged with every other gradient later); dx needs the global sums
+            TK(ps_op_bn_train_bwd_sums_ex(c, ds.p, ds.ld, xa.p, ga, ba, mean_a, invstd_a, R, C, 0, gga, gba));
+            TK(ps_op_bn_train_bwd_sums_ex(c, ds.p, ds.ld, xb.p, gb, bb, mean_b, invstd_b, R, C, 0, ggb, gbb));
+            Tn tot = alloc(4, C, false);
+            hipLaunchKernelGGL(tr_pair_copy_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream(), gba, gga, (int)C, tot.p);
+            hipLaunchKernelGGL(tr_pair_copy_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream(), gbb, ggb, (int)C, tot.p + 2 * C);
+            TK_HIP(hipGetLastError());
+            allreduce(tot.p, 4 * C, 0);
+            Tn dxa = alloc(R, C), dxb = alloc(R, C);
+            TK(ps_op_bn_train_bwd_apply_ex(c, ds.p, ds.ld, xa.p, ga, ba, mean_a, invstd_a, tot.p, tot.p + C, R, R_total, C, 0, dxa.p));
+            TK(ps_op_bn_train_bwd_apply_ex(c, ds.p, ds.ld, xb.p, gb, bb, mean_b, invstd_b, tot.p + 2 * C, tot.p + 3 * C, R, R_total, C, 0, dxb.p));
+            (void)st; (void)ya; (void)yb;
+            accum(xa_in, dxa);
+            accum(xb_in, dxb);
+        });
+        return y;
+    }
+
     // f_xyz = LeakyReLU(BN_train(relative_pos_encoding(xyz, idx) . W + b)) -> [B*N*K, h] (out: optional column block), with nothing but
     // that output in memory: statistics, output and every gradient are recomputed from xyz [B*N,3] and idx [B,N,K] (locse_train.hip)
-    Tn locse_bn_act(const float* xyz, const int32_t* idx, int64_t B, int64_t N, int64_t K, const LayerP& lp, const Tn* out = nullptr, bool act16 = false)
+    // companion: an open PendingBn of an independent layer whose 2 C float sums ride in this layer's all-reduce (as doubles, behind the 2 h)
+    Tn locse_bn_act(const float* xyz, const int32_t* idx, int64_t B, int64_t N, int64_t K, const LayerP& lp, const Tn* out = nullptr, bool act16 = false,
+                    PendingBn* companion = nullptr)
     {
         const int64_t h = lp.cout, R = B * N * K;
         const bool sync = sync_bn && coll_active();
         const int64_t R_total = sync ? R * world : R;
         const float *W = params + lp.w, *b = params + lp.b, *gamma = params + lp.gamma, *beta = params + lp.beta;
-        Tn sums = alloc(1, 4 * h, false);  // 2h doubles: the variance is a difference of nearly equal sums
+        const int64_t n_comp = (sync && companion && companion->open) ? 2 * companion->x.C : 0;
+        Tn sums = alloc(1, 4 * h + 2 * n_comp, false);  // 2h doubles: the variance is a difference of nearly equal sums (+ the companion's sums)
         double* s64 = reinterpret_cast<double*>(sums.p);
         TK(ps_op_locse_train_sums(c, xyz, idx, B, N, K, W, b, h, s64));
-        if (sync) allreduce(s64, 2 * h, 1);
+        if (n_comp) {
+            Stage st(c, "train_bn_fwd", 1);
+            hipLaunchKernelGGL(tr_f2d_kernel, dim3(ceil_div(n_comp, 64)), dim3(64), 0, stream(), companion->sums(), (int)n_comp, s64 + 2 * h);
+            TK_HIP(hipGetLastError());
+        }
+        if (sync) allreduce(s64, 2 * h + n_comp, 1);
+        if (n_comp) {
+            Stage st(c, "train_bn_fwd", 1);
+            hipLaunchKernelGGL(tr_d2f_kernel, dim3(ceil_div(n_comp, 64)), dim3(64), 0, stream(), s64 + 2 * h, (int)n_comp, companion->sums());
+            TK_HIP(hipGetLastError());
+        }
         Tn st4 = alloc(4, h, false);  // mean | var | invstd | scale
         float *mean = st4.p, *invstd = st4.p + 2 * h, *scale = st4.p + 3 * h;
         {
@@ -1463,10 +1603,24 @@ struct ps_trainer {
             const int32_t* idx = pyr->neigh_idx[i];
             const int64_t N = pyr->n[i];
             const Tn feature = f;
-            Tn f_pc = conv(feature, n + "mlp1");
             const LayerP& lfa1 = layer(n + "LFAmlp1");
             const int64_t hloc = lfa1.cout;
             const bool locse_fused = opt.fused_locse && ps_op_locse_train_supported(K, hloc);
+            // shared statistics (world > 1): mlp1 and the LocSE convolution are independent -- mlp1's sums ride in the LocSE layer's all-reduce
+            // (bn_begin here, bn_end right behind the LocSE layer); mlp2 || shortcut further down
+            const bool sync_merge = sync_bn && coll_active() && merge_syncbn;
+            const LayerP& l_mlp1 = layer(n + "mlp1");
+            PendingBn pend1;
+            Tn f_pc, pair_sums;
+            if (sync_merge && l_mlp1.gamma >= 0 && lfa1.gamma >= 0 && !convbn_rect_ok(feature, l_mlp1)) {
+                Tn x1 = linear(feature, Wt(l_mlp1), l_mlp1.b >= 0 ? params + l_mlp1.b : nullptr, gWt(l_mlp1), l_mlp1.b >= 0 ? grads + l_mlp1.b : nullptr,
+                               l_mlp1.kind == kDeconv);
+                if (!locse_fused) pair_sums = alloc(1, 2 * l_mlp1.cout + 2 * hloc, false);  // (op-by-op LocSE: both layers' float sums side by side)
+                pend1 = bn_begin(x1, l_mlp1, true, nullptr, locse_fused ? nullptr : &pair_sums, 0);
+                f_pc = pend1.y;  // (shape, pitch and address are final; the values arrive with bn_end, before the first reader is enqueued)
+            } else {
+                f_pc = conv(feature, n + "mlp1");
+            }
             Tn rel;
             if (!locse_fused) {
                 rel = alloc(B * N * K, 10, false);
@@ -1474,8 +1628,19 @@ struct ps_trainer {
             }
             bool act16 = false;  // (set below for the levels that store their [N*K, h] rows as bfloat16)
             auto locse = [&](const Tn* out) -> Tn {
+                if (!locse_fused && pend1.open) {
+                    // the op-by-op form of the pair: both layers' sums in ONE float all-reduce
+                    Tn xr = linear(rel, Wt(lfa1), lfa1.b >= 0 ? params + lfa1.b : nullptr, gWt(lfa1), lfa1.b >= 0 ? grads + lfa1.b : nullptr, lfa1.kind == kDeconv,
+                                   nullptr, /*fp32_only*/ true);
+                    PendingBn p2 = bn_begin(xr, lfa1, true, out, &pair_sums, 2 * l_mlp1.cout);
+                    allreduce(pair_sums.p, 2 * l_mlp1.cout + 2 * hloc, 0);
+                    bn_end(pend1);
+                    return bn_end(p2);
+                }
                 if (!locse_fused) return conv(rel, n + "LFAmlp1", true, true, out, true);
-                return locse_bn_act(pyr->xyz[i], idx, B, N, K, lfa1, out, act16 && out == nullptr);
+                Tn y = locse_bn_act(pyr->xyz[i], idx, B, N, K, lfa1, out, act16 && out == nullptr, pend1.open ? &pend1 : nullptr);
+                if (pend1.open) bn_end(pend1);
+                return y;
             };
             // tf.concat([f_neighbours, f_xyz]) (RandLANet.py:328,332): both producers write their column block of the concat buffer
             // directly (no concat copy forward, no split copies backward)
@@ -1527,12 +1692,21 @@ struct ps_trainer {
                 Tn fcat2 = concat_views(cat2, f_nb2, f_xyz2);
                 f_agg2 = pre ? att_pre(f_agg, idx, B, N, K, fcat2, f_xyz2, n + "LFAatt_pooling_2") : att(fcat2, n + "LFAatt_pooling_2", K);
             }
-            Tn a = conv(f_agg2, n + "mlp2", true, false);
             Tn f_enc;
-            {
+            const LayerP& l_mlp2 = layer(n + "mlp2");
+            const LayerP& sl = layer(n + "shortcut");
+            if (sync_merge && l_mlp2.gamma >= 0 && sl.gamma >= 0 && l_mlp2.cout == sl.cout) {
+                // shared statistics: mlp2 and the shortcut as one pair -- one all-reduce per direction for both (res_pair_sync)
+                auto lin = [&](const Tn& x, const LayerP& lp) {
+                    return linear(x, Wt(lp), lp.b >= 0 ? params + lp.b : nullptr, gWt(lp), lp.b >= 0 ? grads + lp.b : nullptr, lp.kind == kDeconv);
+                };
+                Tn xa = lin(f_agg2, l_mlp2);
+                Tn xb = lin(feature, sl);
+                f_enc = res_pair_sync(xa, l_mlp2, xb, sl);
+            } else {
+                Tn a = conv(f_agg2, n + "mlp2", true, false);
                 // the residual sum + LeakyReLU inside the shortcut's apply pass where that layer runs in the recompute form (levels 0-1)
                 const bool fuse = c->tune.train_fuse_residual;  // (A/B knob)
-                const LayerP& sl = layer(n + "shortcut");
                 if (fuse && sl.gamma >= 0 && convbn_rect_ok(feature, sl) && a.contiguous() && a.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.p) & 15) == 0 && a.req) {
                     f_enc = conv_bn_rect(feature, sl, false, &a);
                 } else {
@@ -1804,6 +1978,7 @@ int ps_trainer_create(ps_context* c, const ps_randla_config* cfg, const ps_train
     t->act_bf16_on = c->tune.train_act_bf16;
     t->att_split_env = c->tune.train_att_gemm_split;
     t->att_gemm_on = c->tune.train_att_gemm;
+    t->merge_syncbn = c->tune.train_merge_syncbn;
     t->cfg = *cfg;
     t->opt = *opt;
     build_layout(t);

@@ -17,7 +17,8 @@ from point_unet_amd.helper_tool import ConfigBraTS, ConfigPancreas
 from point_unet_amd.pipeline import ForwardPipeline
 from point_unet_amd.pyramid import build_pyramid
 
-quick = len(sys.argv) > 1 and sys.argv[1] in ("quick", "stage")
+quick = len(sys.argv) > 1 and sys.argv[1] in ("quick", "stage", "base")
+base_only = len(sys.argv) > 1 and sys.argv[1] == "base"  # one-query-per-lane kernel of whatever library is loaded: stage time + pipeline
 stage_only = len(sys.argv) > 1 and sys.argv[1] == "stage"
 
 
@@ -71,6 +72,8 @@ if quick:
     variants = variants[:5]
 if stage_only:
     variants = variants[:3]
+if base_only:
+    variants = variants[:1]
 for name, cfg, x in cases:
     ref = None
     for refill, q, rmin in variants:
@@ -121,7 +124,7 @@ def run(mode, steps=300):
 
 run("whole")
 for rep in range(2):
-    for refill, q, rmin in variants[:6]:
+    for refill, q, rmin in variants[:1 if base_only else 6]:
         setenv(refill, q, rmin)
         print("pipeline x4: refill=%d Q=%s min=%s  whole %.4f  pyramid only %.4f ms per cloud" % (refill, q, rmin, run("whole"), run("pyramid")), flush=True)
 pipe.close()
