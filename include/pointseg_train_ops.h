@@ -116,9 +116,9 @@ int ps_op_att_pool_train_fwd(ps_context* ctx, const float* fset, int64_t ld, con
                              float* agg);
 int ps_op_att_pool_train_bwd(ps_context* ctx, const float* fset, int64_t ld, const float* wfc, const float* dagg, int64_t R,
                              int64_t K, int64_t d, float* dfset, int64_t lddf, float* dwfc);
-/* The wide levels (d = 128 / 256: encoder levels 2-3; csrc/attpool_gemm.hip): the same fused op on the frame of the large split-bf16
+/* The wide levels (d = 128 / 256 / 512: encoder levels 2-4; csrc/attpool_gemm.hip): the same fused op on the frame of the large split-bf16
  * GEMMs -- a wave owns the 16 neighbour rows of two points, the scores live only in its accumulator registers.  fwd writes agg [R, d];
- * bwd recomputes the scores and returns dfset (row stride lddf; accumulate != 0: added to what the rows hold) and dscores [R*K, d]
+ * bwd (d = 512: two launches, each over half of the dfset columns) recomputes the scores and returns dfset (row stride lddf; accumulate != 0: added to what the rows hold) and dscores [R*K, d]
  * (row stride ldds) -- the weight gradient is dwfc = fset^T . dscores (ps_op_linear_wgrad_ex).  K = 16, rows 16-byte aligned;
  * follows ps_set_train_gemm_bf16 (one plane of rounded operands instead of the exact three-way split).
  * Replaces: tf.layers.dense + tf.nn.softmax + tf.reduce_sum and their gradients, RandLANet.py:394-398. */

@@ -25,6 +25,8 @@
 //                 (F, dS) (wgrad_b3_kernel), whose d x d accumulators per row slab no row-owning wave could hold at d >= 256.
 // Passes over [N*K, d] per pooling: forward 1 (was 4), backward 3 + 2 for dW (was 9).
 #include "common.h"
+
+#include <type_traits>
 #include "mfma_tile.h"
 #include "b3_ops.h"
 #include "attpool_train.h"
@@ -52,6 +54,15 @@ struct AttGArgs {
     int f_bf16;                // forward, split form, bf16-MLP mode: the rows of `f` are STORED as bfloat16 (ps_set_train_act_bf16; ld in elements)
 };
 
+template <int N, class F>
+__device__ __forceinline__ void attg_static_for(F&& f)
+{
+    if constexpr (N > 0) {
+        attg_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
 __device__ __forceinline__ float attg_swap_max(float v)
 {
     auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -67,10 +78,13 @@ __device__ __forceinline__ float attg_swap_sum(float v)
 // cut out of an image [K/16][D/32][P][64] at (chunk pair s, tile group g).  Sequence per panel p: the D/32 K-steps of the score product
 // (image w1, group p), then per 32-column tile t of the panel and per group ig of four output tiles the blocks of dS . W^T (image w2,
 // chunk pair 4 p + t, group ig).
-template <int D, int P, bool BWD>
+// HALF (backward of d = 512 only): the launch produces the dF columns [256 HALF, 256 HALF + 256) -- NIG = NPAN / 2 groups of four output
+// tiles per (panel, tile) instead of NPAN; -1 = all columns in one launch.
+template <int D, int P, bool BWD, int HALF = -1>
 struct AttGStream {
     static constexpr int NCB = D / 32, NPAN = D / 128, STEPS = D / 32;
-    static constexpr int PER = BWD ? STEPS + 4 * NPAN : STEPS;
+    static constexpr int NIG = HALF < 0 ? NPAN : NPAN / 2, IG0 = HALF < 0 ? 0 : HALF * NIG;
+    static constexpr int PER = BWD ? STEPS + 4 * NIG : STEPS;
     static constexpr int NB = NPAN * PER;
     struct Blk {
         const uint4* img;
@@ -80,7 +94,7 @@ struct AttGStream {
     {
         const int p = n / PER, m = n - p * PER;
         if (!BWD || m < STEPS) return Blk{a.w1, m, p};
-        const int m2 = m - STEPS, t = m2 / NPAN, ig = m2 - t * NPAN;
+        const int m2 = m - STEPS, t = m2 / NIG, ig = IG0 + (m2 - t * NIG);
         return Blk{a.w2, 4 * p + t, ig};
     }
     static __device__ __forceinline__ const uint4* src(const Blk& b, int i)  // i in [0, 512 P): (u, rest)
@@ -278,11 +292,14 @@ __global__ __launch_bounds__(256) void attg_fwd_kernel(AttGArgs a)
 
 // (d = 128: 64 + 64 accumulators leave room for two waves per SIMD -- asked for, the P = 1 form otherwise hoists its way past 256 registers;
 //  d = 256 holds 64 + 128 accumulators: one wave per SIMD, the accumulators of dF in the second half of the register file)
-template <int D, int P, bool SPLIT>
+//  d = 512 would hold 64 + 256: it runs as TWO launches, HALF = 0 / 1, each recomputing the scores and dS of every panel and accumulating
+//  the dF columns of its half -- 64 + 128 accumulators like d = 256; dS is stored by the first)
+template <int D, int P, bool SPLIT, int HALF = -1>
 __global__ __launch_bounds__(256, D == 128 ? 2 : 1) void attg_bwd_kernel(AttGArgs a)
 {
-    using S = AttGStream<D, P, true>;
-    constexpr int NT = D / 32;
+    static_assert(HALF < 0 || (D == 512 && !SPLIT), "the two-launch form is d = 512's");
+    using S = AttGStream<D, P, true, HALF>;
+    constexpr int NT = HALF < 0 ? D / 32 : D / 64, IT0 = HALF < 0 ? 0 : HALF * NT;  // dF tiles of this launch: IT0 .. IT0 + NT - 1
     __shared__ uint4 Bs[2][2 * 4 * P * 64];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int hl = lane >> 5, c32 = lane & 31;
@@ -330,8 +347,10 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 1) void attg_bwd_kernel(AttGArg
     PS_ATTG_STORE_B(0);
     __syncthreads();
     int n = 0;
-#pragma unroll
-    for (int p = 0; p < S::NPAN; ++p) {
+    // (the panels through a compile-time index: `#pragma unroll` alone left the four-panel loop of d = 512 rolled at P = 3, and a run-time
+    //  index into acc2 puts the dF accumulators into scratch memory)
+    auto panel = [&](auto pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value;
         f32x16 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -366,7 +385,7 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 1) void attg_bwd_kernel(AttGArg
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float pg = e[j] * ginv;
-                    acc2[4 * p + t][8 * pi + j] += pg;
+                    if constexpr (4 * p >= IT0 && 4 * p < IT0 + NT) acc2[4 * p + t - IT0][8 * pi + j] += pg;
                     acc[t][8 * pi + j] = pg * (fv[j] - agg);
                 }
             }
@@ -388,7 +407,7 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 1) void attg_bwd_kernel(AttGArg
                 for (int pl = P - 1; pl >= 0; --pl) T = b3_mfma(dp.p[pl], ident[k], T);  // (smallest pieces first: every partial sum is exact)
             }
             // T: lane = row c32 of the wave, register r = column 128 p + 32 t + (r & 3) + 8 (r >> 2) + 4 hl
-            if (c32 < rw.nvalid) {
+            if (HALF <= 0 && c32 < rw.nvalid) {  // (two-launch form: the first launch stores dS)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4)
                     *reinterpret_cast<float4*>(dsb + (dsoff + (unsigned)(32 * t + 8 * g4))) = make_float4(T[4 * g4], T[4 * g4 + 1], T[4 * g4 + 2], T[4 * g4 + 3]);
@@ -397,7 +416,7 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 1) void attg_bwd_kernel(AttGArg
             tp[0] = b3_split8<P>(make_float4(T[0], T[1], T[2], T[3]), make_float4(T[4], T[5], T[6], T[7]));
             tp[1] = b3_split8<P>(make_float4(T[8], T[9], T[10], T[11]), make_float4(T[12], T[13], T[14], T[15]));
 #pragma unroll
-            for (int ig = 0; ig < S::NPAN; ++ig, ++n) {
+            for (int ig = 0; ig < S::NIG; ++ig, ++n) {
                 const int buf = n & 1;
                 const bool more = n + 1 < S::NB;
                 if (more) PS_ATTG_LOAD_B(n + 1);
@@ -415,7 +434,8 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 1) void attg_bwd_kernel(AttGArg
                 __syncthreads();
             }
         }
-    }
+    };
+    attg_static_for<S::NPAN>(panel);
     // ---- dF: register r of tile it = row (r & 3) + 8 (r >> 2) + 4 hl of the wave, column 32 it + c32 ----
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
@@ -424,7 +444,7 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 1) void attg_bwd_kernel(AttGArg
         float* dfb = left ? a.dfl_rows + (size_t)rw.rbase * a.ld_rows : a.df + (size_t)rw.rbase * a.lddf;  // wave-uniform
         const int pitch = left ? a.ld_rows : a.lddf;
         const bool accum = !left && a.df_accum != 0;
-        const unsigned doff = (unsigned)(4 * hl * pitch + 32 * it + c32 - (SPLIT && !left ? D / 2 : 0));
+        const unsigned doff = (unsigned)(4 * hl * pitch + 32 * (IT0 + it) + c32 - (SPLIT && !left ? D / 2 : 0));
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (16 * half < rw.nvalid) {  // (wave-uniform: registers 8 half .. are the rows of point `half`)
@@ -490,6 +510,15 @@ static int launch_attg_s(ps_context* c, const AttGArgs& a)
         PS_CHECK(!a.f_bf16, "att_pool_gemm: bfloat16 rows are taken by the split-source forward at d = 128 only");
         if (c->train_bf16) hipLaunchKernelGGL((attg_fwd_kernel<D, 1, SPLIT>), dim3(blocks), dim3(256), 0, c->stream, a);
         else hipLaunchKernelGGL((attg_fwd_kernel<D, 3, SPLIT>), dim3(blocks), dim3(256), 0, c->stream, a);
+    } else if constexpr (D == 512) {
+        // 64 + 256 accumulators do not fit a wave: two launches over halves of the dF columns (attg_bwd_kernel, HALF)
+        if (c->train_bf16) {
+            hipLaunchKernelGGL((attg_bwd_kernel<D, 1, false, 0>), dim3(blocks), dim3(256), 0, c->stream, a);
+            hipLaunchKernelGGL((attg_bwd_kernel<D, 1, false, 1>), dim3(blocks), dim3(256), 0, c->stream, a);
+        } else {
+            hipLaunchKernelGGL((attg_bwd_kernel<D, 3, false, 0>), dim3(blocks), dim3(256), 0, c->stream, a);
+            hipLaunchKernelGGL((attg_bwd_kernel<D, 3, false, 1>), dim3(blocks), dim3(256), 0, c->stream, a);
+        }
     } else {
         if (c->train_bf16) hipLaunchKernelGGL((attg_bwd_kernel<D, 1, SPLIT>), dim3(blocks), dim3(256), 0, c->stream, a);
         else hipLaunchKernelGGL((attg_bwd_kernel<D, 3, SPLIT>), dim3(blocks), dim3(256), 0, c->stream, a);
@@ -873,7 +902,7 @@ static bool attg_ok(int64_t K, int64_t d, const void* f, int64_t ld)
 
 using namespace ps;
 
-extern "C" int ps_op_att_pool_gemm_supported(int64_t K, int64_t d) { return K == 16 && (d == 128 || d == 256) ? 1 : 0; }
+extern "C" int ps_op_att_pool_gemm_supported(int64_t K, int64_t d) { return K == 16 && (d == 128 || d == 256 || d == 512) ? 1 : 0; }
 
 extern "C" int ps_op_att_pool_gemm_fwd(ps_context* c, const float* fset, int64_t ld, const float* wfc, int64_t R, int64_t K, int64_t d, float* agg)
 {
@@ -897,10 +926,10 @@ extern "C" int ps_op_att_pool_gemm_bwd(ps_context* c, const float* fset, int64_t
                                        float* dfset, int64_t lddf, int accumulate, float* dscores, int64_t ldds)
 {
     PS_CHECK(c && fset && wfc && dagg && dfset && dscores, "ps_op_att_pool_gemm_bwd: NULL argument");
-    // (the backward is built for d = 128 / 256 only -- ps_op_att_pool_gemm_supported; d = 512, which the forward accepts, would run the 256-wide
-    //  kernel over 512-wide rows.  dfset / dscores leave in 16-byte stores: their bases and pitches are checked like the inputs')
-    PS_CHECK((d == 128 || d == 256) && attg_ok(K, d, fset, ld) && R * K < (1ll << 31) && attg_ok(K, d, dfset, lddf) && attg_ok(K, d, dscores, ldds),
-             "ps_op_att_pool_gemm_bwd: K = 16, d in {128, 256}, rows of fset / dfset / dscores 16-byte aligned with pitches %% 4 == 0 (got K %lld, d %lld, ld %lld, lddf %lld, ldds %lld)",
+    // (d = 512 runs as two launches over halves of the dF columns.  dfset / dscores leave in 16-byte stores: their bases and pitches are
+    //  checked like the inputs')
+    PS_CHECK(attg_ok(K, d, fset, ld) && R * K < (1ll << 31) && attg_ok(K, d, dfset, lddf) && attg_ok(K, d, dscores, ldds),
+             "ps_op_att_pool_gemm_bwd: K = 16, d in {128, 256, 512}, rows of fset / dfset / dscores 16-byte aligned with pitches %% 4 == 0 (got K %lld, d %lld, ld %lld, lddf %lld, ldds %lld)",
              (long long)K, (long long)d, (long long)ld, (long long)lddf, (long long)ldds);
     if (R <= 0) return PS_OK;
     PS_HIP(hipSetDevice(c->device));
@@ -910,7 +939,7 @@ extern "C" int ps_op_att_pool_gemm_bwd(ps_context* c, const float* fset, int64_t
     a.rows = R * K; a.points = R; a.df_accum = accumulate ? 1 : 0;
     PS_TRY(attg_planes(c, wfc, d, false, &a.w1));
     PS_TRY(attg_planes(c, wfc, d, true, &a.w2));
-    return d == 128 ? launch_attg<128, true>(c, a) : launch_attg<256, true>(c, a);
+    return d == 128 ? launch_attg<128, true>(c, a) : (d == 256 ? launch_attg<256, true>(c, a) : launch_attg<512, true>(c, a));
 }
 
 /* split-source forms: F = [fl[idx] | fr] is never materialised (include/pointseg_train_ops.h) */

@@ -1340,6 +1340,13 @@ struct ps_trainer {
         return agg;
     }
 
+    // d = 512 (level 4) exists on the frame too (round 6: its backward as two launches over halves of the dF columns, 64 + 128 accumulators
+    // each) and is NOT used by the step: measured on MI355X, 8 x 703 points (profiles/tools/exp_attg.py), the two launches take 1.13 ms
+    // against 0.46 ms for the softmax-pool backward + input-gradient GEMM they would replace (bf16-MLP: 0.63 against 0.36) -- every launch
+    // recomputes all four score panels at one wave per SIMD --, which the forward's gain (0.37 -> 0.30) does not buy back: batch-8 step
+    // 38.2 -> 39.8 ms with it.  Level 4 stays op by op.
+    static bool att_gemm_pays(int64_t K, int64_t d) { return ps_op_att_pool_gemm_supported(K, d) != 0 && d <= 256; }
+
     // the wide-level pooling over fset = [gather(f_src, idx) | f_xyz] without the gather and the concat buffer (attpool_gemm.hip, split-source
     // forms): the gathered half's gradient leaves as rows for the fixed-order gather-reduction, the f_xyz half is added in place, dS feeds the
     // split-bf16 weight-gradient kernel, whose loader gathers the rows of X it needs through idx
@@ -1347,7 +1354,7 @@ struct ps_trainer {
     {
         const int64_t d = 2 * f_src.C, rows = B * M * K;
         auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-        return opt.fused_att && att_gemm_on && c->train_b3 && ps_op_att_pool_gemm_supported(K, d) && rows >= 16384 && rows < (1ll << 31) && d % 128 == 0 &&
+        return opt.fused_att && att_gemm_on && c->train_b3 && ps_op_att_pool_gemm_supported(K, d) && d <= 256 /* (the split-source kernels) */ && rows >= 16384 && rows < (1ll << 31) && d % 128 == 0 &&
                f_src.ld % 4 == 0 && f_xyz.ld % 4 == 0 && f_xyz.C == f_src.C && al(f_src.p) && al(f_xyz.p) && al(idx) && f_src.R / B * f_src.ld < (1ll << 31);
     }
     Tn attpool_gemm_split(const Tn& f_src_in, const int32_t* idx, int64_t B, int64_t M, int64_t K, const Tn& f_xyz, const Tn& W, const Tn& gW)
@@ -1576,7 +1583,7 @@ struct ps_trainer {
         Tn agg;
         if (opt.fused_att && ps_op_att_pool_train_supported(K, fcat.C)) {
             agg = attpool(fcat, W, gW, K);  // levels whose [N*K, d] tensors are large: one kernel per direction
-        } else if (opt.fused_att && att_gemm_on && ps_op_att_pool_gemm_supported(K, fcat.C) && fcat.ld % 4 == 0 &&
+        } else if (opt.fused_att && att_gemm_on && att_gemm_pays(K, fcat.C) && fcat.ld % 4 == 0 &&
                    (reinterpret_cast<uintptr_t>(fcat.p) & 15) == 0) {
             agg = attpool_gemm(fcat, W, gW, K);  // the wide levels: scores in registers on the frame of the large GEMMs
         } else {
@@ -1674,7 +1681,7 @@ struct ps_trainer {
                 f_agg2 = att_split(f_agg, idx, B, N, K, f_xyz2, n + "LFAatt_pooling_2", wide_split && att_gemm_split_ok(f_agg, idx, f_xyz2, B, N, K));
             } else {
                 // (d = 128: the pre-product form measured slower, HBM bound there; bf16 mode: its yardstick rounds the operands of the ONE d x d product)
-                const bool pre = !opt.mlp_bf16 && 2 * hc >= 256 && !(opt.fused_att && att_gemm_on && ps_op_att_pool_gemm_supported(K, 2 * hc));
+                const bool pre = !opt.mlp_bf16 && 2 * hc >= 256 && !(opt.fused_att && att_gemm_on && att_gemm_pays(K, 2 * hc));
                 Tn cat1 = alloc(B * N * K, 2 * hc);
                 Tn right1 = cols(cat1, hc, hc);
                 Tn f_xyz = locse(&right1);

@@ -531,7 +531,8 @@ def test_fused_attentive_pooling_forward_backward(mode):
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_wide_level_attentive_pooling_on_the_gemm_frame(mode):
     """ps_op_att_pool_gemm_fwd / _bwd (csrc/attpool_gemm.hip: the score product, the softmax over K, the weighted sum and -- backward --
-    dS and dF = p g + dS . W^T with the scores only in accumulator registers; d = 128 / 256, forward also 512) against torch float64
+    dS and dF = p g + dS . W^T with the scores only in accumulator registers; d = 128 / 256 / 512, the backward of 512 as two launches over
+    halves of the dF columns) against torch float64
     autograd of  agg = sum_K softmax_K(F.W) * F  (RandLANet.py:394-398), the bf16 mode with the operands of the products rounded as the
     kernel rounds them.  Strided input (a column block of a wider buffer), ragged point counts (the last workgroup holds an odd number
     of points / waves without rows), accumulation into an existing dF, and the weight gradient through ps_op_linear_wgrad_ex over
@@ -549,8 +550,8 @@ def test_wide_level_attentive_pooling_on_the_gemm_frame(mode):
     try:
         _lib.check(L.ps_set_train_gemm_bf16(h, 1 if mode == "bf16" else 0))
         for R, d, wide, bwd in [(1000, 128, 128, True), (1033, 128, 160, True), (7, 128, 128, True), (1500, 256, 256, True), (333, 256, 320, True),
-                                (1, 256, 256, True), (515, 512, 512, False)]:
-            assert L.ps_op_att_pool_gemm_supported(K, d) == (1 if bwd else 0) or not bwd
+                                (1, 256, 256, True), (515, 512, 512, True), (130, 512, 544, True)]:
+            assert L.ps_op_att_pool_gemm_supported(K, d) == 1
             buf = torch.randn(R * K, wide, generator=g).cuda()
             F = buf[:, wide - d:]
             W = (torch.randn(d, d, generator=g) / d ** 0.5).cuda()
