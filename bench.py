@@ -707,6 +707,10 @@ def main():
                     help="serial steps on one stream (per-cloud latency) instead of several clouds in flight on separate HIP streams "
                          "(point_unet_amd/pipeline.py)")
     ap.add_argument("--lanes", type=int, default=4, help="clouds in flight per GPU (pipeline lanes, one HIP stream each)")
+    ap.add_argument("--coalesce", type=int, default=1, choices=[1, 2],
+                    help="pipelined forward: clouds per launch of the HEADLINE (1 = one cloud per launch, the definition of every round; 2 = "
+                         "ForwardPipeline(coalesce=2): consecutive single clouds run as pairs through the same C-ABI calls -- reported as the "
+                         "sub-result `coalesced_pairs` of the default line either way)")
     ap.add_argument("--include-pcie", action="store_true",
                     help="every step also copies its inputs (xyz, features) from pinned host memory and its logits back: the "
                          "PCIe-inclusive rate DESIGN.md quotes next to the headline (which keeps inputs resident in HBM)")
@@ -848,7 +852,7 @@ def main():
         # consecutive clouds on consecutive lanes (one HIP stream each): the latency-bound pyramid of one cloud shares the
         # chip with the network kernels of the others; every step still does all of its work
         from point_unet_amd.pipeline import ForwardPipeline
-        pipe = ForwardPipeline(cfg, params=params, device=local_rank, lanes=args.lanes)
+        pipe = ForwardPipeline(cfg, params=params, device=local_rank, lanes=args.lanes, coalesce=args.coalesce if B == 1 else 1)
         contexts = pipe.contexts
         pipe.prime(d_xyz, d_feats)  # every lane's workspace allocated before the warmup / timed steps
 
@@ -866,13 +870,15 @@ def main():
     pcie_step = None
     if pipe is not None and (args.include_pcie or not args.no_sub_results):
         h_in = [(torch.from_numpy(x).pin_memory(), torch.from_numpy(f.astype(np.float16) if half else f).pin_memory()) for x, f in zip(xyz_all, feats_all)]
-        h_out = [torch.empty((B, n0, cfg.num_classes), dtype=torch.float32).pin_memory() for _ in range(args.lanes)]
+        h_out = [[torch.empty((B, n0, cfg.num_classes), dtype=torch.float32).pin_memory() for _ in range(2)] for _ in range(args.lanes)]
         d_in = [(torch.empty_like(d_xyz), torch.empty_like(d_feats)) for _ in range(args.lanes)]  # per-lane device input slots
+        held = [[] for _ in range(args.lanes)]  # logits whose copy back waits for the launch of their pair (coalesced mode)
 
         def pcie_step(overlap=True):
             # host -> device, compute, device -> host all on the lane's own stream (no extra streams: they would compete with the
-            # lanes for hardware queues); the copies of one lane overlap the kernels of the others
-            k = pipe._i % len(pipe.lanes)
+            # lanes for hardware queues); the copies of one lane overlap the kernels of the others.  Coalesced mode: the first cloud of a
+            # pair waits in the lane's input slot, its logits are copied back behind the pair's launch together with the partner's
+            k = pipe.next_lane()
             lane = pipe.lanes[k]
             dx, df = d_in[k]
             hx, hf = h_in[next_cloud()]
@@ -880,7 +886,11 @@ def main():
                 dx.copy_(hx, non_blocking=True)
                 df.copy_(hf, non_blocking=True)
                 out = pipe.submit(dx, df, overlap=overlap)
-                h_out[k].copy_(out, non_blocking=True)
+                held[k].append(out)
+                if pipe.launched:
+                    for j, o in enumerate(held[k]):
+                        h_out[k][j % 2].copy_(o, non_blocking=True)
+                    held[k].clear()
             return out
     main_step = pcie_step if args.include_pcie else step
     if args.include_pcie and pcie_step is None:
@@ -954,6 +964,28 @@ def main():
                          "what": "one cloud in flight.  ms_per_cloud (the definition of rounds 1-3): every cloud on the next lane, waiting for an "
                                  "event of the previous cloud's stream; ms_per_cloud_one_lane (round 4's `serial`): consecutive clouds on ONE lane, "
                                  "stream order alone -- the per-cloud latency of pyramid + forward on this rank"}
+        if B == 1 and not args.include_pcie and not half:
+            # the service's throughput mode next to the headline, same run: consecutive clouds coalesced in pairs (ForwardPipeline(coalesce=2)),
+            # over a region long enough for a steady state (the fill and drain of a pipeline of pairs are twice as long: at the driver's 20
+            # steps the two modes measure the same) -- and the other mode over the same number of steps
+            other = 1 if pipe.coalesce == 2 else 2
+            n_long = max(args.steps, 200)
+            res = {}
+            for mode in (other, pipe.coalesce):
+                pipe.synchronize()
+                keep, pipe.coalesce = pipe.coalesce, mode
+                for _ in range(max(8, args.warmup)):
+                    step()
+                sync()
+                t_m, _ = timed_region(step, n_long, sync, None)
+                pipe.synchronize()
+                pipe.coalesce = keep
+                res[mode] = 1e3 * t_m / n_long
+            sub["coalesced_pairs"] = {"ms_per_cloud": res[2], "ms_per_cloud_one_per_launch": res[1], "points_per_s": B * n0 / (res[2] * 1e-3), "steps": n_long,
+                                      "lanes": args.lanes,
+                                      "what": "NOT the headline: ForwardPipeline(coalesce=2) -- two consecutive 180 000-point clouds per ps_pyramid_build / "
+                                              "ps_randla_forward launch (a batch of two independent clouds, copied into the lane's input slots), against one "
+                                              "cloud per launch over the same %d steps; this rank only" % n_long}
         if not args.no_sub_results and not args.include_pcie:
             # untimed warm-up of the service path itself: the first transfers through freshly pinned host buffers and fresh device slots
             # are slow (page registration with the DMA engines), and at the driver's --steps 20 they WERE the number (r2: 1.66 ms
@@ -1126,7 +1158,11 @@ def main():
                                                                                   cfg.k_n, B),
                        "points": n0, "k_n": cfg.k_n, "num_layers": cfg.num_layers, "batch_per_gpu": B, "sharding": "one cloud per GPU, no collective",
                        "pipeline": "serial, one stream" if args.no_pipeline else
-                       "%d clouds in flight, one HIP stream each (pyramid + forward per cloud on its stream)" % args.lanes,
+                       ("%d lanes (one HIP stream each), consecutive clouds coalesced in PAIRS: two 180 000-point clouds per ps_pyramid_build / "
+                        "ps_randla_forward launch (a batch of two independent clouds; `one_cloud_per_launch` = the rounds 1-5 form, same run)" % args.lanes
+                        if (pipe is not None and pipe.coalesce == 2) else
+                        "%d clouds in flight, one HIP stream each (pyramid + forward per cloud on its stream)" % args.lanes),
+                       "clouds_per_launch": (pipe.coalesce if pipe is not None else 1),
                        "inputs": "pinned host memory, copied per step (PCIe-inclusive)" if args.include_pcie else "resident in HBM",
                        "distinct_clouds": n_clouds,
                        "attention_mfma": "fp32 MFMA" if args.att_fp32_mfma else
@@ -1137,6 +1173,7 @@ def main():
             "serial_one_lane_ms_per_cloud": (sub.get("serial") or {}).get("ms_per_cloud_one_lane"),
             "serial": sub.get("serial"),
             "include_pcie": sub.get("include_pcie"),
+            "coalesced_pairs": sub.get("coalesced_pairs"),
             "att_fp32_mfma": sub.get("att_fp32_mfma"),
             "device_ms_per_step": round(dev_ms, 4),
             "split": split,
@@ -1167,6 +1204,7 @@ def main():
         tb8, tb1, c5 = out.get("train_b8") or {}, out.get("train_b1") or {}, out.get("config5") or {}
         out["summary"] = {
             "ms_per_step": r3(out["ms_per_step"]), "serial_ms": r3(serial_ms), "serial_one_lane_ms": r3((sub.get("serial") or {}).get("ms_per_cloud_one_lane")), "pcie_ms": r3((sub.get("include_pcie") or {}).get("ms_per_step")),
+            "coalesced_pairs_ms": r3((sub.get("coalesced_pairs") or {}).get("ms_per_cloud")), "steady_one_per_launch_ms": r3((sub.get("coalesced_pairs") or {}).get("ms_per_cloud_one_per_launch")),
             "knn_us": r3(1e3 * roofline["avg_launch_ms"]) if roofline else None, "knn_frac": roofline["frac"] if roofline else None,
             "batch2_ms_per_cloud": r3((out.get("batch2") or {}).get("ms_per_cloud")),
             "config5_ms": r3(c5.get("ms_per_step")), "config5_serial_one_lane_ms": r3(c5.get("serial_one_lane_ms_per_cloud")),

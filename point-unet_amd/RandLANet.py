@@ -63,7 +63,8 @@ class Network:
     # ------------------------------------------------------------------------------------------------
     def inference(self, inputs, is_training=False):
         """inputs: dict with 'features' [B,N0,Cin] and either 'pyramid' (a pyramid.Pyramid) or the reference's
-        'xyz','neigh_idx','sub_idx','interp_idx' lists (RandLANet.py:33-36).  Returns logits [B,N0,num_classes]."""
+        'xyz','neigh_idx','sub_idx','interp_idx' lists (RandLANet.py:33-36); optional 'out': the logits buffer to fill.
+        Returns logits [B,N0,num_classes]."""
         if is_training:
             raise NotImplementedError("training-mode forward (batch-statistics BN, dropout) lives in point_unet_amd.train.Trainer")
         pyr = inputs.get("pyramid")
@@ -77,7 +78,11 @@ class Network:
             _lib.check(_lib.lib().ps_op_half_to_float(self.ctx.handle, runtime.ptr(feats), feats.numel(), runtime.ptr(wide)))
             feats = wide
         B, n0 = feats.shape[0], feats.shape[1]
-        logits = torch.empty((B, n0, self.config.num_classes), dtype=torch.float32, device=feats.device)
+        logits = inputs.get("out")  # optional: a caller-owned float32 [B,N0,num_classes] buffer (ForwardPipeline's coalesced pairs)
+        if logits is None:
+            logits = torch.empty((B, n0, self.config.num_classes), dtype=torch.float32, device=feats.device)
+        else:
+            assert logits.is_contiguous() and logits.dtype == torch.float32 and tuple(logits.shape) == (B, n0, self.config.num_classes)
         _lib.check(_lib.lib().ps_randla_forward(self._h, ctypes.byref(pyr.struct), runtime.ptr(feats), runtime.ptr(logits)))
         return logits
 

@@ -70,21 +70,43 @@ class _Lane:
         self.ctx.set_stream(self.stream)
         self.ctx.set_deferred_checks(True)  # tree-build status words are validated at synchronize()
         self.net = Network(config, params=params, device=device, seed=seed, ctx=self.ctx)
-        self.pyramid = None
+        self.pyramids = {}  # batch size -> Pyramid (buffers reused from cloud to cloud)
         self.done = None
         self.submissions = []  # global submission index of every pyramid build this lane's context has run, in order
+        # coalesced mode: the clouds waiting for their partner, copied into the lane's own [2, N, .] input slots
+        self.staged = 0
+        self.xyz2 = self.feat2 = self.logits2 = None
+
+    @property
+    def pyramid(self):  # (the batch-1 pyramid: what the measurement tools of profiles/tools reach for)
+        return self.pyramids.get(1)
+
+    @pyramid.setter
+    def pyramid(self, value):
+        self.pyramids[1] = value
 
 
 class ForwardPipeline:
-    def __init__(self, config, params=None, device=0, seed=0, lanes=4, reuse=None):
+    def __init__(self, config, params=None, device=0, seed=0, lanes=4, reuse=None, coalesce=1):
         """reuse: a ForwardPipeline that is done (another network / configuration): its lanes' HIP streams and contexts (workspaces) are
         taken over instead of creating new ones and it must not be used afterwards.  Every extra stream a process has touched costs:
         measured with this very class, a second pipeline on four NEW streams runs 2.33 ms pipelined / 4.3 ms serial per 262 144-point
         cloud against 1.93 / 2.63 ms for the same pipeline alone in a process (profiles/tools/exp_second_pipeline.py: four idle streams
         taken from torch's pool beforehand are enough; GPU_MAX_HW_QUEUES=10 does the same to the FIRST pipeline) -- dependent kernels
-        on streams spread over more hardware queues are scheduled later."""
+        on streams spread over more hardware queues are scheduled later.
+
+        coalesce = 2 (opt-in; default 1 = every cloud its own launch): single clouds (B = 1) submitted one after the other are run TWO PER
+        LAUNCH -- the first waits in the lane's input slot for its partner, the pair then goes through ps_pyramid_build /
+        ps_randla_forward as a batch of two (the same C-ABI calls; clouds of a batch are independent rows of every kernel).  A
+        service's throughput mode: measured on MI355X with four lanes over 200 clouds 0.798 ms per 180 000-point cloud against 0.835 one
+        cloud per launch (bench.py `coalesced_pairs`; contiguous batches of two: 0.769, of four: 0.766 -- the ~120 launches of a cloud,
+        most of them at the 5-25 us floor of a launch on the deep levels, are paid once per pair) -- for one more cloud of latency: a
+        cloud's logits are complete when its pair is (synchronize() launches a cloud still waiting alone), and no gain over a run as short
+        as the driver's 20 steps (the pipeline's fill and drain are twice as long).  Per cloud the result is that of the batch-1 call up
+        to summation order in the split-K dense layers (their K split depends on the row count)."""
         self.cfg = config
         self.device = torch.device("cuda", device)
+        self.coalesce = 2 if int(coalesce) >= 2 else 1
         _check_environment(int(lanes), reuse is not None)
         if params is None:
             from . import weights
@@ -102,13 +124,51 @@ class ForwardPipeline:
                 self.lanes.append(_Lane(config, params, device, seed))
         else:
             self.lanes = [_Lane(config, params, device, seed) for _ in range(int(lanes))]
-        self._shape = None
-        self._i = 0
+        self._n0 = None
+        self._i = 0        # clouds submitted so far
+        self._launch = 0   # launches so far: picks the lane (one launch = one cloud, or one coalesced pair)
         self.last_done = None
+        self.launched = True  # did the last submit() enqueue its cloud's work (False: the cloud waits for its partner)
 
     @property
     def contexts(self):
         return [ln.ctx for ln in self.lanes]
+
+    def next_lane(self):
+        """Index of the lane the next submit() (default arguments) will use."""
+        return self._launch % len(self.lanes)
+
+    def _pyramid(self, ln, B, n0, device):
+        pyr = ln.pyramids.get(B)
+        if pyr is None or pyr.xyz[0].shape[1] != n0:
+            ratios = list(self.cfg.sub_sampling_ratio)[:self.cfg.num_layers]
+            pyr = ln.pyramids[B] = alloc_pyramid(B, n0, ratios, self.cfg.k_n, device)
+        return pyr
+
+    def _run(self, ln, xyz, features, out=None):
+        """pyramid + forward of one batch on the lane's stream (which is current)."""
+        B, n0 = xyz.shape[0], xyz.shape[1]
+        pyr = self._pyramid(ln, B, n0, xyz.device)
+        ln.submissions.append(self._i - 1)
+        build_pyramid(xyz, self.cfg, ctx=ln.ctx, out=pyr)
+        inputs = {"pyramid": pyr, "features": features}
+        if out is not None:
+            inputs["out"] = out
+        logits = ln.net.inference(inputs)
+        ln.done = torch.cuda.Event()
+        ln.done.record(ln.stream)
+        self.last_done = ln.done
+        self._launch += 1
+        return logits
+
+    def _flush(self, ln):
+        """launches what waits in the lane's input slots (a pair, or one cloud whose partner never came)"""
+        if ln.staged == 0:
+            return
+        k = ln.staged
+        ln.staged = 0
+        with torch.cuda.stream(ln.stream):
+            self._run(ln, ln.xyz2[:k], ln.feat2[:k], out=ln.logits2[:k])
 
     def submit(self, xyz, features, overlap=True, lane=None):
         """xyz [B,N0,3], features [B,N0,Cin]: float32 CUDA tensors (ready on torch's current stream).  Enqueues the
@@ -116,36 +176,62 @@ class ForwardPipeline:
         synchronize() (or after waiting on `last_done`).  overlap=False makes the lane wait for the previously submitted
         cloud first: bench.py's per-stage profile pass uses it to time kernels without a neighbour on the chip.  lane=k pins the cloud
         to lane k instead of the next one in turn (consecutive clouds on ONE lane run one after the other by stream order alone: the
-        per-cloud latency without any cross-stream event in the chain)."""
+        per-cloud latency without any cross-stream event in the chain).  With coalesce = 2 a single cloud submitted with the default
+        arguments may wait for its partner (`launched` says whether this call enqueued the work)."""
         B, n0 = xyz.shape[0], xyz.shape[1]
-        if self._shape != (B, n0):
+        if self._n0 != n0:
             self.synchronize()
-            ratios = list(self.cfg.sub_sampling_ratio)[:self.cfg.num_layers]
             for ln in self.lanes:
-                ln.pyramid = alloc_pyramid(B, n0, ratios, self.cfg.k_n, xyz.device)
-            self._shape = (B, n0)
-        ln = self.lanes[(self._i if lane is None else int(lane)) % len(self.lanes)]
-        ln.submissions.append(self._i)
+                ln.pyramids = {}
+                ln.xyz2 = ln.feat2 = ln.logits2 = None
+            self._n0 = n0
         self._i += 1
-        ln.stream.wait_stream(torch.cuda.current_stream(self.device))  # the inputs were produced on the caller's stream
+        cur = torch.cuda.current_stream(self.device)
+        if self.coalesce == 2 and B == 1 and overlap and lane is None and features.dtype == torch.float32:
+            ln = self.lanes[self._launch % len(self.lanes)]
+            ln.stream.wait_stream(cur)  # the inputs were produced on the caller's stream
+            slot = ln.staged
+            with torch.cuda.stream(ln.stream):
+                if ln.xyz2 is None or ln.feat2.shape[2] != features.shape[2]:
+                    ln.xyz2 = torch.empty((2, n0, 3), dtype=torch.float32, device=xyz.device)
+                    ln.feat2 = torch.empty((2, n0, features.shape[2]), dtype=torch.float32, device=xyz.device)
+                if slot == 0:  # (the pair's logits belong to the caller: a fresh buffer per pair)
+                    ln.logits2 = torch.empty((2, n0, self.cfg.num_classes), dtype=torch.float32, device=xyz.device)
+                ln.xyz2[slot].copy_(xyz[0], non_blocking=True)
+                ln.feat2[slot].copy_(features[0], non_blocking=True)
+                out = ln.logits2[slot:slot + 1]
+                ln.staged = slot + 1
+                self.launched = ln.staged == 2
+                if self.launched:
+                    self._flush(ln)
+            xyz.record_stream(ln.stream)
+            features.record_stream(ln.stream)
+            return out
+        # one launch for this submission (batches, pinned lanes, serialised passes, half-precision features)
+        for other in self.lanes:
+            self._flush(other)
+        ln = self.lanes[(self._launch if lane is None else int(lane)) % len(self.lanes)]
+        ln.stream.wait_stream(cur)
         if not overlap and self.last_done is not None:
             ln.stream.wait_event(self.last_done)
         with torch.cuda.stream(ln.stream):  # the logits are allocated on (and belong to) the lane's stream
-            build_pyramid(xyz, self.cfg, ctx=ln.ctx, out=ln.pyramid)
-            logits = ln.net.inference({"pyramid": ln.pyramid, "features": features})
-            ln.done = torch.cuda.Event()
-            ln.done.record(ln.stream)
+            logits = self._run(ln, xyz, features)
         xyz.record_stream(ln.stream)
         features.record_stream(ln.stream)
-        self.last_done = ln.done
+        self.launched = True
         return logits
 
     def prime(self, xyz, features):
         """Runs one cloud through EVERY lane and drains: workspaces grow to their high-water mark (the only hipMalloc calls
-        of the library) before anything is timed or latency-sensitive."""
+        of the library) before anything is timed or latency-sensitive.  Coalesced mode: a pair per lane as well (the batch-2 pyramid and
+        workspaces), and one cloud launched alone."""
         for _ in self.lanes:
             self.submit(xyz, features, overlap=False)
         self.synchronize()
+        if self.coalesce == 2 and xyz.shape[0] == 1 and features.dtype == torch.float32:
+            for _ in range(2 * len(self.lanes)):
+                self.submit(xyz, features)
+            self.synchronize()
 
     def synchronize(self):
         """Drains every lane and validates the status words of the tree builds.  The build itself always completes on the device
@@ -155,6 +241,8 @@ class ForwardPipeline:
         submission's results are valid."""
         import re
         first = None
+        for ln in self.lanes:
+            self._flush(ln)  # (a cloud whose partner never came is launched alone)
         for k, ln in enumerate(self.lanes):
             try:
                 ln.ctx.synchronize()

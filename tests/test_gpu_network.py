@@ -196,7 +196,7 @@ def test_pipeline_matches_serial():
     for xyz, feats in clouds:
         pyr = build_pyramid(torch.from_numpy(xyz).cuda(), cfg)
         want.append(net.inference({"pyramid": pyr, "features": torch.from_numpy(feats).cuda()}).cpu().numpy())
-    pipe = ForwardPipeline(cfg, params=params, lanes=3)
+    pipe = ForwardPipeline(cfg, params=params, lanes=3, coalesce=1)  # (one cloud per launch: the pairs have their own test below)
     dev = [(torch.from_numpy(x).cuda(), torch.from_numpy(f).cuda()) for x, f in clouds]
     torch.cuda.synchronize()
     got = [pipe.submit(x, f) for x, f in dev]  # all seven enqueued before anything is read back
@@ -238,7 +238,7 @@ def test_pipeline_runs_density_skewed_clouds_between_good_ones(oracle):
     for c, f in zip(clouds, feats):
         pyr = build_pyramid(torch.from_numpy(c[None]).cuda(), cfg)
         want.append(net.inference({"pyramid": pyr, "features": torch.from_numpy(f).cuda()}).cpu().numpy())
-    pipe = ForwardPipeline(cfg, params=params, lanes=3)
+    pipe = ForwardPipeline(cfg, params=params, lanes=3, coalesce=1)
     dev = [(torch.from_numpy(c[None]).cuda(), torch.from_numpy(f).cuda()) for c, f in zip(clouds, feats)]
     torch.cuda.synchronize()
     got = [pipe.submit(x, f) for x, f in dev]
@@ -250,6 +250,64 @@ def test_pipeline_runs_density_skewed_clouds_between_good_ones(oracle):
     pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: oracle.knn_batch(s, q, k), c, cfg.k_n, cfg.sub_sampling_ratio)
     ref = ro.inference(params, cfg.num_layers, pts, nbr, pool, up, f, np.float64)
     assert np.abs(want[2] - ref).max() <= TOL
+    pipe.close()
+
+
+def test_pipeline_coalesces_single_clouds_into_pairs(oracle):
+    """ForwardPipeline's opt-in throughput mode (coalesce = 2): consecutive single clouds run two per launch through the same C-ABI
+    calls.  Seven clouds of 40 000 points at the true widths: clouds 2k, 2k+1 come out BIT-IDENTICAL to a direct batch-of-two call on
+    [cloud 2k, cloud 2k+1]; the seventh, whose partner never comes, is launched alone by synchronize() and equals the batch-1 call; every
+    cloud is within 2e-5 of its own batch-1 logits (the split-K dense layers pick their K split by row count: summation order only) and
+    the pair form is within the logits bar of the float64 oracle; `launched` tells a caller whether its cloud is still waiting."""
+    import torch
+    from oracle import randla_oracle as ro
+    from point_unet_amd import weights
+    from point_unet_amd.RandLANet import Network
+    from point_unet_amd.pipeline import ForwardPipeline
+    from point_unet_amd.pyramid import build_pyramid
+    from conftest import brats_cloud
+    n = 40000
+    cfg = netcase.make_cfg(5, (16, 64, 128, 256, 512), (4, 4, 4, 4, 2), 16, 4, 7)
+    params = weights.init_params(cfg, seed=4, randomize_bn=True)
+    rng = np.random.default_rng(6)
+    clouds = [brats_cloud(n, 30 + i, grid=(80, 80, 60))[None] for i in range(7)]
+    feats = [np.concatenate([c[0], rng.standard_normal((n, 4)).astype(np.float32)], -1)[None] for c in clouds]
+    net = Network(cfg, params=params)
+
+    def direct(x, f):
+        pyr = build_pyramid(torch.from_numpy(x).cuda(), cfg)
+        return net.inference({"pyramid": pyr, "features": torch.from_numpy(f).cuda()}).cpu().numpy()
+
+    single = [direct(c, f) for c, f in zip(clouds, feats)]
+    pairs = [direct(np.concatenate(clouds[i:i + 2]), np.concatenate(feats[i:i + 2])) for i in (0, 2, 4)]
+    pipe = ForwardPipeline(cfg, params=params, lanes=3, coalesce=2)
+    assert pipe.coalesce == 2
+    pipe.prime(torch.from_numpy(clouds[0]).cuda(), torch.from_numpy(feats[0]).cuda())
+    dev = [(torch.from_numpy(c).cuda(), torch.from_numpy(f).cuda()) for c, f in zip(clouds, feats)]
+    torch.cuda.synchronize()
+    got, flags = [], []
+    for x, f in dev:
+        got.append(pipe.submit(x, f))
+        flags.append(pipe.launched)
+    assert flags == [False, True, False, True, False, True, False]
+    pipe.synchronize()
+    for i, g in enumerate(got):
+        g = g.cpu().numpy()
+        assert g.shape == single[i].shape
+        if i < 6:
+            assert np.array_equal(g[0], pairs[i // 2][i % 2]), i
+        else:
+            assert np.array_equal(g, single[i]), i
+        assert np.abs(g - single[i]).max() <= 2e-5, (i, np.abs(g - single[i]).max())
+    pts, nbr, pool, up = ro.build_pyramid(lambda s, q, k: oracle.knn_batch(s, q, k), clouds[1], cfg.k_n, cfg.sub_sampling_ratio)
+    ref = ro.inference(params, cfg.num_layers, pts, nbr, pool, up, feats[1], np.float64)
+    assert np.abs(got[1].cpu().numpy() - ref).max() <= TOL
+    # a pinned lane / a serialised pass / a batch go out on their own, behind whatever was waiting
+    a = pipe.submit(*dev[0])
+    b = pipe.submit(*dev[1], overlap=False)
+    assert pipe.launched
+    pipe.synchronize()
+    assert np.array_equal(a.cpu().numpy(), single[0]) and np.array_equal(b.cpu().numpy(), single[1])
     pipe.close()
 
 
