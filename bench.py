@@ -365,7 +365,7 @@ def train_roofline(cfg, n0, B, ms, bf16):
            "algorithmic_flops_per_step": step_flops, "algorithmic_bytes_per_step": step_bytes,
            "mfma_frac": round(tfs / peak, 5), "hbm_frac": round(gbs / HBM_PEAK_GBS, 5)}
     # HBM bytes of one step from the committed rocprofv3 --pmc passes of `bench.py --mode train` (profiles/regen_r4.sh), labelled with their source
-    pmc = next((q for q in (os.path.join(ROOT, "profiles", "r%d_pmc_traffic_train.json" % k) for k in (5, 4)) if os.path.exists(q)), "")
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", "r%d_pmc_traffic_train.json" % k) for k in (6, 5, 4)) if os.path.exists(q)), "")
     key = "b%d_%s" % (B, "bf16" if bf16 else "f32")
     if pmc:
         t = json.load(open(pmc))
@@ -1099,7 +1099,7 @@ def main():
             # HBM bytes per launch cannot be counted from inside this process: they come from separate rocprofv3 --pmc passes of this
             # same command (profiles/run_pmc.sh; FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), committed with the commit they
             # were taken at.  The number is labelled with that source; null when no such file exists for this round.
-            pmc = next((q for q in (os.path.join(ROOT, "profiles", "r%d_pmc_traffic.json" % k) for k in (5, 4, 3, 2)) if os.path.exists(q)), "")
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", "r%d_pmc_traffic.json" % k) for k in (6, 5, 4, 3, 2)) if os.path.exists(q)), "")
             if pmc:
                 t = json.load(open(pmc))
                 roofline["traffic"] = t.get(dominant)

@@ -19,12 +19,18 @@ struct TreeSetPlan {
     std::vector<int4*> d_fat;        // [3 * 2n] per tree: every inner node with its children's records (TreeView::fat)
     std::vector<float4*> d_pts;      // [n]  per tree (vind order, w = original index)
     TreeMeta* d_meta = nullptr;      // [trees]
-    void* d_jobs = nullptr;          // KnnJob table (trees + extra_jobs entries of 64 B)
-    int32_t* d_flags = nullptr;      // [16] error flags, zeroed by build_trees
-    void* d_scratch = nullptr;       // builder scratch
+    // ONE contiguous "head" block that ONE host-to-device copy initialises (round 6: it was an upload of the tree table, a kernel zeroing
+    // the counters and priming the bounding-box accumulators, and a second upload of the job table -- three dependent stream operations):
+    //   [ KnnJob table | 16 status words (zero) | BuildTree table | bounding-box accumulators (primed) | queue counters (zero) | level counters (zero) ]
+    char* d_head = nullptr;
+    size_t head_bytes = 0, off_flags = 0, off_trees = 0, off_bbox = 0, off_cnt = 0, off_hcnt = 0;
+    void* d_jobs = nullptr;          // = d_head: KnnJob table (trees + extra_jobs entries of 128 B)
+    int32_t* d_flags = nullptr;      // [16] error flags, zero after the head copy
+    void* d_scratch = nullptr;       // builder scratch (everything that needs no initial contents)
     size_t scratch_bytes = 0;
     int launches = 0;                // kernels launched by build_trees (for the stage timer)
-    std::vector<char> host_blob;     // host staging of the builder's tables (must outlive the async copies)
+    std::vector<char> host_blob;     // host image of the head block; the caller writes its job table at offset 0 BEFORE build_trees
+    char* host_jobs() { return host_blob.data(); }
 
     void add(int32_t count)
     {

@@ -25,6 +25,7 @@
 #include "wave_ops.h"
 
 #include <algorithm>
+#include <cstring>
 #include <type_traits>
 
 namespace ps {
@@ -87,17 +88,6 @@ struct GArr {
 };
 
 // ---- init -----------------------------------------------------------------------------------------------------
-// zeroes the counters / flags and primes the ordered-uint bounding-box accumulators (one launch instead of an upload and
-// three memsets on the stream)
-__global__ void build_prep_kernel(int32_t* cnt, int n_cnt, int32_t* hcnt, int n_hcnt, int32_t* flags, unsigned* bbox, int n_trees)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_cnt) cnt[i] = 0;
-    if (i < n_hcnt) hcnt[i] = 0;
-    if (i < 16) flags[i] = 0;
-    if (i < 8 * n_trees) bbox[i] = (i & 7) < 3 ? 0xffffffffu : 0u;
-}
-
 __global__ __launch_bounds__(256) void init_points_kernel(const BuildTree* __restrict__ trees, int chunks_x)
 {
     __shared__ float s_mn[4][3], s_mx[4][3];
@@ -1625,22 +1615,31 @@ void TreeSetPlan::carve(Arena& a)
         d_pts[i] = a.take<float4>((size_t)(n[i] > 0 ? n[i] : 1) + kLeafMax);  // (+ kLeafMax: the search reads whole leaf slots, kdtree.h)
     }
     d_meta = a.take<TreeMeta>(T);
-    d_jobs = a.take<char>(128 * (T + (size_t)extra_jobs));
-    d_flags = a.take<int32_t>(16);
-    // builder scratch: tree table, bbox accumulators, posL/posR, queues, counters
+    {   // the head block (kdtree_build.h): one copy initialises all of it
+        size_t hb = 0;
+        auto addh = [&](size_t b) { size_t o = hb; hb += (b + 255) & ~size_t(255); return o; };
+        addh(128 * (T + (size_t)extra_jobs));                      // job table at offset 0
+        off_flags = addh(sizeof(int32_t) * 16);
+        off_trees = addh(sizeof(BuildTree) * T);
+        off_bbox = addh(sizeof(unsigned) * 8 * T);
+        off_cnt = addh(sizeof(int32_t) * (kMaxLevels + 8));
+        off_hcnt = addh(sizeof(int32_t) * 2 * (kHugeLevels + 2));
+        head_bytes = hb;
+        d_head = a.take<char>(hb);
+        d_jobs = d_head;
+        d_flags = reinterpret_cast<int32_t*>(d_head + off_flags);
+        host_blob.assign(hb, 0);
+    }
+    // builder scratch: posL/posR, queues, chunked-level state (no initial contents needed)
     const size_t q_cap = tot / kSmall + 2 * T + 64, small_cap = tot / 4 + 2 * T + 1024;
     size_t bytes = 0;
     auto add = [&](size_t b) { size_t o = bytes; bytes += (b + 255) & ~size_t(255); return o; };
-    add(sizeof(BuildTree) * T);
-    add(sizeof(unsigned) * 8 * T);
     add(sizeof(int32_t) * 2 * (tot + T));
     add(sizeof(BuildTask) * q_cap * 3);
     add(sizeof(BuildTask) * small_cap);
-    add(sizeof(int32_t) * (kMaxLevels + 8));
-    {   // chunked-level state (must stay AFTER everything build_trees_continue() re-derives)
+    {   // chunked-level state
         const size_t cap_tasks = tot / kHuge + T + 8, cap_chunks = tot / kChunk + cap_tasks + 8;
         add(sizeof(HugeTask) * cap_tasks * 2);
-        add(sizeof(int32_t) * 2 * (kHugeLevels + 2));
         add(sizeof(int32_t) * 3 * cap_chunks);
         add(sizeof(ChunkDesc) * 2 * cap_chunks);
         add(tot + 16 * T + 16);
@@ -1658,22 +1657,25 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
     char* base = static_cast<char*>(plan.d_scratch);
     size_t off = 0;
     auto take = [&](size_t b) { char* p = base + off; off += (b + 255) & ~size_t(255); return p; };
-    BuildTree* d_trees = reinterpret_cast<BuildTree*>(take(sizeof(BuildTree) * T));
-    unsigned* d_bbox = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * 8 * T));
+    BuildTree* d_trees = reinterpret_cast<BuildTree*>(plan.d_head + plan.off_trees);
+    unsigned* d_bbox = reinterpret_cast<unsigned*>(plan.d_head + plan.off_bbox);
+    int32_t* d_cnt = reinterpret_cast<int32_t*>(plan.d_head + plan.off_cnt);
+    int32_t* d_hcnt = reinterpret_cast<int32_t*>(plan.d_head + plan.off_hcnt);
     int32_t* d_pos = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 2 * (tot + T)));
     BuildTask* d_q = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * q_cap * 3));
     BuildTask* d_small = reinterpret_cast<BuildTask*>(take(sizeof(BuildTask) * small_cap));
-    int32_t* d_cnt = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (kMaxLevels + 8)));
     const size_t cap_tasks = tot / kHuge + T + 8, cap_chunks = tot / kChunk + cap_tasks + 8;
     HugeTask* d_huge = reinterpret_cast<HugeTask*>(take(sizeof(HugeTask) * cap_tasks * 2));
-    int32_t* d_hcnt = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 2 * (kHugeLevels + 2)));
     int32_t* d_cm = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 3 * cap_chunks));
     ChunkDesc* d_desc = reinterpret_cast<ChunkDesc*>(take(sizeof(ChunkDesc) * 2 * cap_chunks));
     uint8_t* d_cls = reinterpret_cast<uint8_t*>(take(tot + 16 * T + 16));
 
-    // host staging lives in the plan (the caller keeps the plan alive until its final stream synchronisation)
-    plan.host_blob.resize(sizeof(BuildTree) * T);
-    BuildTree* h_trees = reinterpret_cast<BuildTree*>(plan.host_blob.data());
+    // host image of the head block (the caller has written its job table at offset 0; flags and counters are zero from carve())
+    PS_CHECK(plan.host_blob.size() == plan.head_bytes, "build_trees: the plan was not carved");
+    std::memset(plan.host_blob.data() + plan.off_flags, 0, plan.head_bytes - plan.off_flags);
+    BuildTree* h_trees = reinterpret_cast<BuildTree*>(plan.host_blob.data() + plan.off_trees);
+    unsigned* h_bbox = reinterpret_cast<unsigned*>(plan.host_blob.data() + plan.off_bbox);
+    for (size_t i = 0; i < 8 * T; ++i) h_bbox[i] = (i & 7) < 3 ? 0xffffffffu : 0u;  // ordered-uint min / max accumulators
     size_t pos_off = 0, cls_off = 0;
     int32_t max_n = 0;
     for (size_t i = 0; i < T; ++i) {
@@ -1694,12 +1696,7 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
         max_n = std::max(max_n, t.n);
     }
     hipStream_t st = c->stream;
-    PS_TRY(c->upload_async(d_trees, h_trees, sizeof(BuildTree) * T));
-    {
-        const int n_prep = std::max<int>({kMaxLevels + 8, 2 * (kHugeLevels + 2), 16, (int)(8 * T)});
-        hipLaunchKernelGGL(build_prep_kernel, dim3(ceil_div(n_prep, 256)), dim3(256), 0, st, d_cnt, kMaxLevels + 8, d_hcnt, 2 * (kHugeLevels + 2),
-                           plan.d_flags, d_bbox, (int)T);
-    }
+    PS_TRY(c->upload_async(plan.d_head, plan.host_blob.data(), plan.head_bytes));  // jobs, status words, tree table, accumulators, counters
 
     HugeState H;
     H.tasks[0] = d_huge;
@@ -1757,7 +1754,7 @@ int build_trees(ps_context* c, TreeSetPlan& plan)
         hipLaunchKernelGGL(fatten_kernel, dim3(ids_x, (unsigned)T), dim3(256), 0, st, d_trees, ids_x);
         PS_HIP(hipGetLastError());
     }
-    plan.launches = 7 + 5 * huge_levels;
+    plan.launches = 6 + 5 * huge_levels;
     return PS_OK;
 }
 

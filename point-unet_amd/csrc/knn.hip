@@ -14,6 +14,7 @@
 #include "kdtree_build.h"
 
 #include <cfloat>
+#include <cstring>
 
 namespace ps {
 
@@ -747,11 +748,6 @@ static int knn_batch_impl(ps_context* c, const float* support, const float* quer
         plan.carve(c->knn_arena);
         if (pass == 0) PS_TRY(c->knn_arena.buf.reserve(c->knn_arena.off));
     }
-    {
-        Stage st(c, "kdtree_build", 1);
-        for (int64_t b = 0; b < B; ++b) plan.src[b] = d_support + (size_t)b * n1 * 3;
-        PS_TRY(build_trees(c, plan));
-    }
     std::vector<KnnJob> jobs(B);
     for (int64_t b = 0; b < B; ++b) {
         jobs[b].tree = plan.view((int)b);
@@ -762,7 +758,12 @@ static int knn_batch_impl(ps_context* c, const float* support, const float* quer
         jobs[b].overflow = plan.d_flags;
         jobs[b].order = nullptr;
     }
-    PS_TRY(c->upload_async(plan.d_jobs, jobs.data(), sizeof(KnnJob) * B));
+    std::memcpy(plan.host_jobs(), jobs.data(), sizeof(KnnJob) * B);  // (travels with the builder's own tables: one copy, kdtree_build.h)
+    {
+        Stage st(c, "kdtree_build", 1);
+        for (int64_t b = 0; b < B; ++b) plan.src[b] = d_support + (size_t)b * n1 * 3;
+        PS_TRY(build_trees(c, plan));
+    }
     int32_t flag[3] = {0, 0, 0};
     {
         Stage st(c, "knn_search", 1);
@@ -846,11 +847,6 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
             plan.src[l * B + b] = xyz0 + (size_t)b * n0 * 3;
             if (l < L && !(l == 0 && pyr->xyz[0] == xyz0)) plan.copy_dst[l * B + b] = pyr->xyz[l] + (size_t)b * n[l] * 3;
         }
-    {
-        Stage st(c, "kdtree_build", 1);
-        PS_TRY(build_trees(c, plan));
-        st.n = plan.launches;
-    }
 
     // jobs: K-NN self queries per level, then 1-NN up-sampling queries per level, both in the query set's own
     // tree (leaf) order so neighbouring lanes walk neighbouring paths.
@@ -886,9 +882,12 @@ extern "C" int ps_pyramid_build(ps_context* c, const float* xyz0, int64_t B, int
             j.prefix = 1;
             jobs.push_back(j);
         }
-    // NOTE: jobs is pageable host memory: the copy below is synchronous w.r.t. the host buffer by the time
-    // hipMemcpyAsync returns for pageable sources, but we do not rely on it -- see the stream sync at the end.
-    PS_TRY(c->upload_async(plan.d_jobs, jobs.data(), sizeof(KnnJob) * jobs.size()));
+    std::memcpy(plan.host_jobs(), jobs.data(), sizeof(KnnJob) * jobs.size());  // (uploaded by build_trees with its own tables: one copy)
+    {
+        Stage st(c, "kdtree_build", 1);
+        PS_TRY(build_trees(c, plan));
+        st.n = plan.launches;
+    }
     const KnnJob* dj = reinterpret_cast<const KnnJob*>(plan.d_jobs);
     int32_t flag[3] = {0, 0, 0};
     {
