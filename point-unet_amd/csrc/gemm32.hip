@@ -57,6 +57,9 @@ __global__ __launch_bounds__(SK > 4 ? 64 * SK : 256) void gemm32_kernel(Gemm32Ar
     for (int j = 0; j < CW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float bias_r[CW];  // (requested in front of the K loop: behind it the load is one more exposed round trip of a ~9 us launch)
+#pragma unroll
+    for (int j = 0; j < CW; ++j) bias_r[j] = (kw == 0) ? a.bias[(cb + j) * 32 + c32] : 0.f;
     if (live) {
         const int rr = min(rb * 32 + c32, a.R - 1);
         const int s1 = a.g1 ? (a.g1m ? (rr / a.g1m) * a.g1n : 0) + a.g1[rr] : rr;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(SK > 4 ? 64 * SK : 256) void gemm32_kernel(Gemm32Ar
 #pragma unroll
     for (int j = 0; j < CW; ++j) {
         const int col = (cb + j) * 32 + c32;
-        const float bb = a.bias[col];
+        const float bb = bias_r[j];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;

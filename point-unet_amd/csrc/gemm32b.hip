@@ -119,6 +119,11 @@ __global__ __launch_bounds__(SK > 4 ? 64 * SK : 256) void gemm32b_kernel(Gemm32b
         for (int j = 0; j < CW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // the epilogue's bias values are requested now (round 6: loaded behind the K loop they were one more exposed round trip of a launch
+    // whose waves live ~15 us)
+    float bias_r[CW];
+#pragma unroll
+    for (int j = 0; j < CW; ++j) bias_r[j] = (kw == 0) ? a.bias[(cb + j) * 32 + c32] : 0.f;
     if (live) {
         const float* p1[RW];
         const float* p2[RW];
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(SK > 4 ? 64 * SK : 256) void gemm32b_kernel(Gemm32b
 #pragma unroll
     for (int j = 0; j < CW; ++j) {
         const int col = (cb + j) * 32 + c32;
-        const float bb = a.bias[col];
+        const float bb = bias_r[j];
 #pragma unroll
         for (int i = 0; i < RW; ++i)
 #pragma unroll
