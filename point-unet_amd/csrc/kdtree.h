@@ -254,6 +254,10 @@ PS_HD bool knn_search_one(const TreeView& t, float qx, float qy, float qz, float
             pv[0] = gload(t.pts + lf_x);
 #pragma unroll
             for (int j = 1; j < kLeafMax; ++j) { pv[j] = pv[0]; pv[j].x += 1e-3f * j; }
+#elif defined(PS_KNN_EXP_MASKED_LEAF)
+            // EXPERIMENT: only the slots the leaf has -- a lane's record loads are one vector-memory lookup each, and a leaf holds ~7 of 10
+#pragma unroll
+            for (int j = 0; j < kLeafMax; ++j) pv[j] = lf_x + j < lf_y ? gload(t.pts + lf_x + j) : make_float4(0.f, 0.f, 0.f, 0.f);
 #else
 #pragma unroll
             for (int j = 0; j < kLeafMax; ++j) pv[j] = gload(t.pts + lf_x + j);  // one address, ten immediate offsets: the record
