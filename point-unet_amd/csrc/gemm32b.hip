@@ -143,7 +143,12 @@ __global__ __launch_bounds__(SK > 4 ? 64 * SK : 256) void gemm32b_kernel(Gemm32b
         // PD chunks ahead: a wave's loop is a chain of dependent round trips to L2 / MALL (the weight planes of a layer are read once per
         // 32-row block), and one chunk in flight left the launch latency-bound (23 us for 0.74 GFLOP); the ring is refilled in place
         // behind its last reader
+#ifdef PS_G32B_PD
+        constexpr int PD = RW * CW >= 4 ? 3 : PS_G32B_PD;  // (experiment: ring depth of the (1, 1) / (1, 2) tiles.  Round 6: 6 / 8 chunks ahead take 256
+                                                           //  VGPRs and run the enc2-4 dense stages 0.086 / 0.097 / 0.086 and 0.090 / 0.102 / 0.090 ms against 0.078 / 0.077 / 0.075)
+#else
         constexpr int PD = RW * CW >= 4 ? 3 : 4;
+#endif
         float4 xl[PD][RW], xh[PD][RW];
         uint4 bw[PD][CW][3];
         auto fetch = [&](int slot, int q) __attribute__((always_inline)) {
