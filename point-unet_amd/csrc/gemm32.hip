@@ -71,20 +71,42 @@ __global__ __launch_bounds__(SK > 4 ? 64 * SK : 256) void gemm32_kernel(Gemm32Ar
         }
         const float4* wq = reinterpret_cast<const float4*>(a.wp) + (size_t)cb * nq * 64 + lane;
         const size_t wstride = (size_t)nq * 64;  // float4s between consecutive column blocks
-#pragma unroll 8
-        for (int q = qa; q < qb; ++q) {
-            const float4 ax = *reinterpret_cast<const float4*>((q < nq1 ? p1 : p2) + 8 * q);
-            float4 bw[CW];
+        // A ring of PD K-chunks in flight, refilled in place behind its reader (gemm32b.hip's scheme).  Round 6: the `#pragma unroll 8` loop
+        // this replaces was NOT unrolled ("-Wpass-failed: loop not unrolled", silenced by the Makefile's -Wno-pass-failed): every 8-wide K chunk
+        // was a load, a wait for it and four MFMAs -- one exposed L2 round trip per chunk, eight to sixteen of them per ~9 us launch.
+        constexpr int PD = 4;
+        float4 axr[PD], bwr[PD][CW];
+        auto fetch = [&](int slot, int q) __attribute__((always_inline)) {
+            q = min(q, qb - 1);  // (past the end: a harmless repeat of the last chunk, never used)
+            axr[slot] = *reinterpret_cast<const float4*>((q < nq1 ? p1 : p2) + 8 * q);
 #pragma unroll
-            for (int j = 0; j < CW; ++j) bw[j] = wq[(size_t)j * wstride + (size_t)q * 64];
+            for (int j = 0; j < CW; ++j) bwr[slot][j] = wq[(size_t)j * wstride + (size_t)q * 64];
+        };
+        auto products = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < CW; ++j) {
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax.x, bw[j].x, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax.y, bw[j].y, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax.z, bw[j].z, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax.w, bw[j].w, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(axr[slot].x, bwr[slot][j].x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(axr[slot].y, bwr[slot][j].y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(axr[slot].z, bwr[slot][j].z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(axr[slot].w, bwr[slot][j].w, acc[j], 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < PD; ++d) fetch(d, qa + d);
+        int q0 = qa;
+#pragma unroll 1
+        for (; q0 + PD <= qb; q0 += PD) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+                products(d);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(d, q0 + d + PD);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+#pragma unroll
+        for (int d = 0; d < PD - 1; ++d)  // the last qb - q0 < PD chunks are already in the ring's first slots
+            if (q0 + d < qb) products(d);
     }
     if constexpr (SK > 1) {
         // partial blocks of the K slices 1 .. SK-1 go through LDS (register-major: conflict-free), slice 0 adds them up

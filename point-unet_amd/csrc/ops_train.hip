@@ -629,8 +629,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x,
             gd.load(dy, lddy, n0, wd, live, r + CH);
         }
         if constexpr (BF16) {
+            // (the loop index starts at a compile-time 0: with the wave-dependent start `s = wk` the compiler could not unroll it --
+            //  "-Wpass-failed: loop not unrolled", silenced by the Makefile -- and every k-step waited for its own LDS reads; same-box A/B of
+            //  the training step: no measurable change, 38.0 / 7.91 ms either way: the fp32 kernel only takes the small products now)
 #pragma unroll
-            for (int s = wk; s < CH / 16; s += WK) {
+            for (int s0 = 0; s0 < CH / 16; s0 += WK) {
+                const int s = s0 + wk;
+                if (s >= CH / 16) break;
                 bf16x4s a[TI], b[TJ];
                 const int rb = 16 * s + 4 * k4;
 #pragma unroll
@@ -650,7 +655,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x,
             }
         } else
 #pragma unroll
-        for (int s = wk; s < CH / 4; s += WK) {
+        for (int s0 = 0; s0 < CH / 4; s0 += WK) {
+            const int s = s0 + wk;
+            if (s >= CH / 4) break;
             float a[TI], b[TJ];
 #pragma unroll
             for (int i = 0; i < TI; ++i) a[i] = xs[(4 * s + k4) * SX + (wi * TI + i) * 16 + i16];
