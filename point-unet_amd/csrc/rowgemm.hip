@@ -83,6 +83,13 @@ __global__ __launch_bounds__(256) void rowgemm_direct_kernel(RowGemmArgs a)
 
     const bfrag* wq = reinterpret_cast<const bfrag*>(a.wp) + (size_t)cb * nchunks * 16 * 64 + lane;
     const int c_begin = SPLITK ? wave : 0, c_step = SPLITK ? 4 : 1;
+    // (the epilogue's bias values requested in front of the K loop, as in gemm32.hip: one exposed round trip less per launch)
+    float bias_r[NTB];
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) {
+        const int col = (cb * NTB + j) * 16 + (lane & 15);
+        bias_r[j] = (!SPLITK && a.bias && col < a.cout) ? a.bias[col] : 0.f;
+    }
     float4 cur[RT][4], nxt[RT][4];
     if (c_begin < nchunks) load_chunk(c_begin, cur);
     for (int c = c_begin; c < nchunks; c += c_step) {
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256) void rowgemm_direct_kernel(RowGemmArgs a)
         for (int j = 0; j < NTB; ++j) {
             const int col = (cb * NTB + j) * 16 + (lane & 15);
             if (col >= a.cout) continue;
-            const float bb = a.bias ? a.bias[col] : 0.f;
+            const float bb = bias_r[j];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
