@@ -71,10 +71,14 @@ __global__ __launch_bounds__(SK > 4 ? 64 * SK : 256) void gemm32_kernel(Gemm32Ar
         }
         const float4* wq = reinterpret_cast<const float4*>(a.wp) + (size_t)cb * nq * 64 + lane;
         const size_t wstride = (size_t)nq * 64;  // float4s between consecutive column blocks
-        // A ring of PD K-chunks in flight, refilled in place behind its reader (gemm32b.hip's scheme).  Round 6: the `#pragma unroll 8` loop
+        // A ring of PD K-chunks in flight, refilled in place behind its reader (gemm32b.hip's scheme; here PD = 2: a double buffer).  Round 6: the `#pragma unroll 8` loop
         // this replaces was NOT unrolled ("-Wpass-failed: loop not unrolled", silenced by the Makefile's -Wno-pass-failed): every 8-wide K chunk
         // was a load, a wait for it and four MFMAs -- one exposed L2 round trip per chunk, eight to sixteen of them per ~9 us launch.
-        constexpr int PD = 4;
+#ifdef PS_G32_PD
+        constexpr int PD = PS_G32_PD;
+#else
+        constexpr int PD = 2;  // (measured, serial cloud, same box: 2 / 3 chunks ahead 1.306-1.308 ms, 4: 1.325, 8: 1.315 -- the K slices are 4-16 chunks)
+#endif
         float4 axr[PD], bwr[PD][CW];
         auto fetch = [&](int slot, int q) __attribute__((always_inline)) {
             q = min(q, qb - 1);  // (past the end: a harmless repeat of the last chunk, never used)
