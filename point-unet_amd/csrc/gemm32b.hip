@@ -144,10 +144,12 @@ __global__ __launch_bounds__(SK > 4 ? 64 * SK : 256) void gemm32b_kernel(Gemm32b
         // 32-row block), and one chunk in flight left the launch latency-bound (23 us for 0.74 GFLOP); the ring is refilled in place
         // behind its last reader
 #ifdef PS_G32B_PD
-        constexpr int PD = RW * CW >= 4 ? 3 : PS_G32B_PD;  // (experiment: ring depth of the (1, 1) / (1, 2) tiles.  Round 6: 6 / 8 chunks ahead take 256
-                                                           //  VGPRs and run the enc2-4 dense stages 0.086 / 0.097 / 0.086 and 0.090 / 0.102 / 0.090 ms against 0.078 / 0.077 / 0.075)
+        constexpr int PD = RW * CW >= 4 ? 3 : PS_G32B_PD;  // (experiment: ring depth of the (1, 1) / (1, 2) tiles)
 #else
-        constexpr int PD = RW * CW >= 4 ? 3 : 4;
+        // Round 6, serial cloud on one box: 2 chunks ahead 1.280-1.286 ms, 3: 1.283-1.296, 4 (rounds 4-5): 1.295-1.306; 6 / 8 take 256 VGPRs
+        // and run the enc2-4 dense stages 0.086 / 0.097 / 0.086 and 0.090 / 0.102 / 0.090 ms against 0.078 / 0.077 / 0.075 -- the K slices
+        // of these launches are 8-24 chunks, and every chunk fetched past the end of a slice is a wasted request
+        constexpr int PD = RW * CW >= 4 ? 3 : 2;
 #endif
         float4 xl[PD][RW], xh[PD][RW];
         uint4 bw[PD][CW][3];
