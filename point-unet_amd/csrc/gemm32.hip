@@ -99,7 +99,7 @@ __global__ __launch_bounds__(SK > 4 ? 64 * SK : 256) void gemm32_kernel(Gemm32Ar
         for (int d = 0; d < PD; ++d) fetch(d, qa + d);
         int q0 = qa;
 #pragma unroll 1
-        for (; q0 + PD <= qb; q0 += PD) {
+        for (; q0 + 2 * PD <= qb; q0 += PD) {  // (groups whose refills all exist: nothing is requested past the end of the slice)
 #pragma unroll
             for (int d = 0; d < PD; ++d) {
                 products(d);
@@ -109,8 +109,15 @@ __global__ __launch_bounds__(SK > 4 ? 64 * SK : 256) void gemm32_kernel(Gemm32Ar
             }
         }
 #pragma unroll
-        for (int d = 0; d < PD - 1; ++d)  // the last qb - q0 < PD chunks are already in the ring's first slots
-            if (q0 + d < qb) products(d);
+        for (int d = 0; d < PD; ++d) {  // the ring holds the next PD chunks; fewer than 2 PD are left
+            if (q0 + d < qb) {
+                products(d);
+                if (q0 + d + PD < qb) fetch(d, q0 + d + PD);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < PD - 1; ++d)
+            if (q0 + PD + d < qb) products(d);
     }
     if constexpr (SK > 1) {
         // partial blocks of the K slices 1 .. SK-1 go through LDS (register-major: conflict-free), slice 0 adds them up

@@ -169,17 +169,22 @@ __global__ __launch_bounds__(SK > 4 ? 64 * SK : 256) void gemm32b_kernel(Gemm32b
 #pragma unroll
         for (int d = 0; d < PD; ++d) fetch(d, qa + d);
         int q0 = qa;
-        // full groups of PD chunks: straight-line code (a branch inside the group made the compiler drain every load at each join)
+        auto products = [&](int d) __attribute__((always_inline)) {
+            Planes A[RW], B[CW];
+#pragma unroll
+            for (int i = 0; i < RW; ++i) A[i] = split8(xl[d][i], xh[d][i]);
+#pragma unroll
+            for (int j = 0; j < CW; ++j) { B[j].p[0] = bw[d][j][0]; B[j].p[1] = bw[d][j][1]; B[j].p[2] = bw[d][j][2]; }
+            mfma6_all<RW, CW>(A, B, acc);
+        };
+        // full groups of PD chunks whose refills all exist: straight-line code (a branch inside the group made the compiler drain every
+        // load at each join).  Round 6: the loop stops one group early -- it used to refill past the end of the slice (a clamped repeat of
+        // the last chunk: 2-4 wasted chunk requests of the 8-24 a wave makes)
 #pragma unroll 1
-        for (; q0 + PD <= qb; q0 += PD) {
+        for (; q0 + 2 * PD <= qb; q0 += PD) {
 #pragma unroll
             for (int d = 0; d < PD; ++d) {
-                Planes A[RW], B[CW];
-#pragma unroll
-                for (int i = 0; i < RW; ++i) A[i] = split8(xl[d][i], xh[d][i]);
-#pragma unroll
-                for (int j = 0; j < CW; ++j) { B[j].p[0] = bw[d][j][0]; B[j].p[1] = bw[d][j][1]; B[j].p[2] = bw[d][j][2]; }
-                mfma6_all<RW, CW>(A, B, acc);
+                products(d);
                 // the refill goes into the registers the products just read (issued earlier it needs other registers and a drained copy at
                 // the loop's end), in program order: the wait in front of slot d + 1 leaves the PD - 1 younger refills in flight
                 __builtin_amdgcn_sched_barrier(0);
@@ -187,18 +192,18 @@ __global__ __launch_bounds__(SK > 4 ? 64 * SK : 256) void gemm32b_kernel(Gemm32b
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // the last qb - q0 < PD chunks are already in the ring's first slots
+        // the ring holds the next PD chunks; fewer than 2 PD are left.  Slices whose length is a multiple of PD (every layer of the network)
+        // need no further request; the others fetch their last few chunks behind the products that free the slot
 #pragma unroll
-        for (int d = 0; d < PD - 1; ++d) {
+        for (int d = 0; d < PD; ++d) {
             if (q0 + d < qb) {
-                Planes A[RW], B[CW];
-#pragma unroll
-                for (int i = 0; i < RW; ++i) A[i] = split8(xl[d][i], xh[d][i]);
-#pragma unroll
-                for (int j = 0; j < CW; ++j) { B[j].p[0] = bw[d][j][0]; B[j].p[1] = bw[d][j][1]; B[j].p[2] = bw[d][j][2]; }
-                mfma6_all<RW, CW>(A, B, acc);
+                products(d);
+                if (q0 + d + PD < qb) fetch(d, q0 + d + PD);
             }
         }
+#pragma unroll
+        for (int d = 0; d < PD - 1; ++d)
+            if (q0 + PD + d < qb) products(d);
     }
     if constexpr (SK > 1) {
         // partial blocks of the K slices 1 .. SK-1 go through LDS (register-major: conflict-free), slice 0 adds them up in slice order
