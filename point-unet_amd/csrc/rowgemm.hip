@@ -428,8 +428,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a)
         // ---- MFMA over the chunk ----
         const int steps = kc4 >> 2;
         const bfrag* wps = wp + (size_t)(k0 >> 2) * 64;
-#pragma unroll 4
-        for (int s = 0; s < steps; ++s) {
+        for (int s = 0; s < steps; ++s) {  // (run-time trip count: an unroll request here is refused by the compiler -- and warned about)
             const float av = tile[arow * kPitch + s * 4 + ag];
             const bfrag bv = wps[(size_t)s * 64];
 #pragma unroll

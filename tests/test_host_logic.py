@@ -340,3 +340,12 @@ def test_the_default_library_never_reads_the_environment():
     so = open(os.path.join(os.path.dirname(csrc), "libpointseg_hip.so"), "rb").read()
     for var in (b"PS_INV_BUCKET", b"PS_WGRAD_WGS", b"PS_INV_TILE", b"PS_TRAIN_ATT_GEMM", b"PS_GEMM32B_RW", b"PS_KNN_REFILL"):
         assert var not in so, var
+
+
+def test_unroll_failures_stay_visible_in_the_build():
+    """Round 6: `#pragma unroll 8` had been silently refused in gemm32.hip's K loop (one exposed round trip per 8-wide chunk, nine launches of
+    a cloud 20 % slower than they had to be) behind -Wno-pass-failed.  The flag is gone: a "loop not unrolled" warning is a performance bug
+    report -- and the recipe keeps -Wall, so it is printed by every build (the tree compiles without one)."""
+    mk = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "point-unet_amd", "csrc", "Makefile")).read()
+    flags = [ln for ln in mk.splitlines() if ln.startswith("FLAGS")][0]
+    assert "-Wno-pass-failed" not in flags and "-Wall" in flags
